@@ -1,0 +1,183 @@
+/*
+ * volcanosv.h — C-ABI of the MI355X-native SV-signature hot path.
+ *
+ * The reference (maiziezhoulab/VolcanoSV) has no FFI for this path: the boundary is a
+ * process + file contract (Raw_variant_call.py:65-73 spawns extract_contig_signature_<dtype>.py,
+ * Raw_variant_call.py:83-88 spawns extract_reads_signature.py). This header is what a binding for
+ * the *functions behind those scripts* would bind; each entry point cites the reference function it
+ * replaces. Paths are relative to bin/VolcanoSV-vc/ in the reference:
+ *   H  = Large_INDEL/extract_contig_signature_Hifi.py     O = ..._ONT.py     C = ..._CLR.py
+ *   RS = Large_INDEL/extract_reads_signature.py
+ *   SV = Complex_SV/svim-asm-1.0.2/src/svim_asm/
+ *
+ * Conventions: plain C, no C++ types or exceptions across the boundary; every call returns an int
+ * status (0 = ok, <0 = vsv_status); no global mutable state; one handle per device/stream; calls on
+ * one handle are not thread-safe, different handles are independent. Strings (qname, REF/ALT) never
+ * cross the boundary — records are referenced by index into the caller's SoA.
+ */
+#ifndef VOLCANOSV_H
+#define VOLCANOSV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VSV_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------------------------ */
+typedef enum vsv_status {
+  VSV_OK = 0,
+  VSV_E_INVALID = -1,      /* bad argument (null pointer, misaligned cigar, n < 0 ...)            */
+  VSV_E_HIP = -2,          /* HIP runtime error, text in vsv_last_error                            */
+  VSV_E_CAPACITY = -3,     /* signature capacity exceeded; required count in vsv_last_count         */
+  VSV_E_EMPTY_CIGAR = -4,  /* record with 0 CIGAR ops (reference: IndexError at H:63 cigar[0])      */
+  VSV_E_REFEND = -5,       /* reference `assert offset_ref==read.reference_end` (H:396, RS:123)     */
+  VSV_E_READLEN = -6,      /* reference `assert rl1==rl2` (H:331, RS:172)                           */
+  VSV_E_UNSORTED = -7,     /* reference `assert read1.pos<=read2.pos` (H:315) / cigar_off not mono. */
+  VSV_E_ZERODIV = -8,      /* CLR gate ZeroDivisionError (C:61, C:70)                               */
+  VSV_E_NO_DEVICE = -9     /* no HIP device / extension built without a GPU present                */
+} vsv_status;
+
+/* ---- data types (dtype of the extractor) -------------------------------------------------- */
+enum {
+  VSV_DTYPE_HIFI = 0,  /* H  */
+  VSV_DTYPE_ONT = 1,   /* O  */
+  VSV_DTYPE_CLR = 2,   /* C  */
+  VSV_DTYPE_READS = 3, /* RS: M-like ops {0,7,8}, N advances ref, no fold / cluster / pair          */
+  VSV_DTYPE_SVIM = 4   /* SV/SVIM_intra.py:8-30 op table (CIGAR stage only)                         */
+};
+
+/* ---- record flag bits (u8 per record) ------------------------------------------------------ */
+enum {
+  VSV_F_REVERSE = 1,   /* read.is_reverse                                                        */
+  VSV_F_SUPP = 2,      /* supplementary (only used by the svim table)                             */
+  VSV_F_HP1 = 4,       /* 'hp1' in qname (H:392)                                                  */
+  VSV_F_HP2 = 8,       /* 'hp2' in qname                                                          */
+  VSV_F_SECONDARY = 16,
+  VSV_F_UNMAPPED = 32
+};
+
+/* ---- caller-owned SoA of alignment records (BAM order: tid, pos ascending) ------------------ */
+typedef struct vsv_records {
+  int64_t n_records;
+  int64_t n_ops;               /* == cigar_off[n_records]                                         */
+  const int32_t* pos;          /* [n]   0-based leftmost reference position (read.pos)             */
+  const int32_t* tid;          /* [n]   reference id                                               */
+  const uint32_t* qid;         /* [n]   dense query-name id (same qname <=> same qid)              */
+  const uint64_t* cigar_off;   /* [n+1] exclusive prefix of per-record op counts                   */
+  const uint8_t* mapq;         /* [n]                                                              */
+  const uint8_t* flag;         /* [n]   VSV_F_* bits                                               */
+  const uint32_t* cigar;       /* [n_ops] BAM packing: len<<4 | op ; 16-byte aligned               */
+  int32_t on_device;           /* 0: host pointers (library uploads), 1: device pointers           */
+  int32_t n_qids;              /* number of distinct qids (max qid + 1)                            */
+} vsv_records;
+
+/* ---- parameters; defaults equal the hard-coded reference values ----------------------------- */
+typedef struct vsv_params {
+  int32_t dtype;            /* VSV_DTYPE_*                                                       */
+  int32_t min_svlen;        /* 30  (H:395 extract_sig_from_cigar(read,min_svlen=30))              */
+  int32_t min_cigar_mapq;   /* 50  (H:24)                                                         */
+  int32_t min_split_mapq;   /* 50  (H:41 assigns min_cigar_mapq); RS: 0 (RS:235)                  */
+  int32_t max_split_svlen;  /* 50000 (H:455)                                                      */
+  int32_t cluster_shift;    /* 100 (H:407-415)                                                    */
+  int32_t pair_shift;       /* 200 (H:562,564)                                                    */
+  int32_t pair_window;      /* 1000 (H:768 max_compare_dist)                                      */
+  int32_t enable_split;     /* 1: run the split-alignment stage                                   */
+  int32_t reserved[7];
+} vsv_params;
+
+/* ---- signature row (32 bytes) ---------------------------------------------------------------
+ * Mirrors the reference 10-field list (H:80,84): chrom->tid, type/source/hap in meta, pos, svlen,
+ * qname/strand/mapq via rec (and rec2 for split signatures, whose mapq is "m1-m2", H:358).      */
+typedef struct vsv_sig {
+  int32_t pos;      /* sig[2]                                                                     */
+  int32_t svlen;    /* sig[3]                                                                     */
+  int32_t q_start;  /* sig[5]                                                                     */
+  int32_t q_end;    /* sig[6]  (READS cigar signatures have no q_end: 0)                          */
+  uint32_t rec;     /* record index of read / read1                                               */
+  uint32_t rec2;    /* record index of read2 for split signatures, 0xFFFFFFFF otherwise           */
+  uint32_t meta;    /* VSV_M_* bits                                                               */
+  int32_t tid;      /* sig[0]                                                                     */
+} vsv_sig;
+
+enum {
+  VSV_M_DEL = 1,    /* bit0: 0 = INS, 1 = DEL                                                     */
+  VSV_M_SPLIT = 2,  /* bit1: 0 = 'cigar', 1 = 'split-alignment'                                   */
+  VSV_M_HP2 = 4,    /* bit2: 0 = hp1 pass, 1 = hp2 pass (always 0 for READS/SVIM)                 */
+  VSV_M_DEAD = 8    /* internal: folded away by the intra-read merge                              */
+};
+
+/* ---- call row (48 bytes): pair_sig output (H:571-592) ---------------------------------------- */
+typedef struct vsv_call {
+  vsv_sig sig;      /* the kept signature (sig1 if l1>l2 else sig2, H:583-586)                    */
+  int32_t a;        /* index into VSV_T_MERGED of the hp1 member, -1 if none                      */
+  int32_t b;        /* index into VSV_T_MERGED of the hp2 member, -1 if none                      */
+  int32_t gt;       /* 1 = '0/1', 2 = '1/1'                                                       */
+  int32_t pad;
+} vsv_call;
+
+/* ---- stage tables a caller can read back ----------------------------------------------------- */
+enum {
+  VSV_T_RAW = 0,      /* vsv_sig: CIGAR emit stream, (rec, op) order, before the intra-read fold  */
+  VSV_T_CIGAR = 1,    /* vsv_sig: after the fold (H:108-161), same order, dead rows removed       */
+  VSV_T_SPLIT = 2,    /* vsv_sig: split signatures in (hap, name first-appearance, pair) order    */
+  VSV_T_CLUSTER1 = 3, /* vsv_sig: representatives of the per-source clustering (H:407-415,465-473) */
+  VSV_T_MERGED = 4,   /* vsv_sig: merge_all output per (tid, hap), sorted by pos (H:492-499)      */
+  VSV_T_CALLS = 5,    /* vsv_call: pair_sig output, sorted by (tid,pos) (H:548-603)               */
+  VSV_T_READS = 6     /* vsv_sig: RS merge_all order: sort(del_cigar+ins_cigar+del_split+ins_split) */
+};
+
+typedef struct vsv_handle vsv_handle;
+
+int vsv_abi_version(void);
+const char* vsv_status_string(int status);
+
+/* create/destroy a per-device context. `hip_stream` is a hipStream_t (NULL = default stream).      */
+int vsv_create(int device_id, void* hip_stream, vsv_handle** out);
+void vsv_destroy(vsv_handle* h);
+const char* vsv_last_error(vsv_handle* h);
+int64_t vsv_last_count(vsv_handle* h);
+
+/* params with the reference's hard-coded values for `dtype` */
+int vsv_default_params(int dtype, vsv_params* p);
+
+/* capacity (rows) of the signature tables; default 1<<22. Re-allocates the workspace. */
+int vsv_reserve(vsv_handle* h, int64_t max_records, int64_t max_ops, int64_t max_sigs);
+
+/* Stage entry points. Each consumes the handle state left by the previous one.
+ * vsv_cigar_scan      replaces extract_sig_from_cigar + the loop of extract_signature_from_cigar
+ *                     (H:53-166, 386-400; RS:47-83, 107-125; SV/SVIM_intra.py:8-30)
+ * vsv_split_pairs     replaces extract_sig_from_split_reads + extract_sig_from_split
+ *                     (H:307-371, 421-457; O:307-382; C:328-402; RS:147-248)
+ * vsv_sort_cluster    replaces sort_sig + cluster_del/cluster_ins on the per-source lists
+ *                     (H:170-179, 196-288, 402-415, 459-473)
+ * vsv_merge_sources   replaces merge_all (H:478-499)
+ * vsv_pair_haplotypes replaces pair_sig (H:515-603)
+ * vsv_run_chromosome  = all of the above for every tid present, no host synchronisation between
+ *                     stages (replaces the per-chromosome body of H:742-772 minus VCF text).     */
+int vsv_cigar_scan(vsv_handle* h, const vsv_records* recs, const vsv_params* p);
+int vsv_split_pairs(vsv_handle* h, const vsv_records* recs, const vsv_params* p);
+int vsv_sort_cluster(vsv_handle* h, const vsv_params* p);
+int vsv_merge_sources(vsv_handle* h, const vsv_params* p);
+int vsv_pair_haplotypes(vsv_handle* h, const vsv_params* p);
+int vsv_run_chromosome(vsv_handle* h, const vsv_records* recs, const vsv_params* p);
+
+/* Asynchronous variant for benchmarking: enqueues the whole path on the handle's stream and does
+ * not synchronise; errors and counts are picked up by vsv_finish().                              */
+int vsv_run_chromosome_async(vsv_handle* h, const vsv_records* recs, const vsv_params* p);
+int vsv_finish(vsv_handle* h);
+
+/* two-phase readback: count, then fill a caller buffer (host or device) */
+int vsv_table_count(vsv_handle* h, int table, int64_t* n_rows);
+int vsv_table_fill(vsv_handle* h, int table, void* dst, int64_t cap_rows, int dst_on_device);
+
+/* timing of the dominant kernel (cigar_scan_emit) of the last vsv_finish()/sync call, measured
+ * with HIP events on the handle's stream. Returns milliseconds in *ms.                            */
+int vsv_last_scan_ms(vsv_handle* h, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VOLCANOSV_H */

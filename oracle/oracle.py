@@ -1,0 +1,70 @@
+"""ctypes binding of the CPU oracle (oracle/vsv_oracle.c). TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+product package volcanosv_amd never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from volcanosv_amd.types import CALL_DTYPE, SIG_DTYPE, Params, Records
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class _Out(C.Structure):
+    _fields_ = [(n, t) for pair in (
+        ("raw", "n_raw"), ("cigar", "n_cigar"), ("split", "n_split"), ("cluster1", "n_cluster1"),
+        ("merged", "n_merged"), ("calls", "n_calls"), ("reads", "n_reads"))
+        for n, t in ((pair[0], C.c_void_p), (pair[1], C.c_int64))] + [("status", C.c_int32)]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libvsv_oracle.so")
+    src = os.path.join(_HERE, "vsv_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.orc_run.argtypes = [C.POINTER(Records), C.POINTER(Params), C.c_int, C.POINTER(_Out)]
+        _LIB.orc_run.restype = C.c_int
+        _LIB.orc_free.argtypes = [C.POINTER(_Out)]
+        _LIB.orc_default_params.argtypes = [C.c_int, C.POINTER(Params)]
+    return _LIB
+
+
+def default_params(dtype):
+    p = Params()
+    lib().orc_default_params(int(dtype), C.byref(p))
+    return p
+
+
+def _copy(ptr, n, dtype):
+    if n == 0:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_char * (n * dtype.itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=n).copy()
+
+
+def run(soa, params=None, dtype=None, literal=False):
+    """Runs the whole path on the host. Returns (status, dict of stage tables)."""
+    p = params if params is not None else default_params(dtype)
+    r = soa.as_struct()
+    out = _Out()
+    st = lib().orc_run(C.byref(r), C.byref(p), 1 if literal else 0, C.byref(out))
+    tabs = {
+        "raw": _copy(out.raw, out.n_raw, SIG_DTYPE), "cigar": _copy(out.cigar, out.n_cigar, SIG_DTYPE),
+        "split": _copy(out.split, out.n_split, SIG_DTYPE), "cluster1": _copy(out.cluster1, out.n_cluster1, SIG_DTYPE),
+        "merged": _copy(out.merged, out.n_merged, SIG_DTYPE), "calls": _copy(out.calls, out.n_calls, CALL_DTYPE),
+        "reads": _copy(out.reads, out.n_reads, SIG_DTYPE),
+    }
+    lib().orc_free(C.byref(out))
+    return st, tabs

@@ -1,0 +1,573 @@
+/*
+ * vsv_oracle.c — CPU restatement (plain C) of VolcanoSV's SV-signature hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY. Nothing in the product path (volcanosv_amd/) may import, link or call
+ * this file; it is the checker for tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+ *
+ * Parity pinning: every function below is checked against the JSON files in tests/golden/, which were generated
+ * by tests/golden/make_golden.py from the reference's own functions (AST-extracted FunctionDefs of
+ * the files cited below, run in the build container), plus the reference's own known-answer vectors
+ * (svim-asm tests/test_intra.py:8-22, tests/test_inter.py:8-11).
+ *
+ * Citations are relative to /root/reference/bin/VolcanoSV-vc/ :
+ *   H  = Large_INDEL/extract_contig_signature_Hifi.py   O = ..._ONT.py   C = ..._CLR.py
+ *   RS = Large_INDEL/extract_reads_signature.py         SV = Complex_SV/svim-asm-1.0.2/src/svim_asm/
+ *
+ * Canonical tie rule (SURVEY.md §7 hard part 1): sort_sig (H:170-179) is restated as a STABLE sort
+ * by pos; ties keep list order. The reference uses numpy's default (unstable) argsort, so tie-rich
+ * goldens were generated with argsort(kind='stable') injected; tie-free goldens with the unmodified
+ * function.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+
+#include "../include/volcanosv.h"
+
+typedef struct {
+  vsv_sig* v;
+  int64_t n, cap;
+} sigvec;
+
+static void sv_push(sigvec* s, const vsv_sig* x) {
+  if (s->n == s->cap) {
+    s->cap = s->cap ? s->cap * 2 : 1024;
+    s->v = (vsv_sig*)realloc(s->v, (size_t)s->cap * sizeof(vsv_sig));
+  }
+  s->v[s->n++] = *x;
+}
+
+typedef struct orc_out {
+  vsv_sig* raw;      int64_t n_raw;
+  vsv_sig* cigar;    int64_t n_cigar;
+  vsv_sig* split;    int64_t n_split;
+  vsv_sig* cluster1; int64_t n_cluster1;
+  vsv_sig* merged;   int64_t n_merged;
+  vsv_call* calls;   int64_t n_calls;
+  vsv_sig* reads;    int64_t n_reads;
+  int32_t status;
+} orc_out;
+
+/* ------------------------------------------------------------------------------------------------
+ * op tables. contig (H:72-85): M(0) advances both, S(4) advances contig, D(2)/I(1) emit+advance,
+ * everything else ignored. reads (RS:66-81): {0,7,8} both, N(3) advances ref. svim
+ * (SV/SVIM_intra.py:13-29): {0,7,8} both, no hard-clip offset, H ignored.
+ * ------------------------------------------------------------------------------------------------ */
+static inline int ref_adv(int dtype, int op) {
+  if (dtype == VSV_DTYPE_READS) return op == 0 || op == 7 || op == 8 || op == 2 || op == 3;
+  if (dtype == VSV_DTYPE_SVIM) return op == 0 || op == 7 || op == 8 || op == 2;
+  return op == 0 || op == 2;
+}
+static inline int qry_adv(int dtype, int op) {
+  if (dtype == VSV_DTYPE_READS || dtype == VSV_DTYPE_SVIM) return op == 0 || op == 7 || op == 8 || op == 1 || op == 4;
+  return op == 0 || op == 1 || op == 4;
+}
+
+/* pysam reference_end = pos + sum of M,D,N,=,X */
+static int64_t ref_end_pysam(const vsv_records* r, int64_t i) {
+  int64_t e = r->pos[i];
+  for (uint64_t k = r->cigar_off[i]; k < r->cigar_off[i + 1]; ++k) {
+    int op = r->cigar[k] & 15; int64_t len = r->cigar[k] >> 4;
+    if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) e += len;
+  }
+  return e;
+}
+
+/* get_readlen: H:308-313 {0,1,4,5}; RS:148-153 {0,7,8,1,4,5} */
+static int64_t read_len(const vsv_records* r, int64_t i, int dtype) {
+  int64_t rl = 0;
+  for (uint64_t k = r->cigar_off[i]; k < r->cigar_off[i + 1]; ++k) {
+    int op = r->cigar[k] & 15; int64_t len = r->cigar[k] >> 4;
+    if (op == 0 || op == 1 || op == 4 || op == 5) rl += len;
+    else if (dtype == VSV_DTYPE_READS && (op == 7 || op == 8)) rl += len;
+  }
+  return rl;
+}
+
+/* CLR gate C:53-70, 425-427: ins_pct <= 0.13 or var_dist >= 200, in exact integer form
+ * (100*ins <= 13*(M+ins); sumM >= 200*nM). Returns 1 pass, 0 fail, <0 error. */
+static int clr_gate(const vsv_records* r, int64_t i) {
+  int64_t ins = 0, m = 0, nm = 0;
+  for (uint64_t k = r->cigar_off[i]; k < r->cigar_off[i + 1]; ++k) {
+    int op = r->cigar[k] & 15; int64_t len = r->cigar[k] >> 4;
+    if (op == 0) { m += len; nm++; } else if (op == 1) ins += len;
+  }
+  if (m + ins == 0 || nm == 0) return VSV_E_ZERODIV;
+  return (100 * ins <= 13 * (m + ins)) || (m >= 200 * nm);
+}
+
+/* extract_sig_from_cigar (H:53-85 / RS:47-83 / SV/SVIM_intra.py:8-30) for one record and one hap
+ * pass; appends the raw (pre-fold) signatures in CIGAR order. */
+static int walk_record(const vsv_records* r, int64_t i, const vsv_params* p, uint32_t hapbit, sigvec* out) {
+  uint64_t a = r->cigar_off[i], b = r->cigar_off[i + 1];
+  if (b <= a) return VSV_E_EMPTY_CIGAR;
+  int dtype = p->dtype;
+  int64_t off_ref = r->pos[i], off_q = 0, hc = 0;
+  if (dtype != VSV_DTYPE_SVIM && (r->cigar[a] & 15) == 5) hc = r->cigar[a] >> 4; /* H:63-65 */
+  for (uint64_t k = a; k < b; ++k) {
+    int op = r->cigar[k] & 15; int64_t len = r->cigar[k] >> 4;
+    if (op == 2 || op == 1) {
+      if (len >= p->min_svlen) {
+        vsv_sig s; memset(&s, 0, sizeof s);
+        s.pos = (int32_t)off_ref; s.svlen = (int32_t)len; s.q_start = (int32_t)(off_q + hc);
+        s.rec = (uint32_t)i; s.rec2 = 0xFFFFFFFFu; s.tid = r->tid[i];
+        s.meta = hapbit | (op == 2 ? VSV_M_DEL : 0);
+        if (dtype == VSV_DTYPE_READS) s.q_end = 0;            /* RS:72,76: 8-field sig, no q_end */
+        else s.q_end = s.q_start + (op == 2 ? 1 : (int32_t)len); /* H:80, H:84 */
+        sv_push(out, &s);
+      }
+    }
+    if (ref_adv(dtype, op)) off_ref += len;
+    if (qry_adv(dtype, op)) off_q += len;
+  }
+  /* assert offset_ref==read.reference_end (H:396, RS:123) */
+  if (dtype != VSV_DTYPE_SVIM && off_ref != ref_end_pysam(r, i)) return VSV_E_REFEND;
+  return 0;
+}
+
+/* cluster_ins_one_read / cluster_del_one_read (H:91-161): left fold over one record's signatures
+ * of one type, in place on raw[lo,hi) (all same rec & hap). Dead rows get VSV_M_DEAD. */
+static void fold_record(vsv_sig* s, int64_t lo, int64_t hi) {
+  int64_t last_ins = -1, last_del = -1;
+  for (int64_t k = lo; k < hi; ++k) {
+    if (s[k].meta & VSV_M_DEL) {
+      if (last_del < 0) { last_del = k; continue; }
+      vsv_sig* s1 = &s[last_del]; vsv_sig* s2 = &s[k];
+      int64_t d = (int64_t)s2->pos - s1->pos; if (d < 0) d = -d;
+      if (s1->svlen > 150 && s2->svlen > 150 && d < 150) {     /* H:148-150 */
+        s1->svlen = s2->pos + s2->svlen - s1->pos;              /* H:104 */
+        s1->q_end = s1->q_start + 1;                            /* H:101-102 */
+        s2->meta |= VSV_M_DEAD;
+      } else last_del = k;
+    } else {
+      if (last_ins < 0) { last_ins = k; continue; }
+      vsv_sig* s1 = &s[last_ins]; vsv_sig* s2 = &s[k];
+      int64_t d = (int64_t)s2->pos - s1->pos; if (d < 0) d = -d;
+      int m = (s1->svlen > 250 && s2->svlen > 250 && d < 250) ||  /* H:115-117 */
+              (s1->svlen > 320 && s2->svlen > 320 && d < 380) ||  /* H:120-122 */
+              (s1->svlen > 100 && s2->svlen > 100 && d < 250);    /* H:126-128 */
+      if (m) {
+        s1->q_end = s2->q_end;                                   /* H:94 read_end = sig2[6] */
+        s1->svlen = s1->q_end - s1->q_start;                     /* H:96 */
+        s2->meta |= VSV_M_DEAD;
+      } else last_ins = k;
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * split-alignment pair rule (H:307-371, O:307-382, C:328-402, RS:147-197)
+ * ------------------------------------------------------------------------------------------------ */
+static int split_pair(const vsv_records* r, int64_t i1, int64_t i2, const vsv_params* p, uint32_t hapbit,
+                      int min_mapq, sigvec* out) {
+  int dtype = p->dtype;
+  if (r->pos[i1] > r->pos[i2]) return VSV_E_UNSORTED;            /* H:315 */
+  int rev1 = r->flag[i1] & VSV_F_REVERSE, rev2 = r->flag[i2] & VSV_F_REVERSE;
+  uint32_t last1 = r->cigar[r->cigar_off[i1 + 1] - 1], first2 = r->cigar[r->cigar_off[i2]];
+  int lop = last1 & 15, fop = first2 & 15;
+  if (!((rev1 == rev2) && r->mapq[i1] >= min_mapq && r->mapq[i2] >= min_mapq &&
+        (lop == 4 || lop == 5) && (fop == 4 || fop == 5)))
+    return 0;                                                    /* H:323-324 */
+  int64_t rl1 = read_len(r, i1, dtype), rl2 = read_len(r, i2, dtype);
+  if (rl1 != rl2) return VSV_E_READLEN;                          /* H:331 */
+  int64_t Ref1e = ref_end_pysam(r, i1), Ref2s = r->pos[i2];
+  int64_t Read1e = rl1 - (last1 >> 4), Read2s = first2 >> 4;
+  int64_t Diffdis = (Ref2s - Ref1e) - (Read2s - Read1e);
+  int64_t absd = Diffdis < 0 ? -Diffdis : Diffdis;
+  if (absd > p->max_split_svlen) return 0;                       /* H:354 */
+  vsv_sig s; memset(&s, 0, sizeof s);
+  s.rec = (uint32_t)i1; s.rec2 = (uint32_t)i2; s.tid = r->tid[i1];
+  s.meta = hapbit | VSV_M_SPLIT;
+  if (dtype == VSV_DTYPE_HIFI) {
+    if (Diffdis >= 30) {
+      int64_t Diffolp = Read1e - Read2s, ao = Diffolp < 0 ? -Diffolp : Diffolp;
+      if (ao <= 3000) {                                          /* H:357 */
+        int64_t h = Diffolp / 2;                                 /* int(Diffolp/2): trunc toward 0 */
+        s.pos = (int32_t)(Ref1e - h); s.svlen = (int32_t)Diffdis;
+        s.q_start = (int32_t)(Read1e - h); s.q_end = s.q_start + 1; s.meta |= VSV_M_DEL;
+        sv_push(out, &s);
+      }
+    } else if (Diffdis <= -30) {
+      int64_t Diffolp = Ref1e - Ref2s, ao = Diffolp < 0 ? -Diffolp : Diffolp;
+      if (Diffolp < 3000) {                                      /* H:362 */
+        int64_t sv = Read2s - Read1e + Diffolp; if (sv < 0) sv = -sv;
+        s.pos = (int32_t)(ao > 400 ? (Ref1e + Ref2s) / 2 : Ref2s);
+        s.svlen = (int32_t)sv; s.q_start = (int32_t)(Read1e - Diffolp); s.q_end = (int32_t)Read2s;
+        sv_push(out, &s);
+      }
+    }
+  } else if (dtype == VSV_DTYPE_ONT || dtype == VSV_DTYPE_CLR) {
+    double r_ = dtype == VSV_DTYPE_ONT ? 0.5 : 0.3;              /* O:348, C:369 */
+    double lo_f = dtype == VSV_DTYPE_ONT ? 0.8 : 0.3;            /* O:373 Diffdis*0.8 ; C:377 Diffdis*r */
+    if (Diffdis >= 30) {
+      int64_t Diffolp = Read1e - Read2s;
+      double dr = (double)Diffdis * r_;
+      if (-dr <= (double)Diffolp && (double)Diffolp <= dr) {     /* O:354 */
+        s.pos = (int32_t)Ref1e; s.svlen = (int32_t)Diffdis;
+        s.q_start = (int32_t)Read1e; s.q_end = (int32_t)Read2s; s.meta |= VSV_M_DEL;
+        sv_push(out, &s);
+      }
+    } else {
+      int64_t Diffolp = Ref1e - Ref2s, ao = Diffolp < 0 ? -Diffolp : Diffolp;
+      double lo = (double)Diffdis * lo_f, hi = (double)absd * r_;
+      if (lo <= (double)Diffolp && (double)Diffolp <= hi && Diffdis <= -30) { /* O:373 */
+        int64_t sv = Read2s - Read1e + Diffolp; if (sv < 0) sv = -sv;
+        s.pos = (int32_t)(ao > 400 ? (Ref1e + Ref2s) / 2 : Ref2s);
+        s.svlen = (int32_t)sv; s.q_start = (int32_t)(Read1e - Diffolp); s.q_end = (int32_t)Read2s;
+        sv_push(out, &s);
+      }
+    }
+  } else { /* READS RS:179-196 */
+    int64_t Diffolp = Ref1e - Ref2s;
+    if (Diffolp < 30 && Diffdis >= 30) {
+      s.pos = (int32_t)Ref1e; s.svlen = (int32_t)Diffdis; s.q_start = (int32_t)Read1e; s.q_end = (int32_t)Read2s;
+      s.meta |= VSV_M_DEL; sv_push(out, &s);
+    } else if (Diffolp < 30 && Diffdis <= -30) {
+      s.pos = (int32_t)((Ref1e + Ref2s) / 2); s.svlen = (int32_t)absd;
+      s.q_start = (int32_t)Read1e; s.q_end = (int32_t)Read2s; sv_push(out, &s);
+    }
+  }
+  return 0;
+}
+
+/* extract_sig_from_split_reads (H:421-457, RS:199-237) for one (tid range, hap pass).
+ * Names counted among eligible records; groups with count>1 in first-appearance order; consecutive
+ * pairs in BAM order. */
+static int split_pass(const vsv_records* r, int64_t lo, int64_t hi, const vsv_params* p, uint32_t hapbit,
+                      uint32_t hapflag, int min_mapq, sigvec* out) {
+  int nq = r->n_qids;
+  int32_t* cnt = (int32_t*)calloc((size_t)nq + 1, sizeof(int32_t));
+  int64_t* head = (int64_t*)malloc(((size_t)nq + 1) * sizeof(int64_t));
+  int64_t* tail = (int64_t*)malloc(((size_t)nq + 1) * sizeof(int64_t));
+  int64_t* next = (int64_t*)malloc((size_t)(hi - lo + 1) * sizeof(int64_t));
+  int64_t* order = (int64_t*)malloc(((size_t)nq + 1) * sizeof(int64_t));
+  int64_t n_order = 0;
+  int st = 0;
+  for (int64_t i = lo; i < hi; ++i) {
+    int elig = (hapflag == 0) ? 1 : ((r->flag[i] & hapflag) && r->mapq[i] >= min_mapq);
+    if (!elig) continue;
+    uint32_t q = r->qid[i];
+    if (cnt[q] == 0) { head[q] = i; order[n_order++] = q; } else next[tail[q] - lo] = i;
+    tail[q] = i; next[i - lo] = -1; cnt[q]++;
+  }
+  for (int64_t g = 0; g < n_order && st == 0; ++g) {
+    uint32_t q = (uint32_t)order[g];
+    if (cnt[q] < 2) continue;
+    for (int64_t i = head[q]; next[i - lo] >= 0 && st == 0; i = next[i - lo])
+      st = split_pair(r, i, next[i - lo], p, hapbit, min_mapq, out);
+  }
+  free(cnt); free(head); free(tail); free(next); free(order);
+  return st;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * stable sort of sig rows by a 64-bit key (sort_sig H:170-179 with the canonical stable tie rule)
+ * ------------------------------------------------------------------------------------------------ */
+typedef uint64_t (*keyfn)(const vsv_sig*);
+static uint64_t upos(int32_t pos) { return (uint32_t)(pos ^ 0x80000000); }
+/* list = (tid, hap, type, src): per-source lists of H:402-415 / H:459-473 */
+static uint64_t key_stage1(const vsv_sig* s) {
+  uint64_t hap = (s->meta & VSV_M_HP2) ? 1 : 0, del = (s->meta & VSV_M_DEL) ? 1 : 0, sp = (s->meta & VSV_M_SPLIT) ? 1 : 0;
+  return ((uint64_t)(uint32_t)s->tid << 35) | (hap << 34) | (del << 33) | (sp << 32) | upos(s->pos);
+}
+/* list = (tid, hap, type): merge_sig_ins / merge_sig_del H:478-490 */
+static uint64_t key_stage2(const vsv_sig* s) {
+  uint64_t hap = (s->meta & VSV_M_HP2) ? 1 : 0, del = (s->meta & VSV_M_DEL) ? 1 : 0;
+  return ((uint64_t)(uint32_t)s->tid << 35) | (hap << 34) | (del << 33) | upos(s->pos);
+}
+/* list = (tid, hap): final sort of merge_all H:495 */
+static uint64_t key_stage3(const vsv_sig* s) {
+  uint64_t hap = (s->meta & VSV_M_HP2) ? 1 : 0;
+  return ((uint64_t)(uint32_t)s->tid << 35) | (hap << 34) | upos(s->pos);
+}
+static uint64_t key_tidpos(const vsv_sig* s) { return ((uint64_t)(uint32_t)s->tid << 35) | upos(s->pos); }
+
+static void stable_sort_idx(const uint64_t* key, int64_t* idx, int64_t n) {
+  int64_t* tmp = (int64_t*)malloc((size_t)(n > 0 ? n : 1) * sizeof(int64_t));
+  for (int64_t w = 1; w < n; w *= 2) {
+    for (int64_t lo = 0; lo < n; lo += 2 * w) {
+      int64_t mid = lo + w < n ? lo + w : n, hi = lo + 2 * w < n ? lo + 2 * w : n;
+      int64_t a = lo, b = mid, k = lo;
+      while (a < mid && b < hi) tmp[k++] = (key[idx[b]] < key[idx[a]]) ? idx[b++] : idx[a++];
+      while (a < mid) tmp[k++] = idx[a++];
+      while (b < hi) tmp[k++] = idx[b++];
+    }
+    memcpy(idx, tmp, (size_t)n * sizeof(int64_t));
+  }
+  free(tmp);
+}
+
+static void sort_sigs(vsv_sig* s, int64_t n, keyfn kf) {
+  if (n <= 1) return;
+  uint64_t* key = (uint64_t*)malloc((size_t)n * sizeof(uint64_t));
+  int64_t* idx = (int64_t*)malloc((size_t)n * sizeof(int64_t));
+  vsv_sig* t = (vsv_sig*)malloc((size_t)n * sizeof(vsv_sig));
+  for (int64_t i = 0; i < n; ++i) { key[i] = kf(&s[i]); idx[i] = i; }
+  stable_sort_idx(key, idx, n);
+  for (int64_t i = 0; i < n; ++i) t[i] = s[idx[i]];
+  memcpy(s, t, (size_t)n * sizeof(vsv_sig));
+  free(key); free(idx); free(t);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * cluster_del / cluster_ins (H:196-288) on one sorted list s[lo,hi). Predicates in exact integer
+ * form (SURVEY §7 hard part 3). literal=1 keeps the reference's full inner scan; literal=0 starts at
+ * i+1 and stops once pos_j - pos_i > max_shift (identical result on a list sorted by pos).
+ * ------------------------------------------------------------------------------------------------ */
+static inline int match_sig(const vsv_sig* a, const vsv_sig* b, int max_shift) {
+  int64_t shift = (int64_t)a->pos - b->pos; if (shift < 0) shift = -shift;
+  if (shift > max_shift) return 0;
+  int64_t l1 = a->svlen, l2 = b->svlen, mn = l1 < l2 ? l1 : l2, mx = l1 < l2 ? l2 : l1;
+  if (2 * mn < mx) return 0;                                   /* size_similarity >= 0.5 */
+  if (a->meta & VSV_M_DEL) {
+    int64_t s1 = a->pos, e1 = s1 + l1, s2 = b->pos, e2 = s2 + l2;
+    int64_t ov = (e1 < e2 ? e1 : e2) - (s1 > s2 ? s1 : s2);
+    if (2 * ov < mn) return 0;                                 /* overlap_ratio >= 0.5 (H:200-204) */
+  }
+  return 1;
+}
+
+static void cluster_list(const vsv_sig* s, int64_t lo, int64_t hi, int max_shift, int literal, sigvec* out) {
+  int64_t n = hi - lo;
+  if (n <= 0) return;
+  int64_t* cl = (int64_t*)malloc((size_t)n * sizeof(int64_t));
+  for (int64_t i = 0; i < n; ++i) cl[i] = -1;
+  for (int64_t i = 0; i < n; ++i) {
+    if (cl[i] != -1) continue;
+    cl[i] = i;                                                  /* H:209-210 */
+    const vsv_sig* s1 = &s[lo + i];
+    int64_t best = i;
+    for (int64_t j = literal ? 0 : i + 1; j < n; ++j) {
+      if (!literal && (int64_t)s[lo + j].pos - s1->pos > max_shift) break;
+      if (cl[j] != -1) continue;
+      if (match_sig(s1, &s[lo + j], max_shift)) {
+        cl[j] = i;
+        if (s[lo + j].svlen > s[lo + best].svlen) best = j;     /* H:239-246: first longest, index order */
+      }
+    }
+    if (literal) { /* representative scan in index order over members, as H:236-247 */
+      best = -1;
+      for (int64_t j = 0; j < n; ++j) if (cl[j] == i && (best < 0 || s[lo + j].svlen > s[lo + best].svlen)) best = j;
+    }
+    sv_push(out, &s[lo + best]);
+  }
+  free(cl);
+}
+
+static void cluster_all(const vsv_sig* s, int64_t n, keyfn listkey, int max_shift, int literal, sigvec* out) {
+  int64_t lo = 0;
+  while (lo < n) {
+    int64_t hi = lo + 1;
+    uint64_t k = listkey(&s[lo]) >> 32;
+    while (hi < n && (listkey(&s[hi]) >> 32) == k) hi++;
+    cluster_list(s, lo, hi, max_shift, literal, out);
+    lo = hi;
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * pair_sig (H:548-603) for one tid: hp1 list a[0,na), hp2 list b[0,nb), both sorted by pos.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct { vsv_call* v; int64_t n, cap; } callvec;
+static void cv_push(callvec* c, const vsv_call* x) {
+  if (c->n == c->cap) { c->cap = c->cap ? c->cap * 2 : 1024; c->v = (vsv_call*)realloc(c->v, (size_t)c->cap * sizeof(vsv_call)); }
+  c->v[c->n++] = *x;
+}
+
+static void pair_tid(const vsv_sig* m, int64_t a0, int64_t na, int64_t b0, int64_t nb, const vsv_params* p,
+                     int literal, callvec* out) {
+  int64_t* st1 = (int64_t*)malloc((size_t)(na + 1) * sizeof(int64_t));
+  int64_t* st2 = (int64_t*)malloc((size_t)(nb + 1) * sizeof(int64_t));
+  for (int64_t i = 0; i < na; ++i) st1[i] = -1;
+  for (int64_t j = 0; j < nb; ++j) st2[j] = -1;
+  int64_t jlo = 0;
+  for (int64_t i = 0; i < na; ++i) {
+    const vsv_sig* s1 = &m[a0 + i];
+    if (!literal) while (jlo < nb && (int64_t)s1->pos - m[b0 + jlo].pos > p->pair_shift) jlo++;
+    for (int64_t j = literal ? 0 : jlo; j < nb; ++j) {
+      const vsv_sig* s2 = &m[b0 + j];
+      int64_t dist = (int64_t)s2->pos - s1->pos;
+      if (dist > p->pair_window) break;                         /* H:557-559 */
+      if (((s1->meta ^ s2->meta) & VSV_M_DEL) == 0 && st2[j] == -1) { /* H:560 */
+        if (match_sig(s1, s2, p->pair_shift)) { st1[i] = j; st2[j] = i; break; } /* H:561-569 */
+      }
+    }
+  }
+  for (int64_t i = 0; i < na; ++i) {                             /* H:571-586 */
+    vsv_call c; memset(&c, 0, sizeof c);
+    const vsv_sig* s1 = &m[a0 + i];
+    if (st1[i] == -1) { c.sig = *s1; c.a = (int32_t)(a0 + i); c.b = -1; c.gt = 1; }
+    else {
+      const vsv_sig* s2 = &m[b0 + st1[i]];
+      c.sig = (s1->svlen > s2->svlen) ? *s1 : *s2;
+      c.a = (int32_t)(a0 + i); c.b = (int32_t)(b0 + st1[i]); c.gt = 2;
+    }
+    cv_push(out, &c);
+  }
+  for (int64_t j = 0; j < nb; ++j)                               /* H:588-592 */
+    if (st2[j] == -1) {
+      vsv_call c; memset(&c, 0, sizeof c);
+      c.sig = m[b0 + j]; c.a = -1; c.b = (int32_t)(b0 + j); c.gt = 1;
+      cv_push(out, &c);
+    }
+  free(st1); free(st2);
+}
+
+static void sort_calls(vsv_call* c, int64_t n) {
+  if (n <= 1) return;
+  uint64_t* key = (uint64_t*)malloc((size_t)n * sizeof(uint64_t));
+  int64_t* idx = (int64_t*)malloc((size_t)n * sizeof(int64_t));
+  vsv_call* t = (vsv_call*)malloc((size_t)n * sizeof(vsv_call));
+  for (int64_t i = 0; i < n; ++i) { key[i] = key_tidpos(&c[i].sig); idx[i] = i; }
+  stable_sort_idx(key, idx, n);
+  for (int64_t i = 0; i < n; ++i) t[i] = c[idx[i]];
+  memcpy(c, t, (size_t)n * sizeof(vsv_call));
+  free(key); free(idx); free(t);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * whole path. For contig dtypes: per-chromosome body of H:742-772 without VCF text. For READS:
+ * RS:268-286. For SVIM: CIGAR stage only (SV/SVIM_intra.py:8-30).
+ * ------------------------------------------------------------------------------------------------ */
+static vsv_sig* sv_dup(const sigvec* s) {
+  vsv_sig* v = (vsv_sig*)malloc((size_t)(s->n > 0 ? s->n : 1) * sizeof(vsv_sig));
+  if (s->n) memcpy(v, s->v, (size_t)s->n * sizeof(vsv_sig));
+  return v;
+}
+
+int orc_run(const vsv_records* r, const vsv_params* p, int literal, orc_out* o) {
+  memset(o, 0, sizeof *o);
+  int dtype = p->dtype;
+  int contig = dtype == VSV_DTYPE_HIFI || dtype == VSV_DTYPE_ONT || dtype == VSV_DTYPE_CLR;
+  sigvec raw = {0}, cig = {0}, spl = {0}, c1 = {0}, mg = {0};
+  callvec calls = {0};
+  int st = 0;
+
+  /* ---- CIGAR stage (H:386-400 / C:422-433 / RS:107-125) ---- */
+  for (int64_t i = 0; i < r->n_records && st == 0; ++i) {
+    if (r->cigar_off[i + 1] <= r->cigar_off[i]) { st = VSV_E_EMPTY_CIGAR; break; }
+    if (contig) {
+      if (!(r->flag[i] & (VSV_F_HP1 | VSV_F_HP2))) continue;
+      int gate = 1;
+      if (dtype == VSV_DTYPE_CLR) { gate = clr_gate(r, i); if (gate < 0) { st = gate; break; } }
+      if (r->mapq[i] < p->min_cigar_mapq || !gate) continue;
+      if (r->flag[i] & VSV_F_HP1) st = walk_record(r, i, p, 0, &raw);
+      if (st == 0 && (r->flag[i] & VSV_F_HP2)) st = walk_record(r, i, p, VSV_M_HP2, &raw);
+    } else if (dtype == VSV_DTYPE_READS) {
+      if (r->mapq[i] < p->min_cigar_mapq) continue;            /* RS:120 */
+      st = walk_record(r, i, p, 0, &raw);
+    } else {
+      if ((r->flag[i] & (VSV_F_UNMAPPED | VSV_F_SECONDARY)) || r->mapq[i] < p->min_cigar_mapq) continue; /* SV/SVIM_COLLECT.py:67 */
+      st = walk_record(r, i, p, 0, &raw);
+    }
+  }
+  o->raw = sv_dup(&raw); o->n_raw = raw.n;
+
+  /* ---- intra-read fold (H:108-161): contig dtypes only ---- */
+  if (contig) {
+    int64_t lo = 0;
+    while (lo < raw.n) {
+      int64_t hi = lo + 1;
+      while (hi < raw.n && raw.v[hi].rec == raw.v[lo].rec && ((raw.v[hi].meta ^ raw.v[lo].meta) & VSV_M_HP2) == 0) hi++;
+      fold_record(raw.v, lo, hi);
+      lo = hi;
+    }
+  }
+  for (int64_t k = 0; k < raw.n; ++k) if (!(raw.v[k].meta & VSV_M_DEAD)) sv_push(&cig, &raw.v[k]);
+  o->cigar = sv_dup(&cig); o->n_cigar = cig.n;
+
+  /* ---- split stage, per tid (fetch(chr) H:424) and hap pass ---- */
+  if (st == 0 && p->enable_split && dtype != VSV_DTYPE_SVIM) {
+    int64_t lo = 0;
+    while (lo < r->n_records && st == 0) {
+      int64_t hi = lo + 1;
+      while (hi < r->n_records && r->tid[hi] == r->tid[lo]) hi++;
+      if (contig) {
+        st = split_pass(r, lo, hi, p, 0, VSV_F_HP1, p->min_split_mapq, &spl);
+        if (st == 0) st = split_pass(r, lo, hi, p, VSV_M_HP2, VSV_F_HP2, p->min_split_mapq, &spl);
+      } else st = split_pass(r, lo, hi, p, 0, 0, 0, &spl);      /* RS:235 min_mapq=0, no filter */
+      lo = hi;
+    }
+  }
+  o->split = sv_dup(&spl); o->n_split = spl.n;
+
+  if (dtype == VSV_DTYPE_READS) {
+    /* RS:281-286: del_cigar_sorted + ins_cigar_sorted + del_split_sorted + ins_split_sorted, then
+     * sort by pos. With a stable sort this is: key (tid, pos), ties by (DEL<INS within source,
+     * cigar<split, list order). */
+    sigvec all = {0};
+    for (int pass = 0; pass < 4; ++pass) {
+      const sigvec* src = pass < 2 ? &cig : &spl;
+      int want_del = (pass % 2) == 0;
+      sigvec tmp = {0};
+      for (int64_t k = 0; k < src->n; ++k) if (((src->v[k].meta & VSV_M_DEL) != 0) == want_del) sv_push(&tmp, &src->v[k]);
+      sort_sigs(tmp.v, tmp.n, key_tidpos);
+      for (int64_t k = 0; k < tmp.n; ++k) sv_push(&all, &tmp.v[k]);
+      free(tmp.v);
+    }
+    /* per-tid final sort: different tids are different files in the reference; tid-major here */
+    sort_sigs(all.v, all.n, key_tidpos);
+    o->reads = sv_dup(&all); o->n_reads = all.n; free(all.v);
+  }
+
+  if (contig && st == 0) {
+    /* ---- stage 1: per-source sort + cluster (H:402-415, 459-473) ---- */
+    sigvec s1 = {0};
+    for (int64_t k = 0; k < cig.n; ++k) sv_push(&s1, &cig.v[k]);
+    for (int64_t k = 0; k < spl.n; ++k) sv_push(&s1, &spl.v[k]);
+    sort_sigs(s1.v, s1.n, key_stage1);
+    cluster_all(s1.v, s1.n, key_stage1, p->cluster_shift, literal, &c1);
+    o->cluster1 = sv_dup(&c1); o->n_cluster1 = c1.n;
+    /* ---- stage 2: merge_sig_ins / merge_sig_del (H:478-490): cigar list + split list, sort, cluster ---- */
+    sigvec s2 = {0}, c2 = {0};
+    for (int64_t k = 0; k < c1.n; ++k) sv_push(&s2, &c1.v[k]);
+    sort_sigs(s2.v, s2.n, key_stage2);
+    cluster_all(s2.v, s2.n, key_stage2, p->cluster_shift, literal, &c2);
+    /* ---- stage 3: sort_sig(ins_final + del_final) per hap (H:495) ---- */
+    sort_sigs(c2.v, c2.n, key_stage3);
+    for (int64_t k = 0; k < c2.n; ++k) sv_push(&mg, &c2.v[k]);
+    o->merged = sv_dup(&mg); o->n_merged = mg.n;
+    /* ---- pair_sig per tid (H:768) ---- */
+    int64_t lo = 0;
+    while (lo < mg.n) {
+      int64_t hi = lo + 1;
+      while (hi < mg.n && mg.v[hi].tid == mg.v[lo].tid) hi++;
+      int64_t mid = lo;
+      while (mid < hi && !(mg.v[mid].meta & VSV_M_HP2)) mid++;
+      int64_t c0 = calls.n;
+      pair_tid(mg.v, lo, mid - lo, mid, hi - mid, p, literal, &calls);
+      sort_calls(calls.v + c0, calls.n - c0);                   /* H:594 */
+      lo = hi;
+    }
+    o->calls = calls.v; o->n_calls = calls.n; calls.v = NULL;
+    free(s1.v); free(s2.v); free(c2.v);
+  }
+  if (!o->cluster1) o->cluster1 = (vsv_sig*)malloc(sizeof(vsv_sig));
+  if (!o->merged) o->merged = (vsv_sig*)malloc(sizeof(vsv_sig));
+  if (!o->calls) o->calls = (vsv_call*)malloc(sizeof(vsv_call));
+  if (!o->reads) o->reads = (vsv_sig*)malloc(sizeof(vsv_sig));
+  free(raw.v); free(cig.v); free(spl.v); free(c1.v); free(mg.v); free(calls.v);
+  o->status = st;
+  return st;
+}
+
+void orc_free(orc_out* o) {
+  free(o->raw); free(o->cigar); free(o->split); free(o->cluster1); free(o->merged); free(o->calls); free(o->reads);
+  memset(o, 0, sizeof *o);
+}
+
+/* default parameters = hard-coded reference values (same table as vsv_default_params) */
+int orc_default_params(int dtype, vsv_params* p) {
+  memset(p, 0, sizeof *p);
+  p->dtype = dtype;
+  p->min_svlen = dtype == VSV_DTYPE_SVIM ? 40 : 30;   /* SV/SVIM_input_parsing.py min_sv_size 40 */
+  p->min_cigar_mapq = dtype == VSV_DTYPE_SVIM ? 20 : 50;
+  p->min_split_mapq = dtype == VSV_DTYPE_READS ? 0 : 50;
+  p->max_split_svlen = 50000;
+  p->cluster_shift = 100;
+  p->pair_shift = 200;
+  p->pair_window = 1000;
+  p->enable_split = dtype == VSV_DTYPE_SVIM ? 0 : 1;
+  return 0;
+}

@@ -1,0 +1,57 @@
+"""Host-side views of the C-ABI tables in the reference's own list-of-fields form.
+
+The reference's only data type on this path is a Python list of 10 fields
+(extract_contig_signature_Hifi.py:80,84): [chrom, 'DEL'|'INS', pos, svlen, qname, q_start, q_end,
+'+'|'-', 'cigar'|'split-alignment', mapq | "m1-m2"], extended by pair_sig (H:573-592) with
+[GT, contig_info, strands, sources, mapqs]. The C-ABI carries integers only (include/volcanosv.h
+`vsv_sig`, `vsv_call`); these helpers re-attach the strings from the caller's SoA.
+"""
+from .types import DTYPE_READS, M_DEL, M_HP2, M_SPLIT
+
+
+def _chrom(soa, tid):
+    if soa.tid_names is not None:
+        return soa.tid_names[int(tid)]
+    return "chr%d" % (int(tid) + 1)
+
+
+def sig_fields(soa, s, dtype=None):
+    """One vsv_sig row -> the reference's field list (10 fields; READS: 8/9 fields, RS:72-76,191-195)."""
+    chrom = _chrom(soa, s["tid"])
+    is_del = bool(s["meta"] & M_DEL)
+    typ = "DEL" if is_del else "INS"
+    rec = int(s["rec"])
+    qname, strand = soa.qname(rec), soa.strand(rec)
+    if dtype == DTYPE_READS:
+        if s["meta"] & M_SPLIT:
+            # the reference's own spellings (RS:191, RS:194)
+            return [chrom, typ, int(s["pos"]), int(s["svlen"]), qname, int(s["q_start"]), int(s["q_end"]), strand,
+                    "split-alignemnt" if is_del else "split_alignment"]
+        return [chrom, typ, int(s["pos"]), int(s["svlen"]), qname, int(s["q_start"]), strand, "cigar"]
+    if s["meta"] & M_SPLIT:
+        src = "split-alignment"
+        mapq = "%d-%d" % (int(soa.mapq[rec]), int(soa.mapq[int(s["rec2"])]))
+    else:
+        src = "cigar"
+        mapq = int(soa.mapq[rec])
+    return [chrom, typ, int(s["pos"]), int(s["svlen"]), qname, int(s["q_start"]), int(s["q_end"]), strand, src, mapq]
+
+
+def call_fields(soa, c, merged):
+    """One vsv_call row -> the 15-field paired signature of pair_sig (H:571-592)."""
+    base = sig_fields(soa, c["sig"])
+    a, b = int(c["a"]), int(c["b"])
+
+    def info(s):
+        f = sig_fields(soa, s)
+        return "%s:%d-%d" % (f[4], f[5], f[6]), f[7], f[8], str(f[9])
+
+    if a >= 0 and b >= 0:
+        i1, i2 = info(merged[a]), info(merged[b])
+        return base + ["1/1", i1[0] + "," + i2[0], i1[1] + "," + i2[1], i1[2] + "," + i2[2], i1[3] + "," + i2[3]]
+    i1 = info(merged[a] if a >= 0 else merged[b])
+    return base + ["0/1", i1[0], i1[1], i1[2], i1[3]]
+
+
+def hap_of(s):
+    return "hp2" if s["meta"] & M_HP2 else "hp1"

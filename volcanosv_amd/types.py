@@ -1,0 +1,59 @@
+"""Shared layouts of the C-ABI (include/volcanosv.h): ctypes structs + numpy dtypes.
+
+The field order and sizes here must match include/volcanosv.h exactly; tests/test_abi.py checks
+sizeof() against the compiled library.
+"""
+import ctypes as C
+
+import numpy as np
+
+ABI_VERSION = 1
+
+# dtype of the extractor (reference: extract_contig_signature_{Hifi,ONT,CLR}.py, extract_reads_signature.py,
+# svim_asm/SVIM_intra.py)
+DTYPE_HIFI, DTYPE_ONT, DTYPE_CLR, DTYPE_READS, DTYPE_SVIM = 0, 1, 2, 3, 4
+DTYPE_BY_NAME = {"Hifi": DTYPE_HIFI, "ONT": DTYPE_ONT, "CLR": DTYPE_CLR, "READS": DTYPE_READS, "SVIM": DTYPE_SVIM}
+
+F_REVERSE, F_SUPP, F_HP1, F_HP2, F_SECONDARY, F_UNMAPPED = 1, 2, 4, 8, 16, 32
+M_DEL, M_SPLIT, M_HP2, M_DEAD = 1, 2, 4, 8
+
+T_RAW, T_CIGAR, T_SPLIT, T_CLUSTER1, T_MERGED, T_CALLS, T_READS = range(7)
+
+STATUS = {
+    0: "VSV_OK", -1: "VSV_E_INVALID", -2: "VSV_E_HIP", -3: "VSV_E_CAPACITY", -4: "VSV_E_EMPTY_CIGAR",
+    -5: "VSV_E_REFEND", -6: "VSV_E_READLEN", -7: "VSV_E_UNSORTED", -8: "VSV_E_ZERODIV", -9: "VSV_E_NO_DEVICE",
+}
+
+SIG_DTYPE = np.dtype([
+    ("pos", "<i4"), ("svlen", "<i4"), ("q_start", "<i4"), ("q_end", "<i4"),
+    ("rec", "<u4"), ("rec2", "<u4"), ("meta", "<u4"), ("tid", "<i4"),
+])
+CALL_DTYPE = np.dtype([("sig", SIG_DTYPE), ("a", "<i4"), ("b", "<i4"), ("gt", "<i4"), ("pad", "<i4")])
+assert SIG_DTYPE.itemsize == 32 and CALL_DTYPE.itemsize == 48
+
+
+class Records(C.Structure):
+    _fields_ = [
+        ("n_records", C.c_int64), ("n_ops", C.c_int64),
+        ("pos", C.c_void_p), ("tid", C.c_void_p), ("qid", C.c_void_p), ("cigar_off", C.c_void_p),
+        ("mapq", C.c_void_p), ("flag", C.c_void_p), ("cigar", C.c_void_p),
+        ("on_device", C.c_int32), ("n_qids", C.c_int32),
+    ]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32), ("min_svlen", C.c_int32), ("min_cigar_mapq", C.c_int32),
+        ("min_split_mapq", C.c_int32), ("max_split_svlen", C.c_int32), ("cluster_shift", C.c_int32),
+        ("pair_shift", C.c_int32), ("pair_window", C.c_int32), ("enable_split", C.c_int32),
+        ("reserved", C.c_int32 * 7),
+    ]
+
+
+class VsvError(RuntimeError):
+    """Raised when a C-ABI call returns a negative status. `.status` holds the vsv_status value; the
+    reference raises AssertionError / IndexError / ZeroDivisionError at the cited lines instead."""
+
+    def __init__(self, status, msg=""):
+        self.status = int(status)
+        super().__init__("%s (%d)%s" % (STATUS.get(int(status), "VSV_E_?"), status, (": " + msg) if msg else ""))
