@@ -9,7 +9,7 @@ import subprocess
 
 import numpy as np
 
-from volcanosv_amd.types import CALL_DTYPE, SIG_DTYPE, Params, Records
+from volcanosv_amd.abi import CALL_DTYPE, SIG_DTYPE, Params, Records
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None

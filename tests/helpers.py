@@ -6,7 +6,7 @@ import numpy as np
 
 from volcanosv_amd import sigtable
 from volcanosv_amd.soa import RecordSoA
-from volcanosv_amd.types import DTYPE_BY_NAME, DTYPE_READS, M_DEL, M_HP2, M_SPLIT
+from volcanosv_amd.abi import DTYPE_BY_NAME, DTYPE_READS, M_DEL, M_HP2, M_SPLIT
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")

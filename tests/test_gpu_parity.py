@@ -1,0 +1,238 @@
+"""GPU parity tests (run on the MI355X box with -m gpu): HIP path through the C-ABI vs the CPU oracle and the
+golden fixtures produced by the reference's own functions. Bit-exact on every stage table."""
+import numpy as np
+import pytest
+
+from helpers import compare_contig_tables, load_fixture, rows, sel
+from volcanosv_amd.abi import (DTYPE_CLR, DTYPE_HIFI, DTYPE_ONT, DTYPE_READS, DTYPE_SVIM, F_HP1, F_HP2, M_DEL, VsvError)
+from volcanosv_amd.soa import RecordSoA
+
+pytestmark = pytest.mark.gpu
+
+CONTIG = ["contig_hifi_tiefree", "contig_hifi_stable", "contig_ont_tiefree", "contig_ont_stable",
+          "contig_clr_tiefree", "contig_clr_stable"]
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from volcanosv_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def oracle_run(soa, dtype, params=None):
+    from oracle import oracle
+    return oracle.run(soa, params=params, dtype=dtype)
+
+
+def assert_tables_equal(got, want, names):
+    for k in names:
+        assert got[k].shape == want[k].shape, (k, got[k].shape, want[k].shape)
+        if not np.array_equal(got[k], want[k]):
+            bad = np.nonzero(got[k] != want[k])[0]
+            i = int(bad[0])
+            raise AssertionError("table %s differs at row %d of %d: got %s want %s (%d rows differ)" %
+                                 (k, i, len(want[k]), got[k][i], want[k][i], len(bad)))
+
+
+def run_both(eng, soa, dtype, params=None):
+    from volcanosv_amd.engine import default_params
+    p = params if params is not None else default_params(dtype)
+    eng.run(soa, p)
+    got = eng.tables(dtype)
+    st, want = oracle_run(soa, dtype, p)
+    assert st == 0
+    assert_tables_equal(got, want, list(got.keys()))
+    return got
+
+
+@pytest.mark.parametrize("name", CONTIG)
+def test_golden_contig(eng, name):
+    doc, soa, dtype = load_fixture(name)
+    got = run_both(eng, soa, dtype)
+    compare_contig_tables(doc, soa, got)     # straight against the reference's outputs
+
+
+@pytest.mark.parametrize("name", ["reads_tiefree", "reads_stable"])
+def test_golden_reads(eng, name):
+    doc, soa, dtype = load_fixture(name)
+    got = run_both(eng, soa, dtype)
+    for t, chrom in enumerate(doc["expected"]["chroms"]):
+        assert rows(soa, got["reads"], dtype=DTYPE_READS, where=sel(t)) == doc["expected"]["per_chrom"][chrom]["merged"]
+
+
+def test_svim_known_answers(eng):
+    """svim-asm tests/test_intra.py:8-22 through the HIP kernel."""
+    from volcanosv_amd.engine import default_params
+    cases = [
+        ([(5, 10), (4, 20), (0, 10), (7, 10), (8, 5), (0, 5), (1, 50), (0, 30), (4, 25), (5, 15)], [(30, 50, 50, "INS")]),
+        ([(5, 10), (4, 20), (0, 30), (2, 50), (0, 30), (4, 25), (5, 15)], [(30, 50, 50, "DEL")]),
+        ([(5, 10), (4, 20), (0, 30), (2, 40), (1, 50), (0, 30), (4, 25), (5, 15)], [(30, 50, 40, "DEL"), (70, 50, 50, "INS")]),
+        ([(5, 10), (4, 20), (0, 30), (1, 40), (2, 50), (0, 30), (4, 25), (5, 15)], [(30, 50, 40, "INS"), (30, 90, 50, "DEL")]),
+    ]
+    soa = RecordSoA.from_tuples([(0, 0, i, 60, False, c[0]) for i, c in enumerate(cases)])
+    p = default_params(DTYPE_SVIM)
+    p.min_svlen = 30
+    eng.run(soa, p)
+    raw = eng.table("raw")
+    for i, (_, want) in enumerate(cases):
+        got = [(int(s["pos"]), int(s["q_start"]), int(s["svlen"]), "DEL" if s["meta"] & M_DEL else "INS") for s in raw if int(s["rec"]) == i]
+        assert got == want
+
+
+SYNTH = [
+    ("hifi", 200000, DTYPE_HIFI, {}),
+    ("hifi", 100000, DTYPE_HIFI, dict(chrom_len=2000000, events_per_record=0.2, site_step=1000)),
+    ("hifi", 100000, DTYPE_ONT, dict(chrom_len=2000000, events_per_record=0.2, site_step=1000)),
+    ("hifi", 100000, DTYPE_CLR, dict(chrom_len=2000000, events_per_record=0.2, site_step=1000)),
+    ("hifi", 100000, DTYPE_READS, dict(chrom_len=2000000, events_per_record=0.2, site_step=1000)),
+    ("ont", 20000, DTYPE_ONT, dict(chrom_len=1000000)),
+    ("ont", 20000, DTYPE_READS, dict(chrom_len=1000000)),
+    ("contig", 60, DTYPE_HIFI, dict(chrom_len=20000000)),
+    ("contig", 60, DTYPE_CLR, dict(chrom_len=20000000)),
+    ("contig", 3, DTYPE_SVIM, dict(chrom_len=20000000)),
+]
+
+
+@pytest.mark.parametrize("shape,n,dtype,kw", SYNTH)
+def test_synthetic_vs_oracle(eng, shape, n, dtype, kw):
+    from volcanosv_amd import synth
+    t, nq, nt = synth.generate(n, shape, seed=7, **kw)
+    soa = synth.to_soa(t, nq)
+    got = run_both(eng, soa, dtype)
+    assert len(got["raw"]) > 0
+
+
+def test_multi_tid(eng):
+    from volcanosv_amd import synth
+    parts = []
+    for tid in range(3):
+        t, nq, _ = synth.generate(30000, "hifi", seed=100 + tid, tid=tid, chrom_len=1500000, events_per_record=0.2, site_step=1000)
+        parts.append((t, nq))
+    t, nq = synth.concat(parts)
+    soa = synth.to_soa(t, nq)
+    got = run_both(eng, soa, DTYPE_HIFI)
+    assert set(np.unique(got["calls"]["sig"]["tid"])) == {0, 1, 2}
+
+
+def test_staged_api_equals_fused(eng):
+    from volcanosv_amd import synth
+    from volcanosv_amd.engine import default_params
+    t, nq, _ = synth.generate(50000, "hifi", seed=3, chrom_len=1000000, events_per_record=0.2, site_step=1000)
+    soa = synth.to_soa(t, nq)
+    p = default_params(DTYPE_HIFI)
+    eng.run(soa, p)
+    fused = eng.tables(DTYPE_HIFI)
+    eng.cigar_scan(soa, p)
+    raw = eng.table("raw")
+    eng.split_pairs(p)
+    eng.sort_cluster(p)
+    c1 = eng.table("cluster1")
+    eng.merge_sources(p)
+    eng.pair_haplotypes(p)
+    staged = eng.tables(DTYPE_HIFI)
+    assert np.array_equal(raw, fused["raw"]) and np.array_equal(c1, fused["cluster1"])
+    assert_tables_equal(staged, fused, list(fused.keys()))
+
+
+def test_edge_cases(eng):
+    from volcanosv_amd.engine import default_params
+    p = default_params(DTYPE_HIFI)
+    # empty input
+    soa = RecordSoA.from_tuples([])
+    soa = RecordSoA(np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.uint32), np.zeros(1, np.uint64),
+                    np.zeros(0, np.uint8), np.zeros(0, np.uint8), np.zeros(0, np.uint32))
+    eng.run(soa, p)
+    assert len(eng.table("calls")) == 0
+    # single record, single op
+    soa = RecordSoA.from_tuples([(0, 5, "x_hp1", 60, False, [(0, 100)])])
+    run_both(eng, soa, DTYPE_HIFI)
+    # ragged: 1-op records, a record straddling several 2048-op parts, event as first / last op, both hp tags
+    big = []
+    for i in range(3000):
+        big += [(0, 40), (1 if i % 2 else 2, 31 if i % 500 == 0 else 3)]
+    big.append((0, 10))
+    recs = [(0, 10, "a_hp1", 60, False, [(1, 45), (0, 100)]),
+            (0, 11, "b_hp2", 60, True, [(0, 100), (2, 77)]),
+            (0, 12, "c_hp1", 60, False, [(0, 7)]),
+            (0, 13, "d_hp1_hp2", 60, False, big),
+            (0, 14, "e_hp2", 60, False, [(5, 9), (1, 300), (0, 5), (1, 300), (4, 3)]),
+            (0, 15, "f_hp1", 49, False, [(0, 10), (1, 100), (0, 10)]),
+            (0, 16, "g", 60, False, [(0, 10), (1, 100), (0, 10)])]
+    for i in range(300):
+        recs.append((0, 20 + i, "z%d_hp%d" % (i, 1 + i % 2), 60, False, [(0, 3)] if i % 3 else [(0, 3), (2, 50 + i), (0, 2)]))
+    soa = RecordSoA.from_tuples(recs)
+    run_both(eng, soa, DTYPE_HIFI)
+    run_both(eng, soa, DTYPE_READS)
+    # op count an exact multiple of the part size (2048) and of the chunk size (256)
+    recs = [(0, i, "r%d_hp1" % i, 60, False, [(0, 5), (2, 30 + i % 7)] * 128) for i in range(64)]
+    soa = RecordSoA.from_tuples(recs)
+    assert soa.n_ops % 2048 == 0
+    run_both(eng, soa, DTYPE_HIFI)
+
+
+def test_error_statuses(eng):
+    from volcanosv_amd.engine import default_params
+    soa = RecordSoA.from_tuples([(0, 10, "a_hp1", 60, False, [(0, 50), (7, 10), (0, 50)])])
+    with pytest.raises(VsvError) as e:
+        eng.run(soa, default_params(DTYPE_HIFI))
+    assert e.value.status == -5          # VSV_E_REFEND, reference assert at Hifi.py:396
+    eng.run(soa, default_params(DTYPE_READS))
+    soa = RecordSoA.from_tuples([(0, 10, "a_hp1", 60, False, [(0, 500), (4, 100)]), (0, 900, "a_hp1", 60, False, [(4, 400), (0, 300)])])
+    with pytest.raises(VsvError) as e:
+        eng.run(soa, default_params(DTYPE_HIFI))
+    assert e.value.status == -6          # VSV_E_READLEN, reference assert at Hifi.py:331
+    # empty CIGAR
+    soa = RecordSoA(np.array([1, 2], np.int32), np.zeros(2, np.int32), np.array([0, 1], np.uint32), np.array([0, 0, 1], np.uint64),
+                    np.array([60, 60], np.uint8), np.array([F_HP1, F_HP1], np.uint8), np.array([(5 << 4)], np.uint32))
+    with pytest.raises(VsvError) as e:
+        eng.run(soa, default_params(DTYPE_HIFI))
+    assert e.value.status == -4
+
+
+def test_capacity_overflow_reports_required_count():
+    from volcanosv_amd import synth
+    from volcanosv_amd.engine import Engine, default_params
+    t, nq, _ = synth.generate(50000, "hifi", seed=3, chrom_len=1000000, events_per_record=0.5, site_step=500)
+    soa = synth.to_soa(t, nq)
+    e = Engine(0, max_sigs=2048)
+    try:
+        with pytest.raises(VsvError) as ex:
+            e.run(soa, default_params(DTYPE_HIFI))
+        assert ex.value.status == -3
+        need = e.last_count()
+        assert need > 2048
+        e.reserve(0, 0, need + 16)
+        e.run(soa, default_params(DTYPE_HIFI))
+        from oracle import oracle
+        st, want = oracle.run(soa, dtype=DTYPE_HIFI)
+        assert np.array_equal(e.table("calls"), want["calls"])
+    finally:
+        e.close()
+
+
+def test_full_size_config2_properties(eng):
+    """BASELINE.json config 2 at full size (10 M HiFi-like records, device-resident): idempotence, sortedness,
+    call-table checksum equal to the CPU oracle's."""
+    import torch
+    from volcanosv_amd import synth
+    from volcanosv_amd.engine import DeviceRecords, default_params
+    t, nq, nt = synth.generate(10_000_000, "hifi", seed=20250330, device="cuda")
+    dr = DeviceRecords(t, nq, nt)
+    p = default_params(DTYPE_HIFI)
+    eng.run(dr, p)
+    a = eng.tables(DTYPE_HIFI)
+    eng.run(dr, p)
+    b = eng.tables(DTYPE_HIFI)
+    assert_tables_equal(a, b, list(a.keys()))                      # idempotent / deterministic
+    calls = a["calls"]
+    assert len(calls) > 10000
+    key = calls["sig"]["tid"].astype(np.int64) << 32 | calls["sig"]["pos"].astype(np.int64)
+    assert np.all(np.diff(key) >= 0)                               # sorted by (tid, pos)
+    soa = synth.to_soa(t, nq)
+    st, want = oracle_run(soa, DTYPE_HIFI)
+    assert st == 0
+    assert_tables_equal(a, want, list(a.keys()))
+    del t
+    torch.cuda.empty_cache()

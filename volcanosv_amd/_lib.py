@@ -1,0 +1,61 @@
+"""ctypes loader of the in-tree HIP library (volcanosv_amd/libvolcanosv_hip.so).
+
+There is NO CPU fallback: if the library is missing or cannot be loaded this raises, and every product
+entry point goes through it. (The CPU oracle under oracle/ is test infrastructure and is never imported
+from this package.)
+"""
+import ctypes as C
+import os
+
+from .abi import ABI_VERSION, Params, Records
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvolcanosv_hip.so")
+_lib = None
+
+# every symbol include/volcanosv.h declares
+SYMBOLS = [
+    "vsv_abi_version", "vsv_status_string", "vsv_create", "vsv_destroy", "vsv_last_error", "vsv_last_count",
+    "vsv_default_params", "vsv_reserve", "vsv_cigar_scan", "vsv_split_pairs", "vsv_sort_cluster", "vsv_merge_sources",
+    "vsv_pair_haplotypes", "vsv_run_chromosome", "vsv_run_chromosome_async", "vsv_finish", "vsv_table_count",
+    "vsv_table_fill", "vsv_last_scan_ms",
+]
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "HIP extension %s not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or python volcanosv_amd/build.py); there is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    H = C.c_void_p
+    lib.vsv_abi_version.restype = C.c_int
+    lib.vsv_status_string.restype = C.c_char_p
+    lib.vsv_status_string.argtypes = [C.c_int]
+    lib.vsv_create.argtypes = [C.c_int, C.c_void_p, C.POINTER(H)]
+    lib.vsv_destroy.argtypes = [H]
+    lib.vsv_destroy.restype = None
+    lib.vsv_last_error.argtypes = [H]
+    lib.vsv_last_error.restype = C.c_char_p
+    lib.vsv_last_count.argtypes = [H]
+    lib.vsv_last_count.restype = C.c_int64
+    lib.vsv_default_params.argtypes = [C.c_int, C.POINTER(Params)]
+    lib.vsv_reserve.argtypes = [H, C.c_int64, C.c_int64, C.c_int64]
+    for name in ("vsv_cigar_scan", "vsv_split_pairs", "vsv_run_chromosome", "vsv_run_chromosome_async"):
+        getattr(lib, name).argtypes = [H, C.POINTER(Records), C.POINTER(Params)]
+    for name in ("vsv_sort_cluster", "vsv_merge_sources", "vsv_pair_haplotypes"):
+        getattr(lib, name).argtypes = [H, C.POINTER(Params)]
+    lib.vsv_finish.argtypes = [H]
+    lib.vsv_table_count.argtypes = [H, C.c_int, C.POINTER(C.c_int64)]
+    lib.vsv_table_fill.argtypes = [H, C.c_int, C.c_void_p, C.c_int64, C.c_int]
+    lib.vsv_last_scan_ms.argtypes = [H, C.POINTER(C.c_float)]
+    for name in SYMBOLS:
+        if name not in ("vsv_destroy", "vsv_last_error", "vsv_last_count", "vsv_status_string"):
+            getattr(lib, name).restype = C.c_int
+    if lib.vsv_abi_version() != ABI_VERSION:
+        raise ImportError("ABI mismatch: library %d, python %d" % (lib.vsv_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib

@@ -1,0 +1,481 @@
+// capi.hip — extern "C" entry points of include/volcanosv.h: handle, workspace, stage orchestration.
+// All device work is enqueued on the handle's stream without host synchronisation; counts and error
+// bits live in a device `Counters` block that vsv_finish() reads back once.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "vsv_device.h"
+
+namespace {
+
+constexpr int OPS_PER_PART = 2048;
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+}  // namespace
+
+struct vsv_handle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  int64_t last_count = 0;
+  // capacities
+  int64_t cap_sigs = 0, cap_records = 0, cap_ops = 0;
+  std::vector<DevBuf*> all;
+  // record upload buffers (host-pointer callers)
+  DevBuf r_pos, r_tid, r_qid, r_off, r_mapq, r_flag, r_cigar;
+  // workspace
+  DevBuf part_rb, part_count, part_off, scan_tmp;
+  DevBuf pool, pool_key, raw0, s1in, s1s, c1, s2s, c2, merged, calls_tmp, calls, reads;
+  DevBuf tab, blk_cnt, blk_off, ckey, crec, okey, oval;
+  DevBuf key, idx, cl, key2, idx2, key_alt, val_alt, hist;
+  DevBuf ctr;
+  Counters host_ctr;
+  Counters* pinned = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool have_scan_ev = false;
+  // state
+  RecView rv{};
+  int n_tids = 0;
+  vsv_params prm{};
+  int stage_done = 0;     // 0 none, 1 scan, 2 split, 3 sort_cluster, 4 merge, 5 pair
+  bool pending = false;   // work enqueued, counters not read back
+  uint32_t tab_size = 0;
+};
+
+namespace {
+
+int fail(vsv_handle* h, int status, const std::string& msg) {
+  if (h) h->err = msg;
+  return status;
+}
+
+#define HIPCHK(h, expr)                                                                      \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) return fail(h, VSV_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+int ensure(vsv_handle* h, DevBuf& b, size_t bytes) {
+  if (bytes < 256) bytes = 256;
+  if (b.bytes >= bytes) return 0;
+  if (b.p) { HIPCHK(h, hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
+  HIPCHK(h, hipMalloc(&b.p, bytes));
+  b.bytes = bytes;
+  return 0;
+}
+
+uint32_t pow2_at_least(uint64_t n) { uint32_t p = 1024; while (p < n && p < (1u << 30)) p <<= 1; return p; }
+int bits_for(uint64_t n) { int b = 1; while ((1ull << b) < n && b < 63) ++b; return b; }
+
+int reserve(vsv_handle* h, int64_t max_records, int64_t max_ops, int64_t max_sigs) {
+  if (max_sigs < 1024) max_sigs = 1024;
+  if (max_records < 1) max_records = 1;
+  if (max_ops < 1) max_ops = 1;
+  if (max_sigs > h->cap_sigs) {
+    const size_t n = (size_t)max_sigs;
+    DevBuf* sigbufs[] = {&h->pool, &h->raw0, &h->s1in, &h->s1s, &h->c1, &h->s2s, &h->c2, &h->merged, &h->reads};
+    for (DevBuf* b : sigbufs) { int st = ensure(h, *b, n * sizeof(vsv_sig)); if (st) return st; }
+    DevBuf* callbufs[] = {&h->calls_tmp, &h->calls};
+    for (DevBuf* b : callbufs) { int st = ensure(h, *b, n * sizeof(vsv_call)); if (st) return st; }
+    DevBuf* u64bufs[] = {&h->pool_key, &h->ckey, &h->okey, &h->key, &h->key2, &h->key_alt};
+    for (DevBuf* b : u64bufs) { int st = ensure(h, *b, n * sizeof(uint64_t)); if (st) return st; }
+    DevBuf* u32bufs[] = {&h->crec, &h->oval, &h->idx, &h->cl, &h->idx2, &h->val_alt};
+    for (DevBuf* b : u32bufs) { int st = ensure(h, *b, n * sizeof(uint32_t)); if (st) return st; }
+    int st = ensure(h, h->hist, (size_t)vsv_radix_hist_entries(max_sigs) * sizeof(uint32_t));
+    if (st) return st;
+    h->cap_sigs = max_sigs;
+  }
+  if (max_ops > h->cap_ops || max_records > h->cap_records) {
+    const int64_t ops = max_ops > h->cap_ops ? max_ops : h->cap_ops;
+    const int64_t recs = max_records > h->cap_records ? max_records : h->cap_records;
+    const size_t n_parts = (size_t)vsv_cigar_parts(ops, OPS_PER_PART) + 2;
+    const size_t nblk = (size_t)((recs * 2 + 2047) / 2048) + 2;
+    int st;
+    if ((st = ensure(h, h->part_rb, (n_parts + 1) * 4))) return st;
+    if ((st = ensure(h, h->part_count, n_parts * 4))) return st;
+    if ((st = ensure(h, h->part_off, n_parts * 4))) return st;
+    if ((st = ensure(h, h->blk_cnt, nblk * 4))) return st;
+    if ((st = ensure(h, h->blk_off, nblk * 4))) return st;
+    const size_t m = n_parts > nblk ? n_parts : nblk;
+    if ((st = ensure(h, h->scan_tmp, (m / 2048 + 2) * 4))) return st;
+    h->cap_ops = ops;
+    h->cap_records = recs;
+  }
+  return 0;
+}
+
+int upload(vsv_handle* h, DevBuf& b, const void* src, size_t bytes) {
+  int st = ensure(h, b, bytes + 16);
+  if (st) return st;
+  if (bytes) HIPCHK(h, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, h->stream));
+  return 0;
+}
+
+int bind_records(vsv_handle* h, const vsv_records* r) {
+  if (!r) return fail(h, VSV_E_INVALID, "records is NULL");
+  if (r->n_records < 0 || r->n_ops < 0 || r->n_records > 0xFFFFFFF0ll) return fail(h, VSV_E_INVALID, "bad record counts");
+  if (r->n_records > 0 && (!r->pos || !r->tid || !r->qid || !r->cigar_off || !r->mapq || !r->flag || (r->n_ops > 0 && !r->cigar)))
+    return fail(h, VSV_E_INVALID, "NULL record array");
+  RecView v{};
+  v.n_records = r->n_records; v.n_ops = r->n_ops; v.n_qids = r->n_qids;
+  if (r->on_device) {
+    if (((uintptr_t)r->cigar & 15) != 0) return fail(h, VSV_E_INVALID, "cigar must be 16-byte aligned");
+    v.pos = r->pos; v.tid = r->tid; v.qid = r->qid; v.cigar_off = r->cigar_off; v.mapq = r->mapq; v.flag = r->flag; v.cigar = r->cigar;
+  } else {
+    const size_t n = (size_t)r->n_records;
+    int st;
+    if ((st = upload(h, h->r_pos, r->pos, n * 4))) return st;
+    if ((st = upload(h, h->r_tid, r->tid, n * 4))) return st;
+    if ((st = upload(h, h->r_qid, r->qid, n * 4))) return st;
+    if ((st = upload(h, h->r_off, r->cigar_off, (n + 1) * 8))) return st;
+    if ((st = upload(h, h->r_mapq, r->mapq, n))) return st;
+    if ((st = upload(h, h->r_flag, r->flag, n))) return st;
+    if ((st = upload(h, h->r_cigar, r->cigar, (size_t)r->n_ops * 4))) return st;
+    v.pos = (const int32_t*)h->r_pos.p; v.tid = (const int32_t*)h->r_tid.p; v.qid = (const uint32_t*)h->r_qid.p;
+    v.cigar_off = (const uint64_t*)h->r_off.p; v.mapq = (const uint8_t*)h->r_mapq.p; v.flag = (const uint8_t*)h->r_flag.p;
+    v.cigar = (const uint32_t*)h->r_cigar.p;
+  }
+  h->rv = v;
+  h->n_tids = r->n_tids;
+  int st = reserve(h, r->n_records, r->n_ops, h->cap_sigs > 0 ? h->cap_sigs : (1 << 22));
+  if (st) return st;
+  // split hash table: >= 2 slots per (qid, hap)
+  const uint64_t nq = r->n_qids > 0 ? (uint64_t)r->n_qids : (uint64_t)r->n_records;
+  const uint32_t ts = pow2_at_least(2 * nq + 2);
+  if ((st = ensure(h, h->tab, (size_t)ts * 4))) return st;
+  h->tab_size = ts;
+  return 0;
+}
+
+SortWork sort_work(vsv_handle* h) {
+  SortWork w;
+  w.key_alt = (uint64_t*)h->key_alt.p; w.val_alt = (uint32_t*)h->val_alt.p; w.hist = (uint32_t*)h->hist.p; w.max_items = h->cap_sigs;
+  return w;
+}
+StageBufs stage_bufs(vsv_handle* h) { return StageBufs{(uint64_t*)h->key.p, (uint32_t*)h->idx.p, (int32_t*)h->cl.p}; }
+Counters* dctr(vsv_handle* h) { return (Counters*)h->ctr.p; }
+int key_bits(vsv_handle* h) { return 35 + bits_for((uint64_t)(h->n_tids > 0 ? h->n_tids : 65536) + 1) + 1; }
+
+bool is_contig(int dtype) { return dtype == VSV_DTYPE_HIFI || dtype == VSV_DTYPE_ONT || dtype == VSV_DTYPE_CLR; }
+
+// ---- stage enqueue functions ------------------------------------------------------------------------
+int enq_scan(vsv_handle* h) {
+  hipStream_t st = h->stream;
+  HIPCHK(h, hipMemsetAsync(h->ctr.p, 0, sizeof(Counters), st));
+  const int n_parts = vsv_cigar_parts(h->rv.n_ops, OPS_PER_PART);
+  vsv_launch_cigar_scan(st, h->rv, h->prm, (uint32_t*)h->part_rb.p, n_parts, OPS_PER_PART, (vsv_sig*)h->pool.p,
+                        (uint64_t*)h->pool_key.p, (uint32_t)h->cap_sigs, (uint32_t*)h->part_count.p, (uint32_t*)h->part_off.p,
+                        (uint32_t*)h->scan_tmp.p, (vsv_sig*)h->s1in.p, dctr(h), h->ev0, h->ev1);
+  h->have_scan_ev = n_parts > 0;
+  vsv_launch_fold(st, (vsv_sig*)h->s1in.p, (vsv_sig*)h->raw0.p, h->rv, h->prm.dtype, dctr(h));
+  HIPCHK(h, hipGetLastError());
+  h->stage_done = 1;
+  return 0;
+}
+
+int enq_split(vsv_handle* h) {
+  hipStream_t st = h->stream;
+  vsv_params p = h->prm;
+  RecView rv = h->rv;
+  if (!p.enable_split || p.dtype == VSV_DTYPE_SVIM) rv.n_records = 0;  // n_s1 = n_raw
+  vsv_launch_split(st, rv, p, h->n_tids, (uint32_t*)h->tab.p, h->tab_size, (uint32_t*)h->blk_cnt.p, (uint32_t*)h->blk_off.p,
+                   (uint32_t*)h->scan_tmp.p, (uint64_t*)h->ckey.p, (uint32_t*)h->crec.p, (uint64_t*)h->okey.p,
+                   (uint32_t*)h->oval.p, sort_work(h), (vsv_sig*)h->s1in.p, (uint32_t)h->cap_sigs, dctr(h));
+  if (p.dtype == VSV_DTYPE_READS) {
+    // reads.py:281-286 merge_all: one stable sort of [del_cigar, ins_cigar, del_split, ins_split] by pos
+    const int nbits = 34 + bits_for((uint64_t)(h->n_tids > 0 ? h->n_tids : 65536) + 1) + 1;
+    vsv_launch_sort_stage(st, (vsv_sig*)h->s1in.p, &dctr(h)->n_s1, 5, nbits, (vsv_sig*)h->reads.p, &dctr(h)->n_reads,
+                          stage_bufs(h), sort_work(h), h->cap_sigs);
+  }
+  HIPCHK(h, hipGetLastError());
+  h->stage_done = 2;
+  return 0;
+}
+
+int enq_stage1(vsv_handle* h) {
+  hipStream_t st = h->stream;
+  Counters* c = dctr(h);
+  vsv_launch_sort_stage(st, (vsv_sig*)h->s1in.p, &c->n_s1, 1, key_bits(h), (vsv_sig*)h->s1s.p, &c->n_alive1, stage_bufs(h),
+                        sort_work(h), h->cap_sigs);
+  vsv_launch_cluster(st, (vsv_sig*)h->s1s.p, &c->n_alive1, h->prm.cluster_shift, (vsv_sig*)h->c1.p, stage_bufs(h));
+  HIPCHK(h, hipGetLastError());
+  h->stage_done = 3;
+  return 0;
+}
+
+int enq_merge(vsv_handle* h) {
+  hipStream_t st = h->stream;
+  Counters* c = dctr(h);
+  vsv_launch_sort_stage(st, (vsv_sig*)h->c1.p, &c->n_alive1, 2, key_bits(h), (vsv_sig*)h->s2s.p, &c->n_alive2, stage_bufs(h),
+                        sort_work(h), h->cap_sigs);
+  vsv_launch_cluster(st, (vsv_sig*)h->s2s.p, &c->n_alive2, h->prm.cluster_shift, (vsv_sig*)h->c2.p, stage_bufs(h));
+  vsv_launch_sort_stage(st, (vsv_sig*)h->c2.p, &c->n_alive2, 3, key_bits(h), (vsv_sig*)h->merged.p, &c->n_alive3, stage_bufs(h),
+                        sort_work(h), h->cap_sigs);
+  HIPCHK(h, hipGetLastError());
+  h->stage_done = 4;
+  return 0;
+}
+
+int enq_pair(vsv_handle* h) {
+  hipStream_t st = h->stream;
+  Counters* c = dctr(h);
+  vsv_launch_pair(st, (vsv_sig*)h->merged.p, &c->n_alive3, h->prm.pair_shift, (vsv_call*)h->calls_tmp.p, (vsv_call*)h->calls.p,
+                  &c->n_calls, stage_bufs(h), (uint64_t*)h->key2.p, (uint32_t*)h->idx2.p, sort_work(h), key_bits(h), h->cap_sigs);
+  HIPCHK(h, hipGetLastError());
+  h->stage_done = 5;
+  return 0;
+}
+
+int finish(vsv_handle* h) {
+  HIPCHK(h, hipMemcpyAsync(h->pinned, h->ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->host_ctr = *h->pinned;
+  h->pending = false;
+  const uint32_t e = h->host_ctr.err;
+  h->last_count = h->host_ctr.n_pool;
+  if (e & ERRB_CAPACITY) {
+    char b[160];
+    snprintf(b, sizeof b, "signature capacity %lld exceeded (cigar signatures emitted: %u, split candidates: %u)",
+             (long long)h->cap_sigs, h->host_ctr.n_pool, h->host_ctr.n_cand);
+    int64_t need = (int64_t)h->host_ctr.n_pool + h->host_ctr.n_cand;
+    h->last_count = need;
+    return fail(h, VSV_E_CAPACITY, b);
+  }
+  if (e & ERRB_EMPTY_CIGAR) return fail(h, VSV_E_EMPTY_CIGAR, "record with no CIGAR ops / cigar_off not increasing");
+  if (e & ERRB_RANGE) return fail(h, VSV_E_INVALID, "a batch of 64 records spans >= 2^31 CIGAR ops");
+  if (e & ERRB_REFEND) return fail(h, VSV_E_REFEND, "N/=/X op in an eligible record on the contig path (offset_ref != reference_end)");
+  if (e & ERRB_ZERODIV) return fail(h, VSV_E_ZERODIV, "CLR gate on a record without M ops");
+  if (e & ERRB_UNSORTED) return fail(h, VSV_E_UNSORTED, "split pair with pos1 > pos2");
+  if (e & ERRB_READLEN) return fail(h, VSV_E_READLEN, "split pair with unequal read lengths");
+  return 0;
+}
+
+int start(vsv_handle* h, const vsv_records* recs, const vsv_params* p) {
+  if (!h || !p) return VSV_E_INVALID;
+  if (p->dtype < 0 || p->dtype > VSV_DTYPE_SVIM) return fail(h, VSV_E_INVALID, "bad dtype");
+  HIPCHK(h, hipSetDevice(h->device));
+  h->prm = *p;
+  return bind_records(h, recs);
+}
+
+}  // namespace
+
+// ============================================ C ABI ==================================================
+extern "C" {
+
+int vsv_abi_version(void) { return VSV_ABI_VERSION; }
+
+const char* vsv_status_string(int s) {
+  switch (s) {
+    case VSV_OK: return "VSV_OK";
+    case VSV_E_INVALID: return "VSV_E_INVALID";
+    case VSV_E_HIP: return "VSV_E_HIP";
+    case VSV_E_CAPACITY: return "VSV_E_CAPACITY";
+    case VSV_E_EMPTY_CIGAR: return "VSV_E_EMPTY_CIGAR";
+    case VSV_E_REFEND: return "VSV_E_REFEND";
+    case VSV_E_READLEN: return "VSV_E_READLEN";
+    case VSV_E_UNSORTED: return "VSV_E_UNSORTED";
+    case VSV_E_ZERODIV: return "VSV_E_ZERODIV";
+    case VSV_E_NO_DEVICE: return "VSV_E_NO_DEVICE";
+  }
+  return "VSV_E_?";
+}
+
+int vsv_default_params(int dtype, vsv_params* p) {
+  if (!p || dtype < 0 || dtype > VSV_DTYPE_SVIM) return VSV_E_INVALID;
+  memset(p, 0, sizeof *p);
+  p->dtype = dtype;
+  p->min_svlen = dtype == VSV_DTYPE_SVIM ? 40 : 30;
+  p->min_cigar_mapq = dtype == VSV_DTYPE_SVIM ? 20 : 50;
+  p->min_split_mapq = dtype == VSV_DTYPE_READS ? 0 : 50;
+  p->max_split_svlen = 50000;
+  p->cluster_shift = 100;
+  p->pair_shift = 200;
+  p->pair_window = 1000;
+  p->enable_split = dtype == VSV_DTYPE_SVIM ? 0 : 1;
+  return 0;
+}
+
+int vsv_create(int device_id, void* hip_stream, vsv_handle** out) {
+  if (!out) return VSV_E_INVALID;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return VSV_E_NO_DEVICE;
+  vsv_handle* h = new vsv_handle();
+  h->device = device_id;
+  h->stream = (hipStream_t)hip_stream;
+  if (hipSetDevice(device_id) != hipSuccess) { delete h; return VSV_E_NO_DEVICE; }
+  if (hipMalloc(&h->ctr.p, 256) != hipSuccess) { delete h; return VSV_E_HIP; }
+  h->ctr.bytes = 256;
+  if (hipHostMalloc((void**)&h->pinned, sizeof(Counters)) != hipSuccess) { hipFree(h->ctr.p); delete h; return VSV_E_HIP; }
+  hipEventCreate(&h->ev0);
+  hipEventCreate(&h->ev1);
+  memset(&h->host_ctr, 0, sizeof h->host_ctr);
+  *out = h;
+  return 0;
+}
+
+void vsv_destroy(vsv_handle* h) {
+  if (!h) return;
+  hipSetDevice(h->device);
+  hipStreamSynchronize(h->stream);
+  DevBuf* bufs[] = {&h->r_pos, &h->r_tid, &h->r_qid, &h->r_off, &h->r_mapq, &h->r_flag, &h->r_cigar, &h->part_rb, &h->part_count,
+                    &h->part_off, &h->scan_tmp, &h->pool, &h->pool_key, &h->raw0, &h->s1in, &h->s1s, &h->c1, &h->s2s, &h->c2,
+                    &h->merged, &h->calls_tmp, &h->calls, &h->reads, &h->tab, &h->blk_cnt, &h->blk_off, &h->ckey, &h->crec,
+                    &h->okey, &h->oval, &h->key, &h->idx, &h->cl, &h->key2, &h->idx2, &h->key_alt, &h->val_alt, &h->hist, &h->ctr};
+  for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
+  if (h->pinned) hipHostFree(h->pinned);
+  if (h->ev0) hipEventDestroy(h->ev0);
+  if (h->ev1) hipEventDestroy(h->ev1);
+  delete h;
+}
+
+const char* vsv_last_error(vsv_handle* h) { return h ? h->err.c_str() : "null handle"; }
+int64_t vsv_last_count(vsv_handle* h) { return h ? h->last_count : 0; }
+
+int vsv_reserve(vsv_handle* h, int64_t max_records, int64_t max_ops, int64_t max_sigs) {
+  if (!h) return VSV_E_INVALID;
+  if (hipSetDevice(h->device) != hipSuccess) return VSV_E_HIP;
+  if (max_sigs > 0x7FFFFF00ll) return fail(h, VSV_E_INVALID, "max_sigs too large");
+  if (max_sigs != h->cap_sigs && max_sigs > 0 && max_sigs < h->cap_sigs) {
+    // shrinking the row capacity only lowers the logical limit (used by capacity tests)
+    h->cap_sigs = max_sigs;
+    return 0;
+  }
+  return reserve(h, max_records, max_ops, max_sigs);
+}
+
+int vsv_cigar_scan(vsv_handle* h, const vsv_records* recs, const vsv_params* p) {
+  int st = start(h, recs, p);
+  if (st) return st;
+  if ((st = enq_scan(h))) return st;
+  return finish(h);
+}
+
+int vsv_split_pairs(vsv_handle* h, const vsv_records* recs, const vsv_params* p) {
+  if (!h || h->stage_done < 1) return fail(h, VSV_E_INVALID, "vsv_cigar_scan must run first");
+  (void)recs;
+  if (p) { h->prm.enable_split = p->enable_split; h->prm.min_split_mapq = p->min_split_mapq; h->prm.max_split_svlen = p->max_split_svlen; }
+  int st = enq_split(h);
+  if (st) return st;
+  return finish(h);
+}
+
+int vsv_sort_cluster(vsv_handle* h, const vsv_params* p) {
+  if (!h || h->stage_done < 2) return fail(h, VSV_E_INVALID, "vsv_split_pairs must run first");
+  if (!is_contig(h->prm.dtype)) return fail(h, VSV_E_INVALID, "clustering exists only on the contig path");
+  if (p) h->prm.cluster_shift = p->cluster_shift;
+  int st = enq_stage1(h);
+  if (st) return st;
+  return finish(h);
+}
+
+int vsv_merge_sources(vsv_handle* h, const vsv_params* p) {
+  if (!h || h->stage_done < 3) return fail(h, VSV_E_INVALID, "vsv_sort_cluster must run first");
+  if (p) h->prm.cluster_shift = p->cluster_shift;
+  int st = enq_merge(h);
+  if (st) return st;
+  return finish(h);
+}
+
+int vsv_pair_haplotypes(vsv_handle* h, const vsv_params* p) {
+  if (!h || h->stage_done < 4) return fail(h, VSV_E_INVALID, "vsv_merge_sources must run first");
+  if (p) h->prm.pair_shift = p->pair_shift;
+  int st = enq_pair(h);
+  if (st) return st;
+  return finish(h);
+}
+
+int vsv_run_chromosome_async(vsv_handle* h, const vsv_records* recs, const vsv_params* p) {
+  int st = start(h, recs, p);
+  if (st) return st;
+  if ((st = enq_scan(h))) return st;
+  if (p->dtype != VSV_DTYPE_SVIM) { if ((st = enq_split(h))) return st; }
+  if (is_contig(p->dtype)) {
+    if ((st = enq_stage1(h))) return st;
+    if ((st = enq_merge(h))) return st;
+    if ((st = enq_pair(h))) return st;
+  }
+  h->pending = true;
+  return 0;
+}
+
+int vsv_finish(vsv_handle* h) {
+  if (!h) return VSV_E_INVALID;
+  return finish(h);
+}
+
+int vsv_run_chromosome(vsv_handle* h, const vsv_records* recs, const vsv_params* p) {
+  int st = vsv_run_chromosome_async(h, recs, p);
+  if (st) return st;
+  return finish(h);
+}
+
+int vsv_last_scan_ms(vsv_handle* h, float* ms) {
+  if (!h || !ms || !h->have_scan_ev) return VSV_E_INVALID;
+  HIPCHK(h, hipEventSynchronize(h->ev1));
+  HIPCHK(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
+  return 0;
+}
+
+static int table_src(vsv_handle* h, int table, const void** src, int64_t* n_rows, size_t* row, bool* filter) {
+  const Counters& c = h->host_ctr;
+  *filter = true;
+  *row = sizeof(vsv_sig);
+  switch (table) {
+    case VSV_T_RAW: if (h->stage_done < 1) return VSV_E_INVALID; *src = h->raw0.p; *n_rows = c.n_raw; return 0;
+    case VSV_T_CIGAR: if (h->stage_done < 1) return VSV_E_INVALID; *src = h->s1in.p; *n_rows = c.n_raw; return 0;
+    case VSV_T_SPLIT: if (h->stage_done < 2) return VSV_E_INVALID; *src = (const vsv_sig*)h->s1in.p + c.n_raw; *n_rows = c.n_s1 - c.n_raw; return 0;
+    case VSV_T_CLUSTER1: if (h->stage_done < 3) return VSV_E_INVALID; *src = h->c1.p; *n_rows = c.n_alive1; return 0;
+    case VSV_T_MERGED: if (h->stage_done < 4) return VSV_E_INVALID; *src = h->merged.p; *n_rows = c.n_alive3; *filter = false; return 0;
+    case VSV_T_CALLS: if (h->stage_done < 5) return VSV_E_INVALID; *src = h->calls.p; *n_rows = c.n_calls; *row = sizeof(vsv_call); *filter = false; return 0;
+    case VSV_T_READS: if (h->stage_done < 2 || h->prm.dtype != VSV_DTYPE_READS) return VSV_E_INVALID; *src = h->reads.p; *n_rows = c.n_reads; *filter = false; return 0;
+  }
+  return VSV_E_INVALID;
+}
+
+static int table_read(vsv_handle* h, int table, std::vector<char>& host, int64_t* n_out, size_t* row_out) {
+  if (!h) return VSV_E_INVALID;
+  if (h->pending) { int st = finish(h); if (st) return st; }
+  const void* src; int64_t n; size_t row; bool filter;
+  int st = table_src(h, table, &src, &n, &row, &filter);
+  if (st) return fail(h, st, "table not available at this stage");
+  host.resize((size_t)n * row + 1);
+  if (n) HIPCHK(h, hipMemcpy(host.data(), src, (size_t)n * row, hipMemcpyDeviceToHost));
+  int64_t m = n;
+  if (filter) {  // drop rows a stage marked dead
+    m = 0;
+    vsv_sig* s = (vsv_sig*)host.data();
+    for (int64_t i = 0; i < n; ++i) if (!(s[i].meta & VSV_M_DEAD)) s[m++] = s[i];
+  }
+  *n_out = m; *row_out = row;
+  return 0;
+}
+
+int vsv_table_count(vsv_handle* h, int table, int64_t* n_rows) {
+  if (!n_rows) return VSV_E_INVALID;
+  std::vector<char> host; size_t row;
+  return table_read(h, table, host, n_rows, &row);
+}
+
+int vsv_table_fill(vsv_handle* h, int table, void* dst, int64_t cap_rows, int dst_on_device) {
+  if (!dst && cap_rows > 0) return VSV_E_INVALID;
+  std::vector<char> host; int64_t n; size_t row;
+  int st = table_read(h, table, host, &n, &row);
+  if (st) return st;
+  if (n > cap_rows) { h->last_count = n; return fail(h, VSV_E_CAPACITY, "destination too small"); }
+  if (n == 0) return 0;
+  if (dst_on_device) HIPCHK(h, hipMemcpy(dst, host.data(), (size_t)n * row, hipMemcpyHostToDevice));
+  else memcpy(dst, host.data(), (size_t)n * row);
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,519 @@
+// sig_stages.hip — everything downstream of the CIGAR scan, on <= a few % of the input bytes:
+//   fold_kernel        cluster_ins_one_read / cluster_del_one_read   (Hifi.py:91-161)
+//   clr_gate_kernel    ins_pct / var_dist gate                        (CLR.py:53-70, 425-427)
+//   split_*            extract_sig_from_split_reads + extract_sig_from_split
+//                      (Hifi.py:307-371, 421-457; ONT.py:307-382; CLR.py:328-402; reads.py:147-237)
+//   cluster_kernel     cluster_del / cluster_ins seeded greedy        (Hifi.py:196-288)
+//   pair_kernel        pair_sig                                        (Hifi.py:548-592)
+// All paths are relative to bin/VolcanoSV-vc/Large_INDEL/extract_contig_signature_<X>.py /
+// extract_reads_signature.py in the reference.
+//
+// No stage compacts: rows that a stage drops are marked VSV_M_DEAD, get the all-ones sort key and
+// fall to the end of the next stable radix sort; `count_alive` then publishes the live row count on
+// the device. Nothing here synchronises with the host.
+#include "vsv_device.h"
+
+namespace {
+
+__device__ __forceinline__ vsv_sig dead_sig() {
+  vsv_sig s;
+  s.pos = 0; s.svlen = 0; s.q_start = 0; s.q_end = 0; s.rec = 0; s.rec2 = 0; s.meta = VSV_M_DEAD; s.tid = 0;
+  return s;
+}
+
+__device__ __forceinline__ int64_t wave_sum64(int64_t v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+// ---- intra-read fold ------------------------------------------------------------------------------
+// One thread per (record, hap) group of consecutive raw rows; left fold in op order.
+__global__ __launch_bounds__(256) void fold_kernel(vsv_sig* __restrict__ s, const Counters* ctr) {
+  const uint32_t n = ctr->n_raw;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint32_t rec = s[i].rec, hap = s[i].meta & VSV_M_HP2;
+    if (i > 0 && s[i - 1].rec == rec && (s[i - 1].meta & VSV_M_HP2) == hap) continue;  // not a group head
+    int64_t last_ins = -1, last_del = -1;
+    for (uint32_t k = i; k < n && s[k].rec == rec && (s[k].meta & VSV_M_HP2) == hap; ++k) {
+      vsv_sig s2 = s[k];
+      if (s2.meta & VSV_M_DEL) {
+        if (last_del < 0) { last_del = k; continue; }
+        vsv_sig s1 = s[last_del];
+        int64_t d = (int64_t)s2.pos - s1.pos; if (d < 0) d = -d;
+        if (s1.svlen > 150 && s2.svlen > 150 && d < 150) {            // Hifi.py:148-150
+          s1.svlen = s2.pos + s2.svlen - s1.pos;                       // Hifi.py:104
+          s1.q_end = s1.q_start + 1;
+          s[last_del] = s1;
+          s[k].meta = s2.meta | VSV_M_DEAD;
+        } else last_del = k;
+      } else {
+        if (last_ins < 0) { last_ins = k; continue; }
+        vsv_sig s1 = s[last_ins];
+        int64_t d = (int64_t)s2.pos - s1.pos; if (d < 0) d = -d;
+        const bool m = (s1.svlen > 100 && s2.svlen > 100 && d < 250) ||  // Hifi.py:115-117 (subset), 126-128
+                       (s1.svlen > 320 && s2.svlen > 320 && d < 380);    // Hifi.py:120-122
+        if (m) {
+          s1.q_end = s2.q_end;                                          // Hifi.py:94
+          s1.svlen = s1.q_end - s1.q_start;                             // Hifi.py:96
+          s[last_ins] = s1;
+          s[k].meta = s2.meta | VSV_M_DEAD;
+        } else last_ins = k;
+      }
+    }
+  }
+}
+
+// ---- CLR gate: one wave per (record, hap) group head; marks the group dead if the gate fails ---------
+__global__ __launch_bounds__(256) void clr_gate_kernel(vsv_sig* __restrict__ s, RecView rv, Counters* ctr) {
+  const uint32_t n = ctr->n_raw;
+  const int lane = threadIdx.x & 63;
+  const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+  for (uint32_t i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < n; i += nwaves) {
+    const uint32_t rec = s[i].rec, hap = s[i].meta & VSV_M_HP2;
+    if (i > 0 && s[i - 1].rec == rec && (s[i - 1].meta & VSV_M_HP2) == hap) continue;
+    const uint64_t a = rv.cigar_off[rec], b = rv.cigar_off[rec + 1];
+    int64_t ins = 0, m = 0, nm = 0;
+    for (uint64_t k = a + lane; k < b; k += 64) {
+      const uint32_t w = rv.cigar[k], op = w & 15u;
+      if (op == 0) { m += w >> 4; nm++; } else if (op == 1) ins += w >> 4;
+    }
+    ins = wave_sum64(ins); m = wave_sum64(m); nm = wave_sum64(nm);
+    bool pass;
+    if (m + ins == 0 || nm == 0) { if (lane == 0) atomicOr(&ctr->err, ERRB_ZERODIV); pass = false; }
+    else pass = (100 * ins <= 13 * (m + ins)) || (m >= 200 * nm);       // CLR.py:61, 70, 427 in exact integers
+    if (!pass && lane == 0) {
+      for (uint32_t k = i; k < n && s[k].rec == rec && (s[k].meta & VSV_M_HP2) == hap; ++k) s[k].meta |= VSV_M_DEAD;
+    }
+  }
+}
+
+// ---- split stage ----------------------------------------------------------------------------------
+struct SplitCfg {
+  int contig;        // 1: hp/mapq eligibility, two hap passes; 0: reads path, every record, one pass
+  int min_mapq;
+  uint32_t tab_mask;
+  int qid_bits;
+  int tid_shift;     // ckey = tid << tid_shift | hap << qid_bits | qid
+};
+
+__device__ __forceinline__ bool split_elig(const RecView& rv, const SplitCfg& c, uint32_t r, uint32_t hap) {
+  if (!c.contig) return hap == 0;
+  const uint32_t fl = rv.flag[r];
+  return (fl & (hap ? VSV_F_HP2 : VSV_F_HP1)) && rv.mapq[r] >= c.min_mapq;   // Hifi.py:425-427
+}
+__device__ __forceinline__ uint32_t split_hash(const RecView& rv, const SplitCfg& c, uint32_t r, uint32_t hap) {
+  return ((rv.qid[r] * 2u + hap) ^ ((uint32_t)rv.tid[r] * 0x9E3779B1u)) & c.tab_mask;
+}
+
+__global__ __launch_bounds__(256) void split_count(RecView rv, SplitCfg c, uint32_t* __restrict__ tab) {
+  const uint64_t n2 = (uint64_t)rv.n_records * 2;
+  for (uint64_t it = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; it < n2; it += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t r = (uint32_t)(it >> 1), hap = (uint32_t)(it & 1);
+    if (split_elig(rv, c, r, hap)) atomicAdd(&tab[split_hash(rv, c, r, hap)], 1u);
+  }
+}
+
+// ordered compaction of candidate (record,hap) items, block tile = 256 threads x 8 rounds
+constexpr int SC_ROUNDS = 8;
+constexpr int SC_TILE = 256 * SC_ROUNDS;
+template <bool WRITE>
+__global__ __launch_bounds__(256) void split_cand(RecView rv, SplitCfg c, const uint32_t* __restrict__ tab,
+                                                  uint32_t* __restrict__ blk, uint64_t* __restrict__ ckey,
+                                                  uint32_t* __restrict__ crec, uint32_t cap, Counters* ctr) {
+  __shared__ uint32_t cnt[SC_ROUNDS][4];
+  const uint64_t n2 = (uint64_t)rv.n_records * 2;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint64_t base = (uint64_t)blockIdx.x * SC_TILE;
+  bool f[SC_ROUNDS];
+  uint32_t below[SC_ROUNDS];
+#pragma unroll
+  for (int k = 0; k < SC_ROUNDS; ++k) {
+    const uint64_t it = base + (uint64_t)k * 256 + threadIdx.x;
+    f[k] = false;
+    if (it < n2) {
+      const uint32_t r = (uint32_t)(it >> 1), hap = (uint32_t)(it & 1);
+      f[k] = split_elig(rv, c, r, hap) && tab[split_hash(rv, c, r, hap)] > 1u;
+    }
+    const uint64_t bal = __ballot(f[k]);
+    below[k] = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) cnt[k][wv] = (uint32_t)__popcll(bal);
+  }
+  __syncthreads();
+  if (!WRITE) {
+    if (threadIdx.x == 0) {
+      uint32_t t = 0;
+      for (int k = 0; k < SC_ROUNDS; ++k) for (int w = 0; w < 4; ++w) t += cnt[k][w];
+      blk[blockIdx.x] = t;
+    }
+    return;
+  }
+  uint32_t off = blk[blockIdx.x];  // exclusive block offset
+#pragma unroll
+  for (int k = 0; k < SC_ROUNDS; ++k) {
+    uint32_t pre = 0;
+    for (int w = 0; w < wv; ++w) pre += cnt[k][w];
+    if (f[k]) {
+      const uint64_t it = base + (uint64_t)k * 256 + threadIdx.x;
+      const uint32_t r = (uint32_t)(it >> 1), hap = (uint32_t)(it & 1);
+      const uint32_t dst = off + pre + below[k];
+      if (dst < cap) {
+        ckey[dst] = ((uint64_t)(uint32_t)rv.tid[r] << c.tid_shift) | ((uint64_t)hap << c.qid_bits) | rv.qid[r];
+        crec[dst] = r;
+      }
+    }
+    off += cnt[k][0] + cnt[k][1] + cnt[k][2] + cnt[k][3];
+  }
+}
+
+__global__ void split_set_ncand(const uint32_t* __restrict__ blk_off, const uint32_t* __restrict__ blk_cnt, int nblk,
+                                uint32_t cap, Counters* ctr) {
+  const uint32_t t = blk_off[nblk - 1] + blk_cnt[nblk - 1];
+  ctr->n_cand = t < cap ? t : cap;
+  if (t > cap) atomicOr(&ctr->err, ERRB_CAPACITY);
+}
+
+// slot j of the sorted candidate list starts a pair iff slot j+1 has the same (tid,hap,qid) key.
+// okey orders pairs like the reference: per (tid, hap pass) by first appearance of the name
+// (Counter insertion order, Hifi.py:428-432,446), then by position in the name's record list.
+__global__ __launch_bounds__(256) void split_mark_pairs(const uint64_t* __restrict__ ckey, const uint32_t* __restrict__ crec,
+                                                        SplitCfg c, int rec_bits, uint64_t* __restrict__ okey,
+                                                        uint32_t* __restrict__ oval, const Counters* ctr) {
+  const uint32_t n = ctr->n_cand;
+  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    const uint64_t k = ckey[j];
+    uint64_t ok = VSV_KEY_DEAD;
+    if (j + 1 < n && ckey[j + 1] == k) {
+      uint32_t g = j;
+      while (g > 0 && ckey[g - 1] == k) --g;
+      const uint64_t tidhap = k >> c.qid_bits;  // (tid, hap)
+      ok = (tidhap << rec_bits) | crec[g];
+    }
+    okey[j] = ok;
+    oval[j] = j;
+  }
+}
+
+struct RecSum { int64_t ref_len, read_len; uint32_t first, last; };
+__device__ __forceinline__ RecSum rec_summary(const RecView& rv, uint32_t r, bool reads, int lane) {
+  const uint64_t a = rv.cigar_off[r], b = rv.cigar_off[r + 1];
+  int64_t rl = 0, rf = 0;
+  for (uint64_t k = a + lane; k < b; k += 64) {
+    const uint32_t w = rv.cigar[k], op = w & 15u, len = w >> 4;
+    if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rf += len;           // pysam reference_end
+    if (op == 0 || op == 1 || op == 4 || op == 5 || (reads && (op == 7 || op == 8))) rl += len;  // get_readlen
+  }
+  RecSum s;
+  s.ref_len = wave_sum64(rf);
+  s.read_len = wave_sum64(rl);
+  s.first = rv.cigar[a];
+  s.last = rv.cigar[b - 1];
+  return s;
+}
+
+// one wave per pair slot (in okey order); writes one signature row (possibly dead) per slot
+__global__ __launch_bounds__(256) void split_eval(RecView rv, const uint64_t* __restrict__ okey, const uint32_t* __restrict__ oval,
+                                                  const uint64_t* __restrict__ ckey, const uint32_t* __restrict__ crec,
+                                                  SplitCfg c, int dtype, int max_svlen, vsv_sig* __restrict__ s1in,
+                                                  uint32_t cap, Counters* ctr) {
+  const uint32_t n = ctr->n_cand, n_raw = ctr->n_raw;
+  const int lane = threadIdx.x & 63;
+  const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+  const bool reads = dtype == VSV_DTYPE_READS;
+  for (uint32_t q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); q < n; q += nwaves) {
+    if (n_raw + q >= cap) { if (lane == 0) atomicOr(&ctr->err, ERRB_CAPACITY); continue; }
+    vsv_sig out = dead_sig();
+    if (okey[q] != VSV_KEY_DEAD) {
+      const uint32_t j = oval[q];
+      const uint32_t i1 = crec[j], i2 = crec[j + 1];
+      const uint32_t hap = (uint32_t)(ckey[j] >> c.qid_bits) & 1u;
+      if (rv.pos[i1] > rv.pos[i2]) { if (lane == 0) atomicOr(&ctr->err, ERRB_UNSORTED); }   // Hifi.py:315
+      else {
+        const int minq = c.min_mapq;
+        const uint32_t f1 = rv.flag[i1], f2 = rv.flag[i2];
+        const uint32_t last1 = rv.cigar[rv.cigar_off[i1 + 1] - 1], first2 = rv.cigar[rv.cigar_off[i2]];
+        const uint32_t lop = last1 & 15u, fop = first2 & 15u;
+        if (((f1 ^ f2) & VSV_F_REVERSE) == 0 && rv.mapq[i1] >= minq && rv.mapq[i2] >= minq &&
+            (lop == 4 || lop == 5) && (fop == 4 || fop == 5)) {                                  // Hifi.py:323-324
+          const RecSum a = rec_summary(rv, i1, reads, lane), b = rec_summary(rv, i2, reads, lane);
+          if (a.read_len != b.read_len) { if (lane == 0) atomicOr(&ctr->err, ERRB_READLEN); }  // Hifi.py:331
+          else {
+            const int64_t Ref1e = (int64_t)rv.pos[i1] + a.ref_len, Ref2s = rv.pos[i2];
+            const int64_t Read1e = a.read_len - (int64_t)(last1 >> 4), Read2s = first2 >> 4;
+            const int64_t Diffdis = (Ref2s - Ref1e) - (Read2s - Read1e);
+            const int64_t absd = Diffdis < 0 ? -Diffdis : Diffdis;
+            if (absd <= max_svlen) {                                                             // Hifi.py:354
+              vsv_sig s = dead_sig();
+              s.rec = i1; s.rec2 = i2; s.tid = rv.tid[i1];
+              uint32_t meta = VSV_M_SPLIT | (hap ? VSV_M_HP2 : 0u);
+              bool emit = false;
+              if (dtype == VSV_DTYPE_HIFI) {
+                if (Diffdis >= 30) {
+                  const int64_t Diffolp = Read1e - Read2s, ao = Diffolp < 0 ? -Diffolp : Diffolp;
+                  if (ao <= 3000) {                                                             // Hifi.py:357
+                    const int64_t h = Diffolp / 2;                                              // int(Diffolp/2)
+                    s.pos = (int32_t)(Ref1e - h); s.svlen = (int32_t)Diffdis;
+                    s.q_start = (int32_t)(Read1e - h); s.q_end = s.q_start + 1; meta |= VSV_M_DEL; emit = true;
+                  }
+                } else if (Diffdis <= -30) {
+                  const int64_t Diffolp = Ref1e - Ref2s, ao = Diffolp < 0 ? -Diffolp : Diffolp;
+                  if (Diffolp < 3000) {                                                         // Hifi.py:362
+                    int64_t sv = Read2s - Read1e + Diffolp; if (sv < 0) sv = -sv;
+                    s.pos = (int32_t)(ao > 400 ? (Ref1e + Ref2s) / 2 : Ref2s);
+                    s.svlen = (int32_t)sv; s.q_start = (int32_t)(Read1e - Diffolp); s.q_end = (int32_t)Read2s; emit = true;
+                  }
+                }
+              } else if (dtype == VSV_DTYPE_ONT || dtype == VSV_DTYPE_CLR) {
+                // fp64 products exactly as CPython evaluates them (ONT.py:348-373, CLR.py:369-377); this
+                // file is compiled with -ffp-contract=off.
+                const double r_ = dtype == VSV_DTYPE_ONT ? 0.5 : 0.3;
+                const double lo_f = dtype == VSV_DTYPE_ONT ? 0.8 : 0.3;
+                if (Diffdis >= 30) {
+                  const int64_t Diffolp = Read1e - Read2s;
+                  const double dr = (double)Diffdis * r_;
+                  if (-dr <= (double)Diffolp && (double)Diffolp <= dr) {
+                    s.pos = (int32_t)Ref1e; s.svlen = (int32_t)Diffdis; s.q_start = (int32_t)Read1e; s.q_end = (int32_t)Read2s;
+                    meta |= VSV_M_DEL; emit = true;
+                  }
+                } else {
+                  const int64_t Diffolp = Ref1e - Ref2s, ao = Diffolp < 0 ? -Diffolp : Diffolp;
+                  const double lo = (double)Diffdis * lo_f, hi = (double)absd * r_;
+                  if (lo <= (double)Diffolp && (double)Diffolp <= hi && Diffdis <= -30) {
+                    int64_t sv = Read2s - Read1e + Diffolp; if (sv < 0) sv = -sv;
+                    s.pos = (int32_t)(ao > 400 ? (Ref1e + Ref2s) / 2 : Ref2s);
+                    s.svlen = (int32_t)sv; s.q_start = (int32_t)(Read1e - Diffolp); s.q_end = (int32_t)Read2s; emit = true;
+                  }
+                }
+              } else {  // READS: reads.py:179-196
+                const int64_t Diffolp = Ref1e - Ref2s;
+                if (Diffolp < 30 && Diffdis >= 30) {
+                  s.pos = (int32_t)Ref1e; s.svlen = (int32_t)Diffdis; s.q_start = (int32_t)Read1e; s.q_end = (int32_t)Read2s;
+                  meta |= VSV_M_DEL; emit = true;
+                } else if (Diffolp < 30 && Diffdis <= -30) {
+                  s.pos = (int32_t)((Ref1e + Ref2s) / 2); s.svlen = (int32_t)absd;
+                  s.q_start = (int32_t)Read1e; s.q_end = (int32_t)Read2s; emit = true;
+                }
+              }
+              if (emit) { s.meta = meta; out = s; }
+            }
+          }
+        }
+      }
+    }
+    if (lane == 0) s1in[n_raw + q] = out;
+  }
+}
+
+__global__ void set_n_s1(Counters* ctr, uint32_t cap) {
+  uint32_t t = ctr->n_raw + ctr->n_cand;
+  ctr->n_s1 = t < cap ? t : cap;
+}
+
+// ---- keys / gather / alive count --------------------------------------------------------------------
+__global__ __launch_bounds__(256) void build_keys(const vsv_sig* __restrict__ s, const uint32_t* __restrict__ d_n, int stage,
+                                                  uint64_t* __restrict__ key, uint32_t* __restrict__ idx) {
+  const uint32_t n = *d_n;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const vsv_sig v = s[i];
+    uint64_t k;
+    if (stage == 5) {  // READS final order (reads.py:281-286): (tid,pos) then source, DEL before INS, list order
+      k = (v.meta & VSV_M_DEAD) ? VSV_KEY_DEAD
+          : ((uint64_t)(uint32_t)v.tid << 34) | (vsv_upos(v.pos) << 2) | ((v.meta & VSV_M_SPLIT) ? 2u : 0u) | ((v.meta & VSV_M_DEL) ? 0u : 1u);
+    } else k = vsv_key_stage(v, stage);
+    key[i] = k;
+    idx[i] = i;
+  }
+}
+__global__ __launch_bounds__(256) void build_call_keys(const vsv_call* __restrict__ c, const uint32_t* __restrict__ d_n,
+                                                       uint64_t* __restrict__ key, uint32_t* __restrict__ idx) {
+  const uint32_t n = *d_n;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    key[i] = vsv_key_stage(c[i].sig, 4);
+    idx[i] = i;
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows(const T* __restrict__ in, const uint32_t* __restrict__ idx,
+                                                   const uint32_t* __restrict__ d_n, T* __restrict__ out) {
+  const uint32_t n = *d_n;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = in[idx[i]];
+}
+// keys sorted ascending with dead (all ones) last: alive count = index of the first dead key
+__global__ __launch_bounds__(256) void count_alive(const uint64_t* __restrict__ key, const uint32_t* __restrict__ d_n,
+                                                   uint32_t* __restrict__ d_alive) {
+  const uint32_t n = *d_n;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    if (key[i] != VSV_KEY_DEAD && (i + 1 == n || key[i + 1] == VSV_KEY_DEAD)) *d_alive = i + 1;
+  }
+}
+
+// ---- seeded greedy clustering ------------------------------------------------------------------------
+// A run = maximal stretch of one list whose consecutive positions differ by <= max_shift; no match can
+// cross a run boundary (every match needs shift <= max_shift), so runs are independent and the
+// reference's full scans (Hifi.py:207-226) reduce to a scan inside the run. One lane owns one run and
+// performs the sequential greedy exactly: seed = first unassigned, members = unassigned rows matching
+// the SEED, representative = first longest member (Hifi.py:236-247). Output row i = representative
+// if i is a seed, dead otherwise, so seed order is preserved.
+__global__ __launch_bounds__(256) void cluster_kernel(const vsv_sig* __restrict__ s, const uint64_t* __restrict__ key,
+                                                      const uint32_t* __restrict__ d_n, int max_shift,
+                                                      int32_t* __restrict__ cl, vsv_sig* __restrict__ out) {
+  const uint32_t n = *d_n;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint64_t lk = key[i] >> 32;
+    if (i > 0 && (key[i - 1] >> 32) == lk && (int64_t)s[i].pos - s[i - 1].pos <= max_shift) continue;  // not a run head
+    uint32_t e = i + 1;
+    while (e < n && (key[e] >> 32) == lk && (int64_t)s[e].pos - s[e - 1].pos <= max_shift) ++e;
+    for (uint32_t k = i; k < e; ++k) cl[k] = -1;
+    for (uint32_t a = i; a < e; ++a) {
+      if (cl[a] != -1) { out[a] = dead_sig(); continue; }
+      cl[a] = (int32_t)a;
+      const vsv_sig s1 = s[a];
+      uint32_t best = a;
+      int32_t best_len = s1.svlen;
+      for (uint32_t b = a + 1; b < e; ++b) {
+        const vsv_sig s2 = s[b];
+        if ((int64_t)s2.pos - s1.pos > max_shift) break;
+        if (cl[b] != -1) continue;
+        if (vsv_match(s1, s2, max_shift)) {
+          cl[b] = (int32_t)a;
+          if (s2.svlen > best_len) { best = b; best_len = s2.svlen; }
+        }
+      }
+      out[a] = s[best];
+    }
+  }
+}
+
+// ---- haplotype pairing --------------------------------------------------------------------------------
+// merged table m sorted by (tid, hap, pos), keys = stage-3 keys. One lane owns a stretch of hp1 rows whose
+// consecutive positions differ by <= 2*pair_shift (candidate windows of different stretches are disjoint,
+// so stretches are independent); inside it the greedy of Hifi.py:552-569 runs in hp1 order: first unpaired
+// hp2 row of the same type within pair_shift that matches. The reference's scan from j=0 with a break
+// at dist > pair_window visits the same candidates in the same order.
+__device__ __forceinline__ uint32_t lower_bound_key(const uint64_t* __restrict__ key, uint32_t n, uint64_t target) {
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (key[mid] >= target) hi = mid; else lo = mid + 1; }
+  return lo;
+}
+__global__ __launch_bounds__(256) void pair_kernel(const vsv_sig* __restrict__ m, const uint64_t* __restrict__ key,
+                                                   const uint32_t* __restrict__ d_n, int pair_shift,
+                                                   int32_t* __restrict__ st2, vsv_call* __restrict__ out) {
+  const uint32_t n = *d_n;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const vsv_sig me = m[i];
+    if (me.meta & VSV_M_HP2) continue;                                  // stretches are led by hp1 rows
+    const uint64_t tk = key[i] >> 35;
+    if (i > 0 && (key[i - 1] >> 34) == (key[i] >> 34) && (int64_t)me.pos - m[i - 1].pos <= 2 * (int64_t)pair_shift) continue;
+    const uint32_t b0 = lower_bound_key(key, n, (tk << 35) | (1ull << 34));
+    const uint32_t b1 = lower_bound_key(key, n, (tk + 1) << 35);
+    uint32_t jlo = b0;
+    for (uint32_t a = i; a < n; ++a) {
+      const vsv_sig s1 = m[a];
+      if ((key[a] >> 34) != (key[i] >> 34)) break;
+      if (a > i && (int64_t)s1.pos - m[a - 1].pos > 2 * (int64_t)pair_shift) break;
+      while (jlo < b1 && (int64_t)s1.pos - m[jlo].pos > pair_shift) ++jlo;
+      int32_t mate = -1;
+      for (uint32_t j = jlo; j < b1; ++j) {
+        const vsv_sig s2 = m[j];
+        if ((int64_t)s2.pos - s1.pos > pair_shift) break;
+        if (((s1.meta ^ s2.meta) & VSV_M_DEL) == 0 && st2[j] == -1 && vsv_match(s1, s2, pair_shift)) {
+          mate = (int32_t)j; st2[j] = (int32_t)a; break;                 // Hifi.py:560-569
+        }
+      }
+      vsv_call c;
+      c.a = (int32_t)a; c.pad = 0;
+      if (mate < 0) { c.sig = s1; c.b = -1; c.gt = 1; }                  // Hifi.py:575-576
+      else { const vsv_sig s2 = m[mate]; c.sig = (s1.svlen > s2.svlen) ? s1 : s2; c.b = mate; c.gt = 2; }  // Hifi.py:583-586
+      out[a] = c;
+    }
+  }
+}
+// hp2 rows: unpaired -> 0/1 call (Hifi.py:588-592), paired -> dead slot
+__global__ __launch_bounds__(256) void pair_finish(const vsv_sig* __restrict__ m, const uint32_t* __restrict__ d_n,
+                                                   const int32_t* __restrict__ st2, vsv_call* __restrict__ out) {
+  const uint32_t n = *d_n;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const vsv_sig me = m[i];
+    if (!(me.meta & VSV_M_HP2)) continue;
+    vsv_call c;
+    c.pad = 0; c.a = -1; c.b = (int32_t)i; c.gt = 1;
+    c.sig = (st2[i] == -1) ? me : dead_sig();
+    out[i] = c;
+  }
+}
+__global__ void fill_i32(int32_t* p, int32_t v, const uint32_t* d_n) {
+  const uint32_t n = *d_n;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v;
+}
+template <typename T>
+__global__ void copy_rows(const T* __restrict__ in, const uint32_t* __restrict__ d_n, T* __restrict__ out) {
+  const uint32_t n = *d_n;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = in[i];
+}
+
+constexpr int EW_GRID = 512;
+
+}  // namespace
+
+// ======================================= host-side launchers ==========================================
+void vsv_launch_fold(hipStream_t st, vsv_sig* raw, vsv_sig* raw_copy, const RecView& rv, int dtype, Counters* ctr) {
+  // the reference applies the CLR gate before extraction (CLR.py:425-427), so gated rows are not part of T_RAW
+  if (dtype == VSV_DTYPE_CLR) clr_gate_kernel<<<EW_GRID, 256, 0, st>>>(raw, rv, ctr);
+  copy_rows<vsv_sig><<<EW_GRID, 256, 0, st>>>(raw, &ctr->n_raw, raw_copy);
+  if (dtype == VSV_DTYPE_HIFI || dtype == VSV_DTYPE_ONT || dtype == VSV_DTYPE_CLR) fold_kernel<<<EW_GRID, 256, 0, st>>>(raw, ctr);
+}
+
+static int bits_for(uint64_t n) { int b = 1; while ((1ull << b) < n && b < 63) ++b; return b; }
+
+void vsv_launch_split(hipStream_t st, const RecView& rv, const vsv_params& p, int n_tids, uint32_t* tab, uint32_t tab_size,
+                      uint32_t* blk_cnt, uint32_t* blk_off, uint32_t* scan_tmp, uint64_t* ckey, uint32_t* crec,
+                      uint64_t* okey, uint32_t* oval, const SortWork& sw, vsv_sig* s1in, uint32_t cap, Counters* ctr) {
+  SplitCfg c;
+  c.contig = p.dtype != VSV_DTYPE_READS;
+  c.min_mapq = p.min_split_mapq;
+  c.tab_mask = tab_size - 1;
+  c.qid_bits = bits_for((uint64_t)(rv.n_qids > 0 ? rv.n_qids : rv.n_records) + 1);
+  c.tid_shift = c.qid_bits + 1;
+  const int tid_bits = bits_for((uint64_t)(n_tids > 0 ? n_tids : 65536) + 1);
+  const int rec_bits = bits_for((uint64_t)rv.n_records + 1);
+  if (rv.n_records > 0) {
+    hipMemsetAsync(tab, 0, (size_t)tab_size * sizeof(uint32_t), st);
+    split_count<<<1024, 256, 0, st>>>(rv, c, tab);
+    const int nblk = (int)(((uint64_t)rv.n_records * 2 + SC_TILE - 1) / SC_TILE);
+    split_cand<false><<<nblk, 256, 0, st>>>(rv, c, tab, blk_cnt, ckey, crec, cap, ctr);
+    vsv_scan_u32_exclusive(st, blk_cnt, nblk, blk_off, scan_tmp);
+    split_cand<true><<<nblk, 256, 0, st>>>(rv, c, tab, blk_off, ckey, crec, cap, ctr);
+    split_set_ncand<<<1, 1, 0, st>>>(blk_off, blk_cnt, nblk, cap, ctr);
+    vsv_radix_sort_pairs(st, ckey, crec, &ctr->n_cand, cap, c.tid_shift + tid_bits, sw);
+    split_mark_pairs<<<EW_GRID, 256, 0, st>>>(ckey, crec, c, rec_bits, okey, oval, ctr);
+    vsv_radix_sort_pairs(st, okey, oval, &ctr->n_cand, cap, rec_bits + 1 + tid_bits + 1, sw);
+    split_eval<<<2048, 256, 0, st>>>(rv, okey, oval, ckey, crec, c, p.dtype, p.max_split_svlen, s1in, cap, ctr);
+  }
+  set_n_s1<<<1, 1, 0, st>>>(ctr, cap);
+}
+
+// sort rows `in[0,n)` by the stage key into `sorted`, publish the alive count
+void vsv_launch_sort_stage(hipStream_t st, const vsv_sig* in, const uint32_t* d_n, int stage, int nbits, vsv_sig* sorted,
+                           uint32_t* d_alive, const StageBufs& b, const SortWork& sw, int64_t cap) {
+  build_keys<<<EW_GRID, 256, 0, st>>>(in, d_n, stage, b.key, b.idx);
+  vsv_radix_sort_pairs(st, b.key, b.idx, d_n, cap, nbits, sw);
+  gather_rows<vsv_sig><<<EW_GRID, 256, 0, st>>>(in, b.idx, d_n, sorted);
+  count_alive<<<EW_GRID, 256, 0, st>>>(b.key, d_n, d_alive);
+}
+
+void vsv_launch_cluster(hipStream_t st, const vsv_sig* sorted, const uint32_t* d_alive, int max_shift, vsv_sig* out,
+                        const StageBufs& b) {
+  cluster_kernel<<<EW_GRID, 256, 0, st>>>(sorted, b.key, d_alive, max_shift, b.cl, out);
+}
+
+void vsv_launch_pair(hipStream_t st, const vsv_sig* merged, const uint32_t* d_alive3, int pair_shift, vsv_call* calls_tmp,
+                     vsv_call* calls, uint32_t* d_ncalls, const StageBufs& b, uint64_t* key2, uint32_t* idx2,
+                     const SortWork& sw, int nbits, int64_t cap) {
+  fill_i32<<<EW_GRID, 256, 0, st>>>(b.cl, -1, d_alive3);
+  pair_kernel<<<EW_GRID, 256, 0, st>>>(merged, b.key, d_alive3, pair_shift, b.cl, calls_tmp);
+  pair_finish<<<EW_GRID, 256, 0, st>>>(merged, d_alive3, b.cl, calls_tmp);
+  build_call_keys<<<EW_GRID, 256, 0, st>>>(calls_tmp, d_alive3, key2, idx2);
+  vsv_radix_sort_pairs(st, key2, idx2, d_alive3, cap, nbits, sw);
+  gather_rows<vsv_call><<<EW_GRID, 256, 0, st>>>(calls_tmp, idx2, d_alive3, calls);
+  count_alive<<<EW_GRID, 256, 0, st>>>(key2, d_alive3, d_ncalls);
+}

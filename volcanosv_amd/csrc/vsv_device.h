@@ -1,0 +1,117 @@
+// vsv_device.h — shared device-side definitions for the gfx950 kernels (wave64, CDNA4 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/volcanosv.h"
+
+#define VSV_WAVE 64
+
+// device-side error bits (OR-ed into Counters::err by kernels)
+enum : uint32_t {
+  ERRB_EMPTY_CIGAR = 1u << 0,
+  ERRB_REFEND = 1u << 1,
+  ERRB_READLEN = 1u << 2,
+  ERRB_UNSORTED = 1u << 3,
+  ERRB_ZERODIV = 1u << 4,
+  ERRB_CAPACITY = 1u << 5,
+  ERRB_RANGE = 1u << 6,  // a 64-record batch spans >= 2^31 CIGAR ops
+};
+
+// One cache line of device counters, zeroed at the start of every run.
+struct Counters {
+  uint32_t n_pool;     // cigar emit cursor (keeps counting past capacity)
+  uint32_t n_raw;      // min(n_pool, cap)
+  uint32_t n_cand;     // split candidates
+  uint32_t n_pairs;    // split pair slots
+  uint32_t n_s1;       // rows entering stage 1 (n_raw + n_pairs)
+  uint32_t n_alive1;   // alive rows after stage-1 sort
+  uint32_t n_alive2;
+  uint32_t n_alive3;   // == rows of T_MERGED
+  uint32_t n_calls;
+  uint32_t n_reads;
+  uint32_t err;
+  uint32_t pad[5];
+};
+
+struct RecView {
+  int64_t n_records;
+  int64_t n_ops;
+  const int32_t* pos;
+  const int32_t* tid;
+  const uint32_t* qid;
+  const uint64_t* cigar_off;
+  const uint8_t* mapq;
+  const uint8_t* flag;
+  const uint32_t* cigar;
+  int32_t n_qids;
+};
+
+// ---- sort keys: [tid | hap | type | source | pos], list id in the high bits ------------------------
+#define VSV_KEY_DEAD 0xFFFFFFFFFFFFFFFFull
+__host__ __device__ inline uint64_t vsv_upos(int32_t pos) { return (uint32_t)(pos ^ 0x80000000); }
+__host__ __device__ inline uint64_t vsv_key_stage(const vsv_sig& s, int stage) {
+  if (s.meta & VSV_M_DEAD) return VSV_KEY_DEAD;
+  uint64_t hap = (s.meta & VSV_M_HP2) ? 1 : 0, del = (s.meta & VSV_M_DEL) ? 1 : 0, sp = (s.meta & VSV_M_SPLIT) ? 1 : 0;
+  uint64_t k = ((uint64_t)(uint32_t)s.tid << 35) | vsv_upos(s.pos);
+  if (stage == 1) return k | (hap << 34) | (del << 33) | (sp << 32);   // list = (tid,hap,type,src)
+  if (stage == 2) return k | (hap << 34) | (del << 33);                // list = (tid,hap,type)
+  if (stage == 3) return k | (hap << 34);                              // list = (tid,hap)
+  return k;                                                            // (tid,pos)
+}
+
+// exact integer form of the reference's ratio predicates (SURVEY.md §7 hard part 3):
+// shift<=max_shift, min(l)/max(l)>=0.5, DEL: (min(e)-max(s))/min(l)>=0.5  (H:200-226, 515-546)
+__host__ __device__ inline bool vsv_match(const vsv_sig& a, const vsv_sig& b, int max_shift) {
+  int64_t shift = (int64_t)a.pos - b.pos;
+  if (shift < 0) shift = -shift;
+  if (shift > max_shift) return false;
+  int64_t l1 = a.svlen, l2 = b.svlen, mn = l1 < l2 ? l1 : l2, mx = l1 < l2 ? l2 : l1;
+  if (2 * mn < mx) return false;
+  if (a.meta & VSV_M_DEL) {
+    int64_t s1 = a.pos, e1 = s1 + l1, s2 = b.pos, e2 = s2 + l2;
+    int64_t ov = (e1 < e2 ? e1 : e2) - (s1 > s2 ? s1 : s2);
+    if (2 * ov < mn) return false;
+  }
+  return true;
+}
+
+// ---- launch wrappers implemented in the .hip files ------------------------------------------------
+struct SortWork {       // scratch for vsv_radix_sort_pairs
+  uint64_t* key_alt;
+  uint32_t* val_alt;
+  uint32_t* hist;       // [256 * max_tiles]
+  int64_t max_items;
+};
+struct StageBufs {
+  uint64_t* key;        // sort keys of the current stage (kept sorted for cluster / pair kernels)
+  uint32_t* idx;
+  int32_t* cl;          // cluster ids / pairing state
+};
+
+// radix_sort.hip: stable LSD radix sort of (key,val) pairs on bits [0,nbits); n on the device.
+void vsv_radix_sort_pairs(hipStream_t st, uint64_t* key, uint32_t* val, const uint32_t* d_n, int64_t max_n, int nbits,
+                          const SortWork& w);
+int64_t vsv_radix_hist_entries(int64_t max_n);
+
+// cigar_scan.hip
+int vsv_cigar_parts(int64_t n_ops, int ops_per_part);
+void vsv_scan_u32_exclusive(hipStream_t st, const uint32_t* in, int n, uint32_t* out, uint32_t* tmp);
+void vsv_launch_cigar_scan(hipStream_t st, const RecView& rv, const vsv_params& p, uint32_t* part_rb, int n_parts,
+                           int ops_per_part, vsv_sig* pool, uint64_t* pool_key, uint32_t cap, uint32_t* part_count,
+                           uint32_t* part_off, uint32_t* scan_tmp, vsv_sig* raw, Counters* ctr, hipEvent_t ev0,
+                           hipEvent_t ev1);
+
+// sig_stages.hip
+void vsv_launch_fold(hipStream_t st, vsv_sig* raw, vsv_sig* raw_copy, const RecView& rv, int dtype, Counters* ctr);
+void vsv_launch_split(hipStream_t st, const RecView& rv, const vsv_params& p, int n_tids, uint32_t* tab, uint32_t tab_size,
+                      uint32_t* blk_cnt, uint32_t* blk_off, uint32_t* scan_tmp, uint64_t* ckey, uint32_t* crec,
+                      uint64_t* okey, uint32_t* oval, const SortWork& sw, vsv_sig* s1in, uint32_t cap, Counters* ctr);
+void vsv_launch_sort_stage(hipStream_t st, const vsv_sig* in, const uint32_t* d_n, int stage, int nbits, vsv_sig* sorted,
+                           uint32_t* d_alive, const StageBufs& b, const SortWork& sw, int64_t cap);
+void vsv_launch_cluster(hipStream_t st, const vsv_sig* sorted, const uint32_t* d_alive, int max_shift, vsv_sig* out,
+                        const StageBufs& b);
+void vsv_launch_pair(hipStream_t st, const vsv_sig* merged, const uint32_t* d_alive3, int pair_shift, vsv_call* calls_tmp,
+                     vsv_call* calls, uint32_t* d_ncalls, const StageBufs& b, uint64_t* key2, uint32_t* idx2,
+                     const SortWork& sw, int nbits, int64_t cap);

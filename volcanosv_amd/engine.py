@@ -1,0 +1,134 @@
+"""Thin host wrapper over the C-ABI (include/volcanosv.h): one Engine = one vsv_handle = one GPU stream.
+
+The stage methods mirror the reference's function boundaries
+(extract_contig_signature_Hifi.py: extract_signature_from_cigar :386, extract_sig_from_split_reads :421,
+cluster_* :196-288, merge_all :492, pair_sig :548); `run()` is the fused per-chromosome body of :742-772.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .abi import (CALL_DTYPE, SIG_DTYPE, T_CALLS, T_CIGAR, T_CLUSTER1, T_MERGED, T_RAW, T_READS, T_SPLIT, DTYPE_BY_NAME,
+                  DTYPE_READS, DTYPE_SVIM, Params, Records, VsvError)
+
+_TABLE_IDS = {"raw": T_RAW, "cigar": T_CIGAR, "split": T_SPLIT, "cluster1": T_CLUSTER1, "merged": T_MERGED,
+              "calls": T_CALLS, "reads": T_READS}
+
+
+def default_params(dtype):
+    if isinstance(dtype, str):
+        dtype = DTYPE_BY_NAME[dtype]
+    p = Params()
+    st = _lib.load().vsv_default_params(int(dtype), C.byref(p))
+    if st:
+        raise VsvError(st)
+    return p
+
+
+class DeviceRecords:
+    """Record SoA already resident in HBM: a dict of torch CUDA tensors (pos,tid,qid,cigar_off,mapq,flag,cigar)."""
+
+    def __init__(self, tensors, n_qids=0, n_tids=0):
+        self.t = tensors
+        self.n_records = int(tensors["pos"].numel())
+        self.n_ops = int(tensors["cigar"].numel())
+        self.n_qids, self.n_tids = int(n_qids), int(n_tids)
+
+    def as_struct(self):
+        r = Records()
+        r.n_records, r.n_ops = self.n_records, self.n_ops
+        for name in ("pos", "tid", "qid", "cigar_off", "mapq", "flag", "cigar"):
+            setattr(r, name, C.c_void_p(self.t[name].data_ptr()))
+        r.on_device, r.n_qids, r.n_tids = 1, self.n_qids, self.n_tids
+        return r
+
+
+class Engine:
+    def __init__(self, device=0, stream=None, max_sigs=None):
+        self.lib = _lib.load()
+        self.h = C.c_void_p()
+        st = self.lib.vsv_create(int(device), C.c_void_p(stream or 0), C.byref(self.h))
+        if st:
+            raise VsvError(st, "vsv_create failed (no MI355X visible?)")
+        if max_sigs:
+            self.reserve(0, 0, max_sigs)
+        self._keep = None
+
+    def close(self):
+        if self.h:
+            self.lib.vsv_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st):
+        if st:
+            raise VsvError(st, self.lib.vsv_last_error(self.h).decode())
+
+    def reserve(self, max_records, max_ops, max_sigs):
+        self._check(self.lib.vsv_reserve(self.h, int(max_records), int(max_ops), int(max_sigs)))
+
+    def last_count(self):
+        return int(self.lib.vsv_last_count(self.h))
+
+    # ---- stage entry points --------------------------------------------------------------------------
+    def _recs(self, soa):
+        self._keep = soa  # keep host arrays / tensors alive while the GPU reads them
+        return soa.as_struct()
+
+    def cigar_scan(self, soa, params):
+        r = self._recs(soa)
+        self._check(self.lib.vsv_cigar_scan(self.h, C.byref(r), C.byref(params)))
+
+    def split_pairs(self, params=None):
+        self._check(self.lib.vsv_split_pairs(self.h, None, C.byref(params) if params is not None else None))
+
+    def sort_cluster(self, params=None):
+        self._check(self.lib.vsv_sort_cluster(self.h, C.byref(params) if params is not None else None))
+
+    def merge_sources(self, params=None):
+        self._check(self.lib.vsv_merge_sources(self.h, C.byref(params) if params is not None else None))
+
+    def pair_haplotypes(self, params=None):
+        self._check(self.lib.vsv_pair_haplotypes(self.h, C.byref(params) if params is not None else None))
+
+    def run(self, soa, params):
+        r = self._recs(soa)
+        self._check(self.lib.vsv_run_chromosome(self.h, C.byref(r), C.byref(params)))
+
+    def run_async(self, soa, params):
+        r = self._recs(soa)
+        self._check(self.lib.vsv_run_chromosome_async(self.h, C.byref(r), C.byref(params)))
+
+    def finish(self):
+        self._check(self.lib.vsv_finish(self.h))
+
+    def scan_ms(self):
+        ms = C.c_float()
+        self._check(self.lib.vsv_last_scan_ms(self.h, C.byref(ms)))
+        return float(ms.value)
+
+    # ---- readback ------------------------------------------------------------------------------------
+    def table(self, name):
+        tid = _TABLE_IDS[name]
+        n = C.c_int64()
+        self._check(self.lib.vsv_table_count(self.h, tid, C.byref(n)))
+        dt = CALL_DTYPE if name == "calls" else SIG_DTYPE
+        out = np.zeros(int(n.value), dtype=dt)
+        if n.value:
+            self._check(self.lib.vsv_table_fill(self.h, tid, out.ctypes.data_as(C.c_void_p), n.value, 0))
+        return out
+
+    def tables(self, dtype):
+        if dtype == DTYPE_SVIM:
+            names = ["raw", "cigar"]
+        elif dtype == DTYPE_READS:
+            names = ["raw", "cigar", "split", "reads"]
+        else:
+            names = ["raw", "cigar", "split", "cluster1", "merged", "calls"]
+        return {k: self.table(k) for k in names}

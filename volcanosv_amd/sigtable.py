@@ -6,7 +6,7 @@ The reference's only data type on this path is a Python list of 10 fields
 [GT, contig_info, strands, sources, mapqs]. The C-ABI carries integers only (include/volcanosv.h
 `vsv_sig`, `vsv_call`); these helpers re-attach the strings from the caller's SoA.
 """
-from .types import DTYPE_READS, M_DEL, M_HP2, M_SPLIT
+from .abi import DTYPE_READS, M_DEL, M_HP2, M_SPLIT
 
 
 def _chrom(soa, tid):

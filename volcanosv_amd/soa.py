@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-from .types import F_HP1, F_HP2, F_REVERSE, Records
+from .abi import F_HP1, F_HP2, F_REVERSE, Records
 
 
 class RecordSoA:
@@ -29,6 +29,7 @@ class RecordSoA:
         self.qnames = qnames
         self.tid_names = tid_names
         self.n_qids = int(self.qid.max()) + 1 if n else 0
+        self.n_tids = int(self.tid.max()) + 1 if n else 0
 
     @property
     def n_records(self):
@@ -47,7 +48,7 @@ class RecordSoA:
         r.n_records, r.n_ops = self.n_records, self.n_ops
         for name in ("pos", "tid", "qid", "cigar_off", "mapq", "flag", "cigar"):
             setattr(r, name, getattr(self, name).ctypes.data_as(C.c_void_p))
-        r.on_device, r.n_qids = 0, self.n_qids
+        r.on_device, r.n_qids, r.n_tids = 0, self.n_qids, self.n_tids
         return r
 
     def qname(self, rec):

@@ -1,0 +1,189 @@
+"""Synthetic alignment-record streams of the BASELINE.json shapes, generated with torch so
+the same code fills host tensors (tests, CPU baseline sample) or HBM directly (bench, Philox on device).
+
+Shapes
+  hifi    config 2: k ~ Poisson(16), n_ops = 2k+1, M U[50,1000) alternating with I/D U[1,6); 1 % of records
+          carry one >=50 bp event U[50,5000); mapq 60 w.p. 0.95; 1 % of names own a clipped split pair.
+  ont     config 3: k ~ Poisson(100), M U[5,80), indel Geometric(0.5); 3 % events; 10 % split names; mapq 60 w.p. 0.8.
+  contig  config 2c: k ~ Poisson(8000) (Mb-scale contigs), 1 % ... per-op event rate as hifi.
+Records are (tid, pos)-sorted like a coordinate-sorted BAM; hp flag = record parity (hp1/hp2 names).
+"""
+import numpy as np
+import torch
+
+from .abi import F_HP1, F_HP2, F_REVERSE
+from .soa import RecordSoA
+
+SHAPES = {
+    # k_mean, M lo, M hi, indel small (lo,hi) or geometric, event fraction, split fraction, p(mapq 60)
+    "hifi": dict(k=16.0, m_lo=50, m_hi=1000, small=(1, 6), geometric=False, ev=0.01, split=0.01, mq=0.95),
+    "ont": dict(k=100.0, m_lo=5, m_hi=80, small=None, geometric=True, ev=0.03, split=0.10, mq=0.80),
+    "contig": dict(k=8000.0, m_lo=50, m_hi=1000, small=(1, 6), geometric=False, ev=0.01, split=0.01, mq=0.95),
+}
+CHR10_LEN = 135534747  # hg19 chr10 (reference Large_INDEL/header:14)
+
+
+def _randint(gen, lo, hi, n, device):
+    return torch.randint(int(lo), int(hi), (int(n),), generator=gen, device=device, dtype=torch.int64)
+
+
+def _rand(gen, n, device):
+    return torch.rand(int(n), generator=gen, device=device)
+
+
+def generate(n_records, shape="hifi", seed=20250330, tid=0, chrom_len=CHR10_LEN, device="cpu", events_per_record=None,
+             site_step=5000):
+    """Returns a dict of torch tensors in the C-ABI SoA layout plus n_qids / n_tids."""
+    cfg = SHAPES[shape]
+    dev = torch.device(device)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(int(seed))
+    n_mates = int(round(n_records * cfg["split"] / (1.0 + cfg["split"])))
+    nb = int(n_records) - n_mates  # base records
+    # ---- base records -------------------------------------------------------------------------------
+    k = torch.poisson(torch.full((nb,), cfg["k"], device=dev), generator=gen).to(torch.int64)
+    n_ops = 2 * k + 1
+    pos = torch.sort(_randint(gen, 0, max(1, chrom_len - 40000), nb, dev)).values
+    has_mate = torch.zeros(nb, dtype=torch.bool, device=dev)
+    if n_mates > 0:
+        sel = torch.randperm(nb, generator=gen, device=dev)[:n_mates]
+        has_mate[sel] = True
+    n_ops_b = n_ops + has_mate.to(torch.int64)  # +1 tail clip
+    off_b = torch.zeros(nb + 1, dtype=torch.int64, device=dev)
+    off_b[1:] = torch.cumsum(n_ops_b, 0)
+    tot = int(off_b[-1])
+    rec_of = torch.repeat_interleave(torch.arange(nb, device=dev), n_ops_b)
+    j = torch.arange(tot, device=dev) - off_b[rec_of]           # op index inside the record
+    is_m = (j % 2 == 0)
+    m_len = _randint(gen, cfg["m_lo"], cfg["m_hi"], tot, dev)
+    if cfg["geometric"]:
+        u = _rand(gen, tot, dev).clamp_(min=1e-12)
+        small = (torch.floor(torch.log2(1.0 / u)).to(torch.int64) + 1).clamp_(max=60)   # Geometric(0.5) on {1,2,...}
+    else:
+        small = _randint(gen, cfg["small"][0], cfg["small"][1], tot, dev)
+    is_del = _rand(gen, tot, dev) < 0.5
+    op = torch.where(is_m, torch.zeros_like(j), torch.where(is_del, torch.full_like(j, 2), torch.ones_like(j)))
+    ln = torch.where(is_m, m_len, small)
+    # events: a record carries one >=50 bp I/D taken from a grid of shared "truth" sites (one every `site_step` bp), so
+    # overlapping records of both haplotypes report the same SV with small position / length jitter and the
+    # clustering and pairing stages have real work. The M op containing the site is cut at the site and the I/D
+    # op after it becomes the event; type and base length U[50,5000) are a hash of the site index.
+    ev_frac = cfg["ev"] if events_per_record is None else events_per_record
+    mean_span = (cfg["k"] + 1.0) * 0.5 * (cfg["m_lo"] + cfg["m_hi"])
+    # probability that an M op crossing a site carries the event: events/record ~= ev_frac (contig shape: every
+    # other site, i.e. hundreds of events per Mb-scale contig)
+    p_cross = 0.5 if shape == "contig" else min(1.0, ev_frac * site_step / mean_span)
+    r_adv0 = torch.where((op == 0) | (op == 2), ln, torch.zeros_like(ln))
+    csum = torch.cumsum(r_adv0, 0)
+    rec_base = torch.zeros(nb, dtype=torch.int64, device=dev)
+    rec_base[1:] = csum[off_b[1:-1] - 1]
+    ref_start = pos[rec_of] + (csum - r_adv0) - rec_base[rec_of]          # reference offset before each op
+    site = ref_start // site_step + 1                                      # first grid site right of the op start
+    g = site * site_step
+    crosses = is_m & (j + 1 < 2 * k[rec_of] + 1) & (g < ref_start + ln) & (ln >= 3)
+    hit = crosses & (_rand(gen, tot, dev) < p_cross)
+    m_idx = torch.nonzero(hit).flatten()
+    if m_idx.numel():
+        ne = m_idx.numel()
+        gj = g[m_idx] + _randint(gen, -20, 21, ne, dev)
+        gj = torch.minimum(torch.maximum(gj, ref_start[m_idx] + 1), ref_start[m_idx] + ln[m_idx] - 1)
+        h = (site[m_idx] * 2654435761) & 0xFFFFFFFF
+        base_len = 50 + (h >> 8) % 4950
+        scale = torch.where(_rand(gen, ne, dev) < 0.1, 0.3, 1.0) * (0.95 + 0.1 * _rand(gen, ne, dev))
+        ev_len = (base_len.to(torch.float64) * scale.to(torch.float64)).to(torch.int64).clamp_(min=50)
+        ln[m_idx] = gj - ref_start[m_idx]
+        op[m_idx + 1] = torch.where((h & 1) == 1, 2, 1)
+        ln[m_idx + 1] = ev_len
+    # per-record sums needed for the planted split pairs
+    q_adv = torch.where((op == 0) | (op == 1), ln, torch.zeros_like(ln))
+    r_adv = torch.where((op == 0) | (op == 2), ln, torch.zeros_like(ln))
+    tail = (j == n_ops_b[rec_of] - 1) & has_mate[rec_of]
+    q_adv = torch.where(tail, torch.zeros_like(ln), q_adv)
+    r_adv = torch.where(tail, torch.zeros_like(ln), r_adv)
+    q1 = torch.zeros(nb, dtype=torch.int64, device=dev).index_add_(0, rec_of, q_adv)
+    rspan = torch.zeros(nb, dtype=torch.int64, device=dev).index_add_(0, rec_of, r_adv)
+    mapq = torch.where(_rand(gen, nb, dev) < cfg["mq"], torch.full((nb,), 60, device=dev, dtype=torch.int64),
+                       _randint(gen, 0, 50, nb, dev))
+    rev = _rand(gen, nb, dev) < 0.5
+    # ---- mates (second segment of a split alignment) --------------------------------------------------
+    mi = torch.nonzero(has_mate).flatten()
+    nm = mi.numel()
+    G = _randint(gen, 0, 1000, nm, dev)                       # Ref2s - Ref1e
+    D = _randint(gen, 50, 5000, nm, dev) * torch.where(_rand(gen, nm, dev) < 0.5, 1, -1)   # planted Diffdis
+    D = torch.where(q1[mi] + G - D >= 1, D, -D.abs())
+    h2 = q1[mi] + G - D                                        # head clip of the mate = Read2s
+    q2 = (D - G).clamp_(min=0) + _randint(gen, 200, 2000, nm, dev)
+    t1 = G - D + q2                                            # tail clip of the first segment
+    clip1 = torch.where(_rand(gen, nm, dev) < 0.5, 4, 5)
+    clip2 = torch.where(_rand(gen, nm, dev) < 0.5, 4, 5)
+    tail_idx = off_b[mi + 1] - 1
+    op[tail_idx] = clip1
+    ln[tail_idx] = t1
+    pos_m = pos[mi] + rspan[mi] + G
+    rev_m = torch.where(_rand(gen, nm, dev) < 0.95, rev[mi], ~rev[mi])
+    mapq_m = torch.where(_rand(gen, nm, dev) < cfg["mq"], torch.full((nm,), 60, device=dev, dtype=torch.int64),
+                         _randint(gen, 0, 50, nm, dev))
+    # ---- concatenate, sort by pos (stable), reorder the ragged CIGAR array ---------------------------
+    n = nb + nm
+    all_pos = torch.cat([pos, pos_m])
+    all_nops = torch.cat([n_ops_b, torch.full((nm,), 2, dtype=torch.int64, device=dev)])
+    all_qid = torch.cat([torch.arange(nb, device=dev), mi])
+    all_mapq = torch.cat([mapq, mapq_m])
+    all_rev = torch.cat([rev, rev_m])
+    hp2 = (all_qid % 2 == 1)
+    mate_op = torch.stack([clip2, torch.zeros_like(clip2)], 1).flatten()
+    mate_ln = torch.stack([h2, q2], 1).flatten()
+    op_all = torch.cat([op, mate_op])
+    ln_all = torch.cat([ln, mate_ln])
+    old_off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    old_off[1:] = torch.cumsum(all_nops, 0)
+    order = torch.sort(all_pos, stable=True).indices
+    new_nops = all_nops[order]
+    new_off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    new_off[1:] = torch.cumsum(new_nops, 0)
+    rec_new = torch.repeat_interleave(torch.arange(n, device=dev), new_nops)
+    src = old_off[order][rec_new] + (torch.arange(int(new_off[-1]), device=dev) - new_off[rec_new])
+    packed = ((ln_all[src] << 4) | op_all[src]).to(torch.int64)
+    flag = (all_rev[order].to(torch.int64) * F_REVERSE) | torch.where(hp2[order], F_HP2, F_HP1)
+    out = {
+        "pos": all_pos[order].to(torch.int32),
+        "tid": torch.full((n,), int(tid), dtype=torch.int32, device=dev),
+        # uint32 tensors are awkward in torch: qid / cigar keep int32 storage with the same bits
+        "qid": all_qid[order].to(torch.int32),
+        "cigar_off": new_off,   # int64 bits == uint64 (non-negative)
+        "mapq": all_mapq[order].to(torch.uint8),
+        "flag": flag.to(torch.uint8),
+        "cigar": packed.to(torch.int32),
+    }
+    return out, nb, int(tid) + 1
+
+
+def to_soa(tensors, n_qids=None):
+    """torch dict -> host RecordSoA (numpy views of the same bits)."""
+    t = {k: v.cpu().numpy() for k, v in tensors.items()}
+    soa = RecordSoA(t["pos"], t["tid"], t["qid"].view(np.uint32), t["cigar_off"].view(np.uint64), t["mapq"], t["flag"],
+                    t["cigar"].view(np.uint32))
+    if n_qids:
+        soa.n_qids = int(n_qids)
+    return soa
+
+
+def concat(parts):
+    """Concatenates per-tid tensor dicts (tid-major, like a coordinate-sorted multi-chromosome BAM).
+    qids of later parts are shifted so names stay distinct across chromosomes."""
+    out = {}
+    qshift, oshift = 0, 0
+    offs = []
+    for t, nq in parts:
+        offs.append(t["cigar_off"][:-1] + oshift)
+        oshift += int(t["cigar_off"][-1])
+    last = torch.tensor([oshift], dtype=torch.int64, device=parts[0][0]["pos"].device)
+    for name in ("pos", "tid", "mapq", "flag", "cigar"):
+        out[name] = torch.cat([t[name] for t, _ in parts])
+    qs = []
+    for t, nq in parts:
+        qs.append(t["qid"] + qshift)
+        qshift += nq
+    out["qid"] = torch.cat(qs)
+    out["cigar_off"] = torch.cat(offs + [last])
+    return out, qshift
