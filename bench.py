@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""bench.py — alignment-records/s through SV-signature extraction + clustering + pairing on MI355X.
+
+One step = one pass of the whole hot path (vsv_run_chromosome: cigar_scan_emit -> fold -> split pairs ->
+sort/cluster x2 -> merge -> hap pairing) over one device-resident shard of BASELINE.json config 2
+(10 M HiFi-like records of one chromosome). With N GPUs every rank owns one such chromosome shard (weak scaling,
+no data-path collective); the per-rank call tables are gathered to rank 0 once, inside the timed region.
+
+Prints ONE JSON line (see the task contract) with `roofline` for the dominant kernel (cigar_scan_emit, HBM-bound,
+timed with HIP events on the launch stream inside the library) and `cpu_baseline` (the CPU oracle = C port of the
+reference path, one core, on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--records", type=int, default=10_000_000, help="records per GPU (config 2: 10 M)")
+    ap.add_argument("--shape", default="hifi", choices=["hifi", "ont", "contig"])
+    ap.add_argument("--dtype", default=None, help="Hifi | ONT | CLR | READS (default by shape)")
+    ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="records of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--max-sigs", type=int, default=1 << 22)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from volcanosv_amd import shard, synth
+    from volcanosv_amd.abi import DTYPE_BY_NAME
+    from volcanosv_amd.engine import DeviceRecords, Engine, default_params
+
+    dtype_name = args.dtype or {"hifi": "Hifi", "ont": "ONT", "contig": "Hifi"}[args.shape]
+    dtype = DTYPE_BY_NAME[dtype_name]
+    config_idx = {"hifi": 2, "ont": 3, "contig": 6}[args.shape]
+    # reference index (contig lengths + per-tid record counts): rank 0 owns it, RCCL broadcast to the others
+    index = torch.tensor([[synth.CHR10_LEN, args.records]] * world, dtype=torch.int64, device=dev)
+    index = shard.broadcast_index(index, dev)
+    chrom_len, n_rec = int(index[rank, 0]), int(index[rank, 1])
+    # synthetic shard generated directly in HBM (torch CUDA generator = Philox); tid = rank
+    t, nq, _ = synth.generate(n_rec, args.shape, seed=20250328 + config_idx + 1000 * rank, tid=rank, chrom_len=chrom_len, device=dev)
+    recs = DeviceRecords(t, nq, world)
+    eng = Engine(local_rank, stream=torch.cuda.current_stream().cuda_stream, max_sigs=args.max_sigs)
+    p = default_params(dtype)
+
+    def step():
+        eng.run_async(recs, p)
+
+    for _ in range(args.warmup):
+        step()
+        eng.finish()
+    torch.cuda.synchronize()
+    scan_ms = []
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        eng.finish()          # one counter readback per step: status + table sizes
+        scan_ms.append(eng.scan_ms())
+    calls = eng.table("calls") if dtype != DTYPE_BY_NAME["READS"] else eng.table("reads")
+    gathered = shard.gather_calls(calls, dev) if dtype != DTYPE_BY_NAME["READS"] else calls
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    n_raw = len(eng.table("raw"))
+    alg_bytes = 24 * recs.n_records + 4 * recs.n_ops + 32 * n_raw      # SURVEY.md §8d, per launch
+    scan_s = sum(scan_ms) / len(scan_ms) / 1e3
+    achieved = alg_bytes / scan_s / 1e9
+
+    if rank == 0:
+        cpu = None
+        if args.cpu_sample > 0:
+            from oracle import oracle
+            ns = min(args.cpu_sample, recs.n_records)
+            host = {k: (v[: ns + 1] if k == "cigar_off" else v[:ns]).cpu() for k, v in t.items() if k != "cigar"}
+            n_ops_s = int(host["cigar_off"][ns])
+            host["cigar"] = t["cigar"][:n_ops_s].cpu()
+            soa = synth.to_soa(host, nq)
+            pc = oracle.default_params(dtype)
+            c0 = time.perf_counter()
+            st, tabs = oracle.run(soa, params=pc)
+            c1 = time.perf_counter()
+            assert st == 0
+            cpu = {"value": ns / (c1 - c0), "unit": "records/s", "cores": 1, "kind": "port",
+                   "sample": "first %d records of the same shard through oracle/vsv_oracle.c (windowed cluster/pair loops), %.2f s"
+                             % (ns, c1 - c0)}
+        total_records = recs.n_records * world * args.steps
+        line = {
+            "metric": "alignment-records/s through SV-signature+cluster; VCF bit-match vs CPU",
+            "value": total_records / dt,
+            "unit": "records/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": "config2: %d %s-like records/GPU, 1 chromosome per GPU, dtype %s, %d CIGAR ops, %d raw signatures, %d calls gathered"
+                                   % (recs.n_records, args.shape, dtype_name, recs.n_ops, n_raw, len(gathered) if gathered is not None else 0),
+                       "records_per_gpu": recs.n_records, "parallelism": "chromosome-sharded x%d" % world},
+            "roofline": {"bound": "hbm", "kernel": "cigar_scan_emit", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": scan_s * 1e3},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

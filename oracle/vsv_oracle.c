@@ -99,7 +99,9 @@ static int clr_gate(const vsv_records* r, int64_t i) {
 
 /* extract_sig_from_cigar (H:53-85 / RS:47-83 / SV/SVIM_intra.py:8-30) for one record and one hap
  * pass; appends the raw (pre-fold) signatures in CIGAR order. */
-static int walk_record(const vsv_records* r, int64_t i, const vsv_params* p, uint32_t hapbit, sigvec* out) {
+/* hapmask: bit0 = emit an hp1-pass row, bit1 = emit an hp2-pass row (a qname holding both 'hp1' and 'hp2' is
+ * walked by both passes of H:760-766; T_RAW order is (record, op, hap)). */
+static int walk_record(const vsv_records* r, int64_t i, const vsv_params* p, uint32_t hapmask, sigvec* out) {
   uint64_t a = r->cigar_off[i], b = r->cigar_off[i + 1];
   if (b <= a) return VSV_E_EMPTY_CIGAR;
   int dtype = p->dtype;
@@ -112,10 +114,11 @@ static int walk_record(const vsv_records* r, int64_t i, const vsv_params* p, uin
         vsv_sig s; memset(&s, 0, sizeof s);
         s.pos = (int32_t)off_ref; s.svlen = (int32_t)len; s.q_start = (int32_t)(off_q + hc);
         s.rec = (uint32_t)i; s.rec2 = 0xFFFFFFFFu; s.tid = r->tid[i];
-        s.meta = hapbit | (op == 2 ? VSV_M_DEL : 0);
+        s.meta = (op == 2 ? VSV_M_DEL : 0);
         if (dtype == VSV_DTYPE_READS) s.q_end = 0;            /* RS:72,76: 8-field sig, no q_end */
         else s.q_end = s.q_start + (op == 2 ? 1 : (int32_t)len); /* H:80, H:84 */
-        sv_push(out, &s);
+        if (hapmask & 1) sv_push(out, &s);
+        if (hapmask & 2) { s.meta |= VSV_M_HP2; sv_push(out, &s); }
       }
     }
     if (ref_adv(dtype, op)) off_ref += len;
@@ -128,9 +131,10 @@ static int walk_record(const vsv_records* r, int64_t i, const vsv_params* p, uin
 
 /* cluster_ins_one_read / cluster_del_one_read (H:91-161): left fold over one record's signatures
  * of one type, in place on raw[lo,hi) (all same rec & hap). Dead rows get VSV_M_DEAD. */
-static void fold_record(vsv_sig* s, int64_t lo, int64_t hi) {
+static void fold_record_hap(vsv_sig* s, int64_t lo, int64_t hi, uint32_t hap) {
   int64_t last_ins = -1, last_del = -1;
   for (int64_t k = lo; k < hi; ++k) {
+    if ((s[k].meta & VSV_M_HP2) != hap) continue;
     if (s[k].meta & VSV_M_DEL) {
       if (last_del < 0) { last_del = k; continue; }
       vsv_sig* s1 = &s[last_del]; vsv_sig* s2 = &s[k];
@@ -154,6 +158,11 @@ static void fold_record(vsv_sig* s, int64_t lo, int64_t hi) {
       } else last_ins = k;
     }
   }
+}
+
+static void fold_record(vsv_sig* s, int64_t lo, int64_t hi) {
+  fold_record_hap(s, lo, hi, 0);
+  fold_record_hap(s, lo, hi, VSV_M_HP2);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -452,14 +461,13 @@ int orc_run(const vsv_records* r, const vsv_params* p, int literal, orc_out* o) 
       int gate = 1;
       if (dtype == VSV_DTYPE_CLR) { gate = clr_gate(r, i); if (gate < 0) { st = gate; break; } }
       if (r->mapq[i] < p->min_cigar_mapq || !gate) continue;
-      if (r->flag[i] & VSV_F_HP1) st = walk_record(r, i, p, 0, &raw);
-      if (st == 0 && (r->flag[i] & VSV_F_HP2)) st = walk_record(r, i, p, VSV_M_HP2, &raw);
+      st = walk_record(r, i, p, (r->flag[i] >> 2) & 3u, &raw);
     } else if (dtype == VSV_DTYPE_READS) {
       if (r->mapq[i] < p->min_cigar_mapq) continue;            /* RS:120 */
-      st = walk_record(r, i, p, 0, &raw);
+      st = walk_record(r, i, p, 1, &raw);
     } else {
       if ((r->flag[i] & (VSV_F_UNMAPPED | VSV_F_SECONDARY)) || r->mapq[i] < p->min_cigar_mapq) continue; /* SV/SVIM_COLLECT.py:67 */
-      st = walk_record(r, i, p, 0, &raw);
+      st = walk_record(r, i, p, 1, &raw);
     }
   }
   o->raw = sv_dup(&raw); o->n_raw = raw.n;
@@ -469,7 +477,7 @@ int orc_run(const vsv_records* r, const vsv_params* p, int literal, orc_out* o) 
     int64_t lo = 0;
     while (lo < raw.n) {
       int64_t hi = lo + 1;
-      while (hi < raw.n && raw.v[hi].rec == raw.v[lo].rec && ((raw.v[hi].meta ^ raw.v[lo].meta) & VSV_M_HP2) == 0) hi++;
+      while (hi < raw.n && raw.v[hi].rec == raw.v[lo].rec) hi++;
       fold_record(raw.v, lo, hi);
       lo = hi;
     }

@@ -30,6 +30,14 @@ def load():
         raise ImportError(
             "HIP extension %s not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or python volcanosv_amd/build.py); there is no CPU fallback." % LIB_PATH)
+    # One HIP runtime per process: PyTorch bundles its own libamdhip64 (SONAME libamdhip64.so.7, requested by
+    # torch under the name libamdhip64.so). If this library pulled in /opt/rocm's copy first, torch would load a
+    # second runtime and its streams / device would not be ours. Importing torch first makes the dynamic loader
+    # resolve our DT_NEEDED libamdhip64.so.7 to the copy torch already mapped.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     H = C.c_void_p
     lib.vsv_abi_version.restype = C.c_int

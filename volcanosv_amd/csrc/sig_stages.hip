@@ -28,37 +28,41 @@ __device__ __forceinline__ int64_t wave_sum64(int64_t v) {
 }
 
 // ---- intra-read fold ------------------------------------------------------------------------------
-// One thread per (record, hap) group of consecutive raw rows; left fold in op order.
+// One thread per record's group of consecutive raw rows (T_RAW order is (record, op, hap)); left fold in op
+// order, independently for each hap pass and type.
 __global__ __launch_bounds__(256) void fold_kernel(vsv_sig* __restrict__ s, const Counters* ctr) {
   const uint32_t n = ctr->n_raw;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const uint32_t rec = s[i].rec, hap = s[i].meta & VSV_M_HP2;
-    if (i > 0 && s[i - 1].rec == rec && (s[i - 1].meta & VSV_M_HP2) == hap) continue;  // not a group head
-    int64_t last_ins = -1, last_del = -1;
-    for (uint32_t k = i; k < n && s[k].rec == rec && (s[k].meta & VSV_M_HP2) == hap; ++k) {
+    const uint32_t rec = s[i].rec;
+    if (i > 0 && s[i - 1].rec == rec) continue;  // not a group head
+    int64_t last[4] = {-1, -1, -1, -1};          // [hap*2 + is_del]
+    for (uint32_t k = i; k < n && s[k].rec == rec; ++k) {
       vsv_sig s2 = s[k];
-      if (s2.meta & VSV_M_DEL) {
-        if (last_del < 0) { last_del = k; continue; }
-        vsv_sig s1 = s[last_del];
+      if (s2.meta & VSV_M_DEAD) continue;        // gated out (CLR)
+      const int slot = ((s2.meta & VSV_M_HP2) ? 2 : 0) + ((s2.meta & VSV_M_DEL) ? 1 : 0);
+      const int64_t lk = slot == 0 ? last[0] : slot == 1 ? last[1] : slot == 2 ? last[2] : last[3];
+      bool merged = false;
+      if (lk >= 0) {
+        vsv_sig s1 = s[lk];
         int64_t d = (int64_t)s2.pos - s1.pos; if (d < 0) d = -d;
-        if (s1.svlen > 150 && s2.svlen > 150 && d < 150) {            // Hifi.py:148-150
-          s1.svlen = s2.pos + s2.svlen - s1.pos;                       // Hifi.py:104
-          s1.q_end = s1.q_start + 1;
-          s[last_del] = s1;
-          s[k].meta = s2.meta | VSV_M_DEAD;
-        } else last_del = k;
-      } else {
-        if (last_ins < 0) { last_ins = k; continue; }
-        vsv_sig s1 = s[last_ins];
-        int64_t d = (int64_t)s2.pos - s1.pos; if (d < 0) d = -d;
-        const bool m = (s1.svlen > 100 && s2.svlen > 100 && d < 250) ||  // Hifi.py:115-117 (subset), 126-128
-                       (s1.svlen > 320 && s2.svlen > 320 && d < 380);    // Hifi.py:120-122
-        if (m) {
-          s1.q_end = s2.q_end;                                          // Hifi.py:94
-          s1.svlen = s1.q_end - s1.q_start;                             // Hifi.py:96
-          s[last_ins] = s1;
-          s[k].meta = s2.meta | VSV_M_DEAD;
-        } else last_ins = k;
+        if (s2.meta & VSV_M_DEL) {
+          if (s1.svlen > 150 && s2.svlen > 150 && d < 150) {            // Hifi.py:148-150
+            s1.svlen = s2.pos + s2.svlen - s1.pos;                       // Hifi.py:104
+            s1.q_end = s1.q_start + 1;
+            merged = true;
+          }
+        } else {
+          if ((s1.svlen > 100 && s2.svlen > 100 && d < 250) ||           // Hifi.py:115-117 (subset), 126-128
+              (s1.svlen > 320 && s2.svlen > 320 && d < 380)) {           // Hifi.py:120-122
+            s1.q_end = s2.q_end;                                          // Hifi.py:94
+            s1.svlen = s1.q_end - s1.q_start;                             // Hifi.py:96
+            merged = true;
+          }
+        }
+        if (merged) { s[lk] = s1; s[k].meta = s2.meta | VSV_M_DEAD; }
+      }
+      if (!merged) {
+        if (slot == 0) last[0] = k; else if (slot == 1) last[1] = k; else if (slot == 2) last[2] = k; else last[3] = k;
       }
     }
   }
@@ -70,8 +74,8 @@ __global__ __launch_bounds__(256) void clr_gate_kernel(vsv_sig* __restrict__ s, 
   const int lane = threadIdx.x & 63;
   const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
   for (uint32_t i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < n; i += nwaves) {
-    const uint32_t rec = s[i].rec, hap = s[i].meta & VSV_M_HP2;
-    if (i > 0 && s[i - 1].rec == rec && (s[i - 1].meta & VSV_M_HP2) == hap) continue;
+    const uint32_t rec = s[i].rec;
+    if (i > 0 && s[i - 1].rec == rec) continue;
     const uint64_t a = rv.cigar_off[rec], b = rv.cigar_off[rec + 1];
     int64_t ins = 0, m = 0, nm = 0;
     for (uint64_t k = a + lane; k < b; k += 64) {
@@ -83,7 +87,7 @@ __global__ __launch_bounds__(256) void clr_gate_kernel(vsv_sig* __restrict__ s, 
     if (m + ins == 0 || nm == 0) { if (lane == 0) atomicOr(&ctr->err, ERRB_ZERODIV); pass = false; }
     else pass = (100 * ins <= 13 * (m + ins)) || (m >= 200 * nm);       // CLR.py:61, 70, 427 in exact integers
     if (!pass && lane == 0) {
-      for (uint32_t k = i; k < n && s[k].rec == rec && (s[k].meta & VSV_M_HP2) == hap; ++k) s[k].meta |= VSV_M_DEAD;
+      for (uint32_t k = i; k < n && s[k].rec == rec; ++k) s[k].meta |= VSV_M_DEAD;
     }
   }
 }
