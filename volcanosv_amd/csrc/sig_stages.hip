@@ -410,7 +410,9 @@ __global__ __launch_bounds__(256) void pair_kernel(const vsv_sig* __restrict__ m
     if (i > 0 && (key[i - 1] >> 34) == (key[i] >> 34) && (int64_t)me.pos - m[i - 1].pos <= 2 * (int64_t)pair_shift) continue;
     const uint32_t b0 = lower_bound_key(key, n, (tk << 35) | (1ull << 34));
     const uint32_t b1 = lower_bound_key(key, n, (tk + 1) << 35);
-    uint32_t jlo = b0;
+    // first hp2 row of this tid with pos >= pos_i - pair_shift (rows further left can never match)
+    uint32_t jlo = lower_bound_key(key, n, (tk << 35) | (1ull << 34) | vsv_upos((int32_t)max((int64_t)me.pos - pair_shift, (int64_t)INT32_MIN)));
+    if (jlo < b0) jlo = b0;
     for (uint32_t a = i; a < n; ++a) {
       const vsv_sig s1 = m[a];
       if ((key[a] >> 34) != (key[i] >> 34)) break;
