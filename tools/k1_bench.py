@@ -17,7 +17,7 @@ ap.add_argument("--shapes", default="hifi:10000000,ont:2000000,contig:20000")
 ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--dtype", default="Hifi")
 args = ap.parse_args()
-eng = Engine(0)
+eng = Engine(0, max_sigs=1 << 24)
 p = default_params(DTYPE_BY_NAME[args.dtype])
 for spec in args.shapes.split(","):
     shape, n = spec.split(":")

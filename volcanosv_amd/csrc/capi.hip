@@ -12,7 +12,7 @@
 
 namespace {
 
-constexpr int OPS_PER_PART = 2048;
+constexpr int OPS_PER_PART = 8192;
 
 struct DevBuf {
   void* p = nullptr;
@@ -36,7 +36,7 @@ struct vsv_handle {
   DevBuf pool, pool_key, raw0, s1in, s1s, c1, s2s, c2, merged, calls_tmp, calls, reads;
   DevBuf tab, blk_cnt, blk_off, ckey, crec, okey, oval;
   DevBuf key, idx, cl, key2, idx2, key_alt, val_alt, hist;
-  DevBuf ctr;
+  DevBuf ctr, shard_cnt;
   Counters host_ctr;
   Counters* pinned = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -91,6 +91,7 @@ int reserve(vsv_handle* h, int64_t max_records, int64_t max_ops, int64_t max_sig
     for (DevBuf* b : u32bufs) { int st = ensure(h, *b, n * sizeof(uint32_t)); if (st) return st; }
     int st = ensure(h, h->hist, (size_t)vsv_radix_hist_entries(max_sigs) * sizeof(uint32_t));
     if (st) return st;
+    if ((st = ensure(h, h->shard_cnt, 256 * 16 * sizeof(uint32_t)))) return st;
     h->cap_sigs = max_sigs;
   }
   if (max_ops > h->cap_ops || max_records > h->cap_records) {
@@ -173,7 +174,7 @@ int enq_scan(vsv_handle* h) {
   const int n_parts = vsv_cigar_parts(h->rv.n_ops, OPS_PER_PART);
   vsv_launch_cigar_scan(st, h->rv, h->prm, (uint32_t*)h->part_rb.p, n_parts, OPS_PER_PART, (vsv_sig*)h->pool.p,
                         (uint64_t*)h->pool_key.p, (uint32_t)h->cap_sigs, (uint32_t*)h->part_count.p, (uint32_t*)h->part_off.p,
-                        (uint32_t*)h->scan_tmp.p, (vsv_sig*)h->s1in.p, dctr(h), h->ev0, h->ev1);
+                        (uint32_t*)h->scan_tmp.p, (vsv_sig*)h->s1in.p, dctr(h), (uint32_t*)h->shard_cnt.p, h->ev0, h->ev1);
   h->have_scan_ev = n_parts > 0;
   vsv_launch_fold(st, (vsv_sig*)h->s1in.p, (vsv_sig*)h->raw0.p, h->rv, h->prm.dtype, dctr(h));
   HIPCHK(h, hipGetLastError());
@@ -330,7 +331,7 @@ void vsv_destroy(vsv_handle* h) {
   DevBuf* bufs[] = {&h->r_pos, &h->r_tid, &h->r_qid, &h->r_off, &h->r_mapq, &h->r_flag, &h->r_cigar, &h->part_rb, &h->part_count,
                     &h->part_off, &h->scan_tmp, &h->pool, &h->pool_key, &h->raw0, &h->s1in, &h->s1s, &h->c1, &h->s2s, &h->c2,
                     &h->merged, &h->calls_tmp, &h->calls, &h->reads, &h->tab, &h->blk_cnt, &h->blk_off, &h->ckey, &h->crec,
-                    &h->okey, &h->oval, &h->key, &h->idx, &h->cl, &h->key2, &h->idx2, &h->key_alt, &h->val_alt, &h->hist, &h->ctr};
+                    &h->okey, &h->oval, &h->key, &h->idx, &h->cl, &h->key2, &h->idx2, &h->key_alt, &h->val_alt, &h->hist, &h->ctr, &h->shard_cnt};
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
   if (h->pinned) hipHostFree(h->pinned);
   if (h->ev0) hipEventDestroy(h->ev0);

@@ -22,6 +22,8 @@
 //    mapq/hp filters and appends to a pool with one atomic. Each row carries (part, ordinal), and
 //    place_raw scatters rows to part_off[part]+ordinal, so T_RAW is in (record, op) order whatever
 //    the atomic order was.
+#include <stdlib.h>
+
 #include "vsv_device.h"
 
 namespace {
@@ -76,70 +78,156 @@ __global__ void partition_kernel(const uint64_t* __restrict__ cigar_off, int64_t
   rb[p] = (uint32_t)lo;
 }
 
+// Emit pool = K1_SHARDS independent sub-pools (cursor s on its own 64-byte line). A single cursor word saturates at
+// ~88 returning atomics/us (MI355X_MICROARCH.md "dequeue"), which made 88 k emissions cost 0.8 ms; a part uses
+// shard = part % K1_SHARDS and takes slots in geometrically growing batches (4,8,..,64), so both the contention and
+// the number of round trips per wave vanish. Slots a wave does not use are tagged with the sentinel key.
+constexpr int K1_SHARDS = 256;
+constexpr uint64_t K1_SENTINEL = 0xFFFFFFFFFFFFFFFFull;
 struct EmitCtx {
   vsv_sig* pool;
   uint64_t* pool_key;
-  uint32_t cap;
+  uint32_t* shard_cnt;   // [K1_SHARDS * 16]
+  uint32_t shard_cap;    // rows per shard
   Counters* ctr;
 };
 
+// four wave-uniform dword loads through the scalar cache (lgkmcnt): they do not drain the in-flight vector loads
+__device__ __forceinline__ void sload4(const void* p0, const void* p1, const void* p2, const void* p3, uint32_t& v0,
+                                       uint32_t& v1, uint32_t& v2, uint32_t& v3) {
+  asm volatile(
+      "s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %5, 0x0\n\ts_load_dword %2, %6, 0x0\n\ts_load_dword %3, %7, 0x0\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&s"(v0), "=&s"(v1), "=&s"(v2), "=&s"(v3)
+      : "s"(p0), "s"(p1), "s"(p2), "s"(p3)
+      : "memory");
+}
+__device__ __forceinline__ uint32_t byte_of(uint32_t word, const void* p) { return (word >> (8u * ((uintptr_t)p & 3u))) & 0xFFu; }
+__device__ __forceinline__ const void* align4(const void* p) { return (const void*)((uintptr_t)p & ~(uintptr_t)3); }
+
 // ---- K1 ------------------------------------------------------------------------------------------
+// Per-wave state while streaming a part:
+//   chunk grid    256-op chunks on absolute 16-byte boundaries, continuous over the whole part. Three chunks
+//                 (3 KiB per wave) are always in flight: the loop is unrolled by three so no in-flight register is
+//                 ever copied, and chunk loads go through a raw buffer descriptor clipped to the part.
+//   record table  the part's record starts (relative, u32) and positions staged ONCE per part in LDS (wave-private
+//                 slice, K1_RMAX records; parts with more records restage). A 64-record window of the table is the
+//                 "block": lane i <-> record wbase+i. A chunk that straddles two windows is processed twice with
+//                 complementary op masks (segment [seg_lo, seg_hi)).
+//   open record   scalars describing the record that is open at the start of the current segment.
+constexpr int K1_RMAX = 320;   // records staged per wave (8192-op parts of ~33-op reads hold ~250)
+constexpr int K1_WAVES = 4;
+
 template <int CLS>
 __global__ __launch_bounds__(256) void cigar_scan_emit(RecView rv, const uint32_t* __restrict__ rb, int n_parts,
                                                         int min_svlen, int min_mapq, EmitCtx ec,
-                                                        uint32_t* __restrict__ part_count) {
+                                                        uint32_t* __restrict__ part_count, int ablate) {
   using T = OpTab<CLS>;
+  __shared__ uint32_t sh_off[K1_WAVES][K1_RMAX + 1];
+  __shared__ uint32_t sh_pos[K1_WAVES][K1_RMAX];
   const int lane = threadIdx.x & 63;
-  const int part = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int wv = threadIdx.x >> 6;
+  const int part = blockIdx.x * K1_WAVES + wv;
   if (part >= n_parts) return;
-  const uint32_t r0 = rb[part], r1 = rb[part + 1];
+  const uint32_t r0 = __builtin_amdgcn_readfirstlane(rb[part]), r1 = __builtin_amdgcn_readfirstlane(rb[part + 1]);
   uint32_t ord = 0;  // signatures emitted by this part so far (wave-uniform)
-  const uint4* __restrict__ cig4 = reinterpret_cast<const uint4*>(rv.cigar);
+  if (r0 >= r1) { if (lane == 0) part_count[part] = 0; return; }
+  const uint64_t o0 = rv.cigar_off[r0], o1 = rv.cigar_off[r1];
+  const uint64_t cb0 = o0 & ~3ull;  // absolute op index of rel 0 (16-byte aligned)
+  if (o1 <= o0 || o1 - cb0 >= 0x3FFFFF00ull) {  // relative BYTE offsets must fit 32 bits
+    if (lane == 0) { atomicOr(&ec.ctr->err, o1 <= o0 ? ERRB_EMPTY_CIGAR : ERRB_RANGE); part_count[part] = 0; }
+    return;
+  }
+  const uint32_t ob_rel = (uint32_t)(o0 - cb0), oe_rel = (uint32_t)(o1 - cb0);
 
-  for (uint32_t rbase = r0; rbase < r1; rbase += 64) {
-    const uint32_t nrec = min(64u, r1 - rbase);
-    const bool rv_ok = (uint32_t)lane < nrec;
-    const uint32_t my_r = rbase + min((uint32_t)lane, nrec - 1);
-    const uint64_t so = rv.cigar_off[my_r];
-    const uint32_t rpos = (uint32_t)rv.pos[my_r];
-    const uint64_t ob = __builtin_amdgcn_readfirstlane((uint32_t)so) |
-                        ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(so >> 32)) << 32);
-    const uint64_t oe = rv.cigar_off[rbase + nrec];
-    const uint64_t cb0 = ob & ~3ull;  // absolute op index of rel 0 (16-byte aligned)
-    if (oe - cb0 >= 0x7FFFFF00ull) {  // relative offsets must fit 31 bits
-      if (lane == 0) atomicOr(&ec.ctr->err, ERRB_RANGE);
-      break;
-    }
-    const uint32_t s_rel = (uint32_t)(so - cb0);
-    const uint32_t ob_rel = (uint32_t)(ob - cb0), oe_rel = (uint32_t)(oe - cb0);
-    {  // strictly increasing starts (empty CIGAR => reference IndexError at H:63)
-      uint64_t nxt = rv.cigar_off[my_r + 1];
-      if (__ballot(rv_ok && nxt <= so)) {
-        if (lane == 0) atomicOr(&ec.ctr->err, ERRB_EMPTY_CIGAR);
-        break;
+  // Chunk loads go through a raw buffer descriptor whose range is exactly this part: [cb0, o1). The hardware
+  // range check returns 0 for every dword at or beyond the end, so the prefetch that runs past the part needs no
+  // branch, touches no memory and yields op 0 / len 0 (advances nothing).
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const uint32_t* part_base = rv.cigar + cb0;
+  const uint32_t base_lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)part_base);
+  const uint32_t base_hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)part_base >> 32));
+  const uint32_t part_bytes = __builtin_amdgcn_readfirstlane(oe_rel * 4u);
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(((uintptr_t)base_hi << 32) | (uintptr_t)base_lo), (short)0, (int)part_bytes, 0x00020000);
+  auto load_chunk = [&](uint32_t cb) -> uint4 {
+    const uint32_t voff = (cb + 4u * (uint32_t)lane) * 4u;
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, 0, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+  };
+  uint4 wa = load_chunk(0), wb = load_chunk(256), wc = load_chunk(512);
+
+  // Only the low dwords of cigar_off are read: relative offsets are < 2^30, so (lo - cb0_lo) mod 2^32 is exact.
+  const uint32_t* __restrict__ off_lo = reinterpret_cast<const uint32_t*>(rv.cigar_off);
+  const uint32_t cb0_lo = (uint32_t)cb0;
+  uint32_t* my_off = sh_off[wv];
+  uint32_t* my_pos = sh_pos[wv];
+  uint32_t tbase = r0;      // first record of the staged table
+  uint32_t n_tab = 0;       // records in the table
+  bool bad = false;
+  auto stage = [&](uint32_t first) {
+    tbase = first;
+    n_tab = min((uint32_t)K1_RMAX, r1 - first);
+    bool mono = true;
+    for (uint32_t i = lane; i <= n_tab && !(ablate & 4); i += 64) {
+      const uint32_t v = off_lo[2 * (size_t)(first + i)] - cb0_lo;
+      my_off[i] = v;
+      if (i < n_tab) {
+        my_pos[i] = (uint32_t)rv.pos[first + i];
+        const uint32_t nx = off_lo[2 * (size_t)(first + i) + 2] - cb0_lo;
+        mono = mono && (int32_t)(nx - v) > 0;   // empty CIGAR => reference IndexError at H:63
       }
     }
+    __builtin_amdgcn_wave_barrier();
+    if (__ballot(!mono)) { if (lane == 0) atomicOr(&ec.ctr->err, ERRB_EMPTY_CIGAR); bad = true; }
+  };
+  stage(r0);
 
-    uint32_t pbase_r = 0, pbase_q = 0;   // prefix value at chunk start (mod 2^32)
-    uint32_t open_r = 0, open_q = 0;     // prefix value at the open record's start
-    uint32_t jprev = 0;                  // records of this batch started before the current chunk
+  uint32_t wbase = 0;                  // window = table entries [wbase, wbase+64)
+  uint32_t pbase_r = 0, pbase_q = 0;   // prefix value at the start of the current segment (mod 2^32)
+  uint32_t open_r = 0, open_q = 0;     // prefix value at the open record's start
+  uint32_t open_rec = r0, open_pos = 0, open_s = ob_rel;
+  uint32_t jprev = 0;                  // records of the current window started before the current segment
 
-    for (uint32_t cb = 0; cb < oe_rel; cb += 256) {
-      const uint32_t x = cb + 4u * (uint32_t)lane;  // rel index of this lane's first op
-      uint32_t w[4] = {15u, 15u, 15u, 15u};        // op 15 / len 0: advances nothing, emits nothing
-      const uint64_t xa = cb0 + x;
-      if (x < oe_rel) {
-        if (xa + 4 <= (uint64_t)rv.n_ops) {
-          uint4 v = cig4[xa >> 2];
-          w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-        } else {
+  // slot allocator of this wave inside its shard (all wave-uniform)
+  const uint32_t shard = (uint32_t)part % K1_SHARDS;
+  const uint32_t shard_off = shard * ec.shard_cap;
+  uint32_t al_base = 0, al_left = 0, al_next = 4;
+  auto release_left = [&]() {
+    if ((uint32_t)lane < al_left && al_base + (uint32_t)lane < ec.shard_cap) ec.pool_key[shard_off + al_base + lane] = K1_SENTINEL;
+  };
+  auto alloc = [&](uint32_t n) -> uint32_t {
+    if (al_left < n) {
+      release_left();
+      uint32_t b = 0;
+      if (lane == 0) b = atomicAdd(&ec.shard_cnt[shard * 16], al_next);
+      al_base = __builtin_amdgcn_readfirstlane(b);
+      al_left = al_next;
+      al_next = al_next < 64u ? al_next * 2u : 64u;
+    }
+    const uint32_t sl = al_base;
+    al_base += n;
+    al_left -= n;
+    return sl;
+  };
+
+  auto process_chunk = [&](const uint4& wcur, const uint32_t cb) {
+    if (cb >= oe_rel || bad) return;             // ring slots past the end of the part
+    const uint32_t x = cb + 4u * (uint32_t)lane;  // rel index of this lane's first op
+    uint32_t seg_lo = cb == 0 ? ob_rel : cb;
+    const uint32_t chunk_hi = min(cb + 256u, oe_rel);
+    for (;;) {
+      const uint32_t nwin = min(64u, n_tab - wbase);
+      const bool rv_ok = (uint32_t)lane < nwin;
+      const uint32_t li = wbase + min((uint32_t)lane, nwin - 1u);
+      const uint32_t s_rel = my_off[li];
+      const uint32_t nbfs = my_off[wbase + nwin];            // first start after this window (oe_rel at the end)
+      const uint32_t nbfs_s = (ablate & 8) ? oe_rel : __builtin_amdgcn_readfirstlane(nbfs);
+      const uint32_t seg_hi = chunk_hi < nbfs_s ? chunk_hi : nbfs_s;
+      uint32_t w[4] = {wcur.x, wcur.y, wcur.z, wcur.w};
+      if (seg_lo > cb || seg_hi < cb + 256u) {  // partial segment (wave-uniform): mask ops outside [seg_lo, seg_hi)
 #pragma unroll
-          for (int k = 0; k < 4; ++k) if (xa + k < (uint64_t)rv.n_ops) w[k] = rv.cigar[xa + k];
-        }
-      }
-      if (cb < ob_rel || cb + 256 > oe_rel) {  // edge chunk (wave-uniform): mask ops outside [ob,oe)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) if (x + k < ob_rel || x + k >= oe_rel) w[k] = 15u;
+        for (int k = 0; k < 4; ++k) if (x + k < seg_lo || x + k >= seg_hi) w[k] = 15u;
       }
       uint32_t ar[4], aq[4];
       uint32_t em = 0;
@@ -157,38 +245,47 @@ __global__ __launch_bounds__(256) void cigar_scan_emit(RecView rv, const uint32_
       const uint32_t incl_r = wave_incl_scan(sum_r), incl_q = wave_incl_scan(sum_q);
       const uint32_t excl_r = incl_r - sum_r, excl_q = incl_q - sum_q;
 
-      // ---- slow path: one scalar iteration per candidate op, in (lane, sub) = op order --------------
-      uint64_t anym = __ballot(em != 0);
+      // in-chunk exclusive prefix at rel op index s (wave-uniform s inside this chunk)
+      auto prefix_at = [&](uint32_t s, uint32_t& b_r, uint32_t& b_q) {
+        const uint32_t ls = (s - cb) >> 2, ss = (s - cb) & 3u;
+        b_r = rdlane(excl_r, ls); b_q = rdlane(excl_q, ls);
+        if (ss > 0) { b_r += rdlane(ar[0], ls); b_q += rdlane(aq[0], ls); }
+        if (ss > 1) { b_r += rdlane(ar[1], ls); b_q += rdlane(aq[1], ls); }
+        if (ss > 2) { b_r += rdlane(ar[2], ls); b_q += rdlane(aq[2], ls); }
+      };
+
+      // ---- slow path: one scalar iteration per candidate op, in (lane, sub) = op order ------------
+      uint64_t anym = (ablate & 1) ? 0ull : __ballot(em != 0);
       while (anym) {
         const uint32_t l = (uint32_t)__builtin_ctzll(anym);
         anym &= anym - 1;
         const uint32_t eml = rdlane(em, l);
-        const uint32_t wl[4] = {rdlane(w[0], l), rdlane(w[1], l), rdlane(w[2], l), rdlane(w[3], l)};
-        const uint32_t arl[4] = {rdlane(ar[0], l), rdlane(ar[1], l), rdlane(ar[2], l), rdlane(ar[3], l)};
-        const uint32_t aql[4] = {rdlane(aq[0], l), rdlane(aq[1], l), rdlane(aq[2], l), rdlane(aq[3], l)};
         uint32_t px_r = rdlane(excl_r, l), px_q = rdlane(excl_q, l);  // in-chunk exclusive prefix at (l,0)
         for (uint32_t sub = 0; sub < 4; ++sub) {
+          const uint32_t wsel = sub == 0 ? w[0] : sub == 1 ? w[1] : sub == 2 ? w[2] : w[3];
+          const uint32_t wl = rdlane(wsel, l);
           if (eml & (1u << sub)) {
             const uint32_t xo = cb + 4u * l + sub;
-            const uint32_t op = wl[sub] & 15u, len = wl[sub] >> 4;
-            // record of op xo: last lane-held start <= xo (starts ascend with the lane index)
-            const uint32_t rloc = (uint32_t)__popcll(__ballot(rv_ok && s_rel <= xo)) - 1u;
-            const uint32_t s_r = rdlane(s_rel, rloc);
-            uint32_t a_r, a_q;  // advances from the record start to xo
-            if (rloc + 1u == jprev) {        // record was already open at the chunk edge
+            const uint32_t op = wl & 15u, len = wl >> 4;
+            // record of op xo: last table start <= xo (starts ascend with the lane index), or the open record
+            const uint32_t cnt = (uint32_t)__popcll(__ballot(rv_ok && s_rel <= xo));
+            uint32_t a_r, a_q, rec, rpos_r, s_r;
+            if (cnt == jprev) {              // record was already open at the segment start
               a_r = pbase_r + px_r - open_r;
               a_q = pbase_q + px_q - open_q;
-            } else {                         // record starts inside this chunk
-              const uint32_t ls = (s_r - cb) >> 2, ss = (s_r - cb) & 3u;
-              uint32_t b_r = rdlane(excl_r, ls), b_q = rdlane(excl_q, ls);
-              if (ss > 0) { b_r += rdlane(ar[0], ls); b_q += rdlane(aq[0], ls); }
-              if (ss > 1) { b_r += rdlane(ar[1], ls); b_q += rdlane(aq[1], ls); }
-              if (ss > 2) { b_r += rdlane(ar[2], ls); b_q += rdlane(aq[2], ls); }
+              rec = open_rec; rpos_r = open_pos; s_r = open_s;
+            } else {                         // record starts inside this segment
+              s_r = rdlane(s_rel, cnt - 1u);
+              uint32_t b_r, b_q;
+              prefix_at(s_r, b_r, b_q);
               a_r = px_r - b_r;
               a_q = px_q - b_q;
+              rec = tbase + wbase + cnt - 1u;
+              rpos_r = __builtin_amdgcn_readfirstlane(my_pos[wbase + cnt - 1u]);
             }
-            const uint32_t rec = rbase + rloc;
-            const uint32_t fl = rv.flag[rec], mq = rv.mapq[rec];
+            uint32_t wfl, wmq, tid_r, first;
+            sload4(align4(rv.flag + rec), align4(rv.mapq + rec), rv.tid + rec, rv.cigar + cb0 + s_r, wfl, wmq, tid_r, first);
+            const uint32_t fl = byte_of(wfl, rv.flag + rec), mq = byte_of(wmq, rv.mapq + rec);
             uint32_t hapbits;
             if (CLS == 0) hapbits = (mq >= (uint32_t)min_mapq) ? ((fl >> 2) & 3u) : 0u;               // H:392-394
             else if (CLS == 1) hapbits = (mq >= (uint32_t)min_mapq) ? 1u : 0u;                        // RS:120
@@ -197,55 +294,74 @@ __global__ __launch_bounds__(256) void cigar_scan_emit(RecView rv, const uint32_
               if (op != 1u && op != 2u) {  // N/=/X on the contig table: assert offset_ref==reference_end (H:396)
                 if (lane == 0) atomicOr(&ec.ctr->err, ERRB_REFEND);
               } else {
-                uint32_t hc = 0;
-                if (T::HC) {
-                  const uint32_t first = rv.cigar[cb0 + s_r];
-                  hc = ((first & 15u) == 5u) ? (first >> 4) : 0u;                                     // H:63-65
-                }
+                const uint32_t hc = (T::HC && (first & 15u) == 5u) ? (first >> 4) : 0u;               // H:63-65
                 const uint32_t nemit = (hapbits == 3u) ? 2u : 1u;
-                uint32_t slot = 0;
-                if (lane == 0) slot = atomicAdd(&ec.ctr->n_pool, nemit);
-                slot = __builtin_amdgcn_readfirstlane(slot);
-                if (lane < (int)nemit && slot + (uint32_t)lane < ec.cap) {
-                  vsv_sig s;
-                  s.pos = (int32_t)(rdlane(rpos, rloc) + a_r);
-                  s.svlen = (int32_t)len;
-                  s.q_start = (int32_t)(a_q + hc);
-                  s.q_end = (CLS == 1) ? 0 : s.q_start + (op == 2u ? 1 : (int32_t)len);
-                  s.rec = rec;
-                  s.rec2 = 0xFFFFFFFFu;
-                  const uint32_t hp2 = (CLS == 0) ? ((hapbits == 3u) ? (uint32_t)lane : (hapbits >> 1)) : 0u;
-                  s.meta = (op == 2u ? VSV_M_DEL : 0u) | (hp2 ? VSV_M_HP2 : 0u);
-                  s.tid = rv.tid[rec];
-                  ec.pool[slot + lane] = s;
-                  ec.pool_key[slot + lane] = ((uint64_t)(uint32_t)part << 32) | (uint64_t)(ord + (uint32_t)lane);
+                const uint32_t slot = alloc(nemit);
+                if (lane < (int)nemit) {
+                  if (slot + (uint32_t)lane < ec.shard_cap) {
+                    vsv_sig s;
+                    s.pos = (int32_t)(rpos_r + a_r);
+                    s.svlen = (int32_t)len;
+                    s.q_start = (int32_t)(a_q + hc);
+                    s.q_end = (CLS == 1) ? 0 : s.q_start + (op == 2u ? 1 : (int32_t)len);
+                    s.rec = rec;
+                    s.rec2 = 0xFFFFFFFFu;
+                    const uint32_t hp2 = (CLS == 0) ? ((hapbits == 3u) ? (uint32_t)lane : (hapbits >> 1)) : 0u;
+                    s.meta = (op == 2u ? VSV_M_DEL : 0u) | (hp2 ? VSV_M_HP2 : 0u);
+                    s.tid = (int32_t)tid_r;
+                    ec.pool[shard_off + slot + lane] = s;
+                    ec.pool_key[shard_off + slot + lane] = ((uint64_t)(uint32_t)part << 32) | (uint64_t)(ord + (uint32_t)lane);
+                  }
                 }
                 ord += nemit;
               }
             }
           }
-          px_r += arl[sub];
-          px_q += aql[sub];
+          const uint32_t arsel = sub == 0 ? ar[0] : sub == 1 ? ar[1] : sub == 2 ? ar[2] : ar[3];
+          const uint32_t aqsel = sub == 0 ? aq[0] : sub == 1 ? aq[1] : sub == 2 ? aq[2] : aq[3];
+          px_r += rdlane(arsel, l);
+          px_q += rdlane(aqsel, l);
         }
       }
 
-      // ---- scalar bookkeeping: which record is open at the end of this chunk ----------------------
-      const uint32_t j = (uint32_t)__popcll(__ballot(rv_ok && s_rel < cb + 256u));
-      if (j > jprev) {
+      // ---- scalar bookkeeping: which record is open at the end of this segment ----------------------
+      const uint32_t j = (uint32_t)__popcll(__ballot(rv_ok && s_rel < seg_hi));
+      if (j > jprev && !(ablate & 2)) {
         const uint32_t s = rdlane(s_rel, j - 1u);
-        const uint32_t ls = (s - cb) >> 2, ss = (s - cb) & 3u;
-        uint32_t b_r = rdlane(excl_r, ls), b_q = rdlane(excl_q, ls);
-        if (ss > 0) { b_r += rdlane(ar[0], ls); b_q += rdlane(aq[0], ls); }
-        if (ss > 1) { b_r += rdlane(ar[1], ls); b_q += rdlane(aq[1], ls); }
-        if (ss > 2) { b_r += rdlane(ar[2], ls); b_q += rdlane(aq[2], ls); }
+        uint32_t b_r, b_q;
+        prefix_at(s, b_r, b_q);
         open_r = pbase_r + b_r;
         open_q = pbase_q + b_q;
+        open_rec = tbase + wbase + j - 1u;
+        open_pos = __builtin_amdgcn_readfirstlane(my_pos[wbase + j - 1u]);
+        open_s = s;
         jprev = j;
       }
       pbase_r += rdlane(incl_r, 63);
       pbase_q += rdlane(incl_q, 63);
+      if (seg_hi >= chunk_hi) break;
+      // ---- the chunk continues in the next window of the record table ---------------------------------
+      wbase += 64;
+      if (wbase >= n_tab) {               // table exhausted (part with > K1_RMAX records): restage
+        stage(tbase + n_tab);
+        wbase = 0;
+        if (bad) return;
+      }
+      jprev = 0;
+      seg_lo = seg_hi;
     }
+  };
+
+  // three chunks in flight per wave; the ring is unrolled so no in-flight register is ever copied
+  for (uint32_t cb = 0; cb < oe_rel && !bad; cb += 768) {
+    process_chunk(wa, cb);
+    wa = load_chunk(cb + 768);
+    process_chunk(wb, cb + 256);
+    wb = load_chunk(cb + 1024);
+    process_chunk(wc, cb + 512);
+    wc = load_chunk(cb + 1280);
   }
+  release_left();
   if (lane == 0) part_count[part] = ord;
 }
 
@@ -304,19 +420,28 @@ __global__ __launch_bounds__(256) void scan_tile_apply(const uint32_t* __restric
   for (int k = 0; k < 8; ++k) { if (base + k < n) out[base + k] = run; run += v[k]; }
 }
 
-// ---- ordered placement: raw[part_off[part] + ordinal] = pool[e] ----------------------------------
+// ---- ordered placement: raw[part_off[part] + ordinal] = pool row; one block per shard --------------
 __global__ __launch_bounds__(256) void place_raw(const vsv_sig* __restrict__ pool, const uint64_t* __restrict__ pool_key,
-                                                 const uint32_t* __restrict__ part_off, vsv_sig* __restrict__ raw,
-                                                 uint32_t cap, Counters* ctr) {
-  const uint32_t n = min(ctr->n_pool, cap);
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    ctr->n_raw = n;
-    if (ctr->n_pool > cap) atomicOr(&ctr->err, ERRB_CAPACITY);
+                                                 const uint32_t* __restrict__ shard_cnt, uint32_t shard_cap,
+                                                 const uint32_t* __restrict__ part_off, const uint32_t* __restrict__ part_count,
+                                                 int n_parts, vsv_sig* __restrict__ raw, uint32_t cap, Counters* ctr) {
+  const uint32_t s = blockIdx.x;
+  const uint32_t used = shard_cnt[s * 16];
+  if (threadIdx.x == 0) {
+    if (used > shard_cap) { atomicOr(&ctr->err, ERRB_CAPACITY); }
+    atomicMax(&ctr->n_pool, used > 0xFFFFFFFFu / K1_SHARDS ? 0xFFFFFFFFu : used * K1_SHARDS);  // rows a retry needs
+    if (s == 0) {
+      const uint32_t total = part_off[n_parts - 1] + part_count[n_parts - 1];
+      ctr->n_raw = total < cap ? total : cap;
+      if (total > cap) atomicOr(&ctr->err, ERRB_CAPACITY);
+    }
   }
-  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
-    const uint64_t k = pool_key[e];
+  const uint32_t n = used < shard_cap ? used : shard_cap;
+  for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
+    const uint64_t k = pool_key[(size_t)s * shard_cap + e];
+    if (k == K1_SENTINEL) continue;
     const uint32_t dst = part_off[(uint32_t)(k >> 32)] + (uint32_t)k;
-    if (dst < cap) raw[dst] = pool[e];
+    if (dst < cap) raw[dst] = pool[(size_t)s * shard_cap + e];
   }
 }
 
@@ -334,21 +459,23 @@ int vsv_cigar_parts(int64_t n_ops, int ops_per_part) { return (int)((n_ops + ops
 
 void vsv_launch_cigar_scan(hipStream_t st, const RecView& rv, const vsv_params& p, uint32_t* part_rb, int n_parts,
                            int ops_per_part, vsv_sig* pool, uint64_t* pool_key, uint32_t cap, uint32_t* part_count,
-                           uint32_t* part_off, uint32_t* scan_tmp, vsv_sig* raw, Counters* ctr, hipEvent_t ev0,
-                           hipEvent_t ev1) {
+                           uint32_t* part_off, uint32_t* scan_tmp, vsv_sig* raw, Counters* ctr, uint32_t* shard_cnt,
+                           hipEvent_t ev0, hipEvent_t ev1) {
   if (n_parts <= 0) return;
+  (void)hipMemsetAsync(shard_cnt, 0, K1_SHARDS * 16 * sizeof(uint32_t), st);
   partition_kernel<<<(n_parts + 1 + 255) / 256, 256, 0, st>>>(rv.cigar_off, rv.n_records, part_rb, n_parts, ops_per_part);
-  EmitCtx ec{pool, pool_key, cap, ctr};
+  EmitCtx ec{pool, pool_key, shard_cnt, cap / K1_SHARDS, ctr};
   const int waves_per_block = 4;
   const int grid = (n_parts + waves_per_block - 1) / waves_per_block;
-  if (ev0) hipEventRecord(ev0, st);
+  if (ev0) (void)hipEventRecord(ev0, st);
+  static const int ablate = getenv("VSV_K1_ABLATE") ? atoi(getenv("VSV_K1_ABLATE")) : 0;  // timing experiments only
   if (p.dtype == VSV_DTYPE_READS)
-    cigar_scan_emit<1><<<grid, 256, 0, st>>>(rv, part_rb, n_parts, p.min_svlen, p.min_cigar_mapq, ec, part_count);
+    cigar_scan_emit<1><<<grid, 256, 0, st>>>(rv, part_rb, n_parts, p.min_svlen, p.min_cigar_mapq, ec, part_count, ablate);
   else if (p.dtype == VSV_DTYPE_SVIM)
-    cigar_scan_emit<2><<<grid, 256, 0, st>>>(rv, part_rb, n_parts, p.min_svlen, p.min_cigar_mapq, ec, part_count);
+    cigar_scan_emit<2><<<grid, 256, 0, st>>>(rv, part_rb, n_parts, p.min_svlen, p.min_cigar_mapq, ec, part_count, ablate);
   else
-    cigar_scan_emit<0><<<grid, 256, 0, st>>>(rv, part_rb, n_parts, p.min_svlen, p.min_cigar_mapq, ec, part_count);
-  if (ev1) hipEventRecord(ev1, st);
+    cigar_scan_emit<0><<<grid, 256, 0, st>>>(rv, part_rb, n_parts, p.min_svlen, p.min_cigar_mapq, ec, part_count, ablate);
+  if (ev1) (void)hipEventRecord(ev1, st);
   vsv_scan_u32_exclusive(st, part_count, n_parts, part_off, scan_tmp);
-  place_raw<<<256, 256, 0, st>>>(pool, pool_key, part_off, raw, cap, ctr);
+  place_raw<<<K1_SHARDS, 256, 0, st>>>(pool, pool_key, shard_cnt, cap / K1_SHARDS, part_off, part_count, n_parts, raw, cap, ctr);
 }

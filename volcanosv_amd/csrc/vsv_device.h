@@ -21,7 +21,7 @@ enum : uint32_t {
 
 // One cache line of device counters, zeroed at the start of every run.
 struct Counters {
-  uint32_t n_pool;     // cigar emit cursor (keeps counting past capacity)
+  uint32_t n_pool;     // rows the emit pool would need (max shard use x shards); > capacity => VSV_E_CAPACITY
   uint32_t n_raw;      // min(n_pool, cap)
   uint32_t n_cand;     // split candidates
   uint32_t n_pairs;    // split pair slots
@@ -100,8 +100,8 @@ int vsv_cigar_parts(int64_t n_ops, int ops_per_part);
 void vsv_scan_u32_exclusive(hipStream_t st, const uint32_t* in, int n, uint32_t* out, uint32_t* tmp);
 void vsv_launch_cigar_scan(hipStream_t st, const RecView& rv, const vsv_params& p, uint32_t* part_rb, int n_parts,
                            int ops_per_part, vsv_sig* pool, uint64_t* pool_key, uint32_t cap, uint32_t* part_count,
-                           uint32_t* part_off, uint32_t* scan_tmp, vsv_sig* raw, Counters* ctr, hipEvent_t ev0,
-                           hipEvent_t ev1);
+                           uint32_t* part_off, uint32_t* scan_tmp, vsv_sig* raw, Counters* ctr, uint32_t* shard_cnt,
+                           hipEvent_t ev0, hipEvent_t ev1);
 
 // sig_stages.hip
 void vsv_launch_fold(hipStream_t st, vsv_sig* raw, vsv_sig* raw_copy, const RecView& rv, int dtype, Counters* ctr);
