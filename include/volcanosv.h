@@ -179,6 +179,22 @@ int vsv_table_fill(vsv_handle* h, int table, void* dst, int64_t cap_rows, int ds
  * with HIP events on the handle's stream. Returns milliseconds in *ms.                            */
 int vsv_last_scan_ms(vsv_handle* h, float* ms);
 
+/* ---- host-side ingest: BAM/BGZF -> record SoA ----------------------------------------------------
+ * Replaces pysam.AlignmentFile(bam).fetch(chr) (H:387-391, RS:108-113). Arrays returned through `out` are owned
+ * by the vsv_bam object and stay valid until the next vsv_bam_load / vsv_bam_close. No index is used. */
+typedef struct vsv_bam vsv_bam;
+int vsv_bam_open(const char* path, vsv_bam** out);
+void vsv_bam_close(vsv_bam* b);
+const char* vsv_bam_error(vsv_bam* b);
+int vsv_bam_n_refs(vsv_bam* b);
+const char* vsv_bam_ref_name(vsv_bam* b, int i);
+int64_t vsv_bam_ref_len(vsv_bam* b, int i);
+int vsv_bam_load(vsv_bam* b, int tid, vsv_records* out);       /* tid < 0: every placed record */
+const char* vsv_bam_qnames(vsv_bam* b, int64_t* len);           /* '\n'-joined names, qid order   */
+const char* vsv_bam_sa_tags(vsv_bam* b, int64_t* len);          /* '\n'-joined SA tags, record order */
+const uint32_t* vsv_bam_l_seq(vsv_bam* b);
+const uint32_t* vsv_bam_sam_flags(vsv_bam* b);
+
 #ifdef __cplusplus
 }
 #endif

@@ -288,6 +288,28 @@ def jsonable(x):
     return x
 
 
+def synth_seq(name, n):
+    """Deterministic pseudo-random ACGT string for a contig / chromosome name (tests regenerate it from the name)."""
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    return "".join(np.array(list("ACGT"))[rng.integers(0, 4, n)])
+
+
+def vcf_digest(lines):
+    """VCF record lines -> compact rows: REF/ALT replaced by (length, crc32)."""
+    import zlib
+    rows = []
+    for l in lines:
+        if l.startswith("#"):
+            continue
+        f = l.rstrip("\n").split("\t")
+        rows.append([f[0], int(f[1]), f[2], len(f[3]), zlib.crc32(f[3].encode()), len(f[4]), zlib.crc32(f[4].encode()), f[5], f[6], f[7], f[8], f[9]])
+    return rows
+
+
+SEQ_LEN = 410000
+
+
 def run_contig(style, recs, stable):
     tie_log = []
     ns = load_functions(SCRIPTS[style], stable, tie_log)
@@ -322,6 +344,19 @@ def run_contig(style, recs, stable):
                 pc["merged_%s" % hp] = jsonable(finals[hp])
             paired = ns["pair_sig"](finals["hp1"], finals["hp2"], 1000, 200, 0.5, 0.5)
             pc["paired"] = jsonable(paired)
+            # write_vcf (H:678-714) with deterministic sequences; contigs named *_both* are absent from the FASTA (H:648)
+            names = sorted({r[2] for r in recs if "both" not in r[2]})
+            ns["dc_contig"] = {n: synth_seq(n, SEQ_LEN) for n in names}
+            ns["ref_seq"] = synth_seq(c, SEQ_LEN)
+            hdr = os.path.join(td, "header")
+            with open(hdr, "w") as fh:
+                fh.write("##fileformat=VCFv4.2\n")
+            ns["header_path"] = hdr
+            if style != "Hifi":   # ONT/CLR load the chromosome with load_seq(ref_path) (O:662,704)
+                ns["load_seq"] = lambda path: ns["ref_seq"]
+            vp = os.path.join(td, "out_%s.vcf" % c)
+            ns["write_vcf"](paired, vp, "ref.fa", "contig.fa")
+            pc["vcf"] = vcf_digest(open(vp).readlines())
             out["per_chrom"][c] = pc
     out["had_ties"] = bool(tie_log)
     return out

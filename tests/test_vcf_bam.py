@@ -1,0 +1,139 @@
+"""Host-side pieces either side of the hot path: BAM ingest (C-ABI, no compute) and VCF text, pinned against the
+reference's own write_vcf output stored in the contig_* fixtures (tests/golden/make_golden.py)."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from helpers import load_fixture
+from volcanosv_amd import bam, vcf
+
+CONTIG = ["contig_hifi_tiefree", "contig_hifi_stable", "contig_ont_tiefree", "contig_clr_tiefree"]
+SEQ_LEN = 410000
+
+
+def synth_seq(name, n=SEQ_LEN):
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    return "".join(np.array(list("ACGT"))[rng.integers(0, 4, n)])
+
+
+def digest(lines):
+    rows = []
+    for l in lines:
+        f = l.rstrip("\n").split("\t")
+        rows.append([f[0], int(f[1]), f[2], len(f[3]), zlib.crc32(f[3].encode()), len(f[4]), zlib.crc32(f[4].encode()), f[5], f[6], f[7], f[8], f[9]])
+    return rows
+
+
+def fixture_inputs(doc):
+    names = sorted({r[2] for r in doc["records"] if "both" not in r[2]})
+    return {n: synth_seq(n) for n in names}
+
+
+@pytest.mark.parametrize("name", CONTIG)
+def test_vcf_lines_match_reference_write_vcf(name):
+    from oracle import oracle
+    doc, soa, dtype = load_fixture(name)
+    st, tabs = oracle.run(soa, dtype=dtype)
+    assert st == 0
+    dc_contig = fixture_inputs(doc)
+    for t, chrom in enumerate(doc["expected"]["chroms"]):
+        calls = tabs["calls"][tabs["calls"]["sig"]["tid"] == t]
+        lines = vcf.vcf_lines(soa, calls, tabs["merged"], synth_seq(chrom), dc_contig)
+        assert digest(lines) == doc["expected"]["per_chrom"][chrom]["vcf"]
+        cols = vcf.integer_columns(lines)
+        assert all(c[4] is None for c in cols)            # Large_INDEL records carry no END key
+
+
+def test_default_header_shape():
+    h = vcf.default_header()
+    assert len(h) == 35 and h[0] == "##fileformat=VCFv4.2\n" and h[13] == "##contig=<ID=chr10,length=135534747>\n"
+    assert h[-1].startswith("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t")
+
+
+def fixture_to_bam(doc, path):
+    chroms = doc["expected"]["chroms"]
+    refs = [(c, SEQ_LEN) for c in chroms]
+    recs = [dict(tid=chroms.index(r[0]), pos=r[1], qname=r[2], mapq=r[3], flag=16 if r[4] else 0, cigar=[tuple(c) for c in r[5]])
+            for r in doc["records"]]
+    bam.write_bam(path, refs, recs)
+
+
+def test_bam_ingest_roundtrip(tmp_path):
+    doc, soa, _ = load_fixture("contig_hifi_tiefree")
+    p = str(tmp_path / "x.bam")
+    fixture_to_bam(doc, p)
+    got = bam.read_bam(p)
+    for k in ("pos", "tid", "qid", "cigar_off", "mapq", "flag", "cigar"):
+        assert np.array_equal(getattr(soa, k), getattr(got, k)), k
+    assert got.tid_names == doc["expected"]["chroms"]
+    one = bam.read_bam(p, "chr2")
+    assert one.n_records == int((soa.tid == 1).sum()) and set(one.tid) == {1}
+    with pytest.raises(KeyError):
+        bam.read_bam(p, "chrZ")
+
+
+def test_bam_long_cigar_and_sa_tag(tmp_path):
+    cig = [(0, 3), (1, 1)] * 40000 + [(0, 5)]             # 80 001 ops > 65535: CG:B,I tag
+    recs = [dict(tid=0, pos=7, qname="ctg_hp1_long", mapq=60, flag=0, cigar=cig, seq_len=10),
+            dict(tid=0, pos=9, qname="r2", mapq=3, flag=0x810, cigar=[(4, 5), (0, 5)], tags={b"SA": "chr1,8,+,5M5S,60,0;"})]
+    p = str(tmp_path / "l.bam")
+    bam.write_bam(p, [("chr1", 1000000)], recs)
+    s = bam.read_bam(p, "chr1")
+    assert s.n_records == 2 and int(s.cigar_off[1]) == len(cig)
+    assert [(int(w) & 15, int(w) >> 4) for w in s.cigar[:4]] == cig[:4]
+    assert s.sa_tags == ["", "chr1,8,+,5M5S,60,0;"]
+    assert s.flag[1] & 1 and s.flag[1] & 2 and s.flag[0] & 4      # reverse, supplementary, hp1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,style", [("contig_hifi_tiefree", "Hifi"), ("contig_ont_tiefree", "ONT"), ("contig_clr_tiefree", "CLR")])
+def test_cli_plumbing_config1(tmp_path, name, style):
+    """BASELINE config 1 plumbing: BAM + contig FASTA + reference FASTA -> extract_contig_signature_<dtype>.py (CLI,
+    same flags as the reference) -> volcano_variant_chr<N>.vcf identical to the reference's write_vcf output."""
+    import subprocess
+    import sys
+    doc, soa, _ = load_fixture(name)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    b = str(tmp_path / "contigs.sorted.bam")
+    fixture_to_bam(doc, b)
+    with open(tmp_path / "contigs.fa", "w") as f:
+        for n, s in fixture_inputs(doc).items():
+            f.write(">%s\n%s\n" % (n, s))
+    with open(tmp_path / "ref.fa", "w") as f:
+        for c in doc["expected"]["chroms"]:
+            f.write(">%s\n%s\n" % (c, synth_seq(c)))
+    hdr = tmp_path / "header"
+    hdr.write_text("".join(vcf.default_header()))
+    for i, chrom in enumerate(doc["expected"]["chroms"]):
+        ref = tmp_path / "ref.fa"
+        if style != "Hifi":                      # ONT/CLR take a single-chromosome FASTA (O:653-662)
+            ref = tmp_path / ("ref_%s.fa" % chrom)
+            ref.write_text(">%s\n%s\n" % (chrom, synth_seq(chrom)))
+        cmd = [sys.executable, os.path.join(root, "volcanosv_amd", "cli", "extract_contig_signature_%s.py" % style),
+               "-bam", b, "-contig", str(tmp_path / "contigs.fa"), "-header", str(hdr), "-ref", str(ref), "-o", str(tmp_path / "out"),
+               "-chr", str(i + 1)]
+        subprocess.check_call(cmd)
+        lines = open(tmp_path / "out" / ("volcano_variant_chr%d.vcf" % (i + 1))).readlines()
+        assert lines[:35] == vcf.default_header()
+        assert digest(lines[35:]) == doc["expected"]["per_chrom"][chrom]["vcf"]
+
+
+@pytest.mark.gpu
+def test_cli_reads_signature(tmp_path):
+    import subprocess
+    import sys
+    doc, soa, _ = load_fixture("reads_tiefree")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    chroms = doc["expected"]["chroms"]
+    recs = [dict(tid=chroms.index(r[0]), pos=r[1], qname=r[2], mapq=r[3], flag=16 if r[4] else 0, cigar=[tuple(c) for c in r[5]])
+            for r in doc["records"]]
+    b = str(tmp_path / "reads.bam")
+    bam.write_bam(b, [(c, 1000000) for c in chroms], recs)
+    for i, chrom in enumerate(chroms):
+        subprocess.check_call([sys.executable, os.path.join(root, "volcanosv_amd", "cli", "extract_reads_signature.py"),
+                               "-i", b, "-o", str(tmp_path / "out"), "-chr", str(i + 1)])
+        got = [l.rstrip("\n").split("\t") for l in open(tmp_path / "out" / "reads_signature" / ("%s_reads_sig.txt" % chrom))]
+        want = [[str(x) for x in row] for row in doc["expected"]["per_chrom"][chrom]["merged"]]
+        assert got == want

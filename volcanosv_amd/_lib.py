@@ -19,6 +19,8 @@ SYMBOLS = [
     "vsv_default_params", "vsv_reserve", "vsv_cigar_scan", "vsv_split_pairs", "vsv_sort_cluster", "vsv_merge_sources",
     "vsv_pair_haplotypes", "vsv_run_chromosome", "vsv_run_chromosome_async", "vsv_finish", "vsv_table_count",
     "vsv_table_fill", "vsv_last_scan_ms",
+    "vsv_bam_open", "vsv_bam_close", "vsv_bam_error", "vsv_bam_n_refs", "vsv_bam_ref_name", "vsv_bam_ref_len", "vsv_bam_load",
+    "vsv_bam_qnames", "vsv_bam_sa_tags", "vsv_bam_l_seq", "vsv_bam_sam_flags",
 ]
 
 
@@ -61,8 +63,29 @@ def load():
     lib.vsv_table_fill.argtypes = [H, C.c_int, C.c_void_p, C.c_int64, C.c_int]
     lib.vsv_last_scan_ms.argtypes = [H, C.POINTER(C.c_float)]
     for name in SYMBOLS:
-        if name not in ("vsv_destroy", "vsv_last_error", "vsv_last_count", "vsv_status_string"):
+        if name not in ("vsv_destroy", "vsv_last_error", "vsv_last_count", "vsv_status_string") and not name.startswith("vsv_bam"):
             getattr(lib, name).restype = C.c_int
+    B = C.c_void_p
+    lib.vsv_bam_open.argtypes = [C.c_char_p, C.POINTER(B)]
+    lib.vsv_bam_open.restype = C.c_int
+    lib.vsv_bam_close.argtypes = [B]
+    lib.vsv_bam_close.restype = None
+    lib.vsv_bam_error.argtypes = [B]
+    lib.vsv_bam_error.restype = C.c_char_p
+    lib.vsv_bam_n_refs.argtypes = [B]
+    lib.vsv_bam_n_refs.restype = C.c_int
+    lib.vsv_bam_ref_name.argtypes = [B, C.c_int]
+    lib.vsv_bam_ref_name.restype = C.c_char_p
+    lib.vsv_bam_ref_len.argtypes = [B, C.c_int]
+    lib.vsv_bam_ref_len.restype = C.c_int64
+    lib.vsv_bam_load.argtypes = [B, C.c_int, C.POINTER(Records)]
+    lib.vsv_bam_load.restype = C.c_int
+    for name in ("vsv_bam_qnames", "vsv_bam_sa_tags"):
+        getattr(lib, name).argtypes = [B, C.POINTER(C.c_int64)]
+        getattr(lib, name).restype = C.c_void_p
+    for name in ("vsv_bam_l_seq", "vsv_bam_sam_flags"):
+        getattr(lib, name).argtypes = [B]
+        getattr(lib, name).restype = C.c_void_p
     if lib.vsv_abi_version() != ABI_VERSION:
         raise ImportError("ABI mismatch: library %d, python %d" % (lib.vsv_abi_version(), ABI_VERSION))
     _lib = lib

@@ -1,0 +1,132 @@
+"""BAM <-> record SoA on the host.
+
+`read_bam` is the replacement of `pysam.AlignmentFile(path).fetch(chrom)` in the reference
+(extract_contig_signature_Hifi.py:387-391, extract_reads_signature.py:108-113): it goes through the C-ABI ingest
+(vsv_bam_open / vsv_bam_load, BGZF inflate + record parse in native code) and returns a RecordSoA plus the name tables.
+`write_bam` is a small pure-Python BAM writer used to build test inputs (no samtools / pysam in this image).
+"""
+import ctypes as C
+import struct
+import zlib
+
+import numpy as np
+
+from . import _lib
+from .abi import Records, VsvError
+from .soa import RecordSoA
+
+
+class BamFile:
+    def __init__(self, path):
+        self.lib = _lib.load()
+        self.h = C.c_void_p()
+        st = self.lib.vsv_bam_open(str(path).encode(), C.byref(self.h))
+        if st:
+            raise VsvError(st, "cannot open BAM %s" % path)
+        n = self.lib.vsv_bam_n_refs(self.h)
+        self.references = [self.lib.vsv_bam_ref_name(self.h, i).decode() for i in range(n)]
+        self.lengths = [int(self.lib.vsv_bam_ref_len(self.h, i)) for i in range(n)]
+
+    def close(self):
+        if self.h:
+            self.lib.vsv_bam_close(self.h)
+            self.h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def get_tid(self, name):
+        return self.references.index(name) if name in self.references else -1
+
+    def fetch_soa(self, chrom=None):
+        """All records of `chrom` (or of every reference) in file order as a RecordSoA (arrays are copied out of the
+        ingest object). soa.sa_tags[i] is the SA tag text of record i ('' if absent)."""
+        tid = -1 if chrom is None else self.get_tid(chrom)
+        if chrom is not None and tid < 0:
+            raise KeyError("reference %r not in BAM header" % chrom)
+        r = Records()
+        st = self.lib.vsv_bam_load(self.h, tid, C.byref(r))
+        if st:
+            raise VsvError(st, self.lib.vsv_bam_error(self.h).decode())
+        n, nops = int(r.n_records), int(r.n_ops)
+
+        def arr(ptr, count, dt):
+            if count == 0:
+                return np.zeros(0, dtype=dt)
+            return np.frombuffer((C.c_char * (count * np.dtype(dt).itemsize)).from_address(ptr), dtype=dt, count=count).copy()
+
+        ln = C.c_int64()
+        p = self.lib.vsv_bam_qnames(self.h, C.byref(ln))
+        qnames = C.string_at(p, ln.value).decode().split("\n") if ln.value else []
+        p = self.lib.vsv_bam_sa_tags(self.h, C.byref(ln))
+        sa = C.string_at(p, ln.value).decode().split("\n") if n else []
+        if len(sa) < n:
+            sa += [""] * (n - len(sa))
+        soa = RecordSoA(arr(r.pos, n, np.int32), arr(r.tid, n, np.int32), arr(r.qid, n, np.uint32),
+                        arr(r.cigar_off, n + 1, np.uint64) if n else np.zeros(1, np.uint64), arr(r.mapq, n, np.uint8),
+                        arr(r.flag, n, np.uint8), arr(r.cigar, nops, np.uint32), qnames, self.references)
+        soa.n_tids = len(self.references)
+        soa.sa_tags = sa
+        soa.l_seq = arr(self.lib.vsv_bam_l_seq(self.h), n, np.uint32)
+        soa.sam_flags = arr(self.lib.vsv_bam_sam_flags(self.h), n, np.uint32)
+        return soa
+
+
+def read_bam(path, chrom=None):
+    with BamFile(path) as b:
+        return b.fetch_soa(chrom)
+
+
+# ---- minimal writer (tests / synthetic plumbing inputs) ------------------------------------------------------------
+def _bgzf_block(data):
+    comp = zlib.compressobj(6, zlib.DEFLATED, -15)
+    c = comp.compress(data) + comp.flush()
+    bsize = len(c) + 25
+    return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize) + c +
+            struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data)))
+
+
+def _reg2bin(beg, end):
+    end -= 1
+    for shift, off in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+        if beg >> shift == end >> shift:
+            return off + (beg >> shift)
+    return 0
+
+
+def write_bam(path, references, records, header_text=None):
+    """references: [(name, length)]; records: iterable of dicts with keys tid, pos, qname, mapq, flag (SAM flag),
+    cigar [(op,len)], optional seq_len (bases are written as 'N'; 0 => '*'), optional tags {b'SA': 'text'}."""
+    if header_text is None:
+        header_text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % (n, l) for n, l in references)
+    out = bytearray()
+    ht = header_text.encode()
+    out += b"BAM\x01" + struct.pack("<i", len(ht)) + ht + struct.pack("<i", len(references))
+    for name, length in references:
+        nm = name.encode() + b"\x00"
+        out += struct.pack("<i", len(nm)) + nm + struct.pack("<i", length)
+    for r in records:
+        qn = r["qname"].encode() + b"\x00"
+        cig = r["cigar"]
+        ref_len = sum(l for op, l in cig if op in (0, 2, 3, 7, 8))
+        l_seq = int(r.get("seq_len", 0))
+        long_cigar = len(cig) > 65535
+        cig_words = [(l << 4) | op for op, l in cig]
+        tags = b""
+        if long_cigar:  # htslib convention: placeholder CIGAR kSmN + real CIGAR in CG:B,I
+            tags += b"CGBI" + struct.pack("<I", len(cig_words)) + struct.pack("<%dI" % len(cig_words), *cig_words)
+            cig_words = [(l_seq << 4) | 4, (ref_len << 4) | 3]
+        for k, v in (r.get("tags") or {}).items():
+            tags += k + b"Z" + v.encode() + b"\x00"
+        body = struct.pack("<iiBBHHHiiii", r["tid"], r["pos"], len(qn), r["mapq"], _reg2bin(r["pos"], r["pos"] + max(ref_len, 1)),
+                           len(cig_words), r["flag"], l_seq, -1, -1, 0)
+        body += qn + struct.pack("<%dI" % len(cig_words), *cig_words)
+        body += b"\xff" * ((l_seq + 1) // 2) + b"\xff" * l_seq + tags
+        out += struct.pack("<i", len(body)) + body
+    with open(path, "wb") as f:
+        for i in range(0, len(out), 60000):
+            f.write(_bgzf_block(bytes(out[i:i + 60000])))
+        f.write(_bgzf_block(b""))  # EOF marker

@@ -10,7 +10,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["cigar_scan.hip", "radix_sort.hip", "sig_stages.hip", "capi.hip"]
+SOURCES = ["cigar_scan.hip", "radix_sort.hip", "sig_stages.hip", "capi.hip", "bam_ingest.cc"]
 LIB = os.path.join(HERE, "libvolcanosv_hip.so")
 # -ffp-contract=off: the ONT/CLR split rule compares fp64 products exactly as CPython does
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
@@ -39,7 +39,7 @@ def build(force=False, verbose=False, extra=()):
     os.makedirs(bdir, exist_ok=True)
     procs = []
     for src in SOURCES:
-        obj = os.path.join(bdir, src.replace(".hip", ".o"))
+        obj = os.path.join(bdir, src.replace(".hip", ".o").replace(".cc", ".o"))
         cmd = [hipcc()] + FLAGS + list(extra) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
@@ -48,7 +48,7 @@ def build(force=False, verbose=False, extra=()):
     for p, cmd in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lz"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

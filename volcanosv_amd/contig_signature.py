@@ -1,0 +1,42 @@
+"""Host driver of the contig path: the per-chromosome body of extract_contig_signature_<dtype>.py
+(reference Large_INDEL/extract_contig_signature_Hifi.py:725-772) on top of the HIP engine."""
+import os
+
+from . import vcf
+from .abi import DTYPE_BY_NAME
+from .bam import BamFile
+from .engine import Engine, default_params
+
+
+def run(dtype_name, bam_path, contig_path, ref_path, output_dir, chr_number=None, header_path=None, params=None, device=0,
+        engine=None, log=print):
+    """Writes <output_dir>/volcano_variant_chr<N>.vcf for chr_number (or chr1..22, H:729-742). Returns {chrom: lines}."""
+    dtype = DTYPE_BY_NAME[dtype_name]
+    os.makedirs(os.path.join(output_dir, "signature"), exist_ok=True)          # H:717-718
+    dc_contig = vcf.load_contigs(contig_path)
+    dc_ref = vcf.load_contigs(ref_path)
+    if header_path:
+        with open(header_path) as f:
+            header = f.readlines()
+    else:
+        header = vcf.default_header()
+    chroms = [chr_number] if chr_number is not None else list(range(1, 23))
+    eng = engine or Engine(device)
+    p = params or default_params(dtype)
+    out = {}
+    with BamFile(bam_path) as bam:
+        for i in chroms:
+            name = "chr%d" % i
+            if bam.get_tid(name) < 0:
+                raise KeyError("%s not in the BAM header" % name)
+            soa = bam.fetch_soa(name)
+            eng.run(soa, p)
+            calls, merged = eng.table("calls"), eng.table("merged")
+            ref_seq = dc_ref[name] if name in dc_ref else next(iter(dc_ref.values()))   # ONT/CLR: single-chromosome FASTA (O:653-662)
+            lines = vcf.vcf_lines(soa, calls, merged, ref_seq, dc_contig)
+            vcf.write_vcf(os.path.join(output_dir, "volcano_variant_chr%d.vcf" % i), header, lines)
+            log("%s: %d records -> %d calls (%d written)" % (name, soa.n_records, len(calls), len(lines)))
+            out[name] = lines
+    if engine is None:
+        eng.close()
+    return out

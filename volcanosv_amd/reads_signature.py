@@ -1,0 +1,27 @@
+"""Host driver of the reads path: extract_reads_signature.py (reference Large_INDEL/extract_reads_signature.py:268-286)."""
+import os
+
+from . import sigtable
+from .abi import DTYPE_READS
+from .bam import BamFile
+from .engine import Engine, default_params
+
+
+def run(input_path, output_dir, chr_number, device=0, engine=None, params=None):
+    """Writes <output_dir>/reads_signature/chr<N>_reads_sig.txt (RS:251-265): tab-joined str() fields, sorted by pos."""
+    chrom = "chr%d" % chr_number
+    out_dir = os.path.join(output_dir, "reads_signature")
+    os.makedirs(out_dir, exist_ok=True)
+    eng = engine or Engine(device)
+    p = params or default_params(DTYPE_READS)
+    with BamFile(input_path) as bam:
+        soa = bam.fetch_soa(chrom)
+    eng.run(soa, p)
+    rows = [sigtable.sig_fields(soa, s, DTYPE_READS) for s in eng.table("reads")]
+    path = os.path.join(out_dir, chrom + "_reads_sig.txt")
+    with open(path, "w") as f:
+        for r in rows:
+            f.write("\t".join(str(x) for x in r) + "\n")
+    if engine is None:
+        eng.close()
+    return path, rows
