@@ -59,7 +59,7 @@ def main():
     chrom_len, n_rec = int(index[rank, 0]), int(index[rank, 1])
     # synthetic shard generated directly in HBM (torch CUDA generator = Philox); tid = rank
     t, nq, _ = synth.generate(n_rec, args.shape, seed=20250328 + config_idx + 1000 * rank, tid=rank, chrom_len=chrom_len, device=dev)
-    recs = DeviceRecords(t, nq, world)
+    recs = DeviceRecords(t, nq, world, max_pos=chrom_len + 200000)   # the reference index carries the contig length
     eng = Engine(local_rank, stream=torch.cuda.current_stream().cuda_stream, max_sigs=args.max_sigs)
     p = default_params(dtype)
 

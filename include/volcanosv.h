@@ -73,7 +73,7 @@ typedef struct vsv_records {
   int32_t on_device;           /* 0: host pointers (library uploads), 1: device pointers           */
   int32_t n_qids;              /* number of distinct qids (max qid + 1); 0 = unknown (<= n_records)  */
   int32_t n_tids;              /* max tid + 1; 0 = unknown (16 key bits are reserved for it)       */
-  int32_t reserved;
+  int32_t max_pos;             /* upper bound of pos (e.g. contig length); 0 = unknown. Only trims sort passes. */
 } vsv_records;
 
 /* ---- parameters; defaults equal the hard-coded reference values ----------------------------- */

@@ -37,7 +37,7 @@ class Records(C.Structure):
         ("n_records", C.c_int64), ("n_ops", C.c_int64),
         ("pos", C.c_void_p), ("tid", C.c_void_p), ("qid", C.c_void_p), ("cigar_off", C.c_void_p),
         ("mapq", C.c_void_p), ("flag", C.c_void_p), ("cigar", C.c_void_p),
-        ("on_device", C.c_int32), ("n_qids", C.c_int32), ("n_tids", C.c_int32), ("reserved", C.c_int32),
+        ("on_device", C.c_int32), ("n_qids", C.c_int32), ("n_tids", C.c_int32), ("max_pos", C.c_int32),
     ]
 
 

@@ -44,6 +44,7 @@ struct vsv_handle {
   // state
   RecView rv{};
   int n_tids = 0;
+  int64_t max_pos = 0;
   vsv_params prm{};
   int stage_done = 0;     // 0 none, 1 scan, 2 split, 3 sort_cluster, 4 merge, 5 pair
   bool pending = false;   // work enqueued, counters not read back
@@ -146,6 +147,7 @@ int bind_records(vsv_handle* h, const vsv_records* r) {
   }
   h->rv = v;
   h->n_tids = r->n_tids;
+  h->max_pos = r->max_pos > 0 ? r->max_pos : 0;
   int st = reserve(h, r->n_records, r->n_ops, h->cap_sigs > 0 ? h->cap_sigs : (1 << 22));
   if (st) return st;
   // split hash table: >= 2 slots per (qid, hap)
@@ -163,7 +165,9 @@ SortWork sort_work(vsv_handle* h) {
 }
 StageBufs stage_bufs(vsv_handle* h) { return StageBufs{(uint64_t*)h->key.p, (uint32_t*)h->idx.p, (int32_t*)h->cl.p}; }
 Counters* dctr(vsv_handle* h) { return (Counters*)h->ctr.p; }
-int key_bits(vsv_handle* h) { return 35 + bits_for((uint64_t)(h->n_tids > 0 ? h->n_tids : 65536) + 1) + 1; }
+int pos_bits(vsv_handle* h) { return h->max_pos > 0 ? bits_for((uint64_t)h->max_pos + VSV_POS_BIAS + 2) : 32; }
+int tid_bits(vsv_handle* h) { return bits_for((uint64_t)(h->n_tids > 0 ? h->n_tids : 65536) + 1); }
+int key_bits(vsv_handle* h) { return pos_bits(h) + 3 + tid_bits(h) + 1; }   // +1: dead keys (all ones) sort last
 
 bool is_contig(int dtype) { return dtype == VSV_DTYPE_HIFI || dtype == VSV_DTYPE_ONT || dtype == VSV_DTYPE_CLR; }
 
@@ -192,9 +196,9 @@ int enq_split(vsv_handle* h) {
                    (uint32_t*)h->oval.p, sort_work(h), (vsv_sig*)h->s1in.p, (uint32_t)h->cap_sigs, dctr(h));
   if (p.dtype == VSV_DTYPE_READS) {
     // reads.py:281-286 merge_all: one stable sort of [del_cigar, ins_cigar, del_split, ins_split] by pos
-    const int nbits = 34 + bits_for((uint64_t)(h->n_tids > 0 ? h->n_tids : 65536) + 1) + 1;
-    vsv_launch_sort_stage(st, (vsv_sig*)h->s1in.p, &dctr(h)->n_s1, 5, nbits, (vsv_sig*)h->reads.p, &dctr(h)->n_reads,
-                          stage_bufs(h), sort_work(h), h->cap_sigs);
+    const int nbits = pos_bits(h) + 2 + tid_bits(h) + 1;
+    vsv_launch_sort_stage(st, (vsv_sig*)h->s1in.p, &dctr(h)->n_s1, 5, pos_bits(h), nbits, (vsv_sig*)h->reads.p, &dctr(h)->n_reads,
+                          stage_bufs(h), sort_work(h), h->cap_sigs, dctr(h));
   }
   HIPCHK(h, hipGetLastError());
   h->stage_done = 2;
@@ -204,9 +208,9 @@ int enq_split(vsv_handle* h) {
 int enq_stage1(vsv_handle* h) {
   hipStream_t st = h->stream;
   Counters* c = dctr(h);
-  vsv_launch_sort_stage(st, (vsv_sig*)h->s1in.p, &c->n_s1, 1, key_bits(h), (vsv_sig*)h->s1s.p, &c->n_alive1, stage_bufs(h),
-                        sort_work(h), h->cap_sigs);
-  vsv_launch_cluster(st, (vsv_sig*)h->s1s.p, &c->n_alive1, h->prm.cluster_shift, (vsv_sig*)h->c1.p, stage_bufs(h));
+  vsv_launch_sort_stage(st, (vsv_sig*)h->s1in.p, &c->n_s1, 1, pos_bits(h), key_bits(h), (vsv_sig*)h->s1s.p, &c->n_alive1, stage_bufs(h),
+                        sort_work(h), h->cap_sigs, dctr(h));
+  vsv_launch_cluster(st, (vsv_sig*)h->s1s.p, &c->n_alive1, h->prm.cluster_shift, pos_bits(h), (vsv_sig*)h->c1.p, stage_bufs(h));
   HIPCHK(h, hipGetLastError());
   h->stage_done = 3;
   return 0;
@@ -215,11 +219,11 @@ int enq_stage1(vsv_handle* h) {
 int enq_merge(vsv_handle* h) {
   hipStream_t st = h->stream;
   Counters* c = dctr(h);
-  vsv_launch_sort_stage(st, (vsv_sig*)h->c1.p, &c->n_alive1, 2, key_bits(h), (vsv_sig*)h->s2s.p, &c->n_alive2, stage_bufs(h),
-                        sort_work(h), h->cap_sigs);
-  vsv_launch_cluster(st, (vsv_sig*)h->s2s.p, &c->n_alive2, h->prm.cluster_shift, (vsv_sig*)h->c2.p, stage_bufs(h));
-  vsv_launch_sort_stage(st, (vsv_sig*)h->c2.p, &c->n_alive2, 3, key_bits(h), (vsv_sig*)h->merged.p, &c->n_alive3, stage_bufs(h),
-                        sort_work(h), h->cap_sigs);
+  vsv_launch_sort_stage(st, (vsv_sig*)h->c1.p, &c->n_alive1, 2, pos_bits(h), key_bits(h), (vsv_sig*)h->s2s.p, &c->n_alive2, stage_bufs(h),
+                        sort_work(h), h->cap_sigs, dctr(h));
+  vsv_launch_cluster(st, (vsv_sig*)h->s2s.p, &c->n_alive2, h->prm.cluster_shift, pos_bits(h), (vsv_sig*)h->c2.p, stage_bufs(h));
+  vsv_launch_sort_stage(st, (vsv_sig*)h->c2.p, &c->n_alive2, 3, pos_bits(h), key_bits(h), (vsv_sig*)h->merged.p, &c->n_alive3, stage_bufs(h),
+                        sort_work(h), h->cap_sigs, dctr(h));
   HIPCHK(h, hipGetLastError());
   h->stage_done = 4;
   return 0;
@@ -229,7 +233,7 @@ int enq_pair(vsv_handle* h) {
   hipStream_t st = h->stream;
   Counters* c = dctr(h);
   vsv_launch_pair(st, (vsv_sig*)h->merged.p, &c->n_alive3, h->prm.pair_shift, (vsv_call*)h->calls_tmp.p, (vsv_call*)h->calls.p,
-                  &c->n_calls, stage_bufs(h), (uint64_t*)h->key2.p, (uint32_t*)h->idx2.p, sort_work(h), key_bits(h), h->cap_sigs);
+                  &c->n_calls, stage_bufs(h), (uint64_t*)h->key2.p, (uint32_t*)h->idx2.p, sort_work(h), pos_bits(h), key_bits(h), h->cap_sigs);
   HIPCHK(h, hipGetLastError());
   h->stage_done = 5;
   return 0;
@@ -251,7 +255,7 @@ int finish(vsv_handle* h) {
     return fail(h, VSV_E_CAPACITY, b);
   }
   if (e & ERRB_EMPTY_CIGAR) return fail(h, VSV_E_EMPTY_CIGAR, "record with no CIGAR ops / cigar_off not increasing");
-  if (e & ERRB_RANGE) return fail(h, VSV_E_INVALID, "a batch of 64 records spans >= 2^31 CIGAR ops");
+  if (e & ERRB_RANGE) return fail(h, VSV_E_INVALID, "a part spans >= 2^30 CIGAR ops, or a position exceeds the max_pos hint");
   if (e & ERRB_REFEND) return fail(h, VSV_E_REFEND, "N/=/X op in an eligible record on the contig path (offset_ref != reference_end)");
   if (e & ERRB_ZERODIV) return fail(h, VSV_E_ZERODIV, "CLR gate on a record without M ops");
   if (e & ERRB_UNSORTED) return fail(h, VSV_E_UNSORTED, "split pair with pos1 > pos2");
@@ -462,15 +466,29 @@ static int table_read(vsv_handle* h, int table, std::vector<char>& host, int64_t
 }
 
 int vsv_table_count(vsv_handle* h, int table, int64_t* n_rows) {
-  if (!n_rows) return VSV_E_INVALID;
-  std::vector<char> host; size_t row;
+  if (!n_rows || !h) return VSV_E_INVALID;
+  if (h->pending) { int st = finish(h); if (st) return st; }
+  const void* src; int64_t n; size_t row; bool filter;
+  int st = table_src(h, table, &src, &n, &row, &filter);
+  if (st) return fail(h, st, "table not available at this stage");
+  if (!filter) { *n_rows = n; return 0; }      // live tables: the device counter is the row count
+  std::vector<char> host;
   return table_read(h, table, host, n_rows, &row);
 }
 
 int vsv_table_fill(vsv_handle* h, int table, void* dst, int64_t cap_rows, int dst_on_device) {
-  if (!dst && cap_rows > 0) return VSV_E_INVALID;
-  std::vector<char> host; int64_t n; size_t row;
-  int st = table_read(h, table, host, &n, &row);
+  if (!h || (!dst && cap_rows > 0)) return VSV_E_INVALID;
+  if (h->pending) { int st = finish(h); if (st) return st; }
+  const void* src; int64_t n; size_t row; bool filter;
+  int st = table_src(h, table, &src, &n, &row, &filter);
+  if (st) return fail(h, st, "table not available at this stage");
+  if (!filter) {                                 // straight copy, no staging
+    if (n > cap_rows) { h->last_count = n; return fail(h, VSV_E_CAPACITY, "destination too small"); }
+    if (n) HIPCHK(h, hipMemcpy(dst, src, (size_t)n * row, dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+    return 0;
+  }
+  std::vector<char> host;
+  st = table_read(h, table, host, &n, &row);
   if (st) return st;
   if (n > cap_rows) { h->last_count = n; return fail(h, VSV_E_CAPACITY, "destination too small"); }
   if (n == 0) return 0;

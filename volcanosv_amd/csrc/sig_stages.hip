@@ -314,25 +314,26 @@ __global__ void set_n_s1(Counters* ctr, uint32_t cap) {
 }
 
 // ---- keys / gather / alive count --------------------------------------------------------------------
-__global__ __launch_bounds__(256) void build_keys(const vsv_sig* __restrict__ s, const uint32_t* __restrict__ d_n, int stage,
-                                                  uint64_t* __restrict__ key, uint32_t* __restrict__ idx) {
+__global__ __launch_bounds__(256) void build_keys(const vsv_sig* __restrict__ s, const uint32_t* __restrict__ d_n, int stage, int pb,
+                                                  uint64_t* __restrict__ key, uint32_t* __restrict__ idx, Counters* ctr) {
   const uint32_t n = *d_n;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const vsv_sig v = s[i];
     uint64_t k;
     if (stage == 5) {  // READS final order (reads.py:281-286): (tid,pos) then source, DEL before INS, list order
       k = (v.meta & VSV_M_DEAD) ? VSV_KEY_DEAD
-          : ((uint64_t)(uint32_t)v.tid << 34) | (vsv_upos(v.pos) << 2) | ((v.meta & VSV_M_SPLIT) ? 2u : 0u) | ((v.meta & VSV_M_DEL) ? 0u : 1u);
-    } else k = vsv_key_stage(v, stage);
+          : ((uint64_t)(uint32_t)v.tid << (pb + 2)) | (vsv_kpos(v.pos) << 2) | ((v.meta & VSV_M_SPLIT) ? 2u : 0u) | ((v.meta & VSV_M_DEL) ? 0u : 1u);
+    } else k = vsv_key_stage(v, stage, pb);
+    if (!(v.meta & VSV_M_DEAD) && pb < 32 && (vsv_kpos(v.pos) >> pb) != 0) atomicOr(&ctr->err, ERRB_RANGE);  // max_pos hint too small
     key[i] = k;
     idx[i] = i;
   }
 }
-__global__ __launch_bounds__(256) void build_call_keys(const vsv_call* __restrict__ c, const uint32_t* __restrict__ d_n,
+__global__ __launch_bounds__(256) void build_call_keys(const vsv_call* __restrict__ c, const uint32_t* __restrict__ d_n, int pb,
                                                        uint64_t* __restrict__ key, uint32_t* __restrict__ idx) {
   const uint32_t n = *d_n;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    key[i] = vsv_key_stage(c[i].sig, 4);
+    key[i] = vsv_key_stage(c[i].sig, 4, pb);
     idx[i] = i;
   }
 }
@@ -359,14 +360,14 @@ __global__ __launch_bounds__(256) void count_alive(const uint64_t* __restrict__ 
 // the SEED, representative = first longest member (Hifi.py:236-247). Output row i = representative
 // if i is a seed, dead otherwise, so seed order is preserved.
 __global__ __launch_bounds__(256) void cluster_kernel(const vsv_sig* __restrict__ s, const uint64_t* __restrict__ key,
-                                                      const uint32_t* __restrict__ d_n, int max_shift,
+                                                      const uint32_t* __restrict__ d_n, int max_shift, int pb,
                                                       int32_t* __restrict__ cl, vsv_sig* __restrict__ out) {
   const uint32_t n = *d_n;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const uint64_t lk = key[i] >> 32;
-    if (i > 0 && (key[i - 1] >> 32) == lk && (int64_t)s[i].pos - s[i - 1].pos <= max_shift) continue;  // not a run head
+    const uint64_t lk = key[i] >> pb;
+    if (i > 0 && (key[i - 1] >> pb) == lk && (int64_t)s[i].pos - s[i - 1].pos <= max_shift) continue;  // not a run head
     uint32_t e = i + 1;
-    while (e < n && (key[e] >> 32) == lk && (int64_t)s[e].pos - s[e - 1].pos <= max_shift) ++e;
+    while (e < n && (key[e] >> pb) == lk && (int64_t)s[e].pos - s[e - 1].pos <= max_shift) ++e;
     for (uint32_t k = i; k < e; ++k) cl[k] = -1;
     for (uint32_t a = i; a < e; ++a) {
       if (cl[a] != -1) { out[a] = dead_sig(); continue; }
@@ -400,22 +401,23 @@ __device__ __forceinline__ uint32_t lower_bound_key(const uint64_t* __restrict__
   return lo;
 }
 __global__ __launch_bounds__(256) void pair_kernel(const vsv_sig* __restrict__ m, const uint64_t* __restrict__ key,
-                                                   const uint32_t* __restrict__ d_n, int pair_shift,
+                                                   const uint32_t* __restrict__ d_n, int pair_shift, int pb,
                                                    int32_t* __restrict__ st2, vsv_call* __restrict__ out) {
   const uint32_t n = *d_n;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const vsv_sig me = m[i];
     if (me.meta & VSV_M_HP2) continue;                                  // stretches are led by hp1 rows
-    const uint64_t tk = key[i] >> 35;
-    if (i > 0 && (key[i - 1] >> 34) == (key[i] >> 34) && (int64_t)me.pos - m[i - 1].pos <= 2 * (int64_t)pair_shift) continue;
-    const uint32_t b0 = lower_bound_key(key, n, (tk << 35) | (1ull << 34));
-    const uint32_t b1 = lower_bound_key(key, n, (tk + 1) << 35);
+    const int sh_hap = pb + 2, sh_tid = pb + 3;
+    const uint64_t tk = key[i] >> sh_tid;
+    if (i > 0 && (key[i - 1] >> sh_hap) == (key[i] >> sh_hap) && (int64_t)me.pos - m[i - 1].pos <= 2 * (int64_t)pair_shift) continue;
+    const uint32_t b0 = lower_bound_key(key, n, (tk << sh_tid) | (1ull << sh_hap));
+    const uint32_t b1 = lower_bound_key(key, n, (tk + 1) << sh_tid);
     // first hp2 row of this tid with pos >= pos_i - pair_shift (rows further left can never match)
-    uint32_t jlo = lower_bound_key(key, n, (tk << 35) | (1ull << 34) | vsv_upos((int32_t)max((int64_t)me.pos - pair_shift, (int64_t)INT32_MIN)));
+    uint32_t jlo = lower_bound_key(key, n, (tk << sh_tid) | (1ull << sh_hap) | vsv_kpos((int32_t)max((int64_t)me.pos - pair_shift, (int64_t)-VSV_POS_BIAS)));
     if (jlo < b0) jlo = b0;
     for (uint32_t a = i; a < n; ++a) {
       const vsv_sig s1 = m[a];
-      if ((key[a] >> 34) != (key[i] >> 34)) break;
+      if ((key[a] >> sh_hap) != (key[i] >> sh_hap)) break;
       if (a > i && (int64_t)s1.pos - m[a - 1].pos > 2 * (int64_t)pair_shift) break;
       while (jlo < b1 && (int64_t)s1.pos - m[jlo].pos > pair_shift) ++jlo;
       int32_t mate = -1;
@@ -457,7 +459,7 @@ __global__ void copy_rows(const T* __restrict__ in, const uint32_t* __restrict__
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = in[i];
 }
 
-constexpr int EW_GRID = 512;
+constexpr int EW_GRID = 128;
 
 }  // namespace
 
@@ -499,26 +501,26 @@ void vsv_launch_split(hipStream_t st, const RecView& rv, const vsv_params& p, in
 }
 
 // sort rows `in[0,n)` by the stage key into `sorted`, publish the alive count
-void vsv_launch_sort_stage(hipStream_t st, const vsv_sig* in, const uint32_t* d_n, int stage, int nbits, vsv_sig* sorted,
-                           uint32_t* d_alive, const StageBufs& b, const SortWork& sw, int64_t cap) {
-  build_keys<<<EW_GRID, 256, 0, st>>>(in, d_n, stage, b.key, b.idx);
+void vsv_launch_sort_stage(hipStream_t st, const vsv_sig* in, const uint32_t* d_n, int stage, int pb, int nbits, vsv_sig* sorted,
+                           uint32_t* d_alive, const StageBufs& b, const SortWork& sw, int64_t cap, Counters* ctr) {
+  build_keys<<<EW_GRID, 256, 0, st>>>(in, d_n, stage, pb, b.key, b.idx, ctr);
   vsv_radix_sort_pairs(st, b.key, b.idx, d_n, cap, nbits, sw);
   gather_rows<vsv_sig><<<EW_GRID, 256, 0, st>>>(in, b.idx, d_n, sorted);
   count_alive<<<EW_GRID, 256, 0, st>>>(b.key, d_n, d_alive);
 }
 
-void vsv_launch_cluster(hipStream_t st, const vsv_sig* sorted, const uint32_t* d_alive, int max_shift, vsv_sig* out,
+void vsv_launch_cluster(hipStream_t st, const vsv_sig* sorted, const uint32_t* d_alive, int max_shift, int pb, vsv_sig* out,
                         const StageBufs& b) {
-  cluster_kernel<<<EW_GRID, 256, 0, st>>>(sorted, b.key, d_alive, max_shift, b.cl, out);
+  cluster_kernel<<<EW_GRID, 256, 0, st>>>(sorted, b.key, d_alive, max_shift, pb, b.cl, out);
 }
 
 void vsv_launch_pair(hipStream_t st, const vsv_sig* merged, const uint32_t* d_alive3, int pair_shift, vsv_call* calls_tmp,
                      vsv_call* calls, uint32_t* d_ncalls, const StageBufs& b, uint64_t* key2, uint32_t* idx2,
-                     const SortWork& sw, int nbits, int64_t cap) {
+                     const SortWork& sw, int pb, int nbits, int64_t cap) {
   fill_i32<<<EW_GRID, 256, 0, st>>>(b.cl, -1, d_alive3);
-  pair_kernel<<<EW_GRID, 256, 0, st>>>(merged, b.key, d_alive3, pair_shift, b.cl, calls_tmp);
+  pair_kernel<<<EW_GRID, 256, 0, st>>>(merged, b.key, d_alive3, pair_shift, pb, b.cl, calls_tmp);
   pair_finish<<<EW_GRID, 256, 0, st>>>(merged, d_alive3, b.cl, calls_tmp);
-  build_call_keys<<<EW_GRID, 256, 0, st>>>(calls_tmp, d_alive3, key2, idx2);
+  build_call_keys<<<EW_GRID, 256, 0, st>>>(calls_tmp, d_alive3, pb, key2, idx2);
   vsv_radix_sort_pairs(st, key2, idx2, d_alive3, cap, nbits, sw);
   gather_rows<vsv_call><<<EW_GRID, 256, 0, st>>>(calls_tmp, idx2, d_alive3, calls);
   count_alive<<<EW_GRID, 256, 0, st>>>(key2, d_alive3, d_ncalls);

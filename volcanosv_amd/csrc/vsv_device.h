@@ -50,15 +50,18 @@ struct RecView {
 
 // ---- sort keys: [tid | hap | type | source | pos], list id in the high bits ------------------------
 #define VSV_KEY_DEAD 0xFFFFFFFFFFFFFFFFull
-__host__ __device__ inline uint64_t vsv_upos(int32_t pos) { return (uint32_t)(pos ^ 0x80000000); }
-__host__ __device__ inline uint64_t vsv_key_stage(const vsv_sig& s, int stage) {
+#define VSV_POS_BIAS 65536   // keys order positions >= -65536 (split DEL positions can dip slightly below 0)
+// key = tid << (pb+3) | hap << (pb+2) | type << (pb+1) | source << pb | (pos + bias); pb = position bits of the run
+// (32 without a max_pos hint). Same ORDER as the oracle's keys; only the bit packing differs.
+__host__ __device__ inline uint64_t vsv_kpos(int32_t pos) { return (uint32_t)(pos + VSV_POS_BIAS); }
+__host__ __device__ inline uint64_t vsv_key_stage(const vsv_sig& s, int stage, int pb) {
   if (s.meta & VSV_M_DEAD) return VSV_KEY_DEAD;
   uint64_t hap = (s.meta & VSV_M_HP2) ? 1 : 0, del = (s.meta & VSV_M_DEL) ? 1 : 0, sp = (s.meta & VSV_M_SPLIT) ? 1 : 0;
-  uint64_t k = ((uint64_t)(uint32_t)s.tid << 35) | vsv_upos(s.pos);
-  if (stage == 1) return k | (hap << 34) | (del << 33) | (sp << 32);   // list = (tid,hap,type,src)
-  if (stage == 2) return k | (hap << 34) | (del << 33);                // list = (tid,hap,type)
-  if (stage == 3) return k | (hap << 34);                              // list = (tid,hap)
-  return k;                                                            // (tid,pos)
+  uint64_t k = ((uint64_t)(uint32_t)s.tid << (pb + 3)) | vsv_kpos(s.pos);
+  if (stage == 1) return k | (hap << (pb + 2)) | (del << (pb + 1)) | (sp << pb);   // list = (tid,hap,type,src)
+  if (stage == 2) return k | (hap << (pb + 2)) | (del << (pb + 1));                // list = (tid,hap,type)
+  if (stage == 3) return k | (hap << (pb + 2));                                    // list = (tid,hap)
+  return k;                                                                        // (tid,pos)
 }
 
 // exact integer form of the reference's ratio predicates (SURVEY.md §7 hard part 3):
@@ -108,10 +111,10 @@ void vsv_launch_fold(hipStream_t st, vsv_sig* raw, vsv_sig* raw_copy, const RecV
 void vsv_launch_split(hipStream_t st, const RecView& rv, const vsv_params& p, int n_tids, uint32_t* tab, uint32_t tab_size,
                       uint32_t* blk_cnt, uint32_t* blk_off, uint32_t* scan_tmp, uint64_t* ckey, uint32_t* crec,
                       uint64_t* okey, uint32_t* oval, const SortWork& sw, vsv_sig* s1in, uint32_t cap, Counters* ctr);
-void vsv_launch_sort_stage(hipStream_t st, const vsv_sig* in, const uint32_t* d_n, int stage, int nbits, vsv_sig* sorted,
-                           uint32_t* d_alive, const StageBufs& b, const SortWork& sw, int64_t cap);
-void vsv_launch_cluster(hipStream_t st, const vsv_sig* sorted, const uint32_t* d_alive, int max_shift, vsv_sig* out,
+void vsv_launch_sort_stage(hipStream_t st, const vsv_sig* in, const uint32_t* d_n, int stage, int pb, int nbits, vsv_sig* sorted,
+                           uint32_t* d_alive, const StageBufs& b, const SortWork& sw, int64_t cap, Counters* ctr);
+void vsv_launch_cluster(hipStream_t st, const vsv_sig* sorted, const uint32_t* d_alive, int max_shift, int pb, vsv_sig* out,
                         const StageBufs& b);
 void vsv_launch_pair(hipStream_t st, const vsv_sig* merged, const uint32_t* d_alive3, int pair_shift, vsv_call* calls_tmp,
                      vsv_call* calls, uint32_t* d_ncalls, const StageBufs& b, uint64_t* key2, uint32_t* idx2,
-                     const SortWork& sw, int nbits, int64_t cap);
+                     const SortWork& sw, int pb, int nbits, int64_t cap);

@@ -29,8 +29,9 @@ def default_params(dtype):
 class DeviceRecords:
     """Record SoA already resident in HBM: a dict of torch CUDA tensors (pos,tid,qid,cigar_off,mapq,flag,cigar)."""
 
-    def __init__(self, tensors, n_qids=0, n_tids=0):
+    def __init__(self, tensors, n_qids=0, n_tids=0, max_pos=0):
         self.t = tensors
+        self.max_pos = int(max_pos)
         self.n_records = int(tensors["pos"].numel())
         self.n_ops = int(tensors["cigar"].numel())
         self.n_qids, self.n_tids = int(n_qids), int(n_tids)
@@ -41,6 +42,7 @@ class DeviceRecords:
         for name in ("pos", "tid", "qid", "cigar_off", "mapq", "flag", "cigar"):
             setattr(r, name, C.c_void_p(self.t[name].data_ptr()))
         r.on_device, r.n_qids, r.n_tids = 1, self.n_qids, self.n_tids
+        r.max_pos = self.max_pos
         return r
 
 

@@ -49,6 +49,7 @@ class RecordSoA:
         for name in ("pos", "tid", "qid", "cigar_off", "mapq", "flag", "cigar"):
             setattr(r, name, getattr(self, name).ctypes.data_as(C.c_void_p))
         r.on_device, r.n_qids, r.n_tids = 0, self.n_qids, self.n_tids
+        r.max_pos = int(getattr(self, "max_pos", 0))
         return r
 
     def qname(self, rec):
