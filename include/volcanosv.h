@@ -179,6 +179,64 @@ int vsv_table_fill(vsv_handle* h, int table, void* dst, int64_t cap_rows, int ds
  * with HIP events on the handle's stream. Returns milliseconds in *ms.                            */
 int vsv_last_scan_ms(vsv_handle* h, float* ms);
 
+/* ---- Complex_SV / svim-asm breakend (BND) branch ---------------------------------------------------
+ * Input: split contigs as segment lists — for every primary alignment that has SA-tag alignments passing
+ * min_mapq, the primary + those alignments (SV/SVIM_COLLECT.py:8-54, 67-76) reduced to the six numbers
+ * analyze_read_segments reads (SV/SVIM_inter.py:62-81): q_start/q_end already flipped for reverse strands.
+ * vsv_bnd_segments  replaces the BND branches of analyze_read_segments (SV/SVIM_inter.py:83-258) and the
+ *                   canonical orientation / clamping of CandidateBreakend (SV/SVCandidate.py:350-373);
+ * vsv_bnd_pair      replaces form_partitions + pair_haplotypes_breakends + the BND part of pair_candidates
+ *                   (SV/SVIM_COMBINE.py:15-32, 105-117, 143-161, 334-365). */
+typedef struct vsv_segments {
+  int64_t n_reads;              /* primary alignments with >= 1 good supplementary alignment            */
+  int64_t n_segs;
+  const uint64_t* seg_off;      /* [n_reads+1]; segment 0 of a read is the primary alignment            */
+  const int32_t* q_start;       /* [n_segs] read coordinates, reverse strands already flipped (:68-73)  */
+  const int32_t* q_end;
+  const int32_t* ref_id;
+  const int32_t* ref_start;
+  const int32_t* ref_end;
+  const uint8_t* is_reverse;
+  const uint8_t* hap;           /* [n_reads] 1 = first BAM (hp1), 2 = second BAM (hp2)                  */
+  const int32_t* contig_len;    /* [n_tids] bam.get_reference_length                                    */
+  const int32_t* contig_rank;   /* [n_tids] rank of the contig NAME in Python string order (:352, 'chr10'<'chr2') */
+  int32_t n_tids;
+  int32_t on_device;
+} vsv_segments;
+
+typedef struct vsv_bnd_params {
+  int32_t min_sv_size;                  /* 40      (SV/SVIM_input_parsing.py:162-164) */
+  int32_t max_sv_size;                  /* 100000  */
+  int32_t query_gap_tolerance;          /* 50 */
+  int32_t query_overlap_tolerance;      /* 50 */
+  int32_t reference_gap_tolerance;      /* 50 */
+  int32_t reference_overlap_tolerance;  /* 50 */
+  int32_t partition_max_distance;       /* 1000 (:219-221) */
+  int32_t pair_distance;                /* 900: (|d1|+|d2|)/3000 <= 0.3 (SV/SVIM_COMBINE.py:105-117, 143) */
+  int32_t max_partition;                /* 10: larger partitions are ignored (:151-152) */
+  int32_t reserved[7];
+} vsv_bnd_params;
+
+typedef struct vsv_bnd {       /* 32 bytes */
+  int32_t src_tid, src_pos;    /* CandidateBreakend.source_contig / source_start (0-based) */
+  int32_t dst_tid, dst_pos;
+  uint32_t read;               /* read row (primary alignment) in vsv_segments that produced it        */
+  uint32_t read2;              /* second read of a 1/1 pair, else 0xFFFFFFFF                          */
+  uint32_t meta;               /* VSV_B_* */
+  uint32_t pad;
+} vsv_bnd;
+enum {
+  VSV_B_SRC_FWD = 1, VSV_B_DST_FWD = 2,
+  VSV_B_HAP2 = 4,              /* candidate came from the second BAM                                  */
+  VSV_B_GT_SHIFT = 4,          /* bits 4-5: 1 = "1/0", 2 = "0/1", 3 = "1/1" (calls only)              */
+  VSV_B_DEAD = 64
+};
+enum { VSV_T_BND_CAND = 7, VSV_T_BND_CALLS = 8 };
+
+int vsv_default_bnd_params(vsv_bnd_params* p);
+int vsv_bnd_segments(vsv_handle* h, const vsv_segments* segs, const vsv_bnd_params* p);
+int vsv_bnd_pair(vsv_handle* h, const vsv_bnd_params* p);
+
 /* ---- host-side ingest: BAM/BGZF -> record SoA ----------------------------------------------------
  * Replaces pysam.AlignmentFile(bam).fetch(chr) (H:387-391, RS:108-113). Arrays returned through `out` are owned
  * by the vsv_bam object and stay valid until the next vsv_bam_load / vsv_bam_close. No index is used. */

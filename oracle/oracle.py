@@ -9,7 +9,7 @@ import subprocess
 
 import numpy as np
 
-from volcanosv_amd.abi import CALL_DTYPE, SIG_DTYPE, Params, Records
+from volcanosv_amd.abi import BND_DTYPE, CALL_DTYPE, SIG_DTYPE, BndParams, Params, Records, Segments
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
@@ -38,6 +38,10 @@ def lib():
         _LIB.orc_run.restype = C.c_int
         _LIB.orc_free.argtypes = [C.POINTER(_Out)]
         _LIB.orc_default_params.argtypes = [C.c_int, C.POINTER(Params)]
+        _LIB.orc_default_bnd_params.argtypes = [C.POINTER(BndParams)]
+        _LIB.orc_bnd.argtypes = [C.POINTER(Segments), C.POINTER(BndParams), C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                                 C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        _LIB.orc_bnd_free.argtypes = [C.c_void_p, C.c_void_p]
     return _LIB
 
 
@@ -68,3 +72,21 @@ def run(soa, params=None, dtype=None, literal=False):
     }
     lib().orc_free(C.byref(out))
     return st, tabs
+
+
+def default_bnd_params():
+    p = BndParams()
+    lib().orc_default_bnd_params(C.byref(p))
+    return p
+
+
+def run_bnd(seg, params=None):
+    """BND branch on the host: returns (candidates, calls) as BND_DTYPE arrays."""
+    p = params if params is not None else default_bnd_params()
+    s = seg.as_struct()
+    a, b, na, nb = C.c_void_p(), C.c_void_p(), C.c_int64(), C.c_int64()
+    st = lib().orc_bnd(C.byref(s), C.byref(p), C.byref(a), C.byref(na), C.byref(b), C.byref(nb))
+    assert st == 0
+    cand, calls = _copy(a.value, na.value, BND_DTYPE), _copy(b.value, nb.value, BND_DTYPE)
+    lib().orc_bnd_free(a, b)
+    return cand, calls

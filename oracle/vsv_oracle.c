@@ -579,3 +579,202 @@ int orc_default_params(int dtype, vsv_params* p) {
   p->enable_split = dtype == VSV_DTYPE_SVIM ? 0 : 1;
   return 0;
 }
+
+/* ================================================================================================
+ * svim-asm breakend (BND) branch: analyze_read_segments BND cases (SV/SVIM_inter.py:62-258),
+ * CandidateBreakend canonical form (SV/SVCandidate.py:350-373), form_partitions +
+ * pair_haplotypes_breakends + BND part of pair_candidates (SV/SVIM_COMBINE.py:15-32,105-117,143-161,334-365).
+ * Complete-linkage clustering at 0.3 with a 99999 distance for same-haplotype / different-direction pairs can only
+ * form clusters of one hp1 + one hp2 member, merged in ascending distance order: restated as a greedy matching on
+ * the integer distance |d1|+|d2| <= 900 (ties: lowest member indices first).
+ * ================================================================================================ */
+typedef struct { int32_t q_start, q_end, ref_id, ref_start, ref_end, rev, ord; } orc_seg;
+
+static int seg_cmp(const void* a, const void* b) {
+  const orc_seg* x = (const orc_seg*)a; const orc_seg* y = (const orc_seg*)b;
+  if (x->q_start != y->q_start) return x->q_start < y->q_start ? -1 : 1;
+  if (x->q_end != y->q_end) return x->q_end < y->q_end ? -1 : 1;
+  return x->ord - y->ord;   /* Python sorted() is stable */
+}
+
+static int clampi(int64_t v, int64_t hi) { if (v < 0) v = 0; if (v > hi) v = hi; return (int)v; }
+
+/* CandidateBreakend.__init__ (SV/SVCandidate.py:351-373) */
+static vsv_bnd make_bnd(const vsv_segments* s, int t1, int64_t p1, int d1, int t2, int64_t p2, int d2, uint32_t read, int hap) {
+  vsv_bnd b; memset(&b, 0, sizeof b);
+  int keep = (s->contig_rank[t1] < s->contig_rank[t2]) || (t1 == t2 && p1 < p2);
+  if (keep) {
+    b.src_tid = t1; b.src_pos = clampi(p1, s->contig_len[t1]); b.dst_tid = t2; b.dst_pos = clampi(p2, s->contig_len[t2]);
+    b.meta = (d1 ? VSV_B_SRC_FWD : 0) | (d2 ? VSV_B_DST_FWD : 0);
+  } else {
+    b.src_tid = t2; b.src_pos = clampi(p2, s->contig_len[t2]); b.dst_tid = t1; b.dst_pos = clampi(p1, s->contig_len[t1]);
+    b.meta = (d2 ? 0 : VSV_B_SRC_FWD) | (d1 ? 0 : VSV_B_DST_FWD);   /* both directions flipped */
+  }
+  if (hap == 2) b.meta |= VSV_B_HAP2;
+  b.read = read; b.read2 = 0xFFFFFFFFu;
+  return b;
+}
+
+/* one adjacent pair of the (q_start,q_end)-sorted segment list; returns 1 and fills *out for a BND */
+static int bnd_of_pair(const vsv_segments* s, const vsv_bnd_params* p, const orc_seg* cur, const orc_seg* nxt, uint32_t read, int hap, vsv_bnd* out) {
+  const int64_t QOT = p->query_overlap_tolerance, QGT = p->query_gap_tolerance, ROT = p->reference_overlap_tolerance;
+  const int64_t MINSV = p->min_sv_size, MAXSV = p->max_sv_size;
+  const int64_t dor = (int64_t)nxt->q_start - cur->q_end;
+  const int c1 = cur->ref_id, c2 = nxt->ref_id;
+  if (c1 == c2) {
+    if (cur->rev == nxt->rev) {
+      const int64_t dref = cur->rev ? (int64_t)cur->ref_start - nxt->ref_end : (int64_t)nxt->ref_start - cur->ref_end;
+      if (dor >= -QOT) {
+        if (dref >= -ROT) {
+          const int64_t dev = dor - dref;
+          if (dev >= MINSV) return 0;                               /* INS candidate */
+          if (-MAXSV <= dev && dev <= -MINSV) return 0;             /* DEL candidate */
+          if (dev < -MAXSV && dor <= QGT) {                         /* :131-139 */
+            *out = cur->rev ? make_bnd(s, c1, cur->ref_start, 0, c1, (int64_t)nxt->ref_end - 1, 0, read, hap)
+                            : make_bnd(s, c1, (int64_t)cur->ref_end - 1, 1, c1, nxt->ref_start, 1, read, hap);
+            return 1;
+          }
+        } else if (dor <= QGT) {                                    /* overlap on reference, :141-168 */
+          const int64_t dev = dor - dref;
+          if (dev >= MINSV) {
+            if (!cur->rev) {
+              if (nxt->ref_end > cur->ref_start) return 0;          /* tandem duplication */
+              if (dref >= -MAXSV) return 0;
+              *out = make_bnd(s, c1, (int64_t)cur->ref_end - 1, 1, c1, nxt->ref_start, 1, read, hap); return 1;
+            } else {
+              if (nxt->ref_start < cur->ref_end) return 0;
+              if (dref >= -MAXSV) return 0;
+              *out = make_bnd(s, c1, cur->ref_start, 0, c1, (int64_t)nxt->ref_end - 1, 0, read, hap); return 1;
+            }
+          }
+        }
+      }
+      return 0;
+    }
+    if (!cur->rev && nxt->rev) {                                    /* :171-192 */
+      const int64_t dref = (int64_t)nxt->ref_end - cur->ref_end, dev = dor - dref;
+      if (-QOT <= dor && dor <= QGT) {
+        if ((int64_t)nxt->ref_start - cur->ref_end >= -ROT) {
+          if (MINSV <= -dev && -dev <= MAXSV) return 0;              /* inversion */
+          *out = make_bnd(s, c1, (int64_t)cur->ref_end - 1, 1, c1, (int64_t)nxt->ref_end - 1, 0, read, hap); return 1;
+        } else if ((int64_t)cur->ref_start - nxt->ref_end >= -ROT) {
+          if (MINSV <= dev && dev <= MAXSV) return 0;
+          *out = make_bnd(s, c1, (int64_t)cur->ref_end - 1, 1, c1, (int64_t)nxt->ref_end - 1, 0, read, hap); return 1;
+        }
+      }
+      return 0;
+    }
+    {                                                               /* reverse to normal, :197-219 */
+      const int64_t dref = (int64_t)nxt->ref_start - cur->ref_start, dev = dor - dref;
+      if (-QOT <= dor && dor <= QGT) {
+        if ((int64_t)nxt->ref_start - cur->ref_end >= -ROT) {
+          if (MINSV <= -dev && -dev <= MAXSV) return 0;
+          *out = make_bnd(s, c1, cur->ref_start, 0, c1, nxt->ref_start, 1, read, hap); return 1;
+        } else if ((int64_t)cur->ref_start - nxt->ref_end >= -ROT) {
+          if (MINSV <= dev && dev <= MAXSV) return 0;
+          *out = make_bnd(s, c1, cur->ref_start, 0, c1, nxt->ref_start, 1, read, hap); return 1;
+        }
+      }
+      return 0;
+    }
+  }
+  if (dor >= -QOT && dor <= QGT) {                                  /* different chromosomes, :224-258 */
+    if (cur->rev == nxt->rev)
+      *out = cur->rev ? make_bnd(s, c1, cur->ref_start, 0, c2, (int64_t)nxt->ref_end - 1, 0, read, hap)
+                      : make_bnd(s, c1, (int64_t)cur->ref_end - 1, 1, c2, nxt->ref_start, 1, read, hap);
+    else
+      *out = cur->rev ? make_bnd(s, c1, cur->ref_start, 0, c2, nxt->ref_start, 1, read, hap)
+                      : make_bnd(s, c1, (int64_t)cur->ref_end - 1, 1, c2, (int64_t)nxt->ref_end - 1, 0, read, hap);
+    return 1;
+  }
+  return 0;
+}
+
+typedef struct { vsv_bnd* v; int64_t n, cap; } bndvec;
+static void bv_push(bndvec* b, const vsv_bnd* x) {
+  if (b->n == b->cap) { b->cap = b->cap ? b->cap * 2 : 256; b->v = (vsv_bnd*)realloc(b->v, (size_t)b->cap * sizeof(vsv_bnd)); }
+  b->v[b->n++] = *x;
+}
+
+int orc_default_bnd_params(vsv_bnd_params* p) {
+  memset(p, 0, sizeof *p);
+  p->min_sv_size = 40; p->max_sv_size = 100000; p->query_gap_tolerance = 50; p->query_overlap_tolerance = 50;
+  p->reference_gap_tolerance = 50; p->reference_overlap_tolerance = 50; p->partition_max_distance = 1000;
+  p->pair_distance = 900; p->max_partition = 10;
+  return 0;
+}
+
+/* candidates in (read, pair) order; calls in (partition, first member) order */
+int orc_bnd(const vsv_segments* s, const vsv_bnd_params* p, vsv_bnd** cand_out, int64_t* n_cand, vsv_bnd** calls_out, int64_t* n_calls) {
+  bndvec cand = {0}, calls = {0};
+  for (int64_t r = 0; r < s->n_reads; ++r) {
+    int64_t a = (int64_t)s->seg_off[r], b = (int64_t)s->seg_off[r + 1], n = b - a;
+    if (n < 2) continue;
+    orc_seg* sg = (orc_seg*)malloc((size_t)n * sizeof(orc_seg));
+    for (int64_t k = 0; k < n; ++k) {
+      sg[k].q_start = s->q_start[a + k]; sg[k].q_end = s->q_end[a + k]; sg[k].ref_id = s->ref_id[a + k];
+      sg[k].ref_start = s->ref_start[a + k]; sg[k].ref_end = s->ref_end[a + k]; sg[k].rev = s->is_reverse[a + k] ? 1 : 0; sg[k].ord = (int32_t)k;
+    }
+    qsort(sg, (size_t)n, sizeof(orc_seg), seg_cmp);
+    for (int64_t k = 0; k + 1 < n; ++k) {
+      vsv_bnd x;
+      if (bnd_of_pair(s, p, &sg[k], &sg[k + 1], (uint32_t)r, s->hap[r], &x)) bv_push(&cand, &x);
+    }
+    free(sg);
+  }
+  /* form_partitions: stable sort of hp1 candidates + hp2 candidates by (contig name, source_start) */
+  int64_t n = cand.n;
+  int64_t* idx = (int64_t*)malloc((size_t)(n + 1) * sizeof(int64_t));
+  uint64_t* key = (uint64_t*)malloc((size_t)(n + 1) * sizeof(uint64_t));
+  int64_t m = 0;
+  for (int hap = 0; hap < 2; ++hap)
+    for (int64_t i = 0; i < n; ++i) if (((cand.v[i].meta & VSV_B_HAP2) != 0) == hap) idx[m++] = i;
+  int64_t* order = (int64_t*)malloc((size_t)(n + 1) * sizeof(int64_t));
+  for (int64_t i = 0; i < n; ++i) { const vsv_bnd* c = &cand.v[idx[i]]; key[i] = ((uint64_t)(uint32_t)s->contig_rank[c->src_tid] << 32) | (uint32_t)c->src_pos; order[i] = i; }
+  stable_sort_idx(key, order, n);
+  int64_t lo = 0;
+  while (lo < n) {
+    int64_t hi = lo + 1;
+    while (hi < n) {
+      const vsv_bnd* x = &cand.v[idx[order[hi - 1]]]; const vsv_bnd* y = &cand.v[idx[order[hi]]];
+      int64_t d = (int64_t)x->src_pos - y->src_pos; if (d < 0) d = -d;
+      if (x->src_tid != y->src_tid || d > p->partition_max_distance) break;
+      hi++;
+    }
+    int64_t sz = hi - lo;
+    if (sz <= p->max_partition) {
+      int used[64]; int mate[64];
+      for (int64_t k = 0; k < sz; ++k) { used[k] = 0; mate[k] = -1; }
+      for (;;) {                                   /* greedy matching in ascending distance */
+        int64_t best = -1; int bi = -1, bj = -1;
+        for (int i = 0; i < sz; ++i) for (int j = i + 1; j < sz; ++j) {
+          if (used[i] || used[j]) continue;
+          const vsv_bnd* x = &cand.v[idx[order[lo + i]]]; const vsv_bnd* y = &cand.v[idx[order[lo + j]]];
+          if (((x->meta ^ y->meta) & VSV_B_HAP2) == 0) continue;                       /* same haplotype: 99999 */
+          if ((x->meta ^ y->meta) & (VSV_B_SRC_FWD | VSV_B_DST_FWD)) continue;         /* different directions: 99999 */
+          int64_t d1 = (int64_t)x->src_pos - y->src_pos, d2 = (int64_t)x->dst_pos - y->dst_pos;
+          if (d1 < 0) d1 = -d1; if (d2 < 0) d2 = -d2;
+          if (d1 + d2 > p->pair_distance) continue;
+          if (best < 0 || d1 + d2 < best) { best = d1 + d2; bi = i; bj = j; }
+        }
+        if (bi < 0) break;
+        used[bi] = used[bj] = 1; mate[bi] = bj; mate[bj] = bi;
+      }
+      for (int i = 0; i < sz; ++i) {
+        if (mate[i] >= 0 && mate[i] < i) continue;                                     /* second member of a pair */
+        vsv_bnd c = cand.v[idx[order[lo + i]]];
+        uint32_t gt = mate[i] >= 0 ? 3u : ((c.meta & VSV_B_HAP2) ? 2u : 1u);
+        if (mate[i] >= 0) c.read2 = cand.v[idx[order[lo + mate[i]]]].read;
+        c.meta = (c.meta & ~(3u << VSV_B_GT_SHIFT)) | (gt << VSV_B_GT_SHIFT);
+        bv_push(&calls, &c);
+      }
+    }
+    lo = hi;
+  }
+  free(idx); free(key); free(order);
+  if (!cand.v) cand.v = (vsv_bnd*)malloc(sizeof(vsv_bnd));
+  if (!calls.v) calls.v = (vsv_bnd*)malloc(sizeof(vsv_bnd));
+  *cand_out = cand.v; *n_cand = cand.n; *calls_out = calls.v; *n_calls = calls.n;
+  return 0;
+}
+void orc_bnd_free(vsv_bnd* a, vsv_bnd* b) { free(a); free(b); }

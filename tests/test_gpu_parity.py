@@ -236,3 +236,50 @@ def test_full_size_config2_properties(eng):
     assert_tables_equal(a, want, list(a.keys()))
     del t
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("name", ["bnd_a", "bnd_b"])
+def test_bnd_branch_golden(eng, name):
+    """Complex_SV breakend branch: HIP kernels vs the oracle (bit-exact rows) and vs the svim-asm reference outputs."""
+    from test_bnd_oracle import check_against_golden, load
+    from oracle import oracle
+    doc, seg = load(name)
+    cand, calls = eng.bnd(seg)
+    ocand, ocalls = oracle.run_bnd(seg)
+    assert np.array_equal(cand, ocand) and np.array_equal(calls, ocalls)
+    check_against_golden(doc, seg, cand, calls)
+
+
+def test_bnd_synthetic_config5(eng):
+    """Config-5 shaped stream: many split contigs over 22 chromosomes, hp2 copies jittered by +-300 bp, dense partitions."""
+    from oracle import oracle
+    from volcanosv_amd import bnd
+    rng = np.random.default_rng(5)
+    contigs = [("chr%d" % (i + 1), 50_000_000 + 1_000_000 * i) for i in range(22)]
+    reads = []
+    for e in range(20000):
+        t1, t2 = int(rng.integers(0, 22)), int(rng.integers(0, 22))
+        p1, p2 = int(rng.integers(100000, 40_000_000)), int(rng.integers(100000, 40_000_000))
+        r1, r2 = bool(rng.random() < 0.5), bool(rng.random() < 0.5)
+        L = 40000
+
+        def read(hap, a, b):
+            segs = [[t1, a - 20000, a, 0, 20000, L, 0], [t2, b, b + 20000, 20000, 40000, L, 0]]
+            if r1:
+                segs[0] = [t1, a, a + 20000, L - 20000, L, L, 1]
+            if r2:
+                segs[1] = [t2, b - 20000, b, 0, L - 20000, L, 1]
+            return {"hap": hap, "name": "PS%d_hp%d" % (e, hap), "segs": segs}
+        reads.append(read(1, p1, p2))
+        if rng.random() < 0.8:
+            reads.append(read(2, p1 + int(rng.integers(-300, 301)), p2 + int(rng.integers(-300, 301))))
+        if e % 100 == 0:
+            for k in range(12):
+                reads.append(read(1 + k % 2, p1 + k, p2 + k))
+    reads.sort(key=lambda r: r["hap"])
+    seg = bnd.SegmentSoA(reads, contigs)
+    cand, calls = eng.bnd(seg)
+    ocand, ocalls = oracle.run_bnd(seg)
+    assert len(cand) > 30000 and np.array_equal(cand, ocand) and np.array_equal(calls, ocalls)
+    gts = (calls["meta"] >> 4) & 3
+    assert (gts == 3).sum() > 5000

@@ -7,7 +7,7 @@ from this package.)
 import ctypes as C
 import os
 
-from .abi import ABI_VERSION, Params, Records
+from .abi import ABI_VERSION, BndParams, Params, Records, Segments
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvolcanosv_hip.so")
@@ -18,7 +18,7 @@ SYMBOLS = [
     "vsv_abi_version", "vsv_status_string", "vsv_create", "vsv_destroy", "vsv_last_error", "vsv_last_count",
     "vsv_default_params", "vsv_reserve", "vsv_cigar_scan", "vsv_split_pairs", "vsv_sort_cluster", "vsv_merge_sources",
     "vsv_pair_haplotypes", "vsv_run_chromosome", "vsv_run_chromosome_async", "vsv_finish", "vsv_table_count",
-    "vsv_table_fill", "vsv_last_scan_ms",
+    "vsv_table_fill", "vsv_last_scan_ms", "vsv_default_bnd_params", "vsv_bnd_segments", "vsv_bnd_pair",
     "vsv_bam_open", "vsv_bam_close", "vsv_bam_error", "vsv_bam_n_refs", "vsv_bam_ref_name", "vsv_bam_ref_len", "vsv_bam_load",
     "vsv_bam_qnames", "vsv_bam_sa_tags", "vsv_bam_l_seq", "vsv_bam_sam_flags",
 ]
@@ -62,6 +62,9 @@ def load():
     lib.vsv_table_count.argtypes = [H, C.c_int, C.POINTER(C.c_int64)]
     lib.vsv_table_fill.argtypes = [H, C.c_int, C.c_void_p, C.c_int64, C.c_int]
     lib.vsv_last_scan_ms.argtypes = [H, C.POINTER(C.c_float)]
+    lib.vsv_default_bnd_params.argtypes = [C.POINTER(BndParams)]
+    lib.vsv_bnd_segments.argtypes = [H, C.POINTER(Segments), C.POINTER(BndParams)]
+    lib.vsv_bnd_pair.argtypes = [H, C.POINTER(BndParams)]
     for name in SYMBOLS:
         if name not in ("vsv_destroy", "vsv_last_error", "vsv_last_count", "vsv_status_string") and not name.startswith("vsv_bam"):
             getattr(lib, name).restype = C.c_int

@@ -50,6 +50,27 @@ class Params(C.Structure):
     ]
 
 
+class Segments(C.Structure):
+    _fields_ = [
+        ("n_reads", C.c_int64), ("n_segs", C.c_int64), ("seg_off", C.c_void_p),
+        ("q_start", C.c_void_p), ("q_end", C.c_void_p), ("ref_id", C.c_void_p), ("ref_start", C.c_void_p), ("ref_end", C.c_void_p),
+        ("is_reverse", C.c_void_p), ("hap", C.c_void_p), ("contig_len", C.c_void_p), ("contig_rank", C.c_void_p),
+        ("n_tids", C.c_int32), ("on_device", C.c_int32),
+    ]
+
+
+class BndParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("min_sv_size", "max_sv_size", "query_gap_tolerance", "query_overlap_tolerance",
+                                         "reference_gap_tolerance", "reference_overlap_tolerance", "partition_max_distance",
+                                         "pair_distance", "max_partition")] + [("reserved", C.c_int32 * 7)]
+
+
+BND_DTYPE = np.dtype([("src_tid", "<i4"), ("src_pos", "<i4"), ("dst_tid", "<i4"), ("dst_pos", "<i4"), ("read", "<u4"), ("read2", "<u4"),
+                      ("meta", "<u4"), ("pad", "<u4")])
+B_SRC_FWD, B_DST_FWD, B_HAP2, B_GT_SHIFT, B_DEAD = 1, 2, 4, 4, 64
+T_BND_CAND, T_BND_CALLS = 7, 8
+
+
 class VsvError(RuntimeError):
     """Raised when a C-ABI call returns a negative status. `.status` holds the vsv_status value; the
     reference raises AssertionError / IndexError / ZeroDivisionError at the cited lines instead."""

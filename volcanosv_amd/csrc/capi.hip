@@ -31,6 +31,9 @@ struct vsv_handle {
   std::vector<DevBuf*> all;
   // record upload buffers (host-pointer callers)
   DevBuf r_pos, r_tid, r_qid, r_off, r_mapq, r_flag, r_cigar;
+  DevBuf g_off, g_qs, g_qe, g_rid, g_rs, g_re, g_rev, g_hap, g_len, g_rank;   // segment uploads (BND branch)
+  vsv_segments segs{};
+  int bnd_stage = 0;
   // workspace
   DevBuf part_rb, part_count, part_off, scan_tmp;
   DevBuf pool, pool_key, raw0, s1in, s1s, c1, s2s, c2, merged, calls_tmp, calls, reads;
@@ -335,7 +338,8 @@ void vsv_destroy(vsv_handle* h) {
   DevBuf* bufs[] = {&h->r_pos, &h->r_tid, &h->r_qid, &h->r_off, &h->r_mapq, &h->r_flag, &h->r_cigar, &h->part_rb, &h->part_count,
                     &h->part_off, &h->scan_tmp, &h->pool, &h->pool_key, &h->raw0, &h->s1in, &h->s1s, &h->c1, &h->s2s, &h->c2,
                     &h->merged, &h->calls_tmp, &h->calls, &h->reads, &h->tab, &h->blk_cnt, &h->blk_off, &h->ckey, &h->crec,
-                    &h->okey, &h->oval, &h->key, &h->idx, &h->cl, &h->key2, &h->idx2, &h->key_alt, &h->val_alt, &h->hist, &h->ctr, &h->shard_cnt};
+                    &h->okey, &h->oval, &h->key, &h->idx, &h->cl, &h->key2, &h->idx2, &h->key_alt, &h->val_alt, &h->hist, &h->ctr, &h->shard_cnt, &h->g_off, &h->g_qs, &h->g_qe, &h->g_rid, &h->g_rs,
+                    &h->g_re, &h->g_rev, &h->g_hap, &h->g_len, &h->g_rank};
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
   if (h->pinned) hipHostFree(h->pinned);
   if (h->ev0) hipEventDestroy(h->ev0);
@@ -424,6 +428,59 @@ int vsv_run_chromosome(vsv_handle* h, const vsv_records* recs, const vsv_params*
   return finish(h);
 }
 
+int vsv_default_bnd_params(vsv_bnd_params* p) {
+  if (!p) return VSV_E_INVALID;
+  memset(p, 0, sizeof *p);
+  p->min_sv_size = 40; p->max_sv_size = 100000; p->query_gap_tolerance = 50; p->query_overlap_tolerance = 50;
+  p->reference_gap_tolerance = 50; p->reference_overlap_tolerance = 50; p->partition_max_distance = 1000;
+  p->pair_distance = 900; p->max_partition = 10;
+  return 0;
+}
+
+int vsv_bnd_segments(vsv_handle* h, const vsv_segments* sg, const vsv_bnd_params* p) {
+  if (!h || !sg || !p) return VSV_E_INVALID;
+  if (sg->n_reads < 0 || sg->n_segs < sg->n_reads || sg->n_tids <= 0) return fail(h, VSV_E_INVALID, "bad segment counts");
+  HIPCHK(h, hipSetDevice(h->device));
+  int st = reserve(h, 1, 1, h->cap_sigs > 0 ? h->cap_sigs : (1 << 22));
+  if (st) return st;
+  if (sg->n_segs - sg->n_reads > h->cap_sigs) { h->last_count = sg->n_segs - sg->n_reads; return fail(h, VSV_E_CAPACITY, "more segment pairs than row capacity"); }
+  vsv_segments d = *sg;
+  if (!sg->on_device) {
+    const size_t nr = (size_t)sg->n_reads, ns = (size_t)sg->n_segs, nt = (size_t)sg->n_tids;
+    if ((st = upload(h, h->g_off, sg->seg_off, (nr + 1) * 8))) return st;
+    if ((st = upload(h, h->g_qs, sg->q_start, ns * 4))) return st;
+    if ((st = upload(h, h->g_qe, sg->q_end, ns * 4))) return st;
+    if ((st = upload(h, h->g_rid, sg->ref_id, ns * 4))) return st;
+    if ((st = upload(h, h->g_rs, sg->ref_start, ns * 4))) return st;
+    if ((st = upload(h, h->g_re, sg->ref_end, ns * 4))) return st;
+    if ((st = upload(h, h->g_rev, sg->is_reverse, ns))) return st;
+    if ((st = upload(h, h->g_hap, sg->hap, nr))) return st;
+    if ((st = upload(h, h->g_len, sg->contig_len, nt * 4))) return st;
+    if ((st = upload(h, h->g_rank, sg->contig_rank, nt * 4))) return st;
+    d.seg_off = (const uint64_t*)h->g_off.p; d.q_start = (const int32_t*)h->g_qs.p; d.q_end = (const int32_t*)h->g_qe.p;
+    d.ref_id = (const int32_t*)h->g_rid.p; d.ref_start = (const int32_t*)h->g_rs.p; d.ref_end = (const int32_t*)h->g_re.p;
+    d.is_reverse = (const uint8_t*)h->g_rev.p; d.hap = (const uint8_t*)h->g_hap.p; d.contig_len = (const int32_t*)h->g_len.p;
+    d.contig_rank = (const int32_t*)h->g_rank.p;
+  }
+  h->segs = d;
+  HIPCHK(h, hipMemsetAsync(h->ctr.p, 0, sizeof(Counters), h->stream));
+  vsv_launch_bnd_segments(h->stream, d, *p, (vsv_bnd*)h->s1in.p, (uint32_t)h->cap_sigs, dctr(h));
+  HIPCHK(h, hipGetLastError());
+  h->bnd_stage = 1;
+  h->stage_done = 0;   // the signature tables share buffers with the BND tables
+  return finish(h);
+}
+
+int vsv_bnd_pair(vsv_handle* h, const vsv_bnd_params* p) {
+  if (!h || !p || h->bnd_stage < 1) return fail(h, VSV_E_INVALID, "vsv_bnd_segments must run first");
+  HIPCHK(h, hipSetDevice(h->device));
+  vsv_launch_bnd_pair(h->stream, (const vsv_bnd*)h->s1in.p, h->segs.contig_rank, bits_for((uint64_t)h->segs.n_tids + 1), *p,
+                      (vsv_bnd*)h->s1s.p, (vsv_bnd*)h->c1.p, dctr(h), stage_bufs(h), sort_work(h), h->cap_sigs);
+  HIPCHK(h, hipGetLastError());
+  h->bnd_stage = 2;
+  return finish(h);
+}
+
 int vsv_last_scan_ms(vsv_handle* h, float* ms) {
   if (!h || !ms || !h->have_scan_ev) return VSV_E_INVALID;
   HIPCHK(h, hipEventSynchronize(h->ev1));
@@ -442,6 +499,8 @@ static int table_src(vsv_handle* h, int table, const void** src, int64_t* n_rows
     case VSV_T_CLUSTER1: if (h->stage_done < 3) return VSV_E_INVALID; *src = h->c1.p; *n_rows = c.n_alive1; return 0;
     case VSV_T_MERGED: if (h->stage_done < 4) return VSV_E_INVALID; *src = h->merged.p; *n_rows = c.n_alive3; *filter = false; return 0;
     case VSV_T_CALLS: if (h->stage_done < 5) return VSV_E_INVALID; *src = h->calls.p; *n_rows = c.n_calls; *row = sizeof(vsv_call); *filter = false; return 0;
+    case VSV_T_BND_CAND: if (h->bnd_stage < 1) return VSV_E_INVALID; *src = h->s1in.p; *n_rows = c.n_s1; return 0;
+    case VSV_T_BND_CALLS: if (h->bnd_stage < 2) return VSV_E_INVALID; *src = h->c1.p; *n_rows = c.n_alive1; return 0;
     case VSV_T_READS: if (h->stage_done < 2 || h->prm.dtype != VSV_DTYPE_READS) return VSV_E_INVALID; *src = h->reads.p; *n_rows = c.n_reads; *filter = false; return 0;
   }
   return VSV_E_INVALID;
@@ -458,8 +517,9 @@ static int table_read(vsv_handle* h, int table, std::vector<char>& host, int64_t
   int64_t m = n;
   if (filter) {  // drop rows a stage marked dead
     m = 0;
-    vsv_sig* s = (vsv_sig*)host.data();
-    for (int64_t i = 0; i < n; ++i) if (!(s[i].meta & VSV_M_DEAD)) s[m++] = s[i];
+    vsv_sig* s = (vsv_sig*)host.data();   // vsv_bnd has the same size and its meta word at the same offset
+    const uint32_t dead = (table == VSV_T_BND_CAND || table == VSV_T_BND_CALLS) ? (uint32_t)VSV_B_DEAD : (uint32_t)VSV_M_DEAD;
+    for (int64_t i = 0; i < n; ++i) if (!(s[i].meta & dead)) s[m++] = s[i];
   }
   *n_out = m; *row_out = row;
   return 0;

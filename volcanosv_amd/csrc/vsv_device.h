@@ -118,3 +118,8 @@ void vsv_launch_cluster(hipStream_t st, const vsv_sig* sorted, const uint32_t* d
 void vsv_launch_pair(hipStream_t st, const vsv_sig* merged, const uint32_t* d_alive3, int pair_shift, vsv_call* calls_tmp,
                      vsv_call* calls, uint32_t* d_ncalls, const StageBufs& b, uint64_t* key2, uint32_t* idx2,
                      const SortWork& sw, int pb, int nbits, int64_t cap);
+
+// bnd.hip
+void vsv_launch_bnd_segments(hipStream_t st, const vsv_segments& s, const vsv_bnd_params& p, vsv_bnd* cand, uint32_t cap, Counters* ctr);
+void vsv_launch_bnd_pair(hipStream_t st, const vsv_bnd* cand, const int32_t* contig_rank, int rank_bits, const vsv_bnd_params& p,
+                         vsv_bnd* sorted, vsv_bnd* calls, Counters* ctr, const StageBufs& b, const SortWork& sw, int64_t cap);

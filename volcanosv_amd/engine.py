@@ -9,11 +9,11 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .abi import (CALL_DTYPE, SIG_DTYPE, T_CALLS, T_CIGAR, T_CLUSTER1, T_MERGED, T_RAW, T_READS, T_SPLIT, DTYPE_BY_NAME,
+from .abi import (BND_DTYPE, T_BND_CALLS, T_BND_CAND, BndParams, CALL_DTYPE, SIG_DTYPE, T_CALLS, T_CIGAR, T_CLUSTER1, T_MERGED, T_RAW, T_READS, T_SPLIT, DTYPE_BY_NAME,
                   DTYPE_READS, DTYPE_SVIM, Params, Records, VsvError)
 
 _TABLE_IDS = {"raw": T_RAW, "cigar": T_CIGAR, "split": T_SPLIT, "cluster1": T_CLUSTER1, "merged": T_MERGED,
-              "calls": T_CALLS, "reads": T_READS}
+              "calls": T_CALLS, "reads": T_READS, "bnd_cand": T_BND_CAND, "bnd_calls": T_BND_CALLS}
 
 
 def default_params(dtype):
@@ -110,6 +110,20 @@ class Engine:
     def finish(self):
         self._check(self.lib.vsv_finish(self.h))
 
+    # ---- Complex_SV breakend branch (svim_asm/SVIM_inter.py, SVIM_COMBINE.py) ----------------------------------------
+    def bnd(self, seg, params=None):
+        """segments -> (candidates, calls): vsv_bnd_segments + vsv_bnd_pair."""
+        p = params
+        if p is None:
+            p = BndParams()
+            self._check(self.lib.vsv_default_bnd_params(C.byref(p)))
+        self._keep = seg
+        s = seg.as_struct()
+        self._check(self.lib.vsv_bnd_segments(self.h, C.byref(s), C.byref(p)))
+        cand = self.table("bnd_cand")
+        self._check(self.lib.vsv_bnd_pair(self.h, C.byref(p)))
+        return cand, self.table("bnd_calls")
+
     def scan_ms(self):
         ms = C.c_float()
         self._check(self.lib.vsv_last_scan_ms(self.h, C.byref(ms)))
@@ -120,7 +134,7 @@ class Engine:
         tid = _TABLE_IDS[name]
         n = C.c_int64()
         self._check(self.lib.vsv_table_count(self.h, tid, C.byref(n)))
-        dt = CALL_DTYPE if name == "calls" else SIG_DTYPE
+        dt = CALL_DTYPE if name == "calls" else (BND_DTYPE if name.startswith("bnd") else SIG_DTYPE)
         out = np.zeros(int(n.value), dtype=dt)
         if n.value:
             self._check(self.lib.vsv_table_fill(self.h, tid, out.ctypes.data_as(C.c_void_p), n.value, 0))
