@@ -236,6 +236,9 @@ enum { VSV_T_BND_CAND = 7, VSV_T_BND_CALLS = 8 };
 int vsv_default_bnd_params(vsv_bnd_params* p);
 int vsv_bnd_segments(vsv_handle* h, const vsv_segments* segs, const vsv_bnd_params* p);
 int vsv_bnd_pair(vsv_handle* h, const vsv_bnd_params* p);
+/* multi-GPU join: install candidate rows received from other ranks (collection order: hp1 rows, then hp2 rows)
+ * as the input of vsv_bnd_pair. */
+int vsv_bnd_set_candidates(vsv_handle* h, const vsv_bnd* rows, int64_t n, const int32_t* contig_rank, int32_t n_tids, int on_device);
 
 /* ---- host-side ingest: BAM/BGZF -> record SoA ----------------------------------------------------
  * Replaces pysam.AlignmentFile(bam).fetch(chr) (H:387-391, RS:108-113). Arrays returned through `out` are owned

@@ -42,6 +42,7 @@ def lib():
         _LIB.orc_bnd.argtypes = [C.POINTER(Segments), C.POINTER(BndParams), C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
                                  C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
         _LIB.orc_bnd_free.argtypes = [C.c_void_p, C.c_void_p]
+        _LIB.orc_bnd_pair.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(BndParams), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
     return _LIB
 
 
@@ -90,3 +91,16 @@ def run_bnd(seg, params=None):
     cand, calls = _copy(a.value, na.value, BND_DTYPE), _copy(b.value, nb.value, BND_DTYPE)
     lib().orc_bnd_free(a, b)
     return cand, calls
+
+
+def run_bnd_pair(rows, contig_rank, params=None):
+    """Pairing step alone on candidate rows in collection order (hp1 rows, then hp2 rows)."""
+    p = params if params is not None else default_bnd_params()
+    rows = np.ascontiguousarray(rows)
+    rank = np.ascontiguousarray(contig_rank, dtype=np.int32)
+    b, nb = C.c_void_p(), C.c_int64()
+    st = lib().orc_bnd_pair(rows.ctypes.data_as(C.c_void_p), len(rows), rank.ctypes.data_as(C.c_void_p), C.byref(p), C.byref(b), C.byref(nb))
+    assert st == 0
+    calls = _copy(b.value, nb.value, BND_DTYPE)
+    lib().orc_bnd_free(b, None)
+    return calls

@@ -704,33 +704,19 @@ int orc_default_bnd_params(vsv_bnd_params* p) {
   return 0;
 }
 
-/* candidates in (read, pair) order; calls in (partition, first member) order */
-int orc_bnd(const vsv_segments* s, const vsv_bnd_params* p, vsv_bnd** cand_out, int64_t* n_cand, vsv_bnd** calls_out, int64_t* n_calls) {
-  bndvec cand = {0}, calls = {0};
-  for (int64_t r = 0; r < s->n_reads; ++r) {
-    int64_t a = (int64_t)s->seg_off[r], b = (int64_t)s->seg_off[r + 1], n = b - a;
-    if (n < 2) continue;
-    orc_seg* sg = (orc_seg*)malloc((size_t)n * sizeof(orc_seg));
-    for (int64_t k = 0; k < n; ++k) {
-      sg[k].q_start = s->q_start[a + k]; sg[k].q_end = s->q_end[a + k]; sg[k].ref_id = s->ref_id[a + k];
-      sg[k].ref_start = s->ref_start[a + k]; sg[k].ref_end = s->ref_end[a + k]; sg[k].rev = s->is_reverse[a + k] ? 1 : 0; sg[k].ord = (int32_t)k;
-    }
-    qsort(sg, (size_t)n, sizeof(orc_seg), seg_cmp);
-    for (int64_t k = 0; k + 1 < n; ++k) {
-      vsv_bnd x;
-      if (bnd_of_pair(s, p, &sg[k], &sg[k + 1], (uint32_t)r, s->hap[r], &x)) bv_push(&cand, &x);
-    }
-    free(sg);
-  }
+/* form_partitions + pair_haplotypes_breakends + pair_candidates (BND part) on a candidate table whose order is the
+ * reference's collection order (hp1 candidates, then hp2 candidates). */
+int orc_bnd_pair(const vsv_bnd* cv, int64_t n, const int32_t* contig_rank, const vsv_bnd_params* p, vsv_bnd** calls_out, int64_t* n_calls) {
+  bndvec calls = {0};
+  struct { const vsv_bnd* v; } cand = { cv };
   /* form_partitions: stable sort of hp1 candidates + hp2 candidates by (contig name, source_start) */
-  int64_t n = cand.n;
   int64_t* idx = (int64_t*)malloc((size_t)(n + 1) * sizeof(int64_t));
   uint64_t* key = (uint64_t*)malloc((size_t)(n + 1) * sizeof(uint64_t));
   int64_t m = 0;
   for (int hap = 0; hap < 2; ++hap)
     for (int64_t i = 0; i < n; ++i) if (((cand.v[i].meta & VSV_B_HAP2) != 0) == hap) idx[m++] = i;
   int64_t* order = (int64_t*)malloc((size_t)(n + 1) * sizeof(int64_t));
-  for (int64_t i = 0; i < n; ++i) { const vsv_bnd* c = &cand.v[idx[i]]; key[i] = ((uint64_t)(uint32_t)s->contig_rank[c->src_tid] << 32) | (uint32_t)c->src_pos; order[i] = i; }
+  for (int64_t i = 0; i < n; ++i) { const vsv_bnd* c = &cand.v[idx[i]]; key[i] = ((uint64_t)(uint32_t)contig_rank[c->src_tid] << 32) | (uint32_t)c->src_pos; order[i] = i; }
   stable_sort_idx(key, order, n);
   int64_t lo = 0;
   while (lo < n) {
@@ -772,9 +758,32 @@ int orc_bnd(const vsv_segments* s, const vsv_bnd_params* p, vsv_bnd** cand_out, 
     lo = hi;
   }
   free(idx); free(key); free(order);
-  if (!cand.v) cand.v = (vsv_bnd*)malloc(sizeof(vsv_bnd));
   if (!calls.v) calls.v = (vsv_bnd*)malloc(sizeof(vsv_bnd));
-  *cand_out = cand.v; *n_cand = cand.n; *calls_out = calls.v; *n_calls = calls.n;
+  *calls_out = calls.v; *n_calls = calls.n;
   return 0;
+}
+
+/* candidates in (read, pair) order; calls in (partition, first member) order */
+int orc_bnd(const vsv_segments* s, const vsv_bnd_params* p, vsv_bnd** cand_out, int64_t* n_cand, vsv_bnd** calls_out, int64_t* n_calls) {
+  bndvec cand = {0};
+  for (int64_t r = 0; r < s->n_reads; ++r) {
+    int64_t a = (int64_t)s->seg_off[r], b = (int64_t)s->seg_off[r + 1], n = b - a;
+    if (n < 2) continue;
+    orc_seg* sg = (orc_seg*)malloc((size_t)n * sizeof(orc_seg));
+    for (int64_t k = 0; k < n; ++k) {
+      sg[k].q_start = s->q_start[a + k]; sg[k].q_end = s->q_end[a + k]; sg[k].ref_id = s->ref_id[a + k];
+      sg[k].ref_start = s->ref_start[a + k]; sg[k].ref_end = s->ref_end[a + k]; sg[k].rev = s->is_reverse[a + k] ? 1 : 0; sg[k].ord = (int32_t)k;
+    }
+    qsort(sg, (size_t)n, sizeof(orc_seg), seg_cmp);
+    for (int64_t k = 0; k + 1 < n; ++k) {
+      vsv_bnd x;
+      if (bnd_of_pair(s, p, &sg[k], &sg[k + 1], (uint32_t)r, s->hap[r], &x)) bv_push(&cand, &x);
+    }
+    free(sg);
+  }
+  int rc = orc_bnd_pair(cand.v, cand.n, s->contig_rank, p, calls_out, n_calls);
+  if (!cand.v) cand.v = (vsv_bnd*)malloc(sizeof(vsv_bnd));
+  *cand_out = cand.v; *n_cand = cand.n;
+  return rc;
 }
 void orc_bnd_free(vsv_bnd* a, vsv_bnd* b) { free(a); free(b); }

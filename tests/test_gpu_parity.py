@@ -283,3 +283,17 @@ def test_bnd_synthetic_config5(eng):
     assert len(cand) > 30000 and np.array_equal(cand, ocand) and np.array_equal(calls, ocalls)
     gts = (calls["meta"] >> 4) & 3
     assert (gts == 3).sum() > 5000
+
+
+def test_bnd_pair_rows_after_exchange(eng):
+    """vsv_bnd_set_candidates + vsv_bnd_pair: the per-rank step after the multi-GPU exchange (config 5)."""
+    from test_bnd_oracle import load
+    from oracle import oracle
+    doc, seg = load("bnd_b")
+    cand = eng.bnd_candidates(seg)
+    hap2 = (cand["meta"] & 4) != 0
+    rows = cand[np.lexsort((np.arange(len(cand)), cand["read"], hap2))]
+    sub = rows[rows["src_tid"] % 2 == 0]                  # the contigs one of two ranks would own
+    got = eng.bnd_pair_rows(sub, seg.contig_rank)
+    want = oracle.run_bnd_pair(sub, seg.contig_rank)
+    assert len(got) > 10 and np.array_equal(got, want)

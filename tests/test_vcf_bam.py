@@ -137,3 +137,60 @@ def test_cli_reads_signature(tmp_path):
         got = [l.rstrip("\n").split("\t") for l in open(tmp_path / "out" / "reads_signature" / ("%s_reads_sig.txt" % chrom))]
         want = [[str(x) for x in row] for row in doc["expected"]["per_chrom"][chrom]["merged"]]
         assert got == want
+
+
+def _cigar_for(seg, primary):
+    """[tid, rs, re, qa, qb, L, rev] -> CIGAR ops realising exactly these numbers (soft clips around M + I/D)."""
+    tid, rs, re_, qa, qb, L, rev = seg
+    qlen, rlen = qb - qa, re_ - rs
+    ops = []
+    if qa > 0:
+        ops.append((4, qa))
+    m = min(qlen, rlen)
+    ops.append((0, m))
+    if qlen > rlen:
+        ops.append((1, qlen - rlen))
+    elif rlen > qlen:
+        ops.append((2, rlen - qlen))
+    if L - qb > 0:
+        ops.append((4, L - qb))
+    return ops
+
+
+@pytest.mark.gpu
+def test_cli_svim_bnd_and_filter_tra(tmp_path):
+    """Complex_SV plumbing: hp1/hp2 contig BAMs with SA tags -> svim-asm diploid drop-in (BND branch) -> variants.vcf equal to
+    the reference svim functions' output; then the filter_tra.py drop-in."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = json.load(open(os.path.join(root, "tests", "golden", "bnd_a.json")))
+    contigs = [tuple(c) for c in doc["contigs"]]
+    names = [c[0] for c in contigs]
+    ops = "MIDNSHP=X"
+    for hap in (1, 2):
+        recs = []
+        for r in doc["reads"]:
+            if r["hap"] != hap:
+                continue
+            p = r["segs"][0]
+            sa = ""
+            for s in r["segs"][1:]:
+                cg = "".join("%d%s" % (l, ops[o]) for o, l in _cigar_for(s, False))
+                sa += "%s,%d,%s,%s,60,0;" % (names[s[0]], s[1] + 1, "-" if s[6] else "+", cg)
+            recs.append(dict(tid=p[0], pos=p[1], qname=r["name"], mapq=60, flag=16 if p[6] else 0, cigar=_cigar_for(p, True), seq_len=p[5],
+                             tags={b"SA": sa}))
+        recs.sort(key=lambda x: (x["tid"], x["pos"]))
+        bam.write_bam(str(tmp_path / ("assembly_hp%d.bam" % hap)), contigs, recs)
+    out = tmp_path / "Raw_Detection"
+    subprocess.check_call([sys.executable, os.path.join(root, "volcanosv_amd", "cli", "svim_asm_bnd.py"), "diploid", str(out),
+                           str(tmp_path / "assembly_hp1.bam"), str(tmp_path / "assembly_hp2.bam"), "ref.fa", "--query_names"])
+    lines = [l.rstrip("\n") for l in open(out / "variants.vcf") if not l.startswith("#")]
+    # the BAM route orders reads by coordinate, the fixture by event: READS order inside a 1/1 record is (hp1, hp2) in both;
+    # ids follow the natural sort, which is unique here
+    assert lines == doc["expected"]["vcf"]
+    subprocess.check_call([sys.executable, os.path.join(root, "volcanosv_amd", "cli", "filter_tra.py"), "-vcf", str(out / "variants.vcf"),
+                           "-o", str(tmp_path / "TRA"), "-bam", "x.bam"])
+    tra = [l for l in open(tmp_path / "TRA" / "TRA_final.vcf") if not l.startswith("#")]
+    assert 0 < len(tra) <= len(lines)

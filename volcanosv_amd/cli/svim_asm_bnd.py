@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Drop-in for the `svim-asm diploid <dir> <hp1.bam> <hp2.bam> <ref> --query_names` call of
+Complex_SV/volcanosv-vc-complex-sv.py:124-126, restricted to the breakend (BND) branch this build accelerates:
+writes <dir>/variants.vcf with the svim header shape and the BND records (two lines per breakend, natural sort,
+ids svim_asm.BND.<n>). INS/DEL/INV/DUP haplotype pairing (edlib) is out of scope."""
+import os
+import sys
+import time
+from argparse import ArgumentParser
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from volcanosv_amd import bnd  # noqa: E402
+from volcanosv_amd.bam import BamFile  # noqa: E402
+from volcanosv_amd.engine import Engine  # noqa: E402
+
+ap = ArgumentParser()
+ap.add_argument("sub", choices=["diploid"])
+ap.add_argument("working_dir")
+ap.add_argument("bam_file1")
+ap.add_argument("bam_file2")
+ap.add_argument("genome")
+ap.add_argument("--query_names", action="store_true")
+ap.add_argument("--min_mapq", type=int, default=20)
+ap.add_argument("--sample", default="Sample")
+args = ap.parse_args()
+
+reads = []
+contigs = None
+for hap, path in ((1, args.bam_file1), (2, args.bam_file2)):
+    with BamFile(path) as b:
+        if contigs is None:
+            contigs = list(zip(b.references, b.lengths))
+        soa = b.fetch_soa(None)
+    reads += bnd.segments_from_soa(soa, hap, args.min_mapq)
+seg = bnd.SegmentSoA(reads, contigs)
+eng = Engine(0)
+cand, calls = eng.bnd(seg)
+eng.close()
+os.makedirs(args.working_dir, exist_ok=True)
+with open(os.path.join(args.working_dir, "variants.vcf"), "w") as f:   # header: SVIM_COMBINE.py:394-425 (BND-relevant lines)
+    f.write("##fileformat=VCFv4.2\n##fileDate=%s\n##source=SVIM-asm-v1.0.2\n" % time.strftime("%Y-%m-%d|%I:%M:%S%p|%Z|%z"))
+    for n, l in contigs:
+        f.write("##contig=<ID=%s,length=%d>\n" % (n, l))
+    f.write('##ALT=<ID=BND,Description="Breakend">\n##INFO=<ID=SVTYPE,Number=1,Type=String,Description="Type of structural variant">\n')
+    if args.query_names:
+        f.write('##INFO=<ID=READS,Number=.,Type=String,Description="Names of all supporting reads">\n')
+    f.write('##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t%s\n' % args.sample)
+    for line in bnd.vcf_lines(seg, calls, args.query_names):
+        f.write(line + "\n")
+print("%d split contigs -> %d breakend candidates -> %d calls" % (len(reads), len(cand), len(calls)))

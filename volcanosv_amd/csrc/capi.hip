@@ -471,6 +471,28 @@ int vsv_bnd_segments(vsv_handle* h, const vsv_segments* sg, const vsv_bnd_params
   return finish(h);
 }
 
+int vsv_bnd_set_candidates(vsv_handle* h, const vsv_bnd* rows, int64_t n, const int32_t* contig_rank, int32_t n_tids, int on_device) {
+  if (!h || n < 0 || n_tids <= 0 || !contig_rank || (n > 0 && !rows)) return VSV_E_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  int st = reserve(h, 1, 1, h->cap_sigs > 0 ? h->cap_sigs : (1 << 22));
+  if (st) return st;
+  if (n > h->cap_sigs) { h->last_count = n; return fail(h, VSV_E_CAPACITY, "more candidate rows than row capacity"); }
+  const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  if (n) HIPCHK(h, hipMemcpyAsync(h->s1in.p, rows, (size_t)n * sizeof(vsv_bnd), kind, h->stream));
+  if ((st = ensure(h, h->g_rank, (size_t)n_tids * 4 + 16))) return st;
+  HIPCHK(h, hipMemcpyAsync(h->g_rank.p, contig_rank, (size_t)n_tids * 4, kind, h->stream));
+  Counters c; memset(&c, 0, sizeof c);
+  c.n_s1 = (uint32_t)n;
+  *h->pinned = c;
+  HIPCHK(h, hipMemcpyAsync(h->ctr.p, h->pinned, sizeof(Counters), hipMemcpyHostToDevice, h->stream));
+  memset(&h->segs, 0, sizeof h->segs);
+  h->segs.contig_rank = (const int32_t*)h->g_rank.p;
+  h->segs.n_tids = n_tids;
+  h->bnd_stage = 1;
+  h->stage_done = 0;
+  return finish(h);
+}
+
 int vsv_bnd_pair(vsv_handle* h, const vsv_bnd_params* p) {
   if (!h || !p || h->bnd_stage < 1) return fail(h, VSV_E_INVALID, "vsv_bnd_segments must run first");
   HIPCHK(h, hipSetDevice(h->device));

@@ -124,6 +124,28 @@ class Engine:
         self._check(self.lib.vsv_bnd_pair(self.h, C.byref(p)))
         return cand, self.table("bnd_calls")
 
+    def bnd_candidates(self, seg, params=None):
+        p = params or self._bnd_params()
+        self._keep = seg
+        s = seg.as_struct()
+        self._check(self.lib.vsv_bnd_segments(self.h, C.byref(s), C.byref(p)))
+        return self.table("bnd_cand")
+
+    def bnd_pair_rows(self, rows, contig_rank, params=None):
+        """Pairs candidate rows (numpy BND_DTYPE, collection order) — the per-rank step after the multi-GPU exchange."""
+        p = params or self._bnd_params()
+        rows = np.ascontiguousarray(rows)
+        rank = np.ascontiguousarray(contig_rank, dtype=np.int32)
+        self._check(self.lib.vsv_bnd_set_candidates(self.h, rows.ctypes.data_as(C.c_void_p), len(rows), rank.ctypes.data_as(C.c_void_p),
+                                                    len(rank), 0))
+        self._check(self.lib.vsv_bnd_pair(self.h, C.byref(p)))
+        return self.table("bnd_calls")
+
+    def _bnd_params(self):
+        p = BndParams()
+        self._check(self.lib.vsv_default_bnd_params(C.byref(p)))
+        return p
+
     def scan_ms(self):
         ms = C.c_float()
         self._check(self.lib.vsv_last_scan_ms(self.h, C.byref(ms)))

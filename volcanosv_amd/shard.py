@@ -11,7 +11,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .abi import CALL_DTYPE
+from .abi import B_HAP2, BND_DTYPE, CALL_DTYPE
 
 
 def lpt_assign(weights, n_ranks):
@@ -63,3 +63,76 @@ def gather_calls(calls, device):
     allc = np.concatenate(parts) if parts else np.zeros(0, CALL_DTYPE)
     key = (allc["sig"]["tid"].astype(np.int64) << 32) | (allc["sig"]["pos"].astype(np.int64) & 0xFFFFFFFF)
     return allc[np.argsort(key, kind="stable")]
+
+
+def _all_to_all_bytes(chunks, device):
+    """chunks[r] = uint8 numpy array destined for rank r. Returns the list received from every rank. One counts
+    all-to-all + one padded all-to-all (RCCL: grouped send/recv over xGMI); all-gather fallback for backends without it."""
+    world = dist.get_world_size()
+    sizes = torch.tensor([len(c) for c in chunks], dtype=torch.int64, device=device)
+    rsizes = torch.empty_like(sizes)
+    try:
+        dist.all_to_all_single(rsizes, sizes)
+        send = torch.from_numpy(np.concatenate(chunks) if sum(len(c) for c in chunks) else np.zeros(0, np.uint8)).to(device)
+        recv = torch.empty(int(rsizes.sum().item()), dtype=torch.uint8, device=device)
+        dist.all_to_all_single(recv, send, output_split_sizes=[int(x) for x in rsizes.tolist()], input_split_sizes=[int(x) for x in sizes.tolist()])
+        out, o = [], 0
+        r = recv.cpu().numpy()
+        for n in rsizes.tolist():
+            out.append(r[o:o + int(n)])
+            o += int(n)
+        return out
+    except (RuntimeError, NotImplementedError):
+        allsizes = [torch.empty_like(sizes) for _ in range(world)]
+        dist.all_gather(allsizes, sizes)
+        mx = max(int(t.max().item()) for t in allsizes)
+        mine = torch.zeros(world * max(mx, 1), dtype=torch.uint8, device=device)
+        for r, c in enumerate(chunks):
+            if len(c):
+                mine[r * mx: r * mx + len(c)] = torch.from_numpy(np.ascontiguousarray(c)).to(device)
+        bufs = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(bufs, mine)
+        me = dist.get_rank()
+        return [bufs[src][me * mx: me * mx + int(allsizes[src][me].item())].cpu().numpy() for src in range(world)]
+
+
+def exchange_bnd(cand, read_base, owner_of_tid, device):
+    """Complex_SV cross-rank breakpoint join. `cand`: this rank's breakend candidates (BND_DTYPE, rows produced from the
+    primary alignments of the chromosomes it owns, svim_asm/SVIM_COLLECT.py:60-76); `read_base`: global id of this
+    rank's read 0. Rows go to owner(src_tid) — partitions are keyed by the canonical source contig
+    (svim_asm/SVCandidate.py:352-373, SVIM_COMBINE.py:17-26) — and come back ordered like the single-process collection:
+    hp1 rows before hp2 rows, each by (global read id, pair order)."""
+    cand = cand.copy()
+    cand["read"] += np.uint32(read_base)
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        got = cand
+    else:
+        world = dist.get_world_size()
+        dest = np.array([owner_of_tid[int(t)] for t in cand["src_tid"]], dtype=np.int64) if len(cand) else np.zeros(0, np.int64)
+        chunks = [np.frombuffer(cand[dest == r].tobytes(), dtype=np.uint8) for r in range(world)]
+        parts = [np.frombuffer(p.tobytes(), dtype=BND_DTYPE) for p in _all_to_all_bytes(chunks, device)]
+        got = np.concatenate(parts) if parts else np.zeros(0, BND_DTYPE)
+    hap2 = (got["meta"] & B_HAP2) != 0
+    order = np.lexsort((np.arange(len(got)), got["read"], hap2))      # stable: (hap, read id, original pair order)
+    return got[order]
+
+
+def gather_rows(rows, dtype, device):
+    """Variable-length gather of structured rows to rank 0 (counts all-gather + padded all-gather); rank order."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return rows
+    world = dist.get_world_size()
+    n = torch.tensor([len(rows)], dtype=torch.int64, device=device)
+    counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(counts, n)
+    counts = [int(c.item()) for c in counts]
+    row = dtype.itemsize
+    mx = max(max(counts), 1)
+    mine = torch.zeros(mx * row, dtype=torch.uint8, device=device)
+    if len(rows):
+        mine[: len(rows) * row] = torch.from_numpy(np.frombuffer(rows.tobytes(), dtype=np.uint8).copy()).to(device)
+    bufs = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(bufs, mine)
+    if dist.get_rank() != 0:
+        return None
+    return np.concatenate([np.frombuffer(bufs[r][: counts[r] * row].cpu().numpy().tobytes(), dtype=dtype) for r in range(world)])
