@@ -96,6 +96,15 @@ def main():
     scan_s = sum(scan_ms) / len(scan_ms) / 1e3
     achieved = alg_bytes / scan_s / 1e9
 
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_cigar_scan_emit_config2.json")
+    if os.path.exists(pmc_path):
+        # HBM bytes per launch of cigar_scan_emit from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
+        # KiB units) on the same shape; scaled by the op count, which sets the traffic (24 B/record headers are read
+        # only in part: pos + cigar_off low dwords).
+        pmc = json.load(open(pmc_path))
+        if args.shape == "hifi" and abs(recs.n_ops - pmc["n_ops"]) < 0.02 * pmc["n_ops"]:
+            traffic = pmc["traffic_bytes_per_launch"] * recs.n_ops / pmc["n_ops"]
     if rank == 0:
         cpu = None
         if args.cpu_sample > 0:
@@ -131,7 +140,7 @@ def main():
                                    % (recs.n_records, args.shape, dtype_name, recs.n_ops, n_raw, len(gathered) if gathered is not None else 0),
                        "records_per_gpu": recs.n_records, "parallelism": "chromosome-sharded x%d" % world},
             "roofline": {"bound": "hbm", "kernel": "cigar_scan_emit", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": scan_s * 1e3},
             "cpu_baseline": cpu,
         }

@@ -71,7 +71,7 @@ typedef struct vsv_records {
   const uint8_t* flag;         /* [n]   VSV_F_* bits                                               */
   const uint32_t* cigar;       /* [n_ops] BAM packing: len<<4 | op ; 16-byte aligned               */
   int32_t on_device;           /* 0: host pointers (library uploads), 1: device pointers           */
-  int32_t n_qids;              /* number of distinct qids (max qid + 1); 0 = unknown (<= n_records)  */
+  int32_t n_qids;              /* max qid + 1 (required when n_records > 0)                            */
   int32_t n_tids;              /* max tid + 1; 0 = unknown (16 key bits are reserved for it)       */
   int32_t max_pos;             /* upper bound of pos (e.g. contig length); 0 = unknown. Only trims sort passes. */
 } vsv_records;

@@ -153,11 +153,11 @@ int bind_records(vsv_handle* h, const vsv_records* r) {
   h->max_pos = r->max_pos > 0 ? r->max_pos : 0;
   int st = reserve(h, r->n_records, r->n_ops, h->cap_sigs > 0 ? h->cap_sigs : (1 << 22));
   if (st) return st;
-  // split hash table: >= 2 slots per (qid, hap)
-  const uint64_t nq = r->n_qids > 0 ? (uint64_t)r->n_qids : (uint64_t)r->n_records;
-  const uint32_t ts = pow2_at_least(2 * nq + 2);
-  if ((st = ensure(h, h->tab, (size_t)ts * 4))) return st;
-  h->tab_size = ts;
+  // 1 bit per query name ("name occurs more than once"); n_qids = max qid + 1 is part of the contract
+  if (r->n_qids <= 0 && r->n_records > 0) return fail(h, VSV_E_INVALID, "n_qids (max qid + 1) is required");
+  const uint32_t words = (uint32_t)(((uint64_t)r->n_qids + 31) / 32 + 2);
+  if ((st = ensure(h, h->tab, (size_t)words * 4))) return st;
+  h->tab_size = words;
   return 0;
 }
 

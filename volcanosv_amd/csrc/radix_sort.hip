@@ -65,10 +65,12 @@ __global__ __launch_bounds__(1024) void rs_scan(uint32_t* __restrict__ hist, con
   uint32_t tot[DPT];
 #pragma unroll
   for (int k = 0; k < DPT; ++k) tot[k] = 0;
-  if (active)
+  if (active) {
+#pragma unroll 8
     for (uint32_t tile = 0; tile < ntiles; ++tile)
 #pragma unroll
       for (int k = 0; k < DPT; ++k) tot[k] += hist[(size_t)tile * BINS + t * DPT + k];
+  }
   uint32_t mine = 0;
 #pragma unroll
   for (int k = 0; k < DPT; ++k) mine += tot[k];
@@ -85,6 +87,7 @@ __global__ __launch_bounds__(1024) void rs_scan(uint32_t* __restrict__ hist, con
     uint32_t base[DPT];
 #pragma unroll
     for (int k = 0; k < DPT; ++k) { base[k] = run; run += tot[k]; }
+#pragma unroll 8
     for (uint32_t tile = 0; tile < ntiles; ++tile)
 #pragma unroll
       for (int k = 0; k < DPT; ++k) {

@@ -96,7 +96,6 @@ __global__ __launch_bounds__(256) void clr_gate_kernel(vsv_sig* __restrict__ s, 
 struct SplitCfg {
   int contig;        // 1: hp/mapq eligibility, two hap passes; 0: reads path, every record, one pass
   int min_mapq;
-  uint32_t tab_mask;
   int qid_bits;
   int tid_shift;     // ckey = tid << tid_shift | hap << qid_bits | qid
 };
@@ -106,16 +105,75 @@ __device__ __forceinline__ bool split_elig(const RecView& rv, const SplitCfg& c,
   const uint32_t fl = rv.flag[r];
   return (fl & (hap ? VSV_F_HP2 : VSV_F_HP1)) && rv.mapq[r] >= c.min_mapq;   // Hifi.py:425-427
 }
-__device__ __forceinline__ uint32_t split_hash(const RecView& rv, const SplitCfg& c, uint32_t r, uint32_t hap) {
-  return ((rv.qid[r] * 2u + hap) ^ ((uint32_t)rv.tid[r] * 0x9E3779B1u)) & c.tab_mask;
+// ---- names that occur more than once, without a counting table ---------------------------------------
+// A record whose qid is <= the running maximum of all earlier qids MAY be a repeated name; every true repeat is such a
+// record (its name appeared before, so the maximum is >= its qid). With qids dense in first-appearance order (the
+// ingest's numbering) the test is exact and only the ~1 % repeat records touch memory: one atomicOr into a
+// 1-bit-per-name table that stays L2-resident. Any other numbering only adds false candidates, which drop out later
+// because a candidate group needs two eligible members with equal (tid, hap, qid).
+constexpr int QM_TILE = 2048;   // 256 threads x 8 consecutive records
+__global__ __launch_bounds__(256) void qid_tile_max(const uint32_t* __restrict__ qid, int64_t n, uint32_t* __restrict__ tile_max) {
+  __shared__ uint32_t sh[256];
+  const int64_t base = (int64_t)blockIdx.x * QM_TILE + threadIdx.x * 8;
+  uint32_t m = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) if (base + k < n) m = max(m, qid[base + k] + 1u);   // +1: 0 means "no record"
+  sh[threadIdx.x] = m;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) { if ((int)threadIdx.x < d) sh[threadIdx.x] = max(sh[threadIdx.x], sh[threadIdx.x + d]); __syncthreads(); }
+  if (threadIdx.x == 0) tile_max[blockIdx.x] = sh[0];
 }
-
-__global__ __launch_bounds__(256) void split_count(RecView rv, SplitCfg c, uint32_t* __restrict__ tab) {
-  const uint64_t n2 = (uint64_t)rv.n_records * 2;
-  for (uint64_t it = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; it < n2; it += (uint64_t)gridDim.x * blockDim.x) {
-    const uint32_t r = (uint32_t)(it >> 1), hap = (uint32_t)(it & 1);
-    if (split_elig(rv, c, r, hap)) atomicAdd(&tab[split_hash(rv, c, r, hap)], 1u);
+// single block: exclusive prefix maximum over the tiles, in place
+__global__ __launch_bounds__(1024) void qid_scan_max(uint32_t* __restrict__ tile_max, int ntiles) {
+  __shared__ uint32_t sh[1024];
+  __shared__ uint32_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < ntiles; base += 1024) {
+    const int i = base + threadIdx.x;
+    const uint32_t v = i < ntiles ? tile_max[i] : 0;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+      const uint32_t t = (int)threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
+      __syncthreads();
+      sh[threadIdx.x] = max(sh[threadIdx.x], t);
+      __syncthreads();
+    }
+    const uint32_t c = carry;
+    const uint32_t excl = max(c, threadIdx.x > 0 ? sh[threadIdx.x - 1] : 0u);
+    const uint32_t last = max(c, sh[1023]);
+    __syncthreads();
+    if (i < ntiles) tile_max[i] = excl;
+    if (threadIdx.x == 0) carry = last;
+    __syncthreads();
   }
+}
+__global__ __launch_bounds__(256) void qid_mark_dups(const uint32_t* __restrict__ qid, int64_t n, const uint32_t* __restrict__ tile_excl,
+                                                     uint32_t* __restrict__ dupbits) {
+  __shared__ uint32_t sh[256];
+  const int64_t base = (int64_t)blockIdx.x * QM_TILE + threadIdx.x * 8;
+  uint32_t q[8], m = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { q[k] = (base + k < n) ? qid[base + k] + 1u : 0u; m = max(m, q[k]); }
+  sh[threadIdx.x] = m;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    const uint32_t t = (int)threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
+    __syncthreads();
+    sh[threadIdx.x] = max(sh[threadIdx.x], t);
+    __syncthreads();
+  }
+  uint32_t run = max(tile_excl[blockIdx.x], threadIdx.x > 0 ? sh[threadIdx.x - 1] : 0u);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (q[k] != 0 && q[k] <= run) atomicOr(&dupbits[(q[k] - 1u) >> 5], 1u << ((q[k] - 1u) & 31u));
+    run = max(run, q[k]);
+  }
+}
+__device__ __forceinline__ bool name_repeats(const RecView& rv, const uint32_t* __restrict__ dupbits, uint32_t r) {
+  const uint32_t q = rv.qid[r];
+  return (dupbits[q >> 5] >> (q & 31u)) & 1u;
 }
 
 // ordered compaction of candidate (record,hap) items, block tile = 256 threads x 8 rounds
@@ -137,7 +195,7 @@ __global__ __launch_bounds__(256) void split_cand(RecView rv, SplitCfg c, const 
     f[k] = false;
     if (it < n2) {
       const uint32_t r = (uint32_t)(it >> 1), hap = (uint32_t)(it & 1);
-      f[k] = split_elig(rv, c, r, hap) && tab[split_hash(rv, c, r, hap)] > 1u;
+      f[k] = split_elig(rv, c, r, hap) && name_repeats(rv, tab, r);
     }
     const uint64_t bal = __ballot(f[k]);
     below[k] = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
@@ -199,33 +257,44 @@ __global__ __launch_bounds__(256) void split_mark_pairs(const uint64_t* __restri
 }
 
 struct RecSum { int64_t ref_len, read_len; uint32_t first, last; };
+constexpr int SE_GROUP = 8;   // lanes cooperating on one pair slot
+__device__ __forceinline__ int64_t group_sum64(int64_t v) {
+#pragma unroll
+  for (int d = SE_GROUP / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
 __device__ __forceinline__ RecSum rec_summary(const RecView& rv, uint32_t r, bool reads, int lane) {
   const uint64_t a = rv.cigar_off[r], b = rv.cigar_off[r + 1];
   int64_t rl = 0, rf = 0;
-  for (uint64_t k = a + lane; k < b; k += 64) {
+  for (uint64_t k = a + lane; k < b; k += SE_GROUP) {
     const uint32_t w = rv.cigar[k], op = w & 15u, len = w >> 4;
     if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rf += len;           // pysam reference_end
     if (op == 0 || op == 1 || op == 4 || op == 5 || (reads && (op == 7 || op == 8))) rl += len;  // get_readlen
   }
   RecSum s;
-  s.ref_len = wave_sum64(rf);
-  s.read_len = wave_sum64(rl);
+  s.ref_len = group_sum64(rf);
+  s.read_len = group_sum64(rl);
   s.first = rv.cigar[a];
   s.last = rv.cigar[b - 1];
   return s;
 }
 
-// one wave per pair slot (in okey order); writes one signature row (possibly dead) per slot
+// SE_GROUP lanes per pair slot (in okey order); writes one signature row (possibly dead) per slot. All lanes of a
+// group take the same branches (the conditions depend only on the slot), so the shuffles inside rec_summary are safe.
 __global__ __launch_bounds__(256) void split_eval(RecView rv, const uint64_t* __restrict__ okey, const uint32_t* __restrict__ oval,
                                                   const uint64_t* __restrict__ ckey, const uint32_t* __restrict__ crec,
                                                   SplitCfg c, int dtype, int max_svlen, vsv_sig* __restrict__ s1in,
                                                   uint32_t cap, Counters* ctr) {
   const uint32_t n = ctr->n_cand, n_raw = ctr->n_raw;
-  const int lane = threadIdx.x & 63;
-  const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+  const int lane = threadIdx.x & (SE_GROUP - 1);
+  const uint32_t ngroups = gridDim.x * (blockDim.x / SE_GROUP);
   const bool reads = dtype == VSV_DTYPE_READS;
-  for (uint32_t q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); q < n; q += nwaves) {
-    if (n_raw + q >= cap) { if (lane == 0) atomicOr(&ctr->err, ERRB_CAPACITY); continue; }
+  // whole waves iterate together (uniform trip count) so that every shuffle sees all its lanes active
+  const uint32_t n_pad = (n + (64 / SE_GROUP) - 1) / (64 / SE_GROUP) * (64 / SE_GROUP);
+  for (uint32_t q0 = blockIdx.x * (blockDim.x / SE_GROUP) + (threadIdx.x / SE_GROUP); q0 < n_pad; q0 += ngroups) {
+    const bool live = q0 < n;
+    const uint32_t q = live ? q0 : n - 1;   // padding groups recompute the last slot and do not store
+    if (n_raw + q >= cap) { if (lane == 0) atomicOr(&ctr->err, ERRB_CAPACITY); continue; }   // uniform per group; shuffles below are group-local
     vsv_sig out = dead_sig();
     if (okey[q] != VSV_KEY_DEAD) {
       const uint32_t j = oval[q];
@@ -304,7 +373,7 @@ __global__ __launch_bounds__(256) void split_eval(RecView rv, const uint64_t* __
         }
       }
     }
-    if (lane == 0) s1in[n_raw + q] = out;
+    if (lane == 0 && live) s1in[n_raw + q] = out;
   }
 }
 
@@ -479,14 +548,17 @@ void vsv_launch_split(hipStream_t st, const RecView& rv, const vsv_params& p, in
   SplitCfg c;
   c.contig = p.dtype != VSV_DTYPE_READS;
   c.min_mapq = p.min_split_mapq;
-  c.tab_mask = tab_size - 1;
   c.qid_bits = bits_for((uint64_t)(rv.n_qids > 0 ? rv.n_qids : rv.n_records) + 1);
   c.tid_shift = c.qid_bits + 1;
   const int tid_bits = bits_for((uint64_t)(n_tids > 0 ? n_tids : 65536) + 1);
   const int rec_bits = bits_for((uint64_t)rv.n_records + 1);
   if (rv.n_records > 0) {
-    hipMemsetAsync(tab, 0, (size_t)tab_size * sizeof(uint32_t), st);
-    split_count<<<1024, 256, 0, st>>>(rv, c, tab);
+    const uint64_t nq = rv.n_qids > 0 ? (uint64_t)rv.n_qids : (uint64_t)tab_size * 32;
+    (void)hipMemsetAsync(tab, 0, (size_t)((nq + 31) / 32 + 1) * sizeof(uint32_t), st);
+    const int qtiles = (int)((rv.n_records + QM_TILE - 1) / QM_TILE);
+    qid_tile_max<<<qtiles, 256, 0, st>>>(rv.qid, rv.n_records, blk_cnt);
+    qid_scan_max<<<1, 1024, 0, st>>>(blk_cnt, qtiles);
+    qid_mark_dups<<<qtiles, 256, 0, st>>>(rv.qid, rv.n_records, blk_cnt, tab);
     const int nblk = (int)(((uint64_t)rv.n_records * 2 + SC_TILE - 1) / SC_TILE);
     split_cand<false><<<nblk, 256, 0, st>>>(rv, c, tab, blk_cnt, ckey, crec, cap, ctr);
     vsv_scan_u32_exclusive(st, blk_cnt, nblk, blk_off, scan_tmp);
@@ -495,7 +567,7 @@ void vsv_launch_split(hipStream_t st, const RecView& rv, const vsv_params& p, in
     vsv_radix_sort_pairs(st, ckey, crec, &ctr->n_cand, cap, c.tid_shift + tid_bits, sw);
     split_mark_pairs<<<EW_GRID, 256, 0, st>>>(ckey, crec, c, rec_bits, okey, oval, ctr);
     vsv_radix_sort_pairs(st, okey, oval, &ctr->n_cand, cap, rec_bits + 1 + tid_bits + 1, sw);
-    split_eval<<<2048, 256, 0, st>>>(rv, okey, oval, ckey, crec, c, p.dtype, p.max_split_svlen, s1in, cap, ctr);
+    split_eval<<<1024, 256, 0, st>>>(rv, okey, oval, ckey, crec, c, p.dtype, p.max_split_svlen, s1in, cap, ctr);
   }
   set_n_s1<<<1, 1, 0, st>>>(ctr, cap);
 }
