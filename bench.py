@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--dtype", default=None, help="Hifi | ONT | CLR | READS (default by shape)")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="records of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--max-sigs", type=int, default=1 << 22)
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one rank per GPU) | gloo (rehearsal: all ranks on cuda:0)")
     args = ap.parse_args()
 
     import torch
@@ -41,10 +42,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
+    rehearsal = args.dist_backend == "gloo"
+    if rehearsal:
+        local_rank = 0                      # every rank shares cuda:0; collectives run on host tensors
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if rehearsal else dev    # device of the collective buffers
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from volcanosv_amd import shard, synth
     from volcanosv_amd.abi import DTYPE_BY_NAME
@@ -54,8 +62,8 @@ def main():
     dtype = DTYPE_BY_NAME[dtype_name]
     config_idx = {"hifi": 2, "ont": 3, "contig": 6}[args.shape]
     # reference index (contig lengths + per-tid record counts): rank 0 owns it, RCCL broadcast to the others
-    index = torch.tensor([[synth.CHR10_LEN, args.records]] * world, dtype=torch.int64, device=dev)
-    index = shard.broadcast_index(index, dev)
+    index = torch.tensor([[synth.CHR10_LEN, args.records]] * world, dtype=torch.int64, device=cdev)
+    index = shard.broadcast_index(index, cdev)
     chrom_len, n_rec = int(index[rank, 0]), int(index[rank, 1])
     # synthetic shard generated directly in HBM (torch CUDA generator = Philox); tid = rank
     t, nq, _ = synth.generate(n_rec, args.shape, seed=20250328 + config_idx + 1000 * rank, tid=rank, chrom_len=chrom_len, device=dev)
@@ -79,18 +87,26 @@ def main():
         step()
         eng.finish()          # one counter readback per step: status + table sizes
         scan_ms.append(eng.scan_ms())
-    calls = eng.table("calls") if dtype != DTYPE_BY_NAME["READS"] else eng.table("reads")
-    gathered = shard.gather_calls(calls, dev) if dtype != DTYPE_BY_NAME["READS"] else calls
+    if dtype == DTYPE_BY_NAME["READS"]:
+        gathered = eng.table("reads")
+    elif rehearsal:
+        gathered = shard.gather_calls(eng.table("calls"), cdev)
+    else:
+        # final gather of the per-rank call tables: device-to-device copy out of the library, RCCL all-gather over
+        # xGMI, one D2H of the merged table on rank 0
+        gathered = shard.gather_calls(eng.table_torch("calls", dev), dev, to_host=False)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
+    if isinstance(gathered, tuple):
+        gathered = shard.finish_gather(gathered)     # host copy for the VCF writer, after the timed region
     n_raw = len(eng.table("raw"))
     alg_bytes = 24 * recs.n_records + 4 * recs.n_ops + 32 * n_raw      # SURVEY.md §8d, per launch
     scan_s = sum(scan_ms) / len(scan_ms) / 1e3

@@ -162,6 +162,20 @@ class Engine:
             self._check(self.lib.vsv_table_fill(self.h, tid, out.ctypes.data_as(C.c_void_p), n.value, 0))
         return out
 
+    def table_torch(self, name, device):
+        """Live table (calls / merged / reads) as a uint8 torch tensor [n_rows * row_bytes] on `device`, copied
+        device-to-device by the library — the form the multi-GPU gather ships over RCCL without touching the host."""
+        import torch
+        tid = _TABLE_IDS[name]
+        n = C.c_int64()
+        self._check(self.lib.vsv_table_count(self.h, tid, C.byref(n)))
+        row = (CALL_DTYPE if name == "calls" else SIG_DTYPE).itemsize
+        out = torch.empty(max(int(n.value), 1) * row, dtype=torch.uint8, device=device)
+        if n.value:
+            self._check(self.lib.vsv_table_fill(self.h, tid, C.c_void_p(out.data_ptr()), n.value, 1))
+            torch.cuda.synchronize(device)
+        return out[: int(n.value) * row]
+
     def tables(self, dtype):
         if dtype == DTYPE_SVIM:
             names = ["raw", "cigar"]

@@ -38,31 +38,53 @@ def broadcast_index(index, device):
     return buf
 
 
-def gather_calls(calls, device):
-    """calls: numpy structured array (CALL_DTYPE) of this rank. Returns on rank 0 the concatenation over ranks sorted by
-    (tid, pos) (stable, rank order breaks ties; tids are disjoint across ranks so the order is unique), None elsewhere.
-    Counts go through an all_gather, rows through one padded all_gather of raw bytes (rows are 48 B, tables are
-    KB-MB: latency-bound, so a single collective beats per-peer send/recv rings on xGMI)."""
+def gather_calls(calls, device, to_host=True):
+    """calls: this rank's call table — a numpy CALL_DTYPE array (host path, gloo tests) or a uint8 torch tensor holding the
+    rows on `device` (GPU path: the bytes go GPU -> RCCL all-gather -> rank 0 with no host hop on the senders).
+    Returns on rank 0 the concatenation over ranks in (tid, pos) order as a numpy array, None elsewhere. Every rank's
+    table is already sorted by (tid, pos) and tids are disjoint across ranks, so the merge is a concatenation of the
+    per-rank tables ordered by their tids (a stable sort only if two ranks interleave tids).
+    Counts go through one all_gather, rows through one padded all_gather (tables are KB-MB: latency-bound, so a single
+    collective beats per-peer send/recv rings on point-to-point xGMI)."""
+    row = CALL_DTYPE.itemsize
+    as_tensor = torch.is_tensor(calls)
     if not dist.is_initialized() or dist.get_world_size() == 1:
-        return calls
+        return np.frombuffer(calls.cpu().numpy().tobytes(), dtype=CALL_DTYPE) if as_tensor else calls
     world = dist.get_world_size()
-    n = torch.tensor([len(calls)], dtype=torch.int64, device=device)
+    n_rows = (calls.numel() // row) if as_tensor else len(calls)
+    n = torch.tensor([n_rows], dtype=torch.int64, device=device)
     counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
     dist.all_gather(counts, n)
     counts = [int(c.item()) for c in counts]
     mx = max(max(counts), 1)
-    row = CALL_DTYPE.itemsize
     mine = torch.zeros(mx * row, dtype=torch.uint8, device=device)
-    if len(calls):
-        mine[: len(calls) * row] = torch.from_numpy(np.frombuffer(calls.tobytes(), dtype=np.uint8).copy()).to(device)
+    if n_rows:
+        src = calls if as_tensor else torch.from_numpy(np.frombuffer(calls.tobytes(), dtype=np.uint8).copy())
+        mine[: n_rows * row] = src.to(device)
     bufs = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(bufs, mine)
     if dist.get_rank() != 0:
         return None
-    parts = [np.frombuffer(bufs[r][: counts[r] * row].cpu().numpy().tobytes(), dtype=CALL_DTYPE) for r in range(world)]
-    allc = np.concatenate(parts) if parts else np.zeros(0, CALL_DTYPE)
-    key = (allc["sig"]["tid"].astype(np.int64) << 32) | (allc["sig"]["pos"].astype(np.int64) & 0xFFFFFFFF)
-    return allc[np.argsort(key, kind="stable")]
+    if not to_host:       # rows are on rank 0's device; `finish_gather` turns them into the merged numpy table later
+        return (bufs, counts)
+    return finish_gather((bufs, counts))
+
+
+def finish_gather(gathered):
+    """Rank 0: (padded device buffers, counts) from gather_calls(..., to_host=False) -> merged numpy call table."""
+    bufs, counts = gathered
+    row = CALL_DTYPE.itemsize
+    world = len(bufs)
+    parts = [bufs[r][: counts[r] * row].cpu().numpy().view(CALL_DTYPE) for r in range(world) if counts[r]]
+    if not parts:
+        return np.zeros(0, CALL_DTYPE)
+    spans = [(int(p["sig"]["tid"][0]), int(p["sig"]["tid"][-1])) for p in parts]
+    order = sorted(range(len(parts)), key=lambda i: spans[i])
+    allc = np.concatenate([parts[i] for i in order])
+    if any(spans[order[i]][1] >= spans[order[i + 1]][0] for i in range(len(order) - 1)):   # interleaved tids: real merge
+        key = (allc["sig"]["tid"].astype(np.int64) << 32) | (allc["sig"]["pos"].astype(np.int64) & 0xFFFFFFFF)
+        allc = allc[np.argsort(key, kind="stable")]
+    return allc
 
 
 def _all_to_all_bytes(chunks, device):
