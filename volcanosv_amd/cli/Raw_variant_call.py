@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Drop-in for Large_INDEL/Raw_variant_call.py (same flags). The aligner and the post-filters stay external; the contig and
+reads signature extraction run on the GPU in this process."""
+import os
+import shutil
+import sys
+from argparse import ArgumentParser
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from volcanosv_amd import contig_signature, pipeline, reads_signature, vcf  # noqa: E402
+
+parser = ArgumentParser(description="", usage='use "python3 %(prog)s --help" for more information')
+parser.add_argument('--contig_path', '-contig')
+parser.add_argument('--reference_path', '-ref')
+parser.add_argument('--signature_dir', '-sigd')
+parser.add_argument('--rbam_file', '-rbam')
+parser.add_argument('--output_dir', '-o')
+parser.add_argument('--data_type', '-dtype', help="Hifi;CLR;ONT")
+parser.add_argument('--chr_num', '-chr')
+parser.add_argument('--header_file', '-header')
+parser.add_argument('--n_thread', '-t', type=int, default=10)
+parser.add_argument('--mem_per_thread', '-mempt', default='1G')
+a = parser.parse_args()
+os.makedirs(a.output_dir, exist_ok=True)
+code_dir = os.environ.get("VOLCANOSV_CODE_DIR")      # reference Large_INDEL/ dir for FP_filter_v1.py / remove_redundancy.py
+prefix = a.contig_path.split('/')[-1].split('.')[0]
+bam = pipeline.align_contigs(a.reference_path, a.contig_path, a.output_dir + '/' + prefix + '.sorted.bam', "asm5", a.n_thread, a.mem_per_thread)
+chr_num = int(a.chr_num) if a.chr_num not in (None, "None") else None
+per_chr = contig_signature.run(a.data_type, bam, a.contig_path, a.reference_path, a.output_dir, chr_num, a.header_file)
+header = open(a.header_file).readlines() if a.header_file else vcf.default_header()
+raw = a.output_dir + "/volcano_raw_variant.vcf"
+vcf.write_vcf(raw, header, [l for lines in per_chr.values() for l in lines])          # Raw_variant_call.py:77-80
+sigd = a.signature_dir
+if sigd is None and a.rbam_file and chr_num is not None:
+    reads_signature.run(a.rbam_file, a.output_dir, chr_num)                            # :83-88
+    sigd = a.output_dir + "/reads_signature/"
+filtered = a.output_dir + "/volcano_variant_filtered.vcf"
+final_dir = a.output_dir + '/final_vcf/'
+if not (pipeline.spawn_reference_script(code_dir, "FP_filter_v1.py", "-i %s -sigd %s -o %s" % (raw, sigd, filtered)) and
+        pipeline.spawn_reference_script(code_dir, "remove_redundancy.py", "-i %s -o %s" % (filtered, final_dir))):
+    os.makedirs(final_dir, exist_ok=True)                                             # post-filters are outside this build
+    shutil.copy(raw, final_dir + "volcano_variant_no_redundancy.vcf")
+    print("note: FP_filter_v1.py / remove_redundancy.py not run (set VOLCANOSV_CODE_DIR to the reference's Large_INDEL dir)")

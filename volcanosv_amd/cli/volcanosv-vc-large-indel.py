@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Drop-in for Large_INDEL/volcanosv-vc-large-indel.py (same flags, plus --gpus). Chromosomes fan out over GPUs (one
+Raw_variant_call.py process per chromosome, LPT over the visible devices) instead of joblib over CPU cores."""
+import argparse
+import os
+import subprocess
+import sys
+from argparse import ArgumentParser
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from volcanosv_amd import pipeline, shard  # noqa: E402
+
+p = ArgumentParser(description="", usage='use "python3 %(prog)s --help" for more information', formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+p.add_argument('--input_dir', '-i')
+p.add_argument('--output_dir', '-o')
+p.add_argument('--data_type', '-dtype', help='Hifi;CLR;ONT')
+p.add_argument('--bam_file', '-bam')
+p.add_argument('--reference', '-ref')
+p.add_argument('--read_signature_dir', '-rdsig')
+p.add_argument('--pre_cutesig', '-presig')
+p.add_argument('--chr_num', '-chr', type=int, default=None)
+p.add_argument('--n_thread', '-t', type=int, default=11)
+p.add_argument('--n_thread_align', '-ta', type=int, default=10)
+p.add_argument('--mem_per_thread', '-mempt', default='768M')
+p.add_argument('--prefix', '-px', default="Sample")
+p.add_argument('--gpus', type=int, default=1, help="GPUs to spread the chromosomes over")
+a = p.parse_args()
+here = os.path.dirname(os.path.abspath(__file__))
+out = a.output_dir
+out_chr = out + "/chr%d/" % a.chr_num if a.chr_num is not None else out
+os.makedirs(out_chr, exist_ok=True)
+header_file = out_chr + "/VCF_header"
+pipeline.generate_vcf_header(a.reference, header_file, a.chr_num, a.prefix)
+ref_dir = out_chr + "/ref_by_chr/"
+pipeline.split_reference(a.reference, ref_dir, a.chr_num)
+chroms = [a.chr_num] if a.chr_num is not None else list(range(1, 23))
+fai = {l.split("\t")[0]: int(l.split("\t")[1]) for l in open(a.reference + ".fai")}
+owner = shard.lpt_assign([fai.get("chr%d" % c, 1) for c in chroms], max(1, a.gpus))
+procs = []
+for c, g in zip(chroms, owner):
+    fasta = a.input_dir + "/chr%d/assembly/final_contigs/%s_final_contigs.fa" % (c, a.prefix)
+    sig = "-sigd %s" % a.read_signature_dir if a.read_signature_dir else "-rbam %s" % a.bam_file
+    cmd = "python3 %s/Raw_variant_call.py -contig %s -ref %s %s -o %s -dtype %s -t %d -chr %d -header %s" % (
+        here, fasta, ref_dir + "/chr%d.fa" % c, sig, out + "/chr%d/" % c, a.data_type, a.n_thread_align, c, header_file)
+    procs.append(subprocess.Popen(cmd, shell=True, env=dict(os.environ, HIP_VISIBLE_DEVICES=str(g))))
+for pr in procs:
+    pr.wait()
+body, header = [], open(header_file).readlines()
+for c in chroms:
+    path = out + '/chr%d/final_vcf/volcano_variant_no_redundancy.vcf' % c
+    body += [l for l in open(path) if l[0] != '#']
+raw_vcf = out + ("/raw_variants_wgs.vcf" if a.chr_num is None else "/chr%d/final_vcf/volcano_variant_no_redundancy.vcf" % a.chr_num)
+if a.chr_num is None:
+    open(raw_vcf, 'w').writelines(header + body)
+code_dir = os.environ.get("VOLCANOSV_CODE_DIR")
+chr_para = "" if a.chr_num is None else " -chr %d" % a.chr_num
+src = ("-presig %s" % a.pre_cutesig) if a.pre_cutesig else ("-bam %s -ref %s" % (a.bam_file, a.reference))
+ran = pipeline.spawn_reference_script(code_dir, "filter_GT_correction.py", "-vcf %s %s -dtype %s -t %d%s" % (raw_vcf, src, a.data_type, a.n_thread, chr_para))
+infile = (out + '/chr%d/final_vcf/variants_filtered_GT_corrected.vcf' % a.chr_num) if a.chr_num is not None else out + "/variants_filtered_GT_corrected.vcf"
+if not ran or not os.path.exists(infile):
+    infile = raw_vcf                                      # GT correction is outside this build
+outfile = (out_chr + "/%s_volcanosv_large_indel_chr%d.vcf" % (a.prefix, a.chr_num)) if a.chr_num is not None else out + "/%s_volcanosv_large_indel.vcf" % a.prefix
+open(outfile, "w").writelines(pipeline.phase_large_indel(open(infile).readlines(), header))
+print("wrote", outfile)
