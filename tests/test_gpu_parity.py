@@ -297,3 +297,20 @@ def test_bnd_pair_rows_after_exchange(eng):
     got = eng.bnd_pair_rows(sub, seg.contig_rank)
     want = oracle.run_bnd_pair(sub, seg.contig_rank)
     assert len(got) > 10 and np.array_equal(got, want)
+
+
+def test_dense_runs_use_the_wave_cooperative_kernels(eng):
+    """Dense regions (hundreds of signatures within 100 bp, runs and stretches > 48 rows): cluster_long / pair_long."""
+    from volcanosv_amd import synth
+    t, nq, nt = synth.generate(3000, "contig", seed=21, chrom_len=30_000_000)     # ~450x contig coverage
+    soa = synth.to_soa(t, nq)
+    from volcanosv_amd.engine import Engine
+    e = Engine(0, max_sigs=1 << 23)
+    try:
+        got = run_both(e, soa, DTYPE_HIFI)
+        assert len(got["raw"]) > 500000
+        t, nq, nt = synth.generate(300000, "ont", seed=22, chrom_len=600_000, events_per_record=0.3, site_step=2000)
+        soa = synth.to_soa(t, nq)
+        run_both(e, soa, DTYPE_ONT)
+    finally:
+        e.close()

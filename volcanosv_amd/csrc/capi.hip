@@ -213,7 +213,7 @@ int enq_stage1(vsv_handle* h) {
   Counters* c = dctr(h);
   vsv_launch_sort_stage(st, (vsv_sig*)h->s1in.p, &c->n_s1, 1, pos_bits(h), key_bits(h), (vsv_sig*)h->s1s.p, &c->n_alive1, stage_bufs(h),
                         sort_work(h), h->cap_sigs, dctr(h));
-  vsv_launch_cluster(st, (vsv_sig*)h->s1s.p, &c->n_alive1, h->prm.cluster_shift, pos_bits(h), (vsv_sig*)h->c1.p, stage_bufs(h));
+  vsv_launch_cluster(st, (vsv_sig*)h->s1s.p, &c->n_alive1, h->prm.cluster_shift, pos_bits(h), (vsv_sig*)h->c1.p, stage_bufs(h), (uint64_t*)h->key2.p, dctr(h));
   HIPCHK(h, hipGetLastError());
   h->stage_done = 3;
   return 0;
@@ -224,7 +224,7 @@ int enq_merge(vsv_handle* h) {
   Counters* c = dctr(h);
   vsv_launch_sort_stage(st, (vsv_sig*)h->c1.p, &c->n_alive1, 2, pos_bits(h), key_bits(h), (vsv_sig*)h->s2s.p, &c->n_alive2, stage_bufs(h),
                         sort_work(h), h->cap_sigs, dctr(h));
-  vsv_launch_cluster(st, (vsv_sig*)h->s2s.p, &c->n_alive2, h->prm.cluster_shift, pos_bits(h), (vsv_sig*)h->c2.p, stage_bufs(h));
+  vsv_launch_cluster(st, (vsv_sig*)h->s2s.p, &c->n_alive2, h->prm.cluster_shift, pos_bits(h), (vsv_sig*)h->c2.p, stage_bufs(h), (uint64_t*)h->key2.p, dctr(h));
   vsv_launch_sort_stage(st, (vsv_sig*)h->c2.p, &c->n_alive2, 3, pos_bits(h), key_bits(h), (vsv_sig*)h->merged.p, &c->n_alive3, stage_bufs(h),
                         sort_work(h), h->cap_sigs, dctr(h));
   HIPCHK(h, hipGetLastError());
@@ -236,7 +236,7 @@ int enq_pair(vsv_handle* h) {
   hipStream_t st = h->stream;
   Counters* c = dctr(h);
   vsv_launch_pair(st, (vsv_sig*)h->merged.p, &c->n_alive3, h->prm.pair_shift, (vsv_call*)h->calls_tmp.p, (vsv_call*)h->calls.p,
-                  &c->n_calls, stage_bufs(h), (uint64_t*)h->key2.p, (uint32_t*)h->idx2.p, sort_work(h), pos_bits(h), key_bits(h), h->cap_sigs);
+                  &c->n_calls, stage_bufs(h), (uint64_t*)h->key2.p, (uint32_t*)h->idx2.p, sort_work(h), pos_bits(h), key_bits(h), h->cap_sigs, dctr(h));
   HIPCHK(h, hipGetLastError());
   h->stage_done = 5;
   return 0;

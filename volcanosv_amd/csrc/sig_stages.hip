@@ -428,15 +428,25 @@ __global__ __launch_bounds__(256) void count_alive(const uint64_t* __restrict__ 
 // performs the sequential greedy exactly: seed = first unassigned, members = unassigned rows matching
 // the SEED, representative = first longest member (Hifi.py:236-247). Output row i = representative
 // if i is a seed, dead otherwise, so seed order is preserved.
+constexpr uint32_t LONG_RUN = 48;   // runs / stretches longer than this go to the wave-cooperative kernels
+
+__device__ __forceinline__ int32_t ld_i32(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_i32(int32_t* p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 __global__ __launch_bounds__(256) void cluster_kernel(const vsv_sig* __restrict__ s, const uint64_t* __restrict__ key,
                                                       const uint32_t* __restrict__ d_n, int max_shift, int pb,
-                                                      int32_t* __restrict__ cl, vsv_sig* __restrict__ out) {
+                                                      int32_t* __restrict__ cl, vsv_sig* __restrict__ out,
+                                                      uint64_t* __restrict__ long_list, uint32_t* __restrict__ n_long) {
   const uint32_t n = *d_n;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const uint64_t lk = key[i] >> pb;
     if (i > 0 && (key[i - 1] >> pb) == lk && (int64_t)s[i].pos - s[i - 1].pos <= max_shift) continue;  // not a run head
     uint32_t e = i + 1;
     while (e < n && (key[e] >> pb) == lk && (int64_t)s[e].pos - s[e - 1].pos <= max_shift) ++e;
+    if (e - i > LONG_RUN) {   // dense region: one wave works on it (cluster_long_kernel)
+      long_list[atomicAdd(n_long, 1u)] = ((uint64_t)i << 32) | e;
+      continue;
+    }
     for (uint32_t k = i; k < e; ++k) cl[k] = -1;
     for (uint32_t a = i; a < e; ++a) {
       if (cl[a] != -1) { out[a] = dead_sig(); continue; }
@@ -458,6 +468,53 @@ __global__ __launch_bounds__(256) void cluster_kernel(const vsv_sig* __restrict_
   }
 }
 
+// One wave per long run: seeds stay sequential (the greedy is order dependent), the scan of a seed's window and the
+// search for the next seed are 64-wide. cl[] is accessed with agent-scope relaxed atomics (L2), so the wave sees its
+// own earlier stores whatever the L1 holds.
+__global__ __launch_bounds__(256) void cluster_long_kernel(const vsv_sig* __restrict__ s, int max_shift, int32_t* __restrict__ cl,
+                                                           vsv_sig* __restrict__ out, const uint64_t* __restrict__ long_list,
+                                                           const uint32_t* __restrict__ n_long) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t nwaves = gridDim.x * (blockDim.x >> 6), nl = *n_long;
+  for (uint32_t r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r < nl; r += nwaves) {
+    const uint32_t i = (uint32_t)(long_list[r] >> 32), e = (uint32_t)long_list[r];
+    for (uint32_t k = i + lane; k < e; k += 64) st_i32(&cl[k], -1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the wave's stores have reached L2 before its next loads
+    uint32_t a = i;
+    while (a < e) {
+      const vsv_sig s1 = s[a];
+      if (lane == 0) st_i32(&cl[a], (int32_t)a);
+      uint64_t best = ((uint64_t)(uint32_t)s1.svlen << 32) | (0xFFFFFFFFu - a);   // max length, then lowest index
+      for (uint32_t b0 = a + 1; b0 < e; b0 += 64) {
+        const uint32_t b = b0 + lane;
+        const bool valid = b < e;
+        vsv_sig s2 = s1;
+        if (valid) s2 = s[b];
+        const bool inwin = valid && (int64_t)s2.pos - s1.pos <= max_shift;
+        if (__ballot(inwin) == 0) break;          // positions ascend: the whole tile is beyond the window
+        if (inwin && ld_i32(&cl[b]) == -1 && vsv_match(s1, s2, max_shift)) {
+          st_i32(&cl[b], (int32_t)a);
+          const uint64_t c = ((uint64_t)(uint32_t)s2.svlen << 32) | (0xFFFFFFFFu - b);
+          if (c > best) best = c;
+        }
+      }
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) { const uint64_t o = __shfl_xor(best, d, 64); if (o > best) best = o; }
+      if (lane == 0) out[a] = s[0xFFFFFFFFu - (uint32_t)best];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      // next seed: first unassigned row after a
+      uint32_t nxt = e;
+      for (uint32_t b0 = a + 1; b0 < e; b0 += 64) {
+        const uint32_t b = b0 + lane;
+        const uint64_t free_m = __ballot(b < e && ld_i32(&cl[b]) == -1);
+        if (free_m) { nxt = b0 + (uint32_t)__builtin_ctzll(free_m); break; }
+      }
+      a = nxt;
+    }
+    for (uint32_t k = i + lane; k < e; k += 64) if (ld_i32(&cl[k]) != (int32_t)k) out[k] = dead_sig();
+  }
+}
+
 // ---- haplotype pairing --------------------------------------------------------------------------------
 // merged table m sorted by (tid, hap, pos), keys = stage-3 keys. One lane owns a stretch of hp1 rows whose
 // consecutive positions differ by <= 2*pair_shift (candidate windows of different stretches are disjoint,
@@ -471,7 +528,8 @@ __device__ __forceinline__ uint32_t lower_bound_key(const uint64_t* __restrict__
 }
 __global__ __launch_bounds__(256) void pair_kernel(const vsv_sig* __restrict__ m, const uint64_t* __restrict__ key,
                                                    const uint32_t* __restrict__ d_n, int pair_shift, int pb,
-                                                   int32_t* __restrict__ st2, vsv_call* __restrict__ out) {
+                                                   int32_t* __restrict__ st2, vsv_call* __restrict__ out,
+                                                   uint64_t* __restrict__ long_list, uint32_t* __restrict__ n_long) {
   const uint32_t n = *d_n;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const vsv_sig me = m[i];
@@ -484,6 +542,11 @@ __global__ __launch_bounds__(256) void pair_kernel(const vsv_sig* __restrict__ m
     // first hp2 row of this tid with pos >= pos_i - pair_shift (rows further left can never match)
     uint32_t jlo = lower_bound_key(key, n, (tk << sh_tid) | (1ull << sh_hap) | vsv_kpos((int32_t)max((int64_t)me.pos - pair_shift, (int64_t)-VSV_POS_BIAS)));
     if (jlo < b0) jlo = b0;
+    {   // dense stretch: hand it to pair_long_kernel
+      uint32_t e = i + 1;
+      while (e < n && e - i <= LONG_RUN && (key[e] >> sh_hap) == (key[i] >> sh_hap) && (int64_t)m[e].pos - m[e - 1].pos <= 2 * (int64_t)pair_shift) ++e;
+      if (e - i > LONG_RUN) { long_list[atomicAdd(n_long, 1u)] = ((uint64_t)i << 32) | jlo; continue; }
+    }
     for (uint32_t a = i; a < n; ++a) {
       const vsv_sig s1 = m[a];
       if ((key[a] >> sh_hap) != (key[i] >> sh_hap)) break;
@@ -505,6 +568,50 @@ __global__ __launch_bounds__(256) void pair_kernel(const vsv_sig* __restrict__ m
     }
   }
 }
+// One wave per long hp1 stretch: hp1 rows stay sequential (first come, first served), the candidate window of a row is
+// scanned 64 hp2 rows at a time and the first match is the lowest set ballot bit.
+__global__ __launch_bounds__(256) void pair_long_kernel(const vsv_sig* __restrict__ m, const uint64_t* __restrict__ key,
+                                                        const uint32_t* __restrict__ d_n, int pair_shift, int pb,
+                                                        int32_t* __restrict__ st2, vsv_call* __restrict__ out,
+                                                        const uint64_t* __restrict__ long_list, const uint32_t* __restrict__ n_long) {
+  const uint32_t n = *d_n;
+  const int lane = threadIdx.x & 63;
+  const int sh_hap = pb + 2, sh_tid = pb + 3;
+  const uint32_t nwaves = gridDim.x * (blockDim.x >> 6), nl = *n_long;
+  for (uint32_t r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r < nl; r += nwaves) {
+    const uint32_t i = (uint32_t)(long_list[r] >> 32);
+    uint32_t jlo = (uint32_t)long_list[r];
+    const uint64_t tk = key[i] >> sh_tid;
+    const uint32_t b1 = lower_bound_key(key, n, (tk + 1) << sh_tid);
+    for (uint32_t a = i; a < n; ++a) {
+      const vsv_sig s1 = m[a];
+      if ((key[a] >> sh_hap) != (key[i] >> sh_hap)) break;
+      if (a > i && (int64_t)s1.pos - m[a - 1].pos > 2 * (int64_t)pair_shift) break;
+      while (jlo < b1 && (int64_t)s1.pos - m[jlo].pos > pair_shift) ++jlo;
+      int32_t mate = -1;
+      for (uint32_t j0 = jlo; j0 < b1; j0 += 64) {
+        const uint32_t j = j0 + lane;
+        const bool valid = j < b1;
+        vsv_sig s2 = s1;
+        if (valid) s2 = m[j];
+        const bool inwin = valid && (int64_t)s2.pos - s1.pos <= pair_shift;
+        if (__ballot(inwin) == 0) break;
+        const bool ok = inwin && ((s1.meta ^ s2.meta) & VSV_M_DEL) == 0 && ld_i32(&st2[j]) == -1 && vsv_match(s1, s2, pair_shift);
+        const uint64_t bal = __ballot(ok);
+        if (bal) { mate = (int32_t)(j0 + (uint32_t)__builtin_ctzll(bal)); break; }
+      }
+      if (lane == 0) {
+        vsv_call c;
+        c.a = (int32_t)a; c.pad = 0;
+        if (mate < 0) { c.sig = s1; c.b = -1; c.gt = 1; }
+        else { st_i32(&st2[mate], (int32_t)a); const vsv_sig s2 = m[mate]; c.sig = (s1.svlen > s2.svlen) ? s1 : s2; c.b = mate; c.gt = 2; }
+        out[a] = c;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    }
+  }
+}
+
 // hp2 rows: unpaired -> 0/1 call (Hifi.py:588-592), paired -> dead slot
 __global__ __launch_bounds__(256) void pair_finish(const vsv_sig* __restrict__ m, const uint32_t* __restrict__ d_n,
                                                    const int32_t* __restrict__ st2, vsv_call* __restrict__ out) {
@@ -582,15 +689,19 @@ void vsv_launch_sort_stage(hipStream_t st, const vsv_sig* in, const uint32_t* d_
 }
 
 void vsv_launch_cluster(hipStream_t st, const vsv_sig* sorted, const uint32_t* d_alive, int max_shift, int pb, vsv_sig* out,
-                        const StageBufs& b) {
-  cluster_kernel<<<EW_GRID, 256, 0, st>>>(sorted, b.key, d_alive, max_shift, pb, b.cl, out);
+                        const StageBufs& b, uint64_t* long_list, Counters* ctr) {
+  (void)hipMemsetAsync(&ctr->n_long, 0, sizeof(uint32_t), st);
+  cluster_kernel<<<EW_GRID, 256, 0, st>>>(sorted, b.key, d_alive, max_shift, pb, b.cl, out, long_list, &ctr->n_long);
+  cluster_long_kernel<<<EW_GRID, 256, 0, st>>>(sorted, max_shift, b.cl, out, long_list, &ctr->n_long);
 }
 
 void vsv_launch_pair(hipStream_t st, const vsv_sig* merged, const uint32_t* d_alive3, int pair_shift, vsv_call* calls_tmp,
                      vsv_call* calls, uint32_t* d_ncalls, const StageBufs& b, uint64_t* key2, uint32_t* idx2,
-                     const SortWork& sw, int pb, int nbits, int64_t cap) {
+                     const SortWork& sw, int pb, int nbits, int64_t cap, Counters* ctr) {
   fill_i32<<<EW_GRID, 256, 0, st>>>(b.cl, -1, d_alive3);
-  pair_kernel<<<EW_GRID, 256, 0, st>>>(merged, b.key, d_alive3, pair_shift, pb, b.cl, calls_tmp);
+  (void)hipMemsetAsync(&ctr->n_long, 0, sizeof(uint32_t), st);
+  pair_kernel<<<EW_GRID, 256, 0, st>>>(merged, b.key, d_alive3, pair_shift, pb, b.cl, calls_tmp, key2, &ctr->n_long);
+  pair_long_kernel<<<EW_GRID, 256, 0, st>>>(merged, b.key, d_alive3, pair_shift, pb, b.cl, calls_tmp, key2, &ctr->n_long);
   pair_finish<<<EW_GRID, 256, 0, st>>>(merged, d_alive3, b.cl, calls_tmp);
   build_call_keys<<<EW_GRID, 256, 0, st>>>(calls_tmp, d_alive3, pb, key2, idx2);
   vsv_radix_sort_pairs(st, key2, idx2, d_alive3, cap, nbits, sw);

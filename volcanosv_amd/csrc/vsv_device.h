@@ -32,7 +32,8 @@ struct Counters {
   uint32_t n_calls;
   uint32_t n_reads;
   uint32_t err;
-  uint32_t pad[5];
+  uint32_t n_long;     // long runs / stretches queued for the wave-cooperative kernels (reset per stage)
+  uint32_t pad[4];
 };
 
 struct RecView {
@@ -114,10 +115,10 @@ void vsv_launch_split(hipStream_t st, const RecView& rv, const vsv_params& p, in
 void vsv_launch_sort_stage(hipStream_t st, const vsv_sig* in, const uint32_t* d_n, int stage, int pb, int nbits, vsv_sig* sorted,
                            uint32_t* d_alive, const StageBufs& b, const SortWork& sw, int64_t cap, Counters* ctr);
 void vsv_launch_cluster(hipStream_t st, const vsv_sig* sorted, const uint32_t* d_alive, int max_shift, int pb, vsv_sig* out,
-                        const StageBufs& b);
+                        const StageBufs& b, uint64_t* long_list, Counters* ctr);
 void vsv_launch_pair(hipStream_t st, const vsv_sig* merged, const uint32_t* d_alive3, int pair_shift, vsv_call* calls_tmp,
                      vsv_call* calls, uint32_t* d_ncalls, const StageBufs& b, uint64_t* key2, uint32_t* idx2,
-                     const SortWork& sw, int pb, int nbits, int64_t cap);
+                     const SortWork& sw, int pb, int nbits, int64_t cap, Counters* ctr);
 
 // bnd.hip
 void vsv_launch_bnd_segments(hipStream_t st, const vsv_segments& s, const vsv_bnd_params& p, vsv_bnd* cand, uint32_t cap, Counters* ctr);

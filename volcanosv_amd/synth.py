@@ -32,8 +32,28 @@ def _rand(gen, n, device):
 
 
 def generate(n_records, shape="hifi", seed=20250330, tid=0, chrom_len=CHR10_LEN, device="cpu", events_per_record=None,
-             site_step=5000):
-    """Returns a dict of torch tensors in the C-ABI SoA layout plus n_qids / n_tids."""
+             site_step=5000, max_chunk_ops=400_000_000):
+    """Returns (dict of torch tensors in the C-ABI SoA layout, n_qids, n_tids). Large streams are generated in position
+    slices of at most ~max_chunk_ops CIGAR ops each (the ragged-array temporaries are int64), so that config 3
+    (50 M ONT-like records, 10^10 ops) fits in HBM while it is being built."""
+    cfg = SHAPES[shape]
+    est_ops = n_records * (2.0 * cfg["k"] + 1.0)
+    n_chunks = int(min(max(1, -(-est_ops // max_chunk_ops)), max(1, n_records // 1000)))
+    if n_chunks > 1 and shape != "contig":
+        parts, per = [], n_records // n_chunks
+        for c in range(n_chunks):
+            n_c = per if c < n_chunks - 1 else n_records - per * (n_chunks - 1)
+            lo, hi = chrom_len * c // n_chunks, chrom_len * (c + 1) // n_chunks
+            t, nq, _ = _generate_slice(n_c, shape, seed + 7919 * c, tid, lo, hi, chrom_len, device, events_per_record, site_step)
+            parts.append((t, nq))
+        t, nq = concat(parts)
+        return t, nq, int(tid) + 1
+    return _generate_slice(n_records, shape, seed, tid, 0, chrom_len, chrom_len, device, events_per_record, site_step)
+
+
+def _generate_slice(n_records, shape, seed, tid, pos_lo, pos_hi, chrom_len, device, events_per_record, site_step):
+    """One position slice [pos_lo, pos_hi): records sorted by pos; split mates are only planted for records whose mate
+    still falls inside the slice, so concatenated slices stay coordinate-sorted."""
     cfg = SHAPES[shape]
     dev = torch.device(device)
     gen = torch.Generator(device=dev)
@@ -43,11 +63,15 @@ def generate(n_records, shape="hifi", seed=20250330, tid=0, chrom_len=CHR10_LEN,
     # ---- base records -------------------------------------------------------------------------------
     k = torch.poisson(torch.full((nb,), cfg["k"], device=dev), generator=gen).to(torch.int64)
     n_ops = 2 * k + 1
-    pos = torch.sort(_randint(gen, 0, max(1, chrom_len - 40000), nb, dev)).values
+    pos = torch.sort(_randint(gen, pos_lo, max(pos_lo + 1, min(pos_hi, chrom_len - 40000)), nb, dev)).values
     has_mate = torch.zeros(nb, dtype=torch.bool, device=dev)
     if n_mates > 0:
         sel = torch.randperm(nb, generator=gen, device=dev)[:n_mates]
         has_mate[sel] = True
+        if pos_hi < chrom_len:   # interior slice: a mate (pos + span + <1 kb) must not spill into the next slice
+            max_span = (2 * k + 1) * cfg["m_hi"] + 6000
+            has_mate &= (pos + max_span) < pos_hi
+    n_mates = int(has_mate.sum())
     n_ops_b = n_ops + has_mate.to(torch.int64)  # +1 tail clip
     off_b = torch.zeros(nb + 1, dtype=torch.int64, device=dev)
     off_b[1:] = torch.cumsum(n_ops_b, 0)
