@@ -66,7 +66,7 @@ __global__ __launch_bounds__(1024) void rs_scan(uint32_t* __restrict__ hist, con
 #pragma unroll
   for (int k = 0; k < DPT; ++k) tot[k] = 0;
   if (active) {
-#pragma unroll 8
+#pragma unroll 16
     for (uint32_t tile = 0; tile < ntiles; ++tile)
 #pragma unroll
       for (int k = 0; k < DPT; ++k) tot[k] += hist[(size_t)tile * BINS + t * DPT + k];
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(1024) void rs_scan(uint32_t* __restrict__ hist, con
     uint32_t base[DPT];
 #pragma unroll
     for (int k = 0; k < DPT; ++k) { base[k] = run; run += tot[k]; }
-#pragma unroll 8
+#pragma unroll 16
     for (uint32_t tile = 0; tile < ntiles; ++tile)
 #pragma unroll
       for (int k = 0; k < DPT; ++k) {

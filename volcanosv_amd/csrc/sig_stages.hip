@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256) void cluster_long_kernel(const vsv_sig* __rest
   for (uint32_t r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r < nl; r += nwaves) {
     const uint32_t i = (uint32_t)(long_list[r] >> 32), e = (uint32_t)long_list[r];
     for (uint32_t k = i + lane; k < e; k += 64) st_i32(&cl[k], -1);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the wave's stores have reached L2 before its next loads
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the wave's (L2, sc1) stores are acknowledged before its next loads
     uint32_t a = i;
     while (a < e) {
       const vsv_sig s1 = s[a];
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(256) void cluster_long_kernel(const vsv_sig* __rest
 #pragma unroll
       for (int d = 32; d > 0; d >>= 1) { const uint64_t o = __shfl_xor(best, d, 64); if (o > best) best = o; }
       if (lane == 0) out[a] = s[0xFFFFFFFFu - (uint32_t)best];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       // next seed: first unassigned row after a
       uint32_t nxt = e;
       for (uint32_t b0 = a + 1; b0 < e; b0 += 64) {
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(256) void pair_long_kernel(const vsv_sig* __restric
         else { st_i32(&st2[mate], (int32_t)a); const vsv_sig s2 = m[mate]; c.sig = (s1.svlen > s2.svlen) ? s1 : s2; c.b = mate; c.gt = 2; }
         out[a] = c;
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
   }
 }
@@ -636,6 +636,7 @@ __global__ void copy_rows(const T* __restrict__ in, const uint32_t* __restrict__
 }
 
 constexpr int EW_GRID = 128;
+constexpr int LONG_GRID = 2048;   // wave-per-run kernels: enough waves to fill the chip when dense regions are many
 
 }  // namespace
 
@@ -692,7 +693,7 @@ void vsv_launch_cluster(hipStream_t st, const vsv_sig* sorted, const uint32_t* d
                         const StageBufs& b, uint64_t* long_list, Counters* ctr) {
   (void)hipMemsetAsync(&ctr->n_long, 0, sizeof(uint32_t), st);
   cluster_kernel<<<EW_GRID, 256, 0, st>>>(sorted, b.key, d_alive, max_shift, pb, b.cl, out, long_list, &ctr->n_long);
-  cluster_long_kernel<<<EW_GRID, 256, 0, st>>>(sorted, max_shift, b.cl, out, long_list, &ctr->n_long);
+  cluster_long_kernel<<<LONG_GRID, 256, 0, st>>>(sorted, max_shift, b.cl, out, long_list, &ctr->n_long);
 }
 
 void vsv_launch_pair(hipStream_t st, const vsv_sig* merged, const uint32_t* d_alive3, int pair_shift, vsv_call* calls_tmp,
@@ -701,7 +702,7 @@ void vsv_launch_pair(hipStream_t st, const vsv_sig* merged, const uint32_t* d_al
   fill_i32<<<EW_GRID, 256, 0, st>>>(b.cl, -1, d_alive3);
   (void)hipMemsetAsync(&ctr->n_long, 0, sizeof(uint32_t), st);
   pair_kernel<<<EW_GRID, 256, 0, st>>>(merged, b.key, d_alive3, pair_shift, pb, b.cl, calls_tmp, key2, &ctr->n_long);
-  pair_long_kernel<<<EW_GRID, 256, 0, st>>>(merged, b.key, d_alive3, pair_shift, pb, b.cl, calls_tmp, key2, &ctr->n_long);
+  pair_long_kernel<<<LONG_GRID, 256, 0, st>>>(merged, b.key, d_alive3, pair_shift, pb, b.cl, calls_tmp, key2, &ctr->n_long);
   pair_finish<<<EW_GRID, 256, 0, st>>>(merged, d_alive3, b.cl, calls_tmp);
   build_call_keys<<<EW_GRID, 256, 0, st>>>(calls_tmp, d_alive3, pb, key2, idx2);
   vsv_radix_sort_pairs(st, key2, idx2, d_alive3, cap, nbits, sw);

@@ -95,8 +95,8 @@ def _generate_slice(n_records, shape, seed, tid, pos_lo, pos_hi, chrom_len, devi
     ev_frac = cfg["ev"] if events_per_record is None else events_per_record
     mean_span = (cfg["k"] + 1.0) * 0.5 * (cfg["m_lo"] + cfg["m_hi"])
     # probability that an M op crossing a site carries the event: events/record ~= ev_frac (contig shape: every
-    # other site, i.e. hundreds of events per Mb-scale contig)
-    p_cross = 0.5 if shape == "contig" else min(1.0, ev_frac * site_step / mean_span)
+    # 25th site, i.e. tens of events per Mb-scale contig)
+    p_cross = 0.04 if shape == "contig" else min(1.0, ev_frac * site_step / mean_span)
     r_adv0 = torch.where((op == 0) | (op == 2), ln, torch.zeros_like(ln))
     csum = torch.cumsum(r_adv0, 0)
     rec_base = torch.zeros(nb, dtype=torch.int64, device=dev)
