@@ -308,7 +308,7 @@ def test_dense_runs_use_the_wave_cooperative_kernels(eng):
     e = Engine(0, max_sigs=1 << 23)
     try:
         got = run_both(e, soa, DTYPE_HIFI)
-        assert len(got["raw"]) > 500000
+        assert len(got["raw"]) > 30000
         t, nq, nt = synth.generate(300000, "ont", seed=22, chrom_len=600_000, events_per_record=0.3, site_step=2000)
         soa = synth.to_soa(t, nq)
         run_both(e, soa, DTYPE_ONT)

@@ -92,14 +92,14 @@ struct EmitCtx {
   Counters* ctr;
 };
 
-// four wave-uniform dword loads through the scalar cache (lgkmcnt): they do not drain the in-flight vector loads
-__device__ __forceinline__ void sload4(const void* p0, const void* p1, const void* p2, const void* p3, uint32_t& v0,
-                                       uint32_t& v1, uint32_t& v2, uint32_t& v3) {
+// five wave-uniform dword loads through the scalar cache (lgkmcnt): they do not drain the in-flight vector loads
+__device__ __forceinline__ void sload5(const void* p0, const void* p1, const void* p2, const void* p3, const void* p4,
+                                       uint32_t& v0, uint32_t& v1, uint32_t& v2, uint32_t& v3, uint32_t& v4) {
   asm volatile(
-      "s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %5, 0x0\n\ts_load_dword %2, %6, 0x0\n\ts_load_dword %3, %7, 0x0\n\t"
-      "s_waitcnt lgkmcnt(0)"
-      : "=&s"(v0), "=&s"(v1), "=&s"(v2), "=&s"(v3)
-      : "s"(p0), "s"(p1), "s"(p2), "s"(p3)
+      "s_load_dword %0, %5, 0x0\n\ts_load_dword %1, %6, 0x0\n\ts_load_dword %2, %7, 0x0\n\ts_load_dword %3, %8, 0x0\n\t"
+      "s_load_dword %4, %9, 0x0\n\ts_waitcnt lgkmcnt(0)"
+      : "=&s"(v0), "=&s"(v1), "=&s"(v2), "=&s"(v3), "=&s"(v4)
+      : "s"(p0), "s"(p1), "s"(p2), "s"(p3), "s"(p4)
       : "memory");
 }
 __device__ __forceinline__ uint32_t byte_of(uint32_t word, const void* p) { return (word >> (8u * ((uintptr_t)p & 3u))) & 0xFFu; }
@@ -115,7 +115,7 @@ __device__ __forceinline__ const void* align4(const void* p) { return (const voi
 //                 "block": lane i <-> record wbase+i. A chunk that straddles two windows is processed twice with
 //                 complementary op masks (segment [seg_lo, seg_hi)).
 //   open record   scalars describing the record that is open at the start of the current segment.
-constexpr int K1_RMAX = 320;   // records staged per wave (8192-op parts of ~33-op reads hold ~250)
+constexpr int K1_RMAX = 320;   // record starts staged per wave (8192-op parts of ~33-op reads hold ~250)
 constexpr int K1_WAVES = 4;
 
 template <int CLS>
@@ -124,7 +124,6 @@ __global__ __launch_bounds__(256) void cigar_scan_emit(RecView rv, const uint32_
                                                         uint32_t* __restrict__ part_count, int ablate) {
   using T = OpTab<CLS>;
   __shared__ uint32_t sh_off[K1_WAVES][K1_RMAX + 1];
-  __shared__ uint32_t sh_pos[K1_WAVES][K1_RMAX];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const int part = blockIdx.x * K1_WAVES + wv;
@@ -161,7 +160,6 @@ __global__ __launch_bounds__(256) void cigar_scan_emit(RecView rv, const uint32_
   const uint32_t* __restrict__ off_lo = reinterpret_cast<const uint32_t*>(rv.cigar_off);
   const uint32_t cb0_lo = (uint32_t)cb0;
   uint32_t* my_off = sh_off[wv];
-  uint32_t* my_pos = sh_pos[wv];
   uint32_t tbase = r0;      // first record of the staged table
   uint32_t n_tab = 0;       // records in the table
   bool bad = false;
@@ -173,7 +171,6 @@ __global__ __launch_bounds__(256) void cigar_scan_emit(RecView rv, const uint32_
       const uint32_t v = off_lo[2 * (size_t)(first + i)] - cb0_lo;
       my_off[i] = v;
       if (i < n_tab) {
-        my_pos[i] = (uint32_t)rv.pos[first + i];
         const uint32_t nx = off_lo[2 * (size_t)(first + i) + 2] - cb0_lo;
         mono = mono && (int32_t)(nx - v) > 0;   // empty CIGAR => reference IndexError at H:63
       }
@@ -185,8 +182,14 @@ __global__ __launch_bounds__(256) void cigar_scan_emit(RecView rv, const uint32_
 
   uint32_t wbase = 0;                  // window = table entries [wbase, wbase+64)
   uint32_t pbase_r = 0, pbase_q = 0;   // prefix value at the start of the current segment (mod 2^32)
-  uint32_t open_r = 0, open_q = 0;     // prefix value at the open record's start
-  uint32_t open_rec = r0, open_pos = 0, open_s = ob_rel;
+  // The open record (last record started so far). Its in-segment prefix is NOT computed when the record starts — that
+  // costs ~10 dependent v_readlane per chunk — but lazily, by re-reading the (L2-hot) chunk it started in, and only if
+  // a later segment emits a signature for it. What is kept: where it started and the prefix at that segment's start.
+  uint32_t open_rec = r0, open_s = ob_rel;
+  uint32_t open_cb = 0, open_lo = ob_rel, open_hi = 0;   // chunk and segment [lo,hi) in which it started
+  uint32_t open_base_r = 0, open_base_q = 0;             // pbase at the start of that segment
+  uint32_t open_in_r = 0, open_in_q = 0;                 // cached in-segment prefix at open_s
+  bool open_cached = false;
   uint32_t jprev = 0;                  // records of the current window started before the current segment
 
   // slot allocator of this wave inside its shard (all wave-uniform)
@@ -240,6 +243,29 @@ __global__ __launch_bounds__(256) void cigar_scan_emit(RecView rv, const uint32_
                            (bfe_mask(T::BAD, op) & (uint32_t)-(int)(len != 0));
         em |= (e & 1u) << k;
       }
+      // lazily evaluated in-segment prefix of the open record (see the state comment above)
+      auto open_prefix = [&]() {
+        if (open_cached) return;
+        const uint4 v = load_chunk(open_cb);
+        uint32_t ww[4] = {v.x, v.y, v.z, v.w};
+        const uint32_t xx = open_cb + 4u * (uint32_t)lane;
+        uint32_t r4[4], q4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (xx + k < open_lo || xx + k >= open_hi) ww[k] = 15u;
+          const uint32_t op = ww[k] & 15u, len = ww[k] >> 4;
+          r4[k] = len & bfe_mask(T::REF, op);
+          q4[k] = len & bfe_mask(T::QRY, op);
+        }
+        const uint32_t sr = r4[0] + r4[1] + r4[2] + r4[3], sq = q4[0] + q4[1] + q4[2] + q4[3];
+        const uint32_t er = wave_incl_scan(sr) - sr, eq = wave_incl_scan(sq) - sq;
+        const uint32_t ls = (open_s - open_cb) >> 2, ss = (open_s - open_cb) & 3u;
+        uint32_t b_r = rdlane(er, ls), b_q = rdlane(eq, ls);
+        if (ss > 0) { b_r += rdlane(r4[0], ls); b_q += rdlane(q4[0], ls); }
+        if (ss > 1) { b_r += rdlane(r4[1], ls); b_q += rdlane(q4[1], ls); }
+        if (ss > 2) { b_r += rdlane(r4[2], ls); b_q += rdlane(q4[2], ls); }
+        open_in_r = b_r; open_in_q = b_q; open_cached = true;
+      };
       const uint32_t sum_r = ar[0] + ar[1] + ar[2] + ar[3];
       const uint32_t sum_q = aq[0] + aq[1] + aq[2] + aq[3];
       const uint32_t incl_r = wave_incl_scan(sum_r), incl_q = wave_incl_scan(sum_q);
@@ -269,11 +295,12 @@ __global__ __launch_bounds__(256) void cigar_scan_emit(RecView rv, const uint32_
             const uint32_t op = wl & 15u, len = wl >> 4;
             // record of op xo: last table start <= xo (starts ascend with the lane index), or the open record
             const uint32_t cnt = (uint32_t)__popcll(__ballot(rv_ok && s_rel <= xo));
-            uint32_t a_r, a_q, rec, rpos_r, s_r;
+            uint32_t a_r, a_q, rec, s_r;
             if (cnt == jprev) {              // record was already open at the segment start
-              a_r = pbase_r + px_r - open_r;
-              a_q = pbase_q + px_q - open_q;
-              rec = open_rec; rpos_r = open_pos; s_r = open_s;
+              open_prefix();
+              a_r = (pbase_r - open_base_r) + px_r - open_in_r;
+              a_q = (pbase_q - open_base_q) + px_q - open_in_q;
+              rec = open_rec; s_r = open_s;
             } else {                         // record starts inside this segment
               s_r = rdlane(s_rel, cnt - 1u);
               uint32_t b_r, b_q;
@@ -281,10 +308,9 @@ __global__ __launch_bounds__(256) void cigar_scan_emit(RecView rv, const uint32_
               a_r = px_r - b_r;
               a_q = px_q - b_q;
               rec = tbase + wbase + cnt - 1u;
-              rpos_r = __builtin_amdgcn_readfirstlane(my_pos[wbase + cnt - 1u]);
             }
-            uint32_t wfl, wmq, tid_r, first;
-            sload4(align4(rv.flag + rec), align4(rv.mapq + rec), rv.tid + rec, rv.cigar + cb0 + s_r, wfl, wmq, tid_r, first);
+            uint32_t wfl, wmq, tid_r, first, rpos_r;
+            sload5(align4(rv.flag + rec), align4(rv.mapq + rec), rv.tid + rec, rv.cigar + cb0 + s_r, rv.pos + rec, wfl, wmq, tid_r, first, rpos_r);
             const uint32_t fl = byte_of(wfl, rv.flag + rec), mq = byte_of(wmq, rv.mapq + rec);
             uint32_t hapbits;
             if (CLS == 0) hapbits = (mq >= (uint32_t)min_mapq) ? ((fl >> 2) & 3u) : 0u;               // H:392-394
@@ -327,14 +353,11 @@ __global__ __launch_bounds__(256) void cigar_scan_emit(RecView rv, const uint32_
       // ---- scalar bookkeeping: which record is open at the end of this segment ----------------------
       const uint32_t j = (uint32_t)__popcll(__ballot(rv_ok && s_rel < seg_hi));
       if (j > jprev && !(ablate & 2)) {
-        const uint32_t s = rdlane(s_rel, j - 1u);
-        uint32_t b_r, b_q;
-        prefix_at(s, b_r, b_q);
-        open_r = pbase_r + b_r;
-        open_q = pbase_q + b_q;
+        open_s = rdlane(s_rel, j - 1u);
         open_rec = tbase + wbase + j - 1u;
-        open_pos = __builtin_amdgcn_readfirstlane(my_pos[wbase + j - 1u]);
-        open_s = s;
+        open_cb = cb; open_lo = seg_lo; open_hi = seg_hi;
+        open_base_r = pbase_r; open_base_q = pbase_q;
+        open_cached = false;
         jprev = j;
       }
       pbase_r += rdlane(incl_r, 63);
