@@ -30,7 +30,8 @@ def main():
     ap.add_argument("--records", type=int, default=10_000_000, help="records per GPU (config 2: 10 M)")
     ap.add_argument("--shape", default="hifi", choices=["hifi", "ont", "contig"])
     ap.add_argument("--dtype", default=None, help="Hifi | ONT | CLR | READS (default by shape)")
-    ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="records of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=10_000_000, help="records of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-reps", type=int, default=5, help="repetitions of the CPU baseline (best is reported)")
     ap.add_argument("--max-sigs", type=int, default=1 << 22)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one rank per GPU) | gloo (rehearsal: all ranks on cuda:0)")
     args = ap.parse_args()
@@ -131,13 +132,18 @@ def main():
             host["cigar"] = t["cigar"][:n_ops_s].cpu()
             soa = synth.to_soa(host, nq)
             pc = oracle.default_params(dtype)
-            c0 = time.perf_counter()
-            st, tabs = oracle.run(soa, params=pc)
-            c1 = time.perf_counter()
-            assert st == 0
-            cpu = {"value": ns / (c1 - c0), "unit": "records/s", "cores": 1, "kind": "port",
-                   "sample": "first %d records of the same shard through oracle/vsv_oracle.c (windowed cluster/pair loops), %.2f s"
-                             % (ns, c1 - c0)}
+            best, total = None, 0.0
+            for _ in range(max(1, args.cpu_reps)):
+                c0 = time.perf_counter()
+                st, tabs = oracle.run(soa, params=pc)
+                c1 = time.perf_counter()
+                assert st == 0
+                total += c1 - c0
+                best = c1 - c0 if best is None else min(best, c1 - c0)
+            cpu = {"value": ns / best, "unit": "records/s", "cores": 1, "kind": "port",
+                   "sample": "first %d records of the same shard through oracle/vsv_oracle.c (C port of the reference path, windowed "
+                             "cluster/pair loops), best of %d runs, %.1f s of CPU work in all; the reference's own Python functions "
+                             "measured 0.17 M records/s for extraction alone (BASELINE.md)" % (ns, max(1, args.cpu_reps), total)}
         total_records = recs.n_records * world * args.steps
         line = {
             "metric": "alignment-records/s through SV-signature+cluster; VCF bit-match vs CPU",

@@ -30,6 +30,7 @@ def run(dtype_name, bam_path, contig_path, ref_path, output_dir, chr_number=None
             if bam.get_tid(name) < 0:
                 raise KeyError("%s not in the BAM header" % name)
             soa = bam.fetch_soa(name)
+            soa.max_pos = bam.lengths[bam.get_tid(name)] + 100000   # sort-key hint: positions never exceed the contig
             eng.run(soa, p)
             calls, merged = eng.table("calls"), eng.table("merged")
             ref_seq = dc_ref[name] if name in dc_ref else next(iter(dc_ref.values()))   # ONT/CLR: single-chromosome FASTA (O:653-662)
