@@ -39,7 +39,9 @@ struct vsv_handle {
   DevBuf pool, pool_key, raw0, s1in, s1s, c1, s2s, c2, merged, calls_tmp, calls, reads;
   DevBuf tab, blk_cnt, blk_off, ckey, crec, okey, oval;
   DevBuf key, idx, cl, key2, idx2, key_alt, val_alt, hist;
-  DevBuf ctr, shard_cnt;
+  DevBuf ctr, shard_cnt, totals;
+  int pass_cursor = 0;
+  bool fused_sort = true;          // small-input sort mode, re-decided after every run from its row counts
   Counters host_ctr;
   Counters* pinned = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -96,6 +98,7 @@ int reserve(vsv_handle* h, int64_t max_records, int64_t max_ops, int64_t max_sig
     int st = ensure(h, h->hist, (size_t)vsv_radix_hist_entries(max_sigs) * sizeof(uint32_t));
     if (st) return st;
     if ((st = ensure(h, h->shard_cnt, 256 * 16 * sizeof(uint32_t)))) return st;
+    if ((st = ensure(h, h->totals, (size_t)64 * 2048 * sizeof(uint32_t)))) return st;
     h->cap_sigs = max_sigs;
   }
   if (max_ops > h->cap_ops || max_records > h->cap_records) {
@@ -161,10 +164,19 @@ int bind_records(vsv_handle* h, const vsv_records* r) {
   return 0;
 }
 
+constexpr int MAX_SORT_PASSES = 64;
 SortWork sort_work(vsv_handle* h) {
   SortWork w;
   w.key_alt = (uint64_t*)h->key_alt.p; w.val_alt = (uint32_t*)h->val_alt.p; w.hist = (uint32_t*)h->hist.p; w.max_items = h->cap_sigs;
+  w.totals = (uint32_t*)h->totals.p; w.pass_cursor = &h->pass_cursor; w.max_passes = MAX_SORT_PASSES; w.fused = h->fused_sort;
   return w;
+}
+// zero the device counters and the per-pass sort totals: start of every run
+int reset_run_state(vsv_handle* h) {
+  HIPCHK(h, hipMemsetAsync(h->ctr.p, 0, sizeof(Counters), h->stream));
+  if (h->totals.p) HIPCHK(h, hipMemsetAsync(h->totals.p, 0, (size_t)MAX_SORT_PASSES * 2048 * sizeof(uint32_t), h->stream));
+  h->pass_cursor = 0;
+  return 0;
 }
 StageBufs stage_bufs(vsv_handle* h) { return StageBufs{(uint64_t*)h->key.p, (uint32_t*)h->idx.p, (int32_t*)h->cl.p}; }
 Counters* dctr(vsv_handle* h) { return (Counters*)h->ctr.p; }
@@ -177,7 +189,7 @@ bool is_contig(int dtype) { return dtype == VSV_DTYPE_HIFI || dtype == VSV_DTYPE
 // ---- stage enqueue functions ------------------------------------------------------------------------
 int enq_scan(vsv_handle* h) {
   hipStream_t st = h->stream;
-  HIPCHK(h, hipMemsetAsync(h->ctr.p, 0, sizeof(Counters), st));
+  { int rs = reset_run_state(h); if (rs) return rs; }
   const int n_parts = vsv_cigar_parts(h->rv.n_ops, OPS_PER_PART);
   vsv_launch_cigar_scan(st, h->rv, h->prm, (uint32_t*)h->part_rb.p, n_parts, OPS_PER_PART, (vsv_sig*)h->pool.p,
                         (uint64_t*)h->pool_key.p, (uint32_t)h->cap_sigs, (uint32_t*)h->part_count.p, (uint32_t*)h->part_off.p,
@@ -247,6 +259,10 @@ int finish(vsv_handle* h) {
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->host_ctr = *h->pinned;
   h->pending = false;
+  {  // sort mode of the NEXT run: fused scatter while the largest table stays within ~128 tiles of 4096 rows
+    const uint32_t big = h->host_ctr.n_s1 > h->host_ctr.n_cand ? h->host_ctr.n_s1 : h->host_ctr.n_cand;
+    h->fused_sort = big <= 128u * 4096u;
+  }
   const uint32_t e = h->host_ctr.err;
   h->last_count = h->host_ctr.n_pool;
   if (e & ERRB_CAPACITY) {
@@ -338,7 +354,7 @@ void vsv_destroy(vsv_handle* h) {
   DevBuf* bufs[] = {&h->r_pos, &h->r_tid, &h->r_qid, &h->r_off, &h->r_mapq, &h->r_flag, &h->r_cigar, &h->part_rb, &h->part_count,
                     &h->part_off, &h->scan_tmp, &h->pool, &h->pool_key, &h->raw0, &h->s1in, &h->s1s, &h->c1, &h->s2s, &h->c2,
                     &h->merged, &h->calls_tmp, &h->calls, &h->reads, &h->tab, &h->blk_cnt, &h->blk_off, &h->ckey, &h->crec,
-                    &h->okey, &h->oval, &h->key, &h->idx, &h->cl, &h->key2, &h->idx2, &h->key_alt, &h->val_alt, &h->hist, &h->ctr, &h->shard_cnt, &h->g_off, &h->g_qs, &h->g_qe, &h->g_rid, &h->g_rs,
+                    &h->okey, &h->oval, &h->key, &h->idx, &h->cl, &h->key2, &h->idx2, &h->key_alt, &h->val_alt, &h->hist, &h->ctr, &h->shard_cnt, &h->totals, &h->g_off, &h->g_qs, &h->g_qe, &h->g_rid, &h->g_rs,
                     &h->g_re, &h->g_rev, &h->g_hap, &h->g_len, &h->g_rank};
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
   if (h->pinned) hipHostFree(h->pinned);
@@ -463,7 +479,7 @@ int vsv_bnd_segments(vsv_handle* h, const vsv_segments* sg, const vsv_bnd_params
     d.contig_rank = (const int32_t*)h->g_rank.p;
   }
   h->segs = d;
-  HIPCHK(h, hipMemsetAsync(h->ctr.p, 0, sizeof(Counters), h->stream));
+  { int rs = reset_run_state(h); if (rs) return rs; }
   vsv_launch_bnd_segments(h->stream, d, *p, (vsv_bnd*)h->s1in.p, (uint32_t)h->cap_sigs, dctr(h));
   HIPCHK(h, hipGetLastError());
   h->bnd_stage = 1;
@@ -481,6 +497,8 @@ int vsv_bnd_set_candidates(vsv_handle* h, const vsv_bnd* rows, int64_t n, const 
   if (n) HIPCHK(h, hipMemcpyAsync(h->s1in.p, rows, (size_t)n * sizeof(vsv_bnd), kind, h->stream));
   if ((st = ensure(h, h->g_rank, (size_t)n_tids * 4 + 16))) return st;
   HIPCHK(h, hipMemcpyAsync(h->g_rank.p, contig_rank, (size_t)n_tids * 4, kind, h->stream));
+  if (h->totals.p) HIPCHK(h, hipMemsetAsync(h->totals.p, 0, (size_t)MAX_SORT_PASSES * 2048 * sizeof(uint32_t), h->stream));
+  h->pass_cursor = 0;
   Counters c; memset(&c, 0, sizeof c);
   c.n_s1 = (uint32_t)n;
   *h->pinned = c;

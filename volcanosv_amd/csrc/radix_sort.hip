@@ -33,7 +33,7 @@ __device__ __forceinline__ uint32_t n_tiles_of(uint32_t n) { return (n + RS_TILE
 // hist[tile * BINS + d] = number of items of this tile with digit d
 template <int BITS>
 __global__ __launch_bounds__(256) void rs_hist(const uint64_t* __restrict__ key, const uint32_t* __restrict__ d_n, int shift,
-                                               uint32_t* __restrict__ hist) {
+                                               uint32_t* __restrict__ hist, uint32_t* __restrict__ totals) {
   constexpr int BINS = 1 << BITS;
   __shared__ uint32_t cnt[BINS];
   const uint32_t n = *d_n, ntiles = n_tiles_of(n);
@@ -46,7 +46,11 @@ __global__ __launch_bounds__(256) void rs_hist(const uint64_t* __restrict__ key,
       if (i < n) atomicAdd(&cnt[(uint32_t)(key[i] >> shift) & (BINS - 1)], 1u);
     }
     __syncthreads();
-    for (int d = threadIdx.x; d < BINS; d += 256) hist[(size_t)tile * BINS + d] = cnt[d];
+    for (int d = threadIdx.x; d < BINS; d += 256) {
+      const uint32_t c = cnt[d];
+      hist[(size_t)tile * BINS + d] = c;
+      if (totals && c) atomicAdd(&totals[d], c);   // per-digit totals of the whole input (zeroed at run start)
+    }
     __syncthreads();
   }
 }
@@ -99,13 +103,56 @@ __global__ __launch_bounds__(1024) void rs_scan(uint32_t* __restrict__ hist, con
   }
 }
 
+// Multi-block scan (used whenever the hist kernel produced the digit totals): block b owns 256 digits; digit base =
+// exclusive scan of the totals (block-local: totals of the digits before the block + in-block scan), then one
+// coalesced sweep over the tiles per digit, 16 tiles in flight. BINS/256 blocks on as many CUs instead of one
+// block on one CU (the single-block scan was bandwidth-bound at ~20 us per pass).
+template <int BITS>
+__global__ __launch_bounds__(256) void rs_scan_mb(uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals,
+                                                  const uint32_t* __restrict__ d_n) {
+  constexpr int BINS = 1 << BITS;
+  __shared__ uint32_t sh[256];
+  const uint32_t ntiles = n_tiles_of(*d_n);
+  const int t = threadIdx.x;
+  const int d = blockIdx.x * 256 + t;
+  uint32_t before = 0;
+  for (int i = t; i < (int)blockIdx.x * 256; i += 256) before += totals[i];
+  sh[t] = before;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) { if (t < k) sh[t] += sh[t + k]; __syncthreads(); }
+  const uint32_t prev = sh[0];
+  __syncthreads();
+  const uint32_t mine = d < BINS ? totals[d] : 0;
+  sh[t] = mine;
+  __syncthreads();
+  for (int k = 1; k < 256; k <<= 1) {
+    const uint32_t v = t >= k ? sh[t - k] : 0;
+    __syncthreads();
+    sh[t] += v;
+    __syncthreads();
+  }
+  uint32_t run = prev + sh[t] - mine;
+  if (d >= BINS) return;
+  for (uint32_t t0 = 0; t0 < ntiles; t0 += 16) {
+    uint32_t c[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) c[k] = (t0 + k < ntiles) ? hist[(size_t)(t0 + k) * BINS + d] : 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      if (t0 + k < ntiles) hist[(size_t)(t0 + k) * BINS + d] = run;
+      run += c[k];
+    }
+  }
+}
+
 template <int BITS>
 __global__ __launch_bounds__(256) void rs_scatter(const uint64_t* __restrict__ key, const uint32_t* __restrict__ val,
                                                   const uint32_t* __restrict__ d_n, int shift,
                                                   const uint32_t* __restrict__ hist, uint64_t* __restrict__ key_out,
-                                                  uint32_t* __restrict__ val_out) {
+                                                  uint32_t* __restrict__ val_out, const uint32_t* __restrict__ totals) {
   constexpr int BINS = 1 << BITS;
   __shared__ uint32_t wcnt[RS_WAVES][BINS];   // per-wave running digit counters, then (wave, digit) bases
+  (void)totals;
   const uint32_t n = *d_n, ntiles = n_tiles_of(n);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint64_t lt = (1ull << lane) - 1ull;
@@ -161,10 +208,11 @@ __global__ void rs_copy(const uint64_t* __restrict__ k_in, const uint32_t* __res
 
 template <int BITS>
 void one_pass(hipStream_t st, int grid, const uint64_t* kin, const uint32_t* vin, const uint32_t* d_n, int shift, uint32_t* hist,
-              uint64_t* kout, uint32_t* vout) {
-  rs_hist<BITS><<<grid, 256, 0, st>>>(kin, d_n, shift, hist);
-  rs_scan<BITS><<<1, 1024, 0, st>>>(hist, d_n);
-  rs_scatter<BITS><<<grid, 256, 0, st>>>(kin, vin, d_n, shift, hist, kout, vout);
+              uint64_t* kout, uint32_t* vout, uint32_t* totals) {
+  rs_hist<BITS><<<grid, 256, 0, st>>>(kin, d_n, shift, hist, totals);
+  if (totals) rs_scan_mb<BITS><<<(1 << BITS) / 256, 256, 0, st>>>(hist, totals, d_n);
+  else rs_scan<BITS><<<1, 1024, 0, st>>>(hist, d_n);
+  rs_scatter<BITS><<<grid, 256, 0, st>>>(kin, vin, d_n, shift, hist, kout, vout, totals);
 }
 
 }  // namespace
@@ -183,11 +231,14 @@ void vsv_radix_sort_pairs(hipStream_t st, uint64_t* key, uint32_t* val, const ui
   for (int p = 0; p < passes; ++p) {
     const int left = nbits - shift;
     const int bits = (left + (passes - p) - 1) / (passes - p);   // spread the bits evenly over the remaining passes
+    // the multi-block scan needs a zeroed 2048-entry totals slot per pass (SortWork::totals, zeroed once per run)
+    uint32_t* totals = nullptr;
+    if (w.totals && *w.pass_cursor < w.max_passes) { totals = w.totals + (size_t)(*w.pass_cursor) * 2048; ++*w.pass_cursor; }
     switch (bits <= 8 ? 8 : bits) {
-      case 8: one_pass<8>(st, grid, kin, vin, d_n, shift, w.hist, kout, vout); shift += 8; break;
-      case 9: one_pass<9>(st, grid, kin, vin, d_n, shift, w.hist, kout, vout); shift += 9; break;
-      case 10: one_pass<10>(st, grid, kin, vin, d_n, shift, w.hist, kout, vout); shift += 10; break;
-      default: one_pass<11>(st, grid, kin, vin, d_n, shift, w.hist, kout, vout); shift += 11; break;
+      case 8: one_pass<8>(st, grid, kin, vin, d_n, shift, w.hist, kout, vout, totals); shift += 8; break;
+      case 9: one_pass<9>(st, grid, kin, vin, d_n, shift, w.hist, kout, vout, totals); shift += 9; break;
+      case 10: one_pass<10>(st, grid, kin, vin, d_n, shift, w.hist, kout, vout, totals); shift += 10; break;
+      default: one_pass<11>(st, grid, kin, vin, d_n, shift, w.hist, kout, vout, totals); shift += 11; break;
     }
     uint64_t* tk = kin; kin = kout; kout = tk;
     uint32_t* tv = vin; vin = vout; vout = tv;

@@ -85,8 +85,13 @@ __host__ __device__ inline bool vsv_match(const vsv_sig& a, const vsv_sig& b, in
 struct SortWork {       // scratch for vsv_radix_sort_pairs
   uint64_t* key_alt;
   uint32_t* val_alt;
-  uint32_t* hist;       // [256 * max_tiles]
+  uint32_t* hist;       // [2048 * max_tiles]
   int64_t max_items;
+  // fused scatter (no scan kernel) for small inputs: per-pass digit totals, zeroed once per run by the caller
+  uint32_t* totals;     // [max_passes * 2048]
+  int* pass_cursor;     // host-side index of the next free totals slot (reset per run)
+  int max_passes;
+  bool fused;           // chosen by the caller from the row count of the previous run (both modes are exact)
 };
 struct StageBufs {
   uint64_t* key;        // sort keys of the current stage (kept sorted for cluster / pair kernels)

@@ -49,7 +49,10 @@ def gather_calls(calls, device, to_host=True):
     row = CALL_DTYPE.itemsize
     as_tensor = torch.is_tensor(calls)
     if not dist.is_initialized() or dist.get_world_size() == 1:
-        return np.frombuffer(calls.cpu().numpy().tobytes(), dtype=CALL_DTYPE) if as_tensor else calls
+        if not as_tensor:
+            return calls
+        single = ([calls], [calls.numel() // row])
+        return single if not to_host else finish_gather(single)
     world = dist.get_world_size()
     n_rows = (calls.numel() // row) if as_tensor else len(calls)
     n = torch.tensor([n_rows], dtype=torch.int64, device=device)
