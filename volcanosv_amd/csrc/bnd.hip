@@ -223,8 +223,8 @@ void vsv_launch_bnd_segments(hipStream_t st, const vsv_segments& s, const vsv_bn
 void vsv_launch_bnd_pair(hipStream_t st, const vsv_bnd* cand, const int32_t* contig_rank, int rank_bits, const vsv_bnd_params& p,
                          vsv_bnd* sorted, vsv_bnd* calls, Counters* ctr, const StageBufs& b, const SortWork& sw, int64_t cap) {
   bnd_keys<<<128, 256, 0, st>>>(cand, contig_rank, &ctr->n_s1, b.key, b.idx);
-  vsv_radix_sort_pairs(st, b.key, b.idx, &ctr->n_s1, cap, 33 + rank_bits + 1, sw);
-  bnd_gather<<<128, 256, 0, st>>>(cand, b.idx, &ctr->n_s1, sorted);
-  bnd_count_alive<<<128, 256, 0, st>>>(b.key, &ctr->n_s1, &ctr->n_alive1);
+  const SortResult r = vsv_radix_sort_pairs(st, b.key, b.idx, sw.key_alt, sw.val_alt, &ctr->n_s1, cap, 33 + rank_bits + 1, sw);
+  bnd_gather<<<128, 256, 0, st>>>(cand, r.val, &ctr->n_s1, sorted);
+  bnd_count_alive<<<128, 256, 0, st>>>(r.key, &ctr->n_s1, &ctr->n_alive1);
   bnd_pair<<<128, 256, 0, st>>>(sorted, &ctr->n_alive1, p, calls);
 }

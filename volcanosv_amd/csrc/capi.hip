@@ -41,6 +41,7 @@ struct vsv_handle {
   DevBuf key, idx, cl, key2, idx2, key_alt, val_alt, hist;
   DevBuf ctr, shard_cnt, totals;
   int pass_cursor = 0;
+  const uint64_t* sorted_key = nullptr;   // sorted keys of the stage just sorted (cluster / pair read them)
   bool fused_sort = true;          // small-input sort mode, re-decided after every run from its row counts
   Counters host_ctr;
   Counters* pinned = nullptr;
@@ -208,7 +209,8 @@ int enq_split(vsv_handle* h) {
   if (!p.enable_split || p.dtype == VSV_DTYPE_SVIM) rv.n_records = 0;  // n_s1 = n_raw
   vsv_launch_split(st, rv, p, h->n_tids, (uint32_t*)h->tab.p, h->tab_size, (uint32_t*)h->blk_cnt.p, (uint32_t*)h->blk_off.p,
                    (uint32_t*)h->scan_tmp.p, (uint64_t*)h->ckey.p, (uint32_t*)h->crec.p, (uint64_t*)h->okey.p,
-                   (uint32_t*)h->oval.p, sort_work(h), (vsv_sig*)h->s1in.p, (uint32_t)h->cap_sigs, dctr(h));
+                   (uint32_t*)h->oval.p, (uint64_t*)h->key2.p, (uint32_t*)h->idx2.p, sort_work(h), (vsv_sig*)h->s1in.p,
+                   (uint32_t)h->cap_sigs, dctr(h));
   if (p.dtype == VSV_DTYPE_READS) {
     // reads.py:281-286 merge_all: one stable sort of [del_cigar, ins_cigar, del_split, ins_split] by pos
     const int nbits = pos_bits(h) + 2 + tid_bits(h) + 1;
@@ -223,9 +225,9 @@ int enq_split(vsv_handle* h) {
 int enq_stage1(vsv_handle* h) {
   hipStream_t st = h->stream;
   Counters* c = dctr(h);
-  vsv_launch_sort_stage(st, (vsv_sig*)h->s1in.p, &c->n_s1, 1, pos_bits(h), key_bits(h), (vsv_sig*)h->s1s.p, &c->n_alive1, stage_bufs(h),
+  h->sorted_key = vsv_launch_sort_stage(st, (vsv_sig*)h->s1in.p, &c->n_s1, 1, pos_bits(h), key_bits(h), (vsv_sig*)h->s1s.p, &c->n_alive1, stage_bufs(h),
                         sort_work(h), h->cap_sigs, dctr(h));
-  vsv_launch_cluster(st, (vsv_sig*)h->s1s.p, &c->n_alive1, h->prm.cluster_shift, pos_bits(h), (vsv_sig*)h->c1.p, stage_bufs(h), (uint64_t*)h->key2.p, dctr(h));
+  vsv_launch_cluster(st, (vsv_sig*)h->s1s.p, h->sorted_key, &c->n_alive1, h->prm.cluster_shift, pos_bits(h), (vsv_sig*)h->c1.p, stage_bufs(h), (uint64_t*)h->key2.p, dctr(h));
   HIPCHK(h, hipGetLastError());
   h->stage_done = 3;
   return 0;
@@ -234,10 +236,10 @@ int enq_stage1(vsv_handle* h) {
 int enq_merge(vsv_handle* h) {
   hipStream_t st = h->stream;
   Counters* c = dctr(h);
-  vsv_launch_sort_stage(st, (vsv_sig*)h->c1.p, &c->n_alive1, 2, pos_bits(h), key_bits(h), (vsv_sig*)h->s2s.p, &c->n_alive2, stage_bufs(h),
+  h->sorted_key = vsv_launch_sort_stage(st, (vsv_sig*)h->c1.p, &c->n_alive1, 2, pos_bits(h), key_bits(h), (vsv_sig*)h->s2s.p, &c->n_alive2, stage_bufs(h),
                         sort_work(h), h->cap_sigs, dctr(h));
-  vsv_launch_cluster(st, (vsv_sig*)h->s2s.p, &c->n_alive2, h->prm.cluster_shift, pos_bits(h), (vsv_sig*)h->c2.p, stage_bufs(h), (uint64_t*)h->key2.p, dctr(h));
-  vsv_launch_sort_stage(st, (vsv_sig*)h->c2.p, &c->n_alive2, 3, pos_bits(h), key_bits(h), (vsv_sig*)h->merged.p, &c->n_alive3, stage_bufs(h),
+  vsv_launch_cluster(st, (vsv_sig*)h->s2s.p, h->sorted_key, &c->n_alive2, h->prm.cluster_shift, pos_bits(h), (vsv_sig*)h->c2.p, stage_bufs(h), (uint64_t*)h->key2.p, dctr(h));
+  h->sorted_key = vsv_launch_sort_stage(st, (vsv_sig*)h->c2.p, &c->n_alive2, 3, pos_bits(h), key_bits(h), (vsv_sig*)h->merged.p, &c->n_alive3, stage_bufs(h),
                         sort_work(h), h->cap_sigs, dctr(h));
   HIPCHK(h, hipGetLastError());
   h->stage_done = 4;
@@ -247,7 +249,7 @@ int enq_merge(vsv_handle* h) {
 int enq_pair(vsv_handle* h) {
   hipStream_t st = h->stream;
   Counters* c = dctr(h);
-  vsv_launch_pair(st, (vsv_sig*)h->merged.p, &c->n_alive3, h->prm.pair_shift, (vsv_call*)h->calls_tmp.p, (vsv_call*)h->calls.p,
+  vsv_launch_pair(st, (vsv_sig*)h->merged.p, h->sorted_key, &c->n_alive3, h->prm.pair_shift, (vsv_call*)h->calls_tmp.p, (vsv_call*)h->calls.p,
                   &c->n_calls, stage_bufs(h), (uint64_t*)h->key2.p, (uint32_t*)h->idx2.p, sort_work(h), pos_bits(h), key_bits(h), h->cap_sigs, dctr(h));
   HIPCHK(h, hipGetLastError());
   h->stage_done = 5;

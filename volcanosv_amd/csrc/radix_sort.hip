@@ -200,12 +200,6 @@ __global__ __launch_bounds__(256) void rs_scatter(const uint64_t* __restrict__ k
   }
 }
 
-__global__ void rs_copy(const uint64_t* __restrict__ k_in, const uint32_t* __restrict__ v_in, const uint32_t* __restrict__ d_n,
-                        uint64_t* __restrict__ k_out, uint32_t* __restrict__ v_out) {
-  const uint32_t n = *d_n;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { k_out[i] = k_in[i]; v_out[i] = v_in[i]; }
-}
-
 template <int BITS>
 void one_pass(hipStream_t st, int grid, const uint64_t* kin, const uint32_t* vin, const uint32_t* d_n, int shift, uint32_t* hist,
               uint64_t* kout, uint32_t* vout, uint32_t* totals) {
@@ -219,12 +213,12 @@ void one_pass(hipStream_t st, int grid, const uint64_t* kin, const uint32_t* vin
 
 // Digit widths are chosen per sort so that the pass count is minimal with digits of at most 11 bits
 // (e.g. 33 key bits -> 3 passes of 11; 26 bits -> 3 passes of 9).
-void vsv_radix_sort_pairs(hipStream_t st, uint64_t* key, uint32_t* val, const uint32_t* d_n, int64_t max_n, int nbits,
-                          const SortWork& w) {
+SortResult vsv_radix_sort_pairs(hipStream_t st, uint64_t* key, uint32_t* val, uint64_t* key_scratch, uint32_t* val_scratch,
+                                const uint32_t* d_n, int64_t max_n, int nbits, const SortWork& w) {
   int64_t max_tiles = (max_n + RS_TILE - 1) / RS_TILE;
   int grid = (int)(max_tiles < 1024 ? (max_tiles < 1 ? 1 : max_tiles) : 1024);
   uint64_t* kin = key; uint32_t* vin = val;
-  uint64_t* kout = w.key_alt; uint32_t* vout = w.val_alt;
+  uint64_t* kout = key_scratch; uint32_t* vout = val_scratch;
   if (nbits < 1) nbits = 1;
   const int passes = (nbits + 10) / 11;
   int shift = 0;
@@ -243,7 +237,7 @@ void vsv_radix_sort_pairs(hipStream_t st, uint64_t* key, uint32_t* val, const ui
     uint64_t* tk = kin; kin = kout; kout = tk;
     uint32_t* tv = vin; vin = vout; vout = tv;
   }
-  if (kin != key) rs_copy<<<64, 256, 0, st>>>(kin, vin, d_n, key, val);
+  return SortResult{kin, vin};   // the sorted pairs live in (key,val) or in the scratch pair, no copy back
 }
 
 int64_t vsv_radix_hist_entries(int64_t max_n) { return 2048 * ((max_n + RS_TILE - 1) / RS_TILE); }

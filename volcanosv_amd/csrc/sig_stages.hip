@@ -231,8 +231,11 @@ __global__ __launch_bounds__(256) void split_cand(RecView rv, SplitCfg c, const 
 __global__ void split_set_ncand(const uint32_t* __restrict__ blk_off, const uint32_t* __restrict__ blk_cnt, int nblk,
                                 uint32_t cap, Counters* ctr) {
   const uint32_t t = blk_off[nblk - 1] + blk_cnt[nblk - 1];
-  ctr->n_cand = t < cap ? t : cap;
+  const uint32_t nc = t < cap ? t : cap;
+  ctr->n_cand = nc;
   if (t > cap) atomicOr(&ctr->err, ERRB_CAPACITY);
+  const uint32_t s1 = ctr->n_raw + nc;
+  ctr->n_s1 = s1 < cap ? s1 : cap;
 }
 
 // slot j of the sorted candidate list starts a pair iff slot j+1 has the same (tid,hap,qid) key.
@@ -406,21 +409,19 @@ __global__ __launch_bounds__(256) void build_call_keys(const vsv_call* __restric
     idx[i] = i;
   }
 }
+// payload gather after a sort; also publishes the alive row count (keys ascend with dead = all ones last: the count is
+// the index of the first dead key) and clears the long-run queue for the cluster / pair kernel that follows
 template <typename T>
 __global__ __launch_bounds__(256) void gather_rows(const T* __restrict__ in, const uint32_t* __restrict__ idx,
-                                                   const uint32_t* __restrict__ d_n, T* __restrict__ out) {
+                                                   const uint64_t* __restrict__ key, const uint32_t* __restrict__ d_n,
+                                                   T* __restrict__ out, uint32_t* __restrict__ d_alive, uint32_t* __restrict__ n_long) {
   const uint32_t n = *d_n;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = in[idx[i]];
-}
-// keys sorted ascending with dead (all ones) last: alive count = index of the first dead key
-__global__ __launch_bounds__(256) void count_alive(const uint64_t* __restrict__ key, const uint32_t* __restrict__ d_n,
-                                                   uint32_t* __restrict__ d_alive) {
-  const uint32_t n = *d_n;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *n_long = 0;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    out[i] = in[idx[i]];
     if (key[i] != VSV_KEY_DEAD && (i + 1 == n || key[i + 1] == VSV_KEY_DEAD)) *d_alive = i + 1;
   }
 }
-
 // ---- seeded greedy clustering ------------------------------------------------------------------------
 // A run = maximal stretch of one list whose consecutive positions differ by <= max_shift; no match can
 // cross a run boundary (every match needs shift <= max_shift), so runs are independent and the
@@ -652,7 +653,8 @@ static int bits_for(uint64_t n) { int b = 1; while ((1ull << b) < n && b < 63) +
 
 void vsv_launch_split(hipStream_t st, const RecView& rv, const vsv_params& p, int n_tids, uint32_t* tab, uint32_t tab_size,
                       uint32_t* blk_cnt, uint32_t* blk_off, uint32_t* scan_tmp, uint64_t* ckey, uint32_t* crec,
-                      uint64_t* okey, uint32_t* oval, const SortWork& sw, vsv_sig* s1in, uint32_t cap, Counters* ctr) {
+                      uint64_t* okey, uint32_t* oval, uint64_t* key2, uint32_t* idx2, const SortWork& sw, vsv_sig* s1in,
+                      uint32_t cap, Counters* ctr) {
   SplitCfg c;
   c.contig = p.dtype != VSV_DTYPE_READS;
   c.min_mapq = p.min_split_mapq;
@@ -672,40 +674,40 @@ void vsv_launch_split(hipStream_t st, const RecView& rv, const vsv_params& p, in
     vsv_scan_u32_exclusive(st, blk_cnt, nblk, blk_off, scan_tmp);
     split_cand<true><<<nblk, 256, 0, st>>>(rv, c, tab, blk_off, ckey, crec, cap, ctr);
     split_set_ncand<<<1, 1, 0, st>>>(blk_off, blk_cnt, nblk, cap, ctr);
-    vsv_radix_sort_pairs(st, ckey, crec, &ctr->n_cand, cap, c.tid_shift + tid_bits, sw);
-    split_mark_pairs<<<EW_GRID, 256, 0, st>>>(ckey, crec, c, rec_bits, okey, oval, ctr);
-    vsv_radix_sort_pairs(st, okey, oval, &ctr->n_cand, cap, rec_bits + 1 + tid_bits + 1, sw);
-    split_eval<<<1024, 256, 0, st>>>(rv, okey, oval, ckey, crec, c, p.dtype, p.max_split_svlen, s1in, cap, ctr);
+    // the first result may live in the shared scratch pair, so the second sort gets a scratch pair of its own
+    const SortResult r1 = vsv_radix_sort_pairs(st, ckey, crec, sw.key_alt, sw.val_alt, &ctr->n_cand, cap, c.tid_shift + tid_bits, sw);
+    split_mark_pairs<<<EW_GRID, 256, 0, st>>>(r1.key, r1.val, c, rec_bits, okey, oval, ctr);
+    const SortResult r2 = vsv_radix_sort_pairs(st, okey, oval, key2, idx2, &ctr->n_cand, cap, rec_bits + 1 + tid_bits + 1, sw);
+    split_eval<<<1024, 256, 0, st>>>(rv, r2.key, r2.val, r1.key, r1.val, c, p.dtype, p.max_split_svlen, s1in, cap, ctr);
+  } else {
+    set_n_s1<<<1, 1, 0, st>>>(ctr, cap);
   }
-  set_n_s1<<<1, 1, 0, st>>>(ctr, cap);
 }
 
 // sort rows `in[0,n)` by the stage key into `sorted`, publish the alive count
-void vsv_launch_sort_stage(hipStream_t st, const vsv_sig* in, const uint32_t* d_n, int stage, int pb, int nbits, vsv_sig* sorted,
-                           uint32_t* d_alive, const StageBufs& b, const SortWork& sw, int64_t cap, Counters* ctr) {
+const uint64_t* vsv_launch_sort_stage(hipStream_t st, const vsv_sig* in, const uint32_t* d_n, int stage, int pb, int nbits,
+                                      vsv_sig* sorted, uint32_t* d_alive, const StageBufs& b, const SortWork& sw, int64_t cap,
+                                      Counters* ctr) {
   build_keys<<<EW_GRID, 256, 0, st>>>(in, d_n, stage, pb, b.key, b.idx, ctr);
-  vsv_radix_sort_pairs(st, b.key, b.idx, d_n, cap, nbits, sw);
-  gather_rows<vsv_sig><<<EW_GRID, 256, 0, st>>>(in, b.idx, d_n, sorted);
-  count_alive<<<EW_GRID, 256, 0, st>>>(b.key, d_n, d_alive);
+  const SortResult r = vsv_radix_sort_pairs(st, b.key, b.idx, sw.key_alt, sw.val_alt, d_n, cap, nbits, sw);
+  gather_rows<vsv_sig><<<EW_GRID, 256, 0, st>>>(in, r.val, r.key, d_n, sorted, d_alive, &ctr->n_long);
+  return r.key;
 }
 
-void vsv_launch_cluster(hipStream_t st, const vsv_sig* sorted, const uint32_t* d_alive, int max_shift, int pb, vsv_sig* out,
-                        const StageBufs& b, uint64_t* long_list, Counters* ctr) {
-  (void)hipMemsetAsync(&ctr->n_long, 0, sizeof(uint32_t), st);
-  cluster_kernel<<<EW_GRID, 256, 0, st>>>(sorted, b.key, d_alive, max_shift, pb, b.cl, out, long_list, &ctr->n_long);
+void vsv_launch_cluster(hipStream_t st, const vsv_sig* sorted, const uint64_t* sorted_key, const uint32_t* d_alive, int max_shift,
+                        int pb, vsv_sig* out, const StageBufs& b, uint64_t* long_list, Counters* ctr) {
+  cluster_kernel<<<EW_GRID, 256, 0, st>>>(sorted, sorted_key, d_alive, max_shift, pb, b.cl, out, long_list, &ctr->n_long);
   cluster_long_kernel<<<LONG_GRID, 256, 0, st>>>(sorted, max_shift, b.cl, out, long_list, &ctr->n_long);
 }
 
-void vsv_launch_pair(hipStream_t st, const vsv_sig* merged, const uint32_t* d_alive3, int pair_shift, vsv_call* calls_tmp,
-                     vsv_call* calls, uint32_t* d_ncalls, const StageBufs& b, uint64_t* key2, uint32_t* idx2,
+void vsv_launch_pair(hipStream_t st, const vsv_sig* merged, const uint64_t* merged_key, const uint32_t* d_alive3, int pair_shift,
+                     vsv_call* calls_tmp, vsv_call* calls, uint32_t* d_ncalls, const StageBufs& b, uint64_t* key2, uint32_t* idx2,
                      const SortWork& sw, int pb, int nbits, int64_t cap, Counters* ctr) {
-  fill_i32<<<EW_GRID, 256, 0, st>>>(b.cl, -1, d_alive3);
-  (void)hipMemsetAsync(&ctr->n_long, 0, sizeof(uint32_t), st);
-  pair_kernel<<<EW_GRID, 256, 0, st>>>(merged, b.key, d_alive3, pair_shift, pb, b.cl, calls_tmp, key2, &ctr->n_long);
-  pair_long_kernel<<<LONG_GRID, 256, 0, st>>>(merged, b.key, d_alive3, pair_shift, pb, b.cl, calls_tmp, key2, &ctr->n_long);
+  fill_i32<<<EW_GRID, 256, 0, st>>>(b.cl, -1, d_alive3);   // (n_long was cleared by the stage-3 gather)
+  pair_kernel<<<EW_GRID, 256, 0, st>>>(merged, merged_key, d_alive3, pair_shift, pb, b.cl, calls_tmp, key2, &ctr->n_long);
+  pair_long_kernel<<<LONG_GRID, 256, 0, st>>>(merged, merged_key, d_alive3, pair_shift, pb, b.cl, calls_tmp, key2, &ctr->n_long);
   pair_finish<<<EW_GRID, 256, 0, st>>>(merged, d_alive3, b.cl, calls_tmp);
   build_call_keys<<<EW_GRID, 256, 0, st>>>(calls_tmp, d_alive3, pb, key2, idx2);
-  vsv_radix_sort_pairs(st, key2, idx2, d_alive3, cap, nbits, sw);
-  gather_rows<vsv_call><<<EW_GRID, 256, 0, st>>>(calls_tmp, idx2, d_alive3, calls);
-  count_alive<<<EW_GRID, 256, 0, st>>>(key2, d_alive3, d_ncalls);
+  const SortResult r = vsv_radix_sort_pairs(st, key2, idx2, sw.key_alt, sw.val_alt, d_alive3, cap, nbits, sw);
+  gather_rows<vsv_call><<<EW_GRID, 256, 0, st>>>(calls_tmp, r.val, r.key, d_alive3, calls, d_ncalls, &ctr->n_long);
 }

@@ -99,9 +99,11 @@ struct StageBufs {
   int32_t* cl;          // cluster ids / pairing state
 };
 
-// radix_sort.hip: stable LSD radix sort of (key,val) pairs on bits [0,nbits); n on the device.
-void vsv_radix_sort_pairs(hipStream_t st, uint64_t* key, uint32_t* val, const uint32_t* d_n, int64_t max_n, int nbits,
-                          const SortWork& w);
+// radix_sort.hip: stable LSD radix sort of (key,val) pairs on bits [0,nbits); n on the device. The result is left in
+// whichever of the two buffer pairs the last pass wrote (returned); nothing is copied back.
+struct SortResult { uint64_t* key; uint32_t* val; };
+SortResult vsv_radix_sort_pairs(hipStream_t st, uint64_t* key, uint32_t* val, uint64_t* key_scratch, uint32_t* val_scratch,
+                                const uint32_t* d_n, int64_t max_n, int nbits, const SortWork& w);
 int64_t vsv_radix_hist_entries(int64_t max_n);
 
 // cigar_scan.hip
@@ -116,13 +118,16 @@ void vsv_launch_cigar_scan(hipStream_t st, const RecView& rv, const vsv_params& 
 void vsv_launch_fold(hipStream_t st, vsv_sig* raw, vsv_sig* raw_copy, const RecView& rv, int dtype, Counters* ctr);
 void vsv_launch_split(hipStream_t st, const RecView& rv, const vsv_params& p, int n_tids, uint32_t* tab, uint32_t tab_size,
                       uint32_t* blk_cnt, uint32_t* blk_off, uint32_t* scan_tmp, uint64_t* ckey, uint32_t* crec,
-                      uint64_t* okey, uint32_t* oval, const SortWork& sw, vsv_sig* s1in, uint32_t cap, Counters* ctr);
-void vsv_launch_sort_stage(hipStream_t st, const vsv_sig* in, const uint32_t* d_n, int stage, int pb, int nbits, vsv_sig* sorted,
-                           uint32_t* d_alive, const StageBufs& b, const SortWork& sw, int64_t cap, Counters* ctr);
-void vsv_launch_cluster(hipStream_t st, const vsv_sig* sorted, const uint32_t* d_alive, int max_shift, int pb, vsv_sig* out,
-                        const StageBufs& b, uint64_t* long_list, Counters* ctr);
-void vsv_launch_pair(hipStream_t st, const vsv_sig* merged, const uint32_t* d_alive3, int pair_shift, vsv_call* calls_tmp,
-                     vsv_call* calls, uint32_t* d_ncalls, const StageBufs& b, uint64_t* key2, uint32_t* idx2,
+                      uint64_t* okey, uint32_t* oval, uint64_t* key2, uint32_t* idx2, const SortWork& sw, vsv_sig* s1in,
+                      uint32_t cap, Counters* ctr);
+// returns the sorted key array (kept for the cluster / pair kernel that follows)
+const uint64_t* vsv_launch_sort_stage(hipStream_t st, const vsv_sig* in, const uint32_t* d_n, int stage, int pb, int nbits,
+                                      vsv_sig* sorted, uint32_t* d_alive, const StageBufs& b, const SortWork& sw, int64_t cap,
+                                      Counters* ctr);
+void vsv_launch_cluster(hipStream_t st, const vsv_sig* sorted, const uint64_t* sorted_key, const uint32_t* d_alive, int max_shift,
+                        int pb, vsv_sig* out, const StageBufs& b, uint64_t* long_list, Counters* ctr);
+void vsv_launch_pair(hipStream_t st, const vsv_sig* merged, const uint64_t* merged_key, const uint32_t* d_alive3, int pair_shift,
+                     vsv_call* calls_tmp, vsv_call* calls, uint32_t* d_ncalls, const StageBufs& b, uint64_t* key2, uint32_t* idx2,
                      const SortWork& sw, int pb, int nbits, int64_t cap, Counters* ctr);
 
 // bnd.hip
