@@ -69,3 +69,33 @@ def test_filter_tra_merge():
     hdr, body = bnd.merge_bnd_lines(lines)
     assert hdr == ["##h\n"] and len(body) == 3
     assert body[0].split()[-1] == "1/1" and body[0].split()[1] == "100"
+
+
+def test_reference_chimeric_read_bam_fixtures():
+    """The reference's own SA-tag fixtures (svim-asm tests/chimeric_read.bam, chimeric_read_errors.bam — data files of
+    tests/test_satag.py, copied verbatim as fixtures) through the BAM ingest (C-ABI vsv_bam_*) and the SA parser:
+    test_satag.py:13-33 (4 records; the primary's SA tag reconstructs the three other alignments field by field) and
+    :36-54 (an SA entry with too many fields is skipped; a negative MAPQ becomes 0)."""
+    from volcanosv_amd import bam
+    ops = "MIDNSHP=X"
+    s = bam.read_bam(os.path.join(GOLDEN, "chimeric_read.bam"))
+    assert s.n_records == 4
+    tid_of = lambda n: s.tid_names.index(n)
+    cig = lambda i: [(int(w) & 15, int(w) >> 4) for w in s.cigar[int(s.cigar_off[i]):int(s.cigar_off[i + 1])]]
+    prim = [i for i in range(4) if not (s.flag[i] & 2)]                    # the non-supplementary record
+    assert len(prim) == 1
+    sa = bnd.parse_sa(s.sa_tags[prim[0]], tid_of)
+    others = [i for i in range(4) if i != prim[0]]
+    assert len(sa) == 3
+    # as test_satag.py:25-35: SA entry k reconstructs alignment k+1
+    for (tid, pos0, rev, c2, mq), i in zip(sa, others):
+        assert int(s.tid[i]) == tid and int(s.pos[i]) == pos0
+        assert c2 == cig(i), "".join("%d%s" % (l, ops[o]) for o, l in c2)
+        assert bool(s.flag[i] & 1) == rev and int(s.mapq[i]) == mq
+        assert int(s.sam_flags[i]) == (2064 if rev else 2048)              # SVIM_COLLECT.py:35-38
+        assert bnd.cigar_stats(c2) == bnd.cigar_stats(cig(i))             # reference_end / query_alignment_start,end
+    e = bam.read_bam(os.path.join(GOLDEN, "chimeric_read_errors.bam"))
+    tid_e = lambda n: e.tid_names.index(n)
+    assert len(bnd.parse_sa(e.sa_tags[0], tid_e)) == 2                     # first SA entry has too many fields
+    neg = bnd.parse_sa(e.sa_tags[1], tid_e)
+    assert len(neg) == 1 and neg[0][4] == 0                                # negative MAPQ -> 0
