@@ -247,6 +247,7 @@ typedef struct vsv_bam vsv_bam;
 int vsv_bam_open(const char* path, vsv_bam** out);
 void vsv_bam_close(vsv_bam* b);
 const char* vsv_bam_error(vsv_bam* b);
+void vsv_bam_set_threads(vsv_bam* b, int n);                  /* BGZF inflate workers, 0 = all (<= 16) */
 int vsv_bam_n_refs(vsv_bam* b);
 const char* vsv_bam_ref_name(vsv_bam* b, int i);
 int64_t vsv_bam_ref_len(vsv_bam* b, int i);

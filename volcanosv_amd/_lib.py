@@ -19,7 +19,7 @@ SYMBOLS = [
     "vsv_default_params", "vsv_reserve", "vsv_cigar_scan", "vsv_split_pairs", "vsv_sort_cluster", "vsv_merge_sources",
     "vsv_pair_haplotypes", "vsv_run_chromosome", "vsv_run_chromosome_async", "vsv_finish", "vsv_table_count",
     "vsv_table_fill", "vsv_last_scan_ms", "vsv_default_bnd_params", "vsv_bnd_segments", "vsv_bnd_pair", "vsv_bnd_set_candidates",
-    "vsv_bam_open", "vsv_bam_close", "vsv_bam_error", "vsv_bam_n_refs", "vsv_bam_ref_name", "vsv_bam_ref_len", "vsv_bam_load",
+    "vsv_bam_open", "vsv_bam_close", "vsv_bam_error", "vsv_bam_set_threads", "vsv_bam_n_refs", "vsv_bam_ref_name", "vsv_bam_ref_len", "vsv_bam_load",
     "vsv_bam_qnames", "vsv_bam_sa_tags", "vsv_bam_l_seq", "vsv_bam_sam_flags",
 ]
 
@@ -74,6 +74,8 @@ def load():
     lib.vsv_bam_open.restype = C.c_int
     lib.vsv_bam_close.argtypes = [B]
     lib.vsv_bam_close.restype = None
+    lib.vsv_bam_set_threads.argtypes = [B, C.c_int]
+    lib.vsv_bam_set_threads.restype = None
     lib.vsv_bam_error.argtypes = [B]
     lib.vsv_bam_error.restype = C.c_char_p
     lib.vsv_bam_n_refs.argtypes = [B]

@@ -16,13 +16,47 @@ from .abi import Records, VsvError
 from .soa import RecordSoA
 
 
+class LazyLines:
+    """'\\n'-joined text blob viewed as a read-only list of strings; lines are decoded on access (a 10^7-record BAM has
+    10^7 names: splitting them eagerly costs more than the ingest itself)."""
+
+    def __init__(self, blob, n):
+        self.blob = blob
+        self.n = n
+        if n:
+            nl = np.flatnonzero(np.frombuffer(blob, dtype=np.uint8) == 10)
+            self.start = np.concatenate(([0], nl + 1)).astype(np.int64)
+            self.end = np.concatenate((nl, [len(blob)])).astype(np.int64)
+        else:
+            self.start = self.end = np.zeros(0, np.int64)
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(self.n))]
+        if i < 0:
+            i += self.n
+        if not 0 <= i < self.n:
+            raise IndexError(i)
+        return self.blob[int(self.start[i]):int(self.end[i])].decode()
+
+    def __iter__(self):
+        return (self[i] for i in range(self.n))
+
+    def __eq__(self, other):
+        return list(self) == list(other)
+
+
 class BamFile:
-    def __init__(self, path):
+    def __init__(self, path, threads=0):
         self.lib = _lib.load()
         self.h = C.c_void_p()
         st = self.lib.vsv_bam_open(str(path).encode(), C.byref(self.h))
         if st:
             raise VsvError(st, "cannot open BAM %s" % path)
+        self.lib.vsv_bam_set_threads(self.h, int(threads))
         n = self.lib.vsv_bam_n_refs(self.h)
         self.references = [self.lib.vsv_bam_ref_name(self.h, i).decode() for i in range(n)]
         self.lengths = [int(self.lib.vsv_bam_ref_len(self.h, i)) for i in range(n)]
@@ -60,11 +94,9 @@ class BamFile:
 
         ln = C.c_int64()
         p = self.lib.vsv_bam_qnames(self.h, C.byref(ln))
-        qnames = C.string_at(p, ln.value).decode().split("\n") if ln.value else []
+        qnames = LazyLines(C.string_at(p, ln.value), int(r.n_qids))
         p = self.lib.vsv_bam_sa_tags(self.h, C.byref(ln))
-        sa = C.string_at(p, ln.value).decode().split("\n") if n else []
-        if len(sa) < n:
-            sa += [""] * (n - len(sa))
+        sa = LazyLines(C.string_at(p, ln.value), n)
         soa = RecordSoA(arr(r.pos, n, np.int32), arr(r.tid, n, np.int32), arr(r.qid, n, np.uint32),
                         arr(r.cigar_off, n + 1, np.uint64) if n else np.zeros(1, np.uint64), arr(r.mapq, n, np.uint8),
                         arr(r.flag, n, np.uint8), arr(r.cigar, nops, np.uint32), qnames, self.references)
@@ -75,8 +107,8 @@ class BamFile:
         return soa
 
 
-def read_bam(path, chrom=None):
-    with BamFile(path) as b:
+def read_bam(path, chrom=None, threads=0):
+    with BamFile(path, threads) as b:
         return b.fetch_soa(chrom)
 
 

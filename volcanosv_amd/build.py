@@ -48,7 +48,7 @@ def build(force=False, verbose=False, extra=()):
     for p, cmd in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lz"]
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lz", "-lpthread"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -11,7 +11,9 @@
 #include <string.h>
 #include <zlib.h>
 
+#include <atomic>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -27,7 +29,7 @@ struct vsv_bam {
   std::vector<uint8_t> buf;   // decompressed bytes not yet consumed
   size_t rd = 0;
   bool eof = false;
-  long data_start_block = 0;  // file offset of the first BGZF block holding alignment data (unused: we rescan)
+  int n_threads = 0;          // inflate workers for vsv_bam_load (0 = hardware_concurrency, capped at 16)
   // loaded records (library-owned, valid until the next load / close)
   std::vector<int32_t> pos, tid;
   std::vector<uint32_t> qid, cigar, l_seq, sam_flag;
@@ -41,42 +43,87 @@ struct vsv_bam {
 
 namespace {
 
+// BGZF members are independent deflate streams: a window of up to WINDOW_BLOCKS members is read, inflated by a small
+// thread pool (each worker takes the next member off an atomic counter) and appended to the byte queue the record
+// parser consumes. Peak memory = one window (<= 64 KiB x WINDOW_BLOCKS decompressed).
+constexpr int WINDOW_BLOCKS = 2048;
+
+struct Member { std::vector<uint8_t> comp; uint32_t isize; size_t out_off; };
+
+bool read_member(vsv_bam* b, Member& m, bool& got) {
+  got = false;
+  uint8_t hdr[18];
+  size_t n = fread(hdr, 1, 18, b->f);
+  if (n == 0) { b->eof = true; return true; }
+  if (n != 18 || hdr[0] != 31 || hdr[1] != 139 || hdr[2] != 8 || !(hdr[3] & 4)) { b->err = "not a BGZF block"; return false; }
+  uint16_t xlen = hdr[10] | (hdr[11] << 8);
+  std::vector<uint8_t> extra(xlen);
+  memcpy(extra.data(), hdr + 12, xlen < 6 ? xlen : 6);
+  if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6, b->f) != (size_t)(xlen - 6)) { b->err = "truncated BGZF extra field"; return false; }
+  int bsize = -1;
+  for (size_t o = 0; o + 4 <= extra.size();) {
+    uint16_t slen = extra[o + 2] | (extra[o + 3] << 8);
+    if (extra[o] == 'B' && extra[o + 1] == 'C' && slen == 2) bsize = extra[o + 4] | (extra[o + 5] << 8);
+    o += 4 + slen;
+  }
+  if (bsize < 0) { b->err = "BGZF block without BC field"; return false; }
+  const size_t clen = (size_t)bsize + 1 - 12 - xlen - 8;
+  m.comp.resize(clen + 8);
+  if (fread(m.comp.data(), 1, clen + 8, b->f) != clen + 8) { b->err = "truncated BGZF block"; return false; }
+  m.comp.resize(clen + 8);
+  m.isize = m.comp[clen + 4] | (m.comp[clen + 5] << 8) | (m.comp[clen + 6] << 16) | ((uint32_t)m.comp[clen + 7] << 24);
+  got = true;
+  return true;
+}
+
+bool inflate_member(const Member& m, uint8_t* dst) {
+  if (!m.isize) return true;
+  z_stream zs;
+  memset(&zs, 0, sizeof zs);
+  if (inflateInit2(&zs, -15) != Z_OK) return false;
+  zs.next_in = const_cast<uint8_t*>(m.comp.data()); zs.avail_in = (uInt)(m.comp.size() - 8);
+  zs.next_out = dst; zs.avail_out = m.isize;
+  const int rc = inflate(&zs, Z_FINISH);
+  inflateEnd(&zs);
+  return rc == Z_STREAM_END && zs.avail_out == 0;
+}
+
 bool fill(vsv_bam* b, size_t need) {
   // make at least `need` unread bytes available in b->buf
   while (b->buf.size() - b->rd < need && !b->eof) {
-    uint8_t hdr[18];
-    size_t got = fread(hdr, 1, 18, b->f);
-    if (got == 0) { b->eof = true; break; }
-    if (got != 18 || hdr[0] != 31 || hdr[1] != 139 || hdr[2] != 8 || !(hdr[3] & 4)) { b->err = "not a BGZF block"; return false; }
-    uint16_t xlen = hdr[10] | (hdr[11] << 8);
-    // the BC subfield is first in every htslib-written file; handle the general case anyway
-    std::vector<uint8_t> extra(xlen);
-    memcpy(extra.data(), hdr + 12, xlen < 6 ? xlen : 6);
-    if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6, b->f) != (size_t)(xlen - 6)) { b->err = "truncated BGZF extra field"; return false; }
-    int bsize = -1;
-    for (size_t o = 0; o + 4 <= extra.size();) {
-      uint16_t slen = extra[o + 2] | (extra[o + 3] << 8);
-      if (extra[o] == 'B' && extra[o + 1] == 'C' && slen == 2) bsize = extra[o + 4] | (extra[o + 5] << 8);
-      o += 4 + slen;
+    std::vector<Member> win;
+    size_t total = 0;
+    while ((int)win.size() < WINDOW_BLOCKS && !b->eof) {
+      Member m; bool got;
+      if (!read_member(b, m, got)) return false;
+      if (!got) break;
+      m.out_off = total; total += m.isize;
+      win.push_back(std::move(m));
+      if (b->n_threads == 1 && total >= need) break;   // single-threaded callers (header parse) stay incremental
     }
-    if (bsize < 0) { b->err = "BGZF block without BC field"; return false; }
-    size_t clen = (size_t)bsize + 1 - 12 - xlen - 8;
-    std::vector<uint8_t> comp(clen + 8);
-    if (fread(comp.data(), 1, clen + 8, b->f) != clen + 8) { b->err = "truncated BGZF block"; return false; }
-    uint32_t isize = comp[clen + 4] | (comp[clen + 5] << 8) | (comp[clen + 6] << 16) | ((uint32_t)comp[clen + 7] << 24);
-    if (b->rd > (1u << 20)) { b->buf.erase(b->buf.begin(), b->buf.begin() + b->rd); b->rd = 0; }
-    size_t old = b->buf.size();
-    b->buf.resize(old + isize);
-    if (isize) {
-      z_stream zs;
-      memset(&zs, 0, sizeof zs);
-      if (inflateInit2(&zs, -15) != Z_OK) { b->err = "inflateInit2 failed"; return false; }
-      zs.next_in = comp.data(); zs.avail_in = (uInt)clen;
-      zs.next_out = b->buf.data() + old; zs.avail_out = isize;
-      int rc = inflate(&zs, Z_FINISH);
-      inflateEnd(&zs);
-      if (rc != Z_STREAM_END || zs.avail_out != 0) { b->err = "inflate failed"; return false; }
-    }
+    if (win.empty()) break;
+    if (b->rd > 0) { b->buf.erase(b->buf.begin(), b->buf.begin() + b->rd); b->rd = 0; }
+    const size_t old = b->buf.size();
+    b->buf.resize(old + total);
+    uint8_t* base = b->buf.data() + old;
+    int nt = b->n_threads > 0 ? b->n_threads : (int)std::thread::hardware_concurrency();
+    if (nt > 16) nt = 16;
+    if (nt < 1) nt = 1;
+    if ((size_t)nt > win.size()) nt = (int)win.size();
+    std::atomic<size_t> next{0};
+    std::atomic<bool> ok{true};
+    auto work = [&]() {
+      for (;;) {
+        const size_t i = next.fetch_add(1);
+        if (i >= win.size()) break;
+        if (!inflate_member(win[i], base + win[i].out_off)) ok = false;
+      }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+    work();
+    for (auto& th : pool) th.join();
+    if (!ok) { b->err = "inflate failed"; return false; }
   }
   return b->buf.size() - b->rd >= need;
 }
@@ -121,7 +168,9 @@ int vsv_bam_open(const char* path, vsv_bam** out) {
   if (!f) return VSV_E_INVALID;
   vsv_bam* b = new vsv_bam();
   b->f = f;
+  b->n_threads = 1;                      // header only: inflate the first members, not a whole window
   if (!read_header(b)) { fclose(f); delete b; return VSV_E_INVALID; }
+  b->n_threads = 0;
   *out = b;
   return 0;
 }
@@ -133,42 +182,59 @@ void vsv_bam_close(vsv_bam* b) {
 }
 
 const char* vsv_bam_error(vsv_bam* b) { return b ? b->err.c_str() : "null"; }
+/* number of inflate worker threads used by vsv_bam_load (0 = all hardware threads, at most 16) */
+void vsv_bam_set_threads(vsv_bam* b, int n) { if (b) b->n_threads = n < 0 ? 0 : n; }
 int vsv_bam_n_refs(vsv_bam* b) { return b ? (int)b->ref_names.size() : 0; }
 const char* vsv_bam_ref_name(vsv_bam* b, int i) { return (b && i >= 0 && i < (int)b->ref_names.size()) ? b->ref_names[i].c_str() : ""; }
 int64_t vsv_bam_ref_len(vsv_bam* b, int i) { return (b && i >= 0 && i < (int)b->ref_lens.size()) ? b->ref_lens[i] : -1; }
 
 /* Loads every record with refID == tid (tid < 0: all mapped-or-placed records) in file order into library-owned
  * arrays and fills `out` with host pointers to them. qids are dense in first-appearance order; the hp flag bits come
- * from the substring test of H:392 ('hp1' in qname / 'hp2' in qname). */
+ * from the substring test of H:392 ('hp1' in qname / 'hp2' in qname). Records are parsed in place from the inflated
+ * byte queue; names go through an open-addressing table over one name blob (no per-record allocations). */
 int vsv_bam_load(vsv_bam* b, int tid, vsv_records* out) {
   if (!b || !out) return VSV_E_INVALID;
   // rewind and skip the header again (simple and index-free)
   fseek(b->f, 0, SEEK_SET);
   b->buf.clear(); b->rd = 0; b->eof = false;
   b->ref_names.clear(); b->ref_lens.clear();
-  if (!read_header(b)) return VSV_E_INVALID;
+  const int user_threads = b->n_threads;
+  b->n_threads = 1;                      // the header is parsed incrementally
+  const bool hdr_ok = read_header(b);
+  b->n_threads = user_threads;
+  if (!hdr_ok) return VSV_E_INVALID;
   b->pos.clear(); b->tid.clear(); b->qid.clear(); b->cigar.clear(); b->cigar_off.assign(1, 0); b->mapq.clear(); b->flag.clear();
   b->qnames.clear(); b->sa.clear(); b->l_seq.clear(); b->sam_flag.clear();
-  std::unordered_map<std::string, uint32_t> ids;
-  std::vector<uint8_t> rec;
+  b->qname_blob.clear(); b->sa_blob.clear();
+  // open-addressing name table: slot -> (hash, offset into qname_blob, length, id)
+  struct Slot { uint64_t h; uint32_t off, len, id; };
+  std::vector<Slot> table(1u << 16, Slot{0, 0, 0, 0xFFFFFFFFu});
+  size_t n_names = 0;
+  auto grow = [&]() {
+    std::vector<Slot> t2(table.size() * 2, Slot{0, 0, 0, 0xFFFFFFFFu});
+    for (const Slot& s : table) if (s.id != 0xFFFFFFFFu) { size_t i = s.h & (t2.size() - 1); while (t2[i].id != 0xFFFFFFFFu) i = (i + 1) & (t2.size() - 1); t2[i] = s; }
+    table.swap(t2);
+  };
+  bool first_rec = true;
   for (;;) {
-    int32_t block_size;
     if (!fill(b, 4)) { if (!b->err.empty()) return VSV_E_INVALID; break; }
-    rd_bytes(b, &block_size, 4);
+    int32_t block_size;
+    memcpy(&block_size, b->buf.data() + b->rd, 4);
     if (block_size < 32) { b->err = "bad BAM record size"; return VSV_E_INVALID; }
-    rec.resize(block_size);
-    if (!rd_bytes(b, rec.data(), block_size)) return VSV_E_INVALID;
+    if (!fill(b, 4 + (size_t)block_size)) { if (b->err.empty()) b->err = "unexpected end of BAM"; return VSV_E_INVALID; }
+    const uint8_t* rec = b->buf.data() + b->rd + 4;
+    b->rd += 4 + (size_t)block_size;
     int32_t refID, pos; memcpy(&refID, &rec[0], 4); memcpy(&pos, &rec[4], 4);
     if (refID < 0 || (tid >= 0 && refID != tid)) continue;
     const uint8_t l_read_name = rec[8], mq = rec[9];
     uint16_t n_cig, fl; memcpy(&n_cig, &rec[12], 2); memcpy(&fl, &rec[14], 2);
     int32_t l_seq; memcpy(&l_seq, &rec[16], 4);
     const char* name = (const char*)&rec[32];
-    std::string qn(name, l_read_name ? l_read_name - 1 : 0);
+    const uint32_t nlen = l_read_name ? l_read_name - 1u : 0u;
     const uint8_t* cg = &rec[32 + l_read_name];
     size_t off = 32 + (size_t)l_read_name + 4u * n_cig + (size_t)((l_seq + 1) / 2) + (size_t)l_seq;
     // tags: SA:Z and CG:B,I
-    std::string sa;
+    const char* sa_p = nullptr; size_t sa_len = 0;
     const uint8_t* cg_long = nullptr; uint32_t n_long = 0;
     while (off + 3 <= (size_t)block_size) {
       const char t0 = rec[off], t1 = rec[off + 1], ty = rec[off + 2];
@@ -178,7 +244,7 @@ int vsv_bam_load(vsv_bam* b, int tid, vsv_records* out) {
         case 'A': case 'c': case 'C': len = 1; break;
         case 's': case 'S': len = 2; break;
         case 'i': case 'I': case 'f': len = 4; break;
-        case 'Z': case 'H': { size_t e = off; while (e < (size_t)block_size && rec[e]) ++e; if (t0 == 'S' && t1 == 'A' && ty == 'Z') sa.assign((const char*)&rec[off], e - off); len = e - off + 1; break; }
+        case 'Z': case 'H': { size_t e = off; while (e < (size_t)block_size && rec[e]) ++e; if (t0 == 'S' && t1 == 'A' && ty == 'Z') { sa_p = (const char*)&rec[off]; sa_len = e - off; } len = e - off + 1; break; }
         case 'B': {
           const char sub = rec[off]; uint32_t cnt; memcpy(&cnt, &rec[off + 1], 4);
           size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
@@ -189,19 +255,36 @@ int vsv_bam_load(vsv_bam* b, int tid, vsv_records* out) {
       }
       off += len;
     }
-    uint32_t q;
-    auto it = ids.find(qn);
-    if (it == ids.end()) { q = (uint32_t)b->qnames.size(); ids.emplace(qn, q); b->qnames.push_back(qn); } else q = it->second;
+    // name -> dense id (FNV-1a)
+    uint64_t h = 1469598103934665603ull;
+    for (uint32_t k = 0; k < nlen; ++k) { h ^= (uint8_t)name[k]; h *= 1099511628211ull; }
+    size_t si = h & (table.size() - 1);
+    uint32_t q = 0xFFFFFFFFu;
+    for (;;) {
+      Slot& s = table[si];
+      if (s.id == 0xFFFFFFFFu) {
+        q = (uint32_t)n_names++;
+        if (q) b->qname_blob.push_back('\n');
+        s = Slot{h, (uint32_t)b->qname_blob.size(), nlen, q};
+        b->qname_blob.append(name, nlen);
+        if (n_names * 2 > table.size()) grow();
+        break;
+      }
+      if (s.h == h && s.len == nlen && memcmp(b->qname_blob.data() + s.off, name, nlen) == 0) { q = s.id; break; }
+      si = (si + 1) & (table.size() - 1);
+    }
     uint8_t f8 = 0;
     if (fl & 0x10) f8 |= VSV_F_REVERSE;
     if (fl & 0x800) f8 |= VSV_F_SUPP;
     if (fl & 0x100) f8 |= VSV_F_SECONDARY;
     if (fl & 0x4) f8 |= VSV_F_UNMAPPED;
-    if (qn.find("hp1") != std::string::npos) f8 |= VSV_F_HP1;
-    if (qn.find("hp2") != std::string::npos) f8 |= VSV_F_HP2;
+    for (uint32_t k = 0; k + 3 <= nlen; ++k)   // 'hp1' in qname / 'hp2' in qname (H:392)
+      if (name[k] == 'h' && name[k + 1] == 'p') { if (name[k + 2] == '1') f8 |= VSV_F_HP1; else if (name[k + 2] == '2') f8 |= VSV_F_HP2; }
     b->pos.push_back(pos); b->tid.push_back(refID); b->qid.push_back(q); b->mapq.push_back(mq); b->flag.push_back(f8);
     b->l_seq.push_back((uint32_t)l_seq); b->sam_flag.push_back(fl);
-    b->sa.push_back(sa);
+    if (!first_rec) b->sa_blob.push_back('\n');
+    first_rec = false;
+    if (sa_len) b->sa_blob.append(sa_p, sa_len);
     if (cg_long && n_cig == 2) {  // real CIGAR lives in the CG tag (htslib convention for > 65535 ops)
       size_t o = b->cigar.size(); b->cigar.resize(o + n_long); memcpy(&b->cigar[o], cg_long, 4u * n_long);
     } else {
@@ -209,17 +292,13 @@ int vsv_bam_load(vsv_bam* b, int tid, vsv_records* out) {
     }
     b->cigar_off.push_back(b->cigar.size());
   }
-  b->qname_blob.clear();
-  for (size_t i = 0; i < b->qnames.size(); ++i) { if (i) b->qname_blob.push_back('\n'); b->qname_blob += b->qnames[i]; }
-  b->sa_blob.clear();
-  for (size_t i = 0; i < b->sa.size(); ++i) { if (i) b->sa_blob.push_back('\n'); b->sa_blob += b->sa[i]; }
   memset(out, 0, sizeof *out);
   out->n_records = (int64_t)b->pos.size();
   out->n_ops = (int64_t)b->cigar.size();
   out->pos = b->pos.data(); out->tid = b->tid.data(); out->qid = b->qid.data(); out->cigar_off = b->cigar_off.data();
   out->mapq = b->mapq.data(); out->flag = b->flag.data(); out->cigar = b->cigar.data();
   out->on_device = 0;
-  out->n_qids = (int32_t)b->qnames.size();
+  out->n_qids = (int32_t)n_names;
   out->n_tids = (int32_t)b->ref_names.size();
   return 0;
 }
