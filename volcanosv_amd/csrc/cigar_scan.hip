@@ -37,6 +37,12 @@ template <> struct OpTab<1> { static constexpr uint32_t REF = 0x18D, QRY = 0x193
 template <> struct OpTab<2> { static constexpr uint32_t REF = 0x185, QRY = 0x193, BAD = 0x000; static constexpr bool HC = false; };
 constexpr uint32_t EMIT_MASK = 0x006;  // I(1), D(2)
 
+constexpr uint32_t rev32(uint32_t v) {
+  uint32_t r = 0;
+  for (int i = 0; i < 32; ++i) r |= ((v >> i) & 1u) << (31 - i);
+  return r;
+}
+
 __device__ __forceinline__ uint32_t bfe_mask(uint32_t table, uint32_t op) {
   // 0xFFFFFFFF if bit `op` of table is set else 0 (v_bfe_i32 with width 1 sign-extends)
   return (uint32_t)__builtin_amdgcn_sbfe(table, op, 1);
@@ -180,17 +186,30 @@ __global__ __launch_bounds__(256) void cigar_scan_emit(RecView rv, const uint32_
   };
   stage(r0);
 
+  // ---- record lookup (slow path only): 64-record window of the LDS table, one start per lane -------------
   uint32_t wbase = 0;                  // window = table entries [wbase, wbase+64)
-  uint32_t pbase_r = 0, pbase_q = 0;   // prefix value at the start of the current segment (mod 2^32)
-  // The open record (last record started so far). Its in-segment prefix is NOT computed when the record starts — that
-  // costs ~10 dependent v_readlane per chunk — but lazily, by re-reading the (L2-hot) chunk it started in, and only if
-  // a later segment emits a signature for it. What is kept: where it started and the prefix at that segment's start.
-  uint32_t open_rec = r0, open_s = ob_rel;
-  uint32_t open_cb = 0, open_lo = ob_rel, open_hi = 0;   // chunk and segment [lo,hi) in which it started
-  uint32_t open_base_r = 0, open_base_q = 0;             // pbase at the start of that segment
-  uint32_t open_in_r = 0, open_in_q = 0;                 // cached in-segment prefix at open_s
-  bool open_cached = false;
-  uint32_t jprev = 0;                  // records of the current window started before the current segment
+  uint32_t nwin = 0, nxt = 0, s_rel = 0;
+  auto load_window = [&]() {
+    nwin = min(64u, n_tab - wbase);
+    s_rel = my_off[wbase + min((uint32_t)lane, nwin - 1u)];
+    nxt = __builtin_amdgcn_readfirstlane(my_off[wbase + nwin]);   // first start after the window (oe_rel at the end)
+  };
+  load_window();
+  // Lookups ascend within a part, so the window only moves forward. Returns the number of window records whose start
+  // is <= xo (>= 1): op xo belongs to record tbase + wbase + cnt - 1.
+  auto lookup = [&](uint32_t xo) -> uint32_t {
+    while (xo >= nxt && !bad) {
+      wbase += 64;
+      if (wbase >= n_tab) { stage(tbase + n_tab); wbase = 0; }   // part with > K1_RMAX records: restage
+      load_window();
+    }
+    return (uint32_t)__popcll(__ballot((uint32_t)lane < nwin && s_rel <= xo));
+  };
+
+  // Checkpoint of the lazily evaluated prefix: for record ck_rec, (ck_r, ck_q) = P(start of chunk ck_chunk) - P(record
+  // start). The streaming path keeps NO running prefix; a signature whose record started in an earlier chunk walks the
+  // (L2-hot) chunks from the checkpoint (or from the record's start chunk) up to the current one.
+  uint32_t ck_rec = 0xFFFFFFFFu, ck_chunk = 0, ck_r = 0, ck_q = 0;
 
   // slot allocator of this wave inside its shard (all wave-uniform)
   const uint32_t shard = (uint32_t)part % K1_SHARDS;
@@ -214,165 +233,166 @@ __global__ __launch_bounds__(256) void cigar_scan_emit(RecView rv, const uint32_
     return sl;
   };
 
-  auto process_chunk = [&](const uint4& wcur, const uint32_t cb) {
-    if (cb >= oe_rel || bad) return;             // ring slots past the end of the part
+  // decoded chunk: per-op (ref, query) advances, their wave-exclusive prefix per lane and the chunk totals
+  struct Dec { uint32_t ar[4], aq[4], excl_r, excl_q, tot_r, tot_q; };
+  auto decode = [&](const uint32_t (&w)[4], Dec& d) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t op = w[k] & 15u, len = w[k] >> 4;
+      d.ar[k] = len & bfe_mask(T::REF, op);
+      d.aq[k] = len & bfe_mask(T::QRY, op);
+    }
+    const uint32_t sum_r = d.ar[0] + d.ar[1] + d.ar[2] + d.ar[3];
+    const uint32_t sum_q = d.aq[0] + d.aq[1] + d.aq[2] + d.aq[3];
+    const uint32_t incl_r = wave_incl_scan(sum_r), incl_q = wave_incl_scan(sum_q);
+    d.excl_r = incl_r - sum_r; d.excl_q = incl_q - sum_q;
+    d.tot_r = rdlane(incl_r, 63); d.tot_q = rdlane(incl_q, 63);
+  };
+  // in-chunk exclusive prefix at rel op index s (wave-uniform, inside chunk cb)
+  auto prefix_at = [&](const Dec& d, uint32_t cb, uint32_t s, uint32_t& b_r, uint32_t& b_q) {
+    const uint32_t ls = (s - cb) >> 2, ss = (s - cb) & 3u;
+    b_r = rdlane(d.excl_r, ls); b_q = rdlane(d.excl_q, ls);
+    if (ss > 0) { b_r += rdlane(d.ar[0], ls); b_q += rdlane(d.aq[0], ls); }
+    if (ss > 1) { b_r += rdlane(d.ar[1], ls); b_q += rdlane(d.aq[1], ls); }
+    if (ss > 2) { b_r += rdlane(d.ar[2], ls); b_q += rdlane(d.aq[2], ls); }
+  };
+  // make (ck_r, ck_q) = P(cb) - P(s_r) for record rec, which started at s_r < cb
+  auto base_for = [&](uint32_t rec, uint32_t s_r, uint32_t cb) {
+    if (ck_rec != rec) {
+      const uint32_t c_s = s_r & ~255u;
+      const uint4 v = load_chunk(c_s);
+      const uint32_t ww[4] = {v.x, v.y, v.z, v.w};
+      Dec e; decode(ww, e);
+      uint32_t b_r, b_q;
+      prefix_at(e, c_s, s_r, b_r, b_q);
+      ck_rec = rec; ck_chunk = c_s + 256u; ck_r = e.tot_r - b_r; ck_q = e.tot_q - b_q;
+    }
+    while (ck_chunk < cb) {
+      const uint4 v = load_chunk(ck_chunk);
+      const uint32_t ww[4] = {v.x, v.y, v.z, v.w};
+      Dec e; decode(ww, e);
+      ck_r += e.tot_r; ck_q += e.tot_q; ck_chunk += 256u;
+    }
+  };
+
+  // ---- slow path: the chunk holds at least one candidate op (wave-uniform) ------------------------------
+  auto slow = [&](const uint4& wcur, const uint32_t cb) {
     const uint32_t x = cb + 4u * (uint32_t)lane;  // rel index of this lane's first op
-    uint32_t seg_lo = cb == 0 ? ob_rel : cb;
-    const uint32_t chunk_hi = min(cb + 256u, oe_rel);
-    for (;;) {
-      const uint32_t nwin = min(64u, n_tab - wbase);
-      const bool rv_ok = (uint32_t)lane < nwin;
-      const uint32_t li = wbase + min((uint32_t)lane, nwin - 1u);
-      const uint32_t s_rel = my_off[li];
-      const uint32_t nbfs = my_off[wbase + nwin];            // first start after this window (oe_rel at the end)
-      const uint32_t nbfs_s = (ablate & 8) ? oe_rel : __builtin_amdgcn_readfirstlane(nbfs);
-      const uint32_t seg_hi = chunk_hi < nbfs_s ? chunk_hi : nbfs_s;
-      uint32_t w[4] = {wcur.x, wcur.y, wcur.z, wcur.w};
-      if (seg_lo > cb || seg_hi < cb + 256u) {  // partial segment (wave-uniform): mask ops outside [seg_lo, seg_hi)
+    uint32_t w[4] = {wcur.x, wcur.y, wcur.z, wcur.w};
+    if (cb == 0) {                                // ops before ob_rel belong to the previous part
 #pragma unroll
-        for (int k = 0; k < 4; ++k) if (x + k < seg_lo || x + k >= seg_hi) w[k] = 15u;
-      }
-      uint32_t ar[4], aq[4];
-      uint32_t em = 0;
+      for (int k = 0; k < 4; ++k) if (x + k < ob_rel) w[k] = 15u;
+    }
+    Dec d; decode(w, d);
+    uint32_t em = 0;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const uint32_t op = w[k] & 15u, len = w[k] >> 4;
-        ar[k] = len & bfe_mask(T::REF, op);
-        aq[k] = len & bfe_mask(T::QRY, op);
-        const uint32_t e = (bfe_mask(EMIT_MASK, op) & (uint32_t)-(int)(len >= (uint32_t)min_svlen)) |
-                           (bfe_mask(T::BAD, op) & (uint32_t)-(int)(len != 0));
-        em |= (e & 1u) << k;
-      }
-      // lazily evaluated in-segment prefix of the open record (see the state comment above)
-      auto open_prefix = [&]() {
-        if (open_cached) return;
-        const uint4 v = load_chunk(open_cb);
-        uint32_t ww[4] = {v.x, v.y, v.z, v.w};
-        const uint32_t xx = open_cb + 4u * (uint32_t)lane;
-        uint32_t r4[4], q4[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          if (xx + k < open_lo || xx + k >= open_hi) ww[k] = 15u;
-          const uint32_t op = ww[k] & 15u, len = ww[k] >> 4;
-          r4[k] = len & bfe_mask(T::REF, op);
-          q4[k] = len & bfe_mask(T::QRY, op);
-        }
-        const uint32_t sr = r4[0] + r4[1] + r4[2] + r4[3], sq = q4[0] + q4[1] + q4[2] + q4[3];
-        const uint32_t er = wave_incl_scan(sr) - sr, eq = wave_incl_scan(sq) - sq;
-        const uint32_t ls = (open_s - open_cb) >> 2, ss = (open_s - open_cb) & 3u;
-        uint32_t b_r = rdlane(er, ls), b_q = rdlane(eq, ls);
-        if (ss > 0) { b_r += rdlane(r4[0], ls); b_q += rdlane(q4[0], ls); }
-        if (ss > 1) { b_r += rdlane(r4[1], ls); b_q += rdlane(q4[1], ls); }
-        if (ss > 2) { b_r += rdlane(r4[2], ls); b_q += rdlane(q4[2], ls); }
-        open_in_r = b_r; open_in_q = b_q; open_cached = true;
-      };
-      const uint32_t sum_r = ar[0] + ar[1] + ar[2] + ar[3];
-      const uint32_t sum_q = aq[0] + aq[1] + aq[2] + aq[3];
-      const uint32_t incl_r = wave_incl_scan(sum_r), incl_q = wave_incl_scan(sum_q);
-      const uint32_t excl_r = incl_r - sum_r, excl_q = incl_q - sum_q;
-
-      // in-chunk exclusive prefix at rel op index s (wave-uniform s inside this chunk)
-      auto prefix_at = [&](uint32_t s, uint32_t& b_r, uint32_t& b_q) {
-        const uint32_t ls = (s - cb) >> 2, ss = (s - cb) & 3u;
-        b_r = rdlane(excl_r, ls); b_q = rdlane(excl_q, ls);
-        if (ss > 0) { b_r += rdlane(ar[0], ls); b_q += rdlane(aq[0], ls); }
-        if (ss > 1) { b_r += rdlane(ar[1], ls); b_q += rdlane(aq[1], ls); }
-        if (ss > 2) { b_r += rdlane(ar[2], ls); b_q += rdlane(aq[2], ls); }
-      };
-
-      // ---- slow path: one scalar iteration per candidate op, in (lane, sub) = op order ------------
-      uint64_t anym = (ablate & 1) ? 0ull : __ballot(em != 0);
-      while (anym) {
-        const uint32_t l = (uint32_t)__builtin_ctzll(anym);
-        anym &= anym - 1;
-        const uint32_t eml = rdlane(em, l);
-        uint32_t px_r = rdlane(excl_r, l), px_q = rdlane(excl_q, l);  // in-chunk exclusive prefix at (l,0)
-        for (uint32_t sub = 0; sub < 4; ++sub) {
-          const uint32_t wsel = sub == 0 ? w[0] : sub == 1 ? w[1] : sub == 2 ? w[2] : w[3];
-          const uint32_t wl = rdlane(wsel, l);
-          if (eml & (1u << sub)) {
-            const uint32_t xo = cb + 4u * l + sub;
-            const uint32_t op = wl & 15u, len = wl >> 4;
-            // record of op xo: last table start <= xo (starts ascend with the lane index), or the open record
-            const uint32_t cnt = (uint32_t)__popcll(__ballot(rv_ok && s_rel <= xo));
-            uint32_t a_r, a_q, rec, s_r;
-            if (cnt == jprev) {              // record was already open at the segment start
-              open_prefix();
-              a_r = (pbase_r - open_base_r) + px_r - open_in_r;
-              a_q = (pbase_q - open_base_q) + px_q - open_in_q;
-              rec = open_rec; s_r = open_s;
-            } else {                         // record starts inside this segment
-              s_r = rdlane(s_rel, cnt - 1u);
-              uint32_t b_r, b_q;
-              prefix_at(s_r, b_r, b_q);
-              a_r = px_r - b_r;
-              a_q = px_q - b_q;
-              rec = tbase + wbase + cnt - 1u;
-            }
-            uint32_t wfl, wmq, tid_r, first, rpos_r;
-            sload5(align4(rv.flag + rec), align4(rv.mapq + rec), rv.tid + rec, rv.cigar + cb0 + s_r, rv.pos + rec, wfl, wmq, tid_r, first, rpos_r);
-            const uint32_t fl = byte_of(wfl, rv.flag + rec), mq = byte_of(wmq, rv.mapq + rec);
-            uint32_t hapbits;
-            if (CLS == 0) hapbits = (mq >= (uint32_t)min_mapq) ? ((fl >> 2) & 3u) : 0u;               // H:392-394
-            else if (CLS == 1) hapbits = (mq >= (uint32_t)min_mapq) ? 1u : 0u;                        // RS:120
-            else hapbits = (!(fl & (VSV_F_UNMAPPED | VSV_F_SECONDARY)) && mq >= (uint32_t)min_mapq) ? 1u : 0u;
-            if (hapbits) {
-              if (op != 1u && op != 2u) {  // N/=/X on the contig table: assert offset_ref==reference_end (H:396)
-                if (lane == 0) atomicOr(&ec.ctr->err, ERRB_REFEND);
-              } else {
-                const uint32_t hc = (T::HC && (first & 15u) == 5u) ? (first >> 4) : 0u;               // H:63-65
-                const uint32_t nemit = (hapbits == 3u) ? 2u : 1u;
-                const uint32_t slot = alloc(nemit);
-                if (lane < (int)nemit) {
-                  if (slot + (uint32_t)lane < ec.shard_cap) {
-                    vsv_sig s;
-                    s.pos = (int32_t)(rpos_r + a_r);
-                    s.svlen = (int32_t)len;
-                    s.q_start = (int32_t)(a_q + hc);
-                    s.q_end = (CLS == 1) ? 0 : s.q_start + (op == 2u ? 1 : (int32_t)len);
-                    s.rec = rec;
-                    s.rec2 = 0xFFFFFFFFu;
-                    const uint32_t hp2 = (CLS == 0) ? ((hapbits == 3u) ? (uint32_t)lane : (hapbits >> 1)) : 0u;
-                    s.meta = (op == 2u ? VSV_M_DEL : 0u) | (hp2 ? VSV_M_HP2 : 0u);
-                    s.tid = (int32_t)tid_r;
-                    ec.pool[shard_off + slot + lane] = s;
-                    ec.pool_key[shard_off + slot + lane] = ((uint64_t)(uint32_t)part << 32) | (uint64_t)(ord + (uint32_t)lane);
-                  }
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t op = w[k] & 15u, len = w[k] >> 4;
+      const uint32_t e = (bfe_mask(EMIT_MASK, op) & (uint32_t)-(int)(len >= (uint32_t)min_svlen)) |
+                         (bfe_mask(T::BAD, op) & (uint32_t)-(int)(len != 0));
+      em |= (e & 1u) << k;
+    }
+    // one scalar iteration per candidate op, in (lane, sub) = op order
+    uint64_t anym = __ballot(em != 0);
+    while (anym) {
+      const uint32_t l = (uint32_t)__builtin_ctzll(anym);
+      anym &= anym - 1;
+      const uint32_t eml = rdlane(em, l);
+      uint32_t px_r = rdlane(d.excl_r, l), px_q = rdlane(d.excl_q, l);  // in-chunk exclusive prefix at (l,0)
+      for (uint32_t sub = 0; sub < 4; ++sub) {
+        const uint32_t wsel = sub == 0 ? w[0] : sub == 1 ? w[1] : sub == 2 ? w[2] : w[3];
+        const uint32_t wl = rdlane(wsel, l);
+        if (eml & (1u << sub)) {
+          const uint32_t xo = cb + 4u * l + sub;
+          const uint32_t op = wl & 15u, len = wl >> 4;
+          const uint32_t cnt = lookup(xo);
+          if (bad) return;
+          const uint32_t rec = tbase + wbase + cnt - 1u;
+          const uint32_t s_r = rdlane(s_rel, cnt - 1u);
+          uint32_t a_r, a_q;
+          if (s_r >= cb) {                 // record starts inside this chunk
+            uint32_t b_r, b_q;
+            prefix_at(d, cb, s_r, b_r, b_q);
+            a_r = px_r - b_r;
+            a_q = px_q - b_q;
+          } else {                         // record was open at the chunk start
+            base_for(rec, s_r, cb);
+            a_r = ck_r + px_r;
+            a_q = ck_q + px_q;
+          }
+          uint32_t wfl, wmq, tid_r, first, rpos_r;
+          sload5(align4(rv.flag + rec), align4(rv.mapq + rec), rv.tid + rec, rv.cigar + cb0 + s_r, rv.pos + rec, wfl, wmq, tid_r, first, rpos_r);
+          const uint32_t fl = byte_of(wfl, rv.flag + rec), mq = byte_of(wmq, rv.mapq + rec);
+          uint32_t hapbits;
+          if (CLS == 0) hapbits = (mq >= (uint32_t)min_mapq) ? ((fl >> 2) & 3u) : 0u;               // H:392-394
+          else if (CLS == 1) hapbits = (mq >= (uint32_t)min_mapq) ? 1u : 0u;                        // RS:120
+          else hapbits = (!(fl & (VSV_F_UNMAPPED | VSV_F_SECONDARY)) && mq >= (uint32_t)min_mapq) ? 1u : 0u;
+          if (hapbits) {
+            if (op != 1u && op != 2u) {  // N/=/X on the contig table: assert offset_ref==reference_end (H:396)
+              if (lane == 0) atomicOr(&ec.ctr->err, ERRB_REFEND);
+            } else {
+              const uint32_t hc = (T::HC && (first & 15u) == 5u) ? (first >> 4) : 0u;               // H:63-65
+              const uint32_t nemit = (hapbits == 3u) ? 2u : 1u;
+              const uint32_t slot = alloc(nemit);
+              if (lane < (int)nemit) {
+                if (slot + (uint32_t)lane < ec.shard_cap) {
+                  vsv_sig s;
+                  s.pos = (int32_t)(rpos_r + a_r);
+                  s.svlen = (int32_t)len;
+                  s.q_start = (int32_t)(a_q + hc);
+                  s.q_end = (CLS == 1) ? 0 : s.q_start + (op == 2u ? 1 : (int32_t)len);
+                  s.rec = rec;
+                  s.rec2 = 0xFFFFFFFFu;
+                  const uint32_t hp2 = (CLS == 0) ? ((hapbits == 3u) ? (uint32_t)lane : (hapbits >> 1)) : 0u;
+                  s.meta = (op == 2u ? VSV_M_DEL : 0u) | (hp2 ? VSV_M_HP2 : 0u);
+                  s.tid = (int32_t)tid_r;
+                  ec.pool[shard_off + slot + lane] = s;
+                  ec.pool_key[shard_off + slot + lane] = ((uint64_t)(uint32_t)part << 32) | (uint64_t)(ord + (uint32_t)lane);
                 }
-                ord += nemit;
               }
+              ord += nemit;
             }
           }
-          const uint32_t arsel = sub == 0 ? ar[0] : sub == 1 ? ar[1] : sub == 2 ? ar[2] : ar[3];
-          const uint32_t aqsel = sub == 0 ? aq[0] : sub == 1 ? aq[1] : sub == 2 ? aq[2] : aq[3];
-          px_r += rdlane(arsel, l);
-          px_q += rdlane(aqsel, l);
         }
+        const uint32_t arsel = sub == 0 ? d.ar[0] : sub == 1 ? d.ar[1] : sub == 2 ? d.ar[2] : d.ar[3];
+        const uint32_t aqsel = sub == 0 ? d.aq[0] : sub == 1 ? d.aq[1] : sub == 2 ? d.aq[2] : d.aq[3];
+        px_r += rdlane(arsel, l);
+        px_q += rdlane(aqsel, l);
       }
-
-      // ---- scalar bookkeeping: which record is open at the end of this segment ----------------------
-      const uint32_t j = (uint32_t)__popcll(__ballot(rv_ok && s_rel < seg_hi));
-      if (j > jprev && !(ablate & 2)) {
-        open_s = rdlane(s_rel, j - 1u);
-        open_rec = tbase + wbase + j - 1u;
-        open_cb = cb; open_lo = seg_lo; open_hi = seg_hi;
-        open_base_r = pbase_r; open_base_q = pbase_q;
-        open_cached = false;
-        jprev = j;
-      }
-      pbase_r += rdlane(incl_r, 63);
-      pbase_q += rdlane(incl_q, 63);
-      if (seg_hi >= chunk_hi) break;
-      // ---- the chunk continues in the next window of the record table ---------------------------------
-      wbase += 64;
-      if (wbase >= n_tab) {               // table exhausted (part with > K1_RMAX records): restage
-        stage(tbase + n_tab);
-        wbase = 0;
-        if (bad) return;
-      }
-      jprev = 0;
-      seg_lo = seg_hi;
     }
+    // checkpoint for the record that is open at the end of this chunk (dense chunks then never walk)
+    const uint32_t last = min(cb + 256u, oe_rel) - 1u;
+    const uint32_t cnt = lookup(last);
+    if (bad) return;
+    const uint32_t rec = tbase + wbase + cnt - 1u;
+    const uint32_t s_r = rdlane(s_rel, cnt - 1u);
+    if (s_r >= cb) {
+      uint32_t b_r, b_q;
+      prefix_at(d, cb, s_r, b_r, b_q);
+      ck_rec = rec; ck_chunk = cb + 256u; ck_r = d.tot_r - b_r; ck_q = d.tot_q - b_q;
+    } else if (ck_rec == rec && ck_chunk == cb) {
+      ck_r += d.tot_r; ck_q += d.tot_q; ck_chunk = cb + 256u;
+    }
+  };
+
+  // ---- streaming path: per op one shift against the (bit-reversed, duplicated) op mask, a sign test and a compare
+  // of the packed word against min_svlen<<4. The test is a superset of the emit predicate; `slow` is exact.
+  const uint32_t thr = (uint32_t)min_svlen;
+  const uint32_t thr16 = thr >= (1u << 28) ? 0xFFFFFFFFu : thr << 4;
+  constexpr uint32_t EMIT_R = rev32(EMIT_MASK | (EMIT_MASK << 16));
+  constexpr uint32_t BAD_R = rev32(T::BAD | (T::BAD << 16));
+  auto process_chunk = [&](const uint4& wcur, const uint32_t cb) {
+    if (cb >= oe_rel || bad) return;             // ring slots past the end of the part
+    bool cand = ((int32_t)(EMIT_R << (wcur.x & 31u)) < 0 && wcur.x >= thr16) |
+                ((int32_t)(EMIT_R << (wcur.y & 31u)) < 0 && wcur.y >= thr16) |
+                ((int32_t)(EMIT_R << (wcur.z & 31u)) < 0 && wcur.z >= thr16) |
+                ((int32_t)(EMIT_R << (wcur.w & 31u)) < 0 && wcur.w >= thr16);
+    if (T::BAD != 0) {
+      const uint32_t t = (BAD_R << (wcur.x & 31u)) | (BAD_R << (wcur.y & 31u)) | (BAD_R << (wcur.z & 31u)) | (BAD_R << (wcur.w & 31u));
+      cand |= (int32_t)t < 0;
+    }
+    if (__ballot(cand) == 0ull || (ablate & 1)) return;
+    slow(wcur, cb);
   };
 
   // three chunks in flight per wave; the ring is unrolled so no in-flight register is ever copied
@@ -384,6 +404,8 @@ __global__ __launch_bounds__(256) void cigar_scan_emit(RecView rv, const uint32_
     process_chunk(wc, cb + 512);
     wc = load_chunk(cb + 1280);
   }
+  // every record start of the part goes through stage() once: an empty CIGAR must raise (H:63 IndexError)
+  while (!bad && tbase + n_tab < r1 && !(ablate & 4)) stage(tbase + n_tab);
   release_left();
   if (lane == 0) part_count[part] = ord;
 }
