@@ -240,6 +240,25 @@ int vsv_bnd_pair(vsv_handle* h, const vsv_bnd_params* p);
  * as the input of vsv_bnd_pair. */
 int vsv_bnd_set_candidates(vsv_handle* h, const vsv_bnd* rows, int64_t n, const int32_t* contig_rank, int32_t n_tids, int on_device);
 
+/* ---- post-filter: read-signature support of the calls (the step right of the path) -------------------
+ * Replaces FP_filter_v1.eval_sig + compare_sigs (Large_INDEL/FP_filter_v1.py:87-123), run by Raw_variant_call.py:91-96
+ * on the raw variant VCF against <chr>_reads_sig.txt. A call is (pos, |len(ALT)-len(REF)|) (FP:41-57), a read signature
+ * is (pos, svlen) (FP:77-86); the SV type is NOT part of the predicate. */
+typedef struct vsv_support_params {
+  int32_t max_comp_svlen;      /* 250   calls longer than this are not checked: support 60 (FP:110-111)  */
+  int32_t max_dist;            /* 1000  scan window around the call position (FP:116-119)                 */
+  int32_t max_shift;           /* 500   |pos_sig - pos_call| <= max_shift (FP:98-99)                      */
+  int32_t pad;
+  double min_size_sim;         /* 0.5   min(len)/max(len) >= min_size_sim; 0/0 counts as 0 (FP:93-96)     */
+} vsv_support_params;
+int vsv_default_support_params(vsv_support_params* p);
+/* support[i] = 60 if call_len[i] > max_comp_svlen, else the number of read signatures inside the window that pass
+ * compare_sigs (FP:106-123). sig_pos must ascend (the reference file is sorted by merge_all, RS:281-286; its early `break` relies on it), else
+ * VSV_E_UNSORTED. on_device: all five arrays are device pointers (and the call synchronises the handle's stream). */
+int vsv_support_join(vsv_handle* h, const int32_t* call_pos, const int32_t* call_len, int64_t n_calls,
+                     const int32_t* sig_pos, const int32_t* sig_len, int64_t n_sigs,
+                     const vsv_support_params* p, int on_device, uint32_t* support);
+
 /* ---- host-side ingest: BAM/BGZF -> record SoA ----------------------------------------------------
  * Replaces pysam.AlignmentFile(bam).fetch(chr) (H:387-391, RS:108-113). Arrays returned through `out` are owned
  * by the vsv_bam object and stay valid until the next vsv_bam_load / vsv_bam_close. No index is used. */

@@ -9,7 +9,7 @@ import subprocess
 
 import numpy as np
 
-from volcanosv_amd.abi import BND_DTYPE, CALL_DTYPE, SIG_DTYPE, BndParams, Params, Records, Segments
+from volcanosv_amd.abi import BND_DTYPE, CALL_DTYPE, SIG_DTYPE, BndParams, Params, Records, Segments, SupportParams
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
@@ -43,6 +43,8 @@ def lib():
                                  C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
         _LIB.orc_bnd_free.argtypes = [C.c_void_p, C.c_void_p]
         _LIB.orc_bnd_pair.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(BndParams), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        _LIB.orc_default_support_params.argtypes = [C.POINTER(SupportParams)]
+        _LIB.orc_support.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(SupportParams), C.c_void_p]
     return _LIB
 
 
@@ -104,3 +106,21 @@ def run_bnd_pair(rows, contig_rank, params=None):
     calls = _copy(b.value, nb.value, BND_DTYPE)
     lib().orc_bnd_free(b, None)
     return calls
+
+
+def default_support_params(**kw):
+    p = SupportParams()
+    lib().orc_default_support_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def run_support(call_pos, call_len, sig_pos, sig_len, params=None):
+    """FP_filter_v1.eval_sig on the host (literal loop). Returns (status, support uint32[n_calls])."""
+    p = params if params is not None else default_support_params()
+    a = [np.ascontiguousarray(x, dtype=np.int32) for x in (call_pos, call_len, sig_pos, sig_len)]
+    out = np.zeros(len(a[0]), dtype=np.uint32)
+    st = lib().orc_support(a[0].ctypes.data_as(C.c_void_p), a[1].ctypes.data_as(C.c_void_p), len(a[0]), a[2].ctypes.data_as(C.c_void_p),
+                           a[3].ctypes.data_as(C.c_void_p), len(a[2]), C.byref(p), out.ctypes.data_as(C.c_void_p))
+    return st, out

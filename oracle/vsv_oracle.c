@@ -787,3 +787,36 @@ int orc_bnd(const vsv_segments* s, const vsv_bnd_params* p, vsv_bnd** cand_out, 
   return rc;
 }
 void orc_bnd_free(vsv_bnd* a, vsv_bnd* b) { free(a); free(b); }
+
+/* ================================================================================================
+ * Post-filter: read-signature support of the calls — FP_filter_v1.eval_sig / compare_sigs
+ * (Large_INDEL/FP_filter_v1.py:87-123), the literal double loop with its `continue` / `break`.
+ * Returns VSV_E_UNSORTED if sig_pos does not ascend (the product path requires the sorted file the reference writes,
+ * RS:281-286); the counts are the literal ones either way.
+ * ================================================================================================ */
+int orc_default_support_params(vsv_support_params* p) {
+  p->max_comp_svlen = 250; p->max_dist = 1000; p->max_shift = 500; p->pad = 0; p->min_size_sim = 0.5;   /* FP:8-11 */
+  return 0;
+}
+
+int orc_support(const int32_t* call_pos, const int32_t* call_len, int64_t n_calls, const int32_t* sig_pos, const int32_t* sig_len,
+                int64_t n_sigs, const vsv_support_params* p, uint32_t* support) {
+  int sorted = 1;
+  for (int64_t j = 0; j + 1 < n_sigs; ++j) if (sig_pos[j] > sig_pos[j + 1]) sorted = 0;
+  for (int64_t i = 0; i < n_calls; ++i) {
+    if (call_len[i] > p->max_comp_svlen) { support[i] = 60; continue; }                 /* FP:110-111 */
+    uint32_t s = 0;
+    for (int64_t j = 0; j < n_sigs; ++j) {
+      const int64_t shift = (int64_t)sig_pos[j] - call_pos[i];                           /* FP:115 */
+      if (shift < -(int64_t)p->max_dist) continue;                                       /* FP:116-117 */
+      if (shift > (int64_t)p->max_dist) break;                                           /* FP:118-119 */
+      const int64_t a = shift < 0 ? -shift : shift;
+      const int32_t l1 = call_len[i], l2 = sig_len[j];
+      const int32_t mn = l1 < l2 ? l1 : l2, mx = l1 < l2 ? l2 : l1;
+      const double sim = mx == 0 ? 0.0 : (double)mn / (double)mx;                        /* FP:93-96 */
+      if (a <= p->max_shift && sim >= p->min_size_sim) ++s;                             /* FP:98-101 */
+    }
+    support[i] = s;
+  }
+  return sorted ? 0 : VSV_E_UNSORTED;
+}

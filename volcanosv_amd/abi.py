@@ -65,6 +65,12 @@ class BndParams(C.Structure):
                                          "pair_distance", "max_partition")] + [("reserved", C.c_int32 * 7)]
 
 
+class SupportParams(C.Structure):
+    """vsv_support_params (FP_filter_v1.py:8-11 defaults)."""
+    _fields_ = [("max_comp_svlen", C.c_int32), ("max_dist", C.c_int32), ("max_shift", C.c_int32), ("pad", C.c_int32),
+                ("min_size_sim", C.c_double)]
+
+
 BND_DTYPE = np.dtype([("src_tid", "<i4"), ("src_pos", "<i4"), ("dst_tid", "<i4"), ("dst_pos", "<i4"), ("read", "<u4"), ("read2", "<u4"),
                       ("meta", "<u4"), ("pad", "<u4")])
 B_SRC_FWD, B_DST_FWD, B_HAP2, B_GT_SHIFT, B_DEAD = 1, 2, 4, 4, 64

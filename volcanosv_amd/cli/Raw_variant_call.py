@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
-"""Drop-in for Large_INDEL/Raw_variant_call.py (same flags). The aligner and the post-filters stay external; the contig and
-reads signature extraction run on the GPU in this process."""
+"""Drop-in for Large_INDEL/Raw_variant_call.py (same flags). The aligner and remove_redundancy.py stay external; the contig and
+reads signature extraction and the false-positive filter (FP_filter_v1.py) run on the GPU in this process."""
 import os
 import shutil
 import sys
 from argparse import ArgumentParser
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-from volcanosv_amd import contig_signature, pipeline, reads_signature, vcf  # noqa: E402
+from volcanosv_amd import contig_signature, fp_filter, pipeline, reads_signature, vcf  # noqa: E402
 
 parser = ArgumentParser(description="", usage='use "python3 %(prog)s --help" for more information')
 parser.add_argument('--contig_path', '-contig')
@@ -36,8 +36,12 @@ if sigd is None and a.rbam_file and chr_num is not None:
     sigd = a.output_dir + "/reads_signature/"
 filtered = a.output_dir + "/volcano_variant_filtered.vcf"
 final_dir = a.output_dir + '/final_vcf/'
-if not (pipeline.spawn_reference_script(code_dir, "FP_filter_v1.py", "-i %s -sigd %s -o %s" % (raw, sigd, filtered)) and
-        pipeline.spawn_reference_script(code_dir, "remove_redundancy.py", "-i %s -o %s" % (filtered, final_dir))):
-    os.makedirs(final_dir, exist_ok=True)                                             # post-filters are outside this build
-    shutil.copy(raw, final_dir + "volcano_variant_no_redundancy.vcf")
-    print("note: FP_filter_v1.py / remove_redundancy.py not run (set VOLCANOSV_CODE_DIR to the reference's Large_INDEL dir)")
+if sigd is not None:
+    fp_filter.run(raw, sigd, filtered)                                                 # :91-96
+else:
+    shutil.copy(raw, filtered)
+    print("note: no reads signature directory (-sigd / -rbam with -chr): FP filter skipped")
+if not pipeline.spawn_reference_script(code_dir, "remove_redundancy.py", "-i %s -o %s" % (filtered, final_dir)):
+    os.makedirs(final_dir, exist_ok=True)                                             # remove_redundancy is outside this build
+    shutil.copy(filtered, final_dir + "volcano_variant_no_redundancy.vcf")
+    print("note: remove_redundancy.py not run (set VOLCANOSV_CODE_DIR to the reference's Large_INDEL dir)")

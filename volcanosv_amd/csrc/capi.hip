@@ -12,7 +12,8 @@
 
 namespace {
 
-constexpr int OPS_PER_PART = 8192;
+// ops per K1 part (one wave each); VSV_OPS_PER_PART overrides it for timing experiments
+static const int OPS_PER_PART = getenv("VSV_OPS_PER_PART") && atoi(getenv("VSV_OPS_PER_PART")) >= 1024 ? atoi(getenv("VSV_OPS_PER_PART")) : 4096;
 
 struct DevBuf {
   void* p = nullptr;
@@ -40,6 +41,7 @@ struct vsv_handle {
   DevBuf tab, blk_cnt, blk_off, ckey, crec, okey, oval;
   DevBuf key, idx, cl, key2, idx2, key_alt, val_alt, hist;
   DevBuf ctr, shard_cnt, totals;
+  DevBuf j_cpos, j_clen, j_spos, j_slen, j_out, j_err;   // support join (post-filter)
   int pass_cursor = 0;
   const uint64_t* sorted_key = nullptr;   // sorted keys of the stage just sorted (cluster / pair read them)
   bool fused_sort = true;          // small-input sort mode, re-decided after every run from its row counts
@@ -170,6 +172,8 @@ SortWork sort_work(vsv_handle* h) {
   SortWork w;
   w.key_alt = (uint64_t*)h->key_alt.p; w.val_alt = (uint32_t*)h->val_alt.p; w.hist = (uint32_t*)h->hist.p; w.max_items = h->cap_sigs;
   w.totals = (uint32_t*)h->totals.p; w.pass_cursor = &h->pass_cursor; w.max_passes = MAX_SORT_PASSES; w.fused = h->fused_sort;
+  static const char* force = getenv("VSV_SORT_TILE");   // timing experiments: "big" / "small"
+  if (force) w.fused = force[0] == 's';
   return w;
 }
 // zero the device counters and the per-pass sort totals: start of every run
@@ -357,7 +361,7 @@ void vsv_destroy(vsv_handle* h) {
                     &h->part_off, &h->scan_tmp, &h->pool, &h->pool_key, &h->raw0, &h->s1in, &h->s1s, &h->c1, &h->s2s, &h->c2,
                     &h->merged, &h->calls_tmp, &h->calls, &h->reads, &h->tab, &h->blk_cnt, &h->blk_off, &h->ckey, &h->crec,
                     &h->okey, &h->oval, &h->key, &h->idx, &h->cl, &h->key2, &h->idx2, &h->key_alt, &h->val_alt, &h->hist, &h->ctr, &h->shard_cnt, &h->totals, &h->g_off, &h->g_qs, &h->g_qe, &h->g_rid, &h->g_rs,
-                    &h->g_re, &h->g_rev, &h->g_hap, &h->g_len, &h->g_rank};
+                    &h->g_re, &h->g_rev, &h->g_hap, &h->g_len, &h->g_rank, &h->j_cpos, &h->j_clen, &h->j_spos, &h->j_slen, &h->j_out, &h->j_err};
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
   if (h->pinned) hipHostFree(h->pinned);
   if (h->ev0) hipEventDestroy(h->ev0);
@@ -521,6 +525,45 @@ int vsv_bnd_pair(vsv_handle* h, const vsv_bnd_params* p) {
   HIPCHK(h, hipGetLastError());
   h->bnd_stage = 2;
   return finish(h);
+}
+
+int vsv_default_support_params(vsv_support_params* p) {
+  if (!p) return VSV_E_INVALID;
+  p->max_comp_svlen = 250; p->max_dist = 1000; p->max_shift = 500; p->pad = 0; p->min_size_sim = 0.5;   // FP:8-11
+  return 0;
+}
+
+int vsv_support_join(vsv_handle* h, const int32_t* call_pos, const int32_t* call_len, int64_t n_calls, const int32_t* sig_pos,
+                     const int32_t* sig_len, int64_t n_sigs, const vsv_support_params* p, int on_device, uint32_t* support) {
+  if (!h || !p) return VSV_E_INVALID;
+  if (n_calls < 0 || n_sigs < 0) return fail(h, VSV_E_INVALID, "negative row count");
+  if (n_calls > 0 && (!call_pos || !call_len || !support)) return fail(h, VSV_E_INVALID, "call arrays are NULL");
+  if (n_sigs > 0 && (!sig_pos || !sig_len)) return fail(h, VSV_E_INVALID, "signature arrays are NULL");
+  if (p->max_dist < 0) return fail(h, VSV_E_INVALID, "max_dist < 0");
+  if (n_calls == 0) return 0;
+  HIPCHK(h, hipSetDevice(h->device));
+  int st;
+  if ((st = ensure(h, h->j_err, 256))) return st;
+  HIPCHK(h, hipMemsetAsync(h->j_err.p, 0, 4, h->stream));
+  const int32_t *cp = call_pos, *cl = call_len, *sp = sig_pos, *sl = sig_len;
+  uint32_t* out = support;
+  if (!on_device) {
+    if ((st = upload(h, h->j_cpos, call_pos, (size_t)n_calls * 4))) return st;
+    if ((st = upload(h, h->j_clen, call_len, (size_t)n_calls * 4))) return st;
+    if ((st = upload(h, h->j_spos, sig_pos, (size_t)n_sigs * 4))) return st;
+    if ((st = upload(h, h->j_slen, sig_len, (size_t)n_sigs * 4))) return st;
+    if ((st = ensure(h, h->j_out, (size_t)n_calls * 4))) return st;
+    cp = (const int32_t*)h->j_cpos.p; cl = (const int32_t*)h->j_clen.p; sp = (const int32_t*)h->j_spos.p; sl = (const int32_t*)h->j_slen.p;
+    out = (uint32_t*)h->j_out.p;
+  }
+  vsv_launch_support_join(h->stream, cp, cl, n_calls, sp, sl, n_sigs, *p, out, (uint32_t*)h->j_err.p);
+  HIPCHK(h, hipGetLastError());
+  uint32_t e = 0;
+  if (!on_device) HIPCHK(h, hipMemcpyAsync(support, out, (size_t)n_calls * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(&e, h->j_err.p, 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (e & ERRB_UNSORTED) return fail(h, VSV_E_UNSORTED, "read signatures are not sorted by position");
+  return 0;
 }
 
 int vsv_last_scan_ms(vsv_handle* h, float* ms) {

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void cigar_scan_emit(RecView rv, const uint32_
     tbase = first;
     n_tab = min((uint32_t)K1_RMAX, r1 - first);
     bool mono = true;
-    for (uint32_t i = lane; i <= n_tab && !(ablate & 4); i += 64) {
+    for (uint32_t i = lane; i <= n_tab; i += 64) {
       const uint32_t v = off_lo[2 * (size_t)(first + i)] - cb0_lo;
       my_off[i] = v;
       if (i < n_tab) {
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256) void cigar_scan_emit(RecView rv, const uint32_
     wc = load_chunk(cb + 1280);
   }
   // every record start of the part goes through stage() once: an empty CIGAR must raise (H:63 IndexError)
-  while (!bad && tbase + n_tab < r1 && !(ablate & 4)) stage(tbase + n_tab);
+  while (!bad && tbase + n_tab < r1) stage(tbase + n_tab);
   release_left();
   if (lane == 0) part_count[part] = ord;
 }

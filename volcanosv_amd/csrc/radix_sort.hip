@@ -12,9 +12,12 @@
 
 namespace {
 
-constexpr int RS_ROUNDS = 16;
+// Tiles are RS_WAVES waves x ROUNDS rounds x 64 items. ROUNDS = 16 (4096 items) amortises the per-tile histogram
+// traffic on large inputs; ROUNDS = 4 (1024 items) spreads a ~100 k-row table over ~100 CUs instead of ~25, which is
+// what bounds the scatter on the signature tables of a read-shaped run (n ~ 1 % of the records).
 constexpr int RS_WAVES = 4;
-constexpr int RS_TILE = RS_WAVES * RS_ROUNDS * 64;  // 4096 items per tile
+constexpr int RS_ROUNDS_BIG = 16, RS_ROUNDS_SMALL = 4;
+template <int ROUNDS> constexpr uint32_t rs_tile() { return RS_WAVES * ROUNDS * 64; }
 
 template <int BITS>
 __device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid) {
@@ -28,20 +31,20 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid) {
   return m;
 }
 
-__device__ __forceinline__ uint32_t n_tiles_of(uint32_t n) { return (n + RS_TILE - 1) / RS_TILE; }
+template <int ROUNDS> __device__ __forceinline__ uint32_t n_tiles_of(uint32_t n) { return (n + rs_tile<ROUNDS>() - 1) / rs_tile<ROUNDS>(); }
 
 // hist[tile * BINS + d] = number of items of this tile with digit d
-template <int BITS>
+template <int BITS, int ROUNDS>
 __global__ __launch_bounds__(256) void rs_hist(const uint64_t* __restrict__ key, const uint32_t* __restrict__ d_n, int shift,
                                                uint32_t* __restrict__ hist, uint32_t* __restrict__ totals) {
   constexpr int BINS = 1 << BITS;
   __shared__ uint32_t cnt[BINS];
-  const uint32_t n = *d_n, ntiles = n_tiles_of(n);
+  const uint32_t n = *d_n, ntiles = n_tiles_of<ROUNDS>(n);
   for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     for (int d = threadIdx.x; d < BINS; d += 256) cnt[d] = 0;
     __syncthreads();
-    const uint32_t base = tile * RS_TILE;
-    for (int k = 0; k < RS_TILE / 256; ++k) {
+    const uint32_t base = tile * rs_tile<ROUNDS>();
+    for (int k = 0; k < (int)rs_tile<ROUNDS>() / 256; ++k) {
       const uint32_t i = base + k * 256 + threadIdx.x;
       if (i < n) atomicAdd(&cnt[(uint32_t)(key[i] >> shift) & (BINS - 1)], 1u);
     }
@@ -58,12 +61,12 @@ __global__ __launch_bounds__(256) void rs_hist(const uint64_t* __restrict__ key,
 // single-block exclusive scan of the [tile][digit] histogram in (digit, tile) order: thread t owns DPT digits, walks
 // the tiles (coalesced rows) for the per-digit totals, one block-wide scan over the BINS totals, second walk writes
 // the offsets.
-template <int BITS>
+template <int BITS, int ROUNDS>
 __global__ __launch_bounds__(1024) void rs_scan(uint32_t* __restrict__ hist, const uint32_t* __restrict__ d_n) {
   constexpr int BINS = 1 << BITS;
   constexpr int DPT = BINS >= 1024 ? BINS / 1024 : 1;
   __shared__ uint32_t sh[1024];
-  const uint32_t ntiles = n_tiles_of(*d_n);
+  const uint32_t ntiles = n_tiles_of<ROUNDS>(*d_n);
   const int t = threadIdx.x;
   const bool active = t * DPT < BINS;
   uint32_t tot[DPT];
@@ -107,12 +110,12 @@ __global__ __launch_bounds__(1024) void rs_scan(uint32_t* __restrict__ hist, con
 // exclusive scan of the totals (block-local: totals of the digits before the block + in-block scan), then one
 // coalesced sweep over the tiles per digit, 16 tiles in flight. BINS/256 blocks on as many CUs instead of one
 // block on one CU (the single-block scan was bandwidth-bound at ~20 us per pass).
-template <int BITS>
+template <int BITS, int ROUNDS>
 __global__ __launch_bounds__(256) void rs_scan_mb(uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals,
                                                   const uint32_t* __restrict__ d_n) {
   constexpr int BINS = 1 << BITS;
   __shared__ uint32_t sh[256];
-  const uint32_t ntiles = n_tiles_of(*d_n);
+  const uint32_t ntiles = n_tiles_of<ROUNDS>(*d_n);
   const int t = threadIdx.x;
   const int d = blockIdx.x * 256 + t;
   uint32_t before = 0;
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(256) void rs_scan_mb(uint32_t* __restrict__ hist, c
   }
 }
 
-template <int BITS>
+template <int BITS, int RS_ROUNDS>
 __global__ __launch_bounds__(256) void rs_scatter(const uint64_t* __restrict__ key, const uint32_t* __restrict__ val,
                                                   const uint32_t* __restrict__ d_n, int shift,
                                                   const uint32_t* __restrict__ hist, uint64_t* __restrict__ key_out,
@@ -153,7 +156,8 @@ __global__ __launch_bounds__(256) void rs_scatter(const uint64_t* __restrict__ k
   constexpr int BINS = 1 << BITS;
   __shared__ uint32_t wcnt[RS_WAVES][BINS];   // per-wave running digit counters, then (wave, digit) bases
   (void)totals;
-  const uint32_t n = *d_n, ntiles = n_tiles_of(n);
+  constexpr uint32_t RS_TILE = rs_tile<RS_ROUNDS>();
+  const uint32_t n = *d_n, ntiles = n_tiles_of<RS_ROUNDS>(n);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint64_t lt = (1ull << lane) - 1ull;
   for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -200,23 +204,20 @@ __global__ __launch_bounds__(256) void rs_scatter(const uint64_t* __restrict__ k
   }
 }
 
-template <int BITS>
-void one_pass(hipStream_t st, int grid, const uint64_t* kin, const uint32_t* vin, const uint32_t* d_n, int shift, uint32_t* hist,
+template <int BITS, int ROUNDS>
+void one_pass(hipStream_t st, int64_t max_n, const uint64_t* kin, const uint32_t* vin, const uint32_t* d_n, int shift, uint32_t* hist,
               uint64_t* kout, uint32_t* vout, uint32_t* totals) {
-  rs_hist<BITS><<<grid, 256, 0, st>>>(kin, d_n, shift, hist, totals);
-  if (totals) rs_scan_mb<BITS><<<(1 << BITS) / 256, 256, 0, st>>>(hist, totals, d_n);
-  else rs_scan<BITS><<<1, 1024, 0, st>>>(hist, d_n);
-  rs_scatter<BITS><<<grid, 256, 0, st>>>(kin, vin, d_n, shift, hist, kout, vout, totals);
+  const int64_t max_tiles = (max_n + rs_tile<ROUNDS>() - 1) / rs_tile<ROUNDS>();
+  const int grid = (int)(max_tiles < 1024 ? (max_tiles < 1 ? 1 : max_tiles) : 1024);
+  rs_hist<BITS, ROUNDS><<<grid, 256, 0, st>>>(kin, d_n, shift, hist, totals);
+  if (totals) rs_scan_mb<BITS, ROUNDS><<<(1 << BITS) / 256, 256, 0, st>>>(hist, totals, d_n);
+  else rs_scan<BITS, ROUNDS><<<1, 1024, 0, st>>>(hist, d_n);
+  rs_scatter<BITS, ROUNDS><<<grid, 256, 0, st>>>(kin, vin, d_n, shift, hist, kout, vout, totals);
 }
 
-}  // namespace
-
-// Digit widths are chosen per sort so that the pass count is minimal with digits of at most 11 bits
-// (e.g. 33 key bits -> 3 passes of 11; 26 bits -> 3 passes of 9).
-SortResult vsv_radix_sort_pairs(hipStream_t st, uint64_t* key, uint32_t* val, uint64_t* key_scratch, uint32_t* val_scratch,
-                                const uint32_t* d_n, int64_t max_n, int nbits, const SortWork& w) {
-  int64_t max_tiles = (max_n + RS_TILE - 1) / RS_TILE;
-  int grid = (int)(max_tiles < 1024 ? (max_tiles < 1 ? 1 : max_tiles) : 1024);
+template <int ROUNDS>
+SortResult sort_pairs(hipStream_t st, uint64_t* key, uint32_t* val, uint64_t* key_scratch, uint32_t* val_scratch,
+                      const uint32_t* d_n, int64_t max_n, int nbits, const SortWork& w) {
   uint64_t* kin = key; uint32_t* vin = val;
   uint64_t* kout = key_scratch; uint32_t* vout = val_scratch;
   if (nbits < 1) nbits = 1;
@@ -229,10 +230,10 @@ SortResult vsv_radix_sort_pairs(hipStream_t st, uint64_t* key, uint32_t* val, ui
     uint32_t* totals = nullptr;
     if (w.totals && *w.pass_cursor < w.max_passes) { totals = w.totals + (size_t)(*w.pass_cursor) * 2048; ++*w.pass_cursor; }
     switch (bits <= 8 ? 8 : bits) {
-      case 8: one_pass<8>(st, grid, kin, vin, d_n, shift, w.hist, kout, vout, totals); shift += 8; break;
-      case 9: one_pass<9>(st, grid, kin, vin, d_n, shift, w.hist, kout, vout, totals); shift += 9; break;
-      case 10: one_pass<10>(st, grid, kin, vin, d_n, shift, w.hist, kout, vout, totals); shift += 10; break;
-      default: one_pass<11>(st, grid, kin, vin, d_n, shift, w.hist, kout, vout, totals); shift += 11; break;
+      case 8: one_pass<8, ROUNDS>(st, max_n, kin, vin, d_n, shift, w.hist, kout, vout, totals); shift += 8; break;
+      case 9: one_pass<9, ROUNDS>(st, max_n, kin, vin, d_n, shift, w.hist, kout, vout, totals); shift += 9; break;
+      case 10: one_pass<10, ROUNDS>(st, max_n, kin, vin, d_n, shift, w.hist, kout, vout, totals); shift += 10; break;
+      default: one_pass<11, ROUNDS>(st, max_n, kin, vin, d_n, shift, w.hist, kout, vout, totals); shift += 11; break;
     }
     uint64_t* tk = kin; kin = kout; kout = tk;
     uint32_t* tv = vin; vin = vout; vout = tv;
@@ -240,4 +241,14 @@ SortResult vsv_radix_sort_pairs(hipStream_t st, uint64_t* key, uint32_t* val, ui
   return SortResult{kin, vin};   // the sorted pairs live in (key,val) or in the scratch pair, no copy back
 }
 
-int64_t vsv_radix_hist_entries(int64_t max_n) { return 2048 * ((max_n + RS_TILE - 1) / RS_TILE); }
+}  // namespace
+
+// Digit widths are chosen per sort so that the pass count is minimal with digits of at most 11 bits
+// (e.g. 33 key bits -> 3 passes of 11; 26 bits -> 3 passes of 9). SortWork::small picks the tile size (both exact).
+SortResult vsv_radix_sort_pairs(hipStream_t st, uint64_t* key, uint32_t* val, uint64_t* key_scratch, uint32_t* val_scratch,
+                                const uint32_t* d_n, int64_t max_n, int nbits, const SortWork& w) {
+  return w.fused ? sort_pairs<RS_ROUNDS_SMALL>(st, key, val, key_scratch, val_scratch, d_n, max_n, nbits, w)
+                 : sort_pairs<RS_ROUNDS_BIG>(st, key, val, key_scratch, val_scratch, d_n, max_n, nbits, w);
+}
+
+int64_t vsv_radix_hist_entries(int64_t max_n) { return 2048 * ((max_n + rs_tile<RS_ROUNDS_SMALL>() - 1) / rs_tile<RS_ROUNDS_SMALL>()); }

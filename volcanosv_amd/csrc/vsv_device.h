@@ -134,3 +134,7 @@ void vsv_launch_pair(hipStream_t st, const vsv_sig* merged, const uint64_t* merg
 void vsv_launch_bnd_segments(hipStream_t st, const vsv_segments& s, const vsv_bnd_params& p, vsv_bnd* cand, uint32_t cap, Counters* ctr);
 void vsv_launch_bnd_pair(hipStream_t st, const vsv_bnd* cand, const int32_t* contig_rank, int rank_bits, const vsv_bnd_params& p,
                          vsv_bnd* sorted, vsv_bnd* calls, Counters* ctr, const StageBufs& b, const SortWork& sw, int64_t cap);
+
+// support.hip: FP_filter_v1.eval_sig as a sorted window join (wave per call)
+void vsv_launch_support_join(hipStream_t st, const int32_t* call_pos, const int32_t* call_len, int64_t n_calls, const int32_t* sig_pos,
+                             const int32_t* sig_len, int64_t n_sigs, const vsv_support_params& p, uint32_t* support, uint32_t* err);

@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .abi import (BND_DTYPE, T_BND_CALLS, T_BND_CAND, BndParams, CALL_DTYPE, SIG_DTYPE, T_CALLS, T_CIGAR, T_CLUSTER1, T_MERGED, T_RAW, T_READS, T_SPLIT, DTYPE_BY_NAME,
+from .abi import (BND_DTYPE, T_BND_CALLS, T_BND_CAND, BndParams, SupportParams, CALL_DTYPE, SIG_DTYPE, T_CALLS, T_CIGAR, T_CLUSTER1, T_MERGED, T_RAW, T_READS, T_SPLIT, DTYPE_BY_NAME,
                   DTYPE_READS, DTYPE_SVIM, Params, Records, VsvError)
 
 _TABLE_IDS = {"raw": T_RAW, "cigar": T_CIGAR, "split": T_SPLIT, "cluster1": T_CLUSTER1, "merged": T_MERGED,
@@ -61,6 +61,12 @@ class Engine:
         if self.h:
             self.lib.vsv_destroy(self.h)
             self.h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
     def __del__(self):
         try:
@@ -140,6 +146,32 @@ class Engine:
                                                     len(rank), 0))
         self._check(self.lib.vsv_bnd_pair(self.h, C.byref(p)))
         return self.table("bnd_calls")
+
+    def support_params(self, **kw):
+        p = SupportParams()
+        self._check(self.lib.vsv_default_support_params(C.byref(p)))
+        for k, v in kw.items():
+            if v is not None:
+                setattr(p, k, v)
+        return p
+
+    def support_join(self, call_pos, call_len, sig_pos, sig_len, params=None):
+        """FP_filter_v1.eval_sig (Large_INDEL/FP_filter_v1.py:106-123) on the GPU: per-call read-signature support.
+        numpy int32 arrays in, numpy uint32 out; torch device tensors in, torch int32 tensor out."""
+        p = params or self.support_params()
+        if hasattr(call_pos, "data_ptr"):
+            import torch
+            ts = [t.contiguous().to(torch.int32) for t in (call_pos, call_len, sig_pos, sig_len)]
+            out = torch.empty(len(ts[0]), dtype=torch.int32, device=ts[0].device)
+            self._check(self.lib.vsv_support_join(self.h, ts[0].data_ptr(), ts[1].data_ptr(), len(ts[0]), ts[2].data_ptr(), ts[3].data_ptr(),
+                                                  len(ts[2]), C.byref(p), 1, out.data_ptr()))
+            return out
+        a = [np.ascontiguousarray(x, dtype=np.int32) for x in (call_pos, call_len, sig_pos, sig_len)]
+        out = np.zeros(len(a[0]), dtype=np.uint32)
+        ptr = [x.ctypes.data_as(C.c_void_p) for x in a]
+        self._check(self.lib.vsv_support_join(self.h, ptr[0], ptr[1], len(a[0]), ptr[2], ptr[3], len(a[2]), C.byref(p), 0,
+                                              out.ctypes.data_as(C.c_void_p)))
+        return out
 
     def _bnd_params(self):
         p = BndParams()
