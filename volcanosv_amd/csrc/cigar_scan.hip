@@ -275,6 +275,12 @@ __global__ __launch_bounds__(256) void cigar_scan_emit(RecView rv, const uint32_
     }
   };
 
+  const uint32_t thr = (uint32_t)min_svlen;
+  const uint32_t thr16 = thr >= (1u << 28) ? 0xFFFFFFFFu : thr << 4;
+  constexpr uint32_t EMIT_R = rev32(EMIT_MASK | (EMIT_MASK << 16));   // bit-reversed, duplicated: sign(EMIT_R << (w & 31)) = bit op
+  constexpr uint32_t BAD_R = rev32(T::BAD | (T::BAD << 16));
+  uint32_t hd_rec = 0xFFFFFFFFu, hd_fl = 0, hd_mq = 0, hd_tid = 0, hd_first = 0, hd_pos = 0;   // cached record header
+
   // ---- slow path: the chunk holds at least one candidate op (wave-uniform) ------------------------------
   auto slow = [&](const uint4& wcur, const uint32_t cb) {
     const uint32_t x = cb + 4u * (uint32_t)lane;  // rel index of this lane's first op
@@ -286,78 +292,77 @@ __global__ __launch_bounds__(256) void cigar_scan_emit(RecView rv, const uint32_
     Dec d; decode(w, d);
     uint32_t em = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const uint32_t op = w[k] & 15u, len = w[k] >> 4;
-      const uint32_t e = (bfe_mask(EMIT_MASK, op) & (uint32_t)-(int)(len >= (uint32_t)min_svlen)) |
-                         (bfe_mask(T::BAD, op) & (uint32_t)-(int)(len != 0));
-      em |= (e & 1u) << k;
+    for (int k = 0; k < 4; ++k) {   // exact emit predicate: len >= min_svlen <=> packed word >= min_svlen << 4
+      const bool e = ((int32_t)(EMIT_R << (w[k] & 31u)) < 0 && w[k] >= thr16) ||
+                     (T::BAD != 0 && (int32_t)(BAD_R << (w[k] & 31u)) < 0 && w[k] >= 16u);
+      em |= (e ? 1u : 0u) << k;
     }
+    // per-lane exclusive prefixes in front of each of the lane's four ops
+    uint32_t pr[4], pq[4];
+    pr[0] = d.excl_r; pq[0] = d.excl_q;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) { pr[k] = pr[k - 1] + d.ar[k - 1]; pq[k] = pq[k - 1] + d.aq[k - 1]; }
     // one scalar iteration per candidate op, in (lane, sub) = op order
     uint64_t anym = __ballot(em != 0);
     while (anym) {
       const uint32_t l = (uint32_t)__builtin_ctzll(anym);
       anym &= anym - 1;
-      const uint32_t eml = rdlane(em, l);
-      uint32_t px_r = rdlane(d.excl_r, l), px_q = rdlane(d.excl_q, l);  // in-chunk exclusive prefix at (l,0)
-      for (uint32_t sub = 0; sub < 4; ++sub) {
-        const uint32_t wsel = sub == 0 ? w[0] : sub == 1 ? w[1] : sub == 2 ? w[2] : w[3];
-        const uint32_t wl = rdlane(wsel, l);
-        if (eml & (1u << sub)) {
-          const uint32_t xo = cb + 4u * l + sub;
-          const uint32_t op = wl & 15u, len = wl >> 4;
-          const uint32_t cnt = lookup(xo);
-          if (bad) return;
-          const uint32_t rec = tbase + wbase + cnt - 1u;
-          const uint32_t s_r = rdlane(s_rel, cnt - 1u);
-          uint32_t a_r, a_q;
-          if (s_r >= cb) {                 // record starts inside this chunk
-            uint32_t b_r, b_q;
-            prefix_at(d, cb, s_r, b_r, b_q);
-            a_r = px_r - b_r;
-            a_q = px_q - b_q;
-          } else {                         // record was open at the chunk start
-            base_for(rec, s_r, cb);
-            a_r = ck_r + px_r;
-            a_q = ck_q + px_q;
-          }
-          uint32_t wfl, wmq, tid_r, first, rpos_r;
-          sload5(align4(rv.flag + rec), align4(rv.mapq + rec), rv.tid + rec, rv.cigar + cb0 + s_r, rv.pos + rec, wfl, wmq, tid_r, first, rpos_r);
-          const uint32_t fl = byte_of(wfl, rv.flag + rec), mq = byte_of(wmq, rv.mapq + rec);
-          uint32_t hapbits;
-          if (CLS == 0) hapbits = (mq >= (uint32_t)min_mapq) ? ((fl >> 2) & 3u) : 0u;               // H:392-394
-          else if (CLS == 1) hapbits = (mq >= (uint32_t)min_mapq) ? 1u : 0u;                        // RS:120
-          else hapbits = (!(fl & (VSV_F_UNMAPPED | VSV_F_SECONDARY)) && mq >= (uint32_t)min_mapq) ? 1u : 0u;
-          if (hapbits) {
-            if (op != 1u && op != 2u) {  // N/=/X on the contig table: assert offset_ref==reference_end (H:396)
-              if (lane == 0) atomicOr(&ec.ctr->err, ERRB_REFEND);
-            } else {
-              const uint32_t hc = (T::HC && (first & 15u) == 5u) ? (first >> 4) : 0u;               // H:63-65
-              const uint32_t nemit = (hapbits == 3u) ? 2u : 1u;
-              const uint32_t slot = alloc(nemit);
-              if (lane < (int)nemit) {
-                if (slot + (uint32_t)lane < ec.shard_cap) {
-                  vsv_sig s;
-                  s.pos = (int32_t)(rpos_r + a_r);
-                  s.svlen = (int32_t)len;
-                  s.q_start = (int32_t)(a_q + hc);
-                  s.q_end = (CLS == 1) ? 0 : s.q_start + (op == 2u ? 1 : (int32_t)len);
-                  s.rec = rec;
-                  s.rec2 = 0xFFFFFFFFu;
-                  const uint32_t hp2 = (CLS == 0) ? ((hapbits == 3u) ? (uint32_t)lane : (hapbits >> 1)) : 0u;
-                  s.meta = (op == 2u ? VSV_M_DEL : 0u) | (hp2 ? VSV_M_HP2 : 0u);
-                  s.tid = (int32_t)tid_r;
-                  ec.pool[shard_off + slot + lane] = s;
-                  ec.pool_key[shard_off + slot + lane] = ((uint64_t)(uint32_t)part << 32) | (uint64_t)(ord + (uint32_t)lane);
-                }
-              }
-              ord += nemit;
-            }
-          }
+      uint32_t eml = rdlane(em, l);
+      while (eml) {
+        const uint32_t sub = (uint32_t)__builtin_ctz(eml);
+        eml &= eml - 1;
+        const uint32_t wl = rdlane(sub == 0 ? w[0] : sub == 1 ? w[1] : sub == 2 ? w[2] : w[3], l);
+        const uint32_t px_r = rdlane(sub == 0 ? pr[0] : sub == 1 ? pr[1] : sub == 2 ? pr[2] : pr[3], l);
+        const uint32_t px_q = rdlane(sub == 0 ? pq[0] : sub == 1 ? pq[1] : sub == 2 ? pq[2] : pq[3], l);
+        const uint32_t xo = cb + 4u * l + sub;
+        const uint32_t op = wl & 15u, len = wl >> 4;
+        const uint32_t cnt = lookup(xo);
+        if (bad) return;
+        const uint32_t rec = tbase + wbase + cnt - 1u;
+        const uint32_t s_r = rdlane(s_rel, cnt - 1u);
+        uint32_t a_r, a_q;
+        if (s_r >= cb) {                 // record starts inside this chunk
+          uint32_t b_r, b_q;
+          prefix_at(d, cb, s_r, b_r, b_q);
+          a_r = px_r - b_r;
+          a_q = px_q - b_q;
+        } else {                         // record was open at the chunk start
+          base_for(rec, s_r, cb);
+          a_r = ck_r + px_r;
+          a_q = ck_q + px_q;
         }
-        const uint32_t arsel = sub == 0 ? d.ar[0] : sub == 1 ? d.ar[1] : sub == 2 ? d.ar[2] : d.ar[3];
-        const uint32_t aqsel = sub == 0 ? d.aq[0] : sub == 1 ? d.aq[1] : sub == 2 ? d.aq[2] : d.aq[3];
-        px_r += rdlane(arsel, l);
-        px_q += rdlane(aqsel, l);
+        if (rec != hd_rec) {             // header of the record (scalar cache); long records emit many times
+          sload5(align4(rv.flag + rec), align4(rv.mapq + rec), rv.tid + rec, rv.cigar + cb0 + s_r, rv.pos + rec, hd_fl, hd_mq, hd_tid, hd_first, hd_pos);
+          hd_rec = rec;
+        }
+        const uint32_t fl = byte_of(hd_fl, rv.flag + rec), mq = byte_of(hd_mq, rv.mapq + rec);
+        uint32_t hapbits;
+        if (CLS == 0) hapbits = (mq >= (uint32_t)min_mapq) ? ((fl >> 2) & 3u) : 0u;               // H:392-394
+        else if (CLS == 1) hapbits = (mq >= (uint32_t)min_mapq) ? 1u : 0u;                        // RS:120
+        else hapbits = (!(fl & (VSV_F_UNMAPPED | VSV_F_SECONDARY)) && mq >= (uint32_t)min_mapq) ? 1u : 0u;
+        if (!hapbits) continue;
+        if (op != 1u && op != 2u) {      // N/=/X on the contig table: assert offset_ref==reference_end (H:396)
+          if (lane == 0) atomicOr(&ec.ctr->err, ERRB_REFEND);
+          continue;
+        }
+        const uint32_t hc = (T::HC && (hd_first & 15u) == 5u) ? (hd_first >> 4) : 0u;             // H:63-65
+        const uint32_t nemit = (hapbits == 3u) ? 2u : 1u;
+        const uint32_t slot = alloc(nemit);
+        if (lane < (int)nemit && slot + (uint32_t)lane < ec.shard_cap) {
+          vsv_sig sg;
+          sg.pos = (int32_t)(hd_pos + a_r);
+          sg.svlen = (int32_t)len;
+          sg.q_start = (int32_t)(a_q + hc);
+          sg.q_end = (CLS == 1) ? 0 : sg.q_start + (op == 2u ? 1 : (int32_t)len);
+          sg.rec = rec;
+          sg.rec2 = 0xFFFFFFFFu;
+          const uint32_t hp2 = (CLS == 0) ? ((hapbits == 3u) ? (uint32_t)lane : (hapbits >> 1)) : 0u;
+          sg.meta = (op == 2u ? VSV_M_DEL : 0u) | (hp2 ? VSV_M_HP2 : 0u);
+          sg.tid = (int32_t)hd_tid;
+          ec.pool[shard_off + slot + lane] = sg;
+          ec.pool_key[shard_off + slot + lane] = ((uint64_t)(uint32_t)part << 32) | (uint64_t)(ord + (uint32_t)lane);
+        }
+        ord += nemit;
       }
     }
     // checkpoint for the record that is open at the end of this chunk (dense chunks then never walk)
@@ -377,10 +382,6 @@ __global__ __launch_bounds__(256) void cigar_scan_emit(RecView rv, const uint32_
 
   // ---- streaming path: per op one shift against the (bit-reversed, duplicated) op mask, a sign test and a compare
   // of the packed word against min_svlen<<4. The test is a superset of the emit predicate; `slow` is exact.
-  const uint32_t thr = (uint32_t)min_svlen;
-  const uint32_t thr16 = thr >= (1u << 28) ? 0xFFFFFFFFu : thr << 4;
-  constexpr uint32_t EMIT_R = rev32(EMIT_MASK | (EMIT_MASK << 16));
-  constexpr uint32_t BAD_R = rev32(T::BAD | (T::BAD << 16));
   auto process_chunk = [&](const uint4& wcur, const uint32_t cb) {
     if (cb >= oe_rel || bad) return;             // ring slots past the end of the part
     bool cand = ((int32_t)(EMIT_R << (wcur.x & 31u)) < 0 && wcur.x >= thr16) |
