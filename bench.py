@@ -3,7 +3,10 @@
 
 One step = one pass of the whole hot path (vsv_run_chromosome: cigar_scan_emit -> fold -> split pairs ->
 sort/cluster x2 -> merge -> hap pairing) over one device-resident shard of BASELINE.json config 2
-(10 M HiFi-like records of one chromosome). With N GPUs every rank owns one such chromosome shard (weak scaling,
+(10 M HiFi-like records of one chromosome). Steps are independent batches, so a rank keeps `--streams` engines
+(one vsv_handle + HIP stream each, default 2) in flight round-robin: the latency-bound signature stages of one
+batch overlap the bandwidth-bound cigar_scan_emit of the next, exactly as a rank that owns several chromosomes
+runs them (volcanosv_amd/contig_signature.py). With N GPUs every rank owns one such chromosome shard (weak scaling,
 no data-path collective); the per-rank call tables are gathered to rank 0 once, inside the timed region.
 
 Prints ONE JSON line (see the task contract) with `roofline` for the dominant kernel (cigar_scan_emit, HBM-bound,
@@ -33,6 +36,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=10_000_000, help="records of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-reps", type=int, default=5, help="repetitions of the CPU baseline (best is reported)")
     ap.add_argument("--max-sigs", type=int, default=1 << 22)
+    ap.add_argument("--streams", type=int, default=2, help="engines (handle + HIP stream) in flight per rank")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one rank per GPU) | gloo (rehearsal: all ranks on cuda:0)")
     args = ap.parse_args()
 
@@ -69,25 +73,34 @@ def main():
     # synthetic shard generated directly in HBM (torch CUDA generator = Philox); tid = rank
     t, nq, _ = synth.generate(n_rec, args.shape, seed=20250328 + config_idx + 1000 * rank, tid=rank, chrom_len=chrom_len, device=dev)
     recs = DeviceRecords(t, nq, world, max_pos=chrom_len + 200000)   # the reference index carries the contig length
-    eng = Engine(local_rank, stream=torch.cuda.current_stream().cuda_stream, max_sigs=args.max_sigs)
+    n_streams = max(1, min(args.streams, max(1, args.steps)))
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(n_streams - 1)]
+    engs = [Engine(local_rank, stream=s.cuda_stream, max_sigs=args.max_sigs) for s in streams]
     p = default_params(dtype)
 
-    def step():
-        eng.run_async(recs, p)
+    def run_steps(k, scan_ms):
+        """k steps round-robin over the engines; a step's counters (status + table sizes) are read back, once, before
+        its engine is reused. Returns the engine that ran the last step."""
+        for i in range(k):
+            e = engs[i % n_streams]
+            if i >= n_streams:
+                e.finish()
+                scan_ms.append(e.scan_ms())
+            e.run_async(recs, p)
+        for i in range(max(0, k - n_streams), k):
+            e = engs[i % n_streams]
+            e.finish()
+            scan_ms.append(e.scan_ms())
+        return engs[(k - 1) % n_streams]
 
-    for _ in range(args.warmup):
-        step()
-        eng.finish()
+    run_steps(max(args.warmup, n_streams), [])
     torch.cuda.synchronize()
     scan_ms = []
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        eng.finish()          # one counter readback per step: status + table sizes
-        scan_ms.append(eng.scan_ms())
+    eng = run_steps(args.steps, scan_ms)
     if dtype == DTYPE_BY_NAME["READS"]:
         gathered = eng.table("reads")
     elif rehearsal:
@@ -160,14 +173,16 @@ def main():
             "data": "synthetic",
             "config": {"workload": "config2: %d %s-like records/GPU, 1 chromosome per GPU, dtype %s, %d CIGAR ops, %d raw signatures, %d calls gathered"
                                    % (recs.n_records, args.shape, dtype_name, recs.n_ops, n_raw, len(gathered) if gathered is not None else 0),
-                       "records_per_gpu": recs.n_records, "parallelism": "chromosome-sharded x%d" % world},
+                       "records_per_gpu": recs.n_records, "parallelism": "chromosome-sharded x%d" % world,
+                       "streams_per_gpu": n_streams},
             "roofline": {"bound": "hbm", "kernel": "cigar_scan_emit", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": scan_s * 1e3},
             "cpu_baseline": cpu,
         }
         print(json.dumps(line))
-    eng.close()
+    for e in engs:
+        e.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -116,6 +116,29 @@ def test_multi_tid(eng):
     assert set(np.unique(got["calls"]["sig"]["tid"])) == {0, 1, 2}
 
 
+def test_unaligned_device_views(eng):
+    """Device arrays that start in the middle of an allocation (a slice of a larger tensor): the split stage's wide loads
+    need 16-byte / 4-byte aligned qid / flag / mapq arrays and must take the element-wise path otherwise."""
+    import torch
+    from volcanosv_amd import synth
+    from volcanosv_amd.engine import DeviceRecords, default_params
+    t, nq, nt = synth.generate(60001, "hifi", seed=17, chrom_len=2000000, events_per_record=0.2, site_step=1000)
+    for skip in (1, 3):
+        host = {k: (v[skip:].clone() if k != "cigar" else v.clone()) for k, v in t.items()}
+        dev = {k: v.cuda() for k, v in t.items()}
+        view = {k: (v[skip:] if k != "cigar" else v) for k, v in dev.items()}       # pointers offset by `skip` elements
+        assert view["qid"].data_ptr() % 16 != 0 and view["flag"].data_ptr() % 4 != 0
+        p = default_params(DTYPE_HIFI)
+        eng.run(DeviceRecords(view, nq, nt), p)
+        got = eng.tables(DTYPE_HIFI)
+        st, want = oracle_run(synth.to_soa(host, nq), DTYPE_HIFI, p)
+        assert st == 0
+        assert_tables_equal(got, want, list(got.keys()))
+        assert len(got["split"]) > 0
+    del dev, view
+    torch.cuda.empty_cache()
+
+
 def test_staged_api_equals_fused(eng):
     from volcanosv_amd import synth
     from volcanosv_amd.engine import default_params

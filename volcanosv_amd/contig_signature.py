@@ -21,23 +21,51 @@ def run(dtype_name, bam_path, contig_path, ref_path, output_dir, chr_number=None
     else:
         header = vcf.default_header()
     chroms = [chr_number] if chr_number is not None else list(range(1, 23))
-    eng = engine or Engine(device)
+    # two engines (handle + HIP stream each) alternate over the chromosomes: the GPU works on chromosome i+1 while the host
+    # formats the VCF of chromosome i, and the latency-bound stages of one overlap the CIGAR scan of the other
+    engs = [engine] if engine is not None else [Engine(device), Engine(device, stream=_side_stream(device))]
     p = params or default_params(dtype)
     out = {}
-    with BamFile(bam_path) as bam:
-        for i in chroms:
-            name = "chr%d" % i
-            if bam.get_tid(name) < 0:
-                raise KeyError("%s not in the BAM header" % name)
-            soa = bam.fetch_soa(name)
-            soa.max_pos = bam.lengths[bam.get_tid(name)] + 100000   # sort-key hint: positions never exceed the contig
-            eng.run(soa, p)
-            calls, merged = eng.table("calls"), eng.table("merged")
-            ref_seq = dc_ref[name] if name in dc_ref else next(iter(dc_ref.values()))   # ONT/CLR: single-chromosome FASTA (O:653-662)
-            lines = vcf.vcf_lines(soa, calls, merged, ref_seq, dc_contig)
-            vcf.write_vcf(os.path.join(output_dir, "volcano_variant_chr%d.vcf" % i), header, lines)
-            log("%s: %d records -> %d calls (%d written)" % (name, soa.n_records, len(calls), len(lines)))
-            out[name] = lines
-    if engine is None:
-        eng.close()
+
+    def drain(job):
+        i, name, soa, eng = job
+        eng.finish()
+        calls, merged = eng.table("calls"), eng.table("merged")
+        ref_seq = dc_ref[name] if name in dc_ref else next(iter(dc_ref.values()))   # ONT/CLR: single-chromosome FASTA (O:653-662)
+        lines = vcf.vcf_lines(soa, calls, merged, ref_seq, dc_contig)
+        vcf.write_vcf(os.path.join(output_dir, "volcano_variant_chr%d.vcf" % i), header, lines)
+        log("%s: %d records -> %d calls (%d written)" % (name, soa.n_records, len(calls), len(lines)))
+        out[name] = lines
+
+    try:
+        with BamFile(bam_path) as bam:
+            pending = []
+            for k, i in enumerate(chroms):
+                name = "chr%d" % i
+                if bam.get_tid(name) < 0:
+                    raise KeyError("%s not in the BAM header" % name)
+                soa = bam.fetch_soa(name)
+                soa.max_pos = bam.lengths[bam.get_tid(name)] + 100000   # sort-key hint: positions never exceed the contig
+                eng = engs[k % len(engs)]
+                while len(pending) >= len(engs):
+                    drain(pending.pop(0))
+                eng.run_async(soa, p)
+                pending.append((i, name, soa, eng))
+            while pending:
+                drain(pending.pop(0))
+    finally:
+        if engine is None:
+            for e in engs:
+                e.close()
     return out
+
+
+def _side_stream(device):
+    """A second HIP stream on `device`, created through torch (kept alive for the life of the process)."""
+    import torch
+    s = torch.cuda.Stream(device=device)
+    _STREAMS.append(s)
+    return s.cuda_stream
+
+
+_STREAMS = []

@@ -124,7 +124,7 @@ __device__ __forceinline__ const void* align4(const void* p) { return (const voi
 constexpr int K1_RMAX = 320;   // record starts staged per wave (8192-op parts of ~33-op reads hold ~250)
 constexpr int K1_WAVES = 4;
 
-template <int CLS>
+template <int CLS, int DEPTH>
 __global__ __launch_bounds__(256) void cigar_scan_emit(RecView rv, const uint32_t* __restrict__ rb, int n_parts,
                                                         int min_svlen, int min_mapq, EmitCtx ec,
                                                         uint32_t* __restrict__ part_count, int ablate) {
@@ -160,7 +160,8 @@ __global__ __launch_bounds__(256) void cigar_scan_emit(RecView rv, const uint32_
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, 0, 0);
     return make_uint4(v.x, v.y, v.z, v.w);
   };
-  uint4 wa = load_chunk(0), wb = load_chunk(256), wc = load_chunk(512);
+  uint4 wa = load_chunk(0), wb = load_chunk(256), wc = load_chunk(512), wd = make_uint4(0, 0, 0, 0);
+  if (DEPTH == 4) wd = load_chunk(768);
 
   // Only the low dwords of cigar_off are read: relative offsets are < 2^30, so (lo - cb0_lo) mod 2^32 is exact.
   const uint32_t* __restrict__ off_lo = reinterpret_cast<const uint32_t*>(rv.cigar_off);
@@ -397,13 +398,26 @@ __global__ __launch_bounds__(256) void cigar_scan_emit(RecView rv, const uint32_
   };
 
   // three chunks in flight per wave; the ring is unrolled so no in-flight register is ever copied
-  for (uint32_t cb = 0; cb < oe_rel && !bad; cb += 768) {
-    process_chunk(wa, cb);
-    wa = load_chunk(cb + 768);
-    process_chunk(wb, cb + 256);
-    wb = load_chunk(cb + 1024);
-    process_chunk(wc, cb + 512);
-    wc = load_chunk(cb + 1280);
+  if (DEPTH == 4) {
+    for (uint32_t cb = 0; cb < oe_rel && !bad; cb += 1024) {
+      process_chunk(wa, cb);
+      wa = load_chunk(cb + 1024);
+      process_chunk(wb, cb + 256);
+      wb = load_chunk(cb + 1280);
+      process_chunk(wc, cb + 512);
+      wc = load_chunk(cb + 1536);
+      process_chunk(wd, cb + 768);
+      wd = load_chunk(cb + 1792);
+    }
+  } else {
+    for (uint32_t cb = 0; cb < oe_rel && !bad; cb += 768) {
+      process_chunk(wa, cb);
+      wa = load_chunk(cb + 768);
+      process_chunk(wb, cb + 256);
+      wb = load_chunk(cb + 1024);
+      process_chunk(wc, cb + 512);
+      wc = load_chunk(cb + 1280);
+    }
   }
   // every record start of the part goes through stage() once: an empty CIGAR must raise (H:63 IndexError)
   while (!bad && tbase + n_tab < r1) stage(tbase + n_tab);
@@ -515,12 +529,16 @@ void vsv_launch_cigar_scan(hipStream_t st, const RecView& rv, const vsv_params& 
   const int grid = (n_parts + waves_per_block - 1) / waves_per_block;
   if (ev0) (void)hipEventRecord(ev0, st);
   static const int ablate = getenv("VSV_K1_ABLATE") ? atoi(getenv("VSV_K1_ABLATE")) : 0;  // timing experiments only
-  if (p.dtype == VSV_DTYPE_READS)
-    cigar_scan_emit<1><<<grid, 256, 0, st>>>(rv, part_rb, n_parts, p.min_svlen, p.min_cigar_mapq, ec, part_count, ablate);
-  else if (p.dtype == VSV_DTYPE_SVIM)
-    cigar_scan_emit<2><<<grid, 256, 0, st>>>(rv, part_rb, n_parts, p.min_svlen, p.min_cigar_mapq, ec, part_count, ablate);
-  else
-    cigar_scan_emit<0><<<grid, 256, 0, st>>>(rv, part_rb, n_parts, p.min_svlen, p.min_cigar_mapq, ec, part_count, ablate);
+  static const int depth = getenv("VSV_K1_DEPTH") ? atoi(getenv("VSV_K1_DEPTH")) : 4;     // chunks in flight per wave (3 or 4)
+#define K1_LAUNCH(CLS)                                                                                                          \
+  do {                                                                                                                          \
+    if (depth == 4) cigar_scan_emit<CLS, 4><<<grid, 256, 0, st>>>(rv, part_rb, n_parts, p.min_svlen, p.min_cigar_mapq, ec, part_count, ablate); \
+    else cigar_scan_emit<CLS, 3><<<grid, 256, 0, st>>>(rv, part_rb, n_parts, p.min_svlen, p.min_cigar_mapq, ec, part_count, ablate);            \
+  } while (0)
+  if (p.dtype == VSV_DTYPE_READS) K1_LAUNCH(1);
+  else if (p.dtype == VSV_DTYPE_SVIM) K1_LAUNCH(2);
+  else K1_LAUNCH(0);
+#undef K1_LAUNCH
   if (ev1) (void)hipEventRecord(ev1, st);
   vsv_scan_u32_exclusive(st, part_count, n_parts, part_off, scan_tmp);
   place_raw<<<K1_SHARDS, 256, 0, st>>>(pool, pool_key, shard_cnt, cap / K1_SHARDS, part_off, part_count, n_parts, raw, cap, ctr);

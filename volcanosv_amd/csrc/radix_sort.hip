@@ -106,43 +106,62 @@ __global__ __launch_bounds__(1024) void rs_scan(uint32_t* __restrict__ hist, con
   }
 }
 
-// Multi-block scan (used whenever the hist kernel produced the digit totals): block b owns 256 digits; digit base =
-// exclusive scan of the totals (block-local: totals of the digits before the block + in-block scan), then one
-// coalesced sweep over the tiles per digit, 16 tiles in flight. BINS/256 blocks on as many CUs instead of one
-// block on one CU (the single-block scan was bandwidth-bound at ~20 us per pass).
+// Multi-block scan (used whenever the hist kernel produced the digit totals): a block owns SCAN_DG digits x SCAN_TG tile
+// groups (1024 threads). Digit base = exclusive scan of the totals (digits before the block + in-block scan); thread
+// (g, d) sums digit d over its tile group, the group sums are exchanged through LDS, and a second sweep over the same
+// (L2-hot) column entries writes the offsets. The sequential depth is ntiles / SCAN_TG loads in batches of 16; the
+// single-group version was the slowest kernel of a pass once the tiles became small (~100 tiles: 14 us -> see DESIGN).
+constexpr int SCAN_DG = 128, SCAN_TG = 8;
 template <int BITS, int ROUNDS>
-__global__ __launch_bounds__(256) void rs_scan_mb(uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals,
-                                                  const uint32_t* __restrict__ d_n) {
+__global__ __launch_bounds__(1024) void rs_scan_mb(uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals,
+                                                   const uint32_t* __restrict__ d_n) {
   constexpr int BINS = 1 << BITS;
-  __shared__ uint32_t sh[256];
+  __shared__ uint32_t red[1024];
+  __shared__ uint32_t dig[SCAN_DG];
+  __shared__ uint32_t part[SCAN_TG][SCAN_DG];
   const uint32_t ntiles = n_tiles_of<ROUNDS>(*d_n);
-  const int t = threadIdx.x;
-  const int d = blockIdx.x * 256 + t;
+  const int t = threadIdx.x, dl = t & (SCAN_DG - 1), g = t >> 7;
+  const int d0 = blockIdx.x * SCAN_DG, d = d0 + dl;
   uint32_t before = 0;
-  for (int i = t; i < (int)blockIdx.x * 256; i += 256) before += totals[i];
-  sh[t] = before;
+  for (int i = t; i < d0; i += 1024) before += totals[i];
+  red[t] = before;
   __syncthreads();
-  for (int k = 128; k > 0; k >>= 1) { if (t < k) sh[t] += sh[t + k]; __syncthreads(); }
-  const uint32_t prev = sh[0];
+  for (int k = 512; k > 0; k >>= 1) { if (t < k) red[t] += red[t + k]; __syncthreads(); }
+  const uint32_t prev = red[0];
+  const uint32_t mine = (t < SCAN_DG && d < BINS) ? totals[d] : 0;
+  if (t < SCAN_DG) dig[t] = mine;
   __syncthreads();
-  const uint32_t mine = d < BINS ? totals[d] : 0;
-  sh[t] = mine;
-  __syncthreads();
-  for (int k = 1; k < 256; k <<= 1) {
-    const uint32_t v = t >= k ? sh[t - k] : 0;
+  for (int k = 1; k < SCAN_DG; k <<= 1) {
+    const uint32_t v = (t < SCAN_DG && t >= k) ? dig[t - k] : 0;
     __syncthreads();
-    sh[t] += v;
+    if (t < SCAN_DG) dig[t] += v;
     __syncthreads();
   }
-  uint32_t run = prev + sh[t] - mine;
+  if (t < SCAN_DG) dig[t] = prev + dig[t] - mine;        // exclusive digit base
+  const uint32_t per = (ntiles + SCAN_TG - 1) / SCAN_TG;
+  const uint32_t t0 = (uint32_t)g * per, t1 = min(ntiles, t0 + per);
+  uint32_t sum = 0;
+  if (d < BINS) {
+    for (uint32_t tb = t0; tb < t1; tb += 16) {
+      uint32_t c[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) c[k] = (tb + k < t1) ? hist[(size_t)(tb + k) * BINS + d] : 0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) sum += c[k];
+    }
+  }
+  part[g][dl] = sum;
+  __syncthreads();
   if (d >= BINS) return;
-  for (uint32_t t0 = 0; t0 < ntiles; t0 += 16) {
+  uint32_t run = dig[dl];
+  for (int gg = 0; gg < g; ++gg) run += part[gg][dl];
+  for (uint32_t tb = t0; tb < t1; tb += 16) {
     uint32_t c[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) c[k] = (t0 + k < ntiles) ? hist[(size_t)(t0 + k) * BINS + d] : 0;
+    for (int k = 0; k < 16; ++k) c[k] = (tb + k < t1) ? hist[(size_t)(tb + k) * BINS + d] : 0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-      if (t0 + k < ntiles) hist[(size_t)(t0 + k) * BINS + d] = run;
+      if (tb + k < t1) hist[(size_t)(tb + k) * BINS + d] = run;
       run += c[k];
     }
   }
@@ -210,7 +229,7 @@ void one_pass(hipStream_t st, int64_t max_n, const uint64_t* kin, const uint32_t
   const int64_t max_tiles = (max_n + rs_tile<ROUNDS>() - 1) / rs_tile<ROUNDS>();
   const int grid = (int)(max_tiles < 1024 ? (max_tiles < 1 ? 1 : max_tiles) : 1024);
   rs_hist<BITS, ROUNDS><<<grid, 256, 0, st>>>(kin, d_n, shift, hist, totals);
-  if (totals) rs_scan_mb<BITS, ROUNDS><<<(1 << BITS) / 256, 256, 0, st>>>(hist, totals, d_n);
+  if (totals) rs_scan_mb<BITS, ROUNDS><<<(1 << BITS) / SCAN_DG, 1024, 0, st>>>(hist, totals, d_n);
   else rs_scan<BITS, ROUNDS><<<1, 1024, 0, st>>>(hist, d_n);
   rs_scatter<BITS, ROUNDS><<<grid, 256, 0, st>>>(kin, vin, d_n, shift, hist, kout, vout, totals);
 }

@@ -100,11 +100,6 @@ struct SplitCfg {
   int tid_shift;     // ckey = tid << tid_shift | hap << qid_bits | qid
 };
 
-__device__ __forceinline__ bool split_elig(const RecView& rv, const SplitCfg& c, uint32_t r, uint32_t hap) {
-  if (!c.contig) return hap == 0;
-  const uint32_t fl = rv.flag[r];
-  return (fl & (hap ? VSV_F_HP2 : VSV_F_HP1)) && rv.mapq[r] >= c.min_mapq;   // Hifi.py:425-427
-}
 // ---- names that occur more than once, without a counting table ---------------------------------------
 // A record whose qid is <= the running maximum of all earlier qids MAY be a repeated name; every true repeat is such a
 // record (its name appeared before, so the maximum is >= its qid). With qids dense in first-appearance order (the
@@ -112,16 +107,28 @@ __device__ __forceinline__ bool split_elig(const RecView& rv, const SplitCfg& c,
 // 1-bit-per-name table that stays L2-resident. Any other numbering only adds false candidates, which drop out later
 // because a candidate group needs two eligible members with equal (tid, hap, qid).
 constexpr int QM_TILE = 2048;   // 256 threads x 8 consecutive records
-__global__ __launch_bounds__(256) void qid_tile_max(const uint32_t* __restrict__ qid, int64_t n, uint32_t* __restrict__ tile_max) {
-  __shared__ uint32_t sh[256];
-  const int64_t base = (int64_t)blockIdx.x * QM_TILE + threadIdx.x * 8;
+// 8 consecutive qids (+1; 0 = no record) of a thread: two 16-byte loads when the array is 16-byte aligned
+__device__ __forceinline__ void load_qid8(const uint32_t* __restrict__ qid, int64_t base, int64_t n, bool vec, uint32_t (&q)[8]) {
+  if (vec && base + 8 <= n) {
+    const uint4 a = *reinterpret_cast<const uint4*>(qid + base), b = *reinterpret_cast<const uint4*>(qid + base + 4);
+    q[0] = a.x + 1u; q[1] = a.y + 1u; q[2] = a.z + 1u; q[3] = a.w + 1u; q[4] = b.x + 1u; q[5] = b.y + 1u; q[6] = b.z + 1u; q[7] = b.w + 1u;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) q[k] = (base + k < n) ? qid[base + k] + 1u : 0u;
+  }
+}
+__global__ __launch_bounds__(256) void qid_tile_max(const uint32_t* __restrict__ qid, int64_t n, uint32_t* __restrict__ tile_max, bool vec) {
+  __shared__ uint32_t sh[4];
+  uint32_t q[8];
+  load_qid8(qid, (int64_t)blockIdx.x * QM_TILE + threadIdx.x * 8, n, vec, q);
   uint32_t m = 0;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) if (base + k < n) m = max(m, qid[base + k] + 1u);   // +1: 0 means "no record"
-  sh[threadIdx.x] = m;
+  for (int k = 0; k < 8; ++k) m = max(m, q[k]);
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
   __syncthreads();
-  for (int d = 128; d > 0; d >>= 1) { if ((int)threadIdx.x < d) sh[threadIdx.x] = max(sh[threadIdx.x], sh[threadIdx.x + d]); __syncthreads(); }
-  if (threadIdx.x == 0) tile_max[blockIdx.x] = sh[0];
+  if (threadIdx.x == 0) tile_max[blockIdx.x] = max(max(sh[0], sh[1]), max(sh[2], sh[3]));
 }
 // single block: exclusive prefix maximum over the tiles, in place
 __global__ __launch_bounds__(1024) void qid_scan_max(uint32_t* __restrict__ tile_max, int ntiles) {
@@ -150,56 +157,77 @@ __global__ __launch_bounds__(1024) void qid_scan_max(uint32_t* __restrict__ tile
   }
 }
 __global__ __launch_bounds__(256) void qid_mark_dups(const uint32_t* __restrict__ qid, int64_t n, const uint32_t* __restrict__ tile_excl,
-                                                     uint32_t* __restrict__ dupbits) {
-  __shared__ uint32_t sh[256];
-  const int64_t base = (int64_t)blockIdx.x * QM_TILE + threadIdx.x * 8;
+                                                     uint32_t* __restrict__ dupbits, bool vec) {
+  __shared__ uint32_t sh[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   uint32_t q[8], m = 0;
+  load_qid8(qid, (int64_t)blockIdx.x * QM_TILE + threadIdx.x * 8, n, vec, q);
 #pragma unroll
-  for (int k = 0; k < 8; ++k) { q[k] = (base + k < n) ? qid[base + k] + 1u : 0u; m = max(m, q[k]); }
-  sh[threadIdx.x] = m;
+  for (int k = 0; k < 8; ++k) m = max(m, q[k]);
+  uint32_t incl = m;                       // inclusive prefix maximum over the wave
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl = max(incl, o); }
+  if (lane == 63) sh[wv] = incl;
+  uint32_t excl = (uint32_t)__shfl_up((int)incl, 1, 64);
+  if (lane == 0) excl = 0;
   __syncthreads();
-  for (int d = 1; d < 256; d <<= 1) {
-    const uint32_t t = (int)threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
-    __syncthreads();
-    sh[threadIdx.x] = max(sh[threadIdx.x], t);
-    __syncthreads();
-  }
-  uint32_t run = max(tile_excl[blockIdx.x], threadIdx.x > 0 ? sh[threadIdx.x - 1] : 0u);
+  uint32_t run = max(tile_excl[blockIdx.x], excl);
+  for (int w = 0; w < wv; ++w) run = max(run, sh[w]);
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     if (q[k] != 0 && q[k] <= run) atomicOr(&dupbits[(q[k] - 1u) >> 5], 1u << ((q[k] - 1u) & 31u));
     run = max(run, q[k]);
   }
 }
-__device__ __forceinline__ bool name_repeats(const RecView& rv, const uint32_t* __restrict__ dupbits, uint32_t r) {
-  const uint32_t q = rv.qid[r];
-  return (dupbits[q >> 5] >> (q & 31u)) & 1u;
-}
 
-// ordered compaction of candidate (record,hap) items, block tile = 256 threads x 8 rounds
-constexpr int SC_ROUNDS = 8;
-constexpr int SC_TILE = 256 * SC_ROUNDS;
+// ordered compaction of candidate (record, hap) items. A thread owns 4 consecutive records per round (flag / mapq as one
+// dword each, qid as one 16-byte load when the arrays are aligned), i.e. 8 items in (record, hap) order as an 8-bit mask.
+constexpr int SC_ROUNDS = 2;
+constexpr int SC_TILE_REC = 256 * 4 * SC_ROUNDS;    // records per block
 template <bool WRITE>
 __global__ __launch_bounds__(256) void split_cand(RecView rv, SplitCfg c, const uint32_t* __restrict__ tab,
                                                   uint32_t* __restrict__ blk, uint64_t* __restrict__ ckey,
-                                                  uint32_t* __restrict__ crec, uint32_t cap, Counters* ctr) {
+                                                  uint32_t* __restrict__ crec, uint32_t cap, bool vec) {
   __shared__ uint32_t cnt[SC_ROUNDS][4];
-  const uint64_t n2 = (uint64_t)rv.n_records * 2;
+  const uint64_t n = (uint64_t)rv.n_records;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const uint64_t base = (uint64_t)blockIdx.x * SC_TILE;
-  bool f[SC_ROUNDS];
-  uint32_t below[SC_ROUNDS];
+  uint32_t m[SC_ROUNDS], below[SC_ROUNDS], q[SC_ROUNDS][4];
 #pragma unroll
   for (int k = 0; k < SC_ROUNDS; ++k) {
-    const uint64_t it = base + (uint64_t)k * 256 + threadIdx.x;
-    f[k] = false;
-    if (it < n2) {
-      const uint32_t r = (uint32_t)(it >> 1), hap = (uint32_t)(it & 1);
-      f[k] = split_elig(rv, c, r, hap) && name_repeats(rv, tab, r);
+    const uint64_t r0 = (uint64_t)blockIdx.x * SC_TILE_REC + (uint64_t)k * 1024 + (uint64_t)threadIdx.x * 4;
+    m[k] = 0;
+    uint32_t fl4 = 0, mq4 = 0;
+    if (vec && r0 + 4 <= n) {
+      const uint4 qq = *reinterpret_cast<const uint4*>(rv.qid + r0);
+      q[k][0] = qq.x; q[k][1] = qq.y; q[k][2] = qq.z; q[k][3] = qq.w;
+      if (c.contig) { fl4 = *reinterpret_cast<const uint32_t*>(rv.flag + r0); mq4 = *reinterpret_cast<const uint32_t*>(rv.mapq + r0); }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        q[k][j] = 0;
+        if (r0 + j < n) {
+          q[k][j] = rv.qid[r0 + j];
+          if (c.contig) { fl4 |= (uint32_t)rv.flag[r0 + j] << (8 * j); mq4 |= (uint32_t)rv.mapq[r0 + j] << (8 * j); }
+        }
+      }
     }
-    const uint64_t bal = __ballot(f[k]);
-    below[k] = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-    if (lane == 0) cnt[k][wv] = (uint32_t)__popcll(bal);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (r0 + j >= n) continue;
+      uint32_t e;                                                     // bit 0: hap 0 item, bit 1: hap 1 item
+      if (!c.contig) e = 1u;
+      else {
+        const uint32_t fl = (fl4 >> (8 * j)) & 0xFFu, mq = (mq4 >> (8 * j)) & 0xFFu;
+        e = (mq >= (uint32_t)c.min_mapq) ? (((fl & VSV_F_HP1) ? 1u : 0u) | ((fl & VSV_F_HP2) ? 2u : 0u)) : 0u;   // Hifi.py:425-427
+      }
+      if (e && ((tab[q[k][j] >> 5] >> (q[k][j] & 31u)) & 1u)) m[k] |= e << (2 * j);
+    }
+    const uint32_t cc = (uint32_t)__popc(m[k]);
+    uint32_t incl = cc;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += o; }
+    below[k] = incl - cc;
+    if (lane == 63) cnt[k][wv] = incl;
   }
   __syncthreads();
   if (!WRITE) {
@@ -213,16 +241,20 @@ __global__ __launch_bounds__(256) void split_cand(RecView rv, SplitCfg c, const 
   uint32_t off = blk[blockIdx.x];  // exclusive block offset
 #pragma unroll
   for (int k = 0; k < SC_ROUNDS; ++k) {
-    uint32_t pre = 0;
-    for (int w = 0; w < wv; ++w) pre += cnt[k][w];
-    if (f[k]) {
-      const uint64_t it = base + (uint64_t)k * 256 + threadIdx.x;
-      const uint32_t r = (uint32_t)(it >> 1), hap = (uint32_t)(it & 1);
-      const uint32_t dst = off + pre + below[k];
+    uint32_t dst = off + below[k];
+    for (int w = 0; w < wv; ++w) dst += cnt[k][w];
+    const uint64_t r0 = (uint64_t)blockIdx.x * SC_TILE_REC + (uint64_t)k * 1024 + (uint64_t)threadIdx.x * 4;
+    uint32_t mm = m[k];
+    while (mm) {
+      const int it = __builtin_ctz(mm);
+      mm &= mm - 1;
+      const uint32_t j = (uint32_t)it >> 1, hap = (uint32_t)it & 1u;
       if (dst < cap) {
-        ckey[dst] = ((uint64_t)(uint32_t)rv.tid[r] << c.tid_shift) | ((uint64_t)hap << c.qid_bits) | rv.qid[r];
-        crec[dst] = r;
+        const uint32_t qj = j == 0 ? q[k][0] : j == 1 ? q[k][1] : j == 2 ? q[k][2] : q[k][3];
+        ckey[dst] = ((uint64_t)(uint32_t)rv.tid[r0 + j] << c.tid_shift) | ((uint64_t)hap << c.qid_bits) | qj;
+        crec[dst] = (uint32_t)(r0 + j);
       }
+      ++dst;
     }
     off += cnt[k][0] + cnt[k][1] + cnt[k][2] + cnt[k][3];
   }
@@ -666,13 +698,15 @@ void vsv_launch_split(hipStream_t st, const RecView& rv, const vsv_params& p, in
     const uint64_t nq = rv.n_qids > 0 ? (uint64_t)rv.n_qids : (uint64_t)tab_size * 32;
     (void)hipMemsetAsync(tab, 0, (size_t)((nq + 31) / 32 + 1) * sizeof(uint32_t), st);
     const int qtiles = (int)((rv.n_records + QM_TILE - 1) / QM_TILE);
-    qid_tile_max<<<qtiles, 256, 0, st>>>(rv.qid, rv.n_records, blk_cnt);
+    // wide loads need 16-byte (qid) / 4-byte (flag, mapq) aligned arrays; anything else takes the element-wise path
+    const bool vec = ((uintptr_t)rv.qid & 15u) == 0 && ((uintptr_t)rv.flag & 3u) == 0 && ((uintptr_t)rv.mapq & 3u) == 0;
+    qid_tile_max<<<qtiles, 256, 0, st>>>(rv.qid, rv.n_records, blk_cnt, vec);
     qid_scan_max<<<1, 1024, 0, st>>>(blk_cnt, qtiles);
-    qid_mark_dups<<<qtiles, 256, 0, st>>>(rv.qid, rv.n_records, blk_cnt, tab);
-    const int nblk = (int)(((uint64_t)rv.n_records * 2 + SC_TILE - 1) / SC_TILE);
-    split_cand<false><<<nblk, 256, 0, st>>>(rv, c, tab, blk_cnt, ckey, crec, cap, ctr);
+    qid_mark_dups<<<qtiles, 256, 0, st>>>(rv.qid, rv.n_records, blk_cnt, tab, vec);
+    const int nblk = (int)(((uint64_t)rv.n_records + SC_TILE_REC - 1) / SC_TILE_REC);
+    split_cand<false><<<nblk, 256, 0, st>>>(rv, c, tab, blk_cnt, ckey, crec, cap, vec);
     vsv_scan_u32_exclusive(st, blk_cnt, nblk, blk_off, scan_tmp);
-    split_cand<true><<<nblk, 256, 0, st>>>(rv, c, tab, blk_off, ckey, crec, cap, ctr);
+    split_cand<true><<<nblk, 256, 0, st>>>(rv, c, tab, blk_off, ckey, crec, cap, vec);
     split_set_ncand<<<1, 1, 0, st>>>(blk_off, blk_cnt, nblk, cap, ctr);
     // the first result may live in the shared scratch pair, so the second sort gets a scratch pair of its own
     const SortResult r1 = vsv_radix_sort_pairs(st, ckey, crec, sw.key_alt, sw.val_alt, &ctr->n_cand, cap, c.tid_shift + tid_bits, sw);
