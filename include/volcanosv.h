@@ -259,6 +259,22 @@ int vsv_support_join(vsv_handle* h, const int32_t* call_pos, const int32_t* call
                      const int32_t* sig_pos, const int32_t* sig_len, int64_t n_sigs,
                      const vsv_support_params* p, int on_device, uint32_t* support);
 
+/* Signature coverage of the calls: calculate_signature_support.py (Large_INDEL), the first step of the GT-correction filter
+ * chain (filter_GT_correction.py:134-137).
+ *  vsv_support_cov_ins  replaces calc_ins_call_cov (CS:81-125): cov[i] = sum of sig_len over the INS signatures with
+ *                       |sig_pos - call_pos[i]| <= flanking (the reference's weighted bins keyed by call position).
+ *  vsv_support_cov_del  replaces calc_del_call_cov (CS:138-280): cov[i] = sum of sig_svlen over the DISTINCT DEL signatures
+ *                       whose closed interval [sig_start, sig_end] meets [call_start[i]-flanking, call_end[i]+flanking]
+ *                       (the union of the reference's four boundary scans, de-duplicated as by its set()).
+ * Signatures must ascend by position / start (VSV_E_UNSORTED otherwise; the .sigs files are sorted, SE:637-638). The reference
+ * orders the call regions with an unstable argsort and mixes sorted and original call indices (CS:171, 213-241); the result
+ * here is the one it produces on a position-sorted VCF with ties kept in file order. */
+int vsv_support_cov_ins(vsv_handle* h, const int32_t* call_pos, int64_t n_calls, const int32_t* sig_pos, const int32_t* sig_len,
+                        int64_t n_sigs, int32_t flanking, int on_device, int64_t* cov);
+int vsv_support_cov_del(vsv_handle* h, const int32_t* call_start, const int32_t* call_end, int64_t n_calls,
+                        const int32_t* sig_start, const int32_t* sig_end, const int32_t* sig_svlen, int64_t n_sigs,
+                        int32_t flanking, int on_device, int64_t* cov);
+
 /* ---- host-side ingest: BAM/BGZF -> record SoA ----------------------------------------------------
  * Replaces pysam.AlignmentFile(bam).fetch(chr) (H:387-391, RS:108-113). Arrays returned through `out` are owned
  * by the vsv_bam object and stay valid until the next vsv_bam_load / vsv_bam_close. No index is used. */

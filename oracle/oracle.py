@@ -43,6 +43,8 @@ def lib():
                                  C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
         _LIB.orc_bnd_free.argtypes = [C.c_void_p, C.c_void_p]
         _LIB.orc_bnd_pair.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(BndParams), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        _LIB.orc_cov_ins.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
+        _LIB.orc_cov_del.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
         _LIB.orc_default_support_params.argtypes = [C.POINTER(SupportParams)]
         _LIB.orc_support.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(SupportParams), C.c_void_p]
     return _LIB
@@ -124,3 +126,27 @@ def run_support(call_pos, call_len, sig_pos, sig_len, params=None):
     st = lib().orc_support(a[0].ctypes.data_as(C.c_void_p), a[1].ctypes.data_as(C.c_void_p), len(a[0]), a[2].ctypes.data_as(C.c_void_p),
                            a[3].ctypes.data_as(C.c_void_p), len(a[2]), C.byref(p), out.ctypes.data_as(C.c_void_p))
     return st, out
+
+
+def _i32(x):
+    return np.ascontiguousarray(x, dtype=np.int32)
+
+
+def run_cov_ins(call_pos, sig_pos, sig_len, flanking=1000):
+    """calc_ins_call_cov on the host: int64 coverage per call."""
+    c, sp, sl = _i32(call_pos), _i32(sig_pos), _i32(sig_len)
+    out = np.zeros(len(c), dtype=np.int64)
+    st = lib().orc_cov_ins(c.ctypes.data_as(C.c_void_p), len(c), sp.ctypes.data_as(C.c_void_p), sl.ctypes.data_as(C.c_void_p), len(sp),
+                           int(flanking), out.ctypes.data_as(C.c_void_p))
+    return st, out
+
+
+def run_cov_del(call_start, call_end, sig_start, sig_end, sig_svlen, flanking=1000):
+    """calc_del_call_cov on the host: (status, int64 coverage per call, has-entry flags)."""
+    cs, ce, ss, se, sv = _i32(call_start), _i32(call_end), _i32(sig_start), _i32(sig_end), _i32(sig_svlen)
+    out = np.zeros(len(cs), dtype=np.int64)
+    has = np.zeros(len(cs), dtype=np.uint8)
+    st = lib().orc_cov_del(cs.ctypes.data_as(C.c_void_p), ce.ctypes.data_as(C.c_void_p), len(cs), ss.ctypes.data_as(C.c_void_p),
+                           se.ctypes.data_as(C.c_void_p), sv.ctypes.data_as(C.c_void_p), len(ss), int(flanking),
+                           out.ctypes.data_as(C.c_void_p), has.ctypes.data_as(C.c_void_p))
+    return st, out, has

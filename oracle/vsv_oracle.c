@@ -820,3 +820,84 @@ int orc_support(const int32_t* call_pos, const int32_t* call_len, int64_t n_call
   }
   return sorted ? 0 : VSV_E_UNSORTED;
 }
+
+/* ================================================================================================
+ * calculate_signature_support.py (Large_INDEL): signature coverage of the calls, restated with the reference's own
+ * loop structure (sorted unique positions, moving start index, four boundary scans + set()).
+ * Canonical call order: stable by start (the reference's np.argsort is unstable and it then mixes sorted and original
+ * call indices, CS:171, 213-241; on a position-sorted VCF without ties both coincide with this).
+ * ================================================================================================ */
+typedef struct { int64_t key; int64_t val; } orc_kv;
+static int orc_kv_cmp(const void* a, const void* b) {
+  const orc_kv *x = (const orc_kv*)a, *y = (const orc_kv*)b;
+  if (x->key != y->key) return x->key < y->key ? -1 : 1;
+  return x->val < y->val ? -1 : (x->val > y->val ? 1 : 0);
+}
+
+/* calc_ins_call_cov (CS:81-125): cov per call = its bin's weight */
+int orc_cov_ins(const int32_t* call_pos, int64_t n_calls, const int32_t* sig_pos, const int32_t* sig_len, int64_t n_sigs,
+                int32_t flanking, int64_t* cov) {
+  /* uniq_pos + weights_list (CS:85-90) */
+  orc_kv* sg = (orc_kv*)malloc(sizeof(orc_kv) * (size_t)(n_sigs + 1));
+  for (int64_t j = 0; j < n_sigs; ++j) { sg[j].key = sig_pos[j]; sg[j].val = sig_len[j]; }
+  qsort(sg, (size_t)n_sigs, sizeof(orc_kv), orc_kv_cmp);
+  int64_t nu = 0;
+  for (int64_t j = 0; j < n_sigs; ++j) {
+    if (nu && sg[nu - 1].key == sg[j].key) sg[nu - 1].val += sg[j].val; else sg[nu++] = sg[j];
+  }
+  /* sorted_call_pos + bins_list (CS:92-93) */
+  orc_kv* bins = (orc_kv*)malloc(sizeof(orc_kv) * (size_t)(n_calls + 1));
+  for (int64_t i = 0; i < n_calls; ++i) { bins[i].key = call_pos[i]; bins[i].val = 0; }
+  qsort(bins, (size_t)n_calls, sizeof(orc_kv), orc_kv_cmp);
+  int64_t nb = 0;
+  for (int64_t i = 0; i < n_calls; ++i) if (!nb || bins[nb - 1].key != bins[i].key) bins[nb++] = bins[i];
+  int64_t start_i = 0;
+  for (int64_t j = 0; j < nu; ++j) {                                             /* CS:96-111 */
+    const int64_t pos = sg[j].key, w = sg[j].val;
+    int64_t cnt = 0, real_i = 0;
+    for (int64_t i = start_i; i < nb; ++i) {
+      const int64_t lb = bins[i].key - flanking, rb = bins[i].key + flanking;
+      if (lb > pos) break;
+      if (pos <= rb) { if (++cnt == 1) real_i = i; bins[i].val += w; }
+    }
+    if (cnt) start_i = real_i;
+  }
+  for (int64_t i = 0; i < n_calls; ++i) {                                         /* dict lookup by call start (CS:340-344) */
+    int64_t lo = 0, hi = nb;
+    while (lo < hi) { const int64_t m = (lo + hi) >> 1; if (bins[m].key >= call_pos[i]) hi = m; else lo = m + 1; }
+    cov[i] = bins[lo].val;
+  }
+  free(sg); free(bins);
+  return 0;
+}
+
+/* calc_del_call_cov (CS:138-280). has_entry[i] = 1 when the call has a dc_svlen entry (at least one supporting signature). */
+int orc_cov_del(const int32_t* call_start, const int32_t* call_end, int64_t n_calls, const int32_t* sig_start, const int32_t* sig_end,
+                const int32_t* sig_svlen, int64_t n_sigs, int32_t flanking, int64_t* cov, uint8_t* has_entry) {
+  int sorted = 1;
+  for (int64_t j = 0; j + 1 < n_sigs; ++j) if (sig_start[j] > sig_start[j + 1]) sorted = 0;
+  /* (call, sig) pairs of the four scans, then set() per call */
+  int64_t cap = 1024, np = 0;
+  orc_kv* pr = (orc_kv*)malloc(sizeof(orc_kv) * (size_t)cap);
+#define ORC_PUSH(c, s) do { if (np == cap) { cap *= 2; pr = (orc_kv*)realloc(pr, sizeof(orc_kv) * (size_t)cap); } pr[np].key = (c); pr[np].val = (s); ++np; } while (0)
+  for (int64_t i = 0; i < n_calls; ++i) {
+    const int64_t lb = (int64_t)call_start[i] - flanking, rb = (int64_t)call_end[i] + flanking;   /* CS:154 */
+    for (int64_t j = 0; j < n_sigs; ++j) {
+      const int64_t s = sig_start[j], e = sig_end[j];
+      if (s >= lb && s <= rb) ORC_PUSH(i, j);          /* signature start inside the call region (CS:171-185) */
+      if (e >= lb && e <= rb) ORC_PUSH(i, j);          /* signature end inside the call region   (CS:188-200) */
+      if (lb >= s && lb <= e) ORC_PUSH(i, j);          /* region start inside the signature      (CS:204-220) */
+      if (rb >= s && rb <= e) ORC_PUSH(i, j);          /* region end inside the signature        (CS:222-241) */
+    }
+  }
+#undef ORC_PUSH
+  qsort(pr, (size_t)np, sizeof(orc_kv), orc_kv_cmp);
+  for (int64_t i = 0; i < n_calls; ++i) { cov[i] = 0; if (has_entry) has_entry[i] = 0; }
+  for (int64_t k = 0; k < np; ++k) {
+    if (k && pr[k].key == pr[k - 1].key && pr[k].val == pr[k - 1].val) continue;   /* list(set(...)) (CS:247) */
+    cov[pr[k].key] += sig_svlen[pr[k].val];                                        /* CS:250 */
+    if (has_entry) has_entry[pr[k].key] = 1;
+  }
+  free(pr);
+  return sorted ? 0 : VSV_E_UNSORTED;
+}

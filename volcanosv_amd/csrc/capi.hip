@@ -41,7 +41,7 @@ struct vsv_handle {
   DevBuf tab, blk_cnt, blk_off, ckey, crec, okey, oval;
   DevBuf key, idx, cl, key2, idx2, key_alt, val_alt, hist;
   DevBuf ctr, shard_cnt, totals;
-  DevBuf j_cpos, j_clen, j_spos, j_slen, j_out, j_err;   // support join (post-filter)
+  DevBuf j_cpos, j_clen, j_spos, j_slen, j_send, j_out, j_err;   // support join (post-filter)
   int pass_cursor = 0;
   const uint64_t* sorted_key = nullptr;   // sorted keys of the stage just sorted (cluster / pair read them)
   bool fused_sort = true;          // small-input sort mode, re-decided after every run from its row counts
@@ -361,7 +361,7 @@ void vsv_destroy(vsv_handle* h) {
                     &h->part_off, &h->scan_tmp, &h->pool, &h->pool_key, &h->raw0, &h->s1in, &h->s1s, &h->c1, &h->s2s, &h->c2,
                     &h->merged, &h->calls_tmp, &h->calls, &h->reads, &h->tab, &h->blk_cnt, &h->blk_off, &h->ckey, &h->crec,
                     &h->okey, &h->oval, &h->key, &h->idx, &h->cl, &h->key2, &h->idx2, &h->key_alt, &h->val_alt, &h->hist, &h->ctr, &h->shard_cnt, &h->totals, &h->g_off, &h->g_qs, &h->g_qe, &h->g_rid, &h->g_rs,
-                    &h->g_re, &h->g_rev, &h->g_hap, &h->g_len, &h->g_rank, &h->j_cpos, &h->j_clen, &h->j_spos, &h->j_slen, &h->j_out, &h->j_err};
+                    &h->g_re, &h->g_rev, &h->g_hap, &h->g_len, &h->g_rank, &h->j_cpos, &h->j_clen, &h->j_spos, &h->j_slen, &h->j_send, &h->j_out, &h->j_err};
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
   if (h->pinned) hipHostFree(h->pinned);
   if (h->ev0) hipEventDestroy(h->ev0);
@@ -564,6 +564,55 @@ int vsv_support_join(vsv_handle* h, const int32_t* call_pos, const int32_t* call
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (e & ERRB_UNSORTED) return fail(h, VSV_E_UNSORTED, "read signatures are not sorted by position");
   return 0;
+}
+
+// shared body of the two coverage entry points: up to three call/signature arrays each, int64 result
+static int cov_common(vsv_handle* h, const int32_t* const* call_arr, int n_call_arr, int64_t n_calls, const int32_t* const* sig_arr,
+                      int n_sig_arr, int64_t n_sigs, int32_t flanking, int on_device, int64_t* cov, bool is_del) {
+  if (!h) return VSV_E_INVALID;
+  if (n_calls < 0 || n_sigs < 0 || flanking < 0) return fail(h, VSV_E_INVALID, "negative count or flanking");
+  for (int k = 0; k < n_call_arr; ++k) if (n_calls > 0 && !call_arr[k]) return fail(h, VSV_E_INVALID, "call arrays are NULL");
+  for (int k = 0; k < n_sig_arr; ++k) if (n_sigs > 0 && !sig_arr[k]) return fail(h, VSV_E_INVALID, "signature arrays are NULL");
+  if (n_calls == 0) return 0;
+  if (!cov) return fail(h, VSV_E_INVALID, "cov is NULL");
+  HIPCHK(h, hipSetDevice(h->device));
+  int st;
+  if ((st = ensure(h, h->j_err, 256))) return st;
+  HIPCHK(h, hipMemsetAsync(h->j_err.p, 0, 8, h->stream));
+  const int32_t* c[2] = {call_arr[0], n_call_arr > 1 ? call_arr[1] : nullptr};
+  const int32_t* g[3] = {sig_arr[0], sig_arr[1], n_sig_arr > 2 ? sig_arr[2] : nullptr};
+  int64_t* out = cov;
+  if (!on_device) {
+    DevBuf* cb[2] = {&h->j_cpos, &h->j_clen};
+    DevBuf* sb[3] = {&h->j_spos, &h->j_slen, &h->j_send};
+    for (int k = 0; k < n_call_arr; ++k) { if ((st = upload(h, *cb[k], call_arr[k], (size_t)n_calls * 4))) return st; c[k] = (const int32_t*)cb[k]->p; }
+    for (int k = 0; k < n_sig_arr; ++k) { if ((st = upload(h, *sb[k], sig_arr[k], (size_t)n_sigs * 4))) return st; g[k] = (const int32_t*)sb[k]->p; }
+    if ((st = ensure(h, h->j_out, (size_t)n_calls * 8))) return st;
+    out = (int64_t*)h->j_out.p;
+  }
+  if (is_del) vsv_launch_cov_del(h->stream, c[0], c[1], n_calls, g[0], g[1], g[2], n_sigs, flanking, out, (uint32_t*)h->j_err.p);
+  else vsv_launch_cov_ins(h->stream, c[0], n_calls, g[0], g[1], n_sigs, flanking, out, (uint32_t*)h->j_err.p);
+  HIPCHK(h, hipGetLastError());
+  uint32_t e = 0;
+  if (!on_device) HIPCHK(h, hipMemcpyAsync(cov, out, (size_t)n_calls * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(&e, h->j_err.p, 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (e & ERRB_UNSORTED) return fail(h, VSV_E_UNSORTED, "signatures are not sorted by position");
+  return 0;
+}
+
+int vsv_support_cov_ins(vsv_handle* h, const int32_t* call_pos, int64_t n_calls, const int32_t* sig_pos, const int32_t* sig_len,
+                        int64_t n_sigs, int32_t flanking, int on_device, int64_t* cov) {
+  const int32_t* ca[1] = {call_pos};
+  const int32_t* sa[2] = {sig_pos, sig_len};
+  return cov_common(h, ca, 1, n_calls, sa, 2, n_sigs, flanking, on_device, cov, false);
+}
+
+int vsv_support_cov_del(vsv_handle* h, const int32_t* call_start, const int32_t* call_end, int64_t n_calls, const int32_t* sig_start,
+                        const int32_t* sig_end, const int32_t* sig_svlen, int64_t n_sigs, int32_t flanking, int on_device, int64_t* cov) {
+  const int32_t* ca[2] = {call_start, call_end};
+  const int32_t* sa[3] = {sig_start, sig_end, sig_svlen};
+  return cov_common(h, ca, 2, n_calls, sa, 3, n_sigs, flanking, on_device, cov, true);
 }
 
 int vsv_last_scan_ms(vsv_handle* h, float* ms) {

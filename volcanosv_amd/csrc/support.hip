@@ -50,7 +50,89 @@ __global__ __launch_bounds__(256) void support_join(const int32_t* __restrict__ 
   }
 }
 
+// ---- calculate_signature_support.py ----------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t wave_sum_i64(int64_t v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+// calc_ins_call_cov (CS:81-125): the reference adds the summed length of every distinct signature position to every call
+// bin [pos-flanking, pos+flanking] that contains it; per call that is the window sum below.
+__global__ __launch_bounds__(256) void cov_ins(const int32_t* __restrict__ cpos, int64_t nc, const int32_t* __restrict__ spos,
+                                               const int32_t* __restrict__ slen, int64_t ns, int32_t flanking,
+                                               int64_t* __restrict__ cov, uint32_t* __restrict__ err) {
+  const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (int64_t)gridDim.x * blockDim.x;
+  bool bad = false;
+  for (int64_t j = gtid; j + 1 < ns; j += gsz) bad |= spos[j] > spos[j + 1];
+  if (bad) atomicOr(err, ERRB_UNSORTED);
+  const int lane = threadIdx.x & 63;
+  for (int64_t i = gtid >> 6; i < nc; i += gsz >> 6) {
+    const int64_t pos = cpos[i];
+    const int64_t lo = lower_bound_pos(spos, ns, pos - (int64_t)flanking);        // lb > pos: break (CS:105-106)
+    const int64_t hi = lower_bound_pos(spos, ns, pos + (int64_t)flanking + 1);    // pos <= rb (CS:107)
+    int64_t sum = 0;
+    for (int64_t j = lo + lane; j < hi; j += 64) sum += (int64_t)slen[j];
+    sum = wave_sum_i64(sum);
+    if (lane == 0) cov[i] = sum;
+  }
+}
+
+__global__ __launch_bounds__(256) void cov_del_span(const int32_t* __restrict__ sstart, const int32_t* __restrict__ send, int64_t ns,
+                                                    uint32_t* __restrict__ err) {
+  const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (int64_t)gridDim.x * blockDim.x;
+  bool bad = false;
+  uint32_t span = 0;
+  for (int64_t j = gtid; j < ns; j += gsz) {
+    if (j + 1 < ns) bad |= sstart[j] > sstart[j + 1];
+    const int64_t d = (int64_t)send[j] - (int64_t)sstart[j];
+    span = max(span, (uint32_t)(d < 0 ? 0 : (d > 0x7FFFFFFF ? 0x7FFFFFFF : d)));
+  }
+  if (bad) atomicOr(&err[0], ERRB_UNSORTED);
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) span = max(span, (uint32_t)__shfl_xor((int)span, d, 64));
+  if ((threadIdx.x & 63) == 0 && span) atomicMax(&err[1], span);
+}
+
+// calc_del_call_cov (CS:138-280): signature j supports call region [lb, rb] when its start or its end lies inside the
+// region (CS:171-200) or when lb or rb lies inside [start, end] (CS:204-241) — i.e. the closed intervals meet — and is
+// counted once (set(), CS:247). Signatures ascend by start, so candidates are those with start in [lb - max_span, rb].
+__global__ __launch_bounds__(256) void cov_del(const int32_t* __restrict__ cstart, const int32_t* __restrict__ cend, int64_t nc,
+                                               const int32_t* __restrict__ sstart, const int32_t* __restrict__ send,
+                                               const int32_t* __restrict__ svlen, int64_t ns, int32_t flanking,
+                                               int64_t* __restrict__ cov, const uint32_t* __restrict__ err) {
+  const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (int64_t)gridDim.x * blockDim.x;
+  const int lane = threadIdx.x & 63;
+  const int64_t max_span = err[1];
+  for (int64_t i = gtid >> 6; i < nc; i += gsz >> 6) {
+    const int64_t lb = (int64_t)cstart[i] - flanking, rb = (int64_t)cend[i] + flanking;   // CS:154
+    const int64_t lo = lower_bound_pos(sstart, ns, lb - max_span);
+    const int64_t hi = lower_bound_pos(sstart, ns, rb + 1);
+    int64_t sum = 0;
+    for (int64_t j = lo + lane; j < hi; j += 64)
+      if ((int64_t)send[j] >= lb) sum += (int64_t)svlen[j];
+    sum = wave_sum_i64(sum);
+    if (lane == 0) cov[i] = sum;
+  }
+}
+
 }  // namespace
+
+static int cov_blocks(int64_t n_calls) {
+  int64_t blocks = (n_calls + 3) / 4;
+  return (int)(blocks > 8192 ? 8192 : (blocks < 1 ? 1 : blocks));
+}
+void vsv_launch_cov_ins(hipStream_t st, const int32_t* call_pos, int64_t n_calls, const int32_t* sig_pos, const int32_t* sig_len,
+                        int64_t n_sigs, int32_t flanking, int64_t* cov, uint32_t* err) {
+  if (n_calls <= 0) return;
+  cov_ins<<<cov_blocks(n_calls), 256, 0, st>>>(call_pos, n_calls, sig_pos, sig_len, n_sigs, flanking, cov, err);
+}
+void vsv_launch_cov_del(hipStream_t st, const int32_t* call_start, const int32_t* call_end, int64_t n_calls, const int32_t* sig_start,
+                        const int32_t* sig_end, const int32_t* sig_svlen, int64_t n_sigs, int32_t flanking, int64_t* cov, uint32_t* err) {
+  if (n_calls <= 0) return;
+  if (n_sigs > 0) cov_del_span<<<(int)((n_sigs + 255) / 256 > 2048 ? 2048 : (n_sigs + 255) / 256), 256, 0, st>>>(sig_start, sig_end, n_sigs, err);
+  cov_del<<<cov_blocks(n_calls), 256, 0, st>>>(call_start, call_end, n_calls, sig_start, sig_end, sig_svlen, n_sigs, flanking, cov, err);
+}
 
 void vsv_launch_support_join(hipStream_t st, const int32_t* call_pos, const int32_t* call_len, int64_t n_calls, const int32_t* sig_pos,
                              const int32_t* sig_len, int64_t n_sigs, const vsv_support_params& p, uint32_t* support, uint32_t* err) {

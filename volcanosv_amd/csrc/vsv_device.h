@@ -138,3 +138,8 @@ void vsv_launch_bnd_pair(hipStream_t st, const vsv_bnd* cand, const int32_t* con
 // support.hip: FP_filter_v1.eval_sig as a sorted window join (wave per call)
 void vsv_launch_support_join(hipStream_t st, const int32_t* call_pos, const int32_t* call_len, int64_t n_calls, const int32_t* sig_pos,
                              const int32_t* sig_len, int64_t n_sigs, const vsv_support_params& p, uint32_t* support, uint32_t* err);
+void vsv_launch_cov_ins(hipStream_t st, const int32_t* call_pos, int64_t n_calls, const int32_t* sig_pos, const int32_t* sig_len,
+                        int64_t n_sigs, int32_t flanking, int64_t* cov, uint32_t* err);
+void vsv_launch_cov_del(hipStream_t st, const int32_t* call_start, const int32_t* call_end, int64_t n_calls, const int32_t* sig_start,
+                        const int32_t* sig_end, const int32_t* sig_svlen, int64_t n_sigs, int32_t flanking, int64_t* cov,
+                        uint32_t* err /* [0] error bits, [1] max signature span (scratch, zeroed by the caller) */);

@@ -173,6 +173,45 @@ class Engine:
                                               out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def _int_arrays(self, arrays):
+        """(pointers, keep-alive list, on_device, torch device or None) for a tuple of int32 arrays (numpy or torch CUDA)."""
+        if hasattr(arrays[0], "data_ptr"):
+            import torch
+            ts = [t.contiguous().to(torch.int32) for t in arrays]
+            return [t.data_ptr() for t in ts], ts, 1, ts[0].device
+        a = [np.ascontiguousarray(x, dtype=np.int32) for x in arrays]
+        return [x.ctypes.data_as(C.c_void_p) for x in a], a, 0, None
+
+    def support_cov_ins(self, call_pos, sig_pos, sig_len, flanking=1000):
+        """calc_ins_call_cov (calculate_signature_support.py:81-125): int64 coverage per call; sig_pos ascending."""
+        (cp,), keep_c, dev_c, device = self._int_arrays((call_pos,))
+        (sp, sl), keep_s, dev_s, _ = self._int_arrays((sig_pos, sig_len))
+        assert dev_c == dev_s
+        n, m = len(keep_c[0]), len(keep_s[0])
+        if dev_c:
+            import torch
+            out = torch.empty(n, dtype=torch.int64, device=device)
+            self._check(self.lib.vsv_support_cov_ins(self.h, cp, n, sp, sl, m, int(flanking), 1, out.data_ptr()))
+            return out
+        out = np.zeros(n, dtype=np.int64)
+        self._check(self.lib.vsv_support_cov_ins(self.h, cp, n, sp, sl, m, int(flanking), 0, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def support_cov_del(self, call_start, call_end, sig_start, sig_end, sig_svlen, flanking=1000):
+        """calc_del_call_cov (calculate_signature_support.py:138-280): int64 coverage per call; sig_start ascending."""
+        (cs, ce), keep_c, dev_c, device = self._int_arrays((call_start, call_end))
+        (ss, se, sv), keep_s, dev_s, _ = self._int_arrays((sig_start, sig_end, sig_svlen))
+        assert dev_c == dev_s
+        n, m = len(keep_c[0]), len(keep_s[0])
+        if dev_c:
+            import torch
+            out = torch.empty(n, dtype=torch.int64, device=device)
+            self._check(self.lib.vsv_support_cov_del(self.h, cs, ce, n, ss, se, sv, m, int(flanking), 1, out.data_ptr()))
+            return out
+        out = np.zeros(n, dtype=np.int64)
+        self._check(self.lib.vsv_support_cov_del(self.h, cs, ce, n, ss, se, sv, m, int(flanking), 0, out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def _bnd_params(self):
         p = BndParams()
         self._check(self.lib.vsv_default_bnd_params(C.byref(p)))
