@@ -46,7 +46,9 @@ enum {
   VSV_DTYPE_ONT = 1,   /* O  */
   VSV_DTYPE_CLR = 2,   /* C  */
   VSV_DTYPE_READS = 3, /* RS: M-like ops {0,7,8}, N advances ref, no fold / cluster / pair          */
-  VSV_DTYPE_SVIM = 4   /* SV/SVIM_intra.py:8-30 op table (CIGAR stage only)                         */
+  VSV_DTYPE_SVIM = 4,  /* SV/SVIM_intra.py:8-30 op table (CIGAR stage only)                         */
+  VSV_DTYPE_CUTESV = 5 /* Large_INDEL/sig_extract.py parse_read (SE:438-493): M,D,=,X advance the reference, every op
+                        * but D the read offset; CIGAR stage + in-read merging (generate_combine_sigs, SE:373-435)   */
 };
 
 /* ---- record flag bits (u8 per record) ------------------------------------------------------ */
@@ -56,7 +58,8 @@ enum {
   VSV_F_HP1 = 4,       /* 'hp1' in qname (H:392)                                                  */
   VSV_F_HP2 = 8,       /* 'hp2' in qname                                                          */
   VSV_F_SECONDARY = 16,
-  VSV_F_UNMAPPED = 32
+  VSV_F_UNMAPPED = 32,
+  VSV_F_SKIP = 64      /* record excluded by the host adaptor (sig_extract: query_length < min_read_len, SE:439; BED) */
 };
 
 /* ---- caller-owned SoA of alignment records (BAM order: tid, pos ascending) ------------------ */
@@ -87,7 +90,9 @@ typedef struct vsv_params {
   int32_t pair_shift;       /* 200 (H:562,564)                                                    */
   int32_t pair_window;      /* 1000 (H:768 max_compare_dist)                                      */
   int32_t enable_split;     /* 1: run the split-alignment stage                                   */
-  int32_t reserved[7];
+  int32_t merge_ins_threshold; /* CUTESV only: 100 (SE -mi): INS signals of one read at most this far apart are merged */
+  int32_t merge_del_threshold; /* CUTESV only: 0   (SE -md)                                           */
+  int32_t reserved[5];
 } vsv_params;
 
 /* ---- signature row (32 bytes) ---------------------------------------------------------------

@@ -55,11 +55,13 @@ typedef struct orc_out {
  * (SV/SVIM_intra.py:13-29): {0,7,8} both, no hard-clip offset, H ignored.
  * ------------------------------------------------------------------------------------------------ */
 static inline int ref_adv(int dtype, int op) {
+  if (dtype == VSV_DTYPE_CUTESV) return op == 0 || op == 7 || op == 8 || op == 2;       /* SE:450-457, 463-464 */
   if (dtype == VSV_DTYPE_READS) return op == 0 || op == 7 || op == 8 || op == 2 || op == 3;
   if (dtype == VSV_DTYPE_SVIM) return op == 0 || op == 7 || op == 8 || op == 2;
   return op == 0 || op == 2;
 }
 static inline int qry_adv(int dtype, int op) {
+  if (dtype == VSV_DTYPE_CUTESV) return op != 2;                                        /* SE:460-461 shift_ins_read */
   if (dtype == VSV_DTYPE_READS || dtype == VSV_DTYPE_SVIM) return op == 0 || op == 7 || op == 8 || op == 1 || op == 4;
   return op == 0 || op == 1 || op == 4;
 }
@@ -106,7 +108,7 @@ static int walk_record(const vsv_records* r, int64_t i, const vsv_params* p, uin
   if (b <= a) return VSV_E_EMPTY_CIGAR;
   int dtype = p->dtype;
   int64_t off_ref = r->pos[i], off_q = 0, hc = 0;
-  if (dtype != VSV_DTYPE_SVIM && (r->cigar[a] & 15) == 5) hc = r->cigar[a] >> 4; /* H:63-65 */
+  if (dtype != VSV_DTYPE_SVIM && dtype != VSV_DTYPE_CUTESV && (r->cigar[a] & 15) == 5) hc = r->cigar[a] >> 4; /* H:63-65 */
   for (uint64_t k = a; k < b; ++k) {
     int op = r->cigar[k] & 15; int64_t len = r->cigar[k] >> 4;
     if (op == 2 || op == 1) {
@@ -115,7 +117,7 @@ static int walk_record(const vsv_records* r, int64_t i, const vsv_params* p, uin
         s.pos = (int32_t)off_ref; s.svlen = (int32_t)len; s.q_start = (int32_t)(off_q + hc);
         s.rec = (uint32_t)i; s.rec2 = 0xFFFFFFFFu; s.tid = r->tid[i];
         s.meta = (op == 2 ? VSV_M_DEL : 0);
-        if (dtype == VSV_DTYPE_READS) s.q_end = 0;            /* RS:72,76: 8-field sig, no q_end */
+        if (dtype == VSV_DTYPE_READS || dtype == VSV_DTYPE_CUTESV) s.q_end = 0;   /* RS:72,76: 8-field sig, no q_end */
         else s.q_end = s.q_start + (op == 2 ? 1 : (int32_t)len); /* H:80, H:84 */
         if (hapmask & 1) sv_push(out, &s);
         if (hapmask & 2) { s.meta |= VSV_M_HP2; sv_push(out, &s); }
@@ -125,7 +127,7 @@ static int walk_record(const vsv_records* r, int64_t i, const vsv_params* p, uin
     if (qry_adv(dtype, op)) off_q += len;
   }
   /* assert offset_ref==read.reference_end (H:396, RS:123) */
-  if (dtype != VSV_DTYPE_SVIM && off_ref != ref_end_pysam(r, i)) return VSV_E_REFEND;
+  if (dtype != VSV_DTYPE_SVIM && dtype != VSV_DTYPE_CUTESV && off_ref != ref_end_pysam(r, i)) return VSV_E_REFEND;
   return 0;
 }
 
@@ -445,6 +447,33 @@ static vsv_sig* sv_dup(const sigvec* s) {
   return v;
 }
 
+/* generate_combine_sigs (SE:373-435), per read and per type over the raw rows in CIGAR order. The merged signal lives in
+ * the row of its first piece: svlen = summed length, q_end = number of pieces, rec2 = raw index of the first piece. */
+static void combine_in_read(vsv_sig* s, int64_t n, int merge_ins, int merge_del) {
+  int64_t lo = 0;
+  while (lo < n) {
+    int64_t hi = lo + 1;
+    while (hi < n && s[hi].rec == s[lo].rec) hi++;
+    for (int type = 0; type < 2; ++type) {                     /* SE:476-477: INS list, then DEL list */
+      int64_t temp = -1, cmp = 0; int first_group = 1;
+      for (int64_t k = lo; k < hi; ++k) {
+        if (((s[k].meta & VSV_M_DEL) != 0) != (type == 1)) continue;
+        if (temp >= 0 && (int64_t)s[k].pos - cmp <= (type ? merge_del : merge_ins)) {   /* SE:395, 417 */
+          s[temp].svlen += s[k].svlen; s[temp].q_end += 1;                              /* SE:396, 418 */
+          cmp = type ? (int64_t)s[k].pos + s[k].svlen : (int64_t)s[k].pos;             /* SE:398, 419 */
+          s[k].meta |= VSV_M_DEAD;
+        } else {
+          /* new temp_sig: SE:392-393 / 414 for the first, SE:406-407 / 427-428 (append(i[0])) afterwards */
+          cmp = (type && first_group) ? (int64_t)s[k].pos + s[k].svlen : (int64_t)s[k].pos;
+          first_group = 0;
+          temp = k; s[k].q_end = 1; s[k].rec2 = (uint32_t)k;
+        }
+      }
+    }
+    lo = hi;
+  }
+}
+
 int orc_run(const vsv_records* r, const vsv_params* p, int literal, orc_out* o) {
   memset(o, 0, sizeof *o);
   int dtype = p->dtype;
@@ -465,6 +494,9 @@ int orc_run(const vsv_records* r, const vsv_params* p, int literal, orc_out* o) 
     } else if (dtype == VSV_DTYPE_READS) {
       if (r->mapq[i] < p->min_cigar_mapq) continue;            /* RS:120 */
       st = walk_record(r, i, p, 1, &raw);
+    } else if (dtype == VSV_DTYPE_CUTESV) {
+      if ((r->flag[i] & VSV_F_SKIP) || r->mapq[i] < p->min_cigar_mapq) continue;   /* SE:439, 446 */
+      st = walk_record(r, i, p, 1, &raw);
     } else {
       if ((r->flag[i] & (VSV_F_UNMAPPED | VSV_F_SECONDARY)) || r->mapq[i] < p->min_cigar_mapq) continue; /* SV/SVIM_COLLECT.py:67 */
       st = walk_record(r, i, p, 1, &raw);
@@ -482,6 +514,7 @@ int orc_run(const vsv_records* r, const vsv_params* p, int literal, orc_out* o) 
       lo = hi;
     }
   }
+  if (dtype == VSV_DTYPE_CUTESV) combine_in_read(raw.v, raw.n, p->merge_ins_threshold, p->merge_del_threshold);
   for (int64_t k = 0; k < raw.n; ++k) if (!(raw.v[k].meta & VSV_M_DEAD)) sv_push(&cig, &raw.v[k]);
   o->cigar = sv_dup(&cig); o->n_cigar = cig.n;
 
@@ -577,6 +610,9 @@ int orc_default_params(int dtype, vsv_params* p) {
   p->pair_shift = 200;
   p->pair_window = 1000;
   p->enable_split = dtype == VSV_DTYPE_SVIM ? 0 : 1;
+  if (dtype == VSV_DTYPE_CUTESV) {   /* SE:703-747 */
+    p->min_svlen = 10; p->min_cigar_mapq = 20; p->enable_split = 0; p->merge_ins_threshold = 100; p->merge_del_threshold = 0;
+  }
   return 0;
 }
 

@@ -11,10 +11,10 @@ ABI_VERSION = 1
 
 # dtype of the extractor (reference: extract_contig_signature_{Hifi,ONT,CLR}.py, extract_reads_signature.py,
 # svim_asm/SVIM_intra.py)
-DTYPE_HIFI, DTYPE_ONT, DTYPE_CLR, DTYPE_READS, DTYPE_SVIM = 0, 1, 2, 3, 4
-DTYPE_BY_NAME = {"Hifi": DTYPE_HIFI, "ONT": DTYPE_ONT, "CLR": DTYPE_CLR, "READS": DTYPE_READS, "SVIM": DTYPE_SVIM}
+DTYPE_HIFI, DTYPE_ONT, DTYPE_CLR, DTYPE_READS, DTYPE_SVIM, DTYPE_CUTESV = 0, 1, 2, 3, 4, 5
+DTYPE_BY_NAME = {"Hifi": DTYPE_HIFI, "ONT": DTYPE_ONT, "CLR": DTYPE_CLR, "READS": DTYPE_READS, "SVIM": DTYPE_SVIM, "CUTESV": DTYPE_CUTESV}
 
-F_REVERSE, F_SUPP, F_HP1, F_HP2, F_SECONDARY, F_UNMAPPED = 1, 2, 4, 8, 16, 32
+F_REVERSE, F_SUPP, F_HP1, F_HP2, F_SECONDARY, F_UNMAPPED, F_SKIP = 1, 2, 4, 8, 16, 32, 64
 M_DEL, M_SPLIT, M_HP2, M_DEAD = 1, 2, 4, 8
 
 T_RAW, T_CIGAR, T_SPLIT, T_CLUSTER1, T_MERGED, T_CALLS, T_READS = range(7)
@@ -46,7 +46,7 @@ class Params(C.Structure):
         ("dtype", C.c_int32), ("min_svlen", C.c_int32), ("min_cigar_mapq", C.c_int32),
         ("min_split_mapq", C.c_int32), ("max_split_svlen", C.c_int32), ("cluster_shift", C.c_int32),
         ("pair_shift", C.c_int32), ("pair_window", C.c_int32), ("enable_split", C.c_int32),
-        ("reserved", C.c_int32 * 7),
+        ("merge_ins_threshold", C.c_int32), ("merge_del_threshold", C.c_int32), ("reserved", C.c_int32 * 5),
     ]
 
 

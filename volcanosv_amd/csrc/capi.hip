@@ -200,7 +200,7 @@ int enq_scan(vsv_handle* h) {
                         (uint64_t*)h->pool_key.p, (uint32_t)h->cap_sigs, (uint32_t*)h->part_count.p, (uint32_t*)h->part_off.p,
                         (uint32_t*)h->scan_tmp.p, (vsv_sig*)h->s1in.p, dctr(h), (uint32_t*)h->shard_cnt.p, h->ev0, h->ev1);
   h->have_scan_ev = n_parts > 0;
-  vsv_launch_fold(st, (vsv_sig*)h->s1in.p, (vsv_sig*)h->raw0.p, h->rv, h->prm.dtype, dctr(h));
+  vsv_launch_fold(st, (vsv_sig*)h->s1in.p, (vsv_sig*)h->raw0.p, h->rv, h->prm, dctr(h));
   HIPCHK(h, hipGetLastError());
   h->stage_done = 1;
   return 0;
@@ -290,7 +290,7 @@ int finish(vsv_handle* h) {
 
 int start(vsv_handle* h, const vsv_records* recs, const vsv_params* p) {
   if (!h || !p) return VSV_E_INVALID;
-  if (p->dtype < 0 || p->dtype > VSV_DTYPE_SVIM) return fail(h, VSV_E_INVALID, "bad dtype");
+  if (p->dtype < 0 || p->dtype > VSV_DTYPE_CUTESV) return fail(h, VSV_E_INVALID, "bad dtype");
   HIPCHK(h, hipSetDevice(h->device));
   h->prm = *p;
   return bind_records(h, recs);
@@ -320,7 +320,7 @@ const char* vsv_status_string(int s) {
 }
 
 int vsv_default_params(int dtype, vsv_params* p) {
-  if (!p || dtype < 0 || dtype > VSV_DTYPE_SVIM) return VSV_E_INVALID;
+  if (!p || dtype < 0 || dtype > VSV_DTYPE_CUTESV) return VSV_E_INVALID;
   memset(p, 0, sizeof *p);
   p->dtype = dtype;
   p->min_svlen = dtype == VSV_DTYPE_SVIM ? 40 : 30;
@@ -331,6 +331,10 @@ int vsv_default_params(int dtype, vsv_params* p) {
   p->pair_shift = 200;
   p->pair_window = 1000;
   p->enable_split = dtype == VSV_DTYPE_SVIM ? 0 : 1;
+  if (dtype == VSV_DTYPE_CUTESV) {   // sig_extract.py defaults (SE:703-747): -sl 10, -q 20, -mi 100, -md 0; CIGAR stage only
+    p->min_svlen = 10; p->min_cigar_mapq = 20; p->enable_split = 0;
+    p->merge_ins_threshold = 100; p->merge_del_threshold = 0;
+  }
   return 0;
 }
 
@@ -429,7 +433,7 @@ int vsv_run_chromosome_async(vsv_handle* h, const vsv_records* recs, const vsv_p
   int st = start(h, recs, p);
   if (st) return st;
   if ((st = enq_scan(h))) return st;
-  if (p->dtype != VSV_DTYPE_SVIM) { if ((st = enq_split(h))) return st; }
+  if (p->dtype != VSV_DTYPE_SVIM && p->dtype != VSV_DTYPE_CUTESV) { if ((st = enq_split(h))) return st; }
   if (is_contig(p->dtype)) {
     if ((st = enq_stage1(h))) return st;
     if ((st = enq_merge(h))) return st;

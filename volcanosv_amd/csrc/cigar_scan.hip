@@ -35,6 +35,8 @@ template <int CLS> struct OpTab;
 template <> struct OpTab<0> { static constexpr uint32_t REF = 0x005, QRY = 0x013, BAD = 0x188; static constexpr bool HC = true; };
 template <> struct OpTab<1> { static constexpr uint32_t REF = 0x18D, QRY = 0x193, BAD = 0x000; static constexpr bool HC = true; };
 template <> struct OpTab<2> { static constexpr uint32_t REF = 0x185, QRY = 0x193, BAD = 0x000; static constexpr bool HC = false; };
+// sig_extract.py parse_read (SE:449-472): M,=,X,D advance shift_del / shift_ins; every op but D advances shift_ins_read.
+template <> struct OpTab<3> { static constexpr uint32_t REF = 0x185, QRY = 0x1FB, BAD = 0x000; static constexpr bool HC = false; };
 constexpr uint32_t EMIT_MASK = 0x006;  // I(1), D(2)
 
 constexpr uint32_t rev32(uint32_t v) {
@@ -340,6 +342,7 @@ __global__ __launch_bounds__(256) void cigar_scan_emit(RecView rv, const uint32_
         uint32_t hapbits;
         if (CLS == 0) hapbits = (mq >= (uint32_t)min_mapq) ? ((fl >> 2) & 3u) : 0u;               // H:392-394
         else if (CLS == 1) hapbits = (mq >= (uint32_t)min_mapq) ? 1u : 0u;                        // RS:120
+        else if (CLS == 3) hapbits = (!(fl & VSV_F_SKIP) && mq >= (uint32_t)min_mapq) ? 1u : 0u; // SE:439, 446
         else hapbits = (!(fl & (VSV_F_UNMAPPED | VSV_F_SECONDARY)) && mq >= (uint32_t)min_mapq) ? 1u : 0u;
         if (!hapbits) continue;
         if (op != 1u && op != 2u) {      // N/=/X on the contig table: assert offset_ref==reference_end (H:396)
@@ -354,7 +357,7 @@ __global__ __launch_bounds__(256) void cigar_scan_emit(RecView rv, const uint32_
           sg.pos = (int32_t)(hd_pos + a_r);
           sg.svlen = (int32_t)len;
           sg.q_start = (int32_t)(a_q + hc);
-          sg.q_end = (CLS == 1) ? 0 : sg.q_start + (op == 2u ? 1 : (int32_t)len);
+          sg.q_end = (CLS == 1 || CLS == 3) ? 0 : sg.q_start + (op == 2u ? 1 : (int32_t)len);
           sg.rec = rec;
           sg.rec2 = 0xFFFFFFFFu;
           const uint32_t hp2 = (CLS == 0) ? ((hapbits == 3u) ? (uint32_t)lane : (hapbits >> 1)) : 0u;
@@ -537,6 +540,7 @@ void vsv_launch_cigar_scan(hipStream_t st, const RecView& rv, const vsv_params& 
   } while (0)
   if (p.dtype == VSV_DTYPE_READS) K1_LAUNCH(1);
   else if (p.dtype == VSV_DTYPE_SVIM) K1_LAUNCH(2);
+  else if (p.dtype == VSV_DTYPE_CUTESV) K1_LAUNCH(3);
   else K1_LAUNCH(0);
 #undef K1_LAUNCH
   if (ev1) (void)hipEventRecord(ev1, st);

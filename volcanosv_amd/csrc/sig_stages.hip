@@ -68,6 +68,45 @@ __global__ __launch_bounds__(256) void fold_kernel(vsv_sig* __restrict__ s, cons
   }
 }
 
+// ---- sig_extract.py generate_combine_sigs (SE:373-435): signals of one read merged by distance ---------------------------
+// One thread per record's group of raw rows, in op order, INS and DEL independently. INS: a signal at most
+// merge_ins_threshold after the LAST merged signal's position joins the current one (lengths add; the host concatenates the
+// sequences of the q_end pieces starting at raw row rec2). DEL: the comparison value is pos+len of the last merged signal —
+// except that a group opened after a flush starts from its own pos (SE:427-428 appends i[0], not sum(i)); kept as is.
+__global__ __launch_bounds__(256) void combine_kernel(vsv_sig* __restrict__ s, const Counters* ctr, int merge_ins, int merge_del) {
+  const uint32_t n = ctr->n_raw;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint32_t rec = s[i].rec;
+    if (i > 0 && s[i - 1].rec == rec) continue;  // not a group head
+    int64_t ins_first = -1, del_first = -1, ins_last = 0, del_cmp = 0;
+    for (uint32_t k = i; k < n && s[k].rec == rec; ++k) {
+      const vsv_sig s2 = s[k];
+      if (s2.meta & VSV_M_DEL) {
+        if (del_first >= 0 && (int64_t)s2.pos - del_cmp <= (int64_t)merge_del) {     // SE:417-419
+          s[del_first].svlen += s2.svlen;
+          s[del_first].q_end += 1;
+          del_cmp = (int64_t)s2.pos + s2.svlen;
+          s[k].meta = s2.meta | VSV_M_DEAD;
+        } else {
+          del_cmp = del_first < 0 ? (int64_t)s2.pos + s2.svlen : (int64_t)s2.pos;    // SE:414 vs SE:427-428
+          del_first = k;
+          s[k].q_end = 1; s[k].rec2 = k;
+        }
+      } else {
+        if (ins_first >= 0 && (int64_t)s2.pos - ins_last <= (int64_t)merge_ins) {     // SE:395-398
+          s[ins_first].svlen += s2.svlen;
+          s[ins_first].q_end += 1;
+          ins_last = s2.pos;
+          s[k].meta = s2.meta | VSV_M_DEAD;
+        } else {
+          ins_first = k; ins_last = s2.pos;                                           // SE:393, 406-407
+          s[k].q_end = 1; s[k].rec2 = k;
+        }
+      }
+    }
+  }
+}
+
 // ---- CLR gate: one wave per (record, hap) group head; marks the group dead if the gate fails ---------
 __global__ __launch_bounds__(256) void clr_gate_kernel(vsv_sig* __restrict__ s, RecView rv, Counters* ctr) {
   const uint32_t n = ctr->n_raw;
@@ -674,11 +713,13 @@ constexpr int LONG_GRID = 2048;   // wave-per-run kernels: enough waves to fill 
 }  // namespace
 
 // ======================================= host-side launchers ==========================================
-void vsv_launch_fold(hipStream_t st, vsv_sig* raw, vsv_sig* raw_copy, const RecView& rv, int dtype, Counters* ctr) {
+void vsv_launch_fold(hipStream_t st, vsv_sig* raw, vsv_sig* raw_copy, const RecView& rv, const vsv_params& p, Counters* ctr) {
+  const int dtype = p.dtype;
   // the reference applies the CLR gate before extraction (CLR.py:425-427), so gated rows are not part of T_RAW
   if (dtype == VSV_DTYPE_CLR) clr_gate_kernel<<<EW_GRID, 256, 0, st>>>(raw, rv, ctr);
   copy_rows<vsv_sig><<<EW_GRID, 256, 0, st>>>(raw, &ctr->n_raw, raw_copy);
   if (dtype == VSV_DTYPE_HIFI || dtype == VSV_DTYPE_ONT || dtype == VSV_DTYPE_CLR) fold_kernel<<<EW_GRID, 256, 0, st>>>(raw, ctr);
+  if (dtype == VSV_DTYPE_CUTESV) combine_kernel<<<EW_GRID, 256, 0, st>>>(raw, ctr, p.merge_ins_threshold, p.merge_del_threshold);
 }
 
 static int bits_for(uint64_t n) { int b = 1; while ((1ull << b) < n && b < 63) ++b; return b; }

@@ -115,7 +115,7 @@ void vsv_launch_cigar_scan(hipStream_t st, const RecView& rv, const vsv_params& 
                            hipEvent_t ev0, hipEvent_t ev1);
 
 // sig_stages.hip
-void vsv_launch_fold(hipStream_t st, vsv_sig* raw, vsv_sig* raw_copy, const RecView& rv, int dtype, Counters* ctr);
+void vsv_launch_fold(hipStream_t st, vsv_sig* raw, vsv_sig* raw_copy, const RecView& rv, const vsv_params& p, Counters* ctr);
 void vsv_launch_split(hipStream_t st, const RecView& rv, const vsv_params& p, int n_tids, uint32_t* tab, uint32_t tab_size,
                       uint32_t* blk_cnt, uint32_t* blk_off, uint32_t* scan_tmp, uint64_t* ckey, uint32_t* crec,
                       uint64_t* okey, uint32_t* oval, uint64_t* key2, uint32_t* idx2, const SortWork& sw, vsv_sig* s1in,

@@ -10,7 +10,7 @@ import numpy as np
 
 from . import _lib
 from .abi import (BND_DTYPE, T_BND_CALLS, T_BND_CAND, BndParams, SupportParams, CALL_DTYPE, SIG_DTYPE, T_CALLS, T_CIGAR, T_CLUSTER1, T_MERGED, T_RAW, T_READS, T_SPLIT, DTYPE_BY_NAME,
-                  DTYPE_READS, DTYPE_SVIM, Params, Records, VsvError)
+                  DTYPE_CUTESV, DTYPE_READS, DTYPE_SVIM, Params, Records, VsvError)
 
 _TABLE_IDS = {"raw": T_RAW, "cigar": T_CIGAR, "split": T_SPLIT, "cluster1": T_CLUSTER1, "merged": T_MERGED,
               "calls": T_CALLS, "reads": T_READS, "bnd_cand": T_BND_CAND, "bnd_calls": T_BND_CALLS}
@@ -248,7 +248,7 @@ class Engine:
         return out[: int(n.value) * row]
 
     def tables(self, dtype):
-        if dtype == DTYPE_SVIM:
+        if dtype in (DTYPE_SVIM, DTYPE_CUTESV):
             names = ["raw", "cigar"]
         elif dtype == DTYPE_READS:
             names = ["raw", "cigar", "split", "reads"]
