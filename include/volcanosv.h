@@ -113,6 +113,7 @@ enum {
   VSV_M_DEL = 1,    /* bit0: 0 = INS, 1 = DEL                                                     */
   VSV_M_SPLIT = 2,  /* bit1: 0 = 'cigar', 1 = 'split-alignment'                                   */
   VSV_M_HP2 = 4,    /* bit2: 0 = hp1 pass, 1 = hp2 pass (always 0 for READS/SVIM)                 */
+  VSV_M_QREV = 16,  /* CUTESV split INS only: the sequence slice [q_start, q_end) is taken from the REVERSED read (SE:215) */
   VSV_M_DEAD = 8    /* internal: folded away by the intra-read merge                              */
 };
 
@@ -244,6 +245,17 @@ int vsv_bnd_pair(vsv_handle* h, const vsv_bnd_params* p);
 /* multi-GPU join: install candidate rows received from other ranks (collection order: hp1 rows, then hp2 rows)
  * as the input of vsv_bnd_pair. */
 int vsv_bnd_set_candidates(vsv_handle* h, const vsv_bnd* rows, int64_t n, const int32_t* contig_rank, int32_t n_tids, int on_device);
+
+/* ---- sig_extract.py split-read branch ------------------------------------------------------------------------------
+ * vsv_cutesv_split replaces analysis_split_read (SE:193-319), INS/DEL candidates only (the TRA candidates of analysis_bnd
+ * never reach INS.sigs / DEL.sigs, SE:637-638). Input: for every flag-0/16 read with an SA tag, the segment list
+ * organize_split_signal builds (SE:341-371): the primary [clip_left, query_length - clip_right, pos, reference_end] when its
+ * mapq passes, then one entry per SA alignment; read_len = read.query_length, read_rec = the record the rows refer to.
+ * Rows (table VSV_T_CUTESV_SPLIT, vsv_sig): pos, svlen, tid = chromosome of the second segment; INS rows carry the
+ * sequence slice [q_start, q_end) (Python slice semantics) and VSV_M_QREV when it indexes the reversed read. */
+enum { VSV_T_CUTESV_SPLIT = 10 };
+int vsv_cutesv_split(vsv_handle* h, const vsv_segments* segs, const int32_t* read_len, const uint32_t* read_rec,
+                     int32_t sv_size, int32_t max_size, int32_t max_split_parts);
 
 /* ---- post-filter: read-signature support of the calls (the step right of the path) -------------------
  * Replaces FP_filter_v1.eval_sig + compare_sigs (Large_INDEL/FP_filter_v1.py:87-123), run by Raw_variant_call.py:91-96

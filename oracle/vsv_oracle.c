@@ -937,3 +937,85 @@ int orc_cov_del(const int32_t* call_start, const int32_t* call_end, int64_t n_ca
   free(pr);
   return sorted ? 0 : VSV_E_UNSORTED;
 }
+
+/* ================================================================================================
+ * sig_extract.py analysis_split_read (SE:193-319), INS/DEL candidates (the TRA candidates of analysis_bnd are dropped by the
+ * `grep -w INS|DEL` of SE:637-638 and are not produced). Segments per read as organize_split_signal builds them.
+ * Rows in (read, emission) order; INS rows carry the sequence slice [q_start, q_end) and VSV_M_QREV when `query` is the
+ * reversed read at that point (SE:215, 254, 312 reverse it cumulatively).
+ * ================================================================================================ */
+typedef struct { int64_t qs, qe, rs, re; int32_t chr, rev; } orc_cseg;
+static orc_cseg orc_cflip(orc_cseg x, int64_t rl) { orc_cseg y = x; y.qs = rl - x.qe; y.qe = rl - x.qs; return y; }
+static void orc_cput(sigvec* out, int del, int64_t pos, int64_t len, int64_t s0, int64_t s1, int32_t chr, int qrev, uint32_t rec) {
+  vsv_sig s; memset(&s, 0, sizeof s);
+  s.pos = (int32_t)pos; s.svlen = (int32_t)len; s.q_start = (int32_t)s0; s.q_end = (int32_t)s1; s.rec = rec; s.rec2 = 0xFFFFFFFFu;
+  s.meta = (del ? VSV_M_DEL : 0) | VSV_M_SPLIT | (qrev ? VSV_M_QREV : 0); s.tid = chr;
+  sv_push(out, &s);
+}
+static void orc_pair_rule(orc_cseg e1, orc_cseg e2, const orc_cseg* e3, int64_t sv, int64_t mx, int qrev, uint32_t rec, sigvec* out) {
+  if (e1.re - e2.rs < sv) {                                                              /* SE:216 / 258 */
+    int64_t ins = e2.qs + e1.re - e2.rs - e1.qe;
+    if (ins >= sv)                                                                       /* SE:217 */
+      if (e2.rs - e1.re <= 100 && (ins <= mx || mx == -1))                               /* SE:218 */
+        if (!e3 || e3->rs >= e2.re) {                                                    /* SE:261 */
+          int64_t half = (e2.rs - e1.re) / 2;                                            /* int((..)/2) */
+          orc_cput(out, 0, (e2.rs + e1.re) / 2, ins, e1.qe + half, e2.qs - half, e2.chr, qrev, rec);
+        }
+    int64_t del = e2.rs - e2.qs + e1.qe - e1.re;
+    if (del >= sv)                                                                       /* SE:225 */
+      if (e2.qs - e1.qe <= 100 && (del <= mx || mx == -1))                               /* SE:226 */
+        if (!e3 || e3->rs >= e2.re) orc_cput(out, 1, e1.re, del, 0, 0, e2.chr, 0, rec);  /* SE:270 */
+  }
+}
+int orc_cutesv_split(const vsv_segments* sg, const int32_t* read_len, const uint32_t* read_rec, int32_t sv_size, int32_t max_size,
+                     int32_t max_parts, vsv_sig** rows_out, int64_t* n_rows) {
+  sigvec out = {0};
+  for (int64_t r = 0; r < sg->n_reads; ++r) {
+    int64_t a = (int64_t)sg->seg_off[r], n = (int64_t)sg->seg_off[r + 1] - a;
+    if (!(n <= max_parts || max_parts == -1)) continue;                                   /* SE:370 */
+    orc_cseg* S = (orc_cseg*)malloc(sizeof(orc_cseg) * (size_t)(n + 1));
+    for (int64_t k = 0; k < n; ++k) {                                                     /* sorted(key=x[0]), stable (SE:198) */
+      orc_cseg s = { sg->q_start[a + k], sg->q_end[a + k], sg->ref_start[a + k], sg->ref_end[a + k], sg->ref_id[a + k], sg->is_reverse[a + k] };
+      int64_t j = k;
+      while (j > 0 && S[j - 1].qs > s.qs) { S[j] = S[j - 1]; --j; }
+      S[j] = s;
+    }
+    int64_t rl = read_len[r], sv = sv_size, mx = max_size; uint32_t rec = read_rec[r];
+    int trigger = 0, qrev = 0;
+    if (n == 2) {
+      orc_cseg e1 = S[0], e2 = S[1];
+      if (e1.chr == e2.chr) {
+        if (e1.rev == e2.rev) {
+          if (e1.rev) { e1 = orc_cflip(S[1], rl); e2 = orc_cflip(S[0], rl); qrev ^= 1; }   /* SE:212-215 */
+          orc_pair_rule(e1, e2, NULL, sv, mx, qrev, rec, &out);
+        }
+      } else trigger = 1;                                                                 /* SE:237-239 */
+    } else {
+      for (int64_t k = 0; k + 2 < n; ++k) {                                               /* SE:243 */
+        orc_cseg e1 = S[k], e2 = S[k + 1], e3 = S[k + 2];
+        if (e1.chr == e2.chr) {
+          if (e2.chr == e3.chr) {
+            if (e1.rev == e3.rev && e1.rev == e2.rev) {                                   /* SE:251 */
+              if (e1.rev) { e1 = orc_cflip(S[k + 2], rl); e2 = orc_cflip(S[k + 1], rl); e3 = orc_cflip(S[k], rl); qrev ^= 1; }
+              orc_pair_rule(e1, e2, &e3, sv, mx, qrev, rec, &out);
+              if (n - 3 == k) orc_pair_rule(e2, e3, NULL, sv, mx, qrev, rec, &out);        /* SE:277-296 */
+            }
+          }
+        } else trigger = 1;                                                               /* SE:298-299 */
+      }
+      if (n >= 3 && trigger) {                                                            /* SE:305-319 */
+        orc_cseg f = S[0], l = S[n - 1];
+        if (f.chr == l.chr && f.rev == l.rev) {
+          orc_cseg e1 = f, e2 = l;
+          if (f.rev) { e1 = orc_cflip(l, rl); e2 = orc_cflip(f, rl); qrev ^= 1; }
+          int64_t dis_ref = e2.rs - e1.re, dis_read = e2.qs - e1.qe;
+          if (dis_ref < 100 && dis_read - dis_ref >= sv && (dis_read - dis_ref <= mx || mx == -1))
+            orc_cput(&out, 0, e2.rs < e1.re ? e2.rs : e1.re, dis_read - dis_ref, e1.qe + dis_ref / 2, e2.qs - dis_ref / 2, e2.chr, qrev, rec);
+        }
+      }
+    }
+    free(S);
+  }
+  *rows_out = sv_dup(&out); *n_rows = out.n; free(out.v);
+  return 0;
+}

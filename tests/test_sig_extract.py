@@ -100,3 +100,58 @@ def test_gpu_synthetic_reads_vs_oracle():
             assert st == 0 and len(want["raw"]) > 3000 and len(want["cigar"]) < len(want["raw"])
             for k in ("raw", "cigar"):
                 assert np.array_equal(got[k], want[k]), k
+
+
+# ---- split-read branch ----------------------------------------------------------------------------------------------
+def split_inputs(doc):
+    from volcanosv_amd import sig_extract
+    reads = doc["cases"]["split"]["reads"]
+    soa = build_soa(reads)
+    ids = {"chr1": 0}
+    names = ["chr1"]
+
+    def chrom_id(n):
+        if n not in ids:
+            ids[n] = len(names)
+            names.append(n)
+        return ids[n]
+
+    sreads = sig_extract.split_reads(soa, [r["flag"] for r in reads], [len(r["seq"]) for r in reads], [r["sa"] or "" for r in reads], chrom_id, 20)
+    return reads, soa, sig_extract.SplitSegments(sreads), names
+
+
+def split_expected(doc):
+    """INS/DEL candidates of the split fixture (its CIGARs are clip-match-clip, so all of them are split-derived); the float
+    positions (a+b)/2 are compared as the %d the script writes (SE:554)."""
+    exp = {}
+    for i, e in enumerate(doc["cases"]["split"]["expected"]):
+        c = [[int(x[0])] + x[1:] for x in e if (len(x) == 6 and x[4] == "INS") or (len(x) == 5 and x[3] == "DEL")]
+        if c:
+            exp[i] = c
+    return exp
+
+
+def test_oracle_split_branch_matches_reference(doc):
+    from oracle import oracle
+    from volcanosv_amd import sig_extract
+    reads, soa, seg, names = split_inputs(doc)
+    rows = oracle.run_cutesv_split(seg, seg.read_len, seg.read_rec, 30, 100000, 7)
+    got = sig_extract.split_candidates(soa, rows, lambda rec: reads[rec]["seq"], lambda t: names[t])
+    want = split_expected(doc)
+    assert got == want
+    assert sum(len(v) for v in want.values()) > 50 and any(len(c) == 6 for v in want.values() for c in v)
+
+
+@pytest.mark.gpu
+def test_gpu_split_branch_matches_reference_and_oracle(doc):
+    from oracle import oracle
+    from volcanosv_amd import sig_extract
+    from volcanosv_amd.engine import Engine
+    reads, soa, seg, names = split_inputs(doc)
+    with Engine(0) as eng:
+        for parts, size in ((7, 100000), (-1, -1), (3, 2000)):
+            rows = eng.cutesv_split(seg, seg.read_len, seg.read_rec, 30, size, parts)
+            assert np.array_equal(rows, oracle.run_cutesv_split(seg, seg.read_len, seg.read_rec, 30, size, parts))
+        rows = eng.cutesv_split(seg, seg.read_len, seg.read_rec, 30, 100000, 7)
+        got = sig_extract.split_candidates(soa, rows, lambda rec: reads[rec]["seq"], lambda t: names[t])
+        assert got == split_expected(doc)

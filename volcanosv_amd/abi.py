@@ -15,7 +15,7 @@ DTYPE_HIFI, DTYPE_ONT, DTYPE_CLR, DTYPE_READS, DTYPE_SVIM, DTYPE_CUTESV = 0, 1, 
 DTYPE_BY_NAME = {"Hifi": DTYPE_HIFI, "ONT": DTYPE_ONT, "CLR": DTYPE_CLR, "READS": DTYPE_READS, "SVIM": DTYPE_SVIM, "CUTESV": DTYPE_CUTESV}
 
 F_REVERSE, F_SUPP, F_HP1, F_HP2, F_SECONDARY, F_UNMAPPED, F_SKIP = 1, 2, 4, 8, 16, 32, 64
-M_DEL, M_SPLIT, M_HP2, M_DEAD = 1, 2, 4, 8
+M_DEL, M_SPLIT, M_HP2, M_DEAD, M_QREV = 1, 2, 4, 8, 16
 
 T_RAW, T_CIGAR, T_SPLIT, T_CLUSTER1, T_MERGED, T_CALLS, T_READS = range(7)
 
@@ -75,6 +75,7 @@ BND_DTYPE = np.dtype([("src_tid", "<i4"), ("src_pos", "<i4"), ("dst_tid", "<i4")
                       ("meta", "<u4"), ("pad", "<u4")])
 B_SRC_FWD, B_DST_FWD, B_HAP2, B_GT_SHIFT, B_DEAD = 1, 2, 4, 4, 64
 T_BND_CAND, T_BND_CALLS = 7, 8
+T_CUTESV_SPLIT = 10
 
 
 class VsvError(RuntimeError):

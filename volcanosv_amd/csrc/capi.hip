@@ -35,6 +35,7 @@ struct vsv_handle {
   DevBuf g_off, g_qs, g_qe, g_rid, g_rs, g_re, g_rev, g_hap, g_len, g_rank;   // segment uploads (BND branch)
   vsv_segments segs{};
   int bnd_stage = 0;
+  int64_t cutesv_rows = -1;   // rows of the last vsv_cutesv_split (c2 buffer)
   // workspace
   DevBuf part_rb, part_count, part_off, scan_tmp;
   DevBuf pool, pool_key, raw0, s1in, s1s, c1, s2s, c2, merged, calls_tmp, calls, reads;
@@ -195,6 +196,7 @@ bool is_contig(int dtype) { return dtype == VSV_DTYPE_HIFI || dtype == VSV_DTYPE
 int enq_scan(vsv_handle* h) {
   hipStream_t st = h->stream;
   { int rs = reset_run_state(h); if (rs) return rs; }
+  h->cutesv_rows = -1;   // the split-candidate table shares a buffer with the merge stage
   const int n_parts = vsv_cigar_parts(h->rv.n_ops, OPS_PER_PART);
   vsv_launch_cigar_scan(st, h->rv, h->prm, (uint32_t*)h->part_rb.p, n_parts, OPS_PER_PART, (vsv_sig*)h->pool.p,
                         (uint64_t*)h->pool_key.p, (uint32_t)h->cap_sigs, (uint32_t*)h->part_count.p, (uint32_t*)h->part_off.p,
@@ -497,6 +499,40 @@ int vsv_bnd_segments(vsv_handle* h, const vsv_segments* sg, const vsv_bnd_params
   return finish(h);
 }
 
+int vsv_cutesv_split(vsv_handle* h, const vsv_segments* sg, const int32_t* read_len, const uint32_t* read_rec, int32_t sv_size,
+                     int32_t max_size, int32_t max_split_parts) {
+  if (!h || !sg) return VSV_E_INVALID;
+  if (sg->n_reads < 0 || sg->n_segs < 0) return fail(h, VSV_E_INVALID, "bad segment counts");
+  if (sg->n_reads > 0 && (!read_len || !read_rec || !sg->seg_off)) return fail(h, VSV_E_INVALID, "read arrays are NULL");
+  HIPCHK(h, hipSetDevice(h->device));
+  const int64_t rows = 2 * sg->n_segs + sg->n_reads;
+  int st = reserve(h, 1, 1, rows > h->cap_sigs ? rows : (h->cap_sigs > 0 ? h->cap_sigs : (1 << 22)));
+  if (st) return st;
+  vsv_segments d = *sg;
+  const int32_t* rl = read_len; const uint32_t* rr = read_rec;
+  if (!sg->on_device) {
+    const size_t nr = (size_t)sg->n_reads, ns = (size_t)sg->n_segs;
+    if ((st = upload(h, h->g_off, sg->seg_off, (nr + 1) * 8))) return st;
+    if ((st = upload(h, h->g_qs, sg->q_start, ns * 4))) return st;
+    if ((st = upload(h, h->g_qe, sg->q_end, ns * 4))) return st;
+    if ((st = upload(h, h->g_rid, sg->ref_id, ns * 4))) return st;
+    if ((st = upload(h, h->g_rs, sg->ref_start, ns * 4))) return st;
+    if ((st = upload(h, h->g_re, sg->ref_end, ns * 4))) return st;
+    if ((st = upload(h, h->g_rev, sg->is_reverse, ns))) return st;
+    if ((st = upload(h, h->g_len, read_len, nr * 4))) return st;
+    if ((st = upload(h, h->g_rank, read_rec, nr * 4))) return st;
+    d.seg_off = (const uint64_t*)h->g_off.p; d.q_start = (const int32_t*)h->g_qs.p; d.q_end = (const int32_t*)h->g_qe.p;
+    d.ref_id = (const int32_t*)h->g_rid.p; d.ref_start = (const int32_t*)h->g_rs.p; d.ref_end = (const int32_t*)h->g_re.p;
+    d.is_reverse = (const uint8_t*)h->g_rev.p;
+    rl = (const int32_t*)h->g_len.p; rr = (const uint32_t*)h->g_rank.p;
+  }
+  { int rs = reset_run_state(h); if (rs) return rs; }
+  vsv_launch_cutesv_split(h->stream, d, rl, rr, sv_size, max_size, max_split_parts, (vsv_sig*)h->c2.p, (uint32_t)h->cap_sigs, dctr(h));
+  HIPCHK(h, hipGetLastError());
+  h->cutesv_rows = rows;
+  return finish(h);
+}
+
 int vsv_bnd_set_candidates(vsv_handle* h, const vsv_bnd* rows, int64_t n, const int32_t* contig_rank, int32_t n_tids, int on_device) {
   if (!h || n < 0 || n_tids <= 0 || !contig_rank || (n > 0 && !rows)) return VSV_E_INVALID;
   HIPCHK(h, hipSetDevice(h->device));
@@ -639,6 +675,7 @@ static int table_src(vsv_handle* h, int table, const void** src, int64_t* n_rows
     case VSV_T_CALLS: if (h->stage_done < 5) return VSV_E_INVALID; *src = h->calls.p; *n_rows = c.n_calls; *row = sizeof(vsv_call); *filter = false; return 0;
     case VSV_T_BND_CAND: if (h->bnd_stage < 1) return VSV_E_INVALID; *src = h->s1in.p; *n_rows = c.n_s1; return 0;
     case VSV_T_BND_CALLS: if (h->bnd_stage < 2) return VSV_E_INVALID; *src = h->c1.p; *n_rows = c.n_alive1; return 0;
+    case VSV_T_CUTESV_SPLIT: if (h->cutesv_rows < 0) return VSV_E_INVALID; *src = h->c2.p; *n_rows = h->cutesv_rows; return 0;
     case VSV_T_READS: if (h->stage_done < 2 || h->prm.dtype != VSV_DTYPE_READS) return VSV_E_INVALID; *src = h->reads.p; *n_rows = c.n_reads; *filter = false; return 0;
   }
   return VSV_E_INVALID;

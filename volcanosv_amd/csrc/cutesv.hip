@@ -1,0 +1,111 @@
+// cutesv.hip — split-read branch of Large_INDEL/sig_extract.py: analysis_split_read (SE:193-319), INS/DEL candidates.
+//
+// One lane per primary read with an SA tag: the read's segments (primary first, then the SA entries in tag order,
+// organize_split_signal SE:341-371) are ordered by read start with a stable insertion sort (sorted(), SE:198), then the
+// two-segment rule (SE:206-236) or the triple scan (SE:242-296) and the INS-in-translocation rule (SE:298-319) run exactly
+// as written; the TRA/BND candidates (analysis_bnd) are not produced — the collector keeps only `grep -w INS|DEL` lines
+// (SE:637-638). Latency-bound, a few dozen integers per read. Rows go to fixed per-read slots (2*seg_off[r] + r ...), so the
+// table order is (read, emission order) whatever the lane order.
+#include "vsv_device.h"
+
+namespace {
+
+struct CSeg { int64_t qs, qe, rs, re; int32_t chr; int32_t rev; };
+
+__device__ __forceinline__ CSeg cflip(const CSeg& x, int64_t rl) { CSeg y = x; y.qs = rl - x.qe; y.qe = rl - x.qs; return y; }   // SE:213-214
+
+struct CEmit {
+  vsv_sig* out; uint32_t base, n, cap_local; uint32_t rec;
+  __device__ void put(bool del, int64_t pos, int64_t len, int64_t s0, int64_t s1, int32_t chr, int qrev) {
+    if (n >= cap_local) return;
+    vsv_sig s;
+    s.pos = (int32_t)pos; s.svlen = (int32_t)len; s.q_start = (int32_t)s0; s.q_end = (int32_t)s1;
+    s.rec = rec; s.rec2 = 0xFFFFFFFFu;
+    s.meta = (del ? VSV_M_DEL : 0u) | VSV_M_SPLIT | (qrev ? VSV_M_QREV : 0u);
+    s.tid = chr;
+    out[base + n++] = s;
+  }
+};
+
+// the INS / DEL test between two consecutive segments (SE:216-235, 258-276, 281-296); e3 = the following segment of a
+// triple (its start must not precede e2's end, SE:261, 270) or nullptr
+__device__ void pair_rule(const CSeg& e1, const CSeg& e2, const CSeg* e3, int64_t sv, int64_t mx, int qrev, CEmit& em) {
+  if (e1.re - e2.rs >= sv) return;
+  const int64_t ins_len = e2.qs + e1.re - e2.rs - e1.qe;
+  if (ins_len >= sv && e2.rs - e1.re <= 100 && (ins_len <= mx || mx == -1) && (!e3 || e3->rs >= e2.re)) {
+    const int64_t half = (e2.rs - e1.re) / 2;                       // int(x / 2): truncation toward zero
+    em.put(false, (e2.rs + e1.re) / 2, ins_len, e1.qe + half, e2.qs - half, e2.chr, qrev);
+  }
+  const int64_t del_len = e2.rs - e2.qs + e1.qe - e1.re;
+  if (del_len >= sv && e2.qs - e1.qe <= 100 && (del_len <= mx || mx == -1) && (!e3 || e3->rs >= e2.re))
+    em.put(true, e1.re, del_len, 0, 0, e2.chr, 0);
+}
+
+constexpr int CS_MAX_SEG = 64;
+
+__global__ __launch_bounds__(64) void cutesv_split(vsv_segments sg, const int32_t* __restrict__ read_len, const uint32_t* __restrict__ read_rec,
+                                                   int sv_size, int max_size, int max_parts, vsv_sig* __restrict__ out, uint32_t cap,
+                                                   Counters* ctr) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= sg.n_reads) return;
+  const uint64_t a = sg.seg_off[r], b = sg.seg_off[r + 1];
+  const uint32_t n = (uint32_t)(b - a);
+  const uint64_t base64 = 2 * a + (uint64_t)r, slots = 2 * (uint64_t)n + 1;
+  if (base64 + slots > cap) { atomicOr(&ctr->err, ERRB_CAPACITY); return; }
+  for (uint64_t k = 0; k < slots; ++k) out[base64 + k].meta = VSV_M_DEAD;
+  if (!(n <= (uint32_t)max_parts || max_parts == -1)) return;         // SE:370
+  if (n > CS_MAX_SEG) { atomicOr(&ctr->err, ERRB_RANGE); return; }
+  uint8_t idx[CS_MAX_SEG];
+  for (uint32_t k = 0; k < n; ++k) {                                   // stable insertion sort by read start (SE:198)
+    const int32_t key = sg.q_start[a + k];
+    uint32_t j = k;
+    while (j > 0 && sg.q_start[a + idx[j - 1]] > key) { idx[j] = idx[j - 1]; --j; }
+    idx[j] = (uint8_t)k;
+  }
+  auto seg = [&](uint32_t k) {
+    const uint64_t i = a + idx[k];
+    CSeg s; s.qs = sg.q_start[i]; s.qe = sg.q_end[i]; s.rs = sg.ref_start[i]; s.re = sg.ref_end[i]; s.chr = sg.ref_id[i]; s.rev = sg.is_reverse[i];
+    return s;
+  };
+  const int64_t rl = read_len[r], sv = sv_size, mx = max_size;
+  CEmit em{out, (uint32_t)base64, 0u, (uint32_t)slots, read_rec[r]};
+  int trigger = 0, qrev = 0;
+  if (n == 2) {
+    CSeg e1 = seg(0), e2 = seg(1);
+    if (e1.chr == e2.chr) {
+      if (e1.rev == e2.rev) {
+        if (e1.rev) { const CSeg t1 = cflip(seg(1), rl), t2 = cflip(seg(0), rl); e1 = t1; e2 = t2; qrev ^= 1; }   // SE:212-215
+        pair_rule(e1, e2, nullptr, sv, mx, qrev, em);
+      }
+    } else trigger = 1;
+  } else if (n >= 3) {
+    for (uint32_t k = 0; k + 2 < n; ++k) {
+      CSeg e1 = seg(k), e2 = seg(k + 1), e3 = seg(k + 2);
+      if (e1.chr == e2.chr) {
+        if (e2.chr == e3.chr && e1.rev == e3.rev && e1.rev == e2.rev) {
+          if (e1.rev) { e1 = cflip(seg(k + 2), rl); e2 = cflip(seg(k + 1), rl); e3 = cflip(seg(k), rl); qrev ^= 1; }  // SE:250-254
+          pair_rule(e1, e2, &e3, sv, mx, qrev, em);
+          if (n - 3 == k) pair_rule(e2, e3, nullptr, sv, mx, qrev, em);                                              // SE:277-296
+        }
+      } else trigger = 1;                                                                                             // SE:298-299
+    }
+    if (trigger) {                                                                                                    // SE:305-319
+      const CSeg f = seg(0), l = seg(n - 1);
+      if (f.chr == l.chr && f.rev == l.rev) {
+        CSeg e1 = f, e2 = l;
+        if (f.rev) { e1 = cflip(l, rl); e2 = cflip(f, rl); qrev ^= 1; }
+        const int64_t dis_ref = e2.rs - e1.re, dis_read = e2.qs - e1.qe;
+        if (dis_ref < 100 && dis_read - dis_ref >= sv && (dis_read - dis_ref <= mx || mx == -1))
+          em.put(false, e2.rs < e1.re ? e2.rs : e1.re, dis_read - dis_ref, e1.qe + dis_ref / 2, e2.qs - dis_ref / 2, e2.chr, qrev);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+void vsv_launch_cutesv_split(hipStream_t st, const vsv_segments& sg, const int32_t* read_len, const uint32_t* read_rec, int sv_size,
+                             int max_size, int max_parts, vsv_sig* out, uint32_t cap, Counters* ctr) {
+  if (sg.n_reads <= 0) return;
+  cutesv_split<<<(int)((sg.n_reads + 63) / 64), 64, 0, st>>>(sg, read_len, read_rec, sv_size, max_size, max_parts, out, cap, ctr);
+}

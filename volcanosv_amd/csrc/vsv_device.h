@@ -143,3 +143,7 @@ void vsv_launch_cov_ins(hipStream_t st, const int32_t* call_pos, int64_t n_calls
 void vsv_launch_cov_del(hipStream_t st, const int32_t* call_start, const int32_t* call_end, int64_t n_calls, const int32_t* sig_start,
                         const int32_t* sig_end, const int32_t* sig_svlen, int64_t n_sigs, int32_t flanking, int64_t* cov,
                         uint32_t* err /* [0] error bits, [1] max signature span (scratch, zeroed by the caller) */);
+
+// cutesv.hip: sig_extract.py analysis_split_read (INS/DEL branches), lane per read
+void vsv_launch_cutesv_split(hipStream_t st, const vsv_segments& sg, const int32_t* read_len, const uint32_t* read_rec, int sv_size,
+                             int max_size, int max_parts, vsv_sig* out, uint32_t cap, Counters* ctr);

@@ -9,11 +9,11 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .abi import (BND_DTYPE, T_BND_CALLS, T_BND_CAND, BndParams, SupportParams, CALL_DTYPE, SIG_DTYPE, T_CALLS, T_CIGAR, T_CLUSTER1, T_MERGED, T_RAW, T_READS, T_SPLIT, DTYPE_BY_NAME,
+from .abi import (BND_DTYPE, T_BND_CALLS, T_BND_CAND, T_CUTESV_SPLIT, BndParams, SupportParams, CALL_DTYPE, SIG_DTYPE, T_CALLS, T_CIGAR, T_CLUSTER1, T_MERGED, T_RAW, T_READS, T_SPLIT, DTYPE_BY_NAME,
                   DTYPE_CUTESV, DTYPE_READS, DTYPE_SVIM, Params, Records, VsvError)
 
 _TABLE_IDS = {"raw": T_RAW, "cigar": T_CIGAR, "split": T_SPLIT, "cluster1": T_CLUSTER1, "merged": T_MERGED,
-              "calls": T_CALLS, "reads": T_READS, "bnd_cand": T_BND_CAND, "bnd_calls": T_BND_CALLS}
+              "calls": T_CALLS, "reads": T_READS, "bnd_cand": T_BND_CAND, "bnd_calls": T_BND_CALLS, "cutesv_split": T_CUTESV_SPLIT}
 
 
 def default_params(dtype):
@@ -146,6 +146,16 @@ class Engine:
                                                     len(rank), 0))
         self._check(self.lib.vsv_bnd_pair(self.h, C.byref(p)))
         return self.table("bnd_calls")
+
+    def cutesv_split(self, seg, read_len, read_rec, sv_size=30, max_size=100000, max_split_parts=7):
+        """sig_extract.py analysis_split_read (SE:193-319), INS/DEL candidates: SIG_DTYPE rows in (read, emission) order."""
+        self._keep = seg
+        s = seg.as_struct()
+        rl = np.ascontiguousarray(read_len, dtype=np.int32)
+        rr = np.ascontiguousarray(read_rec, dtype=np.uint32)
+        self._check(self.lib.vsv_cutesv_split(self.h, C.byref(s), rl.ctypes.data_as(C.c_void_p), rr.ctypes.data_as(C.c_void_p), int(sv_size),
+                                              int(max_size), int(max_split_parts)))
+        return self.table("cutesv_split")
 
     def support_params(self, **kw):
         p = SupportParams()
