@@ -155,3 +155,69 @@ def test_gpu_split_branch_matches_reference_and_oracle(doc):
         rows = eng.cutesv_split(seg, seg.read_len, seg.read_rec, 30, 100000, 7)
         got = sig_extract.split_candidates(soa, rows, lambda rec: reads[rec]["seq"], lambda t: names[t])
         assert got == split_expected(doc)
+
+
+# ---- the script body: BAM in, INS.sigs / DEL.sigs / reads.sigs out ---------------------------------------------------------
+def test_sort_sigs_equals_coreutils_sort(tmp_path):
+    """sort_sigs = `sort -u | sort -k 2,2 -k 3,3n` under LC_ALL=C (the declared locale; SE:637-638)."""
+    import subprocess
+    from volcanosv_amd import sig_extract
+    rng = np.random.default_rng(3)
+    lines = []
+    for _ in range(3000):
+        c = "chr%s" % rng.choice(["1", "10", "2", "X", "1_random"])
+        lines.append("INS\t%s\t%d\t%d\tread%d\t%s\n" % (c, rng.integers(1, 5000), rng.integers(10, 99), rng.integers(0, 50), "".join(rng.choice(list("ACGTacgt_-"), 5))))
+    lines += lines[:500]
+    p = tmp_path / "in.txt"
+    p.write_text("".join(lines))
+    env = dict(os.environ, LC_ALL="C")
+    want = subprocess.run("sort -u %s | sort -k 2,2 -k 3,3n" % p, shell=True, env=env, capture_output=True, text=True, check=True).stdout
+    assert "".join(sig_extract.sort_sigs(lines)) == want
+
+
+def test_task_and_bed_helpers():
+    from volcanosv_amd import sig_extract
+    tasks = sig_extract.make_tasks([("chr1", 25_000_000), ("chrM", 16_571), ("chr2", 20_000_000)], 10_000_000)
+    assert tasks == [["chr1", 0, 10_000_000], ["chr1", 10_000_000, 20_000_000], ["chr1", 20_000_000, 25_000_000], ["chrM", 0, 16_571],
+                     ["chr2", 0, 10_000_000], ["chr2", 10_000_000, 20_000_000]]
+    assert sig_extract.acquire_clip_pos("10S5M2D3=1X7S") == [10, 7, 11] and sig_extract.acquire_clip_pos("5H20M") == [0, 0, 20]
+
+
+@pytest.mark.gpu
+def test_gpu_script_body_on_a_bam(doc, tmp_path):
+    """All fixture reads written to a BAM (real SEQ, SA tags), run through volcanosv_amd.sig_extract.run; the three output files
+    equal what the reference's per-read candidates give after its own formatting (SE:540-560) and `sort`."""
+    import subprocess
+    from volcanosv_amd import bam, sig_extract
+    reads = sorted(doc["cases"]["plain"]["reads"] + doc["cases"]["split"]["reads"], key=lambda r: r["pos"])
+    exp = {r["name"]: e for case in ("plain", "split") for r, e in zip(doc["cases"][case]["reads"], doc["cases"][case]["expected"])}
+    recs = [dict(tid=0, pos=r["pos"], qname=r["name"], mapq=r["mapq"], flag=r["flag"], cigar=[tuple(c) for c in r["cigar"]], seq=r["seq"],
+                 tags=({b"SA": r["sa"]} if r["sa"] else None)) for r in reads]
+    path = str(tmp_path / "reads.bam")
+    bam.write_bam(path, [("chr1", 30_000_000), ("chr2", 30_000_000)], recs)
+    ref = tmp_path / "ref.fa"
+    ref.write_text(">chr1\nA\n")
+    out = sig_extract.run(path, str(ref), str(tmp_path / "work"), log=lambda *a: None)
+    ins, dele = [], []
+    for r in reads:
+        for c in exp[r["name"]]:
+            if len(c) == 6 and c[4] == "INS":
+                ins.append("%s\t%s\t%d\t%d\t%s\t%s\n" % (c[4], c[5], c[0], c[1], c[2], c[3]))
+            elif len(c) == 5 and c[3] == "DEL":
+                dele.append("%s\t%s\t%d\t%d\t%s\n" % (c[3], c[4], c[0], c[1], c[2]))
+    env = dict(os.environ, LC_ALL="C")
+    for name, lines in (("INS.sigs", ins), ("DEL.sigs", dele)):
+        p = tmp_path / ("exp_" + name)
+        p.write_text("".join(lines))
+        want = subprocess.run("sort -u %s | sort -k 2,2 -k 3,3n" % p, shell=True, env=env, capture_output=True, text=True, check=True).stdout
+        assert open(out + name).read() == want, name
+        assert len(want.splitlines()) > 200
+    # reads.sigs: every read with mapq >= 20 whose 10 Mb task produced a candidate (SE:524-535), in file order per task
+    tasks_with_cand = {r["pos"] // 10_000_000 for r in reads if any((len(c) == 6 and c[4] in ("INS",)) or len(c) in (5, 7) for c in exp[r["name"]])}
+    want = []
+    for t in sorted(tasks_with_cand, key=lambda t: ("_chr1_%d_%d" % (t * 10_000_000, (t + 1) * 10_000_000)).encode()):
+        for r in reads:
+            if r["pos"] // 10_000_000 == t and r["mapq"] >= 20:
+                end = r["pos"] + sum(l for op, l in r["cigar"] if op in (0, 2, 3, 7, 8))
+                want.append("chr1\t%d\t%d\t%d\t%s\n" % (r["pos"], end, 1 if r["flag"] in (0, 16) else 0, r["name"]))
+    assert open(out + "reads.sigs").read() == "".join(want)

@@ -21,7 +21,7 @@ SYMBOLS = [
     "vsv_table_fill", "vsv_last_scan_ms", "vsv_default_bnd_params", "vsv_bnd_segments", "vsv_bnd_pair", "vsv_bnd_set_candidates",
     "vsv_cutesv_split", "vsv_default_support_params", "vsv_support_join", "vsv_support_cov_ins", "vsv_support_cov_del",
     "vsv_bam_open", "vsv_bam_close", "vsv_bam_error", "vsv_bam_set_threads", "vsv_bam_n_refs", "vsv_bam_ref_name", "vsv_bam_ref_len", "vsv_bam_load",
-    "vsv_bam_qnames", "vsv_bam_sa_tags", "vsv_bam_l_seq", "vsv_bam_sam_flags",
+    "vsv_bam_qnames", "vsv_bam_sa_tags", "vsv_bam_l_seq", "vsv_bam_sam_flags", "vsv_bam_set_keep_seq", "vsv_bam_seq",
 ]
 
 
@@ -94,7 +94,9 @@ def load():
     lib.vsv_bam_ref_len.restype = C.c_int64
     lib.vsv_bam_load.argtypes = [B, C.c_int, C.POINTER(Records)]
     lib.vsv_bam_load.restype = C.c_int
-    for name in ("vsv_bam_qnames", "vsv_bam_sa_tags"):
+    lib.vsv_bam_set_keep_seq.argtypes = [B, C.c_int]
+    lib.vsv_bam_set_keep_seq.restype = None
+    for name in ("vsv_bam_qnames", "vsv_bam_sa_tags", "vsv_bam_seq"):
         getattr(lib, name).argtypes = [B, C.POINTER(C.c_int64)]
         getattr(lib, name).restype = C.c_void_p
     for name in ("vsv_bam_l_seq", "vsv_bam_sam_flags"):

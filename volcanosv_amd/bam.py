@@ -49,6 +49,26 @@ class LazyLines:
         return list(self) == list(other)
 
 
+class PackedSeq:
+    """The 4-bit SEQ fields of the loaded records (BAM nibble alphabet); `seq[i]` decodes record i like pysam's
+    query_sequence."""
+    ALPHABET = np.frombuffer(b"=ACMGRSVTWYHKDBN", dtype=np.uint8)
+
+    def __init__(self, packed, l_seq):
+        self.packed = packed
+        self.l_seq = l_seq
+        nbytes = (l_seq.astype(np.int64) + 1) // 2
+        self.off = np.concatenate(([0], np.cumsum(nbytes)))
+
+    def __getitem__(self, i):
+        n = int(self.l_seq[i])
+        b = self.packed[int(self.off[i]):int(self.off[i + 1])]
+        nib = np.empty(2 * len(b), dtype=np.uint8)
+        nib[0::2] = b >> 4
+        nib[1::2] = b & 15
+        return self.ALPHABET[nib[:n]].tobytes().decode()
+
+
 class BamFile:
     def __init__(self, path, threads=0):
         self.lib = _lib.load()
@@ -75,13 +95,14 @@ class BamFile:
     def get_tid(self, name):
         return self.references.index(name) if name in self.references else -1
 
-    def fetch_soa(self, chrom=None):
+    def fetch_soa(self, chrom=None, keep_seq=False):
         """All records of `chrom` (or of every reference) in file order as a RecordSoA (arrays are copied out of the
         ingest object). soa.sa_tags[i] is the SA tag text of record i ('' if absent)."""
         tid = -1 if chrom is None else self.get_tid(chrom)
         if chrom is not None and tid < 0:
             raise KeyError("reference %r not in BAM header" % chrom)
         r = Records()
+        self.lib.vsv_bam_set_keep_seq(self.h, 1 if keep_seq else 0)
         st = self.lib.vsv_bam_load(self.h, tid, C.byref(r))
         if st:
             raise VsvError(st, self.lib.vsv_bam_error(self.h).decode())
@@ -104,6 +125,9 @@ class BamFile:
         soa.sa_tags = sa
         soa.l_seq = arr(self.lib.vsv_bam_l_seq(self.h), n, np.uint32)
         soa.sam_flags = arr(self.lib.vsv_bam_sam_flags(self.h), n, np.uint32)
+        if keep_seq:
+            p = self.lib.vsv_bam_seq(self.h, C.byref(ln))
+            soa.seq = PackedSeq(np.frombuffer(C.string_at(p, ln.value), dtype=np.uint8), soa.l_seq)
         return soa
 
 
@@ -131,7 +155,7 @@ def _reg2bin(beg, end):
 
 def write_bam(path, references, records, header_text=None):
     """references: [(name, length)]; records: iterable of dicts with keys tid, pos, qname, mapq, flag (SAM flag),
-    cigar [(op,len)], optional seq_len (bases are written as 'N'; 0 => '*'), optional tags {b'SA': 'text'}."""
+    cigar [(op,len)], optional seq (bases) or seq_len (bases are written as 'N'; 0 => '*'), optional tags {b'SA': 'text'}."""
     if header_text is None:
         header_text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % (n, l) for n, l in references)
     out = bytearray()
@@ -144,7 +168,8 @@ def write_bam(path, references, records, header_text=None):
         qn = r["qname"].encode() + b"\x00"
         cig = r["cigar"]
         ref_len = sum(l for op, l in cig if op in (0, 2, 3, 7, 8))
-        l_seq = int(r.get("seq_len", 0))
+        seq = r.get("seq")
+        l_seq = len(seq) if seq is not None else int(r.get("seq_len", 0))
         long_cigar = len(cig) > 65535
         cig_words = [(l << 4) | op for op, l in cig]
         tags = b""
@@ -156,7 +181,12 @@ def write_bam(path, references, records, header_text=None):
         body = struct.pack("<iiBBHHHiiii", r["tid"], r["pos"], len(qn), r["mapq"], _reg2bin(r["pos"], r["pos"] + max(ref_len, 1)),
                            len(cig_words), r["flag"], l_seq, -1, -1, 0)
         body += qn + struct.pack("<%dI" % len(cig_words), *cig_words)
-        body += b"\xff" * ((l_seq + 1) // 2) + b"\xff" * l_seq + tags
+        if seq is not None:
+            nib = np.array(["=ACMGRSVTWYHKDBN".index(ch) for ch in seq] + [0], dtype=np.uint8)
+            packed = ((nib[0:2 * ((l_seq + 1) // 2):2] << 4) | nib[1:2 * ((l_seq + 1) // 2):2]).tobytes()
+        else:
+            packed = b"\xff" * ((l_seq + 1) // 2)
+        body += packed + b"\xff" * l_seq + tags
         out += struct.pack("<i", len(body)) + body
     with open(path, "wb") as f:
         for i in range(0, len(out), 60000):

@@ -37,6 +37,8 @@ struct vsv_bam {
   std::vector<uint8_t> mapq, flag;
   std::vector<std::string> qnames;       // qid -> name
   std::string qname_blob;                // '\n'-joined, for the binding
+  bool keep_seq = false;                 // vsv_bam_set_keep_seq: store the packed 4-bit SEQ of every loaded record
+  std::vector<uint8_t> seq;              // concatenated, record i occupies (l_seq[i]+1)/2 bytes
   std::vector<std::string> sa;           // per record SA tag ("" if none)
   std::string sa_blob;
 };
@@ -205,7 +207,7 @@ int vsv_bam_load(vsv_bam* b, int tid, vsv_records* out) {
   if (!hdr_ok) return VSV_E_INVALID;
   b->pos.clear(); b->tid.clear(); b->qid.clear(); b->cigar.clear(); b->cigar_off.assign(1, 0); b->mapq.clear(); b->flag.clear();
   b->qnames.clear(); b->sa.clear(); b->l_seq.clear(); b->sam_flag.clear();
-  b->qname_blob.clear(); b->sa_blob.clear();
+  b->qname_blob.clear(); b->sa_blob.clear(); b->seq.clear();
   // open-addressing name table: slot -> (hash, offset into qname_blob, length, id)
   struct Slot { uint64_t h; uint32_t off, len, id; };
   std::vector<Slot> table(1u << 16, Slot{0, 0, 0, 0xFFFFFFFFu});
@@ -282,6 +284,7 @@ int vsv_bam_load(vsv_bam* b, int tid, vsv_records* out) {
       if (name[k] == 'h' && name[k + 1] == 'p') { if (name[k + 2] == '1') f8 |= VSV_F_HP1; else if (name[k + 2] == '2') f8 |= VSV_F_HP2; }
     b->pos.push_back(pos); b->tid.push_back(refID); b->qid.push_back(q); b->mapq.push_back(mq); b->flag.push_back(f8);
     b->l_seq.push_back((uint32_t)l_seq); b->sam_flag.push_back(fl);
+    if (b->keep_seq && l_seq > 0) { const uint8_t* sq = &rec[32 + l_read_name + 4u * n_cig]; b->seq.insert(b->seq.end(), sq, sq + (size_t)((l_seq + 1) / 2)); }
     if (!first_rec) b->sa_blob.push_back('\n');
     first_rec = false;
     if (sa_len) b->sa_blob.append(sa_p, sa_len);
@@ -306,6 +309,8 @@ int vsv_bam_load(vsv_bam* b, int tid, vsv_records* out) {
 /* '\n'-joined query names in qid order / SA tags in record order of the last vsv_bam_load; *len receives the length */
 const char* vsv_bam_qnames(vsv_bam* b, int64_t* len) { if (len) *len = b ? (int64_t)b->qname_blob.size() : 0; return b ? b->qname_blob.data() : ""; }
 const char* vsv_bam_sa_tags(vsv_bam* b, int64_t* len) { if (len) *len = b ? (int64_t)b->sa_blob.size() : 0; return b ? b->sa_blob.data() : ""; }
+void vsv_bam_set_keep_seq(vsv_bam* b, int keep) { if (b) b->keep_seq = keep != 0; }
+const uint8_t* vsv_bam_seq(vsv_bam* b, int64_t* len) { if (len) *len = b ? (int64_t)b->seq.size() : 0; return b ? b->seq.data() : nullptr; }
 const uint32_t* vsv_bam_l_seq(vsv_bam* b) { return b ? b->l_seq.data() : nullptr; }
 const uint32_t* vsv_bam_sam_flags(vsv_bam* b) { return b ? b->sam_flag.data() : nullptr; }
 

@@ -166,3 +166,158 @@ def split_candidates(soa, rows, seq_of, chrom_name):
             c = [int(row["pos"]), int(row["svlen"]), name, str(q[int(row["q_start"]):int(row["q_end"])]), "INS", chrom_name(int(row["tid"]))]
         out.setdefault(rec, []).append(c)
     return out
+
+
+# ---- the script body: main_ctrl / single_pipe (SE:496-645) --------------------------------------------------------------
+def make_tasks(contigs, batches=10000000):
+    """SE:598-612: [[chrom, start, end], ...] in BAM header order; contigs = [(name, length)]."""
+    tasks = []
+    for name, ln in contigs:
+        if ln < batches:
+            tasks.append([name, 0, ln])
+        else:
+            pos = 0
+            for _ in range(int(ln / batches)):
+                tasks.append([name, pos, pos + batches])
+                pos += batches
+            if pos < ln:
+                tasks.append([name, pos, ln])
+    return tasks
+
+
+def load_bed(bed_file, task_list):
+    """SE:59-82: per task, the BED regions (widened by 1000 bp) that start inside it or cover its start; None without a BED."""
+    if bed_file is None:
+        return None
+    bed = {}
+    with open(bed_file) as f:
+        for line in f:
+            seq = line.strip().split('\t')
+            bed.setdefault(seq[0], []).append((int(seq[1]) - 1000, int(seq[2]) + 1000))
+    region_list = [[] for _ in task_list]
+    for chrom in bed:
+        bed[chrom].sort(key=lambda x: (x[0], x[1]))
+        for item in bed[chrom]:
+            for i, t in enumerate(task_list):
+                if chrom == t[0] and ((t[1] <= item[0] and t[2] > item[0]) or item[0] <= t[1] < item[1]):
+                    region_list[i].append(item)
+    return region_list
+
+
+def _pad_empty_cigars(soa, n_ops):
+    """Gives every record without a CIGAR (placed-but-unmapped reads; they are F_SKIP) a single zero-length M op, in place."""
+    new_n = np.maximum(n_ops, 1)
+    new_off = np.concatenate(([0], np.cumsum(new_n))).astype(np.uint64)
+    cig = np.zeros(int(new_off[-1]), dtype=np.uint32)
+    rec_of = np.repeat(np.arange(len(n_ops)), n_ops)
+    within = np.arange(len(soa.cigar), dtype=np.int64) - soa.cigar_off[:-1].astype(np.int64)[rec_of]
+    cig[new_off[:-1].astype(np.int64)[rec_of] + within] = soa.cigar
+    soa.cigar, soa.cigar_off = cig, new_off
+
+
+def sort_sigs(lines):
+    """`sort -u | sort -k 2,2 -k 3,3n` (SE:637-638) with LC_ALL=C: unique lines ordered by chromosome field (bytes), then
+    numeric position, then the whole line (sort's last-resort comparison)."""
+    uniq = set(lines)
+
+    def key(line):
+        f = line.rstrip("\n").split("\t")
+        return (f[1].encode(), int(f[2]), line.encode())
+
+    return sorted(uniq, key=key)
+
+
+def run(input_bam, reference, work_dir, batches=10000000, max_split_parts=7, min_mapq=20, min_read_len=500, merge_del_threshold=0,
+        merge_ins_threshold=100, include_bed=None, min_size=30, max_size=100000, min_siglength=10, device=0, engine=None, log=print):
+    """Writes <work_dir>/INS.sigs, DEL.sigs and reads.sigs like sig_extract.py (SE:575-645). The per-task files under
+    signatures/ are not kept; a task without any candidate contributes no reads (single_pipe returns early, SE:533-535)."""
+    import os
+
+    from .bam import BamFile
+    from .engine import Engine
+    if not os.path.isfile(reference):
+        raise FileNotFoundError("[Errno 2] No such file: '%s'" % reference)
+    os.makedirs(work_dir, exist_ok=True)
+    out_dir = work_dir if work_dir.endswith('/') else work_dir + '/'
+    eng = engine or Engine(device)
+    p = params(min_siglength, min_mapq, merge_del_threshold, merge_ins_threshold)
+    ins_lines, del_lines, task_reads = [], [], {}
+    try:
+        with BamFile(input_bam) as bam:
+            contigs = list(zip(bam.references, bam.lengths))
+            tasks = make_tasks(contigs, batches)
+            beds = load_bed(include_bed, tasks)
+            ids = {n: i for i, n in enumerate(bam.references)}
+            names = list(bam.references)
+
+            def chrom_id(n):
+                if n not in ids:
+                    ids[n] = len(names)
+                    names.append(n)
+                return ids[n]
+
+            for chrom, ln in contigs:
+                soa = bam.fetch_soa(chrom, keep_seq=True)
+                n = soa.n_records
+                if n == 0:
+                    continue
+                starts = np.array([t[1] for t in tasks if t[0] == chrom], dtype=np.int64)
+                tix = [i for i, t in enumerate(tasks) if t[0] == chrom]
+                n_ops = np.diff(soa.cigar_off.astype(np.int64))
+                pos = soa.pos.astype(np.int64)
+                task_of = np.searchsorted(starts, pos, side="right") - 1           # the task a read starts in (SE:521)
+                codes, lens = soa.cigar & 15, (soa.cigar >> 4).astype(np.int64)
+                refspan = np.where((codes == 0) | (codes == 2) | (codes == 3) | (codes == 7) | (codes == 8), lens, 0)
+                csum = np.concatenate(([0], np.cumsum(refspan)))
+                end = pos + csum[soa.cigar_off[1:].astype(np.int64)] - csum[soa.cigar_off[:-1].astype(np.int64)]
+                live = (n_ops > 0) & ((soa.sam_flags & 4) == 0)                    # placed-but-unmapped reads carry no alignment
+                if beds is not None:                                               # SE:510-520
+                    in_bed = np.zeros(n, dtype=bool)
+                    for k, ti in enumerate(tix):
+                        m = task_of == k
+                        for r0, r1 in beds[ti]:
+                            in_bed |= m & ~((end <= r0) | (pos >= r1))
+                    live &= in_bed
+                flags = np.array([flag_bits(int(f), int(q), min_read_len) for f, q in zip(soa.sam_flags, soa.l_seq)], dtype=np.uint8)
+                flags[~live] |= F_SKIP
+                soa.flag = flags
+                if (n_ops == 0).any():                                             # the scan wants >= 1 op per record: pad with one 0M
+                    _pad_empty_cigars(soa, n_ops)
+                eng.run(soa, p)
+                raw, comb = eng.table("raw"), eng.table("cigar")
+                seq_of = lambda rec: soa.seq[rec]
+                cig = cigar_candidates(soa, raw, comb, seq_of, chrom)
+                ok = live & (soa.l_seq.astype(np.int64) >= min_read_len)
+                sflags = np.where(ok, soa.sam_flags, 0xFFFF)                       # skipped reads never reach the split branch
+                sreads = split_reads(soa, sflags, soa.l_seq, soa.sa_tags, chrom_id, min_mapq)
+                spl = {}
+                if sreads:
+                    seg = SplitSegments(sreads)
+                    rows = eng.cutesv_split(seg, seg.read_len, seg.read_rec, min_size, max_size, max_split_parts)
+                    spl = split_candidates(soa, rows, seq_of, lambda t: names[t])
+                has_cand = np.zeros(len(tix), dtype=bool)
+                for rec in sorted(set(cig) | set(spl)):
+                    for c in cig.get(rec, []) + spl.get(rec, []):
+                        has_cand[task_of[rec]] = True
+                        if len(c) == 6:                                            # SE:546-553 (the %d of a float position truncates)
+                            ins_lines.append("%s\t%s\t%d\t%d\t%s\t%s\n" % (c[4], c[5], c[0], c[1], c[2], c[3]))
+                        else:
+                            del_lines.append("%s\t%s\t%d\t%d\t%s\n" % (c[3], c[4], c[0], c[1], c[2]))
+                for k, ti in enumerate(tix):                                       # SE:524-529, 556-560
+                    if has_cand[k]:
+                        t = tasks[ti]
+                        sel = np.flatnonzero(live & (task_of == k) & (soa.mapq >= min_mapq))
+                        task_reads["_%s_%d_%d" % (t[0], t[1], t[2])] = [
+                            "%s\t%d\t%d\t%d\t%s\n" % (chrom, pos[i], end[i], 1 if int(soa.sam_flags[i]) in (0, 16) else 0, soa.qname(i)) for i in sel]
+                log("%s: %d records -> %d INS / %d DEL candidate lines so far" % (chrom, n, len(ins_lines), len(del_lines)))
+    finally:
+        if engine is None:
+            eng.close()
+    with open(out_dir + "INS.sigs", "w") as f:
+        f.writelines(sort_sigs(ins_lines))
+    with open(out_dir + "DEL.sigs", "w") as f:
+        f.writelines(sort_sigs(del_lines))
+    with open(out_dir + "reads.sigs", "w") as f:                                   # cat signatures/*.reads: glob order of the file names
+        for name in sorted(task_reads, key=lambda s: s.encode()):
+            f.writelines(task_reads[name])
+    return out_dir
