@@ -292,6 +292,28 @@ int vsv_support_cov_del(vsv_handle* h, const int32_t* call_start, const int32_t*
                         const int32_t* sig_start, const int32_t* sig_end, const int32_t* sig_svlen, int64_t n_sigs,
                         int32_t flanking, int on_device, int64_t* cov);
 
+/* ---- remove_redundancy.py: redundant-call matching (last step of Raw_variant_call.py, RV:99-104) ------------------------
+ * vsv_redundancy_pairs replaces match_del_chr / match_ins_chr with their pair predicates (RR:92-134, 162-181) for the calls of
+ * one chromosome in ascending position order: DEL = size similarity + reciprocal overlap, INS = size similarity + sequence
+ * similarity (totlen - editDistance)/totlen of the ALT strings, where edlib's global unit-cost edit distance (RR:75-81) is
+ * computed by a bit-parallel (Myers) kernel. Returns the matching pairs i < j in (i, j) order (the reference's link list
+ * holds both directions); connected components and the VCF text stay on the host. */
+typedef struct vsv_redundancy_params {
+  int32_t dist_thresh;          /* 500   INS window and distance (RR:9)  */
+  int32_t dist_thresh_del;      /* 3000  DEL (RR:10)                      */
+  double overlap_thresh;        /* 0     DEL reciprocal overlap (RR:11)   */
+  double size_sim_thresh;       /* 0.5   INS min/max length (RR:12)       */
+  double size_sim_thresh_del;   /* 0.1   DEL (RR:13)                      */
+  double seq_sim_thresh;        /* 0.5   INS sequence similarity (RR:14)  */
+} vsv_redundancy_params;
+int vsv_default_redundancy_params(vsv_redundancy_params* p);
+/* pos ascending (VSV_E_UNSORTED otherwise); svlen = |len(REF)-len(ALT)| > 0 (VSV_E_ZERODIV otherwise, the reference divides);
+ * INS only: seq = concatenated ALT strings (symbols coded 0..15 by the caller), seq_off[n+1]. Host pointers.
+ * pairs: room for cap pairs (2 x u32 each); VSV_E_CAPACITY reports the needed count through vsv_last_count. */
+int vsv_redundancy_pairs(vsv_handle* h, int is_del, const int32_t* pos, const int32_t* svlen, const uint8_t* seq,
+                         const uint64_t* seq_off, int64_t n, const vsv_redundancy_params* p, uint32_t* pairs, int64_t cap,
+                         int64_t* n_pairs);
+
 /* ---- host-side ingest: BAM/BGZF -> record SoA ----------------------------------------------------
  * Replaces pysam.AlignmentFile(bam).fetch(chr) (H:387-391, RS:108-113). Arrays returned through `out` are owned
  * by the vsv_bam object and stay valid until the next vsv_bam_load / vsv_bam_close. No index is used. */

@@ -9,7 +9,7 @@ import subprocess
 
 import numpy as np
 
-from volcanosv_amd.abi import BND_DTYPE, CALL_DTYPE, SIG_DTYPE, BndParams, Params, Records, Segments, SupportParams
+from volcanosv_amd.abi import BND_DTYPE, CALL_DTYPE, SIG_DTYPE, BndParams, Params, Records, RedundancyParams, Segments, SupportParams
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
@@ -43,6 +43,11 @@ def lib():
                                  C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
         _LIB.orc_bnd_free.argtypes = [C.c_void_p, C.c_void_p]
         _LIB.orc_bnd_pair.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(BndParams), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        _LIB.orc_levenshtein.argtypes = [C.c_char_p, C.c_int64, C.c_char_p, C.c_int64]
+        _LIB.orc_levenshtein.restype = C.c_int64
+        _LIB.orc_default_redundancy_params.argtypes = [C.POINTER(RedundancyParams)]
+        _LIB.orc_redundancy_pairs.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(RedundancyParams), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        _LIB.orc_free_u32.argtypes = [C.c_void_p]
         _LIB.orc_cutesv_split.argtypes = [C.POINTER(Segments), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
         _LIB.orc_cov_ins.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
         _LIB.orc_cov_del.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
@@ -165,3 +170,33 @@ def run_cutesv_split(seg, read_len, read_rec, sv_size=30, max_size=100000, max_s
     rows = _copy(a.value, na.value, SIG_DTYPE)
     lib().orc_bnd_free(a, None)
     return rows
+
+
+def levenshtein(a, b):
+    """Unit-cost global edit distance of two byte strings (edlib.align default mode)."""
+    a, b = (x.encode() if isinstance(x, str) else bytes(x) for x in (a, b))
+    return int(lib().orc_levenshtein(a, len(a), b, len(b)))
+
+
+def default_redundancy_params(**kw):
+    p = RedundancyParams()
+    lib().orc_default_redundancy_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def run_redundancy_pairs(is_del, pos, svlen, seq=None, seq_off=None, params=None):
+    """match_del_chr / match_ins_chr on the host: (status, (n_pairs, 2) uint32 pairs i < j)."""
+    p = params if params is not None else default_redundancy_params()
+    pos, svlen = _i32(pos), _i32(svlen)
+    sq = np.ascontiguousarray(seq if seq is not None else [], dtype=np.uint8)
+    so = np.ascontiguousarray(seq_off if seq_off is not None else [0], dtype=np.uint64)
+    a, na = C.c_void_p(), C.c_int64()
+    st = lib().orc_redundancy_pairs(1 if is_del else 0, pos.ctypes.data_as(C.c_void_p), svlen.ctypes.data_as(C.c_void_p),
+                                    sq.ctypes.data_as(C.c_void_p), so.ctypes.data_as(C.c_void_p), len(pos), C.byref(p), C.byref(a), C.byref(na))
+    if st:
+        return st, np.zeros((0, 2), np.uint32)
+    out = np.frombuffer((C.c_char * (na.value * 8)).from_address(a.value), dtype=np.uint32).reshape(-1, 2).copy() if na.value else np.zeros((0, 2), np.uint32)
+    lib().orc_free_u32(a)
+    return 0, out

@@ -1019,3 +1019,72 @@ int orc_cutesv_split(const vsv_segments* sg, const int32_t* read_len, const uint
   *rows_out = sv_dup(&out); *n_rows = out.n; free(out.v);
   return 0;
 }
+
+/* ================================================================================================
+ * remove_redundancy.py (Large_INDEL): redundant-call matching. match_del_chr / match_ins_chr (RR:115-134, 162-181) with
+ * their pair predicates (RR:92-114); edlib.align(...)["editDistance"] (RR:75-81; edlib 1.3.9, default NW mode, unit costs;
+ * the package is absent from this image) restated as the Levenshtein DP. Calls of one chromosome, ascending by position
+ * (sort_sig_per_chr, canonical stable order). Output: matching pairs i < j in (i, j) order; the reference's link list holds
+ * each of them in both directions.
+ * ================================================================================================ */
+int64_t orc_levenshtein(const uint8_t* a, int64_t la, const uint8_t* b, int64_t lb) {
+  int64_t* row = (int64_t*)malloc(sizeof(int64_t) * (size_t)(lb + 1));
+  for (int64_t j = 0; j <= lb; ++j) row[j] = j;
+  for (int64_t i = 1; i <= la; ++i) {
+    int64_t diag = row[0];
+    row[0] = i;
+    for (int64_t j = 1; j <= lb; ++j) {
+      int64_t sub = diag + (a[i - 1] != b[j - 1]);
+      diag = row[j];
+      int64_t v = row[j] + 1;
+      if (row[j - 1] + 1 < v) v = row[j - 1] + 1;
+      if (sub < v) v = sub;
+      row[j] = v;
+    }
+  }
+  int64_t d = row[lb];
+  free(row);
+  return d;
+}
+
+int orc_default_redundancy_params(vsv_redundancy_params* p) {
+  p->dist_thresh = 500; p->dist_thresh_del = 3000; p->overlap_thresh = 0.0; p->size_sim_thresh = 0.5;     /* RR:9-14 */
+  p->size_sim_thresh_del = 0.1; p->seq_sim_thresh = 0.5;
+  return 0;
+}
+
+/* is_del: match_del_one_pair (RR:104-114) else match_ins_one_pair (RR:92-102); seq/seq_off = upper-cased ALT strings (RR:62) */
+int orc_redundancy_pairs(int is_del, const int32_t* pos, const int32_t* svlen, const uint8_t* seq, const uint64_t* seq_off, int64_t n,
+                         const vsv_redundancy_params* p, uint32_t** pairs_out, int64_t* n_pairs) {
+  int64_t cap = 1024, np = 0;
+  uint32_t* pr = (uint32_t*)malloc(sizeof(uint32_t) * 2 * (size_t)cap);
+  const int64_t dist = is_del ? p->dist_thresh_del : p->dist_thresh;
+  const double size_thr = is_del ? p->size_sim_thresh_del : p->size_sim_thresh;
+  for (int64_t i = 0; i < n; ++i) {
+    for (int64_t j = i + 1; j < n; ++j) {
+      if ((int64_t)pos[j] > (int64_t)pos[i] + dist) break;                      /* RR:123-124 */
+      const int64_t l1 = svlen[i], l2 = svlen[j];
+      const int64_t mn = l1 < l2 ? l1 : l2, mx = l1 < l2 ? l2 : l1;
+      if (mx == 0) { free(pr); return VSV_E_ZERODIV; }                          /* get_size_sim divides (RR:88-90) */
+      const double size_sim = (double)mn / (double)mx;
+      if (!(size_sim >= size_thr)) continue;                                    /* dist_ref <= dist holds inside the window */
+      int match;
+      if (is_del) {
+        const int64_t e1 = (int64_t)pos[i] + l1, e2 = (int64_t)pos[j] + l2;
+        const int64_t ov = (e1 < e2 ? e1 : e2) - (pos[i] > pos[j] ? pos[i] : pos[j]);
+        match = (double)ov / (double)mx >= p->overlap_thresh;                   /* RR:103-114 */
+      } else {
+        const int64_t la = (int64_t)(seq_off[i + 1] - seq_off[i]), lb = (int64_t)(seq_off[j + 1] - seq_off[j]);
+        const int64_t ed = orc_levenshtein(seq + seq_off[i], la, seq + seq_off[j], lb);
+        match = (double)(la + lb - ed) / (double)(la + lb) >= p->seq_sim_thresh;   /* RR:75-81, 98-100 */
+      }
+      if (match) {
+        if (np == cap) { cap *= 2; pr = (uint32_t*)realloc(pr, sizeof(uint32_t) * 2 * (size_t)cap); }
+        pr[2 * np] = (uint32_t)i; pr[2 * np + 1] = (uint32_t)j; ++np;
+      }
+    }
+  }
+  *pairs_out = pr; *n_pairs = np;
+  return 0;
+}
+void orc_free_u32(uint32_t* p) { free(p); }

@@ -71,6 +71,12 @@ class SupportParams(C.Structure):
                 ("min_size_sim", C.c_double)]
 
 
+class RedundancyParams(C.Structure):
+    """vsv_redundancy_params (remove_redundancy.py:9-14 defaults)."""
+    _fields_ = [("dist_thresh", C.c_int32), ("dist_thresh_del", C.c_int32), ("overlap_thresh", C.c_double), ("size_sim_thresh", C.c_double),
+                ("size_sim_thresh_del", C.c_double), ("seq_sim_thresh", C.c_double)]
+
+
 BND_DTYPE = np.dtype([("src_tid", "<i4"), ("src_pos", "<i4"), ("dst_tid", "<i4"), ("dst_pos", "<i4"), ("read", "<u4"), ("read2", "<u4"),
                       ("meta", "<u4"), ("pad", "<u4")])
 B_SRC_FWD, B_DST_FWD, B_HAP2, B_GT_SHIFT, B_DEAD = 1, 2, 4, 4, 64

@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
-"""Drop-in for Large_INDEL/Raw_variant_call.py (same flags). The aligner and remove_redundancy.py stay external; the contig and
-reads signature extraction and the false-positive filter (FP_filter_v1.py) run on the GPU in this process."""
+"""Drop-in for Large_INDEL/Raw_variant_call.py (same flags). Only the aligner stays external: the contig and reads signature
+extraction, the false-positive filter (FP_filter_v1.py) and the redundancy removal (remove_redundancy.py) run on the GPU in
+this process."""
 import os
 import shutil
 import sys
 from argparse import ArgumentParser
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-from volcanosv_amd import contig_signature, fp_filter, pipeline, reads_signature, vcf  # noqa: E402
+from volcanosv_amd import contig_signature, fp_filter, pipeline, reads_signature, remove_redundancy, vcf  # noqa: E402
 
 parser = ArgumentParser(description="", usage='use "python3 %(prog)s --help" for more information')
 parser.add_argument('--contig_path', '-contig')
@@ -22,7 +23,6 @@ parser.add_argument('--n_thread', '-t', type=int, default=10)
 parser.add_argument('--mem_per_thread', '-mempt', default='1G')
 a = parser.parse_args()
 os.makedirs(a.output_dir, exist_ok=True)
-code_dir = os.environ.get("VOLCANOSV_CODE_DIR")      # reference Large_INDEL/ dir for FP_filter_v1.py / remove_redundancy.py
 prefix = a.contig_path.split('/')[-1].split('.')[0]
 bam = pipeline.align_contigs(a.reference_path, a.contig_path, a.output_dir + '/' + prefix + '.sorted.bam', "asm5", a.n_thread, a.mem_per_thread)
 chr_num = int(a.chr_num) if a.chr_num not in (None, "None") else None
@@ -41,7 +41,4 @@ if sigd is not None:
 else:
     shutil.copy(raw, filtered)
     print("note: no reads signature directory (-sigd / -rbam with -chr): FP filter skipped")
-if not pipeline.spawn_reference_script(code_dir, "remove_redundancy.py", "-i %s -o %s" % (filtered, final_dir)):
-    os.makedirs(final_dir, exist_ok=True)                                             # remove_redundancy is outside this build
-    shutil.copy(filtered, final_dir + "volcano_variant_no_redundancy.vcf")
-    print("note: remove_redundancy.py not run (set VOLCANOSV_CODE_DIR to the reference's Large_INDEL dir)")
+remove_redundancy.run(filtered, final_dir)                                            # :99-104

@@ -655,6 +655,85 @@ int vsv_support_cov_del(vsv_handle* h, const int32_t* call_start, const int32_t*
   return cov_common(h, ca, 2, n_calls, sa, 3, n_sigs, flanking, on_device, cov, true);
 }
 
+int vsv_default_redundancy_params(vsv_redundancy_params* p) {
+  if (!p) return VSV_E_INVALID;
+  p->dist_thresh = 500; p->dist_thresh_del = 3000; p->overlap_thresh = 0.0; p->size_sim_thresh = 0.5;    // RR:9-14
+  p->size_sim_thresh_del = 0.1; p->seq_sim_thresh = 0.5;
+  return 0;
+}
+
+int vsv_redundancy_pairs(vsv_handle* h, int is_del, const int32_t* pos, const int32_t* svlen, const uint8_t* seq, const uint64_t* seq_off,
+                         int64_t n, const vsv_redundancy_params* p, uint32_t* pairs, int64_t cap, int64_t* n_pairs) {
+  if (!h || !p || !n_pairs) return VSV_E_INVALID;
+  *n_pairs = 0;
+  if (n < 0 || n > 0x7FFFFFF0ll) return fail(h, VSV_E_INVALID, "bad call count");
+  if (n == 0) return 0;
+  if (!pos || !svlen || (!is_del && (!seq || !seq_off))) return fail(h, VSV_E_INVALID, "call arrays are NULL");
+  for (int64_t i = 0; i < n; ++i) {
+    if (i + 1 < n && pos[i] > pos[i + 1]) return fail(h, VSV_E_UNSORTED, "calls are not sorted by position");
+    if (svlen[i] <= 0) return fail(h, VSV_E_ZERODIV, "call with |len(REF)-len(ALT)| == 0 (the reference divides by it, RR:88-90)");
+  }
+  if (!is_del)
+    for (uint64_t k = 0; k < seq_off[n]; ++k) if (seq[k] > 15) return fail(h, VSV_E_INVALID, "sequence symbols must be coded 0..15");
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t st = h->stream;
+  int rc;
+  if ((rc = upload(h, h->j_cpos, pos, (size_t)n * 4))) return rc;
+  if ((rc = upload(h, h->j_clen, svlen, (size_t)n * 4))) return rc;
+  if ((rc = ensure(h, h->j_spos, (size_t)n * 4 + 16))) return rc;          // counts
+  if ((rc = ensure(h, h->j_slen, (size_t)n * 4 + 16))) return rc;          // offsets
+  if ((rc = ensure(h, h->j_err, (size_t)(n / 2048 + 4) * 4 + 256))) return rc;   // scan scratch
+  uint32_t *cnt = (uint32_t*)h->j_spos.p, *off = (uint32_t*)h->j_slen.p;
+  const int64_t dist = is_del ? p->dist_thresh_del : p->dist_thresh;
+  const double size_thr = is_del ? p->size_sim_thresh_del : p->size_sim_thresh;
+  vsv_launch_rr_pairs(st, false, (const int32_t*)h->j_cpos.p, (const int32_t*)h->j_clen.p, n, is_del, dist, size_thr, p->overlap_thresh, cnt, off,
+                      nullptr, 0);
+  vsv_scan_u32_exclusive(st, cnt, (int)n, off, (uint32_t*)h->j_err.p);
+  uint32_t last_off = 0, last_cnt = 0;
+  HIPCHK(h, hipMemcpyAsync(&last_off, off + (n - 1), 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipMemcpyAsync(&last_cnt, cnt + (n - 1), 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  const int64_t n_cand = (int64_t)last_off + last_cnt;
+  if (n_cand == 0) return 0;
+  if ((rc = ensure(h, h->j_out, (size_t)n_cand * 8))) return rc;
+  vsv_launch_rr_pairs(st, true, (const int32_t*)h->j_cpos.p, (const int32_t*)h->j_clen.p, n, is_del, dist, size_thr, p->overlap_thresh, cnt, off,
+                      (uint32_t*)h->j_out.p, (uint32_t)n_cand);
+  std::vector<uint32_t> cand((size_t)n_cand * 2);
+  HIPCHK(h, hipMemcpyAsync(cand.data(), h->j_out.p, (size_t)n_cand * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  std::vector<uint8_t> flag((size_t)n_cand, 1);
+  if (!is_del) {
+    // per-pair slice of the delta scratch: only pairs whose shorter string needs more than one super-block (> 4096 symbols)
+    std::vector<uint64_t> hoff((size_t)n_cand, 0);
+    uint64_t hwords = 1;
+    for (int64_t k = 0; k < n_cand; ++k) {
+      const uint64_t la = seq_off[cand[2 * k] + 1] - seq_off[cand[2 * k]], lb = seq_off[cand[2 * k + 1] + 1] - seq_off[cand[2 * k + 1]];
+      const uint64_t m = la < lb ? la : lb, nn = la < lb ? lb : la;
+      if (m > 4096) { hoff[k] = hwords; hwords += 2 * nn; }
+    }
+    if ((rc = upload(h, h->g_qs, seq, (size_t)seq_off[n]))) return rc;
+    if ((rc = upload(h, h->g_off, seq_off, (size_t)(n + 1) * 8))) return rc;
+    if ((rc = upload(h, h->g_qe, hoff.data(), (size_t)n_cand * 8))) return rc;
+    if ((rc = ensure(h, h->g_rs, (size_t)hwords * 4))) return rc;
+    if ((rc = ensure(h, h->g_rev, (size_t)n_cand))) return rc;
+    if ((rc = ensure(h, h->g_re, (size_t)n_cand * 4))) return rc;
+    vsv_launch_rr_edit_sim(st, (const uint32_t*)h->j_out.p, (uint32_t)n_cand, (const uint8_t*)h->g_qs.p, (const uint64_t*)h->g_off.p,
+                           (const uint64_t*)h->g_qe.p, (int32_t*)h->g_rs.p, p->seq_sim_thresh, (uint8_t*)h->g_rev.p, (uint32_t*)h->g_re.p);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(flag.data(), h->g_rev.p, (size_t)n_cand, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+  }
+  int64_t m = 0;
+  for (int64_t k = 0; k < n_cand; ++k) m += flag[k] ? 1 : 0;
+  h->last_count = m;
+  *n_pairs = m;
+  if (m > cap) return fail(h, VSV_E_CAPACITY, "pair buffer too small");
+  if (m && !pairs) return fail(h, VSV_E_INVALID, "pairs is NULL");
+  int64_t w = 0;
+  for (int64_t k = 0; k < n_cand; ++k) if (flag[k]) { pairs[2 * w] = cand[2 * k]; pairs[2 * w + 1] = cand[2 * k + 1]; ++w; }
+  return 0;
+}
+
 int vsv_last_scan_ms(vsv_handle* h, float* ms) {
   if (!h || !ms || !h->have_scan_ev) return VSV_E_INVALID;
   HIPCHK(h, hipEventSynchronize(h->ev1));

@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .abi import (BND_DTYPE, T_BND_CALLS, T_BND_CAND, T_CUTESV_SPLIT, BndParams, SupportParams, CALL_DTYPE, SIG_DTYPE, T_CALLS, T_CIGAR, T_CLUSTER1, T_MERGED, T_RAW, T_READS, T_SPLIT, DTYPE_BY_NAME,
+from .abi import (BND_DTYPE, T_BND_CALLS, T_BND_CAND, T_CUTESV_SPLIT, BndParams, RedundancyParams, SupportParams, CALL_DTYPE, SIG_DTYPE, T_CALLS, T_CIGAR, T_CLUSTER1, T_MERGED, T_RAW, T_READS, T_SPLIT, DTYPE_BY_NAME,
                   DTYPE_CUTESV, DTYPE_READS, DTYPE_SVIM, Params, Records, VsvError)
 
 _TABLE_IDS = {"raw": T_RAW, "cigar": T_CIGAR, "split": T_SPLIT, "cluster1": T_CLUSTER1, "merged": T_MERGED,
@@ -156,6 +156,37 @@ class Engine:
         self._check(self.lib.vsv_cutesv_split(self.h, C.byref(s), rl.ctypes.data_as(C.c_void_p), rr.ctypes.data_as(C.c_void_p), int(sv_size),
                                               int(max_size), int(max_split_parts)))
         return self.table("cutesv_split")
+
+    def redundancy_params(self, **kw):
+        p = RedundancyParams()
+        self._check(self.lib.vsv_default_redundancy_params(C.byref(p)))
+        for k, v in kw.items():
+            if v is not None:
+                setattr(p, k, v)
+        return p
+
+    def redundancy_pairs(self, is_del, pos, svlen, seq=None, seq_off=None, params=None):
+        """remove_redundancy.py match_del_chr / match_ins_chr for the calls of one chromosome (ascending pos): the matching
+        pairs i < j as an (n_pairs, 2) uint32 array. seq/seq_off: concatenated ALT strings coded 0..15 (INS only)."""
+        p = params or self.redundancy_params()
+        pos = np.ascontiguousarray(pos, dtype=np.int32)
+        svlen = np.ascontiguousarray(svlen, dtype=np.int32)
+        if not is_del:
+            seq = np.ascontiguousarray(seq, dtype=np.uint8)
+            seq_off = np.ascontiguousarray(seq_off, dtype=np.uint64)
+        cap = max(1024, 4 * len(pos))
+        while True:
+            out = np.zeros((cap, 2), dtype=np.uint32)
+            n = C.c_int64()
+            st = self.lib.vsv_redundancy_pairs(self.h, 1 if is_del else 0, pos.ctypes.data_as(C.c_void_p), svlen.ctypes.data_as(C.c_void_p),
+                                               None if is_del else seq.ctypes.data_as(C.c_void_p),
+                                               None if is_del else seq_off.ctypes.data_as(C.c_void_p), len(pos), C.byref(p),
+                                               out.ctypes.data_as(C.c_void_p), cap, C.byref(n))
+            if st == -6 and n.value > cap:          # VSV_E_CAPACITY: retry with the reported size
+                cap = int(n.value)
+                continue
+            self._check(st)
+            return out[: n.value]
 
     def support_params(self, **kw):
         p = SupportParams()
