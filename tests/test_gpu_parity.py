@@ -261,6 +261,39 @@ def test_full_size_config2_properties(eng):
     torch.cuda.empty_cache()
 
 
+def test_full_size_config3_properties():
+    """BASELINE.json config 3 at full size (50 M ONT-like records, ~9.1e9 CIGAR ops, 38 GB device-resident): determinism,
+    sortedness of the call table, and bit-exact tables for a 200 k-record prefix against the CPU oracle."""
+    import torch
+    from volcanosv_amd import synth
+    from volcanosv_amd.abi import DTYPE_ONT
+    from volcanosv_amd.engine import DeviceRecords, Engine, default_params
+    t, nq, nt = synth.generate(50_000_000, "ont", seed=20250331, device="cuda")
+    assert t["cigar"].numel() > 9_000_000_000
+    p = default_params(DTYPE_ONT)
+    with Engine(0, max_sigs=1 << 23) as e:
+        dr = DeviceRecords(t, nq, nt, max_pos=synth.CHR10_LEN + 200000)
+        e.run(dr, p)
+        a = {k: e.table(k) for k in ("raw", "calls")}
+        e.run(dr, p)
+        b = {k: e.table(k) for k in ("raw", "calls")}
+        assert_tables_equal(a, b, ["raw", "calls"])
+        assert len(a["raw"]) > 500_000 and len(a["calls"]) > 300_000
+        key = a["calls"]["sig"]["tid"].astype(np.int64) << 32 | a["calls"]["sig"]["pos"].astype(np.int64)
+        assert np.all(np.diff(key) >= 0)
+        k = 200_000
+        n_ops = int(t["cigar_off"][k])
+        sl = {name: (v[: k + 1] if name == "cigar_off" else v[:n_ops] if name == "cigar" else v[:k]) for name, v in t.items()}
+        nq_k = int(sl["qid"].max()) + 1
+        e.run(DeviceRecords(sl, nq_k, nt, max_pos=synth.CHR10_LEN + 200000), p)
+        got = e.tables(DTYPE_ONT)
+        st, want = oracle_run(synth.to_soa({n: v.cpu() for n, v in sl.items()}, nq_k), DTYPE_ONT, p)
+        assert st == 0
+        assert_tables_equal(got, want, list(got.keys()))
+    del t, sl
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("name", ["bnd_a", "bnd_b"])
 def test_bnd_branch_golden(eng, name):
     """Complex_SV breakend branch: HIP kernels vs the oracle (bit-exact rows) and vs the svim-asm reference outputs."""
