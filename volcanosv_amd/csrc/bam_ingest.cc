@@ -17,6 +17,8 @@
 #include <unordered_map>
 #include <vector>
 
+#include <chrono>
+
 #include "../../include/volcanosv.h"
 
 struct vsv_bam {
@@ -192,8 +194,39 @@ int64_t vsv_bam_ref_len(vsv_bam* b, int i) { return (b && i >= 0 && i < (int)b->
 
 /* Loads every record with refID == tid (tid < 0: all mapped-or-placed records) in file order into library-owned
  * arrays and fills `out` with host pointers to them. qids are dense in first-appearance order; the hp flag bits come
- * from the substring test of H:392 ('hp1' in qname / 'hp2' in qname). Records are parsed in place from the inflated
- * byte queue; names go through an open-addressing table over one name blob (no per-record allocations). */
+ * from the substring test of H:392 ('hp1' in qname / 'hp2' in qname).
+ * Per window of inflated bytes: (1) a sequential hop over the 4-byte block_size fields finds the record starts and sizes
+ * the output arrays, (2) the worker threads fill the fixed fields, copy CIGAR / SEQ, walk the tags (SA:Z, CG:B,I) and hash
+ * the names, (3) a sequential pass interns the names (first-appearance ids need file order) and appends the SA text. */
+namespace {
+struct RecRef { size_t off; uint32_t size; uint32_t n_cig_out; uint64_t cig_off; uint64_t seq_off; };
+struct RecAux { uint64_t name_hash; const char* sa; uint32_t sa_len; const uint8_t* cg_long; };
+
+// walks the tag area of one record; returns false on an unknown tag type
+bool walk_tags(const uint8_t* rec, size_t off, size_t block_size, const char** sa_p, uint32_t* sa_len, const uint8_t** cg_long, uint32_t* n_long) {
+  while (off + 3 <= block_size) {
+    const char t0 = rec[off], t1 = rec[off + 1], ty = rec[off + 2];
+    off += 3;
+    size_t len = 0;
+    switch (ty) {
+      case 'A': case 'c': case 'C': len = 1; break;
+      case 's': case 'S': len = 2; break;
+      case 'i': case 'I': case 'f': len = 4; break;
+      case 'Z': case 'H': { size_t e = off; while (e < block_size && rec[e]) ++e; if (t0 == 'S' && t1 == 'A' && ty == 'Z') { *sa_p = (const char*)&rec[off]; *sa_len = (uint32_t)(e - off); } len = e - off + 1; break; }
+      case 'B': {
+        const char sub = rec[off]; uint32_t cnt; memcpy(&cnt, &rec[off + 1], 4);
+        const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+        if (t0 == 'C' && t1 == 'G' && sub == 'I') { *cg_long = &rec[off + 5]; *n_long = cnt; }
+        len = 5 + es * cnt; break;
+      }
+      default: return false;
+    }
+    off += len;
+  }
+  return true;
+}
+}  // namespace
+
 int vsv_bam_load(vsv_bam* b, int tid, vsv_records* out) {
   if (!b || !out) return VSV_E_INVALID;
   // rewind and skip the header again (simple and index-free)
@@ -217,84 +250,141 @@ int vsv_bam_load(vsv_bam* b, int tid, vsv_records* out) {
     for (const Slot& s : table) if (s.id != 0xFFFFFFFFu) { size_t i = s.h & (t2.size() - 1); while (t2[i].id != 0xFFFFFFFFu) i = (i + 1) & (t2.size() - 1); t2[i] = s; }
     table.swap(t2);
   };
+  int nt = b->n_threads > 0 ? b->n_threads : (int)std::thread::hardware_concurrency();
+  if (nt > 16) nt = 16;
+  if (nt < 1) nt = 1;
+  std::vector<RecRef> refs;
+  std::vector<RecAux> aux;
   bool first_rec = true;
+  static const bool timing = getenv("VSV_BAM_TIMING") != nullptr;
+  double t_fill = 0, t_hop = 0, t_par = 0, t_seq = 0;
+  auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   for (;;) {
-    if (!fill(b, 4)) { if (!b->err.empty()) return VSV_E_INVALID; break; }
-    int32_t block_size;
-    memcpy(&block_size, b->buf.data() + b->rd, 4);
-    if (block_size < 32) { b->err = "bad BAM record size"; return VSV_E_INVALID; }
-    if (!fill(b, 4 + (size_t)block_size)) { if (b->err.empty()) b->err = "unexpected end of BAM"; return VSV_E_INVALID; }
-    const uint8_t* rec = b->buf.data() + b->rd + 4;
-    b->rd += 4 + (size_t)block_size;
-    int32_t refID, pos; memcpy(&refID, &rec[0], 4); memcpy(&pos, &rec[4], 4);
-    if (refID < 0 || (tid >= 0 && refID != tid)) continue;
-    const uint8_t l_read_name = rec[8], mq = rec[9];
-    uint16_t n_cig, fl; memcpy(&n_cig, &rec[12], 2); memcpy(&fl, &rec[14], 2);
-    int32_t l_seq; memcpy(&l_seq, &rec[16], 4);
-    const char* name = (const char*)&rec[32];
-    const uint32_t nlen = l_read_name ? l_read_name - 1u : 0u;
-    const uint8_t* cg = &rec[32 + l_read_name];
-    size_t off = 32 + (size_t)l_read_name + 4u * n_cig + (size_t)((l_seq + 1) / 2) + (size_t)l_seq;
-    // tags: SA:Z and CG:B,I
-    const char* sa_p = nullptr; size_t sa_len = 0;
-    const uint8_t* cg_long = nullptr; uint32_t n_long = 0;
-    while (off + 3 <= (size_t)block_size) {
-      const char t0 = rec[off], t1 = rec[off + 1], ty = rec[off + 2];
-      off += 3;
-      size_t len = 0;
-      switch (ty) {
-        case 'A': case 'c': case 'C': len = 1; break;
-        case 's': case 'S': len = 2; break;
-        case 'i': case 'I': case 'f': len = 4; break;
-        case 'Z': case 'H': { size_t e = off; while (e < (size_t)block_size && rec[e]) ++e; if (t0 == 'S' && t1 == 'A' && ty == 'Z') { sa_p = (const char*)&rec[off]; sa_len = e - off; } len = e - off + 1; break; }
-        case 'B': {
-          const char sub = rec[off]; uint32_t cnt; memcpy(&cnt, &rec[off + 1], 4);
-          size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
-          if (t0 == 'C' && t1 == 'G' && sub == 'I') { cg_long = &rec[off + 5]; n_long = cnt; }
-          len = 5 + es * cnt; break;
+    double tq = now();
+    // ---- make the next window available (at least one whole record, or EOF) -----------------------------------
+    if (b->buf.size() - b->rd < 4) { if (!fill(b, 4)) { if (!b->err.empty()) return VSV_E_INVALID; break; } }
+    {
+      int32_t bs; memcpy(&bs, b->buf.data() + b->rd, 4);
+      if (bs < 32) { b->err = "bad BAM record size"; return VSV_E_INVALID; }
+      if (!fill(b, 4 + (size_t)bs)) { if (b->err.empty()) b->err = "unexpected end of BAM"; return VSV_E_INVALID; }
+    }
+    t_fill += now() - tq; tq = now();
+    // ---- (1) hop scan ---------------------------------------------------------------------------------------
+    refs.clear();
+    const uint8_t* base = b->buf.data();
+    const size_t end = b->buf.size();
+    size_t rd = b->rd;
+    uint64_t cig_total = b->cigar.size(), seq_total = b->seq.size();
+    while (rd + 4 <= end) {
+      int32_t bs; memcpy(&bs, base + rd, 4);
+      if (bs < 32) { b->err = "bad BAM record size"; return VSV_E_INVALID; }
+      if (rd + 4 + (size_t)bs > end) break;                       // partial record: next window
+      const uint8_t* rec = base + rd + 4;
+      int32_t refID; memcpy(&refID, &rec[0], 4);
+      if (!(refID < 0 || (tid >= 0 && refID != tid))) {
+        uint16_t n_cig; memcpy(&n_cig, &rec[12], 2);
+        int32_t l_seq; memcpy(&l_seq, &rec[16], 4);
+        uint32_t n_out = n_cig;
+        if (n_cig == 2) {                                         // possible CG:B,I long CIGAR (htslib: kSmN placeholder)
+          const uint8_t l_read_name = rec[8];
+          const char* sp = nullptr; uint32_t sl = 0; const uint8_t* cgl = nullptr; uint32_t nl = 0;
+          const size_t toff = 32 + (size_t)l_read_name + 8u + (size_t)((l_seq + 1) / 2) + (size_t)l_seq;
+          if (!walk_tags(rec, toff, (size_t)bs, &sp, &sl, &cgl, &nl)) { b->err = "unknown BAM tag type"; return VSV_E_INVALID; }
+          if (cgl) n_out = nl;
         }
-        default: b->err = "unknown BAM tag type"; return VSV_E_INVALID;
+        refs.push_back(RecRef{rd + 4, (uint32_t)bs, n_out, cig_total, seq_total});
+        cig_total += n_out;
+        if (b->keep_seq && l_seq > 0) seq_total += (uint64_t)((l_seq + 1) / 2);
       }
-      off += len;
+      rd += 4 + (size_t)bs;
     }
-    // name -> dense id (FNV-1a)
-    uint64_t h = 1469598103934665603ull;
-    for (uint32_t k = 0; k < nlen; ++k) { h ^= (uint8_t)name[k]; h *= 1099511628211ull; }
-    size_t si = h & (table.size() - 1);
-    uint32_t q = 0xFFFFFFFFu;
-    for (;;) {
-      Slot& s = table[si];
-      if (s.id == 0xFFFFFFFFu) {
-        q = (uint32_t)n_names++;
-        if (q) b->qname_blob.push_back('\n');
-        s = Slot{h, (uint32_t)b->qname_blob.size(), nlen, q};
-        b->qname_blob.append(name, nlen);
-        if (n_names * 2 > table.size()) grow();
-        break;
+    b->rd = rd;
+    const size_t n0 = b->pos.size(), nw = refs.size();
+    t_hop += now() - tq; tq = now();
+    if (nw) {
+      b->pos.resize(n0 + nw); b->tid.resize(n0 + nw); b->qid.resize(n0 + nw); b->mapq.resize(n0 + nw); b->flag.resize(n0 + nw);
+      b->l_seq.resize(n0 + nw); b->sam_flag.resize(n0 + nw); b->cigar_off.resize(n0 + nw + 1);
+      b->cigar.resize(cig_total); b->seq.resize(seq_total);
+      aux.resize(nw);
+      // ---- (2) parallel field parse ---------------------------------------------------------------------------
+      std::atomic<size_t> next{0};
+      std::atomic<bool> ok{true};
+      auto work = [&]() {
+        for (;;) {
+          const size_t c0 = next.fetch_add(4096);
+          if (c0 >= nw) break;
+          const size_t c1 = c0 + 4096 < nw ? c0 + 4096 : nw;
+          for (size_t k = c0; k < c1; ++k) {
+            const RecRef& r = refs[k];
+            const uint8_t* rec = base + r.off;
+            const size_t i = n0 + k;
+            int32_t refID, pos; memcpy(&refID, &rec[0], 4); memcpy(&pos, &rec[4], 4);
+            const uint8_t l_read_name = rec[8], mq = rec[9];
+            uint16_t n_cig, fl; memcpy(&n_cig, &rec[12], 2); memcpy(&fl, &rec[14], 2);
+            int32_t l_seq; memcpy(&l_seq, &rec[16], 4);
+            const char* name = (const char*)&rec[32];
+            const uint32_t nlen = l_read_name ? l_read_name - 1u : 0u;
+            const uint8_t* cg = &rec[32 + l_read_name];
+            const uint8_t* sq = cg + 4u * n_cig;
+            RecAux a{1469598103934665603ull, nullptr, 0, nullptr};
+            uint32_t n_long = 0;
+            if (!walk_tags(rec, 32 + (size_t)l_read_name + 4u * n_cig + (size_t)((l_seq + 1) / 2) + (size_t)l_seq, r.size, &a.sa, &a.sa_len,
+                           &a.cg_long, &n_long)) { ok = false; continue; }
+            for (uint32_t c = 0; c < nlen; ++c) { a.name_hash ^= (uint8_t)name[c]; a.name_hash *= 1099511628211ull; }   // FNV-1a
+            uint8_t f8 = 0;
+            if (fl & 0x10) f8 |= VSV_F_REVERSE;
+            if (fl & 0x800) f8 |= VSV_F_SUPP;
+            if (fl & 0x100) f8 |= VSV_F_SECONDARY;
+            if (fl & 0x4) f8 |= VSV_F_UNMAPPED;
+            for (uint32_t c = 0; c + 3 <= nlen; ++c)   // 'hp1' in qname / 'hp2' in qname (H:392)
+              if (name[c] == 'h' && name[c + 1] == 'p') { if (name[c + 2] == '1') f8 |= VSV_F_HP1; else if (name[c + 2] == '2') f8 |= VSV_F_HP2; }
+            b->pos[i] = pos; b->tid[i] = refID; b->mapq[i] = mq; b->flag[i] = f8; b->l_seq[i] = (uint32_t)l_seq; b->sam_flag[i] = fl;
+            if (a.cg_long && n_cig == 2) memcpy(&b->cigar[r.cig_off], a.cg_long, 4u * (size_t)r.n_cig_out);   // real CIGAR lives in CG:B,I
+            else if (n_cig) memcpy(&b->cigar[r.cig_off], cg, 4u * (size_t)n_cig);
+            b->cigar_off[i + 1] = r.cig_off + r.n_cig_out;
+            if (b->keep_seq && l_seq > 0) memcpy(&b->seq[r.seq_off], sq, (size_t)((l_seq + 1) / 2));
+            aux[k] = a;
+          }
+        }
+      };
+      std::vector<std::thread> pool;
+      const int use = nw < 8192 ? 1 : nt;
+      for (int t = 1; t < use; ++t) pool.emplace_back(work);
+      work();
+      for (auto& th : pool) th.join();
+      if (!ok) { b->err = "unknown BAM tag type"; return VSV_E_INVALID; }
+      t_par += now() - tq; tq = now();
+      // ---- (3) sequential: name interning in file order, SA text -----------------------------------------------
+      for (size_t k = 0; k < nw; ++k) {
+        if (k + 16 < nw) __builtin_prefetch(&table[aux[k + 16].name_hash & (table.size() - 1)]);   // the probe is a cache miss per name
+        const uint8_t* rec = base + refs[k].off;
+        const char* name = (const char*)&rec[32];
+        const uint32_t nlen = rec[8] ? rec[8] - 1u : 0u;
+        const uint64_t h = aux[k].name_hash;
+        size_t si = h & (table.size() - 1);
+        uint32_t q = 0xFFFFFFFFu;
+        for (;;) {
+          Slot& s = table[si];
+          if (s.id == 0xFFFFFFFFu) {
+            q = (uint32_t)n_names++;
+            if (q) b->qname_blob.push_back('\n');
+            s = Slot{h, (uint32_t)b->qname_blob.size(), nlen, q};
+            b->qname_blob.append(name, nlen);
+            if (n_names * 2 > table.size()) grow();
+            break;
+          }
+          if (s.h == h && s.len == nlen && memcmp(b->qname_blob.data() + s.off, name, nlen) == 0) { q = s.id; break; }
+          si = (si + 1) & (table.size() - 1);
+        }
+        b->qid[n0 + k] = q;
+        if (!first_rec) b->sa_blob.push_back('\n');
+        first_rec = false;
+        if (aux[k].sa_len) b->sa_blob.append(aux[k].sa, aux[k].sa_len);
       }
-      if (s.h == h && s.len == nlen && memcmp(b->qname_blob.data() + s.off, name, nlen) == 0) { q = s.id; break; }
-      si = (si + 1) & (table.size() - 1);
+      t_seq += now() - tq;
     }
-    uint8_t f8 = 0;
-    if (fl & 0x10) f8 |= VSV_F_REVERSE;
-    if (fl & 0x800) f8 |= VSV_F_SUPP;
-    if (fl & 0x100) f8 |= VSV_F_SECONDARY;
-    if (fl & 0x4) f8 |= VSV_F_UNMAPPED;
-    for (uint32_t k = 0; k + 3 <= nlen; ++k)   // 'hp1' in qname / 'hp2' in qname (H:392)
-      if (name[k] == 'h' && name[k + 1] == 'p') { if (name[k + 2] == '1') f8 |= VSV_F_HP1; else if (name[k + 2] == '2') f8 |= VSV_F_HP2; }
-    b->pos.push_back(pos); b->tid.push_back(refID); b->qid.push_back(q); b->mapq.push_back(mq); b->flag.push_back(f8);
-    b->l_seq.push_back((uint32_t)l_seq); b->sam_flag.push_back(fl);
-    if (b->keep_seq && l_seq > 0) { const uint8_t* sq = &rec[32 + l_read_name + 4u * n_cig]; b->seq.insert(b->seq.end(), sq, sq + (size_t)((l_seq + 1) / 2)); }
-    if (!first_rec) b->sa_blob.push_back('\n');
-    first_rec = false;
-    if (sa_len) b->sa_blob.append(sa_p, sa_len);
-    if (cg_long && n_cig == 2) {  // real CIGAR lives in the CG tag (htslib convention for > 65535 ops)
-      size_t o = b->cigar.size(); b->cigar.resize(o + n_long); memcpy(&b->cigar[o], cg_long, 4u * n_long);
-    } else {
-      size_t o = b->cigar.size(); b->cigar.resize(o + n_cig); if (n_cig) memcpy(&b->cigar[o], cg, 4u * n_cig);
-    }
-    b->cigar_off.push_back(b->cigar.size());
   }
+  if (timing) fprintf(stderr, "vsv_bam_load: fill(read+inflate) %.3f s, hop scan %.3f s, parallel parse %.3f s, intern %.3f s\n", t_fill, t_hop, t_par, t_seq);
   memset(out, 0, sizeof *out);
   out->n_records = (int64_t)b->pos.size();
   out->n_ops = (int64_t)b->cigar.size();
