@@ -505,7 +505,7 @@ int vsv_cutesv_split(vsv_handle* h, const vsv_segments* sg, const int32_t* read_
   if (sg->n_reads < 0 || sg->n_segs < 0) return fail(h, VSV_E_INVALID, "bad segment counts");
   if (sg->n_reads > 0 && (!read_len || !read_rec || !sg->seg_off)) return fail(h, VSV_E_INVALID, "read arrays are NULL");
   HIPCHK(h, hipSetDevice(h->device));
-  const int64_t rows = 2 * sg->n_segs + sg->n_reads;
+  const int64_t rows = 2 * sg->n_segs + sg->n_reads;    // upper bound of the rows a read can produce, summed
   int st = reserve(h, 1, 1, rows > h->cap_sigs ? rows : (h->cap_sigs > 0 ? h->cap_sigs : (1 << 22)));
   if (st) return st;
   vsv_segments d = *sg;
@@ -527,10 +527,16 @@ int vsv_cutesv_split(vsv_handle* h, const vsv_segments* sg, const int32_t* read_
     rl = (const int32_t*)h->g_len.p; rr = (const uint32_t*)h->g_rank.p;
   }
   { int rs = reset_run_state(h); if (rs) return rs; }
-  vsv_launch_cutesv_split(h->stream, d, rl, rr, sv_size, max_size, max_split_parts, (vsv_sig*)h->c2.p, (uint32_t)h->cap_sigs, dctr(h));
+  if ((st = ensure(h, h->j_spos, (size_t)sg->n_reads * 4 + 16))) return st;      // rows per read
+  if ((st = ensure(h, h->j_slen, (size_t)sg->n_reads * 4 + 16))) return st;      // their exclusive scan
+  if ((st = ensure(h, h->j_err, (size_t)(sg->n_reads / 2048 + 4) * 4 + 256))) return st;
+  if (sg->n_reads > 0)
+    vsv_launch_cutesv_split(h->stream, d, rl, rr, sv_size, max_size, max_split_parts, (vsv_sig*)h->c2.p, (uint32_t)h->cap_sigs,
+                            (uint32_t*)h->j_spos.p, (uint32_t*)h->j_slen.p, (uint32_t*)h->j_err.p, dctr(h));
   HIPCHK(h, hipGetLastError());
-  h->cutesv_rows = rows;
-  return finish(h);
+  st = finish(h);
+  h->cutesv_rows = sg->n_reads > 0 ? (int64_t)h->host_ctr.n_alive2 : 0;
+  return st;
 }
 
 int vsv_bnd_set_candidates(vsv_handle* h, const vsv_bnd* rows, int64_t n, const int32_t* contig_rank, int32_t n_tids, int on_device) {
@@ -754,7 +760,7 @@ static int table_src(vsv_handle* h, int table, const void** src, int64_t* n_rows
     case VSV_T_CALLS: if (h->stage_done < 5) return VSV_E_INVALID; *src = h->calls.p; *n_rows = c.n_calls; *row = sizeof(vsv_call); *filter = false; return 0;
     case VSV_T_BND_CAND: if (h->bnd_stage < 1) return VSV_E_INVALID; *src = h->s1in.p; *n_rows = c.n_s1; return 0;
     case VSV_T_BND_CALLS: if (h->bnd_stage < 2) return VSV_E_INVALID; *src = h->c1.p; *n_rows = c.n_alive1; return 0;
-    case VSV_T_CUTESV_SPLIT: if (h->cutesv_rows < 0) return VSV_E_INVALID; *src = h->c2.p; *n_rows = h->cutesv_rows; return 0;
+    case VSV_T_CUTESV_SPLIT: if (h->cutesv_rows < 0) return VSV_E_INVALID; *src = h->c2.p; *n_rows = h->cutesv_rows; *filter = false; return 0;
     case VSV_T_READS: if (h->stage_done < 2 || h->prm.dtype != VSV_DTYPE_READS) return VSV_E_INVALID; *src = h->reads.p; *n_rows = c.n_reads; *filter = false; return 0;
   }
   return VSV_E_INVALID;

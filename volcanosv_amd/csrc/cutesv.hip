@@ -4,8 +4,8 @@
 // organize_split_signal SE:341-371) are ordered by read start with a stable insertion sort (sorted(), SE:198), then the
 // two-segment rule (SE:206-236) or the triple scan (SE:242-296) and the INS-in-translocation rule (SE:298-319) run exactly
 // as written; the TRA/BND candidates (analysis_bnd) are not produced — the collector keeps only `grep -w INS|DEL` lines
-// (SE:637-638). Latency-bound, a few dozen integers per read. Rows go to fixed per-read slots (2*seg_off[r] + r ...), so the
-// table order is (read, emission order) whatever the lane order.
+// (SE:637-638). Latency-bound, a few dozen integers per read. Count pass -> exclusive scan -> write pass, so the table is dense
+// and in (read, emission) order whatever the lane order.
 #include "vsv_device.h"
 
 namespace {
@@ -15,8 +15,9 @@ struct CSeg { int64_t qs, qe, rs, re; int32_t chr; int32_t rev; };
 __device__ __forceinline__ CSeg cflip(const CSeg& x, int64_t rl) { CSeg y = x; y.qs = rl - x.qe; y.qe = rl - x.qs; return y; }   // SE:213-214
 
 struct CEmit {
-  vsv_sig* out; uint32_t base, n, cap_local; uint32_t rec;
+  vsv_sig* out; uint32_t base, n, cap_local; uint32_t rec;   // out == nullptr: counting pass
   __device__ void put(bool del, int64_t pos, int64_t len, int64_t s0, int64_t s1, int32_t chr, int qrev) {
+    if (!out) { ++n; return; }
     if (n >= cap_local) return;
     vsv_sig s;
     s.pos = (int32_t)pos; s.svlen = (int32_t)len; s.q_start = (int32_t)s0; s.q_end = (int32_t)s1;
@@ -43,18 +44,21 @@ __device__ void pair_rule(const CSeg& e1, const CSeg& e2, const CSeg* e3, int64_
 
 constexpr int CS_MAX_SEG = 64;
 
+// Two passes: WRITE = false counts the rows of every read (cnt[r]); after an exclusive scan WRITE = true stores them at off[r],
+// so the table is dense and in (read, emission) order.
+template <bool WRITE>
 __global__ __launch_bounds__(64) void cutesv_split(vsv_segments sg, const int32_t* __restrict__ read_len, const uint32_t* __restrict__ read_rec,
                                                    int sv_size, int max_size, int max_parts, vsv_sig* __restrict__ out, uint32_t cap,
-                                                   Counters* ctr) {
+                                                   uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, Counters* ctr) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= sg.n_reads) return;
   const uint64_t a = sg.seg_off[r], b = sg.seg_off[r + 1];
   const uint32_t n = (uint32_t)(b - a);
-  const uint64_t base64 = 2 * a + (uint64_t)r, slots = 2 * (uint64_t)n + 1;
-  if (base64 + slots > cap) { atomicOr(&ctr->err, ERRB_CAPACITY); return; }
-  for (uint64_t k = 0; k < slots; ++k) out[base64 + k].meta = VSV_M_DEAD;
+  if (!WRITE) cnt[r] = 0;
   if (!(n <= (uint32_t)max_parts || max_parts == -1)) return;         // SE:370
   if (n > CS_MAX_SEG) { atomicOr(&ctr->err, ERRB_RANGE); return; }
+  const uint64_t base64 = WRITE ? off[r] : 0, slots = WRITE ? cnt[r] : 0xFFFFFFFFull;
+  if (WRITE && base64 + slots > cap) { atomicOr(&ctr->err, ERRB_CAPACITY); return; }
   uint8_t idx[CS_MAX_SEG];
   for (uint32_t k = 0; k < n; ++k) {                                   // stable insertion sort by read start (SE:198)
     const int32_t key = sg.q_start[a + k];
@@ -68,7 +72,7 @@ __global__ __launch_bounds__(64) void cutesv_split(vsv_segments sg, const int32_
     return s;
   };
   const int64_t rl = read_len[r], sv = sv_size, mx = max_size;
-  CEmit em{out, (uint32_t)base64, 0u, (uint32_t)slots, read_rec[r]};
+  CEmit em{WRITE ? out : nullptr, (uint32_t)base64, 0u, (uint32_t)slots, read_rec[r]};
   int trigger = 0, qrev = 0;
   if (n == 2) {
     CSeg e1 = seg(0), e2 = seg(1);
@@ -100,12 +104,22 @@ __global__ __launch_bounds__(64) void cutesv_split(vsv_segments sg, const int32_
       }
     }
   }
+  if (!WRITE) cnt[r] = em.n;
 }
 
 }  // namespace
 
+__global__ void cutesv_set_rows(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, int64_t n_reads, Counters* ctr) {
+  ctr->n_alive2 = off[n_reads - 1] + cnt[n_reads - 1];
+}
+
 void vsv_launch_cutesv_split(hipStream_t st, const vsv_segments& sg, const int32_t* read_len, const uint32_t* read_rec, int sv_size,
-                             int max_size, int max_parts, vsv_sig* out, uint32_t cap, Counters* ctr) {
+                             int max_size, int max_parts, vsv_sig* out, uint32_t cap, uint32_t* cnt, uint32_t* off, uint32_t* scan_tmp,
+                             Counters* ctr) {
   if (sg.n_reads <= 0) return;
-  cutesv_split<<<(int)((sg.n_reads + 63) / 64), 64, 0, st>>>(sg, read_len, read_rec, sv_size, max_size, max_parts, out, cap, ctr);
+  const int grid = (int)((sg.n_reads + 63) / 64);
+  cutesv_split<false><<<grid, 64, 0, st>>>(sg, read_len, read_rec, sv_size, max_size, max_parts, out, cap, cnt, off, ctr);
+  vsv_scan_u32_exclusive(st, cnt, (int)sg.n_reads, off, scan_tmp);
+  cutesv_split<true><<<grid, 64, 0, st>>>(sg, read_len, read_rec, sv_size, max_size, max_parts, out, cap, cnt, off, ctr);
+  cutesv_set_rows<<<1, 1, 0, st>>>(cnt, off, sg.n_reads, ctr);
 }

@@ -9,10 +9,24 @@
 
 namespace {
 
-__device__ __forceinline__ int64_t lower_bound_pos(const int32_t* __restrict__ a, int64_t n, int64_t t) {   // first a[j] >= t
-  int64_t lo = 0, hi = n;
-  while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((int64_t)a[mid] >= t) hi = mid; else lo = mid + 1; }
-  return lo;
+// Wave-cooperative lower bound (first j with a[j] >= t): every round the 64 lanes probe 64 evenly spaced elements of the live
+// range, so a 2 M-element list needs 4 dependent loads instead of 21 — the joins are bound by exactly that latency chain.
+__device__ __forceinline__ int64_t wave_lower_bound(const int32_t* __restrict__ a, int64_t n, int64_t t, int lane) {
+  int64_t lo = 0, hi = n;                                   // answer in [lo, hi]
+  while (hi - lo > 64) {
+    const int64_t step = (hi - lo + 63) / 64;
+    const int64_t p = lo + (int64_t)lane * step;
+    const bool ge = p >= hi || (int64_t)a[p] >= t;
+    const uint64_t m = __ballot(ge);
+    if (m & 1ull) return lo;                                // a[lo] >= t
+    const int f = m ? __builtin_ctzll(m) : 64;              // first probe that is >= t (64: none)
+    const int64_t new_lo = lo + (int64_t)(f - 1) * step + 1;
+    if (f < 64) { const int64_t ph = lo + (int64_t)f * step; hi = ph < hi ? ph : hi; }
+    lo = new_lo;
+  }
+  const int64_t p = lo + lane;
+  const bool lt = p < hi && (int64_t)a[p] < t;
+  return lo + (int64_t)__popcll(__ballot(lt));
 }
 
 __global__ __launch_bounds__(256) void support_join(const int32_t* __restrict__ cpos, const int32_t* __restrict__ clen, int64_t nc,
@@ -30,8 +44,8 @@ __global__ __launch_bounds__(256) void support_join(const int32_t* __restrict__ 
     const int32_t len1 = clen[i];
     if (len1 > p.max_comp_svlen) { if (lane == 0) support[i] = 60u; continue; }      // FP:110-111
     const int64_t pos1 = cpos[i];
-    const int64_t lo = lower_bound_pos(spos, ns, pos1 - (int64_t)p.max_dist);          // shift < -max_dist: continue
-    const int64_t hi = lower_bound_pos(spos, ns, pos1 + (int64_t)p.max_dist + 1);      // shift >  max_dist: break
+    const int64_t lo = wave_lower_bound(spos, ns, pos1 - (int64_t)p.max_dist, lane);          // shift < -max_dist: continue
+    const int64_t hi = wave_lower_bound(spos, ns, pos1 + (int64_t)p.max_dist + 1, lane);      // shift >  max_dist: break
     uint32_t cnt = 0;
     for (int64_t j0 = lo; j0 < hi; j0 += 64) {
       const int64_t j = j0 + lane;
@@ -69,8 +83,8 @@ __global__ __launch_bounds__(256) void cov_ins(const int32_t* __restrict__ cpos,
   const int lane = threadIdx.x & 63;
   for (int64_t i = gtid >> 6; i < nc; i += gsz >> 6) {
     const int64_t pos = cpos[i];
-    const int64_t lo = lower_bound_pos(spos, ns, pos - (int64_t)flanking);        // lb > pos: break (CS:105-106)
-    const int64_t hi = lower_bound_pos(spos, ns, pos + (int64_t)flanking + 1);    // pos <= rb (CS:107)
+    const int64_t lo = wave_lower_bound(spos, ns, pos - (int64_t)flanking, lane);        // lb > pos: break (CS:105-106)
+    const int64_t hi = wave_lower_bound(spos, ns, pos + (int64_t)flanking + 1, lane);    // pos <= rb (CS:107)
     int64_t sum = 0;
     for (int64_t j = lo + lane; j < hi; j += 64) sum += (int64_t)slen[j];
     sum = wave_sum_i64(sum);
@@ -106,8 +120,8 @@ __global__ __launch_bounds__(256) void cov_del(const int32_t* __restrict__ cstar
   const int64_t max_span = err[1];
   for (int64_t i = gtid >> 6; i < nc; i += gsz >> 6) {
     const int64_t lb = (int64_t)cstart[i] - flanking, rb = (int64_t)cend[i] + flanking;   // CS:154
-    const int64_t lo = lower_bound_pos(sstart, ns, lb - max_span);
-    const int64_t hi = lower_bound_pos(sstart, ns, rb + 1);
+    const int64_t lo = wave_lower_bound(sstart, ns, lb - max_span, lane);
+    const int64_t hi = wave_lower_bound(sstart, ns, rb + 1, lane);
     int64_t sum = 0;
     for (int64_t j = lo + lane; j < hi; j += 64)
       if ((int64_t)send[j] >= lb) sum += (int64_t)svlen[j];
