@@ -45,7 +45,7 @@ struct vsv_handle {
   DevBuf j_cpos, j_clen, j_spos, j_slen, j_send, j_out, j_err;   // support join (post-filter)
   int pass_cursor = 0;
   const uint64_t* sorted_key = nullptr;   // sorted keys of the stage just sorted (cluster / pair read them)
-  bool fused_sort = true;          // small-input sort mode, re-decided after every run from its row counts
+  bool small_sort_tiles = true;    // radix tile size, re-decided after every run from its row counts
   Counters host_ctr;
   Counters* pinned = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -172,9 +172,9 @@ constexpr int MAX_SORT_PASSES = 64;
 SortWork sort_work(vsv_handle* h) {
   SortWork w;
   w.key_alt = (uint64_t*)h->key_alt.p; w.val_alt = (uint32_t*)h->val_alt.p; w.hist = (uint32_t*)h->hist.p; w.max_items = h->cap_sigs;
-  w.totals = (uint32_t*)h->totals.p; w.pass_cursor = &h->pass_cursor; w.max_passes = MAX_SORT_PASSES; w.fused = h->fused_sort;
+  w.totals = (uint32_t*)h->totals.p; w.pass_cursor = &h->pass_cursor; w.max_passes = MAX_SORT_PASSES; w.small_tiles = h->small_sort_tiles;
   static const char* force = getenv("VSV_SORT_TILE");   // timing experiments: "big" / "small"
-  if (force) w.fused = force[0] == 's';
+  if (force) w.small_tiles = force[0] == 's';
   return w;
 }
 // zero the device counters and the per-pass sort totals: start of every run
@@ -267,9 +267,9 @@ int finish(vsv_handle* h) {
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->host_ctr = *h->pinned;
   h->pending = false;
-  {  // sort mode of the NEXT run: fused scatter while the largest table stays within ~128 tiles of 4096 rows
+  {  // sort tile size of the NEXT run: small tiles while the largest table stays within ~128 tiles of 4096 rows
     const uint32_t big = h->host_ctr.n_s1 > h->host_ctr.n_cand ? h->host_ctr.n_s1 : h->host_ctr.n_cand;
-    h->fused_sort = big <= 128u * 4096u;
+    h->small_sort_tiles = big <= 128u * 4096u;
   }
   const uint32_t e = h->host_ctr.err;
   h->last_count = h->host_ctr.n_pool;

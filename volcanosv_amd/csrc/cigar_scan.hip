@@ -10,17 +10,18 @@
 //    ops at record boundaries (binary search over cigar_off); one wavefront owns one part, so no
 //    inter-wave communication exists anywhere in K1.
 //  * A wave walks its part in 256-op chunks: every lane loads one aligned dwordx4 (4 ops, 1 KiB per
-//    wave-instruction, fully coalesced), decodes the 4 ops with bit-field extracts against constant op
-//    masks, and the wave takes ONE plain (unsegmented) DPP prefix sum of the (ref,query) advances.
-//    Arithmetic is mod 2^32, so differences of prefix values are exact.
-//  * Record boundaries never enter the vector path. Up to 64 records of the part sit one-per-lane in
-//    registers (start offset, pos); the scalar unit tracks the record that is open at the chunk edge
-//    (ballot + popcount + v_readlane) and its prefix base. A signature's reference position is
-//    pos[rec] + (P(op) - P(record start)).
-//  * Emission (>= min_svlen I/D ops, ~1 per 100 records) is a wave-uniform slow path: ballot, then a
-//    scalar loop per emitting op that finds the record (ballot over lane-held starts), applies the
-//    mapq/hp filters and appends to a pool with one atomic. Each row carries (part, ordinal), and
-//    place_raw scatters rows to part_off[part]+ordinal, so T_RAW is in (record, op) order whatever
+//    wave-instruction, fully coalesced), four chunks in flight. The streaming path only asks "does this chunk
+//    hold an I/D op of at least min_svlen (or an op the table forbids)?": per op one shift of a constant mask,
+//    a sign test and one compare (~25 VALU per chunk), so the kernel is bound by HBM, not by issue slots.
+//  * Everything else is lazy, in a wave-uniform slow path for chunks with a candidate (1 in 14 on read-shaped
+//    input): decode with bit-field extracts against constant op masks, ONE plain (unsegmented) DPP prefix sum
+//    per advance (mod 2^32, differences are exact), record lookup in a 64-record window of the part's
+//    record-start table (LDS), and P(op) - P(record start) through a per-record checkpoint that is advanced at
+//    the end of every slow chunk (a record that started in an earlier chunk re-reads at most the L2-hot chunks
+//    since its checkpoint). A signature's reference position is pos[rec] + (P(op) - P(record start)).
+//  * Emission applies the mapq/hp filters (record header through the scalar cache, kept while consecutive
+//    signatures share the record) and appends to a pool sharded over 256 cursors. Each row carries (part,
+//    ordinal), and place_raw scatters rows to part_off[part]+ordinal, so T_RAW is in (record, op) order whatever
 //    the atomic order was.
 #include <stdlib.h>
 
@@ -115,14 +116,14 @@ __device__ __forceinline__ const void* align4(const void* p) { return (const voi
 
 // ---- K1 ------------------------------------------------------------------------------------------
 // Per-wave state while streaming a part:
-//   chunk grid    256-op chunks on absolute 16-byte boundaries, continuous over the whole part. Three chunks
-//                 (3 KiB per wave) are always in flight: the loop is unrolled by three so no in-flight register is
+//   chunk grid    256-op chunks on absolute 16-byte boundaries, continuous over the whole part. DEPTH chunks
+//                 (DEPTH KiB per wave) are always in flight: the loop is unrolled by DEPTH so no in-flight register is
 //                 ever copied, and chunk loads go through a raw buffer descriptor clipped to the part.
-//   record table  the part's record starts (relative, u32) and positions staged ONCE per part in LDS (wave-private
-//                 slice, K1_RMAX records; parts with more records restage). A 64-record window of the table is the
-//                 "block": lane i <-> record wbase+i. A chunk that straddles two windows is processed twice with
-//                 complementary op masks (segment [seg_lo, seg_hi)).
-//   open record   scalars describing the record that is open at the start of the current segment.
+//   record table  the part's record starts (relative, u32) staged in LDS (wave-private slice, K1_RMAX records; parts
+//                 with more records restage). Only the slow path reads it, through a 64-record window (lane i <->
+//                 record wbase+i) that moves forward with the lookups.
+//   checkpoint    (record, chunk, P(chunk start) - P(record start)) of the record that was open at the end of the last
+//                 slow chunk; the streaming path keeps no running prefix at all.
 constexpr int K1_RMAX = 320;   // record starts staged per wave (8192-op parts of ~33-op reads hold ~250)
 constexpr int K1_WAVES = 4;
 

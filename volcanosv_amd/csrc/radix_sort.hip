@@ -266,7 +266,7 @@ SortResult sort_pairs(hipStream_t st, uint64_t* key, uint32_t* val, uint64_t* ke
 // (e.g. 33 key bits -> 3 passes of 11; 26 bits -> 3 passes of 9). SortWork::small picks the tile size (both exact).
 SortResult vsv_radix_sort_pairs(hipStream_t st, uint64_t* key, uint32_t* val, uint64_t* key_scratch, uint32_t* val_scratch,
                                 const uint32_t* d_n, int64_t max_n, int nbits, const SortWork& w) {
-  return w.fused ? sort_pairs<RS_ROUNDS_SMALL>(st, key, val, key_scratch, val_scratch, d_n, max_n, nbits, w)
+  return w.small_tiles ? sort_pairs<RS_ROUNDS_SMALL>(st, key, val, key_scratch, val_scratch, d_n, max_n, nbits, w)
                  : sort_pairs<RS_ROUNDS_BIG>(st, key, val, key_scratch, val_scratch, d_n, max_n, nbits, w);
 }
 

@@ -87,11 +87,11 @@ struct SortWork {       // scratch for vsv_radix_sort_pairs
   uint32_t* val_alt;
   uint32_t* hist;       // [2048 * max_tiles]
   int64_t max_items;
-  // fused scatter (no scan kernel) for small inputs: per-pass digit totals, zeroed once per run by the caller
+  // per-pass digit totals for the multi-block scan, zeroed once per run by the caller
   uint32_t* totals;     // [max_passes * 2048]
   int* pass_cursor;     // host-side index of the next free totals slot (reset per run)
   int max_passes;
-  bool fused;           // chosen by the caller from the row count of the previous run (both modes are exact)
+  bool small_tiles;     // 1024-row instead of 4096-row tiles; chosen by the caller from the row count of the previous run (both exact)
 };
 struct StageBufs {
   uint64_t* key;        // sort keys of the current stage (kept sorted for cluster / pair kernels)
