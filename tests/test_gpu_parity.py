@@ -116,6 +116,28 @@ def test_multi_tid(eng):
     assert set(np.unique(got["calls"]["sig"]["tid"])) == {0, 1, 2}
 
 
+def test_long_records_with_both_haplotype_tags(eng):
+    """Mb-scale records (every chunk of the scan lies inside one record) whose names carry hp1 AND hp2
+    on every third record (two rows per signature), plus a low-mapq record and the reads / svim / collector op tables."""
+    from volcanosv_amd import synth
+    from volcanosv_amd.abi import DTYPE_CUTESV, DTYPE_READS, DTYPE_SVIM, F_HP1, F_HP2
+    from volcanosv_amd.engine import default_params
+    t, nq, nt = synth.generate(240, "contig", seed=41, chrom_len=60_000_000)
+    t["flag"][::3] |= (F_HP1 | F_HP2)
+    t["mapq"][5] = 3
+    soa = synth.to_soa(t, nq)
+    got = run_both(eng, soa, DTYPE_HIFI)
+    both = np.isin(got["raw"]["rec"], np.arange(0, 240, 3))
+    assert both.sum() > 1000 and ((got["raw"]["meta"][both] & 4) != 0).sum() * 2 == both.sum()
+    for dt in (DTYPE_READS, DTYPE_SVIM, DTYPE_CUTESV):
+        p = default_params(dt)
+        p.enable_split = 0
+        eng.cigar_scan(soa, p)
+        raw = eng.table("raw")
+        st, want = oracle_run(soa, dt, p)
+        assert st == 0 and np.array_equal(raw, want["raw"]) and len(raw) > 1000
+
+
 def test_unaligned_device_views(eng):
     """Device arrays that start in the middle of an allocation (a slice of a larger tensor): the split stage's wide loads
     need 16-byte / 4-byte aligned qid / flag / mapq arrays and must take the element-wise path otherwise."""
