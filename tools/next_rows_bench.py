@@ -13,7 +13,6 @@ import torch  # noqa: E402
 
 from oracle import oracle  # noqa: E402
 from volcanosv_amd import sig_extract, synth  # noqa: E402
-from volcanosv_amd.abi import DTYPE_CUTESV  # noqa: E402
 from volcanosv_amd.engine import DeviceRecords, Engine  # noqa: E402
 
 

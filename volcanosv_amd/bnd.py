@@ -13,7 +13,7 @@ from collections import defaultdict
 
 import numpy as np
 
-from .abi import B_DST_FWD, B_GT_SHIFT, B_HAP2, B_SRC_FWD, Segments
+from .abi import B_DST_FWD, B_GT_SHIFT, B_SRC_FWD, Segments
 
 _CIG = re.compile(r"(\d+)([MIDNSHP=X])")
 _OPS = {"M": 0, "I": 1, "D": 2, "N": 3, "S": 4, "H": 5, "P": 6, "=": 7, "X": 8}

@@ -5,9 +5,12 @@ The per-read work of parse_read (SE:438-493) runs on the GPU: the CIGAR scan wit
 >= min_siglength I/D op) and combined (one row per merged signal: summed length, number of pieces, raw index of the first).
 What stays on the host is text: read names, the inserted sequence (sliced out of the read per piece and concatenated,
 SE:468-469, 397), the `sort -u | sort -k2,2 -k3,3n` of the final files (SE:637-638)."""
+import ctypes as _C
+import re as _re
+
 import numpy as np
 
-from .abi import DTYPE_CUTESV, F_REVERSE, F_SECONDARY, F_SKIP, F_SUPP, F_UNMAPPED, M_DEL
+from .abi import DTYPE_CUTESV, F_REVERSE, F_SECONDARY, F_SKIP, F_SUPP, F_UNMAPPED, M_DEL, M_QREV, Segments
 from .engine import default_params
 
 
@@ -66,11 +69,6 @@ def cigar_candidates(soa, raw, combined, seq_of, chr_name):
 
 
 # ---- split-read branch (organize_split_signal SE:341-371 on the host, analysis_split_read SE:193-319 on the GPU) ---------
-import ctypes as _C
-import re as _re
-
-from .abi import M_QREV, Segments
-
 _CIG = _re.compile(r"(\d+)([MIDNSHP=X])")
 
 
