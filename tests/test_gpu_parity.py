@@ -217,6 +217,41 @@ def test_edge_cases(eng):
     run_both(eng, soa, DTYPE_HIFI)
 
 
+def test_scan_restaging_and_checkpoint_walks(eng):
+    """Shapes that exercise the lazy parts of cigar_scan_emit: (a) thousands of 1-3-op records per 4096-op part (the LDS
+    record table restages and the 64-record lookup window moves many times inside one part), (b) one multi-million-op record
+    whose signatures are thousands of chunks apart (checkpoint walks over long runs of candidate-free chunks), (c) records
+    that start on the last / first op of a 256-op chunk, (d) signatures as first and last op of a part."""
+    rng = np.random.default_rng(77)
+    recs = []
+    pos = 100
+    for i in range(20000):                                    # (a)
+        pos += int(rng.integers(1, 40))
+        k = int(rng.integers(0, 3))
+        cig = [(0, int(rng.integers(1, 60)))]
+        if k >= 1:
+            cig += [(int(rng.integers(1, 3)), int(rng.choice([3, 29, 30, 31, 200]))), (0, int(rng.integers(1, 60)))]
+        if k == 2:
+            cig = [(4, 5)] + cig
+        recs.append((0, pos, "t%d_hp%d" % (i, 1 + i % 2), 60 if i % 11 else 10, bool(i % 2), cig))
+    big = []                                                  # (b)
+    for i in range(1_200_000):
+        big.append((0, int(rng.integers(1, 30))))
+        big.append((1 if i % 2 else 2, 2 if i % 150_000 else 64))
+    big.append((0, 9))
+    recs.append((0, pos + 1000, "big_hp1", 60, False, big))
+    for i in range(600):                                      # (c) op counts 255 / 256 / 257 in rotation
+        n = 255 + i % 3
+        cig = [(0, 2), (2, 30 + i % 5)] * ((n - 1) // 2) + [(0, 2)] * (1 + (n - 1) % 2)
+        recs.append((0, pos + 2000 + i, "c%d_hp2" % i, 60, False, cig))
+    recs.append((0, pos + 5000, "edge_hp1", 60, False, [(1, 50)] + [(0, 3), (2, 1)] * 2047 + [(0, 3), (2, 80)]))   # (d)
+    soa = RecordSoA.from_tuples(recs)
+    got = run_both(eng, soa, DTYPE_HIFI)
+    assert len(got["raw"]) > 5000
+    for dt in (DTYPE_READS,):
+        run_both(eng, soa, dt)
+
+
 def test_error_statuses(eng):
     from volcanosv_amd.engine import default_params
     soa = RecordSoA.from_tuples([(0, 10, "a_hp1", 60, False, [(0, 50), (7, 10), (0, 50)])])
