@@ -93,7 +93,13 @@ def main():
             scan_ms.append(e.scan_ms())
         return engs[(k - 1) % n_streams]
 
-    run_steps(max(args.warmup, n_streams), [])
+    weng = run_steps(max(args.warmup, n_streams), [])
+    if world > 1 and dtype != DTYPE_BY_NAME["READS"]:
+        # warm-up of the gather path as well (the first collective of a shape sets up its channels / staging buffers)
+        if rehearsal:
+            shard.gather_calls(weng.table("calls"), cdev)
+        else:
+            shard.finish_gather(shard.gather_calls(weng.table_torch("calls", dev), dev, to_host=False))
     torch.cuda.synchronize()
     scan_ms = []
     if world > 1:
