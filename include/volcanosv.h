@@ -314,6 +314,13 @@ int vsv_redundancy_pairs(vsv_handle* h, int is_del, const int32_t* pos, const in
                          const uint64_t* seq_off, int64_t n, const vsv_redundancy_params* p, uint32_t* pairs, int64_t cap,
                          int64_t* n_pairs);
 
+/* ---- BGZF inflate on the GPU ------------------------------------------------------------------------------------------
+ * The members of a BGZF file (htslib bgzf.c: independent raw-deflate streams, <= 64 KiB of output each) are decoded one lane
+ * per member. comp = the members' deflate payloads back to back (host), comp_off[n+1] their byte offsets, isize[n] the
+ * uncompressed sizes from the member trailers; out (host) receives sum(isize) bytes in member order. A member that is not a
+ * valid deflate stream of exactly isize bytes fails the call with VSV_E_INVALID (vsv_last_count = its index). */
+int vsv_bgzf_inflate(vsv_handle* h, const uint8_t* comp, const uint64_t* comp_off, const uint32_t* isize, int64_t n_members, uint8_t* out);
+
 /* ---- host-side ingest: BAM/BGZF -> record SoA ----------------------------------------------------
  * Replaces pysam.AlignmentFile(bam).fetch(chr) (H:387-391, RS:108-113). Arrays returned through `out` are owned
  * by the vsv_bam object and stay valid until the next vsv_bam_load / vsv_bam_close. No index is used. */
@@ -322,6 +329,7 @@ int vsv_bam_open(const char* path, vsv_bam** out);
 void vsv_bam_close(vsv_bam* b);
 const char* vsv_bam_error(vsv_bam* b);
 void vsv_bam_set_threads(vsv_bam* b, int n);                  /* BGZF inflate workers, 0 = all (<= 16) */
+void vsv_bam_set_inflate_device(vsv_bam* b, vsv_handle* h);   /* inflate the windows of vsv_bam_load with vsv_bgzf_inflate (NULL: host zlib) */
 int vsv_bam_n_refs(vsv_bam* b);
 const char* vsv_bam_ref_name(vsv_bam* b, int i);
 int64_t vsv_bam_ref_len(vsv_bam* b, int i);

@@ -95,6 +95,11 @@ class BamFile:
     def get_tid(self, name):
         return self.references.index(name) if name in self.references else -1
 
+    def use_gpu_inflate(self, engine):
+        """Inflate the BGZF windows of the following loads on the GPU (engine = volcanosv_amd.engine.Engine; None: host zlib)."""
+        self.lib.vsv_bam_set_inflate_device(self.h, engine.h if engine is not None else None)
+        self._inflate_engine = engine
+
     def fetch_soa(self, chrom=None, keep_seq=False):
         """All records of `chrom` (or of every reference) in file order as a RecordSoA (arrays are copied out of the
         ingest object). soa.sa_tags[i] is the SA tag text of record i ('' if absent)."""

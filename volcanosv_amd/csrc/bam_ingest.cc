@@ -32,6 +32,7 @@ struct vsv_bam {
   size_t rd = 0;
   bool eof = false;
   int n_threads = 0;          // inflate workers for vsv_bam_load (0 = hardware_concurrency, capped at 16)
+  vsv_handle* gpu = nullptr;  // vsv_bam_set_inflate_device: windows are inflated by vsv_bgzf_inflate instead of zlib
   // loaded records (library-owned, valid until the next load / close)
   std::vector<int32_t> pos, tid;
   std::vector<uint32_t> qid, cigar, l_seq, sam_flag;
@@ -110,6 +111,15 @@ bool fill(vsv_bam* b, size_t need) {
     const size_t old = b->buf.size();
     b->buf.resize(old + total);
     uint8_t* base = b->buf.data() + old;
+    if (b->gpu && win.size() >= 64) {                    // whole window on the GPU, one lane per member
+      std::vector<uint64_t> coff(win.size() + 1, 0);
+      std::vector<uint32_t> isz(win.size());
+      for (size_t i = 0; i < win.size(); ++i) { coff[i + 1] = coff[i] + (win[i].comp.size() - 8); isz[i] = win[i].isize; }
+      std::vector<uint8_t> comp((size_t)coff.back() + 1);
+      for (size_t i = 0; i < win.size(); ++i) memcpy(comp.data() + coff[i], win[i].comp.data(), win[i].comp.size() - 8);
+      if (vsv_bgzf_inflate(b->gpu, comp.data(), coff.data(), isz.data(), (int64_t)win.size(), base) != 0) { b->err = std::string("GPU inflate failed: ") + vsv_last_error(b->gpu); return false; }
+      continue;
+    }
     int nt = b->n_threads > 0 ? b->n_threads : (int)std::thread::hardware_concurrency();
     if (nt > 16) nt = 16;
     if (nt < 1) nt = 1;
@@ -188,6 +198,7 @@ void vsv_bam_close(vsv_bam* b) {
 const char* vsv_bam_error(vsv_bam* b) { return b ? b->err.c_str() : "null"; }
 /* number of inflate worker threads used by vsv_bam_load (0 = all hardware threads, at most 16) */
 void vsv_bam_set_threads(vsv_bam* b, int n) { if (b) b->n_threads = n < 0 ? 0 : n; }
+void vsv_bam_set_inflate_device(vsv_bam* b, vsv_handle* h) { if (b) b->gpu = h; }
 int vsv_bam_n_refs(vsv_bam* b) { return b ? (int)b->ref_names.size() : 0; }
 const char* vsv_bam_ref_name(vsv_bam* b, int i) { return (b && i >= 0 && i < (int)b->ref_names.size()) ? b->ref_names[i].c_str() : ""; }
 int64_t vsv_bam_ref_len(vsv_bam* b, int i) { return (b && i >= 0 && i < (int)b->ref_lens.size()) ? b->ref_lens[i] : -1; }

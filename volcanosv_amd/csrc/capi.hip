@@ -42,7 +42,8 @@ struct vsv_handle {
   DevBuf tab, blk_cnt, blk_off, ckey, crec, okey, oval;
   DevBuf key, idx, cl, key2, idx2, key_alt, val_alt, hist;
   DevBuf ctr, shard_cnt, totals;
-  DevBuf j_cpos, j_clen, j_spos, j_slen, j_send, j_out, j_err;   // support join (post-filter)
+  DevBuf j_cpos, j_clen, j_spos, j_slen, j_send, j_out, j_err;
+  DevBuf z_comp, z_coff, z_ooff, z_out, z_stat;          // BGZF inflate   // support join (post-filter)
   int pass_cursor = 0;
   const uint64_t* sorted_key = nullptr;   // sorted keys of the stage just sorted (cluster / pair read them)
   bool small_sort_tiles = true;    // radix tile size, re-decided after every run from its row counts
@@ -367,7 +368,7 @@ void vsv_destroy(vsv_handle* h) {
                     &h->part_off, &h->scan_tmp, &h->pool, &h->pool_key, &h->raw0, &h->s1in, &h->s1s, &h->c1, &h->s2s, &h->c2,
                     &h->merged, &h->calls_tmp, &h->calls, &h->reads, &h->tab, &h->blk_cnt, &h->blk_off, &h->ckey, &h->crec,
                     &h->okey, &h->oval, &h->key, &h->idx, &h->cl, &h->key2, &h->idx2, &h->key_alt, &h->val_alt, &h->hist, &h->ctr, &h->shard_cnt, &h->totals, &h->g_off, &h->g_qs, &h->g_qe, &h->g_rid, &h->g_rs,
-                    &h->g_re, &h->g_rev, &h->g_hap, &h->g_len, &h->g_rank, &h->j_cpos, &h->j_clen, &h->j_spos, &h->j_slen, &h->j_send, &h->j_out, &h->j_err};
+                    &h->g_re, &h->g_rev, &h->g_hap, &h->g_len, &h->g_rank, &h->j_cpos, &h->j_clen, &h->j_spos, &h->j_slen, &h->j_send, &h->j_out, &h->j_err, &h->z_comp, &h->z_coff, &h->z_ooff, &h->z_out, &h->z_stat};
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
   if (h->pinned) hipHostFree(h->pinned);
   if (h->ev0) hipEventDestroy(h->ev0);
@@ -659,6 +660,38 @@ int vsv_support_cov_del(vsv_handle* h, const int32_t* call_start, const int32_t*
   const int32_t* ca[2] = {call_start, call_end};
   const int32_t* sa[3] = {sig_start, sig_end, sig_svlen};
   return cov_common(h, ca, 2, n_calls, sa, 3, n_sigs, flanking, on_device, cov, true);
+}
+
+int vsv_bgzf_inflate(vsv_handle* h, const uint8_t* comp, const uint64_t* comp_off, const uint32_t* isize, int64_t n, uint8_t* out) {
+  if (!h) return VSV_E_INVALID;
+  if (n < 0) return fail(h, VSV_E_INVALID, "negative member count");
+  if (n == 0) return 0;
+  if (!comp || !comp_off || !isize || !out) return fail(h, VSV_E_INVALID, "member arrays are NULL");
+  HIPCHK(h, hipSetDevice(h->device));
+  std::vector<uint64_t> ooff((size_t)n + 1, 0);
+  for (int64_t i = 0; i < n; ++i) {
+    if (comp_off[i + 1] < comp_off[i] || isize[i] > 65536u) return fail(h, VSV_E_INVALID, "bad BGZF member table");
+    ooff[i + 1] = ooff[i] + isize[i];
+  }
+  const size_t cbytes = (size_t)(comp_off[n] - comp_off[0]), obytes = (size_t)ooff[n];
+  int st;
+  if ((st = upload(h, h->z_comp, comp + comp_off[0], cbytes))) return st;
+  std::vector<uint64_t> coff((size_t)n + 1);
+  for (int64_t i = 0; i <= n; ++i) coff[i] = comp_off[i] - comp_off[0];
+  if ((st = upload(h, h->z_coff, coff.data(), (size_t)(n + 1) * 8))) return st;
+  if ((st = upload(h, h->z_ooff, ooff.data(), (size_t)(n + 1) * 8))) return st;
+  if ((st = ensure(h, h->z_out, obytes + 16))) return st;
+  if ((st = ensure(h, h->z_stat, (size_t)n * 4))) return st;
+  vsv_launch_bgzf_inflate(h->stream, (const uint8_t*)h->z_comp.p, (const uint64_t*)h->z_coff.p, (const uint64_t*)h->z_ooff.p, n,
+                          (uint8_t*)h->z_out.p, (int32_t*)h->z_stat.p);
+  HIPCHK(h, hipGetLastError());
+  std::vector<int32_t> stat((size_t)n);
+  if (obytes) HIPCHK(h, hipMemcpyAsync(out, h->z_out.p, obytes, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(stat.data(), h->z_stat.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  for (int64_t i = 0; i < n; ++i)
+    if (stat[i]) { h->last_count = i; char m[96]; snprintf(m, sizeof m, "BGZF member %lld is not a valid deflate stream (code %d)", (long long)i, stat[i]); return fail(h, VSV_E_INVALID, m); }
+  return 0;
 }
 
 int vsv_default_redundancy_params(vsv_redundancy_params* p) {

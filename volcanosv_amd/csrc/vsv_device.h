@@ -154,3 +154,7 @@ void vsv_launch_rr_pairs(hipStream_t st, bool write, const int32_t* pos, const i
                          double size_thr, double overlap_thr, uint32_t* cnt, const uint32_t* off, uint32_t* pairs, uint32_t cap);
 void vsv_launch_rr_edit_sim(hipStream_t st, const uint32_t* pairs, uint32_t n_pairs, const uint8_t* seq, const uint64_t* seq_off,
                             const uint64_t* hoff, int32_t* hbuf, double seq_sim_thr, uint8_t* flag, uint32_t* dist_out);
+
+// inflate.hip: BGZF members (raw deflate) -> bytes, one lane per member
+void vsv_launch_bgzf_inflate(hipStream_t st, const uint8_t* comp, const uint64_t* comp_off, const uint64_t* out_off, int64_t n, uint8_t* out,
+                             int32_t* status);

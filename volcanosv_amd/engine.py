@@ -188,6 +188,19 @@ class Engine:
             self._check(st)
             return out[: n.value]
 
+    def bgzf_inflate(self, payloads, isizes):
+        """Raw-deflate payloads of BGZF members (list of bytes) -> list of their inflated bytes, decoded on the GPU."""
+        n = len(payloads)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum([len(p) for p in payloads], out=off[1:])
+        comp = np.frombuffer(b"".join(payloads) or b"\0", dtype=np.uint8)
+        isz = np.ascontiguousarray(isizes, dtype=np.uint32)
+        out = np.zeros(max(1, int(isz.sum())), dtype=np.uint8)
+        self._check(self.lib.vsv_bgzf_inflate(self.h, comp.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p),
+                                              isz.ctypes.data_as(C.c_void_p), n, out.ctypes.data_as(C.c_void_p)))
+        o = np.concatenate(([0], np.cumsum(isz.astype(np.int64))))
+        return [out[o[i]:o[i + 1]].tobytes() for i in range(n)]
+
     def support_params(self, **kw):
         p = SupportParams()
         self._check(self.lib.vsv_default_support_params(C.byref(p)))
