@@ -158,6 +158,11 @@ def _reg2bin(beg, end):
     return 0
 
 
+_NIBBLE = np.full(256, 15, dtype=np.uint8)      # ASCII base -> BAM 4-bit code ('N' for anything outside the alphabet)
+for _i, _ch in enumerate("=ACMGRSVTWYHKDBN"):
+    _NIBBLE[ord(_ch)] = _i
+
+
 def write_bam(path, references, records, header_text=None):
     """references: [(name, length)]; records: iterable of dicts with keys tid, pos, qname, mapq, flag (SAM flag),
     cigar [(op,len)], optional seq (bases) or seq_len (bases are written as 'N'; 0 => '*'), optional tags {b'SA': 'text'}."""
@@ -187,7 +192,7 @@ def write_bam(path, references, records, header_text=None):
                            len(cig_words), r["flag"], l_seq, -1, -1, 0)
         body += qn + struct.pack("<%dI" % len(cig_words), *cig_words)
         if seq is not None:
-            nib = np.array(["=ACMGRSVTWYHKDBN".index(ch) for ch in seq] + [0], dtype=np.uint8)
+            nib = np.append(_NIBBLE[np.frombuffer(seq.encode(), dtype=np.uint8)], np.uint8(0))
             packed = ((nib[0:2 * ((l_seq + 1) // 2):2] << 4) | nib[1:2 * ((l_seq + 1) // 2):2]).tobytes()
         else:
             packed = b"\xff" * ((l_seq + 1) // 2)

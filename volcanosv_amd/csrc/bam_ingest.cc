@@ -52,6 +52,7 @@ namespace {
 // thread pool (each worker takes the next member off an atomic counter) and appended to the byte queue the record
 // parser consumes. Peak memory = one window (<= 64 KiB x WINDOW_BLOCKS decompressed).
 constexpr int WINDOW_BLOCKS = 2048;
+constexpr int WINDOW_BLOCKS_GPU = 16384;
 
 struct Member { std::vector<uint8_t> comp; uint32_t isize; size_t out_off; };
 
@@ -98,7 +99,8 @@ bool fill(vsv_bam* b, size_t need) {
   while (b->buf.size() - b->rd < need && !b->eof) {
     std::vector<Member> win;
     size_t total = 0;
-    while ((int)win.size() < WINDOW_BLOCKS && !b->eof) {
+    const int window_blocks = b->gpu ? WINDOW_BLOCKS_GPU : WINDOW_BLOCKS;   // the GPU wants tens of thousands of members in flight
+    while ((int)win.size() < window_blocks && !b->eof) {
       Member m; bool got;
       if (!read_member(b, m, got)) return false;
       if (!got) break;

@@ -16,10 +16,13 @@ namespace {
 
 constexpr int MAXBITS = 15, MAXLCODES = 286, MAXDCODES = 30, FIXLCODES = 288;
 
+constexpr int LFAST = 9, DFAST = 8;    // bits resolved by one table lookup; longer codes fall back to the bit-serial decode
 struct Tables {
   uint16_t lcount[MAXBITS + 1], lsymbol[FIXLCODES];
   uint16_t dcount[MAXBITS + 1], dsymbol[MAXDCODES];
   uint8_t lengths[MAXLCODES + MAXDCODES + 2];
+  uint16_t lfast[1 << LFAST];          // [next LFAST stream bits] -> symbol << 4 | code length, 0 = longer code
+  uint16_t dfast[1 << DFAST];
 };
 
 // one dword of the compressed stream through the scalar cache (lgkmcnt): it does not queue behind the output stores
@@ -112,6 +115,36 @@ __device__ __forceinline__ int construct_by_lane0(uint16_t* count, uint16_t* sym
   return __builtin_amdgcn_readfirstlane(r);
 }
 
+// Fast table of a code whose count[] / symbol[] are built: entry [v] for every LFAST-bit value v of the stream whose low bits
+// are a complete code of length <= BITS (stream bits arrive LSB first, code bits MSB first, hence the bit reversal).
+// The 64 lanes share the work: lane handles the sorted symbols lane, lane + 64, ...
+template <int BITS>
+__device__ __forceinline__ void build_fast(const uint16_t* count, const uint16_t* symbol, uint16_t* fast, int lane) {
+  for (int i = lane; i < (1 << BITS); i += 64) fast[i] = 0;
+  __builtin_amdgcn_wave_barrier();
+  int code = 0, index = 0;                           // canonical first code / first sorted index of the current length
+  for (int len = 1; len <= BITS; ++len) {
+    const int c = __builtin_amdgcn_readfirstlane((int)count[len]);
+    for (int r = lane; r < c; r += 64) {
+      const uint32_t rev = __builtin_bitreverse32((uint32_t)(code + r)) >> (32 - len);
+      const uint16_t e = (uint16_t)((symbol[index + r] << 4) | len);
+      for (uint32_t hi = 0; hi < (1u << (BITS - len)); ++hi) fast[rev | (hi << len)] = e;
+    }
+    code = (code + c) << 1;
+    index += c;
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <int BITS>
+__device__ __forceinline__ int decode_fast(Bits& b, const uint16_t* fast, const Counts& k, const uint16_t* symbol) {
+  if (b.cnt < MAXBITS) { b.refill(); if (b.cnt < MAXBITS) b.refill(); }
+  const int e = __builtin_amdgcn_readfirstlane((int)fast[(uint32_t)b.buf & ((1u << BITS) - 1u)]);
+  const int len = e & 15;
+  if (e != 0 && len <= b.cnt) { b.buf >>= len; b.cnt -= len; return e >> 4; }
+  return decode_reg(b, k, symbol);                   // code longer than BITS bits, or the stream is about to end
+}
+
 __constant__ uint16_t LBASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
 __constant__ uint8_t LEXT[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
 __constant__ uint16_t DBASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
@@ -147,10 +180,12 @@ struct Out {
   }
 };
 
-__device__ __forceinline__ int codes(Bits& b, const Tables& T, Out& out) {
+__device__ __forceinline__ int codes(Bits& b, Tables& T, Out& out) {
+  build_fast<LFAST>(T.lcount, T.lsymbol, T.lfast, out.lane);
+  build_fast<DFAST>(T.dcount, T.dsymbol, T.dfast, out.lane);
   const Counts kl = load_counts(T.lcount), kd = load_counts(T.dcount);
   for (;;) {
-    int sym = decode_reg(b, kl, T.lsymbol);
+    int sym = decode_fast<LFAST>(b, T.lfast, kl, T.lsymbol);
     if (sym < 0) return sym;
     if (sym < 256) {
       if (!out.literal((uint32_t)sym)) return -3;
@@ -160,7 +195,7 @@ __device__ __forceinline__ int codes(Bits& b, const Tables& T, Out& out) {
       sym -= 257;
       if (sym >= 29) return -4;
       const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)LBASE[sym]) + b.get(__builtin_amdgcn_readfirstlane((int)LEXT[sym]));
-      const int ds = decode_reg(b, kd, T.dsymbol);
+      const int ds = decode_fast<DFAST>(b, T.dfast, kd, T.dsymbol);
       if (ds < 0) return ds;
       if (ds >= 30) return -5;
       const uint32_t dist = (uint32_t)__builtin_amdgcn_readfirstlane((int)DBASE[ds]) + b.get(__builtin_amdgcn_readfirstlane((int)DEXT[ds]));
