@@ -321,6 +321,19 @@ int vsv_redundancy_pairs(vsv_handle* h, int is_del, const int32_t* pos, const in
  * valid deflate stream of exactly isize bytes fails the call with VSV_E_INVALID (vsv_last_count = its index). */
 int vsv_bgzf_inflate(vsv_handle* h, const uint8_t* comp, const uint64_t* comp_off, const uint32_t* isize, int64_t n_members, uint8_t* out);
 
+/* BAM members -> device-resident record SoA, inflated AND parsed on the GPU (no byte of the records returns to the host except
+ * the query names). comp / comp_off / isize describe all BGZF members of the file as for vsv_bgzf_inflate; first_record = offset
+ * of the first alignment record in the inflated stream (= length of the BAM header block), n_ref = number of reference
+ * sequences; tid < 0 keeps every placed record. On success `out` holds DEVICE pointers (on_device = 1) owned by the handle,
+ * valid until the next call; qids are dense in first-appearance order like vsv_bam_load's; *names / *names_len receive a
+ * library-owned '\n'-joined name blob in qid order. VSV_E_INVALID: the stream is not a well-formed BAM (or a 64-bit name-hash
+ * collision was detected) — use the host reader. SA tags and SEQ are not extracted by this path. */
+/* plain device -> host copy on the handle's stream (for callers without a HIP runtime binding of their own) */
+int vsv_copy_to_host(vsv_handle* h, void* dst, const void* src_device, int64_t bytes);
+int vsv_bam_parse_device(vsv_handle* h, const uint8_t* comp, const uint64_t* comp_off, const uint32_t* isize, int64_t n_members,
+                         uint64_t first_record, int32_t n_ref, int32_t tid, vsv_records* out, const char** names, int64_t* names_len,
+                         const uint32_t** l_seq_dev, const uint32_t** sam_flags_dev);
+
 /* ---- host-side ingest: BAM/BGZF -> record SoA ----------------------------------------------------
  * Replaces pysam.AlignmentFile(bam).fetch(chr) (H:387-391, RS:108-113). Arrays returned through `out` are owned
  * by the vsv_bam object and stay valid until the next vsv_bam_load / vsv_bam_close. No index is used. */
@@ -334,12 +347,15 @@ int vsv_bam_n_refs(vsv_bam* b);
 const char* vsv_bam_ref_name(vsv_bam* b, int i);
 int64_t vsv_bam_ref_len(vsv_bam* b, int i);
 int vsv_bam_load(vsv_bam* b, int tid, vsv_records* out);       /* tid < 0: every placed record */
+int vsv_bam_load_device(vsv_bam* b, vsv_handle* h, int tid, vsv_records* out);   /* same, through vsv_bam_parse_device: device pointers */
 const char* vsv_bam_qnames(vsv_bam* b, int64_t* len);           /* '\n'-joined names, qid order   */
 const char* vsv_bam_sa_tags(vsv_bam* b, int64_t* len);          /* '\n'-joined SA tags, record order */
 void vsv_bam_set_keep_seq(vsv_bam* b, int keep);              /* keep SEQ of the records loaded next (sig_extract INS text) */
 const uint8_t* vsv_bam_seq(vsv_bam* b, int64_t* len);          /* packed 4-bit SEQ (BAM nibbles '=ACMGRSVTWYHKDBN'), record i: (l_seq[i]+1)/2 bytes */
 const uint32_t* vsv_bam_l_seq(vsv_bam* b);
 const uint32_t* vsv_bam_sam_flags(vsv_bam* b);
+const uint32_t* vsv_bam_l_seq_device(vsv_bam* b);             /* device arrays of the last vsv_bam_load_device */
+const uint32_t* vsv_bam_sam_flags_device(vsv_bam* b);
 
 #ifdef __cplusplus
 }

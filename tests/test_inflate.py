@@ -78,3 +78,50 @@ def test_bam_load_with_gpu_inflate_equals_host_inflate(tmp_path):
     for name in ("pos", "tid", "qid", "cigar_off", "mapq", "flag", "cigar", "l_seq", "sam_flags"):
         assert np.array_equal(getattr(host, name), getattr(dev, name)), name
     assert list(host.qnames) == list(dev.qnames) and host.seq[123] == dev.seq[123] and host.n_records == 60000
+
+
+@pytest.mark.gpu
+def test_bam_parsed_on_the_device_equals_host_reader(tmp_path):
+    """vsv_bam_load_device: BGZF inflate + record-start chain + field parse + CIGAR copy + first-appearance query ids, all on the
+    GPU; every array and the name table equal the host reader's, for one chromosome and for the whole file, with repeated
+    names (split reads), records larger than a BGZF member, a long CIGAR in CG:B,I and unmapped-placed records."""
+    from volcanosv_amd import bam, synth
+    from volcanosv_amd.abi import DTYPE_HIFI
+    from volcanosv_amd.engine import Engine, default_params
+    recs = []
+    rng = np.random.default_rng(8)
+    for tid in (0, 1):
+        t, nq, _ = synth.generate(40000, "hifi", seed=30 + tid, chrom_len=30_000_000)
+        soa = synth.to_soa(t, nq)
+        for i in range(soa.n_records):
+            a, b = int(soa.cigar_off[i]), int(soa.cigar_off[i + 1])
+            recs.append(dict(tid=tid, pos=int(soa.pos[i]), qname="c%d_PS%d_hp%d" % (tid, int(soa.qid[i]), 1 + int(soa.qid[i]) % 2), mapq=int(soa.mapq[i]),
+                             flag=16 * (i % 2), cigar=[(int(w) & 15, int(w) >> 4) for w in soa.cigar[a:b]], seq_len=int(rng.integers(0, 400))))
+        # a record far larger than a 64 KiB member (sequence bytes) and one with > 65535 CIGAR ops (CG tag)
+        recs.append(dict(tid=tid, pos=29_000_000, qname="giant%d" % tid, mapq=60, flag=0, cigar=[(0, 100)], seq_len=300_000))
+        recs.append(dict(tid=tid, pos=29_100_000, qname="longcigar%d" % tid, mapq=60, flag=0, cigar=[(0, 3), (1, 1)] * 40000 + [(0, 5)], seq_len=10))
+        recs.append(dict(tid=tid, pos=29_200_000, qname="unmapped_placed%d" % tid, mapq=0, flag=4, cigar=[], seq_len=50))
+    path = str(tmp_path / "two.bam")
+    bam.write_bam(path, [("chr1", 30_000_000), ("chr2", 30_000_000)], recs)
+    with Engine(0) as eng, bam.BamFile(path) as bf:
+        for chrom in ("chr2", None, "chr1"):
+            host = bf.fetch_soa(chrom)
+            view = bf.fetch_device(eng, chrom)
+            dev = view.to_host()
+            assert dev.n_records == host.n_records and dev.n_ops == host.n_ops and view.n_qids == host.n_qids
+            for name in ("pos", "tid", "qid", "cigar_off", "mapq", "flag", "cigar", "l_seq", "sam_flags"):
+                assert np.array_equal(getattr(host, name), getattr(dev, name)), (chrom, name)
+            assert list(host.qnames) == list(dev.qnames)
+        # the device-resident view feeds the hot path directly
+        view = bf.fetch_device(eng, "chr1")
+        view.max_pos = 30_100_000
+        keep = view.to_host()
+        ok = np.flatnonzero(np.diff(keep.cigar_off.astype(np.int64)) > 0)      # the scan rejects empty CIGARs: same input for both
+        p = default_params(DTYPE_HIFI)
+        try:
+            eng.run(view, p)
+            got = eng.table("raw")
+            raised = None
+        except Exception as e:                                                 # noqa: BLE001
+            raised = e
+        assert raised is not None and "CIGAR" in str(raised) and len(ok) == keep.n_records - 1

@@ -69,6 +69,44 @@ class PackedSeq:
         return self.ALPHABET[nib[:n]].tobytes().decode()
 
 
+class DeviceRecordView:
+    """Record SoA resident on the GPU, produced by BamFile.fetch_device (raw device pointers owned by the engine's handle).
+    Quacks like RecordSoA / DeviceRecords where the engine needs it (`as_struct`); `to_host()` copies the arrays back."""
+
+    def __init__(self, rec, qnames, tid_names, l_seq_ptr, sam_flags_ptr, engine):
+        self._rec = rec
+        self.qnames, self.tid_names = qnames, tid_names
+        self.n_records, self.n_ops = int(rec.n_records), int(rec.n_ops)
+        self.n_qids, self.n_tids = int(rec.n_qids), int(rec.n_tids)
+        self.max_pos = 0
+        self._l_seq_ptr, self._sam_flags_ptr = l_seq_ptr, sam_flags_ptr
+        self._engine = engine
+
+    def as_struct(self):
+        self._rec.max_pos = int(self.max_pos)
+        return self._rec
+
+    def qname(self, rec):
+        raise NotImplementedError("qid lives on the device: use to_host().qname(rec)")
+
+    def to_host(self):
+        """RecordSoA copy (plus l_seq / sam_flags) of the device arrays."""
+        r, n, eng = self._rec, self.n_records, self._engine
+
+        def pull(ptr, count, dt):
+            out = np.zeros(count, dtype=dt)
+            if count:
+                eng._check(eng.lib.vsv_copy_to_host(eng.h, out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr if isinstance(ptr, int) else ptr), out.nbytes))
+            return out
+
+        soa = RecordSoA(pull(r.pos, n, np.int32), pull(r.tid, n, np.int32), pull(r.qid, n, np.uint32), pull(r.cigar_off, n + 1, np.uint64),
+                        pull(r.mapq, n, np.uint8), pull(r.flag, n, np.uint8), pull(r.cigar, self.n_ops, np.uint32), self.qnames, self.tid_names)
+        soa.n_tids = self.n_tids
+        soa.l_seq = pull(self._l_seq_ptr, n, np.uint32)
+        soa.sam_flags = pull(self._sam_flags_ptr, n, np.uint32)
+        return soa
+
+
 class BamFile:
     def __init__(self, path, threads=0):
         self.lib = _lib.load()
@@ -94,6 +132,22 @@ class BamFile:
 
     def get_tid(self, name):
         return self.references.index(name) if name in self.references else -1
+
+    def fetch_device(self, engine, chrom=None):
+        """All records of `chrom` (or of every reference) inflated and parsed on the GPU: returns a DeviceRecordView whose arrays
+        live in `engine`'s handle (valid until its next fetch_device). Query names come back to the host (lazily split); SA
+        tags and sequences are not extracted by this path."""
+        tid = -1 if chrom is None else self.get_tid(chrom)
+        if chrom is not None and tid < 0:
+            raise KeyError("reference %r not in BAM header" % chrom)
+        r = Records()
+        st = self.lib.vsv_bam_load_device(self.h, engine.h, tid, C.byref(r))
+        if st:
+            raise VsvError(st, self.lib.vsv_bam_error(self.h).decode())
+        ln = C.c_int64()
+        p = self.lib.vsv_bam_qnames(self.h, C.byref(ln))
+        names = LazyLines(C.string_at(p, ln.value), int(r.n_qids))
+        return DeviceRecordView(r, names, self.references, self.lib.vsv_bam_l_seq_device(self.h), self.lib.vsv_bam_sam_flags_device(self.h), engine)
 
     def use_gpu_inflate(self, engine):
         """Inflate the BGZF windows of the following loads on the GPU (engine = volcanosv_amd.engine.Engine; None: host zlib)."""

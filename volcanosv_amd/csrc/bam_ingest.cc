@@ -31,6 +31,8 @@ struct vsv_bam {
   std::vector<uint8_t> buf;   // decompressed bytes not yet consumed
   size_t rd = 0;
   bool eof = false;
+  uint64_t inflated_total = 0;   // bytes appended to buf since the last rewind (for the header length)
+  const uint32_t* dev_l_seq = nullptr; const uint32_t* dev_sam_flag = nullptr;   // device arrays of the last vsv_bam_load_device
   int n_threads = 0;          // inflate workers for vsv_bam_load (0 = hardware_concurrency, capped at 16)
   vsv_handle* gpu = nullptr;  // vsv_bam_set_inflate_device: windows are inflated by vsv_bgzf_inflate instead of zlib
   // loaded records (library-owned, valid until the next load / close)
@@ -112,6 +114,7 @@ bool fill(vsv_bam* b, size_t need) {
     if (b->rd > 0) { b->buf.erase(b->buf.begin(), b->buf.begin() + b->rd); b->rd = 0; }
     const size_t old = b->buf.size();
     b->buf.resize(old + total);
+    b->inflated_total += total;
     uint8_t* base = b->buf.data() + old;
     if (b->gpu && win.size() >= 64) {                    // whole window on the GPU, one lane per member
       std::vector<uint64_t> coff(win.size() + 1, 0);
@@ -408,6 +411,46 @@ int vsv_bam_load(vsv_bam* b, int tid, vsv_records* out) {
   out->n_tids = (int32_t)b->ref_names.size();
   return 0;
 }
+
+/* Same records, but inflated and parsed on the GPU (vsv_bam_parse_device): `out` holds device pointers owned by `h`. The header
+ * is read on the host (it is a few KB) to learn the reference table and where the first record starts. */
+int vsv_bam_load_device(vsv_bam* b, vsv_handle* h, int tid, vsv_records* out) {
+  if (!b || !h || !out) return VSV_E_INVALID;
+  fseek(b->f, 0, SEEK_SET);
+  b->buf.clear(); b->rd = 0; b->eof = false; b->inflated_total = 0;
+  b->ref_names.clear(); b->ref_lens.clear();
+  const int user_threads = b->n_threads;
+  vsv_handle* user_gpu = b->gpu;
+  b->n_threads = 1; b->gpu = nullptr;
+  const bool hdr_ok = read_header(b);
+  b->n_threads = user_threads; b->gpu = user_gpu;
+  if (!hdr_ok) return VSV_E_INVALID;
+  const uint64_t first_record = b->inflated_total - (b->buf.size() - b->rd);
+  // all members, compressed
+  fseek(b->f, 0, SEEK_SET);
+  b->eof = false;
+  std::vector<uint8_t> comp;
+  std::vector<uint64_t> coff(1, 0);
+  std::vector<uint32_t> isz;
+  for (;;) {
+    Member m; bool got;
+    if (!read_member(b, m, got)) return VSV_E_INVALID;
+    if (!got) break;
+    comp.insert(comp.end(), m.comp.begin(), m.comp.end() - 8);
+    coff.push_back(comp.size());
+    isz.push_back(m.isize);
+  }
+  comp.resize(comp.size() + 8);
+  const char* names = nullptr; int64_t names_len = 0;
+  const int st = vsv_bam_parse_device(h, comp.data(), coff.data(), isz.data(), (int64_t)isz.size(), first_record, (int32_t)b->ref_names.size(), tid, out,
+                                      &names, &names_len, &b->dev_l_seq, &b->dev_sam_flag);
+  if (st) { b->err = std::string("device BAM parse failed: ") + vsv_last_error(h); return st; }
+  b->qname_blob.assign(names ? names : "", (size_t)names_len);
+  b->sa_blob.clear();
+  return 0;
+}
+const uint32_t* vsv_bam_l_seq_device(vsv_bam* b) { return b ? b->dev_l_seq : nullptr; }
+const uint32_t* vsv_bam_sam_flags_device(vsv_bam* b) { return b ? b->dev_sam_flag : nullptr; }
 
 /* '\n'-joined query names in qid order / SA tags in record order of the last vsv_bam_load; *len receives the length */
 const char* vsv_bam_qnames(vsv_bam* b, int64_t* len) { if (len) *len = b ? (int64_t)b->qname_blob.size() : 0; return b ? b->qname_blob.data() : ""; }

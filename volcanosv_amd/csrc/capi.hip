@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -43,7 +44,11 @@ struct vsv_handle {
   DevBuf key, idx, cl, key2, idx2, key_alt, val_alt, hist;
   DevBuf ctr, shard_cnt, totals;
   DevBuf j_cpos, j_clen, j_spos, j_slen, j_send, j_out, j_err;
-  DevBuf z_comp, z_coff, z_ooff, z_out, z_stat;          // BGZF inflate   // support join (post-filter)
+  DevBuf z_comp, z_coff, z_ooff, z_out, z_stat;          // BGZF inflate
+  DevBuf p_spec, p_cnt, p_land, p_base, p_recoff, p_pos, p_tid, p_mapq, p_flag, p_lseq, p_sflag, p_ncig, p_cgsrc, p_hash, p_keep, p_kidx,
+      p_cigoff, p_sums, p_tot, p_err;                     // device BAM parse: per input record
+  DevBuf o_pos, o_tid, o_qid, o_cigoff, o_mapq, o_flag, o_cigar, o_lseq, o_sflag, o_hash, o_recoff, o_first, o_rank, o_nlen, o_noff, o_blob, o_n;
+  std::string names_blob;   // support join (post-filter)
   int pass_cursor = 0;
   const uint64_t* sorted_key = nullptr;   // sorted keys of the stage just sorted (cluster / pair read them)
   bool small_sort_tiles = true;    // radix tile size, re-decided after every run from its row counts
@@ -368,7 +373,10 @@ void vsv_destroy(vsv_handle* h) {
                     &h->part_off, &h->scan_tmp, &h->pool, &h->pool_key, &h->raw0, &h->s1in, &h->s1s, &h->c1, &h->s2s, &h->c2,
                     &h->merged, &h->calls_tmp, &h->calls, &h->reads, &h->tab, &h->blk_cnt, &h->blk_off, &h->ckey, &h->crec,
                     &h->okey, &h->oval, &h->key, &h->idx, &h->cl, &h->key2, &h->idx2, &h->key_alt, &h->val_alt, &h->hist, &h->ctr, &h->shard_cnt, &h->totals, &h->g_off, &h->g_qs, &h->g_qe, &h->g_rid, &h->g_rs,
-                    &h->g_re, &h->g_rev, &h->g_hap, &h->g_len, &h->g_rank, &h->j_cpos, &h->j_clen, &h->j_spos, &h->j_slen, &h->j_send, &h->j_out, &h->j_err, &h->z_comp, &h->z_coff, &h->z_ooff, &h->z_out, &h->z_stat};
+                    &h->g_re, &h->g_rev, &h->g_hap, &h->g_len, &h->g_rank, &h->j_cpos, &h->j_clen, &h->j_spos, &h->j_slen, &h->j_send, &h->j_out, &h->j_err, &h->z_comp, &h->z_coff, &h->z_ooff, &h->z_out, &h->z_stat, &h->p_spec, &h->p_cnt, &h->p_land, &h->p_base, &h->p_recoff, &h->p_pos, &h->p_tid,
+                    &h->p_mapq, &h->p_flag, &h->p_lseq, &h->p_sflag, &h->p_ncig, &h->p_cgsrc, &h->p_hash, &h->p_keep, &h->p_kidx, &h->p_cigoff, &h->p_sums,
+                    &h->p_tot, &h->p_err, &h->o_pos, &h->o_tid, &h->o_qid, &h->o_cigoff, &h->o_mapq, &h->o_flag, &h->o_cigar, &h->o_lseq, &h->o_sflag,
+                    &h->o_hash, &h->o_recoff, &h->o_first, &h->o_rank, &h->o_nlen, &h->o_noff, &h->o_blob, &h->o_n};
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
   if (h->pinned) hipHostFree(h->pinned);
   if (h->ev0) hipEventDestroy(h->ev0);
@@ -662,13 +670,9 @@ int vsv_support_cov_del(vsv_handle* h, const int32_t* call_start, const int32_t*
   return cov_common(h, ca, 2, n_calls, sa, 3, n_sigs, flanking, on_device, cov, true);
 }
 
-int vsv_bgzf_inflate(vsv_handle* h, const uint8_t* comp, const uint64_t* comp_off, const uint32_t* isize, int64_t n, uint8_t* out) {
-  if (!h) return VSV_E_INVALID;
-  if (n < 0) return fail(h, VSV_E_INVALID, "negative member count");
-  if (n == 0) return 0;
-  if (!comp || !comp_off || !isize || !out) return fail(h, VSV_E_INVALID, "member arrays are NULL");
-  HIPCHK(h, hipSetDevice(h->device));
-  std::vector<uint64_t> ooff((size_t)n + 1, 0);
+// inflate into h->z_out and leave it there (shared by vsv_bgzf_inflate's device half and the device parse)
+static int inflate_to_device(vsv_handle* h, const uint8_t* comp, const uint64_t* comp_off, const uint32_t* isize, int64_t n, std::vector<uint64_t>& ooff) {
+  ooff.assign((size_t)n + 1, 0);
   for (int64_t i = 0; i < n; ++i) {
     if (comp_off[i + 1] < comp_off[i] || isize[i] > 65536u) return fail(h, VSV_E_INVALID, "bad BGZF member table");
     ooff[i + 1] = ooff[i] + isize[i];
@@ -680,17 +684,173 @@ int vsv_bgzf_inflate(vsv_handle* h, const uint8_t* comp, const uint64_t* comp_of
   for (int64_t i = 0; i <= n; ++i) coff[i] = comp_off[i] - comp_off[0];
   if ((st = upload(h, h->z_coff, coff.data(), (size_t)(n + 1) * 8))) return st;
   if ((st = upload(h, h->z_ooff, ooff.data(), (size_t)(n + 1) * 8))) return st;
-  if ((st = ensure(h, h->z_out, obytes + 16))) return st;
+  if ((st = ensure(h, h->z_out, obytes + 64))) return st;
   if ((st = ensure(h, h->z_stat, (size_t)n * 4))) return st;
   vsv_launch_bgzf_inflate(h->stream, (const uint8_t*)h->z_comp.p, (const uint64_t*)h->z_coff.p, (const uint64_t*)h->z_ooff.p, n,
                           (uint8_t*)h->z_out.p, (int32_t*)h->z_stat.p);
   HIPCHK(h, hipGetLastError());
   std::vector<int32_t> stat((size_t)n);
-  if (obytes) HIPCHK(h, hipMemcpyAsync(out, h->z_out.p, obytes, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipMemcpyAsync(stat.data(), h->z_stat.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   for (int64_t i = 0; i < n; ++i)
     if (stat[i]) { h->last_count = i; char m[96]; snprintf(m, sizeof m, "BGZF member %lld is not a valid deflate stream (code %d)", (long long)i, stat[i]); return fail(h, VSV_E_INVALID, m); }
+  return 0;
+}
+
+int vsv_bgzf_inflate(vsv_handle* h, const uint8_t* comp, const uint64_t* comp_off, const uint32_t* isize, int64_t n, uint8_t* out) {
+  if (!h) return VSV_E_INVALID;
+  if (n < 0) return fail(h, VSV_E_INVALID, "negative member count");
+  if (n == 0) return 0;
+  if (!comp || !comp_off || !isize || !out) return fail(h, VSV_E_INVALID, "member arrays are NULL");
+  HIPCHK(h, hipSetDevice(h->device));
+  std::vector<uint64_t> ooff;
+  const int rc = inflate_to_device(h, comp, comp_off, isize, n, ooff);
+  if (rc) return rc;
+  if (ooff[n]) HIPCHK(h, hipMemcpyAsync(out, h->z_out.p, (size_t)ooff[n], hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int vsv_bam_parse_device(vsv_handle* h, const uint8_t* comp, const uint64_t* comp_off, const uint32_t* isize, int64_t n_members, uint64_t first_record,
+                         int32_t n_ref, int32_t tid, vsv_records* out, const char** names, int64_t* names_len, const uint32_t** l_seq_dev,
+                         const uint32_t** sam_flags_dev) {
+  if (!h || !out) return VSV_E_INVALID;
+  if (n_members <= 0 || !comp || !comp_off || !isize) return fail(h, VSV_E_INVALID, "no BGZF members");
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t st = h->stream;
+  std::vector<uint64_t> moff;
+  int rc = inflate_to_device(h, comp, comp_off, isize, n_members, moff);
+  if (rc) return rc;
+  const uint64_t total = moff[n_members];
+  if (first_record > total) return fail(h, VSV_E_INVALID, "header longer than the stream");
+  const uint8_t* s = (const uint8_t*)h->z_out.p;
+  const uint64_t* d_moff = (const uint64_t*)h->z_ooff.p;
+  const size_t nm = (size_t)n_members;
+  if ((rc = ensure(h, h->p_spec, nm * 8)) || (rc = ensure(h, h->p_cnt, nm * 4)) || (rc = ensure(h, h->p_land, nm * 8)) || (rc = ensure(h, h->p_base, nm * 8)) ||
+      (rc = ensure(h, h->p_err, 256)) || (rc = ensure(h, h->p_tot, 256)) || (rc = ensure(h, h->o_n, 256))) return rc;
+  HIPCHK(h, hipMemsetAsync(h->p_err.p, 0, 4, st));
+  // ---- record-start chain: speculate per member, walk, verify on the host from the exactly known first record -----------
+  vsv_bamdev_speculate(st, s, d_moff, n_members, first_record, n_ref, (uint64_t*)h->p_spec.p);
+  std::vector<uint64_t> spec(nm), land(nm), base(nm, 0);
+  std::vector<uint32_t> cnt(nm);
+  std::vector<uint8_t> active(nm, 0);
+  HIPCHK(h, hipMemcpyAsync(spec.data(), h->p_spec.p, nm * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  uint64_t n_total = 0;
+  for (int round = 0;; ++round) {
+    if (round > 64) return fail(h, VSV_E_INVALID, "record chain does not settle (not a BAM stream?)");
+    HIPCHK(h, hipMemcpyAsync(h->p_spec.p, spec.data(), nm * 8, hipMemcpyHostToDevice, st));
+    vsv_bamdev_chain(st, false, s, d_moff, n_members, (const uint64_t*)h->p_spec.p, (uint32_t*)h->p_cnt.p, (uint64_t*)h->p_land.p, nullptr, nullptr);
+    HIPCHK(h, hipMemcpyAsync(cnt.data(), h->p_cnt.p, nm * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipMemcpyAsync(land.data(), h->p_land.p, nm * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    std::fill(active.begin(), active.end(), 0);
+    bool patched = false;
+    uint64_t expect = first_record;
+    n_total = 0;
+    while (expect < total) {
+      const size_t m = (size_t)(std::upper_bound(moff.begin(), moff.end(), expect) - moff.begin()) - 1;   // member holding `expect`
+      if (spec[m] != expect) { spec[m] = expect; patched = true; break; }                                  // proven start: patch and rewalk
+      if (land[m] == 0xFFFFFFFFFFFFFFFFull) return fail(h, VSV_E_INVALID, "malformed BAM record chain");
+      active[m] = 1; base[m] = n_total; n_total += cnt[m];
+      expect = land[m];
+    }
+    if (!patched) { if (expect != total) return fail(h, VSV_E_INVALID, "BAM stream ends inside a record"); break; }
+  }
+  if (n_total > 0x7FFFFFF0ull) return fail(h, VSV_E_INVALID, "too many records for the device reader");
+  for (size_t m = 0; m < nm; ++m) if (!active[m]) spec[m] = 0xFFFFFFFFFFFFFFFFull;      // speculated starts the chain never reached
+  const int64_t n = (int64_t)n_total;
+  memset(out, 0, sizeof *out);
+  out->on_device = 1;
+  h->names_blob.clear();
+  if (names) { *names = h->names_blob.c_str(); }
+  if (names_len) *names_len = 0;
+  if (n == 0) return 0;
+  HIPCHK(h, hipMemcpyAsync(h->p_spec.p, spec.data(), nm * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipMemcpyAsync(h->p_base.p, base.data(), nm * 8, hipMemcpyHostToDevice, st));
+  const size_t N = (size_t)n;
+  if ((rc = ensure(h, h->p_recoff, N * 8)) || (rc = ensure(h, h->p_pos, N * 4)) || (rc = ensure(h, h->p_tid, N * 4)) || (rc = ensure(h, h->p_mapq, N)) ||
+      (rc = ensure(h, h->p_flag, N)) || (rc = ensure(h, h->p_lseq, N * 4)) || (rc = ensure(h, h->p_sflag, N * 4)) || (rc = ensure(h, h->p_ncig, N * 4)) ||
+      (rc = ensure(h, h->p_cgsrc, N * 8)) || (rc = ensure(h, h->p_hash, N * 8)) || (rc = ensure(h, h->p_keep, N * 4 + 16)) || (rc = ensure(h, h->p_kidx, N * 4 + 16)) ||
+      (rc = ensure(h, h->p_cigoff, N * 8)) || (rc = ensure(h, h->p_sums, (N / 2048 + 4) * 8))) return rc;
+  vsv_bamdev_chain(st, true, s, d_moff, n_members, (const uint64_t*)h->p_spec.p, nullptr, nullptr, (const uint64_t*)h->p_base.p, (uint64_t*)h->p_recoff.p);
+  vsv_bamdev_fields(st, s, (const uint64_t*)h->p_recoff.p, n, tid, (int32_t*)h->p_pos.p, (int32_t*)h->p_tid.p, (uint8_t*)h->p_mapq.p, (uint8_t*)h->p_flag.p,
+                    (uint32_t*)h->p_lseq.p, (uint32_t*)h->p_sflag.p, (uint32_t*)h->p_ncig.p, (uint64_t*)h->p_cgsrc.p, (uint64_t*)h->p_hash.p,
+                    (uint32_t*)h->p_keep.p, (uint32_t*)h->p_err.p);
+  vsv_scan_u32_exclusive(st, (const uint32_t*)h->p_keep.p, (int)n, (uint32_t*)h->p_kidx.p, (uint32_t*)h->p_sums.p);
+  vsv_bamdev_scan64(st, (const uint32_t*)h->p_ncig.p, (const uint32_t*)h->p_keep.p, n, (uint64_t*)h->p_sums.p, (uint64_t*)h->p_cigoff.p, (uint64_t*)h->p_tot.p);
+  uint32_t last_k = 0, last_keep = 0, err = 0;
+  uint64_t n_ops = 0;
+  HIPCHK(h, hipMemcpyAsync(&last_k, (uint32_t*)h->p_kidx.p + (n - 1), 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipMemcpyAsync(&last_keep, (uint32_t*)h->p_keep.p + (n - 1), 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipMemcpyAsync(&n_ops, h->p_tot.p, 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipMemcpyAsync(&err, h->p_err.p, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  if (err & 1u) return fail(h, VSV_E_INVALID, "unknown BAM tag type");
+  const int64_t nk = (int64_t)last_k + last_keep;
+  out->n_records = nk; out->n_ops = (int64_t)n_ops; out->n_tids = n_ref;
+  if (nk == 0) return 0;
+  const size_t K = (size_t)nk;
+  if ((rc = ensure(h, h->o_pos, K * 4)) || (rc = ensure(h, h->o_tid, K * 4)) || (rc = ensure(h, h->o_qid, K * 4)) || (rc = ensure(h, h->o_cigoff, (K + 1) * 8)) ||
+      (rc = ensure(h, h->o_mapq, K)) || (rc = ensure(h, h->o_flag, K)) || (rc = ensure(h, h->o_cigar, (size_t)n_ops * 4 + 16)) || (rc = ensure(h, h->o_lseq, K * 4)) ||
+      (rc = ensure(h, h->o_sflag, K * 4)) || (rc = ensure(h, h->o_hash, K * 8)) || (rc = ensure(h, h->o_recoff, K * 8)) || (rc = ensure(h, h->o_first, K * 4 + 16)) ||
+      (rc = ensure(h, h->o_rank, K * 4 + 16)) || (rc = ensure(h, h->o_nlen, K * 4 + 16)) || (rc = ensure(h, h->o_noff, K * 4 + 16))) return rc;
+  vsv_bamdev_emit(st, s, n, (const uint32_t*)h->p_keep.p, (const uint32_t*)h->p_kidx.p, (const int32_t*)h->p_pos.p, (const int32_t*)h->p_tid.p,
+                  (const uint8_t*)h->p_mapq.p, (const uint8_t*)h->p_flag.p, (const uint32_t*)h->p_lseq.p, (const uint32_t*)h->p_sflag.p,
+                  (const uint32_t*)h->p_ncig.p, (const uint64_t*)h->p_cgsrc.p, (const uint64_t*)h->p_hash.p, (const uint64_t*)h->p_cigoff.p,
+                  (const uint64_t*)h->p_recoff.p, (int32_t*)h->o_pos.p, (int32_t*)h->o_tid.p, (uint8_t*)h->o_mapq.p, (uint8_t*)h->o_flag.p,
+                  (uint32_t*)h->o_lseq.p, (uint32_t*)h->o_sflag.p, (uint64_t*)h->o_cigoff.p, (uint32_t*)h->o_cigar.p, (uint64_t*)h->o_hash.p,
+                  (uint64_t*)h->o_recoff.p);
+  HIPCHK(h, hipMemcpyAsync((uint64_t*)h->o_cigoff.p + K, &n_ops, 8, hipMemcpyHostToDevice, st));
+  // ---- dense first-appearance query ids: stable sort of (name hash, record), group heads, ranks of the first occurrences ---
+  if ((rc = reserve(h, 1, 1, nk))) return rc;                      // sort scratch (key / idx / alt pair / histograms) for nk rows
+  { int rs = reset_run_state(h); if (rs) return rs; }
+  const uint32_t nk32 = (uint32_t)nk;
+  HIPCHK(h, hipMemcpyAsync(h->o_n.p, &nk32, 4, hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipMemcpyAsync(h->key.p, h->o_hash.p, K * 8, hipMemcpyDeviceToDevice, st));
+  vsv_bamdev_iota(st, (uint32_t*)h->idx.p, nk);
+  SortWork sw = sort_work(h);
+  sw.small_tiles = nk <= 128 * 4096;
+  const SortResult sr = vsv_radix_sort_pairs(st, (uint64_t*)h->key.p, (uint32_t*)h->idx.p, sw.key_alt, sw.val_alt, (const uint32_t*)h->o_n.p, nk, 64, sw);
+  HIPCHK(h, hipMemsetAsync(h->o_first.p, 0, K * 4, st));
+  vsv_bamdev_mark_first(st, sr.key, sr.val, nk, (uint32_t*)h->o_first.p);
+  vsv_scan_u32_exclusive(st, (const uint32_t*)h->o_first.p, (int)nk, (uint32_t*)h->o_rank.p, (uint32_t*)h->p_sums.p);
+  vsv_bamdev_assign(st, sr.key, sr.val, nk, (const uint32_t*)h->o_rank.p, s, (const uint64_t*)h->o_recoff.p, (uint32_t*)h->o_qid.p, (uint32_t*)h->p_err.p);
+  vsv_bamdev_name_lens(st, s, (const uint64_t*)h->o_recoff.p, (const uint32_t*)h->o_first.p, nk, (uint32_t*)h->o_nlen.p);
+  vsv_scan_u32_exclusive(st, (const uint32_t*)h->o_nlen.p, (int)nk, (uint32_t*)h->o_noff.p, (uint32_t*)h->p_sums.p);
+  uint32_t lr = 0, lf = 0, lo = 0, ll = 0;
+  HIPCHK(h, hipMemcpyAsync(&lr, (uint32_t*)h->o_rank.p + (nk - 1), 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipMemcpyAsync(&lf, (uint32_t*)h->o_first.p + (nk - 1), 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipMemcpyAsync(&lo, (uint32_t*)h->o_noff.p + (nk - 1), 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipMemcpyAsync(&ll, (uint32_t*)h->o_nlen.p + (nk - 1), 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipMemcpyAsync(&err, h->p_err.p, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  if (err & 2u) return fail(h, VSV_E_INVALID, "64-bit name hash collision: use the host reader");
+  const size_t blob_bytes = (size_t)lo + ll;
+  if ((rc = ensure(h, h->o_blob, blob_bytes + 16))) return rc;
+  vsv_bamdev_name_copy(st, s, (const uint64_t*)h->o_recoff.p, (const uint32_t*)h->o_first.p, (const uint32_t*)h->o_noff.p, nk, (uint8_t*)h->o_blob.p);
+  h->names_blob.resize(blob_bytes);
+  if (blob_bytes) HIPCHK(h, hipMemcpyAsync(&h->names_blob[0], h->o_blob.p, blob_bytes, hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  if (blob_bytes) h->names_blob.pop_back();                          // the separator after the last name
+  out->pos = (const int32_t*)h->o_pos.p; out->tid = (const int32_t*)h->o_tid.p; out->qid = (const uint32_t*)h->o_qid.p;
+  out->cigar_off = (const uint64_t*)h->o_cigoff.p; out->mapq = (const uint8_t*)h->o_mapq.p; out->flag = (const uint8_t*)h->o_flag.p;
+  out->cigar = (const uint32_t*)h->o_cigar.p;
+  out->n_qids = (int32_t)(lr + lf);
+  if (names) *names = h->names_blob.c_str();
+  if (names_len) *names_len = (int64_t)h->names_blob.size();
+  if (l_seq_dev) *l_seq_dev = (const uint32_t*)h->o_lseq.p;
+  if (sam_flags_dev) *sam_flags_dev = (const uint32_t*)h->o_sflag.p;
+  h->stage_done = 0;
+  return 0;
+}
+
+int vsv_copy_to_host(vsv_handle* h, void* dst, const void* src_device, int64_t bytes) {
+  if (!h || bytes < 0 || (bytes > 0 && (!dst || !src_device))) return VSV_E_INVALID;
+  if (bytes == 0) return 0;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpyAsync(dst, src_device, (size_t)bytes, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
   return 0;
 }
 

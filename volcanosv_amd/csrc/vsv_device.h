@@ -158,3 +158,22 @@ void vsv_launch_rr_edit_sim(hipStream_t st, const uint32_t* pairs, uint32_t n_pa
 // inflate.hip: BGZF members (raw deflate) -> bytes, one lane per member
 void vsv_launch_bgzf_inflate(hipStream_t st, const uint8_t* comp, const uint64_t* comp_off, const uint64_t* out_off, int64_t n, uint8_t* out,
                              int32_t* status);
+
+// bam_device.hip: BAM record parse on the device
+void vsv_bamdev_speculate(hipStream_t st, const uint8_t* s, const uint64_t* moff, int64_t n_members, uint64_t first, int32_t n_ref, uint64_t* spec);
+void vsv_bamdev_chain(hipStream_t st, bool write, const uint8_t* s, const uint64_t* moff, int64_t n_members, const uint64_t* spec, uint32_t* count,
+                      uint64_t* land, const uint64_t* base, uint64_t* rec_off);
+void vsv_bamdev_fields(hipStream_t st, const uint8_t* s, const uint64_t* rec_off, int64_t n, int32_t want_tid, int32_t* pos, int32_t* tid, uint8_t* mapq,
+                       uint8_t* flag, uint32_t* l_seq, uint32_t* sam_flag, uint32_t* n_cig_out, uint64_t* cg_src, uint64_t* hash, uint32_t* keep, uint32_t* err);
+void vsv_bamdev_scan64(hipStream_t st, const uint32_t* v, const uint32_t* keep, int64_t n, uint64_t* sums, uint64_t* out, uint64_t* total);
+void vsv_bamdev_emit(hipStream_t st, const uint8_t* s, int64_t n, const uint32_t* keep, const uint32_t* kidx, const int32_t* pos, const int32_t* tid,
+                     const uint8_t* mapq, const uint8_t* flag, const uint32_t* l_seq, const uint32_t* sam_flag, const uint32_t* n_cig_out,
+                     const uint64_t* cg_src, const uint64_t* hash, const uint64_t* cig_off_in, const uint64_t* rec_off, int32_t* o_pos, int32_t* o_tid,
+                     uint8_t* o_mapq, uint8_t* o_flag, uint32_t* o_l_seq, uint32_t* o_sam_flag, uint64_t* o_cig_off, uint32_t* o_cigar, uint64_t* o_hash,
+                     uint64_t* o_rec_off);
+void vsv_bamdev_iota(hipStream_t st, uint32_t* p, int64_t n);
+void vsv_bamdev_mark_first(hipStream_t st, const uint64_t* skey, const uint32_t* sval, int64_t n, uint32_t* is_first);
+void vsv_bamdev_assign(hipStream_t st, const uint64_t* skey, const uint32_t* sval, int64_t n, const uint32_t* first_rank, const uint8_t* s,
+                       const uint64_t* rec_off, uint32_t* qid, uint32_t* err);
+void vsv_bamdev_name_lens(hipStream_t st, const uint8_t* s, const uint64_t* rec_off, const uint32_t* is_first, int64_t n, uint32_t* len);
+void vsv_bamdev_name_copy(hipStream_t st, const uint8_t* s, const uint64_t* rec_off, const uint32_t* is_first, const uint32_t* noff, int64_t n, uint8_t* blob);
