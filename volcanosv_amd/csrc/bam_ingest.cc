@@ -426,21 +426,34 @@ int vsv_bam_load_device(vsv_bam* b, vsv_handle* h, int tid, vsv_records* out) {
   b->n_threads = user_threads; b->gpu = user_gpu;
   if (!hdr_ok) return VSV_E_INVALID;
   const uint64_t first_record = b->inflated_total - (b->buf.size() - b->rd);
-  // all members, compressed
+  // the whole file in one read; the members' deflate payloads are addressed in place (a deflate stream ends itself, so the
+  // trailer and the next header that follow a payload inside [comp_off[i], comp_off[i+1]) are never consumed)
+  fseek(b->f, 0, SEEK_END);
+  const long fsize = ftell(b->f);
   fseek(b->f, 0, SEEK_SET);
-  b->eof = false;
-  std::vector<uint8_t> comp;
-  std::vector<uint64_t> coff(1, 0);
+  if (fsize <= 0) { b->err = "empty file"; return VSV_E_INVALID; }
+  std::vector<uint8_t> comp((size_t)fsize + 16);
+  if (fread(comp.data(), 1, (size_t)fsize, b->f) != (size_t)fsize) { b->err = "short read"; return VSV_E_INVALID; }
+  std::vector<uint64_t> coff;
   std::vector<uint32_t> isz;
-  for (;;) {
-    Member m; bool got;
-    if (!read_member(b, m, got)) return VSV_E_INVALID;
-    if (!got) break;
-    comp.insert(comp.end(), m.comp.begin(), m.comp.end() - 8);
-    coff.push_back(comp.size());
-    isz.push_back(m.isize);
+  for (size_t o = 0; o < (size_t)fsize;) {
+    const uint8_t* hdr = comp.data() + o;
+    if (o + 18 > (size_t)fsize || hdr[0] != 31 || hdr[1] != 139 || hdr[2] != 8 || !(hdr[3] & 4)) { b->err = "not a BGZF block"; return VSV_E_INVALID; }
+    const uint16_t xlen = hdr[10] | (hdr[11] << 8);
+    int bsize = -1;
+    for (size_t e = 0; e + 4 <= xlen;) {
+      const uint8_t* x = hdr + 12 + e;
+      const uint16_t slen = x[2] | (x[3] << 8);
+      if (x[0] == 'B' && x[1] == 'C' && slen == 2) bsize = x[4] | (x[5] << 8);
+      e += 4 + slen;
+    }
+    if (bsize < 0 || o + (size_t)bsize + 1 > (size_t)fsize) { b->err = "truncated BGZF block"; return VSV_E_INVALID; }
+    const uint8_t* tr = hdr + bsize + 1 - 8;
+    coff.push_back(o + 12 + xlen);
+    isz.push_back((uint32_t)tr[4] | ((uint32_t)tr[5] << 8) | ((uint32_t)tr[6] << 16) | ((uint32_t)tr[7] << 24));
+    o += (size_t)bsize + 1;
   }
-  comp.resize(comp.size() + 8);
+  coff.push_back((uint64_t)fsize);
   const char* names = nullptr; int64_t names_len = 0;
   const int st = vsv_bam_parse_device(h, comp.data(), coff.data(), isz.data(), (int64_t)isz.size(), first_record, (int32_t)b->ref_names.size(), tid, out,
                                       &names, &names_len, &b->dev_l_seq, &b->dev_sam_flag);
