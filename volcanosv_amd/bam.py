@@ -69,6 +69,20 @@ class PackedSeq:
         return self.ALPHABET[nib[:n]].tobytes().decode()
 
 
+class LightRecords:
+    """Host-side companion of a DeviceRecordView for the VCF / signature text: qname(rec), strand(rec), mapq[rec], tid_names."""
+
+    def __init__(self, qid, flag, mapq, tid, qnames, tid_names):
+        self.qid, self.flag, self.mapq, self.tid, self.qnames, self.tid_names = qid, flag, mapq, tid, qnames, tid_names
+        self.n_records = len(qid)
+
+    def qname(self, rec):
+        return self.qnames[int(self.qid[rec])]
+
+    def strand(self, rec):
+        return "-" if self.flag[rec] & 1 else "+"
+
+
 class DeviceRecordView:
     """Record SoA resident on the GPU, produced by BamFile.fetch_device (raw device pointers owned by the engine's handle).
     Quacks like RecordSoA / DeviceRecords where the engine needs it (`as_struct`); `to_host()` copies the arrays back."""
@@ -88,6 +102,32 @@ class DeviceRecordView:
 
     def qname(self, rec):
         raise NotImplementedError("qid lives on the device: use to_host().qname(rec)")
+
+    def _pull(self, ptr, count, dt, first=0):
+        out = np.zeros(count, dtype=dt)
+        if count:
+            eng = self._engine
+            addr = (ptr if isinstance(ptr, int) else int(ptr or 0)) + first * np.dtype(dt).itemsize
+            eng._check(eng.lib.vsv_copy_to_host(eng.h, out.ctypes.data_as(C.c_void_p), C.c_void_p(addr), out.nbytes))
+        return out
+
+    def host_light(self):
+        """What the text writers need on the host (query ids, flags, mapq, tids; 10 bytes per record) — the CIGARs stay on the GPU."""
+        r, n = self._rec, self.n_records
+        return LightRecords(self._pull(r.qid, n, np.uint32), self._pull(r.flag, n, np.uint8), self._pull(r.mapq, n, np.uint8),
+                            self._pull(r.tid, n, np.int32), self.qnames, self.tid_names)
+
+    def slice_records(self, lo, hi):
+        """View of records [lo, hi) (a chromosome of a coordinate-sorted file): same device arrays, offset pointers. The CIGAR
+        array and cigar_off values stay absolute."""
+        r = Records()
+        for name, size in (("pos", 4), ("tid", 4), ("qid", 4), ("cigar_off", 8), ("mapq", 1), ("flag", 1)):
+            setattr(r, name, C.c_void_p(int(getattr(self._rec, name) or 0) + lo * size))
+        r.cigar = self._rec.cigar
+        r.n_records, r.n_ops, r.on_device, r.n_qids, r.n_tids = hi - lo, self._rec.n_ops, 1, self._rec.n_qids, self._rec.n_tids
+        v = DeviceRecordView(r, self.qnames, self.tid_names, int(self._l_seq_ptr or 0) + 4 * lo, int(self._sam_flags_ptr or 0) + 4 * lo, self._engine)
+        v._parent = self
+        return v
 
     def to_host(self):
         """RecordSoA copy (plus l_seq / sam_flags) of the device arrays."""

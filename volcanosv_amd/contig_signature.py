@@ -9,8 +9,10 @@ from .engine import Engine, default_params
 
 
 def run(dtype_name, bam_path, contig_path, ref_path, output_dir, chr_number=None, header_path=None, params=None, device=0,
-        engine=None, log=print):
-    """Writes <output_dir>/volcano_variant_chr<N>.vcf for chr_number (or chr1..22, H:729-742). Returns {chrom: lines}."""
+        engine=None, log=print, device_ingest=True):
+    """Writes <output_dir>/volcano_variant_chr<N>.vcf for chr_number (or chr1..22, H:729-742). Returns {chrom: lines}.
+    device_ingest: the BAM is inflated and parsed on the GPU (the record SoA never visits the host; only names, flags and
+    mapq come back for the VCF text); False uses the host reader."""
     dtype = DTYPE_BY_NAME[dtype_name]
     os.makedirs(os.path.join(output_dir, "signature"), exist_ok=True)          # H:717-718
     dc_contig = vcf.load_contigs(contig_path)
@@ -44,12 +46,22 @@ def run(dtype_name, bam_path, contig_path, ref_path, output_dir, chr_number=None
                 name = "chr%d" % i
                 if bam.get_tid(name) < 0:
                     raise KeyError("%s not in the BAM header" % name)
-                soa = bam.fetch_soa(name)
-                soa.max_pos = bam.lengths[bam.get_tid(name)] + 100000   # sort-key hint: positions never exceed the contig
                 eng = engs[k % len(engs)]
                 while len(pending) >= len(engs):
                     drain(pending.pop(0))
-                eng.run_async(soa, p)
+                if device_ingest:
+                    view = bam.fetch_device(eng, name)
+                    view.max_pos = bam.lengths[bam.get_tid(name)] + 100000
+                    soa = view.host_light()
+                    if view.n_records:
+                        eng.run_async(view, p)
+                    else:
+                        eng.run_async(_EMPTY, p)
+                    soa._view = view                                     # keeps the device arrays' owner alive
+                else:
+                    soa = bam.fetch_soa(name)
+                    soa.max_pos = bam.lengths[bam.get_tid(name)] + 100000   # sort-key hint: positions never exceed the contig
+                    eng.run_async(soa, p)
                 pending.append((i, name, soa, eng))
             while pending:
                 drain(pending.pop(0))
@@ -58,6 +70,16 @@ def run(dtype_name, bam_path, contig_path, ref_path, output_dir, chr_number=None
             for e in engs:
                 e.close()
     return out
+
+
+def _empty_soa():
+    import numpy as np
+    from .soa import RecordSoA
+    return RecordSoA(np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.uint32), np.zeros(1, np.uint64), np.zeros(0, np.uint8),
+                     np.zeros(0, np.uint8), np.zeros(0, np.uint32))
+
+
+_EMPTY = _empty_soa()
 
 
 def _side_stream(device):

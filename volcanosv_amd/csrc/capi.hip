@@ -803,7 +803,10 @@ int vsv_bam_parse_device(vsv_handle* h, const uint8_t* comp, const uint64_t* com
                   (uint64_t*)h->o_recoff.p);
   HIPCHK(h, hipMemcpyAsync((uint64_t*)h->o_cigoff.p + K, &n_ops, 8, hipMemcpyHostToDevice, st));
   // ---- dense first-appearance query ids: stable sort of (name hash, record), group heads, ranks of the first occurrences ---
-  if ((rc = reserve(h, 1, 1, nk))) return rc;                      // sort scratch (key / idx / alt pair / histograms) for nk rows
+  {  // sort scratch (key / idx / alt pair / histograms) for nk rows; never below the default signature capacity of a run
+    const int64_t floor_cap = h->cap_sigs > 0 ? h->cap_sigs : (1 << 22);
+    if ((rc = reserve(h, 1, 1, nk > floor_cap ? nk : floor_cap))) return rc;
+  }
   { int rs = reset_run_state(h); if (rs) return rs; }
   const uint32_t nk32 = (uint32_t)nk;
   HIPCHK(h, hipMemcpyAsync(h->o_n.p, &nk32, 4, hipMemcpyHostToDevice, st));

@@ -7,16 +7,27 @@ from .bam import BamFile
 from .engine import Engine, default_params
 
 
-def run(input_path, output_dir, chr_number, device=0, engine=None, params=None):
-    """Writes <output_dir>/reads_signature/chr<N>_reads_sig.txt (RS:251-265): tab-joined str() fields, sorted by pos."""
+def run(input_path, output_dir, chr_number, device=0, engine=None, params=None, device_ingest=True):
+    """Writes <output_dir>/reads_signature/chr<N>_reads_sig.txt (RS:251-265): tab-joined str() fields, sorted by pos.
+    device_ingest: BAM inflated and parsed on the GPU (volcanosv_amd.bam.BamFile.fetch_device); False = host reader."""
     chrom = "chr%d" % chr_number
     out_dir = os.path.join(output_dir, "reads_signature")
     os.makedirs(out_dir, exist_ok=True)
     eng = engine or Engine(device)
     p = params or default_params(DTYPE_READS)
     with BamFile(input_path) as bam:
-        soa = bam.fetch_soa(chrom)
-    eng.run(soa, p)
+        if device_ingest:
+            view = bam.fetch_device(eng, chrom)
+            soa = view.host_light()
+            if view.n_records:
+                eng.run(view, p)
+            else:
+                device_ingest = False
+                soa = bam.fetch_soa(chrom)
+        else:
+            soa = bam.fetch_soa(chrom)
+    if not device_ingest:
+        eng.run(soa, p)
     rows = [sigtable.sig_fields(soa, s, DTYPE_READS) for s in eng.table("reads")]
     path = os.path.join(out_dir, chrom + "_reads_sig.txt")
     with open(path, "w") as f:
