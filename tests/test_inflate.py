@@ -125,3 +125,42 @@ def test_bam_parsed_on_the_device_equals_host_reader(tmp_path):
         except Exception as e:                                                 # noqa: BLE001
             raised = e
         assert raised is not None and "CIGAR" in str(raised) and len(ok) == keep.n_records - 1
+
+
+@pytest.mark.gpu
+def test_device_reader_rejects_damaged_files(tmp_path):
+    """Truncated files, a corrupted deflate payload and a stream that ends inside a record fail with an error (as the host
+    reader does), they never hang or return partial tables."""
+    from volcanosv_amd import bam, synth
+    from volcanosv_amd.abi import VsvError
+    from volcanosv_amd.engine import Engine
+    t, nq, _ = synth.generate(20000, "hifi", seed=2)
+    soa = synth.to_soa(t, nq)
+    recs = []
+    for i in range(soa.n_records):
+        a, b = int(soa.cigar_off[i]), int(soa.cigar_off[i + 1])
+        recs.append(dict(tid=0, pos=int(soa.pos[i]), qname="r%d" % i, mapq=60, flag=0, cigar=[(int(w) & 15, int(w) >> 4) for w in soa.cigar[a:b]]))
+    good = str(tmp_path / "good.bam")
+    bam.write_bam(good, [("chr10", synth.CHR10_LEN)], recs)
+    raw = open(good, "rb").read()
+    cases = {"cut_in_member.bam": raw[: len(raw) // 2], "bad_payload.bam": raw[: len(raw) // 2] + bytes(64) + raw[len(raw) // 2 + 64:]}
+    # a well-formed BGZF file whose record stream stops inside a record: drop the tail members but keep the EOF marker
+    with bam.BamFile(good) as bf:
+        pass
+    offs, o = [], 0
+    while o < len(raw):
+        bsize = raw[o + 16] | (raw[o + 17] << 8)
+        offs.append(o)
+        o += bsize + 1
+    cases["ends_in_record.bam"] = raw[: offs[len(offs) // 2]] + raw[offs[-1]:]
+    with Engine(0) as eng:
+        with bam.BamFile(good) as bf:
+            assert bf.fetch_device(eng, "chr10").n_records == soa.n_records
+        for name, data in cases.items():
+            p = str(tmp_path / name)
+            open(p, "wb").write(data)
+            with bam.BamFile(p) as bf:
+                with pytest.raises(VsvError):
+                    bf.fetch_device(eng, "chr10")
+                with pytest.raises(VsvError):
+                    bf.fetch_soa("chr10")
