@@ -194,3 +194,29 @@ def test_cli_svim_bnd_and_filter_tra(tmp_path):
                            "-o", str(tmp_path / "TRA"), "-bam", "x.bam"])
     tra = [l for l in open(tmp_path / "TRA" / "TRA_final.vcf") if not l.startswith("#")]
     assert 0 < len(tra) <= len(lines)
+
+
+@pytest.mark.gpu
+def test_all_chromosomes_parse_once_on_the_device(tmp_path):
+    """contig_signature.run without -chr (chr1..chr22, H:729-742): the device reader inflates and parses the file once and every
+    chromosome runs on its record range; the VCFs equal those of the host reader, chromosome by chromosome."""
+    from volcanosv_amd import contig_signature
+    doc, soa, _ = load_fixture("contig_hifi_tiefree")
+    chroms = doc["expected"]["chroms"]
+    b = str(tmp_path / "contigs.sorted.bam")
+    recs = [dict(tid=chroms.index(r[0]), pos=r[1], qname=r[2], mapq=r[3], flag=16 if r[4] else 0, cigar=[tuple(c) for c in r[5]])
+            for r in doc["records"]]
+    bam.write_bam(b, [("chr%d" % i, 1000000) for i in range(1, 23)], recs)
+    with open(tmp_path / "contigs.fa", "w") as f:
+        for n, s in fixture_inputs(doc).items():
+            f.write(">%s\n%s\n" % (n, s))
+    with open(tmp_path / "ref.fa", "w") as f:
+        for i in range(1, 23):
+            f.write(">chr%d\n%s\n" % (i, synth_seq("chr%d" % i)))
+    outs = {}
+    for mode in (True, False):
+        outs[mode] = contig_signature.run("Hifi", b, str(tmp_path / "contigs.fa"), str(tmp_path / "ref.fa"), str(tmp_path / ("out%d" % mode)),
+                                          chr_number=None, device_ingest=mode, log=lambda *a: None)
+    assert outs[True] == outs[False] and sum(len(v) for v in outs[True].values()) > 10
+    for c in chroms:
+        assert digest(outs[True][c]) == doc["expected"]["per_chrom"][c]["vcf"]

@@ -2,6 +2,8 @@
 (reference Large_INDEL/extract_contig_signature_Hifi.py:725-772) on top of the HIP engine."""
 import os
 
+import numpy as np
+
 from . import vcf
 from .abi import DTYPE_BY_NAME
 from .bam import BamFile
@@ -42,6 +44,17 @@ def run(dtype_name, bam_path, contig_path, ref_path, output_dir, chr_number=None
     try:
         with BamFile(bam_path) as bam:
             pending = []
+            whole, ranges = None, {}
+            if device_ingest and len(chroms) > 1:
+                # several chromosomes: inflate and parse the file ONCE, then hand each chromosome's record range to an engine
+                # (a coordinate-sorted BAM keeps a reference's records together); both engines read the same device arrays
+                whole = bam.fetch_device(engs[0], None)
+                tids = whole.host_light().tid
+                if len(tids) and (np.diff(tids) < 0).any():
+                    raise ValueError("BAM is not sorted by reference: use device_ingest=False")
+                for t in np.unique(tids):
+                    lo, hi = np.searchsorted(tids, t, side="left"), np.searchsorted(tids, t, side="right")
+                    ranges[int(t)] = (int(lo), int(hi))
             for k, i in enumerate(chroms):
                 name = "chr%d" % i
                 if bam.get_tid(name) < 0:
@@ -50,7 +63,11 @@ def run(dtype_name, bam_path, contig_path, ref_path, output_dir, chr_number=None
                 while len(pending) >= len(engs):
                     drain(pending.pop(0))
                 if device_ingest:
-                    view = bam.fetch_device(eng, name)
+                    if whole is not None:
+                        lo, hi = ranges.get(bam.get_tid(name), (0, 0))
+                        view = whole.slice_records(lo, hi)
+                    else:
+                        view = bam.fetch_device(eng, name)
                     view.max_pos = bam.lengths[bam.get_tid(name)] + 100000
                     soa = view.host_light()
                     if view.n_records:
