@@ -738,7 +738,7 @@ int vsv_bam_parse_device(vsv_handle* h, const uint8_t* comp, const uint64_t* com
   HIPCHK(h, hipStreamSynchronize(st));
   uint64_t n_total = 0;
   for (int round = 0;; ++round) {
-    if (round > 64) return fail(h, VSV_E_INVALID, "record chain does not settle (not a BAM stream?)");
+    if (round > 1024) return fail(h, VSV_E_INVALID, "record chain does not settle (not a BAM stream?): use the host reader");
     HIPCHK(h, hipMemcpyAsync(h->p_spec.p, spec.data(), nm * 8, hipMemcpyHostToDevice, st));
     vsv_bamdev_chain(st, false, s, d_moff, n_members, (const uint64_t*)h->p_spec.p, (uint32_t*)h->p_cnt.p, (uint64_t*)h->p_land.p, nullptr, nullptr);
     HIPCHK(h, hipMemcpyAsync(cnt.data(), h->p_cnt.p, nm * 4, hipMemcpyDeviceToHost, st));

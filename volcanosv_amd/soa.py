@@ -52,6 +52,10 @@ class RecordSoA:
         r.max_pos = int(getattr(self, "max_pos", 0))
         return r
 
+    def host_light(self):
+        """Same interface as bam.DeviceRecordView.host_light(): a host SoA already is what the text writers need."""
+        return self
+
     def qname(self, rec):
         q = int(self.qid[rec])
         return self.qnames[q] if self.qnames is not None else "q%d" % q
