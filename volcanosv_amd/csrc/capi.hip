@@ -718,6 +718,15 @@ int vsv_bam_parse_device(vsv_handle* h, const uint8_t* comp, const uint64_t* com
   if (n_members <= 0 || !comp || !comp_off || !isize) return fail(h, VSV_E_INVALID, "no BGZF members");
   HIPCHK(h, hipSetDevice(h->device));
   hipStream_t st = h->stream;
+  {  // the single-pass reader keeps the compressed file, the inflated stream and the SoA on the device at once
+    uint64_t inflated = 0;
+    for (int64_t i = 0; i < n_members; ++i) inflated += isize[i];
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(h, hipMemGetInfo(&free_b, &total_b));
+    const uint64_t need = (comp_off[n_members] - comp_off[0]) + 3 * inflated;      // stream + per-record scratch + outputs, generous
+    if (need > (uint64_t)free_b + h->z_comp.bytes + h->z_out.bytes)
+      return fail(h, VSV_E_CAPACITY, "file too large for the single-pass device reader: use the host reader");
+  }
   std::vector<uint64_t> moff;
   int rc = inflate_to_device(h, comp, comp_off, isize, n_members, moff);
   if (rc) return rc;
