@@ -246,6 +246,19 @@ int vsv_bnd_pair(vsv_handle* h, const vsv_bnd_params* p);
  * as the input of vsv_bnd_pair. */
 int vsv_bnd_set_candidates(vsv_handle* h, const vsv_bnd* rows, int64_t n, const int32_t* contig_rank, int32_t n_tids, int on_device);
 
+/* ---- genotype correction: correct_gt_del_real_data.py / correct_gt_ins_real_data.py (filter_GT_correction.py:150-170) ----------
+ * vsv_gt_support  replaces the window sums of match_varlist_siglist (DG:92-137) / extract_sig_support (IG:105-156): for variant i
+ *   sum[i] = sum of sig_cnt over the signatures j in [blk_lo[i], blk_hi[i]) (the variant's chromosome block, positions ascending)
+ *   with pos - max_shift <= sig_pos[j] <= pos + max_shift, max_shift = max(svlen * max_shift_ratio, 500), and
+ *   svlen * min_size_sim <= sig_svlen[j] <= svlen / min_size_sim (fp64 like the reference); lo[i] / hi[i] = the window's index
+ *   range, from which the caller replays the reference's resume-index bookkeeping. Host arrays.
+ * vsv_span_count  replaces count_reads_span_region (DG:140-147) / check_full_cover_reads (IG:178-186): out[i] = records of
+ *   reference q_tid[i] with reference_start < q_a[i] and reference_end > q_b[i]; `recs` ascending by (tid, pos), host or device. */
+int vsv_gt_support(vsv_handle* h, const int32_t* var_pos, const int32_t* var_svlen, const int32_t* blk_lo, const int32_t* blk_hi, int64_t n_var,
+                   const int32_t* sig_pos, const int32_t* sig_svlen, const int32_t* sig_cnt, int64_t n_sig, double max_shift_ratio,
+                   double min_size_sim, int64_t* sum, int32_t* lo, int32_t* hi);
+int vsv_span_count(vsv_handle* h, const vsv_records* recs, const int32_t* q_tid, const int32_t* q_a, const int32_t* q_b, int64_t n_q, uint32_t* out);
+
 /* ---- sig_extract.py split-read branch ------------------------------------------------------------------------------
  * vsv_cutesv_split replaces analysis_split_read (SE:193-319), INS/DEL candidates only (the TRA candidates of analysis_bnd
  * never reach INS.sigs / DEL.sigs, SE:637-638). Input: for every flag-0/16 read with an SA tag, the segment list

@@ -43,6 +43,8 @@ def lib():
                                  C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
         _LIB.orc_bnd_free.argtypes = [C.c_void_p, C.c_void_p]
         _LIB.orc_bnd_pair.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(BndParams), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        _LIB.orc_gt_support.argtypes = [C.c_void_p] * 3 + [C.c_int64] + [C.c_void_p] * 4 + [C.c_int64, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+        _LIB.orc_span_count.argtypes = [C.c_void_p] * 3 + [C.c_int64] + [C.c_void_p] * 3 + [C.c_int64, C.c_void_p]
         _LIB.orc_levenshtein.argtypes = [C.c_char_p, C.c_int64, C.c_char_p, C.c_int64]
         _LIB.orc_levenshtein.restype = C.c_int64
         _LIB.orc_default_redundancy_params.argtypes = [C.POINTER(RedundancyParams)]
@@ -200,3 +202,23 @@ def run_redundancy_pairs(is_del, pos, svlen, seq=None, seq_off=None, params=None
     out = np.frombuffer((C.c_char * (na.value * 8)).from_address(a.value), dtype=np.uint32).reshape(-1, 2).copy() if na.value else np.zeros((0, 2), np.uint32)
     lib().orc_free_u32(a)
     return 0, out
+
+
+def run_gt_support(var_chrom, var_pos, var_svlen, sig_chrom, sig_pos, sig_svlen, sig_cnt, max_shift_ratio=2.3, min_size_sim=0.6):
+    """match_varlist_siglist / extract_sig_support on the host (literal scans): (support list, resume-index list)."""
+    a = [_i32(x) for x in (var_chrom, var_pos, var_svlen, sig_chrom, sig_pos, sig_svlen, sig_cnt)]
+    nv, ns = len(a[0]), len(a[3])
+    cnt, match = np.zeros(nv, np.int64), np.zeros(nv, np.int64)
+    p = [x.ctypes.data_as(C.c_void_p) for x in a]
+    lib().orc_gt_support(p[0], p[1], p[2], nv, p[3], p[4], p[5], p[6], ns, float(max_shift_ratio), float(min_size_sim),
+                         cnt.ctypes.data_as(C.c_void_p), match.ctypes.data_as(C.c_void_p))
+    return cnt, match
+
+
+def run_span_count(read_tid, read_start, read_end, q_tid, q_a, q_b):
+    """count_reads_span_region on the host: reads with start < a and end > b among those fetch(chrom, a, b) returns."""
+    a = [_i32(x) for x in (read_tid, read_start, read_end, q_tid, q_a, q_b)]
+    out = np.zeros(len(a[3]), np.uint32)
+    p = [x.ctypes.data_as(C.c_void_p) for x in a]
+    lib().orc_span_count(p[0], p[1], p[2], len(a[0]), p[3], p[4], p[5], len(a[3]), out.ctypes.data_as(C.c_void_p))
+    return out

@@ -1088,3 +1088,57 @@ int orc_redundancy_pairs(int is_del, const int32_t* pos, const int32_t* svlen, c
   return 0;
 }
 void orc_free_u32(uint32_t* p) { free(p); }
+
+/* ================================================================================================
+ * Genotype correction: correct_gt_del_real_data.py (DG) / correct_gt_ins_real_data.py (IG).
+ * orc_gt_support: match_varlist_siglist (DG:92-137) / extract_sig_support (IG:105-156), the literal forward and backward
+ * scans from the resume index, including their shared visit of that index. Chromosomes are ids; sig arrays in list order.
+ * orc_span_count: count_reads_span_region (DG:140-147) / check_full_cover_reads (IG:178-186).
+ * ================================================================================================ */
+int orc_gt_support(const int32_t* var_chrom, const int32_t* var_pos, const int32_t* var_svlen, int64_t nv, const int32_t* sig_chrom,
+                   const int32_t* sig_pos, const int32_t* sig_svlen, const int32_t* sig_cnt, int64_t ns, double max_shift_ratio,
+                   double min_size_sim, int64_t* cnt_out, int64_t* match_out) {
+  int64_t last = 0;
+  for (int64_t v = 0; v < nv; ++v) {
+    const double svlen = (double)var_svlen[v];
+    const double prod = svlen * max_shift_ratio;
+    const double max_shift = prod > 500.0 ? prod : 500.0;                          /* DG:107, IG:117 */
+    const double min_pos = (double)var_pos[v] - max_shift, max_pos = (double)var_pos[v] + max_shift;
+    const double min_size = svlen * min_size_sim, max_size = svlen / min_size_sim; /* DG:105-106 */
+    int64_t support = 0, min_match = -1;
+    match_out[v] = last;                                                            /* IG:125 */
+    for (int64_t i = last; i < ns; ++i) {                                           /* DG:114-122 */
+      if (sig_chrom[i] != var_chrom[v]) continue;
+      const double p = (double)sig_pos[i];
+      if (min_pos <= p && p <= max_pos) {
+        if (min_match < 0 || i < min_match) min_match = i;
+        const double l = (double)sig_svlen[i];
+        if (min_size <= l && l <= max_size) support += sig_cnt[i];
+      } else if (p > max_pos) break;
+    }
+    for (int64_t i = (ns > 0 ? last : -1); i >= 0; --i) {                           /* DG:124-132 */
+      if (sig_chrom[i] != var_chrom[v]) continue;
+      const double p = (double)sig_pos[i];
+      if (min_pos <= p && p <= max_pos) {
+        if (min_match < 0 || i < min_match) min_match = i;
+        const double l = (double)sig_svlen[i];
+        if (min_size <= l && l <= max_size) support += sig_cnt[i];
+      } else if (p < min_pos) break;
+    }
+    if (min_match >= 0) last = min_match;                                           /* DG:134-135 */
+    cnt_out[v] = support;
+  }
+  return 0;
+}
+
+int orc_span_count(const int32_t* read_tid, const int32_t* read_start, const int32_t* read_end, int64_t nr, const int32_t* q_tid,
+                   const int32_t* q_a, const int32_t* q_b, int64_t nq, uint32_t* out) {
+  for (int64_t i = 0; i < nq; ++i) {
+    uint32_t c = 0;
+    for (int64_t r = 0; r < nr; ++r)
+      if (read_tid[r] == q_tid[i] && read_start[r] < q_b[i] && read_end[r] > q_a[i])   /* fetch(chrom, a, b): overlaps the region */
+        if (read_start[r] < q_a[i] && read_end[r] > q_b[i]) ++c;                          /* DG:144 */
+    out[i] = c;
+  }
+  return 0;
+}

@@ -1,0 +1,173 @@
+"""Genotype correction (correct_gt_del_real_data.py / correct_gt_ins_real_data.py behind filter_GT_correction.py).
+
+CPU: the oracle's literal scans against tests/golden/gt_correction.json (outputs of the reference's own functions,
+tests/golden/make_golden_gt.py), and the host replay of the resume-index bookkeeping over a numpy stand-in of the two joins.
+GPU: vsv_gt_support / vsv_span_count through the C-ABI — support, depth, both TSV tables and the re-genotyped VCF lines equal
+the reference's text; random larger inputs against the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gt_correction.json")
+
+
+@pytest.fixture(scope="module")
+def doc():
+    with open(GOLDEN) as f:
+        return json.load(f)
+
+
+def write_inputs(case, d):
+    vcf = d / "in.vcf"
+    vcf.write_text("".join(case["vcf"]))
+    (d / "DEL.sigs").write_text("".join(case["del_sigs"]))
+    (d / "INS.sigs").write_text("".join(case["ins_sigs"]))
+    return str(vcf)
+
+
+def reads_arrays(case, names):
+    tid, start, end = [], [], []
+    for t, c in enumerate(names):
+        for s, e in case["reads"].get(c, []):
+            tid.append(t); start.append(s); end.append(e)
+    return np.array(tid), np.array(start), np.array(end)
+
+
+class NumpyJoins:
+    """Stand-in for the engine's two joins (window sums / spanning counts), so the host logic runs without a GPU."""
+
+    def __init__(self, case, names):
+        self.tid, self.start, self.end = reads_arrays(case, names)
+
+    def gt_support(self, var_pos, var_svlen, blk_lo, blk_hi, sig_pos, sig_svlen, sig_cnt, ratio=2.3, sim=0.6):
+        sig_pos, sig_svlen, sig_cnt = (np.asarray(x) for x in (sig_pos, sig_svlen, sig_cnt))
+        s, lo, hi = [], [], []
+        for p, l, a, b in zip(var_pos, var_svlen, blk_lo, blk_hi):
+            shift = max(l * ratio, 500)
+            w = sig_pos[a:b]
+            i0 = a + int(np.searchsorted(w, p - shift, side="left"))
+            i1 = a + int(np.searchsorted(w, p + shift, side="right"))
+            ok = (sig_svlen[i0:i1] >= l * sim) & (sig_svlen[i0:i1] <= l / sim)
+            s.append(int(sig_cnt[i0:i1][ok].sum())); lo.append(i0); hi.append(i1)
+        return np.array(s), np.array(lo), np.array(hi)
+
+    def span_count(self, recs, q_tid, q_a, q_b):
+        return np.array([int(((self.tid == t) & (self.start < a) & (self.end > b)).sum()) for t, a, b in zip(q_tid, q_a, q_b)], dtype=np.uint32)
+
+
+def check_text_level(case, eng, reads, d):
+    from volcanosv_amd import gt_correction as gc
+    vcf = write_inputs(case, d)
+    gc.run_del(vcf, str(d / "bnd_del_real.tsv"), None, str(d / "DEL.sigs"), case["dtype"], eng, reads)
+    assert (d / "bnd_del_real.tsv").read_text() == case["del_tsv"]
+    assert (d / "bnd_del_real.tsv.newgt").read_text() == case["del_newgt_tsv"]
+    assert open(vcf + ".newgt.DEL").read() == case["del_newgt_vcf"]
+    gc.run_ins(vcf, str(d / "bnd_ins_real.tsv"), None, str(d / "INS.sigs"), case["dtype"], eng, reads)
+    assert (d / "INS.sigs.gte30auto").read_text() == case["ins_gte30auto"]
+    assert (d / "bnd_ins_real.tsv").read_text() == case["ins_tsv"]
+    assert (d / "bnd_ins_real.tsv.newgt").read_text() == case["ins_newgt_tsv"]
+    assert open(vcf + ".newgt.INS").read() == case["ins_newgt_vcf"]
+
+
+def test_oracle_scans_match_reference(doc, tmp_path):
+    from oracle import oracle
+    from volcanosv_amd import gt_correction as gc
+    for case in doc:
+        d = tmp_path / case["name"]
+        d.mkdir()
+        vcf = write_inputs(case, d)
+        # DEL
+        vs, sl = gc.load_vcf_del(vcf), gc.load_sig_del(str(d / "DEL.sigs"))
+        cid = {}
+        ids = lambda xs: [cid.setdefault(x, len(cid)) for x in xs]
+        cnt, _ = oracle.run_gt_support(ids([v[2].split()[0] for v in vs]), [int(v[2].split()[1]) for v in vs], [v[1] for v in vs],
+                                       ids([s[0] for s in sl]), [s[1] for s in sl], [s[2] for s in sl], [s[3] for s in sl])
+        assert cnt.tolist() == case["del_support"]
+        # INS (with the resume-index column)
+        vi = gc.load_vcf_ins(vcf)
+        sd = gc.load_sig_file_ins(str(d / "INS.sigs"))
+        cnt, match = oracle.run_gt_support([v[0] for v in vi], [v[1] for v in vi], [v[2] for v in vi], [k[0] for k in sd], [k[1] for k in sd],
+                                           [k[2] for k in sd], list(sd.values()))
+        assert cnt.tolist() == case["ins_support"] and match.tolist() == case["ins_match"]
+        # spanning reads
+        names = sorted(case["reads"])
+        tid, start, end = reads_arrays(case, names)
+        q = oracle.run_span_count(tid, start, end, [names.index("chr%d" % v[0]) for v in vi], [v[1] - 100 for v in vi], [v[1] + 100 for v in vi])
+        assert q.tolist() == case["ins_depth"]
+
+
+def test_host_replay_text_level(doc, tmp_path):
+    for case in doc:
+        d = tmp_path / case["name"]
+        d.mkdir()
+        names = sorted(case["reads"])
+        check_text_level(case, NumpyJoins(case, names), (None, {n: i for i, n in enumerate(names)}), d)
+
+
+def reads_bam(case, path):
+    from volcanosv_amd import bam
+    names = ["chr1", "chr2", "chr10"]
+    recs = []
+    for t, c in enumerate(names):
+        for k, (s, e) in enumerate(case["reads"][c]):
+            recs.append(dict(tid=t, pos=s, qname="%s_%d" % (c, k), mapq=60, flag=0, cigar=[(0, (e - s) // 2), (2, 7), (0, e - s - 7 - (e - s) // 2)]))
+    bam.write_bam(path, [(c, 1_000_000) for c in names], recs)
+
+
+@pytest.mark.gpu
+def test_gpu_gt_correction_text_level(doc, tmp_path):
+    from volcanosv_amd import gt_correction as gc
+    from volcanosv_amd.engine import Engine
+    with Engine(0) as eng:
+        for case in doc:
+            d = tmp_path / case["name"]
+            d.mkdir()
+            reads_bam(case, str(d / "reads.bam"))
+            reads = gc._reads_view(eng, str(d / "reads.bam"))
+            check_text_level(case, eng, reads, d)
+
+
+@pytest.mark.gpu
+def test_gpu_joins_vs_oracle_random():
+    from oracle import oracle
+    from volcanosv_amd.engine import Engine
+    from volcanosv_amd.soa import RecordSoA
+    rng = np.random.default_rng(17)
+    ns, nv = 200_000, 20_000
+    sig_chrom = np.sort(rng.integers(0, 3, ns))
+    sig_pos = np.concatenate([np.sort(rng.integers(0, 5_000_000, int((sig_chrom == c).sum()))) for c in range(3)])
+    sig_len = rng.integers(30, 3000, ns)
+    sig_cnt = rng.integers(1, 9, ns)
+    var_chrom = rng.integers(0, 4, nv)                                   # chromosome 3 has no signatures
+    var_pos = rng.integers(0, 5_000_000, nv)
+    var_len = rng.integers(30, 5000, nv)
+    starts = np.searchsorted(sig_chrom, np.arange(4), side="left")
+    ends = np.searchsorted(sig_chrom, np.arange(4), side="right")
+    with Engine(0) as eng:
+        s, lo, hi = eng.gt_support(var_pos, var_len, starts[var_chrom], ends[var_chrom], sig_pos, sig_len, sig_cnt)
+        want, _ = oracle.run_gt_support(var_chrom[:300], var_pos[:300], var_len[:300], sig_chrom, sig_pos, sig_len, sig_cnt)
+        # the oracle carries the resume-index double count; remove it with the same rule the host applies
+        last, fixed = 0, []
+        for v in range(300):
+            t = int(s[v])
+            if lo[v] <= last < hi[v] and var_len[v] * 0.6 <= sig_len[last] <= var_len[v] / 0.6:
+                t += int(sig_cnt[last])
+            if hi[v] > lo[v]:
+                last = int(lo[v])
+            fixed.append(t)
+        assert fixed == want.tolist()
+        # spanning reads over 300 k records on three references, device-resident records
+        n = 300_000
+        tid = np.sort(rng.integers(0, 3, n)).astype(np.int32)
+        pos = np.concatenate([np.sort(rng.integers(0, 3_000_000, int((tid == c).sum()))) for c in range(3)]).astype(np.int32)
+        span = rng.integers(500, 30000, n)
+        span[::5000] = 400_000
+        recs = [(int(tid[i]), int(pos[i]), i, 60, False, [(0, int(span[i]))]) for i in range(n)]
+        soa = RecordSoA.from_tuples(recs)
+        q_t, q_a = rng.integers(0, 3, 4000), rng.integers(1000, 3_000_000, 4000)
+        q_b = q_a + rng.integers(1, 3000, 4000)
+        got = eng.span_count(soa, q_t, q_a, q_b)
+        want = oracle.run_span_count(tid, pos, pos + span, q_t[:400], q_a[:400], q_b[:400])
+        assert got[:400].tolist() == want.tolist() and got.sum() > 0

@@ -37,6 +37,7 @@ def test_cli_scripts_parse(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for s in ("Raw_variant_call.py", "volcanosv-vc-large-indel.py", "volcanosv-vc-complex-sv.py", "extract_contig_signature_Hifi.py",
               "extract_reads_signature.py", "filter_tra.py", "FP_filter_v1.py", "calculate_signature_support.py",
-              "filter_vcf_by_sig_cov_insdel.py", "sig_extract.py", "remove_redundancy.py"):
+              "filter_vcf_by_sig_cov_insdel.py", "sig_extract.py", "remove_redundancy.py", "correct_gt_del_real_data.py",
+              "correct_gt_ins_real_data.py", "filter_GT_correction.py"):
         r = subprocess.run([sys.executable, os.path.join(root, "volcanosv_amd", "cli", s), "--help"], capture_output=True, text=True)
         assert r.returncode == 0, s + r.stderr[-500:]

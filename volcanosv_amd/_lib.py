@@ -19,7 +19,7 @@ SYMBOLS = [
     "vsv_default_params", "vsv_reserve", "vsv_cigar_scan", "vsv_split_pairs", "vsv_sort_cluster", "vsv_merge_sources",
     "vsv_pair_haplotypes", "vsv_run_chromosome", "vsv_run_chromosome_async", "vsv_finish", "vsv_table_count",
     "vsv_table_fill", "vsv_last_scan_ms", "vsv_default_bnd_params", "vsv_bnd_segments", "vsv_bnd_pair", "vsv_bnd_set_candidates",
-    "vsv_cutesv_split", "vsv_bgzf_inflate", "vsv_bam_set_inflate_device", "vsv_bam_parse_device", "vsv_copy_to_host", "vsv_bam_load_device", "vsv_bam_l_seq_device",
+    "vsv_cutesv_split", "vsv_gt_support", "vsv_span_count", "vsv_bgzf_inflate", "vsv_bam_set_inflate_device", "vsv_bam_parse_device", "vsv_copy_to_host", "vsv_bam_load_device", "vsv_bam_l_seq_device",
     "vsv_bam_sam_flags_device", "vsv_default_redundancy_params", "vsv_redundancy_pairs", "vsv_default_support_params", "vsv_support_join", "vsv_support_cov_ins", "vsv_support_cov_del",
     "vsv_bam_open", "vsv_bam_close", "vsv_bam_error", "vsv_bam_set_threads", "vsv_bam_n_refs", "vsv_bam_ref_name", "vsv_bam_ref_len", "vsv_bam_load",
     "vsv_bam_qnames", "vsv_bam_sa_tags", "vsv_bam_l_seq", "vsv_bam_sam_flags", "vsv_bam_set_keep_seq", "vsv_bam_seq",
@@ -74,6 +74,8 @@ def load():
                                          C.c_int64, C.POINTER(C.c_int64)]
     lib.vsv_bam_parse_device.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_int32, C.c_int32, C.POINTER(Records),
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.vsv_gt_support.argtypes = [H] + [C.c_void_p] * 4 + [C.c_int64] + [C.c_void_p] * 3 + [C.c_int64, C.c_double, C.c_double] + [C.c_void_p] * 3
+    lib.vsv_span_count.argtypes = [H, C.POINTER(Records), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.vsv_copy_to_host.argtypes = [H, C.c_void_p, C.c_void_p, C.c_int64]
     lib.vsv_bgzf_inflate.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.vsv_support_cov_ins.argtypes = [H, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int, C.c_void_p]

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Drop-in for Large_INDEL/volcanosv-vc-large-indel.py (same flags, plus --gpus). Chromosomes fan out over GPUs (one
-Raw_variant_call.py process per chromosome, LPT over the visible devices) instead of joblib over CPU cores."""
+Raw_variant_call.py process per chromosome, LPT over the visible devices) instead of joblib over CPU cores; the signature
+filter and the genotype correction that follow (filter_GT_correction.py) run in this process on the GPU."""
 import argparse
 import os
 import subprocess
@@ -52,13 +53,9 @@ for c in chroms:
 raw_vcf = out + ("/raw_variants_wgs.vcf" if a.chr_num is None else "/chr%d/final_vcf/volcano_variant_no_redundancy.vcf" % a.chr_num)
 if a.chr_num is None:
     open(raw_vcf, 'w').writelines(header + body)
-code_dir = os.environ.get("VOLCANOSV_CODE_DIR")
-chr_para = "" if a.chr_num is None else " -chr %d" % a.chr_num
-src = ("-presig %s" % a.pre_cutesig) if a.pre_cutesig else ("-bam %s -ref %s" % (a.bam_file, a.reference))
-ran = pipeline.spawn_reference_script(code_dir, "filter_GT_correction.py", "-vcf %s %s -dtype %s -t %d%s" % (raw_vcf, src, a.data_type, a.n_thread, chr_para))
-infile = (out + '/chr%d/final_vcf/variants_filtered_GT_corrected.vcf' % a.chr_num) if a.chr_num is not None else out + "/variants_filtered_GT_corrected.vcf"
-if not ran or not os.path.exists(infile):
-    infile = raw_vcf                                      # GT correction is outside this build
+# filter_GT_correction.py (DRV: the step after the per-chromosome calls): signatures, coverage band, genotype correction
+from volcanosv_amd import gt_correction  # noqa: E402
+infile = gt_correction.filter_gt_correction(raw_vcf, a.bam_file, a.reference, a.pre_cutesig, a.data_type, a.chr_num)
 outfile = (out_chr + "/%s_volcanosv_large_indel_chr%d.vcf" % (a.prefix, a.chr_num)) if a.chr_num is not None else out + "/%s_volcanosv_large_indel.vcf" % a.prefix
 open(outfile, "w").writelines(pipeline.phase_large_indel(open(infile).readlines(), header))
 print("wrote", outfile)

@@ -857,6 +857,53 @@ int vsv_bam_parse_device(vsv_handle* h, const uint8_t* comp, const uint64_t* com
   return 0;
 }
 
+int vsv_gt_support(vsv_handle* h, const int32_t* var_pos, const int32_t* var_svlen, const int32_t* blk_lo, const int32_t* blk_hi, int64_t nv,
+                   const int32_t* sig_pos, const int32_t* sig_svlen, const int32_t* sig_cnt, int64_t ns, double max_shift_ratio, double min_size_sim,
+                   int64_t* sum, int32_t* lo, int32_t* hi) {
+  if (!h) return VSV_E_INVALID;
+  if (nv < 0 || ns < 0) return fail(h, VSV_E_INVALID, "negative count");
+  if (nv == 0) return 0;
+  if (!var_pos || !var_svlen || !blk_lo || !blk_hi || !sum || !lo || !hi || (ns > 0 && (!sig_pos || !sig_svlen || !sig_cnt))) return fail(h, VSV_E_INVALID, "arrays are NULL");
+  for (int64_t i = 0; i < nv; ++i) {
+    if (blk_lo[i] < 0 || blk_hi[i] < blk_lo[i] || blk_hi[i] > ns) return fail(h, VSV_E_INVALID, "bad chromosome block");
+  }
+  HIPCHK(h, hipSetDevice(h->device));
+  int st;
+  if ((st = upload(h, h->j_cpos, var_pos, (size_t)nv * 4)) || (st = upload(h, h->j_clen, var_svlen, (size_t)nv * 4)) ||
+      (st = upload(h, h->g_qs, blk_lo, (size_t)nv * 4)) || (st = upload(h, h->g_qe, blk_hi, (size_t)nv * 4)) ||
+      (st = upload(h, h->j_spos, sig_pos, (size_t)ns * 4)) || (st = upload(h, h->j_slen, sig_svlen, (size_t)ns * 4)) ||
+      (st = upload(h, h->j_send, sig_cnt, (size_t)ns * 4)) || (st = ensure(h, h->j_out, (size_t)nv * 8)) || (st = ensure(h, h->g_rs, (size_t)nv * 4)) ||
+      (st = ensure(h, h->g_re, (size_t)nv * 4))) return st;
+  vsv_launch_gt_support(h->stream, (const int32_t*)h->j_cpos.p, (const int32_t*)h->j_clen.p, (const int32_t*)h->g_qs.p, (const int32_t*)h->g_qe.p, nv,
+                        (const int32_t*)h->j_spos.p, (const int32_t*)h->j_slen.p, (const int32_t*)h->j_send.p, max_shift_ratio, min_size_sim,
+                        (int64_t*)h->j_out.p, (int32_t*)h->g_rs.p, (int32_t*)h->g_re.p);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(sum, h->j_out.p, (size_t)nv * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(lo, h->g_rs.p, (size_t)nv * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(hi, h->g_re.p, (size_t)nv * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int vsv_span_count(vsv_handle* h, const vsv_records* recs, const int32_t* q_tid, const int32_t* q_a, const int32_t* q_b, int64_t nq, uint32_t* out) {
+  if (!h || !recs) return VSV_E_INVALID;
+  if (nq < 0) return fail(h, VSV_E_INVALID, "negative count");
+  if (nq == 0) return 0;
+  if (!q_tid || !q_a || !q_b || !out) return fail(h, VSV_E_INVALID, "query arrays are NULL");
+  HIPCHK(h, hipSetDevice(h->device));
+  int st = bind_records(h, recs);
+  if (st) return st;
+  if ((st = upload(h, h->j_cpos, q_tid, (size_t)nq * 4)) || (st = upload(h, h->j_clen, q_a, (size_t)nq * 4)) || (st = upload(h, h->j_spos, q_b, (size_t)nq * 4)) ||
+      (st = ensure(h, h->j_out, (size_t)nq * 4)) || (st = ensure(h, h->j_slen, (size_t)(h->rv.n_records + 1) * 4)) || (st = ensure(h, h->j_err, 256))) return st;
+  HIPCHK(h, hipMemsetAsync(h->j_err.p, 0, 8, h->stream));
+  vsv_launch_span_count(h->stream, h->rv, (int32_t*)h->j_slen.p, (uint32_t*)h->j_err.p, (const int32_t*)h->j_cpos.p, (const int32_t*)h->j_clen.p,
+                        (const int32_t*)h->j_spos.p, nq, (uint32_t*)h->j_out.p);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(out, h->j_out.p, (size_t)nq * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
 int vsv_copy_to_host(vsv_handle* h, void* dst, const void* src_device, int64_t bytes) {
   if (!h || bytes < 0 || (bytes > 0 && (!dst || !src_device))) return VSV_E_INVALID;
   if (bytes == 0) return 0;

@@ -155,3 +155,122 @@ void vsv_launch_support_join(hipStream_t st, const int32_t* call_pos, const int3
   if (blocks > 8192) blocks = 8192;
   support_join<<<(int)blocks, 256, 0, st>>>(call_pos, call_len, n_calls, sig_pos, sig_len, n_sigs, p, support, err);
 }
+
+// ---- correct_gt_{del,ins}_real_data.py ------------------------------------------------------------------------------------------
+// Variant-signature support (match_varlist_siglist DG:92-137 / extract_sig_support IG:105-156): the distinct read signatures
+// (chrom, pos, svlen, count) are listed chromosome block by chromosome block with ascending positions; a variant's window is
+// [pos - max_shift, pos + max_shift] with max_shift = max(svlen * ratio, 500), all in floating point like the reference.
+// One wave per variant: bounds by wave-cooperative search inside the variant's block, then the size-filtered count sum.
+// The reference's "resume at the last match" bookkeeping (it makes the element at the previous window's first index count
+// twice) needs the windows of all variants in order and is applied by the caller from lo / hi.
+namespace {
+
+__device__ __forceinline__ int64_t wave_first_ge_f(const int32_t* __restrict__ a, int64_t lo, int64_t hi, double t, bool strict, int lane) {
+  // first j in [lo, hi) with a[j] >= t (strict: a[j] > t); hi if none. Same 64-ary scheme as wave_lower_bound.
+  while (hi - lo > 64) {
+    const int64_t step = (hi - lo + 63) / 64;
+    const int64_t p = lo + (int64_t)lane * step;
+    const bool ge = p >= hi || (strict ? (double)a[p] > t : (double)a[p] >= t);
+    const uint64_t m = __ballot(ge);
+    if (m & 1ull) return lo;
+    const int f = m ? __builtin_ctzll(m) : 64;
+    const int64_t new_lo = lo + (int64_t)(f - 1) * step + 1;
+    if (f < 64) { const int64_t ph = lo + (int64_t)f * step; hi = ph < hi ? ph : hi; }
+    lo = new_lo;
+  }
+  const int64_t p = lo + lane;
+  const bool lt = p < hi && (strict ? !((double)a[p] > t) : !((double)a[p] >= t));
+  return lo + (int64_t)__popcll(__ballot(lt));
+}
+
+__global__ __launch_bounds__(256) void gt_support(const int32_t* __restrict__ vpos, const int32_t* __restrict__ vlen, const int32_t* __restrict__ blo,
+                                                  const int32_t* __restrict__ bhi, int64_t nv, const int32_t* __restrict__ spos,
+                                                  const int32_t* __restrict__ slen, const int32_t* __restrict__ scnt, double shift_ratio,
+                                                  double size_sim, int64_t* __restrict__ sum, int32_t* __restrict__ lo_out, int32_t* __restrict__ hi_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t gw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t i = gw; i < nv; i += nw) {
+    const double svlen = (double)vlen[i], pos = (double)vpos[i];
+    const double prod = svlen * shift_ratio;
+    const double max_shift = prod > 500.0 ? prod : 500.0;                 // max(svlen * ratio, 500)
+    const double min_pos = pos - max_shift, max_pos = pos + max_shift;
+    const double min_size = svlen * size_sim, max_size = svlen / size_sim;
+    const int64_t lo = wave_first_ge_f(spos, blo[i], bhi[i], min_pos, false, lane);
+    const int64_t hi = wave_first_ge_f(spos, lo, bhi[i], max_pos, true, lane);
+    int64_t t = 0;
+    for (int64_t j = lo + lane; j < hi; j += 64) {
+      const double l = (double)slen[j];
+      if (min_size <= l && l <= max_size) t += scnt[j];
+    }
+    t = wave_sum_i64(t);
+    if (lane == 0) { sum[i] = t; lo_out[i] = (int32_t)lo; hi_out[i] = (int32_t)hi; }
+  }
+}
+
+// reference end (pos + M/D/N/=/X lengths, pysam reference_end) of every record: one lane per record
+__global__ __launch_bounds__(256) void ref_end_kernel(RecView rv, int32_t* __restrict__ rend, uint32_t* __restrict__ max_span) {
+  uint32_t ms = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rv.n_records; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t span = 0;
+    for (uint64_t k = rv.cigar_off[i]; k < rv.cigar_off[i + 1]; ++k) {
+      const uint32_t w = rv.cigar[k], op = w & 15u;
+      if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) span += w >> 4;
+    }
+    rend[i] = (int32_t)(rv.pos[i] + span);
+    ms = max(ms, (uint32_t)(span > 0x7FFFFFFF ? 0x7FFFFFFF : span));
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) ms = max(ms, (uint32_t)__shfl_xor((int)ms, d, 64));
+  if ((threadIdx.x & 63) == 0 && ms) atomicMax(max_span, ms);
+}
+
+// first record index with (tid, pos) >= (qt, qp), records ascending by (tid, pos)
+__device__ __forceinline__ int64_t wave_lower_bound_tp(const int32_t* __restrict__ tid, const int32_t* __restrict__ pos, int64_t n, int32_t qt, int64_t qp, int lane) {
+  int64_t lo = 0, hi = n;
+  auto ge = [&](int64_t p) { const int32_t t = tid[p]; return t > qt || (t == qt && (int64_t)pos[p] >= qp); };
+  while (hi - lo > 64) {
+    const int64_t step = (hi - lo + 63) / 64;
+    const int64_t p = lo + (int64_t)lane * step;
+    const uint64_t m = __ballot(p >= hi || ge(p));
+    if (m & 1ull) return lo;
+    const int f = m ? __builtin_ctzll(m) : 64;
+    const int64_t new_lo = lo + (int64_t)(f - 1) * step + 1;
+    if (f < 64) { const int64_t ph = lo + (int64_t)f * step; hi = ph < hi ? ph : hi; }
+    lo = new_lo;
+  }
+  const int64_t p = lo + lane;
+  return lo + (int64_t)__popcll(__ballot(p < hi && !ge(p)));
+}
+
+// count_reads_span_region (DG:140-147) / check_full_cover_reads (IG:178-186): reads of chromosome qt with
+// reference_start < a and reference_end > b. Candidates start in [a - longest span, a).
+__global__ __launch_bounds__(256) void span_count(RecView rv, const int32_t* __restrict__ rend, const uint32_t* __restrict__ max_span,
+                                                  const int32_t* __restrict__ qt, const int32_t* __restrict__ qa, const int32_t* __restrict__ qb,
+                                                  int64_t nq, uint32_t* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t gw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int64_t ms = *max_span;
+  for (int64_t i = gw; i < nq; i += nw) {
+    const int64_t a = qa[i], b = qb[i];
+    const int64_t lo = wave_lower_bound_tp(rv.tid, rv.pos, rv.n_records, qt[i], a - ms, lane);
+    const int64_t hi = wave_lower_bound_tp(rv.tid, rv.pos, rv.n_records, qt[i], a, lane);        // start < a
+    uint32_t c = 0;
+    for (int64_t j = lo + lane; j < hi; j += 64) c += ((int64_t)rend[j] > b && !(rv.flag[j] & VSV_F_UNMAPPED)) ? 1u : 0u;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) c += (uint32_t)__shfl_xor((int)c, d, 64);
+    if (lane == 0) out[i] = c;
+  }
+}
+
+}  // namespace
+
+void vsv_launch_gt_support(hipStream_t st, const int32_t* vpos, const int32_t* vlen, const int32_t* blo, const int32_t* bhi, int64_t nv, const int32_t* spos,
+                           const int32_t* slen, const int32_t* scnt, double shift_ratio, double size_sim, int64_t* sum, int32_t* lo, int32_t* hi) {
+  if (nv <= 0) return;
+  gt_support<<<cov_blocks(nv), 256, 0, st>>>(vpos, vlen, blo, bhi, nv, spos, slen, scnt, shift_ratio, size_sim, sum, lo, hi);
+}
+void vsv_launch_span_count(hipStream_t st, const RecView& rv, int32_t* rend, uint32_t* max_span, const int32_t* qt, const int32_t* qa, const int32_t* qb,
+                           int64_t nq, uint32_t* out) {
+  if (rv.n_records > 0) ref_end_kernel<<<2048, 256, 0, st>>>(rv, rend, max_span);
+  if (nq > 0) span_count<<<cov_blocks(nq), 256, 0, st>>>(rv, rend, max_span, qt, qa, qb, nq, out);
+}

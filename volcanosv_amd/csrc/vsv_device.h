@@ -177,3 +177,9 @@ void vsv_bamdev_assign(hipStream_t st, const uint64_t* skey, const uint32_t* sva
                        const uint64_t* rec_off, uint32_t* qid, uint32_t* err);
 void vsv_bamdev_name_lens(hipStream_t st, const uint8_t* s, const uint64_t* rec_off, const uint32_t* is_first, int64_t n, uint32_t* len);
 void vsv_bamdev_name_copy(hipStream_t st, const uint8_t* s, const uint64_t* rec_off, const uint32_t* is_first, const uint32_t* noff, int64_t n, uint8_t* blob);
+
+// support.hip: GT-correction joins
+void vsv_launch_gt_support(hipStream_t st, const int32_t* vpos, const int32_t* vlen, const int32_t* blo, const int32_t* bhi, int64_t nv, const int32_t* spos,
+                           const int32_t* slen, const int32_t* scnt, double shift_ratio, double size_sim, int64_t* sum, int32_t* lo, int32_t* hi);
+void vsv_launch_span_count(hipStream_t st, const RecView& rv, int32_t* rend, uint32_t* max_span, const int32_t* qt, const int32_t* qa, const int32_t* qb,
+                           int64_t nq, uint32_t* out);

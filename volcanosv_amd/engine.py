@@ -201,6 +201,26 @@ class Engine:
         o = np.concatenate(([0], np.cumsum(isz.astype(np.int64))))
         return [out[o[i]:o[i + 1]].tobytes() for i in range(n)]
 
+    def gt_support(self, var_pos, var_svlen, blk_lo, blk_hi, sig_pos, sig_svlen, sig_cnt, max_shift_ratio=2.3, min_size_sim=0.6):
+        """Window sums of correct_gt_*_real_data.py (vsv_gt_support): (sum int64[n], lo int32[n], hi int32[n])."""
+        a = [np.ascontiguousarray(x, dtype=np.int32) for x in (var_pos, var_svlen, blk_lo, blk_hi, sig_pos, sig_svlen, sig_cnt)]
+        nv, ns = len(a[0]), len(a[4])
+        s, lo, hi = np.zeros(nv, np.int64), np.zeros(nv, np.int32), np.zeros(nv, np.int32)
+        p = [x.ctypes.data_as(C.c_void_p) for x in a]
+        self._check(self.lib.vsv_gt_support(self.h, p[0], p[1], p[2], p[3], nv, p[4], p[5], p[6], ns, float(max_shift_ratio), float(min_size_sim),
+                                            s.ctypes.data_as(C.c_void_p), lo.ctypes.data_as(C.c_void_p), hi.ctypes.data_as(C.c_void_p)))
+        return s, lo, hi
+
+    def span_count(self, recs, q_tid, q_a, q_b):
+        """Reads with reference_start < a and reference_end > b per query (vsv_span_count); recs = RecordSoA / DeviceRecords /
+        DeviceRecordView sorted by (tid, pos)."""
+        r = self._recs(recs)
+        a = [np.ascontiguousarray(x, dtype=np.int32) for x in (q_tid, q_a, q_b)]
+        out = np.zeros(len(a[0]), np.uint32)
+        self._check(self.lib.vsv_span_count(self.h, C.byref(r), a[0].ctypes.data_as(C.c_void_p), a[1].ctypes.data_as(C.c_void_p),
+                                            a[2].ctypes.data_as(C.c_void_p), len(a[0]), out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def support_params(self, **kw):
         p = SupportParams()
         self._check(self.lib.vsv_default_support_params(C.byref(p)))
