@@ -171,3 +171,50 @@ def test_gpu_joins_vs_oracle_random():
         got = eng.span_count(soa, q_t, q_a, q_b)
         want = oracle.run_span_count(tid, pos, pos + span, q_t[:400], q_a[:400], q_b[:400])
         assert got[:400].tolist() == want.tolist() and got.sum() > 0
+
+
+@pytest.mark.gpu
+def test_gpu_filter_gt_correction_driver_runs_end_to_end(doc, tmp_path):
+    """filter_GT_correction.py in one process: read signatures from the reads BAM (sig_extract), signature coverage, coverage band,
+    DEL / INS genotype correction, vcf-sort. No reference output exists for the whole chain (it needs pysam + samtools); the
+    steps are pinned one by one elsewhere — here the driver must produce a well-formed, sorted, deterministic VCF."""
+    from volcanosv_amd import bam, gt_correction as gc
+    from volcanosv_amd.engine import Engine
+    case = doc[0]
+    vcf = tmp_path / "calls.vcf"
+    vcf.write_text("".join(case["vcf"]))
+    names = ["chr1", "chr2", "chr10"]
+    rng = np.random.default_rng(3)
+    calls = [l.split("\t") for l in case["vcf"] if l[0] != "#"]
+    recs = []
+    for t, c in enumerate(names):
+        sites = sorted((int(f[1]), f[7]) for f in calls if f[0] == c)
+        for k, (s, e) in enumerate(case["reads"][c]):
+            cig, cur = [], s
+            for p, info in sites:                                  # reads crossing a call carry its event as a CIGAR op
+                if max(s + 200, cur + 10) < p < e - 200 - 10000 and rng.integers(3):
+                    ln = abs(int(info.split("SVLEN=")[1].split(";")[0]))
+                    cig += [(0, p - cur), ((2, ln) if "SVTYPE=DEL" in info else (1, ln))]
+                    cur = p + (ln if "SVTYPE=DEL" in info else 0)
+            if cur < e:
+                cig.append((0, max(1, e - cur)))
+            qlen = sum(l for op, l in cig if op in (0, 1))
+            recs.append(dict(tid=t, pos=s, qname="%s_%d" % (c, k), mapq=60, flag=0, cigar=cig, seq="ACGT"[k % 4] * qlen))
+    recs.sort(key=lambda r: (r["tid"], r["pos"]))
+    reads = str(tmp_path / "reads.bam")
+    bam.write_bam(reads, [(c, 1_000_000) for c in names], recs)
+    ref = tmp_path / "ref.fa"
+    ref.write_text(">chr1\nA\n")
+    outs = []
+    with Engine(0) as eng:
+        for _ in range(2):
+            final = gc.filter_gt_correction(str(vcf), reads, str(ref), None, "Hifi", engine=eng)
+            outs.append(open(final).read())
+    assert outs[0] == outs[1]
+    lines = outs[0].splitlines()
+    body = [l.split("\t") for l in lines if l[0] != "#"]
+    assert len(body) > 50 and all(f[-1] in ("0/1", "1/1", "./.") for f in body)
+    keys = [(f[0].encode(), int(f[1])) for f in body]
+    assert keys == sorted(keys)
+    sig = open(tmp_path / "cute_sig" / "DEL.sigs").read().splitlines()
+    assert len(sig) > 100 and any(f[-1] == "1/1" for f in body)
