@@ -81,7 +81,7 @@ def test_bam_load_with_gpu_inflate_equals_host_inflate(tmp_path):
 
 
 @pytest.mark.gpu
-def test_bam_parsed_on_the_device_equals_host_reader(tmp_path):
+def test_bam_parsed_on_the_device_equals_host_reader(tmp_path, monkeypatch):
     """vsv_bam_load_device: BGZF inflate + record-start chain + field parse + CIGAR copy + first-appearance query ids, all on the
     GPU; every array and the name table equal the host reader's, for one chromosome and for the whole file, with repeated
     names (split reads), records larger than a BGZF member, a long CIGAR in CG:B,I and unmapped-placed records."""
@@ -107,11 +107,28 @@ def test_bam_parsed_on_the_device_equals_host_reader(tmp_path):
         for chrom in ("chr2", None, "chr1"):
             host = bf.fetch_soa(chrom)
             view = bf.fetch_device(eng, chrom)
+            assert isinstance(view, bam.DeviceRecordView)
             dev = view.to_host()
             assert dev.n_records == host.n_records and dev.n_ops == host.n_ops and view.n_qids == host.n_qids
             for name in ("pos", "tid", "qid", "cigar_off", "mapq", "flag", "cigar", "l_seq", "sam_flags"):
                 assert np.array_equal(getattr(host, name), getattr(dev, name)), (chrom, name)
             assert list(host.qnames) == list(dev.qnames)
+        # the file streamed through the device in small member windows (WGS-size files do not fit at once): records that
+        # straddle a window are completed by the next one; identical output. A window no record of the file fits in is an
+        # error the caller answers with the host reader.
+        host = bf.fetch_soa(None)
+        for window in (16, 37, 300):
+            monkeypatch.setenv("VSV_BAM_WINDOW", str(window))
+            view = bf.fetch_device(eng, None)
+            assert isinstance(view, bam.DeviceRecordView)
+            dev = view.to_host()
+            for name in ("pos", "tid", "qid", "cigar_off", "mapq", "flag", "cigar", "l_seq", "sam_flags"):
+                assert np.array_equal(getattr(host, name), getattr(dev, name)), (window, name)
+            assert list(host.qnames) == list(dev.qnames)
+        monkeypatch.setenv("VSV_BAM_WINDOW", "2")
+        with pytest.warns(UserWarning, match="larger than the device reader's window"):
+            assert not isinstance(bf.fetch_device(eng, None), bam.DeviceRecordView)
+        monkeypatch.delenv("VSV_BAM_WINDOW")
         # the device-resident view feeds the hot path directly
         view = bf.fetch_device(eng, "chr1")
         view.max_pos = 30_100_000

@@ -65,7 +65,8 @@ __global__ __launch_bounds__(64) void rec_speculate(const uint8_t* __restrict__ 
 }
 
 // walks the records of member m from spec[m]: count[m] = records starting in the member, land[m] = absolute offset of the
-// first record start at or beyond the member's end (== total at the end of the stream; NONE on a malformed hop).
+// first record start at or beyond the member's end — or, when a record is not complete inside the inflated window, the start
+// of that record (< member end): the caller resumes there with the next window. NONE on a malformed hop.
 // WRITE: also stores the record offsets at rec_off[base[m] + k].
 template <bool WRITE>
 __global__ __launch_bounds__(256) void rec_chain(const uint8_t* __restrict__ s, const uint64_t* __restrict__ moff, int64_t n_members,
@@ -79,9 +80,10 @@ __global__ __launch_bounds__(256) void rec_chain(const uint8_t* __restrict__ s, 
   uint32_t c = 0;
   const uint64_t b0 = WRITE ? base[m] : 0;
   while (x < hi) {
-    if (x + 4 > total) { x = NONE64; break; }
+    if (x + 4 > total) break;                        // the size field itself is cut off: the record belongs to the next window
     const uint32_t bs = ld32(s + x);
     if (bs < 32) { x = NONE64; break; }
+    if (x + 4ull + bs > total) break;                // record not complete inside this window: land on its start
     if (WRITE) rec_off[b0 + c] = x;
     ++c;
     x += 4ull + bs;
@@ -154,16 +156,17 @@ __global__ __launch_bounds__(256) void rec_emit(const uint8_t* __restrict__ s, i
                                                 int32_t* __restrict__ o_pos, int32_t* __restrict__ o_tid, uint8_t* __restrict__ o_mapq,
                                                 uint8_t* __restrict__ o_flag, uint32_t* __restrict__ o_l_seq, uint32_t* __restrict__ o_sam_flag,
                                                 uint64_t* __restrict__ o_cig_off, uint32_t* __restrict__ o_cigar, uint64_t* __restrict__ o_hash,
-                                                uint64_t* __restrict__ o_rec_off) {
+                                                uint64_t* __restrict__ o_rec_off, uint64_t k0, uint64_t c0) {
   const int lane = threadIdx.x & 63;
   const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
   for (int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < n; i += nw) {
     if (!keep[i]) continue;
-    const uint32_t k = kidx[i];
-    const uint64_t co = cig_off_in[i];
+    const uint32_t kl = kidx[i];                     // index among the kept records of this window
+    const uint64_t k = k0 + kl;                       // ... and of the whole file
+    const uint64_t co = c0 + cig_off_in[i];
     if (lane == 0) {
       o_pos[k] = pos[i]; o_tid[k] = tid[i]; o_mapq[k] = mapq[i]; o_flag[k] = flag[i]; o_l_seq[k] = l_seq[i]; o_sam_flag[k] = sam_flag[i];
-      o_cig_off[k] = co; o_hash[k] = hash[i]; o_rec_off[k] = rec_off[i];
+      o_cig_off[k] = co; o_hash[k] = hash[i]; o_rec_off[kl] = rec_off[i];
     }
     const uint8_t* src = s + cg_src[i];
     const uint32_t nc = n_cig_out[i];
@@ -214,41 +217,56 @@ __global__ __launch_bounds__(256) void qid_mark_first(const uint64_t* __restrict
   for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x)
     if (j == 0 || skey[j] != skey[j - 1]) is_first[sval[j]] = 1u;      // the group's lowest record index
 }
-// a group head hands its (scanned) id to every member; names are compared byte by byte (a 64-bit hash collision between
-// different names raises the error flag and the caller falls back to the host reader)
+// a group head hands its (scanned) id to every member; names (compact store, l_read_name bytes each) are compared byte by
+// byte (a 64-bit hash collision between different names raises the error flag and the caller falls back to the host reader)
 __global__ __launch_bounds__(256) void qid_assign(const uint64_t* __restrict__ skey, const uint32_t* __restrict__ sval, int64_t n,
-                                                  const uint32_t* __restrict__ first_rank, const uint8_t* __restrict__ s,
-                                                  const uint64_t* __restrict__ rec_off, uint32_t* __restrict__ qid, uint32_t* __restrict__ err) {
+                                                  const uint32_t* __restrict__ first_rank, const uint8_t* __restrict__ names,
+                                                  const uint64_t* __restrict__ nm_off, const uint32_t* __restrict__ nm_len, uint32_t* __restrict__ qid,
+                                                  uint32_t* __restrict__ err) {
   for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
     if (j != 0 && skey[j] == skey[j - 1]) continue;
     const uint32_t head = sval[j];
     const uint32_t id = first_rank[head];
-    const uint8_t* hn = s + rec_off[head] + 36;
-    const uint32_t hl = s[rec_off[head] + 12];
+    const uint8_t* hn = names + nm_off[head];
+    const uint32_t hl = nm_len[head];
     for (int64_t k = j; k < n && skey[k] == skey[j]; ++k) {
       const uint32_t r = sval[k];
       qid[r] = id;
       if (k != j) {
-        const uint8_t* rn = s + rec_off[r] + 36;
-        bool same = s[rec_off[r] + 12] == hl;
+        const uint8_t* rn = names + nm_off[r];
+        bool same = nm_len[r] == hl;
         for (uint32_t c = 0; same && c < hl; ++c) same = rn[c] == hn[c];
         if (!same) atomicOr(err, 2u);
       }
     }
   }
 }
-// names of the first occurrences, in id order: length pass (len + 1 for the separator), then copy at the scanned offsets
-__global__ __launch_bounds__(256) void name_lens(const uint8_t* __restrict__ s, const uint64_t* __restrict__ rec_off, const uint32_t* __restrict__ is_first,
-                                                 int64_t n, uint32_t* __restrict__ len) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    len[i] = is_first[i] ? (uint32_t)s[rec_off[i] + 12] : 0u;          // l_read_name counts the NUL: it becomes the '\n' separator
+// names of a window's kept records into the compact store: length pass, then copy at store_base + scanned offset
+__global__ __launch_bounds__(256) void win_name_lens(const uint8_t* __restrict__ s, const uint64_t* __restrict__ w_rec_off, int64_t nk, uint32_t* __restrict__ len) {
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nk; k += (int64_t)gridDim.x * blockDim.x) len[k] = s[w_rec_off[k] + 12];
 }
-__global__ __launch_bounds__(256) void name_copy(const uint8_t* __restrict__ s, const uint64_t* __restrict__ rec_off, const uint32_t* __restrict__ is_first,
-                                                 const uint32_t* __restrict__ noff, int64_t n, uint8_t* __restrict__ blob) {
+__global__ __launch_bounds__(256) void win_name_store(const uint8_t* __restrict__ s, const uint64_t* __restrict__ w_rec_off, const uint32_t* __restrict__ loff,
+                                                      int64_t nk, uint64_t k0, uint64_t n0, uint8_t* __restrict__ names, uint64_t* __restrict__ nm_off,
+                                                      uint32_t* __restrict__ nm_len) {
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nk; k += (int64_t)gridDim.x * blockDim.x) {
+    const uint8_t* nm = s + w_rec_off[k] + 36;
+    const uint32_t l = s[w_rec_off[k] + 12];
+    uint8_t* d = names + n0 + loff[k];
+    for (uint32_t c = 0; c < l; ++c) d[c] = nm[c];
+    nm_off[k0 + k] = n0 + loff[k];
+    nm_len[k0 + k] = l;
+  }
+}
+// name table for the host: the first occurrences in id order, '\n'-separated (the stored NUL becomes the separator)
+__global__ __launch_bounds__(256) void name_lens(const uint32_t* __restrict__ nm_len, const uint32_t* __restrict__ is_first, int64_t n, uint32_t* __restrict__ len) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) len[i] = is_first[i] ? nm_len[i] : 0u;
+}
+__global__ __launch_bounds__(256) void name_copy(const uint8_t* __restrict__ names, const uint64_t* __restrict__ nm_off, const uint32_t* __restrict__ nm_len,
+                                                 const uint32_t* __restrict__ is_first, const uint32_t* __restrict__ noff, int64_t n, uint8_t* __restrict__ blob) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     if (!is_first[i]) continue;
-    const uint8_t* nm = s + rec_off[i] + 36;
-    const uint32_t l = s[rec_off[i] + 12];
+    const uint8_t* nm = names + nm_off[i];
+    const uint32_t l = nm_len[i];
     uint8_t* d = blob + noff[i];
     for (uint32_t c = 0; c + 1 < l; ++c) d[c] = nm[c];
     d[l - 1] = '\n';
@@ -286,22 +304,30 @@ void vsv_bamdev_emit(hipStream_t st, const uint8_t* s, int64_t n, const uint32_t
                      const uint8_t* mapq, const uint8_t* flag, const uint32_t* l_seq, const uint32_t* sam_flag, const uint32_t* n_cig_out,
                      const uint64_t* cg_src, const uint64_t* hash, const uint64_t* cig_off_in, const uint64_t* rec_off, int32_t* o_pos, int32_t* o_tid,
                      uint8_t* o_mapq, uint8_t* o_flag, uint32_t* o_l_seq, uint32_t* o_sam_flag, uint64_t* o_cig_off, uint32_t* o_cigar, uint64_t* o_hash,
-                     uint64_t* o_rec_off) {
+                     uint64_t* w_rec_off, uint64_t k0, uint64_t c0) {
   if (n <= 0) return;
   rec_emit<<<2048, 256, 0, st>>>(s, n, keep, kidx, pos, tid, mapq, flag, l_seq, sam_flag, n_cig_out, cg_src, hash, cig_off_in, rec_off, o_pos, o_tid,
-                                 o_mapq, o_flag, o_l_seq, o_sam_flag, o_cig_off, o_cigar, o_hash, o_rec_off);
+                                 o_mapq, o_flag, o_l_seq, o_sam_flag, o_cig_off, o_cigar, o_hash, w_rec_off, k0, c0);
 }
 void vsv_bamdev_iota(hipStream_t st, uint32_t* p, int64_t n) { if (n > 0) iota_u32<<<1024, 256, 0, st>>>(p, n); }
 void vsv_bamdev_mark_first(hipStream_t st, const uint64_t* skey, const uint32_t* sval, int64_t n, uint32_t* is_first) {
   if (n > 0) qid_mark_first<<<1024, 256, 0, st>>>(skey, sval, n, is_first);
 }
-void vsv_bamdev_assign(hipStream_t st, const uint64_t* skey, const uint32_t* sval, int64_t n, const uint32_t* first_rank, const uint8_t* s,
-                       const uint64_t* rec_off, uint32_t* qid, uint32_t* err) {
-  if (n > 0) qid_assign<<<1024, 256, 0, st>>>(skey, sval, n, first_rank, s, rec_off, qid, err);
+void vsv_bamdev_assign(hipStream_t st, const uint64_t* skey, const uint32_t* sval, int64_t n, const uint32_t* first_rank, const uint8_t* names,
+                       const uint64_t* nm_off, const uint32_t* nm_len, uint32_t* qid, uint32_t* err) {
+  if (n > 0) qid_assign<<<1024, 256, 0, st>>>(skey, sval, n, first_rank, names, nm_off, nm_len, qid, err);
 }
-void vsv_bamdev_name_lens(hipStream_t st, const uint8_t* s, const uint64_t* rec_off, const uint32_t* is_first, int64_t n, uint32_t* len) {
-  if (n > 0) name_lens<<<1024, 256, 0, st>>>(s, rec_off, is_first, n, len);
+void vsv_bamdev_win_name_lens(hipStream_t st, const uint8_t* s, const uint64_t* w_rec_off, int64_t nk, uint32_t* len) {
+  if (nk > 0) win_name_lens<<<1024, 256, 0, st>>>(s, w_rec_off, nk, len);
 }
-void vsv_bamdev_name_copy(hipStream_t st, const uint8_t* s, const uint64_t* rec_off, const uint32_t* is_first, const uint32_t* noff, int64_t n, uint8_t* blob) {
-  if (n > 0) name_copy<<<1024, 256, 0, st>>>(s, rec_off, is_first, noff, n, blob);
+void vsv_bamdev_win_name_store(hipStream_t st, const uint8_t* s, const uint64_t* w_rec_off, const uint32_t* loff, int64_t nk, uint64_t k0, uint64_t n0,
+                               uint8_t* names, uint64_t* nm_off, uint32_t* nm_len) {
+  if (nk > 0) win_name_store<<<1024, 256, 0, st>>>(s, w_rec_off, loff, nk, k0, n0, names, nm_off, nm_len);
+}
+void vsv_bamdev_name_lens(hipStream_t st, const uint32_t* nm_len, const uint32_t* is_first, int64_t n, uint32_t* len) {
+  if (n > 0) name_lens<<<1024, 256, 0, st>>>(nm_len, is_first, n, len);
+}
+void vsv_bamdev_name_copy(hipStream_t st, const uint8_t* names, const uint64_t* nm_off, const uint32_t* nm_len, const uint32_t* is_first, const uint32_t* noff,
+                          int64_t n, uint8_t* blob) {
+  if (n > 0) name_copy<<<1024, 256, 0, st>>>(names, nm_off, nm_len, is_first, noff, n, blob);
 }

@@ -247,7 +247,7 @@ int vsv_bam_load(vsv_bam* b, int tid, vsv_records* out) {
   if (!b || !out) return VSV_E_INVALID;
   // rewind and skip the header again (simple and index-free)
   fseek(b->f, 0, SEEK_SET);
-  b->buf.clear(); b->rd = 0; b->eof = false;
+  b->buf.clear(); b->rd = 0; b->eof = false; b->err.clear();
   b->ref_names.clear(); b->ref_lens.clear();
   const int user_threads = b->n_threads;
   b->n_threads = 1;                      // the header is parsed incrementally
@@ -417,7 +417,7 @@ int vsv_bam_load(vsv_bam* b, int tid, vsv_records* out) {
 int vsv_bam_load_device(vsv_bam* b, vsv_handle* h, int tid, vsv_records* out) {
   if (!b || !h || !out) return VSV_E_INVALID;
   fseek(b->f, 0, SEEK_SET);
-  b->buf.clear(); b->rd = 0; b->eof = false; b->inflated_total = 0;
+  b->buf.clear(); b->rd = 0; b->eof = false; b->inflated_total = 0; b->err.clear();
   b->ref_names.clear(); b->ref_lens.clear();
   const int user_threads = b->n_threads;
   vsv_handle* user_gpu = b->gpu;

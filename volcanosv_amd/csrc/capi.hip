@@ -47,7 +47,7 @@ struct vsv_handle {
   DevBuf z_comp, z_coff, z_ooff, z_out, z_stat;          // BGZF inflate
   DevBuf p_spec, p_cnt, p_land, p_base, p_recoff, p_pos, p_tid, p_mapq, p_flag, p_lseq, p_sflag, p_ncig, p_cgsrc, p_hash, p_keep, p_kidx,
       p_cigoff, p_sums, p_tot, p_err;                     // device BAM parse: per input record
-  DevBuf o_pos, o_tid, o_qid, o_cigoff, o_mapq, o_flag, o_cigar, o_lseq, o_sflag, o_hash, o_recoff, o_first, o_rank, o_nlen, o_noff, o_blob, o_n;
+  DevBuf o_pos, o_tid, o_qid, o_cigoff, o_mapq, o_flag, o_cigar, o_lseq, o_sflag, o_hash, o_recoff, o_first, o_rank, o_nlen, o_noff, o_blob, o_n, o_names, o_nmoff, o_nmlen;
   std::string names_blob;   // support join (post-filter)
   int pass_cursor = 0;
   const uint64_t* sorted_key = nullptr;   // sorted keys of the stage just sorted (cluster / pair read them)
@@ -376,7 +376,7 @@ void vsv_destroy(vsv_handle* h) {
                     &h->g_re, &h->g_rev, &h->g_hap, &h->g_len, &h->g_rank, &h->j_cpos, &h->j_clen, &h->j_spos, &h->j_slen, &h->j_send, &h->j_out, &h->j_err, &h->z_comp, &h->z_coff, &h->z_ooff, &h->z_out, &h->z_stat, &h->p_spec, &h->p_cnt, &h->p_land, &h->p_base, &h->p_recoff, &h->p_pos, &h->p_tid,
                     &h->p_mapq, &h->p_flag, &h->p_lseq, &h->p_sflag, &h->p_ncig, &h->p_cgsrc, &h->p_hash, &h->p_keep, &h->p_kidx, &h->p_cigoff, &h->p_sums,
                     &h->p_tot, &h->p_err, &h->o_pos, &h->o_tid, &h->o_qid, &h->o_cigoff, &h->o_mapq, &h->o_flag, &h->o_cigar, &h->o_lseq, &h->o_sflag,
-                    &h->o_hash, &h->o_recoff, &h->o_first, &h->o_rank, &h->o_nlen, &h->o_noff, &h->o_blob, &h->o_n};
+                    &h->o_hash, &h->o_recoff, &h->o_first, &h->o_rank, &h->o_nlen, &h->o_noff, &h->o_blob, &h->o_n, &h->o_names, &h->o_nmoff, &h->o_nmlen};
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
   if (h->pinned) hipHostFree(h->pinned);
   if (h->ev0) hipEventDestroy(h->ev0);
@@ -711,6 +711,20 @@ int vsv_bgzf_inflate(vsv_handle* h, const uint8_t* comp, const uint64_t* comp_of
   return 0;
 }
 
+// grow a device buffer, keeping its first `used` bytes
+static int ensure_keep(vsv_handle* h, DevBuf& b, size_t need, size_t used) {
+  if (b.bytes >= need) return 0;
+  size_t nb = b.bytes * 2 > need ? b.bytes * 2 : need;
+  if (nb < 4096) nb = 4096;
+  void* p = nullptr;
+  HIPCHK(h, hipMalloc(&p, nb));
+  if (used && b.p) HIPCHK(h, hipMemcpyAsync(p, b.p, used, hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (b.p) HIPCHK(h, hipFree(b.p));
+  b.p = p; b.bytes = nb;
+  return 0;
+}
+
 int vsv_bam_parse_device(vsv_handle* h, const uint8_t* comp, const uint64_t* comp_off, const uint32_t* isize, int64_t n_members, uint64_t first_record,
                          int32_t n_ref, int32_t tid, vsv_records* out, const char** names, int64_t* names_len, const uint32_t** l_seq_dev,
                          const uint32_t** sam_flags_dev) {
@@ -718,103 +732,138 @@ int vsv_bam_parse_device(vsv_handle* h, const uint8_t* comp, const uint64_t* com
   if (n_members <= 0 || !comp || !comp_off || !isize) return fail(h, VSV_E_INVALID, "no BGZF members");
   HIPCHK(h, hipSetDevice(h->device));
   hipStream_t st = h->stream;
-  {  // the single-pass reader keeps the compressed file, the inflated stream and the SoA on the device at once
-    uint64_t inflated = 0;
-    for (int64_t i = 0; i < n_members; ++i) inflated += isize[i];
-    size_t free_b = 0, total_b = 0;
-    HIPCHK(h, hipMemGetInfo(&free_b, &total_b));
-    const uint64_t need = (comp_off[n_members] - comp_off[0]) + 3 * inflated;      // stream + per-record scratch + outputs, generous
-    if (need > (uint64_t)free_b + h->z_comp.bytes + h->z_out.bytes)
-      return fail(h, VSV_E_CAPACITY, "file too large for the single-pass device reader: use the host reader");
-  }
-  std::vector<uint64_t> moff;
-  int rc = inflate_to_device(h, comp, comp_off, isize, n_members, moff);
-  if (rc) return rc;
-  const uint64_t total = moff[n_members];
-  if (first_record > total) return fail(h, VSV_E_INVALID, "header longer than the stream");
-  const uint8_t* s = (const uint8_t*)h->z_out.p;
-  const uint64_t* d_moff = (const uint64_t*)h->z_ooff.p;
-  const size_t nm = (size_t)n_members;
-  if ((rc = ensure(h, h->p_spec, nm * 8)) || (rc = ensure(h, h->p_cnt, nm * 4)) || (rc = ensure(h, h->p_land, nm * 8)) || (rc = ensure(h, h->p_base, nm * 8)) ||
-      (rc = ensure(h, h->p_err, 256)) || (rc = ensure(h, h->p_tot, 256)) || (rc = ensure(h, h->o_n, 256))) return rc;
-  HIPCHK(h, hipMemsetAsync(h->p_err.p, 0, 4, st));
-  // ---- record-start chain: speculate per member, walk, verify on the host from the exactly known first record -----------
-  vsv_bamdev_speculate(st, s, d_moff, n_members, first_record, n_ref, (uint64_t*)h->p_spec.p);
-  std::vector<uint64_t> spec(nm), land(nm), base(nm, 0);
-  std::vector<uint32_t> cnt(nm);
-  std::vector<uint8_t> active(nm, 0);
-  HIPCHK(h, hipMemcpyAsync(spec.data(), h->p_spec.p, nm * 8, hipMemcpyDeviceToHost, st));
-  HIPCHK(h, hipStreamSynchronize(st));
-  uint64_t n_total = 0;
-  for (int round = 0;; ++round) {
-    if (round > 1024) return fail(h, VSV_E_INVALID, "record chain does not settle (not a BAM stream?): use the host reader");
-    HIPCHK(h, hipMemcpyAsync(h->p_spec.p, spec.data(), nm * 8, hipMemcpyHostToDevice, st));
-    vsv_bamdev_chain(st, false, s, d_moff, n_members, (const uint64_t*)h->p_spec.p, (uint32_t*)h->p_cnt.p, (uint64_t*)h->p_land.p, nullptr, nullptr);
-    HIPCHK(h, hipMemcpyAsync(cnt.data(), h->p_cnt.p, nm * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(h, hipMemcpyAsync(land.data(), h->p_land.p, nm * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(h, hipStreamSynchronize(st));
-    std::fill(active.begin(), active.end(), 0);
-    bool patched = false;
-    uint64_t expect = first_record;
-    n_total = 0;
-    while (expect < total) {
-      const size_t m = (size_t)(std::upper_bound(moff.begin(), moff.end(), expect) - moff.begin()) - 1;   // member holding `expect`
-      if (spec[m] != expect) { spec[m] = expect; patched = true; break; }                                  // proven start: patch and rewalk
-      if (land[m] == 0xFFFFFFFFFFFFFFFFull) return fail(h, VSV_E_INVALID, "malformed BAM record chain");
-      active[m] = 1; base[m] = n_total; n_total += cnt[m];
-      expect = land[m];
-    }
-    if (!patched) { if (expect != total) return fail(h, VSV_E_INVALID, "BAM stream ends inside a record"); break; }
-  }
-  if (n_total > 0x7FFFFFF0ull) return fail(h, VSV_E_INVALID, "too many records for the device reader");
-  for (size_t m = 0; m < nm; ++m) if (!active[m]) spec[m] = 0xFFFFFFFFFFFFFFFFull;      // speculated starts the chain never reached
-  const int64_t n = (int64_t)n_total;
+  // The file is processed in windows of members (the whole file when it is small): a window is inflated, its records are
+  // chained / parsed / appended to the output arrays, and the next window starts at the member that holds the first record
+  // the previous one could not complete. VSV_BAM_WINDOW overrides the window size (tests use tiny windows).
+  const int64_t window_members = getenv("VSV_BAM_WINDOW") && atoll(getenv("VSV_BAM_WINDOW")) > 0 ? atoll(getenv("VSV_BAM_WINDOW")) : 32768;
+  std::vector<uint64_t> ginf((size_t)n_members + 1, 0);
+  for (int64_t i = 0; i < n_members; ++i) ginf[i + 1] = ginf[i] + isize[i];
+  const uint64_t stream_total = ginf[n_members];
+  if (first_record > stream_total) return fail(h, VSV_E_INVALID, "header longer than the stream");
   memset(out, 0, sizeof *out);
   out->on_device = 1;
   h->names_blob.clear();
-  if (names) { *names = h->names_blob.c_str(); }
+  if (names) *names = h->names_blob.c_str();
   if (names_len) *names_len = 0;
-  if (n == 0) return 0;
-  HIPCHK(h, hipMemcpyAsync(h->p_spec.p, spec.data(), nm * 8, hipMemcpyHostToDevice, st));
-  HIPCHK(h, hipMemcpyAsync(h->p_base.p, base.data(), nm * 8, hipMemcpyHostToDevice, st));
-  const size_t N = (size_t)n;
-  if ((rc = ensure(h, h->p_recoff, N * 8)) || (rc = ensure(h, h->p_pos, N * 4)) || (rc = ensure(h, h->p_tid, N * 4)) || (rc = ensure(h, h->p_mapq, N)) ||
-      (rc = ensure(h, h->p_flag, N)) || (rc = ensure(h, h->p_lseq, N * 4)) || (rc = ensure(h, h->p_sflag, N * 4)) || (rc = ensure(h, h->p_ncig, N * 4)) ||
-      (rc = ensure(h, h->p_cgsrc, N * 8)) || (rc = ensure(h, h->p_hash, N * 8)) || (rc = ensure(h, h->p_keep, N * 4 + 16)) || (rc = ensure(h, h->p_kidx, N * 4 + 16)) ||
-      (rc = ensure(h, h->p_cigoff, N * 8)) || (rc = ensure(h, h->p_sums, (N / 2048 + 4) * 8))) return rc;
-  vsv_bamdev_chain(st, true, s, d_moff, n_members, (const uint64_t*)h->p_spec.p, nullptr, nullptr, (const uint64_t*)h->p_base.p, (uint64_t*)h->p_recoff.p);
-  vsv_bamdev_fields(st, s, (const uint64_t*)h->p_recoff.p, n, tid, (int32_t*)h->p_pos.p, (int32_t*)h->p_tid.p, (uint8_t*)h->p_mapq.p, (uint8_t*)h->p_flag.p,
-                    (uint32_t*)h->p_lseq.p, (uint32_t*)h->p_sflag.p, (uint32_t*)h->p_ncig.p, (uint64_t*)h->p_cgsrc.p, (uint64_t*)h->p_hash.p,
-                    (uint32_t*)h->p_keep.p, (uint32_t*)h->p_err.p);
-  vsv_scan_u32_exclusive(st, (const uint32_t*)h->p_keep.p, (int)n, (uint32_t*)h->p_kidx.p, (uint32_t*)h->p_sums.p);
-  vsv_bamdev_scan64(st, (const uint32_t*)h->p_ncig.p, (const uint32_t*)h->p_keep.p, n, (uint64_t*)h->p_sums.p, (uint64_t*)h->p_cigoff.p, (uint64_t*)h->p_tot.p);
-  uint32_t last_k = 0, last_keep = 0, err = 0;
-  uint64_t n_ops = 0;
-  HIPCHK(h, hipMemcpyAsync(&last_k, (uint32_t*)h->p_kidx.p + (n - 1), 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(h, hipMemcpyAsync(&last_keep, (uint32_t*)h->p_keep.p + (n - 1), 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(h, hipMemcpyAsync(&n_ops, h->p_tot.p, 8, hipMemcpyDeviceToHost, st));
-  HIPCHK(h, hipMemcpyAsync(&err, h->p_err.p, 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(h, hipStreamSynchronize(st));
-  if (err & 1u) return fail(h, VSV_E_INVALID, "unknown BAM tag type");
-  const int64_t nk = (int64_t)last_k + last_keep;
-  out->n_records = nk; out->n_ops = (int64_t)n_ops; out->n_tids = n_ref;
+  int rc;
+#define DEVMEM(expr) do { if ((rc = (expr))) return rc == VSV_E_HIP ? fail(h, VSV_E_CAPACITY, "device memory exhausted in the device reader: use the host reader") : rc; } while (0)
+  DEVMEM(ensure(h, h->p_err, 256)); DEVMEM(ensure(h, h->p_tot, 256)); DEVMEM(ensure(h, h->o_n, 256));
+  HIPCHK(h, hipMemsetAsync(h->p_err.p, 0, 4, st));
+  uint64_t carry = first_record, K0 = 0, C0 = 0, N0 = 0;
+  std::vector<uint64_t> moff, spec, land, base;
+  std::vector<uint32_t> cnt;
+  std::vector<uint8_t> active;
+  while (carry < stream_total) {
+    const int64_t ma = (int64_t)(std::upper_bound(ginf.begin(), ginf.end(), carry) - ginf.begin()) - 1;
+    const int64_t mb = ma + window_members < n_members ? ma + window_members : n_members;
+    const bool last_window = mb == n_members;
+    rc = inflate_to_device(h, comp, comp_off + ma, isize + ma, mb - ma, moff);
+    if (rc == VSV_E_HIP) return fail(h, VSV_E_CAPACITY, "device memory exhausted in the device reader: use the host reader");
+    if (rc) return rc;
+    const uint64_t total = moff[mb - ma], first_rel = carry - ginf[ma];
+    const uint8_t* s = (const uint8_t*)h->z_out.p;
+    const uint64_t* d_moff = (const uint64_t*)h->z_ooff.p;
+    const size_t nm = (size_t)(mb - ma);
+    DEVMEM(ensure(h, h->p_spec, nm * 8)); DEVMEM(ensure(h, h->p_cnt, nm * 4)); DEVMEM(ensure(h, h->p_land, nm * 8)); DEVMEM(ensure(h, h->p_base, nm * 8));
+    // ---- record-start chain: speculate per member, walk, verify on the host from the exactly known first record -----------
+    vsv_bamdev_speculate(st, s, d_moff, (int64_t)nm, first_rel, n_ref, (uint64_t*)h->p_spec.p);
+    spec.assign(nm, 0); land.assign(nm, 0); base.assign(nm, 0); cnt.assign(nm, 0); active.assign(nm, 0);
+    HIPCHK(h, hipMemcpyAsync(spec.data(), h->p_spec.p, nm * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    uint64_t n_w = 0, next_rel = first_rel;
+    for (int round = 0;; ++round) {
+      if (round > 1024) return fail(h, VSV_E_INVALID, "record chain does not settle (not a BAM stream?): use the host reader");
+      HIPCHK(h, hipMemcpyAsync(h->p_spec.p, spec.data(), nm * 8, hipMemcpyHostToDevice, st));
+      vsv_bamdev_chain(st, false, s, d_moff, (int64_t)nm, (const uint64_t*)h->p_spec.p, (uint32_t*)h->p_cnt.p, (uint64_t*)h->p_land.p, nullptr, nullptr);
+      HIPCHK(h, hipMemcpyAsync(cnt.data(), h->p_cnt.p, nm * 4, hipMemcpyDeviceToHost, st));
+      HIPCHK(h, hipMemcpyAsync(land.data(), h->p_land.p, nm * 8, hipMemcpyDeviceToHost, st));
+      HIPCHK(h, hipStreamSynchronize(st));
+      std::fill(active.begin(), active.end(), 0);
+      bool patched = false;
+      uint64_t expect = first_rel;
+      n_w = 0;
+      while (expect < total) {
+        const size_t m = (size_t)(std::upper_bound(moff.begin(), moff.end(), expect) - moff.begin()) - 1;   // member holding `expect`
+        if (spec[m] != expect) { spec[m] = expect; patched = true; break; }                                  // proven start: patch and rewalk
+        if (land[m] == 0xFFFFFFFFFFFFFFFFull) return fail(h, VSV_E_INVALID, "malformed BAM record chain");
+        active[m] = 1; base[m] = n_w; n_w += cnt[m];
+        const bool stopped = land[m] < moff[m + 1];            // a record that is not complete inside this window starts at land[m]
+        expect = land[m];
+        if (stopped) break;
+      }
+      if (!patched) { next_rel = expect; break; }
+    }
+    if (last_window && next_rel != total) return fail(h, VSV_E_INVALID, "BAM stream ends inside a record");
+    if (n_w == 0 && !last_window) return fail(h, VSV_E_CAPACITY, "a record is larger than the device reader's window: use the host reader");
+    if (K0 + n_w > 0x7FFFFFF0ull) return fail(h, VSV_E_CAPACITY, "too many records for the device reader: use the host reader");
+    if (n_w > 0) {
+      for (size_t m = 0; m < nm; ++m) if (!active[m]) spec[m] = 0xFFFFFFFFFFFFFFFFull;      // speculated starts the chain never reached
+      const int64_t n = (int64_t)n_w;
+      const size_t N = (size_t)n;
+      HIPCHK(h, hipMemcpyAsync(h->p_spec.p, spec.data(), nm * 8, hipMemcpyHostToDevice, st));
+      HIPCHK(h, hipMemcpyAsync(h->p_base.p, base.data(), nm * 8, hipMemcpyHostToDevice, st));
+      DEVMEM(ensure(h, h->p_recoff, N * 8)); DEVMEM(ensure(h, h->p_pos, N * 4)); DEVMEM(ensure(h, h->p_tid, N * 4)); DEVMEM(ensure(h, h->p_mapq, N));
+      DEVMEM(ensure(h, h->p_flag, N)); DEVMEM(ensure(h, h->p_lseq, N * 4)); DEVMEM(ensure(h, h->p_sflag, N * 4)); DEVMEM(ensure(h, h->p_ncig, N * 4));
+      DEVMEM(ensure(h, h->p_cgsrc, N * 8)); DEVMEM(ensure(h, h->p_hash, N * 8)); DEVMEM(ensure(h, h->p_keep, N * 4 + 16)); DEVMEM(ensure(h, h->p_kidx, N * 4 + 16));
+      DEVMEM(ensure(h, h->p_cigoff, N * 8)); DEVMEM(ensure(h, h->p_sums, (N / 2048 + 4) * 8)); DEVMEM(ensure(h, h->o_recoff, N * 8));
+      DEVMEM(ensure(h, h->o_nlen, N * 4 + 16)); DEVMEM(ensure(h, h->o_noff, N * 4 + 16));
+      vsv_bamdev_chain(st, true, s, d_moff, (int64_t)nm, (const uint64_t*)h->p_spec.p, nullptr, nullptr, (const uint64_t*)h->p_base.p, (uint64_t*)h->p_recoff.p);
+      vsv_bamdev_fields(st, s, (const uint64_t*)h->p_recoff.p, n, tid, (int32_t*)h->p_pos.p, (int32_t*)h->p_tid.p, (uint8_t*)h->p_mapq.p, (uint8_t*)h->p_flag.p,
+                        (uint32_t*)h->p_lseq.p, (uint32_t*)h->p_sflag.p, (uint32_t*)h->p_ncig.p, (uint64_t*)h->p_cgsrc.p, (uint64_t*)h->p_hash.p,
+                        (uint32_t*)h->p_keep.p, (uint32_t*)h->p_err.p);
+      vsv_scan_u32_exclusive(st, (const uint32_t*)h->p_keep.p, (int)n, (uint32_t*)h->p_kidx.p, (uint32_t*)h->p_sums.p);
+      vsv_bamdev_scan64(st, (const uint32_t*)h->p_ncig.p, (const uint32_t*)h->p_keep.p, n, (uint64_t*)h->p_sums.p, (uint64_t*)h->p_cigoff.p, (uint64_t*)h->p_tot.p);
+      uint32_t last_k = 0, last_keep = 0, err = 0;
+      uint64_t ops_w = 0;
+      HIPCHK(h, hipMemcpyAsync(&last_k, (uint32_t*)h->p_kidx.p + (n - 1), 4, hipMemcpyDeviceToHost, st));
+      HIPCHK(h, hipMemcpyAsync(&last_keep, (uint32_t*)h->p_keep.p + (n - 1), 4, hipMemcpyDeviceToHost, st));
+      HIPCHK(h, hipMemcpyAsync(&ops_w, h->p_tot.p, 8, hipMemcpyDeviceToHost, st));
+      HIPCHK(h, hipMemcpyAsync(&err, h->p_err.p, 4, hipMemcpyDeviceToHost, st));
+      HIPCHK(h, hipStreamSynchronize(st));
+      if (err & 1u) return fail(h, VSV_E_INVALID, "unknown BAM tag type");
+      const uint64_t nk = (uint64_t)last_k + last_keep;
+      if (nk > 0) {
+        const size_t K = (size_t)(K0 + nk);
+        DEVMEM(ensure_keep(h, h->o_pos, K * 4, (size_t)K0 * 4)); DEVMEM(ensure_keep(h, h->o_tid, K * 4, (size_t)K0 * 4));
+        DEVMEM(ensure_keep(h, h->o_cigoff, (K + 1) * 8, (size_t)K0 * 8)); DEVMEM(ensure_keep(h, h->o_mapq, K, (size_t)K0)); DEVMEM(ensure_keep(h, h->o_flag, K, (size_t)K0));
+        DEVMEM(ensure_keep(h, h->o_cigar, (size_t)(C0 + ops_w) * 4 + 16, (size_t)C0 * 4)); DEVMEM(ensure_keep(h, h->o_lseq, K * 4, (size_t)K0 * 4));
+        DEVMEM(ensure_keep(h, h->o_sflag, K * 4, (size_t)K0 * 4)); DEVMEM(ensure_keep(h, h->o_hash, K * 8, (size_t)K0 * 8));
+        DEVMEM(ensure_keep(h, h->o_nmoff, K * 8, (size_t)K0 * 8)); DEVMEM(ensure_keep(h, h->o_nmlen, K * 4, (size_t)K0 * 4));
+        vsv_bamdev_emit(st, s, n, (const uint32_t*)h->p_keep.p, (const uint32_t*)h->p_kidx.p, (const int32_t*)h->p_pos.p, (const int32_t*)h->p_tid.p,
+                        (const uint8_t*)h->p_mapq.p, (const uint8_t*)h->p_flag.p, (const uint32_t*)h->p_lseq.p, (const uint32_t*)h->p_sflag.p,
+                        (const uint32_t*)h->p_ncig.p, (const uint64_t*)h->p_cgsrc.p, (const uint64_t*)h->p_hash.p, (const uint64_t*)h->p_cigoff.p,
+                        (const uint64_t*)h->p_recoff.p, (int32_t*)h->o_pos.p, (int32_t*)h->o_tid.p, (uint8_t*)h->o_mapq.p, (uint8_t*)h->o_flag.p,
+                        (uint32_t*)h->o_lseq.p, (uint32_t*)h->o_sflag.p, (uint64_t*)h->o_cigoff.p, (uint32_t*)h->o_cigar.p, (uint64_t*)h->o_hash.p,
+                        (uint64_t*)h->o_recoff.p, K0, C0);
+        // names of the kept records into the compact store (the inflated window is gone when the query ids are assigned)
+        vsv_bamdev_win_name_lens(st, s, (const uint64_t*)h->o_recoff.p, (int64_t)nk, (uint32_t*)h->o_nlen.p);
+        vsv_scan_u32_exclusive(st, (const uint32_t*)h->o_nlen.p, (int)nk, (uint32_t*)h->o_noff.p, (uint32_t*)h->p_sums.p);
+        uint32_t lo_ = 0, ll_ = 0;
+        HIPCHK(h, hipMemcpyAsync(&lo_, (uint32_t*)h->o_noff.p + (nk - 1), 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipMemcpyAsync(&ll_, (uint32_t*)h->o_nlen.p + (nk - 1), 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipStreamSynchronize(st));
+        const uint64_t nb_w = (uint64_t)lo_ + ll_;
+        DEVMEM(ensure_keep(h, h->o_names, (size_t)(N0 + nb_w) + 16, (size_t)N0));
+        vsv_bamdev_win_name_store(st, s, (const uint64_t*)h->o_recoff.p, (const uint32_t*)h->o_noff.p, (int64_t)nk, K0, N0, (uint8_t*)h->o_names.p,
+                                  (uint64_t*)h->o_nmoff.p, (uint32_t*)h->o_nmlen.p);
+        HIPCHK(h, hipStreamSynchronize(st));
+        K0 += nk; C0 += ops_w; N0 += nb_w;
+      }
+    }
+    if (next_rel == first_rel && n_w == 0 && last_window) break;
+    carry = ginf[ma] + next_rel;
+  }
+  const int64_t nk = (int64_t)K0;
+  out->n_records = nk; out->n_ops = (int64_t)C0; out->n_tids = n_ref;
   if (nk == 0) return 0;
   const size_t K = (size_t)nk;
-  if ((rc = ensure(h, h->o_pos, K * 4)) || (rc = ensure(h, h->o_tid, K * 4)) || (rc = ensure(h, h->o_qid, K * 4)) || (rc = ensure(h, h->o_cigoff, (K + 1) * 8)) ||
-      (rc = ensure(h, h->o_mapq, K)) || (rc = ensure(h, h->o_flag, K)) || (rc = ensure(h, h->o_cigar, (size_t)n_ops * 4 + 16)) || (rc = ensure(h, h->o_lseq, K * 4)) ||
-      (rc = ensure(h, h->o_sflag, K * 4)) || (rc = ensure(h, h->o_hash, K * 8)) || (rc = ensure(h, h->o_recoff, K * 8)) || (rc = ensure(h, h->o_first, K * 4 + 16)) ||
-      (rc = ensure(h, h->o_rank, K * 4 + 16)) || (rc = ensure(h, h->o_nlen, K * 4 + 16)) || (rc = ensure(h, h->o_noff, K * 4 + 16))) return rc;
-  vsv_bamdev_emit(st, s, n, (const uint32_t*)h->p_keep.p, (const uint32_t*)h->p_kidx.p, (const int32_t*)h->p_pos.p, (const int32_t*)h->p_tid.p,
-                  (const uint8_t*)h->p_mapq.p, (const uint8_t*)h->p_flag.p, (const uint32_t*)h->p_lseq.p, (const uint32_t*)h->p_sflag.p,
-                  (const uint32_t*)h->p_ncig.p, (const uint64_t*)h->p_cgsrc.p, (const uint64_t*)h->p_hash.p, (const uint64_t*)h->p_cigoff.p,
-                  (const uint64_t*)h->p_recoff.p, (int32_t*)h->o_pos.p, (int32_t*)h->o_tid.p, (uint8_t*)h->o_mapq.p, (uint8_t*)h->o_flag.p,
-                  (uint32_t*)h->o_lseq.p, (uint32_t*)h->o_sflag.p, (uint64_t*)h->o_cigoff.p, (uint32_t*)h->o_cigar.p, (uint64_t*)h->o_hash.p,
-                  (uint64_t*)h->o_recoff.p);
-  HIPCHK(h, hipMemcpyAsync((uint64_t*)h->o_cigoff.p + K, &n_ops, 8, hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipMemcpyAsync((uint64_t*)h->o_cigoff.p + K, &C0, 8, hipMemcpyHostToDevice, st));
   // ---- dense first-appearance query ids: stable sort of (name hash, record), group heads, ranks of the first occurrences ---
+  DEVMEM(ensure(h, h->o_qid, K * 4)); DEVMEM(ensure(h, h->o_first, K * 4 + 16)); DEVMEM(ensure(h, h->o_rank, K * 4 + 16));
+  DEVMEM(ensure(h, h->o_nlen, K * 4 + 16)); DEVMEM(ensure(h, h->o_noff, K * 4 + 16)); DEVMEM(ensure(h, h->p_sums, (K / 2048 + 4) * 8));
   {  // sort scratch (key / idx / alt pair / histograms) for nk rows; never below the default signature capacity of a run
     const int64_t floor_cap = h->cap_sigs > 0 ? h->cap_sigs : (1 << 22);
-    if ((rc = reserve(h, 1, 1, nk > floor_cap ? nk : floor_cap))) return rc;
+    DEVMEM(reserve(h, 1, 1, nk > floor_cap ? nk : floor_cap));
   }
   { int rs = reset_run_state(h); if (rs) return rs; }
   const uint32_t nk32 = (uint32_t)nk;
@@ -827,10 +876,11 @@ int vsv_bam_parse_device(vsv_handle* h, const uint8_t* comp, const uint64_t* com
   HIPCHK(h, hipMemsetAsync(h->o_first.p, 0, K * 4, st));
   vsv_bamdev_mark_first(st, sr.key, sr.val, nk, (uint32_t*)h->o_first.p);
   vsv_scan_u32_exclusive(st, (const uint32_t*)h->o_first.p, (int)nk, (uint32_t*)h->o_rank.p, (uint32_t*)h->p_sums.p);
-  vsv_bamdev_assign(st, sr.key, sr.val, nk, (const uint32_t*)h->o_rank.p, s, (const uint64_t*)h->o_recoff.p, (uint32_t*)h->o_qid.p, (uint32_t*)h->p_err.p);
-  vsv_bamdev_name_lens(st, s, (const uint64_t*)h->o_recoff.p, (const uint32_t*)h->o_first.p, nk, (uint32_t*)h->o_nlen.p);
+  vsv_bamdev_assign(st, sr.key, sr.val, nk, (const uint32_t*)h->o_rank.p, (const uint8_t*)h->o_names.p, (const uint64_t*)h->o_nmoff.p,
+                    (const uint32_t*)h->o_nmlen.p, (uint32_t*)h->o_qid.p, (uint32_t*)h->p_err.p);
+  vsv_bamdev_name_lens(st, (const uint32_t*)h->o_nmlen.p, (const uint32_t*)h->o_first.p, nk, (uint32_t*)h->o_nlen.p);
   vsv_scan_u32_exclusive(st, (const uint32_t*)h->o_nlen.p, (int)nk, (uint32_t*)h->o_noff.p, (uint32_t*)h->p_sums.p);
-  uint32_t lr = 0, lf = 0, lo = 0, ll = 0;
+  uint32_t lr = 0, lf = 0, lo = 0, ll = 0, err = 0;
   HIPCHK(h, hipMemcpyAsync(&lr, (uint32_t*)h->o_rank.p + (nk - 1), 4, hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipMemcpyAsync(&lf, (uint32_t*)h->o_first.p + (nk - 1), 4, hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipMemcpyAsync(&lo, (uint32_t*)h->o_noff.p + (nk - 1), 4, hipMemcpyDeviceToHost, st));
@@ -839,12 +889,14 @@ int vsv_bam_parse_device(vsv_handle* h, const uint8_t* comp, const uint64_t* com
   HIPCHK(h, hipStreamSynchronize(st));
   if (err & 2u) return fail(h, VSV_E_INVALID, "64-bit name hash collision: use the host reader");
   const size_t blob_bytes = (size_t)lo + ll;
-  if ((rc = ensure(h, h->o_blob, blob_bytes + 16))) return rc;
-  vsv_bamdev_name_copy(st, s, (const uint64_t*)h->o_recoff.p, (const uint32_t*)h->o_first.p, (const uint32_t*)h->o_noff.p, nk, (uint8_t*)h->o_blob.p);
+  DEVMEM(ensure(h, h->o_blob, blob_bytes + 16));
+  vsv_bamdev_name_copy(st, (const uint8_t*)h->o_names.p, (const uint64_t*)h->o_nmoff.p, (const uint32_t*)h->o_nmlen.p, (const uint32_t*)h->o_first.p,
+                       (const uint32_t*)h->o_noff.p, nk, (uint8_t*)h->o_blob.p);
   h->names_blob.resize(blob_bytes);
   if (blob_bytes) HIPCHK(h, hipMemcpyAsync(&h->names_blob[0], h->o_blob.p, blob_bytes, hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipStreamSynchronize(st));
   if (blob_bytes) h->names_blob.pop_back();                          // the separator after the last name
+#undef DEVMEM
   out->pos = (const int32_t*)h->o_pos.p; out->tid = (const int32_t*)h->o_tid.p; out->qid = (const uint32_t*)h->o_qid.p;
   out->cigar_off = (const uint64_t*)h->o_cigoff.p; out->mapq = (const uint8_t*)h->o_mapq.p; out->flag = (const uint8_t*)h->o_flag.p;
   out->cigar = (const uint32_t*)h->o_cigar.p;

@@ -170,13 +170,17 @@ void vsv_bamdev_emit(hipStream_t st, const uint8_t* s, int64_t n, const uint32_t
                      const uint8_t* mapq, const uint8_t* flag, const uint32_t* l_seq, const uint32_t* sam_flag, const uint32_t* n_cig_out,
                      const uint64_t* cg_src, const uint64_t* hash, const uint64_t* cig_off_in, const uint64_t* rec_off, int32_t* o_pos, int32_t* o_tid,
                      uint8_t* o_mapq, uint8_t* o_flag, uint32_t* o_l_seq, uint32_t* o_sam_flag, uint64_t* o_cig_off, uint32_t* o_cigar, uint64_t* o_hash,
-                     uint64_t* o_rec_off);
+                     uint64_t* w_rec_off, uint64_t k0, uint64_t c0);
 void vsv_bamdev_iota(hipStream_t st, uint32_t* p, int64_t n);
 void vsv_bamdev_mark_first(hipStream_t st, const uint64_t* skey, const uint32_t* sval, int64_t n, uint32_t* is_first);
-void vsv_bamdev_assign(hipStream_t st, const uint64_t* skey, const uint32_t* sval, int64_t n, const uint32_t* first_rank, const uint8_t* s,
-                       const uint64_t* rec_off, uint32_t* qid, uint32_t* err);
-void vsv_bamdev_name_lens(hipStream_t st, const uint8_t* s, const uint64_t* rec_off, const uint32_t* is_first, int64_t n, uint32_t* len);
-void vsv_bamdev_name_copy(hipStream_t st, const uint8_t* s, const uint64_t* rec_off, const uint32_t* is_first, const uint32_t* noff, int64_t n, uint8_t* blob);
+void vsv_bamdev_assign(hipStream_t st, const uint64_t* skey, const uint32_t* sval, int64_t n, const uint32_t* first_rank, const uint8_t* names,
+                       const uint64_t* nm_off, const uint32_t* nm_len, uint32_t* qid, uint32_t* err);
+void vsv_bamdev_win_name_lens(hipStream_t st, const uint8_t* s, const uint64_t* w_rec_off, int64_t nk, uint32_t* len);
+void vsv_bamdev_win_name_store(hipStream_t st, const uint8_t* s, const uint64_t* w_rec_off, const uint32_t* loff, int64_t nk, uint64_t k0, uint64_t n0,
+                               uint8_t* names, uint64_t* nm_off, uint32_t* nm_len);
+void vsv_bamdev_name_lens(hipStream_t st, const uint32_t* nm_len, const uint32_t* is_first, int64_t n, uint32_t* len);
+void vsv_bamdev_name_copy(hipStream_t st, const uint8_t* names, const uint64_t* nm_off, const uint32_t* nm_len, const uint32_t* is_first, const uint32_t* noff,
+                          int64_t n, uint8_t* blob);
 
 // support.hip: GT-correction joins
 void vsv_launch_gt_support(hipStream_t st, const int32_t* vpos, const int32_t* vlen, const int32_t* blo, const int32_t* bhi, int64_t nv, const int32_t* spos,
