@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--cpu-reps", type=int, default=5, help="repetitions of the CPU baseline (best is reported)")
     ap.add_argument("--max-sigs", type=int, default=1 << 22)
     ap.add_argument("--streams", type=int, default=2, help="engines (handle + HIP stream) in flight per rank")
+    ap.add_argument("--host-threads", type=int, default=0, help="1: one host thread per engine enqueues its steps")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one rank per GPU) | gloo (rehearsal: all ranks on cuda:0)")
     args = ap.parse_args()
 
@@ -72,15 +73,32 @@ def main():
     chrom_len, n_rec = int(index[rank, 0]), int(index[rank, 1])
     # synthetic shard generated directly in HBM (torch CUDA generator = Philox); tid = rank
     t, nq, _ = synth.generate(n_rec, args.shape, seed=20250328 + config_idx + 1000 * rank, tid=rank, chrom_len=chrom_len, device=dev)
-    recs = DeviceRecords(t, nq, world, max_pos=chrom_len + 200000)   # the reference index carries the contig length
+    # sort-key hints from the reference index: the contig length, and that this shard holds one chromosome (tid = rank)
+    recs = DeviceRecords(t, nq, rank + 1, max_pos=chrom_len + 200000, tid_lo=rank)
     n_streams = max(1, min(args.streams, max(1, args.steps)))
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(n_streams - 1)]
     engs = [Engine(local_rank, stream=s.cuda_stream, max_sigs=args.max_sigs) for s in streams]
     p = default_params(dtype)
+    pool = None
+    if args.host_threads and n_streams > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=n_streams)
 
     def run_steps(k, scan_ms):
         """k steps round-robin over the engines; a step's counters (status + table sizes) are read back, once, before
-        its engine is reused. Returns the engine that ran the last step."""
+        its engine is reused. Returns the engine that ran the last step. With --host-threads each engine is driven by its
+        own host thread (a step is ~95 kernel launches = 0.4 ms of enqueue on one core; the library calls release the GIL)."""
+        if args.host_threads and n_streams > 1:
+            def drive(j):
+                ms = []
+                for _ in range(j, k, n_streams):
+                    engs[j].run_async(recs, p)
+                    engs[j].finish()
+                    ms.append(engs[j].scan_ms())
+                return ms
+            for ms in pool.map(drive, range(n_streams)):
+                scan_ms.extend(ms)
+            return engs[(k - 1) % n_streams]
         for i in range(k):
             e = engs[i % n_streams]
             if i >= n_streams:

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VSV_ABI_VERSION 1
+#define VSV_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------------------------ */
 typedef enum vsv_status {
@@ -77,6 +77,9 @@ typedef struct vsv_records {
   int32_t n_qids;              /* max qid + 1 (required when n_records > 0)                            */
   int32_t n_tids;              /* max tid + 1; 0 = unknown (16 key bits are reserved for it)       */
   int32_t max_pos;             /* upper bound of pos (e.g. contig length); 0 = unknown. Only trims sort passes. */
+  int32_t tid_lo;              /* lowest tid of this run (0 = unknown): sort keys carry tid - tid_lo, so a single-
+                                  chromosome shard (tid_lo = tid, n_tids = tid + 1) sorts on one tid bit        */
+  int32_t reserved0;
 } vsv_records;
 
 /* ---- parameters; defaults equal the hard-coded reference values ----------------------------- */

@@ -28,10 +28,10 @@ def test_exports_every_declared_symbol(lib):
 
 
 def test_struct_sizes_match_header(lib):
-    assert C.sizeof(Records) == 8 + 8 + 7 * 8 + 4 * 4
+    assert C.sizeof(Records) == 8 + 8 + 7 * 8 + 6 * 4
     assert C.sizeof(Params) == 16 * 4
     assert SIG_DTYPE.itemsize == 32 and CALL_DTYPE.itemsize == 48
-    assert lib.vsv_abi_version() == 1
+    assert lib.vsv_abi_version() == 2
 
 
 def test_default_params_are_reference_constants(lib):

@@ -116,6 +116,51 @@ def test_multi_tid(eng):
     assert set(np.unique(got["calls"]["sig"]["tid"])) == {0, 1, 2}
 
 
+def test_tid_hint_trims_keys_without_changing_results(eng):
+    """vsv_records.tid_lo: a shard that holds chromosomes 5..6 of 7 sorts on tid - 5 (fewer key bits, fewer radix passes); the
+    tables are the ones of the unhinted run and of the oracle. A single-chromosome view uses only_tid. A hint the data
+    violates is reported, never silently mis-sorted."""
+    from volcanosv_amd import synth
+    from volcanosv_amd.engine import default_params
+    parts = []
+    for tid in (5, 6):
+        t, nq, _ = synth.generate(30000, "hifi", seed=200 + tid, tid=tid, chrom_len=1500000, events_per_record=0.2, site_step=1000)
+        parts.append((t, nq))
+    t, nq = synth.concat(parts)
+    soa = synth.to_soa(t, nq)
+    soa.n_tids = 7
+    want = run_both(eng, soa, DTYPE_HIFI)
+
+    class Hinted:                      # same arrays, hinted struct
+        def __init__(self, soa, lo):
+            self.soa, self.lo = soa, lo
+
+        def as_struct(self):
+            r = self.soa.as_struct()
+            r.tid_lo = self.lo
+            return r
+
+    for dtype in (DTYPE_HIFI, DTYPE_READS):
+        p = default_params(dtype)
+        eng.run(soa, p)
+        base = eng.tables(dtype)
+        eng.run(Hinted(soa, 5), p)
+        assert_tables_equal(eng.tables(dtype), base, list(base.keys()))
+    assert set(np.unique(want["calls"]["sig"]["tid"])) == {5, 6}
+    with pytest.raises(VsvError) as e:
+        eng.run(Hinted(soa, 6), default_params(DTYPE_HIFI))          # records of tid 5 lie below the hint
+    assert e.value.status == -1 and "tid" in str(e.value)
+    with pytest.raises(VsvError):
+        eng.run(Hinted(soa, 7), default_params(DTYPE_HIFI))          # tid_lo >= n_tids
+    one, nq1 = parts[1]
+    s1 = synth.to_soa(one, nq1)
+    s1.n_tids = 7
+    base = run_both(eng, s1, DTYPE_HIFI)
+    s1.only_tid = 6
+    eng.run(s1, default_params(DTYPE_HIFI))
+    assert_tables_equal(eng.tables(DTYPE_HIFI), base, list(base.keys()))
+
+
 def test_long_records_with_both_haplotype_tags(eng):
     """Mb-scale records (every chunk of the scan lies inside one record) whose names carry hp1 AND hp2
     on every third record (two rows per signature), plus a low-mapq record and the reads / svim / collector op tables."""

@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # dtype of the extractor (reference: extract_contig_signature_{Hifi,ONT,CLR}.py, extract_reads_signature.py,
 # svim_asm/SVIM_intra.py)
@@ -38,6 +38,7 @@ class Records(C.Structure):
         ("pos", C.c_void_p), ("tid", C.c_void_p), ("qid", C.c_void_p), ("cigar_off", C.c_void_p),
         ("mapq", C.c_void_p), ("flag", C.c_void_p), ("cigar", C.c_void_p),
         ("on_device", C.c_int32), ("n_qids", C.c_int32), ("n_tids", C.c_int32), ("max_pos", C.c_int32),
+        ("tid_lo", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 

@@ -93,11 +93,14 @@ class DeviceRecordView:
         self.n_records, self.n_ops = int(rec.n_records), int(rec.n_ops)
         self.n_qids, self.n_tids = int(rec.n_qids), int(rec.n_tids)
         self.max_pos = 0
+        self.only_tid = None        # set when every record has this tid: trims the sort keys to one tid bit
         self._l_seq_ptr, self._sam_flags_ptr = l_seq_ptr, sam_flags_ptr
         self._engine = engine
 
     def as_struct(self):
         self._rec.max_pos = int(self.max_pos)
+        if self.only_tid is not None:
+            self._rec.tid_lo, self._rec.n_tids = int(self.only_tid), int(self.only_tid) + 1
         return self._rec
 
     def qname(self, rec):

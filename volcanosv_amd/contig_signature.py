@@ -69,6 +69,7 @@ def run(dtype_name, bam_path, contig_path, ref_path, output_dir, chr_number=None
                     else:
                         view = bam.fetch_device(eng, name)
                     view.max_pos = bam.lengths[bam.get_tid(name)] + 100000
+                    view.only_tid = bam.get_tid(name)
                     soa = view.host_light()
                     if view.n_records:
                         eng.run_async(view, p)
@@ -77,7 +78,8 @@ def run(dtype_name, bam_path, contig_path, ref_path, output_dir, chr_number=None
                     soa._view = view                                     # keeps the device arrays' owner alive
                 else:
                     soa = bam.fetch_soa(name)
-                    soa.max_pos = bam.lengths[bam.get_tid(name)] + 100000   # sort-key hint: positions never exceed the contig
+                    soa.max_pos = bam.lengths[bam.get_tid(name)] + 100000   # sort-key hints: positions never exceed the contig,
+                    soa.only_tid = bam.get_tid(name)                        # and every record has this tid
                     eng.run_async(soa, p)
                 pending.append((i, name, soa, eng))
             while pending:

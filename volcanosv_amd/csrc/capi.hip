@@ -161,6 +161,8 @@ int bind_records(vsv_handle* h, const vsv_records* r) {
     v.cigar_off = (const uint64_t*)h->r_off.p; v.mapq = (const uint8_t*)h->r_mapq.p; v.flag = (const uint8_t*)h->r_flag.p;
     v.cigar = (const uint32_t*)h->r_cigar.p;
   }
+  if (r->tid_lo < 0 || (r->n_tids > 0 && r->tid_lo >= r->n_tids)) return fail(h, VSV_E_INVALID, "tid_lo outside [0, n_tids)");
+  v.tid_lo = r->tid_lo;
   h->rv = v;
   h->n_tids = r->n_tids;
   h->max_pos = r->max_pos > 0 ? r->max_pos : 0;
@@ -190,10 +192,11 @@ int reset_run_state(vsv_handle* h) {
   h->pass_cursor = 0;
   return 0;
 }
-StageBufs stage_bufs(vsv_handle* h) { return StageBufs{(uint64_t*)h->key.p, (uint32_t*)h->idx.p, (int32_t*)h->cl.p}; }
+int tid_bits(vsv_handle* h);
+StageBufs stage_bufs(vsv_handle* h) { return StageBufs{(uint64_t*)h->key.p, (uint32_t*)h->idx.p, (int32_t*)h->cl.p, h->rv.tid_lo, tid_bits(h)}; }
 Counters* dctr(vsv_handle* h) { return (Counters*)h->ctr.p; }
 int pos_bits(vsv_handle* h) { return h->max_pos > 0 ? bits_for((uint64_t)h->max_pos + VSV_POS_BIAS + 2) : 32; }
-int tid_bits(vsv_handle* h) { return bits_for((uint64_t)(h->n_tids > 0 ? h->n_tids : 65536) + 1); }
+int tid_bits(vsv_handle* h) { return bits_for((uint64_t)(h->n_tids > 0 ? h->n_tids - h->rv.tid_lo : 65536) + 1); }
 int key_bits(vsv_handle* h) { return pos_bits(h) + 3 + tid_bits(h) + 1; }   // +1: dead keys (all ones) sort last
 
 bool is_contig(int dtype) { return dtype == VSV_DTYPE_HIFI || dtype == VSV_DTYPE_ONT || dtype == VSV_DTYPE_CLR; }
@@ -269,6 +272,7 @@ int enq_pair(vsv_handle* h) {
 }
 
 int finish(vsv_handle* h) {
+  HIPCHK(h, hipSetDevice(h->device));   // the current device is per host thread
   HIPCHK(h, hipMemcpyAsync(h->pinned, h->ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->host_ctr = *h->pinned;
@@ -288,7 +292,7 @@ int finish(vsv_handle* h) {
     return fail(h, VSV_E_CAPACITY, b);
   }
   if (e & ERRB_EMPTY_CIGAR) return fail(h, VSV_E_EMPTY_CIGAR, "record with no CIGAR ops / cigar_off not increasing");
-  if (e & ERRB_RANGE) return fail(h, VSV_E_INVALID, "a part spans >= 2^30 CIGAR ops, or a position exceeds the max_pos hint");
+  if (e & ERRB_RANGE) return fail(h, VSV_E_INVALID, "a part spans >= 2^30 CIGAR ops, a position exceeds the max_pos hint, or a tid lies outside [tid_lo, n_tids)");
   if (e & ERRB_REFEND) return fail(h, VSV_E_REFEND, "N/=/X op in an eligible record on the contig path (offset_ref != reference_end)");
   if (e & ERRB_ZERODIV) return fail(h, VSV_E_ZERODIV, "CLR gate on a record without M ops");
   if (e & ERRB_UNSORTED) return fail(h, VSV_E_UNSORTED, "split pair with pos1 > pos2");

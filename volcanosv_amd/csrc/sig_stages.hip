@@ -136,7 +136,8 @@ struct SplitCfg {
   int contig;        // 1: hp/mapq eligibility, two hap passes; 0: reads path, every record, one pass
   int min_mapq;
   int qid_bits;
-  int tid_shift;     // ckey = tid << tid_shift | hap << qid_bits | qid
+  int tid_shift;     // ckey = (tid - tid_lo) << tid_shift | hap << qid_bits | qid
+  int tid_lo, tid_bits;
 };
 
 // ---- names that occur more than once, without a counting table ---------------------------------------
@@ -226,7 +227,7 @@ constexpr int SC_TILE_REC = 256 * 4 * SC_ROUNDS;    // records per block
 template <bool WRITE>
 __global__ __launch_bounds__(256) void split_cand(RecView rv, SplitCfg c, const uint32_t* __restrict__ tab,
                                                   uint32_t* __restrict__ blk, uint64_t* __restrict__ ckey,
-                                                  uint32_t* __restrict__ crec, uint32_t cap, bool vec) {
+                                                  uint32_t* __restrict__ crec, uint32_t cap, bool vec, uint32_t* __restrict__ err) {
   __shared__ uint32_t cnt[SC_ROUNDS][4];
   const uint64_t n = (uint64_t)rv.n_records;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -290,7 +291,9 @@ __global__ __launch_bounds__(256) void split_cand(RecView rv, SplitCfg c, const 
       const uint32_t j = (uint32_t)it >> 1, hap = (uint32_t)it & 1u;
       if (dst < cap) {
         const uint32_t qj = j == 0 ? q[k][0] : j == 1 ? q[k][1] : j == 2 ? q[k][2] : q[k][3];
-        ckey[dst] = ((uint64_t)(uint32_t)rv.tid[r0 + j] << c.tid_shift) | ((uint64_t)hap << c.qid_bits) | qj;
+        const uint32_t trel = (uint32_t)(rv.tid[r0 + j] - c.tid_lo);
+        if (trel >> c.tid_bits) atomicOr(err, ERRB_RANGE);          // tid outside [tid_lo, n_tids)
+        ckey[dst] = ((uint64_t)trel << c.tid_shift) | ((uint64_t)hap << c.qid_bits) | qj;
         crec[dst] = (uint32_t)(r0 + j);
       }
       ++dst;
@@ -457,26 +460,27 @@ __global__ void set_n_s1(Counters* ctr, uint32_t cap) {
 }
 
 // ---- keys / gather / alive count --------------------------------------------------------------------
-__global__ __launch_bounds__(256) void build_keys(const vsv_sig* __restrict__ s, const uint32_t* __restrict__ d_n, int stage, int pb,
-                                                  uint64_t* __restrict__ key, uint32_t* __restrict__ idx, Counters* ctr) {
+__global__ __launch_bounds__(256) void build_keys(const vsv_sig* __restrict__ s, const uint32_t* __restrict__ d_n, int stage, int pb, int tid_lo,
+                                                  int tid_bits, uint64_t* __restrict__ key, uint32_t* __restrict__ idx, Counters* ctr) {
   const uint32_t n = *d_n;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const vsv_sig v = s[i];
     uint64_t k;
     if (stage == 5) {  // READS final order (reads.py:281-286): (tid,pos) then source, DEL before INS, list order
       k = (v.meta & VSV_M_DEAD) ? VSV_KEY_DEAD
-          : ((uint64_t)(uint32_t)v.tid << (pb + 2)) | (vsv_kpos(v.pos) << 2) | ((v.meta & VSV_M_SPLIT) ? 2u : 0u) | ((v.meta & VSV_M_DEL) ? 0u : 1u);
-    } else k = vsv_key_stage(v, stage, pb);
-    if (!(v.meta & VSV_M_DEAD) && pb < 32 && (vsv_kpos(v.pos) >> pb) != 0) atomicOr(&ctr->err, ERRB_RANGE);  // max_pos hint too small
+          : ((uint64_t)(uint32_t)(v.tid - tid_lo) << (pb + 2)) | (vsv_kpos(v.pos) << 2) | ((v.meta & VSV_M_SPLIT) ? 2u : 0u) | ((v.meta & VSV_M_DEL) ? 0u : 1u);
+    } else k = vsv_key_stage(v, stage, pb, tid_lo);
+    if (!(v.meta & VSV_M_DEAD) && ((pb < 32 && (vsv_kpos(v.pos) >> pb) != 0) || ((uint32_t)(v.tid - tid_lo) >> tid_bits) != 0))
+      atomicOr(&ctr->err, ERRB_RANGE);  // max_pos hint too small / tid outside [tid_lo, n_tids)
     key[i] = k;
     idx[i] = i;
   }
 }
-__global__ __launch_bounds__(256) void build_call_keys(const vsv_call* __restrict__ c, const uint32_t* __restrict__ d_n, int pb,
+__global__ __launch_bounds__(256) void build_call_keys(const vsv_call* __restrict__ c, const uint32_t* __restrict__ d_n, int pb, int tid_lo,
                                                        uint64_t* __restrict__ key, uint32_t* __restrict__ idx) {
   const uint32_t n = *d_n;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    key[i] = vsv_key_stage(c[i].sig, 4, pb);
+    key[i] = vsv_key_stage(c[i].sig, 4, pb, tid_lo);
     idx[i] = i;
   }
 }
@@ -733,7 +737,9 @@ void vsv_launch_split(hipStream_t st, const RecView& rv, const vsv_params& p, in
   c.min_mapq = p.min_split_mapq;
   c.qid_bits = bits_for((uint64_t)(rv.n_qids > 0 ? rv.n_qids : rv.n_records) + 1);
   c.tid_shift = c.qid_bits + 1;
-  const int tid_bits = bits_for((uint64_t)(n_tids > 0 ? n_tids : 65536) + 1);
+  c.tid_lo = rv.tid_lo;
+  const int tid_bits = bits_for((uint64_t)(n_tids > 0 ? n_tids - rv.tid_lo : 65536) + 1);
+  c.tid_bits = tid_bits;
   const int rec_bits = bits_for((uint64_t)rv.n_records + 1);
   if (rv.n_records > 0) {
     const uint64_t nq = rv.n_qids > 0 ? (uint64_t)rv.n_qids : (uint64_t)tab_size * 32;
@@ -745,9 +751,9 @@ void vsv_launch_split(hipStream_t st, const RecView& rv, const vsv_params& p, in
     qid_scan_max<<<1, 1024, 0, st>>>(blk_cnt, qtiles);
     qid_mark_dups<<<qtiles, 256, 0, st>>>(rv.qid, rv.n_records, blk_cnt, tab, vec);
     const int nblk = (int)(((uint64_t)rv.n_records + SC_TILE_REC - 1) / SC_TILE_REC);
-    split_cand<false><<<nblk, 256, 0, st>>>(rv, c, tab, blk_cnt, ckey, crec, cap, vec);
+    split_cand<false><<<nblk, 256, 0, st>>>(rv, c, tab, blk_cnt, ckey, crec, cap, vec, &ctr->err);
     vsv_scan_u32_exclusive(st, blk_cnt, nblk, blk_off, scan_tmp);
-    split_cand<true><<<nblk, 256, 0, st>>>(rv, c, tab, blk_off, ckey, crec, cap, vec);
+    split_cand<true><<<nblk, 256, 0, st>>>(rv, c, tab, blk_off, ckey, crec, cap, vec, &ctr->err);
     split_set_ncand<<<1, 1, 0, st>>>(blk_off, blk_cnt, nblk, cap, ctr);
     // the first result may live in the shared scratch pair, so the second sort gets a scratch pair of its own
     const SortResult r1 = vsv_radix_sort_pairs(st, ckey, crec, sw.key_alt, sw.val_alt, &ctr->n_cand, cap, c.tid_shift + tid_bits, sw);
@@ -763,7 +769,7 @@ void vsv_launch_split(hipStream_t st, const RecView& rv, const vsv_params& p, in
 const uint64_t* vsv_launch_sort_stage(hipStream_t st, const vsv_sig* in, const uint32_t* d_n, int stage, int pb, int nbits,
                                       vsv_sig* sorted, uint32_t* d_alive, const StageBufs& b, const SortWork& sw, int64_t cap,
                                       Counters* ctr) {
-  build_keys<<<EW_GRID, 256, 0, st>>>(in, d_n, stage, pb, b.key, b.idx, ctr);
+  build_keys<<<EW_GRID, 256, 0, st>>>(in, d_n, stage, pb, b.tid_lo, b.tid_bits, b.key, b.idx, ctr);
   const SortResult r = vsv_radix_sort_pairs(st, b.key, b.idx, sw.key_alt, sw.val_alt, d_n, cap, nbits, sw);
   gather_rows<vsv_sig><<<EW_GRID, 256, 0, st>>>(in, r.val, r.key, d_n, sorted, d_alive, &ctr->n_long);
   return r.key;
@@ -782,7 +788,7 @@ void vsv_launch_pair(hipStream_t st, const vsv_sig* merged, const uint64_t* merg
   pair_kernel<<<EW_GRID, 256, 0, st>>>(merged, merged_key, d_alive3, pair_shift, pb, b.cl, calls_tmp, key2, &ctr->n_long);
   pair_long_kernel<<<LONG_GRID, 256, 0, st>>>(merged, merged_key, d_alive3, pair_shift, pb, b.cl, calls_tmp, key2, &ctr->n_long);
   pair_finish<<<EW_GRID, 256, 0, st>>>(merged, d_alive3, b.cl, calls_tmp);
-  build_call_keys<<<EW_GRID, 256, 0, st>>>(calls_tmp, d_alive3, pb, key2, idx2);
+  build_call_keys<<<EW_GRID, 256, 0, st>>>(calls_tmp, d_alive3, pb, b.tid_lo, key2, idx2);
   const SortResult r = vsv_radix_sort_pairs(st, key2, idx2, sw.key_alt, sw.val_alt, d_alive3, cap, nbits, sw);
   gather_rows<vsv_call><<<EW_GRID, 256, 0, st>>>(calls_tmp, r.val, r.key, d_alive3, calls, d_ncalls, &ctr->n_long);
 }

@@ -47,18 +47,19 @@ struct RecView {
   const uint8_t* flag;
   const uint32_t* cigar;
   int32_t n_qids;
+  int32_t tid_lo;   // keys carry tid - tid_lo
 };
 
 // ---- sort keys: [tid | hap | type | source | pos], list id in the high bits ------------------------
 #define VSV_KEY_DEAD 0xFFFFFFFFFFFFFFFFull
 #define VSV_POS_BIAS 65536   // keys order positions >= -65536 (split DEL positions can dip slightly below 0)
-// key = tid << (pb+3) | hap << (pb+2) | type << (pb+1) | source << pb | (pos + bias); pb = position bits of the run
+// key = (tid - tid_lo) << (pb+3) | hap << (pb+2) | type << (pb+1) | source << pb | (pos + bias); pb = position bits of the run
 // (32 without a max_pos hint). Same ORDER as the oracle's keys; only the bit packing differs.
 __host__ __device__ inline uint64_t vsv_kpos(int32_t pos) { return (uint32_t)(pos + VSV_POS_BIAS); }
-__host__ __device__ inline uint64_t vsv_key_stage(const vsv_sig& s, int stage, int pb) {
+__host__ __device__ inline uint64_t vsv_key_stage(const vsv_sig& s, int stage, int pb, int tid_lo) {
   if (s.meta & VSV_M_DEAD) return VSV_KEY_DEAD;
   uint64_t hap = (s.meta & VSV_M_HP2) ? 1 : 0, del = (s.meta & VSV_M_DEL) ? 1 : 0, sp = (s.meta & VSV_M_SPLIT) ? 1 : 0;
-  uint64_t k = ((uint64_t)(uint32_t)s.tid << (pb + 3)) | vsv_kpos(s.pos);
+  uint64_t k = ((uint64_t)(uint32_t)(s.tid - tid_lo) << (pb + 3)) | vsv_kpos(s.pos);
   if (stage == 1) return k | (hap << (pb + 2)) | (del << (pb + 1)) | (sp << pb);   // list = (tid,hap,type,src)
   if (stage == 2) return k | (hap << (pb + 2)) | (del << (pb + 1));                // list = (tid,hap,type)
   if (stage == 3) return k | (hap << (pb + 2));                                    // list = (tid,hap)
@@ -97,6 +98,7 @@ struct StageBufs {
   uint64_t* key;        // sort keys of the current stage (kept sorted for cluster / pair kernels)
   uint32_t* idx;
   int32_t* cl;          // cluster ids / pairing state
+  int tid_lo, tid_bits; // keys carry tid - tid_lo on tid_bits bits
 };
 
 // radix_sort.hip: stable LSD radix sort of (key,val) pairs on bits [0,nbits); n on the device. The result is left in

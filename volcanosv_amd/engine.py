@@ -29,9 +29,10 @@ def default_params(dtype):
 class DeviceRecords:
     """Record SoA already resident in HBM: a dict of torch CUDA tensors (pos,tid,qid,cigar_off,mapq,flag,cigar)."""
 
-    def __init__(self, tensors, n_qids=0, n_tids=0, max_pos=0):
+    def __init__(self, tensors, n_qids=0, n_tids=0, max_pos=0, tid_lo=0):
+        """max_pos / tid_lo are the sort-key hints of vsv_records: positions <= max_pos, tids in [tid_lo, n_tids)."""
         self.t = tensors
-        self.max_pos = int(max_pos)
+        self.max_pos, self.tid_lo = int(max_pos), int(tid_lo)
         self.n_records = int(tensors["pos"].numel())
         self.n_ops = int(tensors["cigar"].numel())
         self.n_qids, self.n_tids = int(n_qids), int(n_tids)
@@ -42,7 +43,7 @@ class DeviceRecords:
         for name in ("pos", "tid", "qid", "cigar_off", "mapq", "flag", "cigar"):
             setattr(r, name, C.c_void_p(self.t[name].data_ptr()))
         r.on_device, r.n_qids, r.n_tids = 1, self.n_qids, self.n_tids
-        r.max_pos = self.max_pos
+        r.max_pos, r.tid_lo = self.max_pos, self.tid_lo
         return r
 
 

@@ -50,6 +50,8 @@ class RecordSoA:
             setattr(r, name, getattr(self, name).ctypes.data_as(C.c_void_p))
         r.on_device, r.n_qids, r.n_tids = 0, self.n_qids, self.n_tids
         r.max_pos = int(getattr(self, "max_pos", 0))
+        if getattr(self, "only_tid", None) is not None:      # single-chromosome table: keys need one tid bit
+            r.tid_lo, r.n_tids = int(self.only_tid), int(self.only_tid) + 1
         return r
 
     def host_light(self):
