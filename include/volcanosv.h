@@ -364,7 +364,8 @@ const char* vsv_bam_ref_name(vsv_bam* b, int i);
 int64_t vsv_bam_ref_len(vsv_bam* b, int i);
 int vsv_bam_load(vsv_bam* b, int tid, vsv_records* out);       /* tid < 0: every placed record */
 int vsv_bam_load_device(vsv_bam* b, vsv_handle* h, int tid, vsv_records* out);   /* same, through vsv_bam_parse_device: device pointers */
-const char* vsv_bam_qnames(vsv_bam* b, int64_t* len);           /* '\n'-joined names, qid order   */
+const char* vsv_bam_qnames(vsv_bam* b, int64_t* len);           /* '\n'-joined names, qid order (after vsv_bam_load_device: owned by
+                                                                    the GPU handle, valid until its next device parse)          */
 const char* vsv_bam_sa_tags(vsv_bam* b, int64_t* len);          /* '\n'-joined SA tags, record order */
 void vsv_bam_set_keep_seq(vsv_bam* b, int keep);              /* keep SEQ of the records loaded next (sig_extract INS text) */
 const uint8_t* vsv_bam_seq(vsv_bam* b, int64_t* len);          /* packed 4-bit SEQ (BAM nibbles '=ACMGRSVTWYHKDBN'), record i: (l_seq[i]+1)/2 bytes */

@@ -23,12 +23,26 @@ class LazyLines:
     def __init__(self, blob, n):
         self.blob = blob
         self.n = n
-        if n:
-            nl = np.flatnonzero(np.frombuffer(blob, dtype=np.uint8) == 10)
-            self.start = np.concatenate(([0], nl + 1)).astype(np.int64)
-            self.end = np.concatenate((nl, [len(blob)])).astype(np.int64)
-        else:
-            self.start = self.end = np.zeros(0, np.int64)
+        self._start = self._end = None
+
+    def _index(self):
+        """Line boundaries, found on the first access (a run that emits no signature never needs them)."""
+        if self._start is None:
+            if self.n:
+                nl = np.flatnonzero(np.frombuffer(self.blob, dtype=np.uint8) == 10)
+                self._start = np.concatenate(([0], nl + 1)).astype(np.int64)
+                self._end = np.concatenate((nl, [len(self.blob)])).astype(np.int64)
+            else:
+                self._start = self._end = np.zeros(0, np.int64)
+        return self._start, self._end
+
+    @property
+    def start(self):
+        return self._index()[0]
+
+    @property
+    def end(self):
+        return self._index()[1]
 
     def __len__(self):
         return self.n

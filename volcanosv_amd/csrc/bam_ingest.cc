@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <zlib.h>
 
 #include <atomic>
@@ -46,6 +47,8 @@ struct vsv_bam {
   std::vector<uint8_t> seq;              // concatenated, record i occupies (l_seq[i]+1)/2 bytes
   std::vector<std::string> sa;           // per record SA tag ("" if none)
   std::string sa_blob;
+  const char* dev_names = nullptr;     // name table of the last vsv_bam_load_device: owned by the GPU handle, not copied
+  int64_t dev_names_len = 0;
 };
 
 namespace {
@@ -256,7 +259,7 @@ int vsv_bam_load(vsv_bam* b, int tid, vsv_records* out) {
   if (!hdr_ok) return VSV_E_INVALID;
   b->pos.clear(); b->tid.clear(); b->qid.clear(); b->cigar.clear(); b->cigar_off.assign(1, 0); b->mapq.clear(); b->flag.clear();
   b->qnames.clear(); b->sa.clear(); b->l_seq.clear(); b->sam_flag.clear();
-  b->qname_blob.clear(); b->sa_blob.clear(); b->seq.clear();
+  b->qname_blob.clear(); b->sa_blob.clear(); b->seq.clear(); b->dev_names = nullptr; b->dev_names_len = 0;
   // open-addressing name table: slot -> (hash, offset into qname_blob, length, id)
   struct Slot { uint64_t h; uint32_t off, len, id; };
   std::vector<Slot> table(1u << 16, Slot{0, 0, 0, 0xFFFFFFFFu});
@@ -417,7 +420,7 @@ int vsv_bam_load(vsv_bam* b, int tid, vsv_records* out) {
 int vsv_bam_load_device(vsv_bam* b, vsv_handle* h, int tid, vsv_records* out) {
   if (!b || !h || !out) return VSV_E_INVALID;
   fseek(b->f, 0, SEEK_SET);
-  b->buf.clear(); b->rd = 0; b->eof = false; b->inflated_total = 0; b->err.clear();
+  b->buf.clear(); b->rd = 0; b->eof = false; b->inflated_total = 0; b->err.clear(); b->dev_names = nullptr; b->dev_names_len = 0;
   b->ref_names.clear(); b->ref_lens.clear();
   const int user_threads = b->n_threads;
   vsv_handle* user_gpu = b->gpu;
@@ -425,19 +428,31 @@ int vsv_bam_load_device(vsv_bam* b, vsv_handle* h, int tid, vsv_records* out) {
   const bool hdr_ok = read_header(b);
   b->n_threads = user_threads; b->gpu = user_gpu;
   if (!hdr_ok) return VSV_E_INVALID;
+  const bool timing = getenv("VSV_BAM_TIMING") != nullptr;
+  auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = now();
   const uint64_t first_record = b->inflated_total - (b->buf.size() - b->rd);
-  // the whole file in one read; the members' deflate payloads are addressed in place (a deflate stream ends itself, so the
-  // trailer and the next header that follow a payload inside [comp_off[i], comp_off[i+1]) are never consumed)
+  // the file is mapped, not copied: the member table reads one header per member and the device reader uploads each window's
+  // bytes straight from the page cache; the members' deflate payloads are addressed in place (a deflate stream ends itself,
+  // so the trailer and the next header that follow a payload inside [comp_off[i], comp_off[i+1]) are never consumed)
   fseek(b->f, 0, SEEK_END);
   const long fsize = ftell(b->f);
   fseek(b->f, 0, SEEK_SET);
   if (fsize <= 0) { b->err = "empty file"; return VSV_E_INVALID; }
-  std::vector<uint8_t> comp((size_t)fsize + 16);
-  if (fread(comp.data(), 1, (size_t)fsize, b->f) != (size_t)fsize) { b->err = "short read"; return VSV_E_INVALID; }
+  struct Mapping {
+    void* p = MAP_FAILED; size_t n = 0;
+    ~Mapping() { if (p != MAP_FAILED) munmap(p, n); }
+  } map;
+  map.n = (size_t)fsize;
+  map.p = mmap(nullptr, map.n, PROT_READ, MAP_PRIVATE, fileno(b->f), 0);
+  if (map.p == MAP_FAILED) { b->err = "cannot map the BAM file"; return VSV_E_INVALID; }
+  (void)madvise(map.p, map.n, MADV_SEQUENTIAL);
+  const uint8_t* comp = (const uint8_t*)map.p;
+  const double t1 = now();
   std::vector<uint64_t> coff;
   std::vector<uint32_t> isz;
   for (size_t o = 0; o < (size_t)fsize;) {
-    const uint8_t* hdr = comp.data() + o;
+    const uint8_t* hdr = comp + o;
     if (o + 18 > (size_t)fsize || hdr[0] != 31 || hdr[1] != 139 || hdr[2] != 8 || !(hdr[3] & 4)) { b->err = "not a BGZF block"; return VSV_E_INVALID; }
     const uint16_t xlen = hdr[10] | (hdr[11] << 8);
     int bsize = -1;
@@ -454,19 +469,26 @@ int vsv_bam_load_device(vsv_bam* b, vsv_handle* h, int tid, vsv_records* out) {
     o += (size_t)bsize + 1;
   }
   coff.push_back((uint64_t)fsize);
+  const double t2 = now();
   const char* names = nullptr; int64_t names_len = 0;
-  const int st = vsv_bam_parse_device(h, comp.data(), coff.data(), isz.data(), (int64_t)isz.size(), first_record, (int32_t)b->ref_names.size(), tid, out,
+  const int st = vsv_bam_parse_device(h, comp, coff.data(), isz.data(), (int64_t)isz.size(), first_record, (int32_t)b->ref_names.size(), tid, out,
                                       &names, &names_len, &b->dev_l_seq, &b->dev_sam_flag);
   if (st) { b->err = std::string("device BAM parse failed: ") + vsv_last_error(h); return st; }
-  b->qname_blob.assign(names ? names : "", (size_t)names_len);
+  b->qname_blob.clear();
+  b->dev_names = names; b->dev_names_len = names_len;     // valid until the handle's next device parse
   b->sa_blob.clear();
+  if (timing) fprintf(stderr, "[vsv_bam_load_device] file map %.1f ms, member table %.1f ms (%zu members), device parse %.1f ms\n", (t1 - t0) * 1e3, (t2 - t1) * 1e3, isz.size(), (now() - t2) * 1e3);
   return 0;
 }
 const uint32_t* vsv_bam_l_seq_device(vsv_bam* b) { return b ? b->dev_l_seq : nullptr; }
 const uint32_t* vsv_bam_sam_flags_device(vsv_bam* b) { return b ? b->dev_sam_flag : nullptr; }
 
 /* '\n'-joined query names in qid order / SA tags in record order of the last vsv_bam_load; *len receives the length */
-const char* vsv_bam_qnames(vsv_bam* b, int64_t* len) { if (len) *len = b ? (int64_t)b->qname_blob.size() : 0; return b ? b->qname_blob.data() : ""; }
+const char* vsv_bam_qnames(vsv_bam* b, int64_t* len) {
+  if (b && b->dev_names) { if (len) *len = b->dev_names_len; return b->dev_names; }
+  if (len) *len = b ? (int64_t)b->qname_blob.size() : 0;
+  return b ? b->qname_blob.data() : "";
+}
 const char* vsv_bam_sa_tags(vsv_bam* b, int64_t* len) { if (len) *len = b ? (int64_t)b->sa_blob.size() : 0; return b ? b->sa_blob.data() : ""; }
 void vsv_bam_set_keep_seq(vsv_bam* b, int keep) { if (b) b->keep_seq = keep != 0; }
 const uint8_t* vsv_bam_seq(vsv_bam* b, int64_t* len) { if (len) *len = b ? (int64_t)b->seq.size() : 0; return b ? b->seq.data() : nullptr; }

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "vsv_device.h"
+#include <chrono>
 
 namespace {
 
@@ -683,13 +684,15 @@ static int inflate_to_device(vsv_handle* h, const uint8_t* comp, const uint64_t*
   }
   const size_t cbytes = (size_t)(comp_off[n] - comp_off[0]), obytes = (size_t)ooff[n];
   int st;
-  if ((st = upload(h, h->z_comp, comp + comp_off[0], cbytes))) return st;
   std::vector<uint64_t> coff((size_t)n + 1);
   for (int64_t i = 0; i <= n; ++i) coff[i] = comp_off[i] - comp_off[0];
   if ((st = upload(h, h->z_coff, coff.data(), (size_t)(n + 1) * 8))) return st;
   if ((st = upload(h, h->z_ooff, ooff.data(), (size_t)(n + 1) * 8))) return st;
   if ((st = ensure(h, h->z_out, obytes + 64))) return st;
   if ((st = ensure(h, h->z_stat, (size_t)n * 4))) return st;
+  if ((st = upload(h, h->z_comp, comp + comp_off[0], cbytes))) return st;
+  // one launch for all members: a member is milliseconds of serial decode, so the launch is as long as its slowest member and
+  // batches (to overlap the upload with the decode) only add such latencies up — tried, 39 -> 71 ms on a 9 k-member file
   vsv_launch_bgzf_inflate(h->stream, (const uint8_t*)h->z_comp.p, (const uint64_t*)h->z_coff.p, (const uint64_t*)h->z_ooff.p, n,
                           (uint8_t*)h->z_out.p, (int32_t*)h->z_stat.p);
   HIPCHK(h, hipGetLastError());
@@ -754,6 +757,12 @@ int vsv_bam_parse_device(vsv_handle* h, const uint8_t* comp, const uint64_t* com
   DEVMEM(ensure(h, h->p_err, 256)); DEVMEM(ensure(h, h->p_tot, 256)); DEVMEM(ensure(h, h->o_n, 256));
   HIPCHK(h, hipMemsetAsync(h->p_err.p, 0, 4, st));
   uint64_t carry = first_record, K0 = 0, C0 = 0, N0 = 0;
+  const bool timing = getenv("VSV_BAM_TIMING") != nullptr;
+  double t_inf = 0, t_chain = 0, t_rec = 0, t_names = 0, t_qid = 0;
+  int n_windows = 0, n_rounds = 0;
+  auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double tq = now();
+  auto lap = [&](double& acc) { const double t = now(); acc += t - tq; tq = t; };
   std::vector<uint64_t> moff, spec, land, base;
   std::vector<uint32_t> cnt;
   std::vector<uint8_t> active;
@@ -764,6 +773,7 @@ int vsv_bam_parse_device(vsv_handle* h, const uint8_t* comp, const uint64_t* com
     rc = inflate_to_device(h, comp, comp_off + ma, isize + ma, mb - ma, moff);
     if (rc == VSV_E_HIP) return fail(h, VSV_E_CAPACITY, "device memory exhausted in the device reader: use the host reader");
     if (rc) return rc;
+    lap(t_inf); ++n_windows;
     const uint64_t total = moff[mb - ma], first_rel = carry - ginf[ma];
     const uint8_t* s = (const uint8_t*)h->z_out.p;
     const uint64_t* d_moff = (const uint64_t*)h->z_ooff.p;
@@ -795,8 +805,10 @@ int vsv_bam_parse_device(vsv_handle* h, const uint8_t* comp, const uint64_t* com
         expect = land[m];
         if (stopped) break;
       }
+      ++n_rounds;
       if (!patched) { next_rel = expect; break; }
     }
+    lap(t_chain);
     if (last_window && next_rel != total) return fail(h, VSV_E_INVALID, "BAM stream ends inside a record");
     if (n_w == 0 && !last_window) return fail(h, VSV_E_CAPACITY, "a record is larger than the device reader's window: use the host reader");
     if (K0 + n_w > 0x7FFFFFF0ull) return fail(h, VSV_E_CAPACITY, "too many records for the device reader: use the host reader");
@@ -839,6 +851,7 @@ int vsv_bam_parse_device(vsv_handle* h, const uint8_t* comp, const uint64_t* com
                         (const uint64_t*)h->p_recoff.p, (int32_t*)h->o_pos.p, (int32_t*)h->o_tid.p, (uint8_t*)h->o_mapq.p, (uint8_t*)h->o_flag.p,
                         (uint32_t*)h->o_lseq.p, (uint32_t*)h->o_sflag.p, (uint64_t*)h->o_cigoff.p, (uint32_t*)h->o_cigar.p, (uint64_t*)h->o_hash.p,
                         (uint64_t*)h->o_recoff.p, K0, C0);
+        lap(t_rec);
         // names of the kept records into the compact store (the inflated window is gone when the query ids are assigned)
         vsv_bamdev_win_name_lens(st, s, (const uint64_t*)h->o_recoff.p, (int64_t)nk, (uint32_t*)h->o_nlen.p);
         vsv_scan_u32_exclusive(st, (const uint32_t*)h->o_nlen.p, (int)nk, (uint32_t*)h->o_noff.p, (uint32_t*)h->p_sums.p);
@@ -852,6 +865,7 @@ int vsv_bam_parse_device(vsv_handle* h, const uint8_t* comp, const uint64_t* com
                                   (uint64_t*)h->o_nmoff.p, (uint32_t*)h->o_nmlen.p);
         HIPCHK(h, hipStreamSynchronize(st));
         K0 += nk; C0 += ops_w; N0 += nb_w;
+        lap(t_names);
       }
     }
     if (next_rel == first_rel && n_w == 0 && last_window) break;
@@ -900,6 +914,10 @@ int vsv_bam_parse_device(vsv_handle* h, const uint8_t* comp, const uint64_t* com
   if (blob_bytes) HIPCHK(h, hipMemcpyAsync(&h->names_blob[0], h->o_blob.p, blob_bytes, hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipStreamSynchronize(st));
   if (blob_bytes) h->names_blob.pop_back();                          // the separator after the last name
+  lap(t_qid);
+  if (timing)
+    fprintf(stderr, "[vsv_bam_parse_device] %d windows: upload+inflate %.1f ms, record chain %.1f ms (%d rounds), fields+emit %.1f ms, names %.1f ms, query ids + name table %.1f ms\n",
+            n_windows, t_inf * 1e3, t_chain * 1e3, n_rounds, t_rec * 1e3, t_names * 1e3, t_qid * 1e3);
 #undef DEVMEM
   out->pos = (const int32_t*)h->o_pos.p; out->tid = (const int32_t*)h->o_tid.p; out->qid = (const uint32_t*)h->o_qid.p;
   out->cigar_off = (const uint64_t*)h->o_cigoff.p; out->mapq = (const uint8_t*)h->o_mapq.p; out->flag = (const uint8_t*)h->o_flag.p;
