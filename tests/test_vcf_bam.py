@@ -120,6 +120,27 @@ def test_cli_plumbing_config1(tmp_path, name, style):
         assert digest(lines[35:]) == doc["expected"]["per_chrom"][chrom]["vcf"]
 
 
+def test_reads_signature_lines_column_wise_equal_row_wise():
+    """sigtable.reads_sig_lines (whole table, column by column) writes the text of the per-row field lists (RS:251-265)."""
+    from volcanosv_amd import sigtable, synth
+    from volcanosv_amd.abi import DTYPE_READS, M_DEL, M_SPLIT, SIG_DTYPE
+    t, nq, _ = synth.generate(3000, "hifi", seed=3)
+    soa = synth.to_soa(t, nq)
+    rng = np.random.default_rng(0)
+    n = 5000
+    tab = np.zeros(n, SIG_DTYPE)
+    tab["pos"] = np.sort(rng.integers(-50, 1 << 27, n)); tab["svlen"] = rng.integers(30, 50000, n)
+    tab["rec"] = rng.integers(0, soa.n_records, n); tab["rec2"] = rng.integers(0, soa.n_records, n)
+    tab["meta"] = rng.integers(0, 2, n) * M_DEL | (rng.random(n) < 0.3) * M_SPLIT
+    tab["q_start"] = rng.integers(0, 20000, n); tab["q_end"] = tab["q_start"] + rng.integers(1, 9000, n)
+    tab["tid"] = rng.integers(0, 3, n)
+    for names in (None, ["chr7", "chrX", "scaffold_12"]):
+        soa.tid_names = names
+        want = ["\t".join(str(x) for x in sigtable.sig_fields(soa, s, DTYPE_READS)) + "\n" for s in tab]
+        assert sigtable.reads_sig_lines(soa, tab) == want
+    assert sigtable.reads_sig_lines(soa, tab[:0]) == []
+
+
 @pytest.mark.gpu
 def test_cli_reads_signature(tmp_path):
     import subprocess

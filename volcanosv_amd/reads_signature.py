@@ -8,7 +8,8 @@ from .engine import Engine, default_params
 
 
 def run(input_path, output_dir, chr_number, device=0, engine=None, params=None, device_ingest=True):
-    """Writes <output_dir>/reads_signature/chr<N>_reads_sig.txt (RS:251-265): tab-joined str() fields, sorted by pos.
+    """Writes <output_dir>/reads_signature/chr<N>_reads_sig.txt (RS:251-265): tab-joined str() fields, sorted by pos; returns
+    (path, number of lines).
     device_ingest: BAM inflated and parsed on the GPU (volcanosv_amd.bam.BamFile.fetch_device); False = host reader."""
     chrom = "chr%d" % chr_number
     out_dir = os.path.join(output_dir, "reads_signature")
@@ -28,11 +29,10 @@ def run(input_path, output_dir, chr_number, device=0, engine=None, params=None, 
             soa = bam.fetch_soa(chrom)
     if not device_ingest:
         eng.run(soa, p)
-    rows = [sigtable.sig_fields(soa, s, DTYPE_READS) for s in eng.table("reads")]
+    lines = sigtable.reads_sig_lines(soa, eng.table("reads"))
     path = os.path.join(out_dir, chrom + "_reads_sig.txt")
     with open(path, "w") as f:
-        for r in rows:
-            f.write("\t".join(str(x) for x in r) + "\n")
+        f.writelines(lines)
     if engine is None:
         eng.close()
-    return path, rows
+    return path, len(lines)

@@ -37,6 +37,39 @@ def sig_fields(soa, s, dtype=None):
     return [chrom, typ, int(s["pos"]), int(s["svlen"]), qname, int(s["q_start"]), int(s["q_end"]), strand, src, mapq]
 
 
+def reads_sig_lines(soa, table):
+    """The text lines of chr<N>_reads_sig.txt (RS:251-265: tab-joined str() of the READS field lists) for a whole table,
+    built column by column: the same text as '\\t'.join(str(x) for x in sig_fields(soa, s, DTYPE_READS)) per row, at
+    about a sixth of the cost (the table of one chromosome of a 30x read set has 10^5-10^6 rows)."""
+    if len(table) == 0:
+        return []
+    import numpy as np
+    rec = table["rec"].astype(np.int64)
+    qid = np.asarray(soa.qid)[rec].tolist()
+    qn = soa.qnames
+    names = [qn[q] for q in qid] if qn is not None else ["q%d" % q for q in qid]
+    rev = (np.asarray(soa.flag)[rec] & 1).tolist()                      # VSV_F_REVERSE
+    tids = table["tid"].tolist()
+    if soa.tid_names is not None:
+        tn = soa.tid_names
+        chrom = [tn[t] for t in tids]
+    else:
+        chrom = ["chr%d" % (t + 1) for t in tids]
+    meta = table["meta"]
+    is_del = ((meta & M_DEL) != 0).tolist()
+    is_split = ((meta & M_SPLIT) != 0).tolist()
+    pos, svlen, qs, qe = table["pos"].tolist(), table["svlen"].tolist(), table["q_start"].tolist(), table["q_end"].tolist()
+    out = []
+    for i in range(len(pos)):
+        strand = "-" if rev[i] else "+"
+        if is_split[i]:       # the reference's own spellings (RS:191, RS:194)
+            out.append("%s\t%s\t%d\t%d\t%s\t%d\t%d\t%s\t%s\n" % (chrom[i], "DEL" if is_del[i] else "INS", pos[i], svlen[i], names[i], qs[i], qe[i],
+                                                             strand, "split-alignemnt" if is_del[i] else "split_alignment"))
+        else:
+            out.append("%s\t%s\t%d\t%d\t%s\t%d\t%s\tcigar\n" % (chrom[i], "DEL" if is_del[i] else "INS", pos[i], svlen[i], names[i], qs[i], strand))
+    return out
+
+
 def call_fields(soa, c, merged):
     """One vsv_call row -> the 15-field paired signature of pair_sig (H:571-592)."""
     base = sig_fields(soa, c["sig"])
