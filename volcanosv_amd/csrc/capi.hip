@@ -40,6 +40,7 @@ struct vsv_handle {
   int64_t cutesv_rows = -1;   // rows of the last vsv_cutesv_split (c2 buffer)
   // workspace
   DevBuf part_rb, part_count, part_off, scan_tmp;
+  DevBuf gflag;           // CLR: flag bytes with the haplotype bits cleared where the gate fails (input of the scan)
   DevBuf pool, pool_key, raw0, s1in, s1s, c1, s2s, c2, merged, calls_tmp, calls, reads;
   DevBuf tab, blk_cnt, blk_off, ckey, crec, okey, oval;
   DevBuf key, idx, cl, key2, idx2, key_alt, val_alt, hist;
@@ -208,7 +209,14 @@ int enq_scan(vsv_handle* h) {
   { int rs = reset_run_state(h); if (rs) return rs; }
   h->cutesv_rows = -1;   // the split-candidate table shares a buffer with the merge stage
   const int n_parts = vsv_cigar_parts(h->rv.n_ops, OPS_PER_PART);
-  vsv_launch_cigar_scan(st, h->rv, h->prm, (uint32_t*)h->part_rb.p, n_parts, OPS_PER_PART, (vsv_sig*)h->pool.p,
+  RecView srv = h->rv;
+  if (h->prm.dtype == VSV_DTYPE_CLR && srv.n_records > 0) {   // the scan sees haplotype tags only where the CLR gate passes
+    int gs = ensure(h, h->gflag, (size_t)srv.n_records + 16);
+    if (gs) return gs;
+    vsv_launch_clr_gate(st, h->rv, (uint8_t*)h->gflag.p, dctr(h));
+    srv.flag = (const uint8_t*)h->gflag.p;
+  }
+  vsv_launch_cigar_scan(st, srv, h->prm, (uint32_t*)h->part_rb.p, n_parts, OPS_PER_PART, (vsv_sig*)h->pool.p,
                         (uint64_t*)h->pool_key.p, (uint32_t)h->cap_sigs, (uint32_t*)h->part_count.p, (uint32_t*)h->part_off.p,
                         (uint32_t*)h->scan_tmp.p, (vsv_sig*)h->s1in.p, dctr(h), (uint32_t*)h->shard_cnt.p, h->ev0, h->ev1);
   h->have_scan_ev = n_parts > 0;
@@ -265,7 +273,7 @@ int enq_merge(vsv_handle* h) {
 int enq_pair(vsv_handle* h) {
   hipStream_t st = h->stream;
   Counters* c = dctr(h);
-  vsv_launch_pair(st, (vsv_sig*)h->merged.p, h->sorted_key, &c->n_alive3, h->prm.pair_shift, (vsv_call*)h->calls_tmp.p, (vsv_call*)h->calls.p,
+  vsv_launch_pair(st, (vsv_sig*)h->merged.p, h->sorted_key, &c->n_alive3, h->prm.pair_shift, h->prm.pair_window, (vsv_call*)h->calls_tmp.p, (vsv_call*)h->calls.p,
                   &c->n_calls, stage_bufs(h), (uint64_t*)h->key2.p, (uint32_t*)h->idx2.p, sort_work(h), pos_bits(h), key_bits(h), h->cap_sigs, dctr(h));
   HIPCHK(h, hipGetLastError());
   h->stage_done = 5;
@@ -381,7 +389,7 @@ void vsv_destroy(vsv_handle* h) {
                     &h->g_re, &h->g_rev, &h->g_hap, &h->g_len, &h->g_rank, &h->j_cpos, &h->j_clen, &h->j_spos, &h->j_slen, &h->j_send, &h->j_out, &h->j_err, &h->z_comp, &h->z_coff, &h->z_ooff, &h->z_out, &h->z_stat, &h->p_spec, &h->p_cnt, &h->p_land, &h->p_base, &h->p_recoff, &h->p_pos, &h->p_tid,
                     &h->p_mapq, &h->p_flag, &h->p_lseq, &h->p_sflag, &h->p_ncig, &h->p_cgsrc, &h->p_hash, &h->p_keep, &h->p_kidx, &h->p_cigoff, &h->p_sums,
                     &h->p_tot, &h->p_err, &h->o_pos, &h->o_tid, &h->o_qid, &h->o_cigoff, &h->o_mapq, &h->o_flag, &h->o_cigar, &h->o_lseq, &h->o_sflag,
-                    &h->o_hash, &h->o_recoff, &h->o_first, &h->o_rank, &h->o_nlen, &h->o_noff, &h->o_blob, &h->o_n, &h->o_names, &h->o_nmoff, &h->o_nmlen};
+                    &h->o_hash, &h->o_recoff, &h->o_first, &h->o_rank, &h->o_nlen, &h->o_noff, &h->o_blob, &h->o_n, &h->o_names, &h->o_nmoff, &h->o_nmlen, &h->gflag};
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
   if (h->pinned) hipHostFree(h->pinned);
   if (h->ev0) hipEventDestroy(h->ev0);
@@ -439,7 +447,7 @@ int vsv_merge_sources(vsv_handle* h, const vsv_params* p) {
 
 int vsv_pair_haplotypes(vsv_handle* h, const vsv_params* p) {
   if (!h || h->stage_done < 4) return fail(h, VSV_E_INVALID, "vsv_merge_sources must run first");
-  if (p) h->prm.pair_shift = p->pair_shift;
+  if (p) { h->prm.pair_shift = p->pair_shift; h->prm.pair_window = p->pair_window; }
   int st = enq_pair(h);
   if (st) return st;
   return finish(h);

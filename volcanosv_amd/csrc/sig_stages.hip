@@ -1,6 +1,6 @@
 // sig_stages.hip — everything downstream of the CIGAR scan, on <= a few % of the input bytes:
 //   fold_kernel        cluster_ins_one_read / cluster_del_one_read   (Hifi.py:91-161)
-//   clr_gate_kernel    ins_pct / var_dist gate                        (CLR.py:53-70, 425-427)
+//   clr_gate_records   ins_pct / var_dist gate                        (CLR.py:53-70, 425-427)
 //   split_*            extract_sig_from_split_reads + extract_sig_from_split
 //                      (Hifi.py:307-371, 421-457; ONT.py:307-382; CLR.py:328-402; reads.py:147-237)
 //   cluster_kernel     cluster_del / cluster_ins seeded greedy        (Hifi.py:196-288)
@@ -107,27 +107,32 @@ __global__ __launch_bounds__(256) void combine_kernel(vsv_sig* __restrict__ s, c
   }
 }
 
-// ---- CLR gate: one wave per (record, hap) group head; marks the group dead if the gate fails ---------
-__global__ __launch_bounds__(256) void clr_gate_kernel(vsv_sig* __restrict__ s, RecView rv, Counters* ctr) {
-  const uint32_t n = ctr->n_raw;
+// ---- CLR gate: one wave per haplotype-tagged record, BEFORE the scan ----------------------------------
+// C:422-427 computes ins_pct / var_dist for every record whose name carries the haplotype tag (whatever its mapq: a record
+// without M ops raises ZeroDivisionError there) and only walks the CIGAR - and asserts reference_end - when the gate passes.
+// The scan therefore reads a gated copy of the flag bytes: haplotype bits cleared where the gate fails. The split stage
+// (C:453-457) is not gated and keeps the caller's flags.
+__global__ __launch_bounds__(256) void clr_gate_records(RecView rv, uint8_t* __restrict__ gflag, Counters* ctr) {
   const int lane = threadIdx.x & 63;
-  const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
-  for (uint32_t i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < n; i += nwaves) {
-    const uint32_t rec = s[i].rec;
-    if (i > 0 && s[i - 1].rec == rec) continue;
-    const uint64_t a = rv.cigar_off[rec], b = rv.cigar_off[rec + 1];
-    int64_t ins = 0, m = 0, nm = 0;
-    for (uint64_t k = a + lane; k < b; k += 64) {
-      const uint32_t w = rv.cigar[k], op = w & 15u;
-      if (op == 0) { m += w >> 4; nm++; } else if (op == 1) ins += w >> 4;
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t rec = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); rec < rv.n_records; rec += nwaves) {
+    const uint8_t fl = rv.flag[rec];
+    uint8_t out = fl;
+    if (fl & (VSV_F_HP1 | VSV_F_HP2)) {
+      const uint64_t a = rv.cigar_off[rec], b = rv.cigar_off[rec + 1];
+      int64_t ins = 0, m = 0, nm = 0;
+      for (uint64_t k = a + lane; k < b; k += 64) {
+        const uint32_t w = rv.cigar[k], op = w & 15u;
+        if (op == 0) { m += w >> 4; nm++; } else if (op == 1) ins += w >> 4;
+      }
+      ins = wave_sum64(ins); m = wave_sum64(m); nm = wave_sum64(nm);
+      bool pass;
+      if (b <= a) pass = true;                                            // empty CIGAR: the scan reports it
+      else if (m + ins == 0 || nm == 0) { if (lane == 0) atomicOr(&ctr->err, ERRB_ZERODIV); pass = false; }
+      else pass = (100 * ins <= 13 * (m + ins)) || (m >= 200 * nm);       // CLR.py:61, 70, 427 in exact integers
+      if (!pass) out = fl & (uint8_t)~(VSV_F_HP1 | VSV_F_HP2);
     }
-    ins = wave_sum64(ins); m = wave_sum64(m); nm = wave_sum64(nm);
-    bool pass;
-    if (m + ins == 0 || nm == 0) { if (lane == 0) atomicOr(&ctr->err, ERRB_ZERODIV); pass = false; }
-    else pass = (100 * ins <= 13 * (m + ins)) || (m >= 200 * nm);       // CLR.py:61, 70, 427 in exact integers
-    if (!pass && lane == 0) {
-      for (uint32_t k = i; k < n && s[k].rec == rec; ++k) s[k].meta |= VSV_M_DEAD;
-    }
+    if (lane == 0) gflag[rec] = out;
   }
 }
 
@@ -595,15 +600,16 @@ __global__ __launch_bounds__(256) void cluster_long_kernel(const vsv_sig* __rest
 // merged table m sorted by (tid, hap, pos), keys = stage-3 keys. One lane owns a stretch of hp1 rows whose
 // consecutive positions differ by <= 2*pair_shift (candidate windows of different stretches are disjoint,
 // so stretches are independent); inside it the greedy of Hifi.py:552-569 runs in hp1 order: first unpaired
-// hp2 row of the same type within pair_shift that matches. The reference's scan from j=0 with a break
-// at dist > pair_window visits the same candidates in the same order.
+// hp2 row of the same type within pair_shift that matches. The reference scans from j=0 and breaks at
+// pos2 - pos1 > pair_window (H:557-559), so a mate lies at most `right` = min(pair_shift, pair_window) to the right and at
+// most pair_shift to the left: the same candidates in the same order.
 __device__ __forceinline__ uint32_t lower_bound_key(const uint64_t* __restrict__ key, uint32_t n, uint64_t target) {
   uint32_t lo = 0, hi = n;
   while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (key[mid] >= target) hi = mid; else lo = mid + 1; }
   return lo;
 }
 __global__ __launch_bounds__(256) void pair_kernel(const vsv_sig* __restrict__ m, const uint64_t* __restrict__ key,
-                                                   const uint32_t* __restrict__ d_n, int pair_shift, int pb,
+                                                   const uint32_t* __restrict__ d_n, int pair_shift, int right, int pb,
                                                    int32_t* __restrict__ st2, vsv_call* __restrict__ out,
                                                    uint64_t* __restrict__ long_list, uint32_t* __restrict__ n_long) {
   const uint32_t n = *d_n;
@@ -631,7 +637,7 @@ __global__ __launch_bounds__(256) void pair_kernel(const vsv_sig* __restrict__ m
       int32_t mate = -1;
       for (uint32_t j = jlo; j < b1; ++j) {
         const vsv_sig s2 = m[j];
-        if ((int64_t)s2.pos - s1.pos > pair_shift) break;
+        if ((int64_t)s2.pos - s1.pos > right) break;
         if (((s1.meta ^ s2.meta) & VSV_M_DEL) == 0 && st2[j] == -1 && vsv_match(s1, s2, pair_shift)) {
           mate = (int32_t)j; st2[j] = (int32_t)a; break;                 // Hifi.py:560-569
         }
@@ -647,7 +653,7 @@ __global__ __launch_bounds__(256) void pair_kernel(const vsv_sig* __restrict__ m
 // One wave per long hp1 stretch: hp1 rows stay sequential (first come, first served), the candidate window of a row is
 // scanned 64 hp2 rows at a time and the first match is the lowest set ballot bit.
 __global__ __launch_bounds__(256) void pair_long_kernel(const vsv_sig* __restrict__ m, const uint64_t* __restrict__ key,
-                                                        const uint32_t* __restrict__ d_n, int pair_shift, int pb,
+                                                        const uint32_t* __restrict__ d_n, int pair_shift, int right, int pb,
                                                         int32_t* __restrict__ st2, vsv_call* __restrict__ out,
                                                         const uint64_t* __restrict__ long_list, const uint32_t* __restrict__ n_long) {
   const uint32_t n = *d_n;
@@ -670,7 +676,7 @@ __global__ __launch_bounds__(256) void pair_long_kernel(const vsv_sig* __restric
         const bool valid = j < b1;
         vsv_sig s2 = s1;
         if (valid) s2 = m[j];
-        const bool inwin = valid && (int64_t)s2.pos - s1.pos <= pair_shift;
+        const bool inwin = valid && (int64_t)s2.pos - s1.pos <= right;
         if (__ballot(inwin) == 0) break;
         const bool ok = inwin && ((s1.meta ^ s2.meta) & VSV_M_DEL) == 0 && ld_i32(&st2[j]) == -1 && vsv_match(s1, s2, pair_shift);
         const uint64_t bal = __ballot(ok);
@@ -717,10 +723,12 @@ constexpr int LONG_GRID = 2048;   // wave-per-run kernels: enough waves to fill 
 }  // namespace
 
 // ======================================= host-side launchers ==========================================
+void vsv_launch_clr_gate(hipStream_t st, const RecView& rv, uint8_t* gflag, Counters* ctr) {
+  if (rv.n_records > 0) clr_gate_records<<<2048, 256, 0, st>>>(rv, gflag, ctr);
+}
+
 void vsv_launch_fold(hipStream_t st, vsv_sig* raw, vsv_sig* raw_copy, const RecView& rv, const vsv_params& p, Counters* ctr) {
   const int dtype = p.dtype;
-  // the reference applies the CLR gate before extraction (CLR.py:425-427), so gated rows are not part of T_RAW
-  if (dtype == VSV_DTYPE_CLR) clr_gate_kernel<<<EW_GRID, 256, 0, st>>>(raw, rv, ctr);
   copy_rows<vsv_sig><<<EW_GRID, 256, 0, st>>>(raw, &ctr->n_raw, raw_copy);
   if (dtype == VSV_DTYPE_HIFI || dtype == VSV_DTYPE_ONT || dtype == VSV_DTYPE_CLR) fold_kernel<<<EW_GRID, 256, 0, st>>>(raw, ctr);
   if (dtype == VSV_DTYPE_CUTESV) combine_kernel<<<EW_GRID, 256, 0, st>>>(raw, ctr, p.merge_ins_threshold, p.merge_del_threshold);
@@ -781,12 +789,13 @@ void vsv_launch_cluster(hipStream_t st, const vsv_sig* sorted, const uint64_t* s
   cluster_long_kernel<<<LONG_GRID, 256, 0, st>>>(sorted, max_shift, b.cl, out, long_list, &ctr->n_long);
 }
 
-void vsv_launch_pair(hipStream_t st, const vsv_sig* merged, const uint64_t* merged_key, const uint32_t* d_alive3, int pair_shift,
+void vsv_launch_pair(hipStream_t st, const vsv_sig* merged, const uint64_t* merged_key, const uint32_t* d_alive3, int pair_shift, int pair_window,
                      vsv_call* calls_tmp, vsv_call* calls, uint32_t* d_ncalls, const StageBufs& b, uint64_t* key2, uint32_t* idx2,
                      const SortWork& sw, int pb, int nbits, int64_t cap, Counters* ctr) {
   fill_i32<<<EW_GRID, 256, 0, st>>>(b.cl, -1, d_alive3);   // (n_long was cleared by the stage-3 gather)
-  pair_kernel<<<EW_GRID, 256, 0, st>>>(merged, merged_key, d_alive3, pair_shift, pb, b.cl, calls_tmp, key2, &ctr->n_long);
-  pair_long_kernel<<<LONG_GRID, 256, 0, st>>>(merged, merged_key, d_alive3, pair_shift, pb, b.cl, calls_tmp, key2, &ctr->n_long);
+  const int right = pair_shift < pair_window ? pair_shift : pair_window;
+  pair_kernel<<<EW_GRID, 256, 0, st>>>(merged, merged_key, d_alive3, pair_shift, right, pb, b.cl, calls_tmp, key2, &ctr->n_long);
+  pair_long_kernel<<<LONG_GRID, 256, 0, st>>>(merged, merged_key, d_alive3, pair_shift, right, pb, b.cl, calls_tmp, key2, &ctr->n_long);
   pair_finish<<<EW_GRID, 256, 0, st>>>(merged, d_alive3, b.cl, calls_tmp);
   build_call_keys<<<EW_GRID, 256, 0, st>>>(calls_tmp, d_alive3, pb, b.tid_lo, key2, idx2);
   const SortResult r = vsv_radix_sort_pairs(st, key2, idx2, sw.key_alt, sw.val_alt, d_alive3, cap, nbits, sw);
