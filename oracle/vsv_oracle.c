@@ -527,7 +527,7 @@ int orc_run(const vsv_records* r, const vsv_params* p, int literal, orc_out* o) 
       if (contig) {
         st = split_pass(r, lo, hi, p, 0, VSV_F_HP1, p->min_split_mapq, &spl);
         if (st == 0) st = split_pass(r, lo, hi, p, VSV_M_HP2, VSV_F_HP2, p->min_split_mapq, &spl);
-      } else st = split_pass(r, lo, hi, p, 0, 0, 0, &spl);      /* RS:235 min_mapq=0, no filter */
+      } else st = split_pass(r, lo, hi, p, 0, 0, p->min_split_mapq, &spl);   /* RS:199-223 collects every record; RS:235 min_mapq (0) only enters the pair test */
       lo = hi;
     }
   }

@@ -61,3 +61,104 @@ def compare_contig_tables(doc, soa, tabs):
             assert rows(soa, tabs["merged"], where=sel(t, hp)) == pc["merged_hp%d" % hp], (chrom, hp, "merged")
         got = [sigtable.call_fields(soa, c, tabs["merged"]) for c in tabs["calls"] if int(c["sig"]["tid"]) == t]
         assert got == pc["paired"], (chrom, "paired")
+
+
+# ---- randomized small inputs (tests/test_gpu_parity.py, tools/fuzz_case.py) ---------------------------------------------------
+def _fuzz_flags_mapq(soa, rng, strands=True):
+    from volcanosv_amd.abi import F_HP1, F_HP2
+    k = soa.n_records
+    soa.mapq = np.where(rng.random(k) < 0.2, rng.integers(0, 61, k), soa.mapq).astype(np.uint8)
+    fl = soa.flag.copy()
+    flip = rng.random(k) < 0.15
+    fl[flip] = (fl[flip] & ~np.uint8(F_HP1 | F_HP2)) | rng.choice(np.array([0, F_HP1, F_HP2, F_HP1 | F_HP2], np.uint8), int(flip.sum()))
+    if strands:
+        fl ^= (rng.random(k) < 0.1).astype(np.uint8)
+    soa.flag = fl
+
+
+def fuzz_case_basic(case, rng):
+    """1-400 records on a 60-300 kb contig (signatures collide, cluster and pair all the time), random haplotype tags / mapq /
+    strands / data type / thresholds, now and then an =/X/N op. Returns (soa, dtype, params)."""
+    from volcanosv_amd import synth
+    from volcanosv_amd.abi import DTYPE_CLR, DTYPE_HIFI, DTYPE_ONT, DTYPE_READS
+    from volcanosv_amd.engine import default_params
+    shape = ("hifi", "ont")[int(rng.integers(0, 2))]
+    n = int(rng.integers(1, 401)) if shape == "hifi" else int(rng.integers(1, 81))
+    t, nq, _ = synth.generate(n, shape, seed=5000 + case, chrom_len=int(rng.integers(60_000, 300_000)) + 40_000,
+                              events_per_record=float(rng.choice([0.0, 0.05, 0.5, 2.0])), site_step=int(rng.choice([200, 1000, 5000])))
+    soa = synth.to_soa(t, nq)
+    _fuzz_flags_mapq(soa, rng)
+    if rng.random() < 0.2 and soa.n_ops:                              # one M becomes '=', 'X' or 'N'
+        cig = soa.cigar.copy()
+        ms = np.flatnonzero((cig & 15) == 0)
+        if len(ms):
+            j = int(ms[rng.integers(0, len(ms))])
+            cig[j] = (cig[j] & ~np.uint32(15)) | np.uint32(rng.choice([7, 8, 3]))
+            soa.cigar = cig
+    dtype = (DTYPE_HIFI, DTYPE_ONT, DTYPE_CLR, DTYPE_READS)[int(rng.integers(0, 4))]
+    p = default_params(dtype)
+    p.min_svlen = int(rng.choice([30, 30, 10, 50]))
+    p.cluster_shift = int(rng.choice([100, 100, 10, 1000]))
+    p.pair_shift = int(rng.choice([200, 200, 0, 2000]))
+    p.min_cigar_mapq = int(rng.choice([50, 50, 0, 60]))
+    return soa, dtype, p
+
+
+def fuzz_case_defects(case, rng):
+    """1-3 chromosomes, every threshold of vsv_params varied, and at most one planted defect: an =/X/N op (reference_end assert,
+    H:396), a record without M ops (CLR: ZeroDivisionError, C:61/70), a clipped end that grows (split mates of unequal read
+    length, H:331). Returns (soa, dtype, params)."""
+    from volcanosv_amd import synth
+    from volcanosv_amd.abi import DTYPE_CLR, DTYPE_HIFI, DTYPE_ONT, DTYPE_READS
+    from volcanosv_amd.engine import default_params
+    parts = []
+    n_t = int(rng.choice([1, 1, 2, 3]))
+    shape = ("hifi", "ont")[int(rng.integers(0, 2))]
+    for tid in range(n_t):
+        n = int(rng.integers(1, 201)) if shape == "hifi" else int(rng.integers(1, 41))
+        t, nq, _ = synth.generate(n, shape, seed=9000 + 7 * case + tid, tid=tid, chrom_len=int(rng.integers(60_000, 200_000)) + 40_000,
+                                  events_per_record=float(rng.choice([0.05, 0.5, 2.0])), site_step=int(rng.choice([200, 1000])))
+        parts.append((t, nq))
+    t, nq = synth.concat(parts) if n_t > 1 else parts[0]
+    soa = synth.to_soa(t, nq)
+    k = soa.n_records
+    _fuzz_flags_mapq(soa, rng, strands=False)
+    defect = rng.choice(["none", "none", "none", "op", "no_m", "readlen", "clip"])
+    cig = soa.cigar.copy()
+    if defect == "op":
+        ms = np.flatnonzero((cig & 15) == 0)
+        if len(ms):
+            j = int(ms[rng.integers(0, len(ms))])
+            cig[j] = (cig[j] & ~np.uint32(15)) | np.uint32(rng.choice([7, 8, 3]))
+    elif defect == "no_m":
+        r = int(rng.integers(0, k))
+        seg = cig[int(soa.cigar_off[r]):int(soa.cigar_off[r + 1])]
+        seg[(seg & 15) == 0] |= np.uint32(7)
+    elif defect in ("readlen", "clip"):
+        sc = np.flatnonzero(((cig & 15) == 4) | ((cig & 15) == 5))
+        if len(sc):
+            j = int(sc[rng.integers(0, len(sc))])
+            cig[j] += np.uint32(16 * int(rng.integers(1, 50)))
+    soa.cigar = cig
+    dtype = (DTYPE_HIFI, DTYPE_ONT, DTYPE_CLR, DTYPE_READS)[int(rng.integers(0, 4))]
+    p = default_params(dtype)
+    p.min_svlen = int(rng.choice([30, 30, 10, 50]))
+    p.cluster_shift = int(rng.choice([100, 100, 10, 1000]))
+    p.pair_shift = int(rng.choice([200, 200, 0, 2000]))
+    p.min_cigar_mapq = int(rng.choice([50, 50, 0, 60]))
+    p.min_split_mapq = int(rng.choice([p.min_split_mapq, 0, 60]))
+    p.max_split_svlen = int(rng.choice([50000, 50000, 500]))
+    p.enable_split = int(rng.random() < 0.9)
+    p.pair_window = int(rng.choice([1000, 1000, 100, 5000]))
+    return soa, dtype, p
+
+
+FUZZ = {"basic": (fuzz_case_basic, 20250403, 240), "defects": (fuzz_case_defects, 77, 300)}
+
+
+def fuzz_cases(kind, upto=None):
+    """Yields (case, soa, dtype, params) for the named family, in the fixed order the tests use."""
+    make, seed, count = FUZZ[kind]
+    rng = np.random.default_rng(seed)
+    for case in range(count if upto is None else upto + 1):
+        yield (case,) + make(case, rng)

@@ -161,57 +161,35 @@ def test_tid_hint_trims_keys_without_changing_results(eng):
     assert_tables_equal(eng.tables(DTYPE_HIFI), base, list(base.keys()))
 
 
-def test_random_small_inputs_statuses_and_tables(eng):
-    """240 small random inputs (1-400 records on a 60-300 kb contig, so signatures collide, cluster and pair all the time) with
-    random haplotype tags / mapq / strands, random data types and thresholds, and now and then an =/X/N op that makes the contig
-    path raise like the reference's assert (H:396): the status equals the oracle's, and so does every table."""
-    from volcanosv_amd import synth
-    from volcanosv_amd.engine import default_params
-    rng = np.random.default_rng(20250403)
+@pytest.mark.parametrize("kind,min_ok,min_err", [("basic", 150, 5), ("defects", 150, 40)])
+def test_random_small_inputs_statuses_and_tables(eng, kind, min_ok, min_err):
+    """Hundreds of small random inputs (helpers.fuzz_case_basic / fuzz_case_defects: dense contigs where signatures collide,
+    cluster and pair all the time; random tags, mapq, strands, data types, every threshold of vsv_params; planted defects that
+    make the reference raise): the status equals the oracle's, and so does every table. `tools/fuzz_case.py KIND K` replays a case."""
+    from helpers import fuzz_cases
     n_err = n_ok = 0
-    for case in range(240):
-        shape = ("hifi", "ont")[int(rng.integers(0, 2))]
-        n = int(rng.integers(1, 401)) if shape == "hifi" else int(rng.integers(1, 81))
-        t, nq, _ = synth.generate(n, shape, seed=5000 + case, chrom_len=int(rng.integers(60_000, 300_000)) + 40_000,
-                                  events_per_record=float(rng.choice([0.0, 0.05, 0.5, 2.0])), site_step=int(rng.choice([200, 1000, 5000])))
-        soa = synth.to_soa(t, nq)
-        k = soa.n_records
-        soa.mapq = np.where(rng.random(k) < 0.2, rng.integers(0, 61, k), soa.mapq).astype(np.uint8)
-        fl = soa.flag.copy()
-        flip = rng.random(k) < 0.15
-        fl[flip] = (fl[flip] & ~np.uint8(F_HP1 | F_HP2)) | rng.choice(np.array([0, F_HP1, F_HP2, F_HP1 | F_HP2], np.uint8), int(flip.sum()))
-        fl ^= (rng.random(k) < 0.1).astype(np.uint8)                      # strand
-        soa.flag = fl
-        if rng.random() < 0.2 and soa.n_ops:                              # one M becomes '=', 'X' or 'N'
-            cig = soa.cigar.copy()
-            ms = np.flatnonzero((cig & 15) == 0)
-            if len(ms):
-                j = int(ms[rng.integers(0, len(ms))])
-                cig[j] = (cig[j] & ~np.uint32(15)) | np.uint32(rng.choice([7, 8, 3]))
-                soa.cigar = cig
-        dtype = (DTYPE_HIFI, DTYPE_ONT, DTYPE_CLR, DTYPE_READS)[int(rng.integers(0, 4))]
-        p = default_params(dtype)
-        p.min_svlen = int(rng.choice([30, 30, 10, 50]))
-        p.cluster_shift = int(rng.choice([100, 100, 10, 1000]))
-        p.pair_shift = int(rng.choice([200, 200, 0, 2000]))
-        p.min_cigar_mapq = int(rng.choice([50, 50, 0, 60]))
+    seen = set()
+    for case, soa, dtype, p in fuzz_cases(kind):
         st_o, want = oracle_run(soa, dtype, p)
         try:
             eng.run(soa, p)
             st_g = 0
         except VsvError as e:
             st_g = e.status
-        assert st_g == st_o, (case, dtype, st_g, st_o)
+        assert st_g == st_o, (kind, case, dtype, st_g, st_o)
+        seen.add(st_o)
         if st_o == 0:
             got = eng.tables(dtype)
             try:
                 assert_tables_equal(got, want, list(got.keys()))
             except AssertionError as e:
-                raise AssertionError("case %d dtype %d: %s" % (case, dtype, e))
+                raise AssertionError("%s case %d dtype %d: %s" % (kind, case, dtype, e))
             n_ok += 1
         else:
             n_err += 1
-    assert n_ok > 150 and n_err > 5
+    assert n_ok >= min_ok and n_err >= min_err
+    if kind == "defects":
+        assert {0, -5, -6, -8} <= seen          # ok, reference_end assert, read-length assert, ZeroDivisionError
 
 
 def test_long_records_with_both_haplotype_tags(eng):
