@@ -183,7 +183,7 @@ class Engine:
                                                None if is_del else seq.ctypes.data_as(C.c_void_p),
                                                None if is_del else seq_off.ctypes.data_as(C.c_void_p), len(pos), C.byref(p),
                                                out.ctypes.data_as(C.c_void_p), cap, C.byref(n))
-            if st == -6 and n.value > cap:          # VSV_E_CAPACITY: retry with the reported size
+            if st == -3 and n.value > cap:          # VSV_E_CAPACITY: retry with the reported size
                 cap = int(n.value)
                 continue
             self._check(st)
