@@ -222,7 +222,7 @@ typedef struct vsv_bnd_params {
   int32_t reference_overlap_tolerance;  /* 50 */
   int32_t partition_max_distance;       /* 1000 (:219-221) */
   int32_t pair_distance;                /* 900: (|d1|+|d2|)/3000 <= 0.3 (SV/SVIM_COMBINE.py:105-117, 143) */
-  int32_t max_partition;                /* 10: larger partitions are ignored (:151-152) */
+  int32_t max_partition;                /* 10: larger partitions are ignored (:151-152); at most 16 */
   int32_t reserved[7];
 } vsv_bnd_params;
 

@@ -764,7 +764,7 @@ int orc_bnd_pair(const vsv_bnd* cv, int64_t n, const int32_t* contig_rank, const
       hi++;
     }
     int64_t sz = hi - lo;
-    if (sz <= p->max_partition) {
+    if (sz <= p->max_partition && sz <= 64) {
       int used[64]; int mate[64];
       for (int64_t k = 0; k < sz; ++k) { used[k] = 0; mate[k] = -1; }
       for (;;) {                                   /* greedy matching in ascending distance */

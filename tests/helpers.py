@@ -153,7 +153,38 @@ def fuzz_case_defects(case, rng):
     return soa, dtype, p
 
 
-FUZZ = {"basic": (fuzz_case_basic, 20250403, 240), "defects": (fuzz_case_defects, 77, 300)}
+def fuzz_case_collectors(case, rng):
+    """The two collector op tables (svim-asm analyze_cigar_indel, SV/SVIM_intra.py:8-30; sig_extract parse_read, SE:438-493): records
+    with =/X/N/P ops, unmapped / secondary / supplementary / host-skipped flags, every merge threshold varied."""
+    from volcanosv_amd import synth
+    from volcanosv_amd.abi import DTYPE_CUTESV, DTYPE_SVIM, F_SKIP
+    from volcanosv_amd.engine import default_params
+    shape = ("hifi", "ont")[int(rng.integers(0, 2))]
+    n = int(rng.integers(1, 301)) if shape == "hifi" else int(rng.integers(1, 61))
+    t, nq, _ = synth.generate(n, shape, seed=13000 + case, chrom_len=int(rng.integers(60_000, 300_000)) + 40_000,
+                              events_per_record=float(rng.choice([0.05, 0.5, 3.0])), site_step=int(rng.choice([200, 1000])))
+    soa = synth.to_soa(t, nq)
+    k = soa.n_records
+    soa.mapq = np.where(rng.random(k) < 0.3, rng.integers(0, 61, k), soa.mapq).astype(np.uint8)
+    fl = soa.flag.copy()
+    for bit, prob in ((2, 0.1), (16, 0.1), (32, 0.05), (F_SKIP, 0.1), (1, 0.3)):     # SUPP, SECONDARY, UNMAPPED, SKIP, REVERSE
+        fl ^= (rng.random(k) < prob).astype(np.uint8) * np.uint8(bit)
+    soa.flag = fl
+    cig = soa.cigar.copy()
+    ms = np.flatnonzero((cig & 15) == 0)
+    sel = ms[rng.random(len(ms)) < 0.1]
+    cig[sel] = (cig[sel] & ~np.uint32(15)) | rng.choice(np.array([7, 8, 3, 6], np.uint32), len(sel))
+    soa.cigar = cig
+    dtype = (DTYPE_SVIM, DTYPE_CUTESV)[int(rng.integers(0, 2))]
+    p = default_params(dtype)
+    p.min_svlen = int(rng.choice([p.min_svlen, 5, 10, 100]))
+    p.min_cigar_mapq = int(rng.choice([p.min_cigar_mapq, 0, 50]))
+    p.merge_ins_threshold = int(rng.choice([100, 0, 30, 1000]))
+    p.merge_del_threshold = int(rng.choice([0, 40, 1000]))
+    return soa, dtype, p
+
+
+FUZZ = {"basic": (fuzz_case_basic, 20250403, 240), "defects": (fuzz_case_defects, 77, 300), "collectors": (fuzz_case_collectors, 5, 200)}
 
 
 def fuzz_cases(kind, upto=None):

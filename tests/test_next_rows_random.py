@@ -128,3 +128,57 @@ def test_cutesv_split_random(eng):
             want = oracle.run_cutesv_split(seg, seg.read_len, seg.read_rec, sv, size, parts)
             got = eng.cutesv_split(seg, seg.read_len, seg.read_rec, sv, size, parts)
             assert np.array_equal(got, want), (case, size, parts, sv, len(got), len(want))
+
+
+def test_bnd_segments_and_pairing_random(eng):
+    """Complex_SV breakend branch (SV/SVIM_inter.py:62-258, SV/SVIM_COMBINE.py:15-32, 143-161) on random multi-segment reads:
+    2-6 segments over 1-4 contigs whose names sort differently as strings ('chr10' < 'chr2'), both strands and haplotypes,
+    breakpoints near contig ends, partitions from singletons to more than ten members, every tolerance varied."""
+    from oracle import oracle
+    from volcanosv_amd import bnd
+    rng = np.random.default_rng(105)
+    n_cand = n_calls = 0
+    for case in range(80):
+        nt = int(rng.integers(1, 5))
+        names = list(rng.permutation(["chr1", "chr2", "chr10", "chrX", "chr21"])[:nt])
+        contigs = [(str(nm), int(rng.integers(50_000, 400_000))) for nm in names]
+        sites = [(int(rng.integers(0, nt)), int(rng.integers(0, 50_000))) for _ in range(int(rng.integers(1, 8)))]
+        reads = []
+        for r in range(int(rng.integers(1, 120))):
+            L = int(rng.integers(5000, 40000))
+            k = int(rng.integers(2, 7))
+            cuts = np.sort(rng.choice(np.arange(100, L - 100), k - 1, replace=False))
+            bounds = [0] + [int(c) for c in cuts] + [L]
+            segs = []
+            for j in range(k):
+                qa, qb = bounds[j], bounds[j + 1]
+                qa = max(0, qa + int(rng.integers(-80, 80))) if j else 0
+                if qb <= qa:
+                    qb = qa + 1
+                t, base = sites[int(rng.integers(0, len(sites)))]
+                clen = contigs[t][1]
+                rs = int(np.clip(base + int(rng.integers(-400, 400)), 0, clen - 2))
+                re_ = int(min(clen, rs + max(1, qb - qa + int(rng.integers(-30, 30)))))
+                segs.append([t, rs, re_, qa, min(qb, L), L, int(rng.random() < 0.4)])
+            reads.append({"hap": 1 + int(rng.random() < 0.5), "name": "PS%d_hp_r%d" % (case, r), "segs": segs})
+        reads.sort(key=lambda x: x["hap"])
+        seg = bnd.SegmentSoA(reads, contigs)
+        kw = dict(query_gap_tolerance=int(rng.choice([50, 0, 500])), query_overlap_tolerance=int(rng.choice([50, 0, 500])),
+                  reference_gap_tolerance=int(rng.choice([50, 0, 1000])), reference_overlap_tolerance=int(rng.choice([50, 0, 1000])),
+                  max_sv_size=int(rng.choice([100000, 1000])), min_sv_size=int(rng.choice([40, 1, 200])),
+                  partition_max_distance=int(rng.choice([1000, 100, 10000])), pair_distance=int(rng.choice([900, 0, 5000])),
+                  max_partition=int(rng.choice([10, 3, 16])))
+        po, pg = oracle.default_bnd_params(), eng._bnd_params()
+        for name, v in kw.items():
+            setattr(po, name, v)
+            setattr(pg, name, v)
+        ocand, ocalls = oracle.run_bnd(seg, po)
+        cand, calls = eng.bnd(seg, pg)
+        assert np.array_equal(cand, ocand), (case, kw, len(cand), len(ocand))
+        assert np.array_equal(calls, ocalls), (case, kw, len(calls), len(ocalls))
+        n_cand += len(cand)
+        n_calls += len(calls)
+    assert n_cand > 1000 and n_calls > 500
+    pg.max_partition = 17                      # the pairing kernel holds a partition in registers: at most 16 members
+    with pytest.raises(Exception, match="max_partition"):
+        eng.bnd(seg, pg)

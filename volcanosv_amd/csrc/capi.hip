@@ -587,6 +587,7 @@ int vsv_bnd_set_candidates(vsv_handle* h, const vsv_bnd* rows, int64_t n, const 
 
 int vsv_bnd_pair(vsv_handle* h, const vsv_bnd_params* p) {
   if (!h || !p || h->bnd_stage < 1) return fail(h, VSV_E_INVALID, "vsv_bnd_segments must run first");
+  if (p->max_partition < 0 || p->max_partition > 16) return fail(h, VSV_E_INVALID, "max_partition must lie in [0, 16] (the pairing kernel holds a partition in registers)");
   HIPCHK(h, hipSetDevice(h->device));
   vsv_launch_bnd_pair(h->stream, (const vsv_bnd*)h->s1in.p, h->segs.contig_rank, bits_for((uint64_t)h->segs.n_tids + 1), *p,
                       (vsv_bnd*)h->s1s.p, (vsv_bnd*)h->c1.p, dctr(h), stage_bufs(h), sort_work(h), h->cap_sigs);
