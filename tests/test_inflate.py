@@ -181,3 +181,84 @@ def test_device_reader_rejects_damaged_files(tmp_path):
                     bf.fetch_device(eng, "chr10")
                 with pytest.raises(VsvError):
                     bf.fetch_soa("chr10")
+
+
+@pytest.mark.gpu
+def test_device_reader_equals_host_reader_on_random_files(tmp_path, monkeypatch):
+    """Random BAM files: 1-3 references, unmapped-placed and reference-less records, names up to 250 characters with 'hp1' / 'hp2'
+    anywhere, repeated names, empty CIGARs, > 65535-op CIGARs in CG:B,I behind aux fields of every type, SA tags, members of
+    17 bytes to 64 KiB, stored / fixed / dynamic deflate blocks, one to many reader windows: every array and the name table of
+    the device reader equal the host reader's."""
+    import struct
+    from volcanosv_amd import bam
+    from volcanosv_amd.engine import Engine
+    rng = np.random.default_rng(606)
+
+    def random_aux():
+        out = b""
+        for _ in range(int(rng.integers(0, 6))):
+            tag = bytes(rng.choice(list(b"ABXYZnm"), 2).astype(np.uint8))
+            if tag in (b"CG", b"SA"):
+                continue
+            ty = rng.choice(list("AcCsSiIfZHB"))
+            if ty == "A":
+                out += tag + b"A" + b"x"
+            elif ty in "cC":
+                out += tag + ty.encode() + struct.pack("<B", int(rng.integers(0, 128)))
+            elif ty in "sS":
+                out += tag + ty.encode() + struct.pack("<H", int(rng.integers(0, 30000)))
+            elif ty in "iI":
+                out += tag + ty.encode() + struct.pack("<I", int(rng.integers(0, 1 << 30)))
+            elif ty == "f":
+                out += tag + b"f" + struct.pack("<f", float(rng.random()))
+            elif ty == "Z":
+                out += tag + b"Z" + bytes(rng.integers(33, 127, int(rng.integers(0, 40))).astype(np.uint8)) + b"\0"
+            elif ty == "H":
+                out += tag + b"H" + b"1AE3" * int(rng.integers(0, 5)) + b"\0"
+            else:
+                sub, cnt = rng.choice(list("cCsSiIf")), int(rng.integers(0, 20))
+                width = {"c": 1, "C": 1, "s": 2, "S": 2, "i": 4, "I": 4, "f": 4}[sub]
+                out += tag + b"B" + sub.encode() + struct.pack("<I", cnt) + bytes(rng.integers(0, 256, cnt * width).astype(np.uint8))
+        return out
+
+    with Engine(0) as eng:
+        for case in range(12):
+            nref = int(rng.integers(1, 4))
+            refs = [("chr%d" % (i + 1), 5_000_000) for i in range(nref)]
+            recs = []
+            for tid in range(nref):
+                pos = np.sort(rng.integers(0, 4_000_000, int(rng.integers(1, 1500))))
+                for p in pos:
+                    kind = rng.random()
+                    if kind < 0.02:
+                        cig = []
+                    elif kind < 0.03:
+                        cig = [(0, 2), (1, 1)] * int(rng.integers(33000, 36000)) + [(0, 1)]
+                    else:
+                        cig = [(int(rng.choice([0, 1, 2, 4, 7, 8, 3])), int(rng.integers(1, 3000))) for _ in range(int(rng.integers(1, 60)))]
+                    stem = "PS%d_%s_x" % (int(rng.integers(0, 300)), rng.choice(["hp1", "hp2", "hp3", "h", "hp1hp2", ""]))
+                    name = (stem + "q" * int(rng.integers(0, 240)))[:250] if rng.random() < 0.1 else stem
+                    r = dict(tid=tid, pos=int(p), qname=name, mapq=int(rng.integers(0, 61)),
+                             flag=int(rng.choice([0, 16, 4, 256, 2048, 2064, 272])), cigar=cig, seq_len=int(rng.integers(0, 3000)), aux=random_aux())
+                    if rng.random() < 0.2:
+                        r["tags"] = {b"SA": "chr1,%d,+,100S200M,60,3;" % int(rng.integers(1, 10000))}
+                    recs.append(r)
+            for _ in range(int(rng.integers(0, 4))):                        # reads without a reference at the end of the file
+                recs.append(dict(tid=-1, pos=-1, qname="unplaced%d" % len(recs), mapq=0, flag=4, cigar=[], seq_len=100))
+            sizes = [17, 300, 5000, 60000, 65280]
+            path = str(tmp_path / ("r%d.bam" % case))
+            fixed = int(rng.choice(sizes[1:]))
+            bam.write_bam(path, refs, recs, block_bytes=(lambda: int(rng.choice(sizes))) if case % 2 else fixed, level=int(rng.choice([0, 1, 6, 9])))
+            need = 300_000 // (17 if case % 2 else fixed) + 20          # members the longest record (a 70 k-op CIGAR) can span
+            monkeypatch.setenv("VSV_BAM_WINDOW", str(int(rng.choice([w for w in (32768, 2000, 300, 40) if w >= need]))))
+            with bam.BamFile(path) as bf:
+                for chrom in [None] + [refs[int(rng.integers(0, nref))][0]]:
+                    host = bf.fetch_soa(chrom)
+                    view = bf.fetch_device(eng, chrom)
+                    assert isinstance(view, bam.DeviceRecordView), (case, chrom)
+                    dev = view.to_host()
+                    assert dev.n_records == host.n_records and dev.n_ops == host.n_ops and view.n_qids == host.n_qids, (case, chrom)
+                    for name in ("pos", "tid", "qid", "cigar_off", "mapq", "flag", "cigar", "l_seq", "sam_flags"):
+                        assert np.array_equal(getattr(host, name), getattr(dev, name)), (case, chrom, name)
+                    assert list(host.qnames) == list(dev.qnames), (case, chrom)
+        monkeypatch.delenv("VSV_BAM_WINDOW")

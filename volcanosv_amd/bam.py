@@ -258,8 +258,8 @@ def read_bam(path, chrom=None, threads=0):
 
 
 # ---- minimal writer (tests / synthetic plumbing inputs) ------------------------------------------------------------
-def _bgzf_block(data):
-    comp = zlib.compressobj(6, zlib.DEFLATED, -15)
+def _bgzf_block(data, level=6):
+    comp = zlib.compressobj(level, zlib.DEFLATED, -15)
     c = comp.compress(data) + comp.flush()
     bsize = len(c) + 25
     return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize) + c +
@@ -279,9 +279,11 @@ for _i, _ch in enumerate("=ACMGRSVTWYHKDBN"):
     _NIBBLE[ord(_ch)] = _i
 
 
-def write_bam(path, references, records, header_text=None):
+def write_bam(path, references, records, header_text=None, block_bytes=60000, level=6):
     """references: [(name, length)]; records: iterable of dicts with keys tid, pos, qname, mapq, flag (SAM flag),
-    cigar [(op,len)], optional seq (bases) or seq_len (bases are written as 'N'; 0 => '*'), optional tags {b'SA': 'text'}."""
+    cigar [(op,len)], optional seq (bases) or seq_len (bases are written as 'N'; 0 => '*'), optional tags {b'SA': 'text'},
+    optional aux (raw, already encoded aux fields written before the CG / Z tags). block_bytes: uncompressed bytes per BGZF
+    member (an int, or a callable returning the size of the next member); level: zlib level (0 = stored blocks)."""
     if header_text is None:
         header_text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % (n, l) for n, l in references)
     out = bytearray()
@@ -298,7 +300,7 @@ def write_bam(path, references, records, header_text=None):
         l_seq = len(seq) if seq is not None else int(r.get("seq_len", 0))
         long_cigar = len(cig) > 65535
         cig_words = [(l << 4) | op for op, l in cig]
-        tags = b""
+        tags = bytes(r.get("aux") or b"")
         if long_cigar:  # htslib convention: placeholder CIGAR kSmN + real CIGAR in CG:B,I
             tags += b"CGBI" + struct.pack("<I", len(cig_words)) + struct.pack("<%dI" % len(cig_words), *cig_words)
             cig_words = [(l_seq << 4) | 4, (ref_len << 4) | 3]
@@ -315,6 +317,10 @@ def write_bam(path, references, records, header_text=None):
         body += packed + b"\xff" * l_seq + tags
         out += struct.pack("<i", len(body)) + body
     with open(path, "wb") as f:
-        for i in range(0, len(out), 60000):
-            f.write(_bgzf_block(bytes(out[i:i + 60000])))
+        i = 0
+        while i < len(out):
+            step = int(block_bytes() if callable(block_bytes) else block_bytes)
+            step = max(1, min(step, 65280))
+            f.write(_bgzf_block(bytes(out[i:i + step]), level))
+            i += step
         f.write(_bgzf_block(b""))  # EOF marker
