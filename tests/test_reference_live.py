@@ -78,3 +78,60 @@ def test_reads_path_on_fresh_random_inputs():
             assert got == exp["per_chrom"][chrom]["merged"], (seed, chrom)
             n_rows += len(got)
     assert n_rows > 100
+
+
+def _golden_module(name):
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    return __import__(name)
+
+
+def test_fp_filter_eval_sig_on_fresh_random_inputs():
+    """FP_filter_v1.eval_sig (FP:106-123) with its thresholds as arguments: the oracle's literal loop on new lists."""
+    mg = _golden_module("make_golden_fp")
+    ns = mg.load_functions()
+    rng = np.random.default_rng(6)
+    for seed in range(50, 90):
+        calls, sigs = mg.make_lists(seed, int(rng.integers(1, 300)), int(rng.integers(0, 3000)), int(rng.choice([20_000, 300_000, 3_000_000])),
+                                    boundary=bool(rng.random() < 0.5))
+        prm = (int(rng.choice([1000, 100, 5000])), int(rng.choice([250, 100, 1200])), int(rng.choice([500, 50, 2000])), float(rng.choice([0.5, 0.3, 0.0, 1.0])))
+        want = [int(x) for x in ns["eval_sig"](calls, sigs, *prm)]
+        p = oracle.default_support_params(max_dist=prm[0], max_comp_svlen=prm[1], max_shift=prm[2], min_size_sim=prm[3])
+        st, got = oracle.run_support([c[2] for c in calls], [c[3] for c in calls], [s[2] for s in sigs], [s[3] for s in sigs], p)
+        assert st == 0 and got.tolist() == want, (seed, prm)
+
+
+def test_signature_coverage_on_fresh_random_inputs(tmp_path):
+    """calculate_signature_support.py calc_ins_call_cov / calc_del_call_cov (CS:81-125, 138-280) through its own load_vcf / load_sig."""
+    mg = _golden_module("make_golden_cov")
+    rng = np.random.default_rng(7)
+    for seed in range(60, 72):
+        ties = bool(rng.random() < 0.5)
+        flank = int(rng.choice([1000, 1000, 200, 5000]))
+        ns = mg.load_functions(stable=ties, flanking=flank)
+        vcf, sig = mg.make_text(seed, int(rng.integers(30, 300)), int(rng.integers(50, 2500)), int(rng.choice([100_000, 600_000])), ties)
+        vp = tmp_path / ("c%d.vcf" % seed)
+        vp.write_text("".join(vcf))
+        (tmp_path / "INS.sigs").write_text("".join(sig["INS"]))
+        (tmp_path / "DEL.sigs").write_text("".join(sig["DEL"]))
+        s_ins, s_del = ns["load_sig"](str(tmp_path / "INS.sigs"), "INS"), ns["load_sig"](str(tmp_path / "DEL.sigs"), "DEL")
+        c_ins, c_del = ns["load_vcf"](str(vp), "INS"), ns["load_vcf"](str(vp), "DEL")
+        if "chr1" in c_ins and "chr1" in s_ins:
+            want = ns["calc_ins_call_cov"](c_ins["chr1"], s_ins["chr1"])
+            pos = np.array(list(want.keys()))
+            sp = np.array([int(l.split()[2]) for l in sig["INS"]])
+            sl = np.array([int(l.split()[3]) for l in sig["INS"]])
+            o = np.argsort(sp, kind="stable")
+            st, cov = oracle.run_cov_ins(pos, sp[o], sl[o], flank)
+            assert st == 0 and cov.tolist() == [int(v) for v in want.values()], (seed, "ins")
+        if "chr1" in c_del and "chr1" in s_del:
+            want = {tuple(int(x) for x in k): int(v) for k, v in ns["calc_del_call_cov"](c_del["chr1"], s_del["chr1"]).items()}
+            sp = np.array([int(l.split()[2]) for l in sig["DEL"]])
+            sl = np.array([int(l.split()[3]) for l in sig["DEL"]])
+            o = np.argsort(sp, kind="stable")
+            sp, sl = sp[o], sl[o]
+            cs = np.array([c[0] for c in c_del["chr1"]])
+            ce = np.array([c[1] for c in c_del["chr1"]])
+            st, cov, has = oracle.run_cov_del(cs, ce, sp, sp + sl, -sl, flank)
+            assert st == 0
+            got = {(int(a), int(b)): int(c) for a, b, c, h in zip(cs, ce, cov, has) if h}
+            assert got == want, (seed, "del", flank)
