@@ -135,3 +135,35 @@ def test_signature_coverage_on_fresh_random_inputs(tmp_path):
             assert st == 0
             got = {(int(a), int(b)): int(c) for a, b, c, h in zip(cs, ce, cov, has) if h}
             assert got == want, (seed, "del", flank)
+
+
+def test_remove_redundancy_links_on_fresh_random_inputs(tmp_path):
+    """remove_redundancy.py match_del_chr / match_ins_chr (RR:127-197) with their thresholds as arguments (edlib stood in for by the
+    Levenshtein DP, networkx real): the link lists of the host mirror over the oracle's pair test."""
+    from test_remove_redundancy import OracleEngine
+    from volcanosv_amd import remove_redundancy as rr
+    mg = _golden_module("make_golden_redundancy")
+    ns = mg.load_functions()
+    rng = np.random.default_rng(8)
+    eng = OracleEngine()
+    n_links = 0
+    for seed in range(30, 36):
+        lines = mg.make_vcf(seed, int(rng.integers(10, 60)))
+        vp = tmp_path / ("r%d.vcf" % seed)
+        vp.write_text("".join(lines))
+        del_sig, ins_sig, vcf_dc, header = ns["vcf_to_sig"](str(vp))
+        d2, i2, _, _ = rr.vcf_to_sig(str(vp))
+        kw = dict(dist_thresh=int(rng.choice([500, 100, 3000])), dist_thresh_del=int(rng.choice([3000, 300])), overlap_thresh=float(rng.choice([0.0, 0.5])),
+                  size_sim_thresh=float(rng.choice([0.5, 0.2, 0.9])), size_sim_thresh_del=float(rng.choice([0.1, 0.6])), seq_sim_thresh=float(rng.choice([0.5, 0.3, 0.8])))
+        p = eng.redundancy_params(**kw)
+        for chrom in sorted({s[0] for s in del_sig}):
+            want = ns["match_del_chr"]([s for s in del_sig if s[0] == chrom], kw["dist_thresh_del"], kw["size_sim_thresh_del"], kw["overlap_thresh"])
+            got = rr.match_chr([s for s in d2 if s[0] == chrom], True, eng, p)
+            assert [list(l) for l in got] == [list(l) for l in want], (seed, chrom, "del", kw)
+            n_links += len(want)
+        for chrom in sorted({s[0] for s in ins_sig}):
+            want = ns["match_ins_chr"]([s for s in ins_sig if s[0] == chrom], kw["dist_thresh"], kw["size_sim_thresh"], kw["seq_sim_thresh"])
+            got = rr.match_chr([s for s in i2 if s[0] == chrom], False, eng, p)
+            assert [list(l) for l in got] == [list(l) for l in want], (seed, chrom, "ins", kw)
+            n_links += len(want)
+    assert n_links > 50
