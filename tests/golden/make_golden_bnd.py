@@ -138,53 +138,60 @@ def load_svim():
     return SVIM_inter, SVCandidate, ns
 
 
-def main():
-    SVIM_inter, SVCandidate, ns = load_svim()
+def make_doc(reads, svim=None):
+    """The fixture document (inputs + the reference's outputs) for one list of reads."""
+    SVIM_inter, SVCandidate, ns = svim or load_svim()
     opts = types.SimpleNamespace(min_mapq=20, min_sv_size=40, max_sv_size=100000, query_gap_tolerance=50, query_overlap_tolerance=50,
                                  reference_gap_tolerance=50, reference_overlap_tolerance=50, partition_max_distance=1000)
     bam = FakeBam(CONTIGS)
+    per_read, cands = [], {1: [], 2: []}
+    for r in reads:
+        alns = [FakeAln(r["name"], s) for s in r["segs"]]
+        out = SVIM_inter.analyze_read_segments(alns[0], alns[1:], bam, opts)
+        b = [c for c in out if c.type == "BND"]
+        per_read.append([[c.source_contig, c.source_start, c.source_direction, c.dest_contig, c.dest_start, c.dest_direction] for c in b])
+        cands[r["hap"]].extend(b)
+    both = [(1, c) for c in cands[1]] + [(2, c) for c in cands[2]]
+    partitions = ns["form_partitions"](both, opts.partition_max_distance)
+    clusters = ns["pair_haplotypes_breakends"](partitions)
+    paired = []
+    for cl in clusters:
+        c = cl[0][1]
+        if len(cl) == 1:
+            gt, rd = ("1/0" if cl[0][0] == 1 else "0/1"), c.reads
+        elif len(cl) == 2:
+            gt, rd = "1/1", cl[0][1].reads + cl[1][1].reads
+        else:
+            continue
+        paired.append(SVCandidate.CandidateBreakend(c.source_contig, c.source_start, c.source_direction, c.dest_contig, c.dest_start,
+                                                    c.dest_direction, rd, bam, gt))
+    entries = []
+    for c in paired:   # SVIM_COMBINE.py:461-464
+        entries.append(((c.get_source()[0], c.get_source()[1] + 1, c.get_source()[1] + 2), c.get_vcf_entry(True), "BND"))
+        entries.append(((c.get_destination()[0], c.get_destination()[1] + 1, c.get_destination()[1] + 2), c.get_vcf_entry_reverse(True), "BND"))
+    lines, n = [], 0
+    for source, entry, svtype in ns["sorted_nicely"](entries):
+        n += 1
+        lines.append(entry.replace("PLACEHOLDERFORID", "svim_asm.BND.%d" % n, 1))
+    doc = {"contigs": CONTIGS, "reads": reads,
+           "expected": {"per_read": per_read,
+                        "paired": sorted([[c.source_contig, c.source_start, c.source_direction, c.dest_contig, c.dest_start, c.dest_direction, c.genotype, c.reads] for c in paired]),
+                        "n_partitions": len(partitions), "n_dropped_partitions": sum(1 for p in partitions if len(p) > 10),
+                        "vcf": lines},
+           "generator": "tests/golden/make_golden_bnd.py"}
+    return doc, len(both), paired
+
+
+def main():
+    svim = load_svim()
     for name, seed in (("bnd_a", 11), ("bnd_b", 12)):
         reads = make_reads(seed)
-        per_read, cands = [], {1: [], 2: []}
-        for r in reads:
-            alns = [FakeAln(r["name"], s) for s in r["segs"]]
-            out = SVIM_inter.analyze_read_segments(alns[0], alns[1:], bam, opts)
-            b = [c for c in out if c.type == "BND"]
-            per_read.append([[c.source_contig, c.source_start, c.source_direction, c.dest_contig, c.dest_start, c.dest_direction] for c in b])
-            cands[r["hap"]].extend(b)
-        both = [(1, c) for c in cands[1]] + [(2, c) for c in cands[2]]
-        partitions = ns["form_partitions"](both, opts.partition_max_distance)
-        clusters = ns["pair_haplotypes_breakends"](partitions)
-        paired = []
-        for cl in clusters:
-            c = cl[0][1]
-            if len(cl) == 1:
-                gt, rd = ("1/0" if cl[0][0] == 1 else "0/1"), c.reads
-            elif len(cl) == 2:
-                gt, rd = "1/1", cl[0][1].reads + cl[1][1].reads
-            else:
-                continue
-            paired.append(SVCandidate.CandidateBreakend(c.source_contig, c.source_start, c.source_direction, c.dest_contig, c.dest_start,
-                                                        c.dest_direction, rd, bam, gt))
-        entries = []
-        for c in paired:   # SVIM_COMBINE.py:461-464
-            entries.append(((c.get_source()[0], c.get_source()[1] + 1, c.get_source()[1] + 2), c.get_vcf_entry(True), "BND"))
-            entries.append(((c.get_destination()[0], c.get_destination()[1] + 1, c.get_destination()[1] + 2), c.get_vcf_entry_reverse(True), "BND"))
-        lines, n = [], 0
-        for source, entry, svtype in ns["sorted_nicely"](entries):
-            n += 1
-            lines.append(entry.replace("PLACEHOLDERFORID", "svim_asm.BND.%d" % n, 1))
-        doc = {"contigs": CONTIGS, "reads": reads,
-               "expected": {"per_read": per_read,
-                            "paired": sorted([[c.source_contig, c.source_start, c.source_direction, c.dest_contig, c.dest_start, c.dest_direction, c.genotype, c.reads] for c in paired]),
-                            "n_partitions": len(partitions), "n_dropped_partitions": sum(1 for p in partitions if len(p) > 10),
-                            "vcf": lines},
-               "generator": "tests/golden/make_golden_bnd.py"}
+        doc, n_both, paired = make_doc(reads, svim)
         path = os.path.join(HERE, name + ".json")
         with open(path, "w") as f:
             json.dump(doc, f, separators=(",", ":"))
         print("wrote %s: %d reads, %d candidates, %d partitions (%d dropped), %d paired (%d 1/1), %d bytes" % (
-            path, len(reads), len(both), len(partitions), doc["expected"]["n_dropped_partitions"], len(paired),
+            path, len(reads), n_both, doc["expected"]["n_partitions"], doc["expected"]["n_dropped_partitions"], len(paired),
             sum(1 for c in paired if c.genotype == "1/1"), os.path.getsize(path)))
 
 

@@ -167,3 +167,21 @@ def test_remove_redundancy_links_on_fresh_random_inputs(tmp_path):
             assert [list(l) for l in got] == [list(l) for l in want], (seed, chrom, "ins", kw)
             n_links += len(want)
     assert n_links > 50
+
+
+def test_breakend_branch_on_fresh_random_inputs():
+    """svim-asm analyze_read_segments / CandidateBreakend / form_partitions / pair_haplotypes_breakends (real scipy linkage) on new
+    read sets: per-read candidates, paired calls and the VCF text of the oracle's breakend branch."""
+    import json
+    from test_bnd_oracle import check_against_golden
+    from volcanosv_amd import bnd
+    mg = _golden_module("make_golden_bnd")
+    svim = mg.load_svim()
+    rng = np.random.default_rng(9)
+    for seed in range(100, 108):
+        reads = mg.make_reads(seed, n_events=int(rng.integers(20, 200)), dense=int(rng.integers(1, 5)))
+        doc, _, _ = mg.make_doc(reads, svim)
+        doc = json.loads(json.dumps(doc))                       # the same normalisation a committed fixture goes through
+        seg = bnd.SegmentSoA(doc["reads"], [tuple(c) for c in doc["contigs"]])
+        cand, calls = oracle.run_bnd(seg)
+        check_against_golden(doc, seg, cand, calls)
