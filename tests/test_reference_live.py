@@ -185,3 +185,36 @@ def test_breakend_branch_on_fresh_random_inputs():
         seg = bnd.SegmentSoA(doc["reads"], [tuple(c) for c in doc["contigs"]])
         cand, calls = oracle.run_bnd(seg)
         check_against_golden(doc, seg, cand, calls)
+
+
+def test_sig_extract_parse_read_on_fresh_random_inputs():
+    """sig_extract.py parse_read (SE:438-493) on new reads: the CIGAR candidates with random length / merge thresholds (oracle tables
+    + the host mirror's text step) and the split-read candidates of reads with SA tags."""
+    import test_sig_extract as ts
+    from volcanosv_amd import sig_extract
+    mg = _golden_module("make_golden_sigextract")
+    ns = mg.load_functions()
+    rng = np.random.default_rng(10)
+    n_cig = n_spl = 0
+    for rep in range(6):
+        reads = mg.make_plain_reads(rng, int(rng.integers(20, 150)))
+        siglen, mdel, mins = int(rng.choice([10, 5, 30, 50])), int(rng.choice([0, 50, 500])), int(rng.choice([100, 20, 0, 1000]))
+        exp = [mg.norm(ns["parse_read"](mg.FakeRead(d), "chr1", 30, 20, 7, 500, siglen, mdel, mins, 100000)) for d in reads]
+        soa = ts.build_soa(reads)
+        st, tabs = oracle.run(soa, params=sig_extract.params(min_mapq=20, min_siglength=siglen, merge_del_threshold=mdel, merge_ins_threshold=mins))
+        assert st == 0
+        got = sig_extract.cigar_candidates(soa, tabs["raw"], tabs["cigar"], lambda rec: reads[rec]["seq"], "chr1")
+        for i, w in enumerate(ts.cigar_expected(exp)):
+            assert got.get(i, []) == w, (rep, i, siglen, mdel, mins)
+            n_cig += len(w)
+    for rep in range(4):
+        reads = mg.make_split_reads(rng, int(rng.integers(30, 200)))
+        exp = [mg.norm(ns["parse_read"](mg.FakeRead(d), "chr1", 30, 20, 7, 500, 10, 0, 100, 100000)) for d in reads]
+        doc = {"cases": {"split": {"reads": reads, "expected": exp}}}
+        rd, soa, seg, names = ts.split_inputs(doc)
+        rows = oracle.run_cutesv_split(seg, seg.read_len, seg.read_rec, 30, 100000, 7)
+        got = sig_extract.split_candidates(soa, rows, lambda rec: rd[rec]["seq"], lambda t: names[t])
+        want = ts.split_expected(doc)
+        assert got == want, rep
+        n_spl += sum(len(v) for v in want.values())
+    assert n_cig > 300 and n_spl > 30
