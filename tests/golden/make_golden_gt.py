@@ -87,9 +87,9 @@ def make_inputs(seed):
     return vcf, sig_lines(sig_del, "DEL", False), sig_lines(sig_ins, "INS", True)
 
 
-def main():
-    out = []
-    for name, seed, dtype in (("a", 21, "Hifi"), ("b", 22, "ONT")):
+def make_case(name, seed, dtype):
+    """Inputs + every output of the two reference scripts for one seed."""
+    if True:
         vcf, dsig, isig = make_inputs(seed)
         reads = {c: [[s, e] for s, e, _ in v] for c, v in READS.items()}
         case = dict(name=name, dtype=dtype, vcf=vcf, del_sigs=dsig, ins_sigs=isig, reads=reads)
@@ -133,6 +133,13 @@ def main():
             case["ins_newgt_tsv"] = open(tsv + ".newgt").read()
             ns["write_new_gt_vcf"](vp, vp + ".newgt.INS", df)
             case["ins_newgt_vcf"] = open(vp + ".newgt.INS").read()
+        return case
+
+
+def main():
+    out = []
+    for name, seed, dtype in (("a", 21, "Hifi"), ("b", 22, "ONT")):
+        case = make_case(name, seed, dtype)
         out.append(case)
         print(name, "DEL vars", len(case["del_support"]), "sum support", sum(case["del_support"]), "| INS vars", len(case["ins_support"]), "sum support", sum(case["ins_support"]),
               "| changed GT (DEL)", sum(1 for a, b in zip(case["del_newgt_tsv"].splitlines()[1:], case["del_tsv"].splitlines()[1:]) if a.split("\t")[-1] != b.split("\t")[2]))

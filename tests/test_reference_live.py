@@ -218,3 +218,17 @@ def test_sig_extract_parse_read_on_fresh_random_inputs():
         assert got == want, rep
         n_spl += sum(len(v) for v in want.values())
     assert n_cig > 300 and n_spl > 30
+
+
+def test_gt_correction_on_fresh_random_inputs(tmp_path):
+    """correct_gt_del_real_data.py / correct_gt_ins_real_data.py on new call / signature / read sets: the oracle's support and span
+    scans, and the host replay's TSV / VCF text, against the reference functions' outputs."""
+    import json
+    import test_gt_correction as tg
+    mg = _golden_module("make_golden_gt")
+    for k, (seed, dtype) in enumerate(((31, "Hifi"), (32, "ONT"), (33, "Hifi"))):
+        case = json.loads(json.dumps(mg.make_case("live%d" % k, seed, dtype)))
+        (tmp_path / ("s%d" % k)).mkdir()
+        (tmp_path / ("t%d" % k)).mkdir()
+        tg.test_oracle_scans_match_reference([case], tmp_path / ("s%d" % k))
+        tg.test_host_replay_text_level([case], tmp_path / ("t%d" % k))
