@@ -64,6 +64,7 @@ def compare_contig_tables(doc, soa, tabs):
 
 
 # ---- randomized small inputs (tests/test_gpu_parity.py, tools/fuzz_case.py) ---------------------------------------------------
+_SOAK = 100003 * int(os.environ.get("VSV_FUZZ_SEED", "0"))
 def _fuzz_flags_mapq(soa, rng, strands=True):
     from volcanosv_amd.abi import F_HP1, F_HP2
     k = soa.n_records
@@ -84,7 +85,7 @@ def fuzz_case_basic(case, rng):
     from volcanosv_amd.engine import default_params
     shape = ("hifi", "ont")[int(rng.integers(0, 2))]
     n = int(rng.integers(1, 401)) if shape == "hifi" else int(rng.integers(1, 81))
-    t, nq, _ = synth.generate(n, shape, seed=5000 + case, chrom_len=int(rng.integers(60_000, 300_000)) + 40_000,
+    t, nq, _ = synth.generate(n, shape, seed=5000 + case + _SOAK, chrom_len=int(rng.integers(60_000, 300_000)) + 40_000,
                               events_per_record=float(rng.choice([0.0, 0.05, 0.5, 2.0])), site_step=int(rng.choice([200, 1000, 5000])))
     soa = synth.to_soa(t, nq)
     _fuzz_flags_mapq(soa, rng)
@@ -116,7 +117,7 @@ def fuzz_case_defects(case, rng):
     shape = ("hifi", "ont")[int(rng.integers(0, 2))]
     for tid in range(n_t):
         n = int(rng.integers(1, 201)) if shape == "hifi" else int(rng.integers(1, 41))
-        t, nq, _ = synth.generate(n, shape, seed=9000 + 7 * case + tid, tid=tid, chrom_len=int(rng.integers(60_000, 200_000)) + 40_000,
+        t, nq, _ = synth.generate(n, shape, seed=9000 + 7 * case + tid + _SOAK, tid=tid, chrom_len=int(rng.integers(60_000, 200_000)) + 40_000,
                                   events_per_record=float(rng.choice([0.05, 0.5, 2.0])), site_step=int(rng.choice([200, 1000])))
         parts.append((t, nq))
     t, nq = synth.concat(parts) if n_t > 1 else parts[0]
@@ -161,7 +162,7 @@ def fuzz_case_collectors(case, rng):
     from volcanosv_amd.engine import default_params
     shape = ("hifi", "ont")[int(rng.integers(0, 2))]
     n = int(rng.integers(1, 301)) if shape == "hifi" else int(rng.integers(1, 61))
-    t, nq, _ = synth.generate(n, shape, seed=13000 + case, chrom_len=int(rng.integers(60_000, 300_000)) + 40_000,
+    t, nq, _ = synth.generate(n, shape, seed=13000 + case + _SOAK, chrom_len=int(rng.integers(60_000, 300_000)) + 40_000,
                               events_per_record=float(rng.choice([0.05, 0.5, 3.0])), site_step=int(rng.choice([200, 1000])))
     soa = synth.to_soa(t, nq)
     k = soa.n_records
@@ -190,6 +191,8 @@ FUZZ = {"basic": (fuzz_case_basic, 20250403, 240), "defects": (fuzz_case_defects
 def fuzz_cases(kind, upto=None):
     """Yields (case, soa, dtype, params) for the named family, in the fixed order the tests use."""
     make, seed, count = FUZZ[kind]
+    seed += int(os.environ.get("VSV_FUZZ_SEED", "0"))          # soak runs: other seeds, VSV_FUZZ_SCALE times as many cases
+    count *= int(os.environ.get("VSV_FUZZ_SCALE", "1"))
     rng = np.random.default_rng(seed)
     for case in range(count if upto is None else upto + 1):
         yield (case,) + make(case, rng)

@@ -1,7 +1,12 @@
 """Randomized parity of the post-filter rows on small, dense inputs: every call collides with many
 signatures, duplicates and zero-length entries occur, every threshold is varied. HIP entry point vs the oracle's literal loops."""
+import os
+
 import numpy as np
 import pytest
+
+SEED = int(os.environ.get("VSV_FUZZ_SEED", "0"))       # soak runs: other seeds, VSV_FUZZ_SCALE times as many cases
+SCALE = int(os.environ.get("VSV_FUZZ_SCALE", "1"))
 
 pytestmark = pytest.mark.gpu
 
@@ -16,8 +21,8 @@ def eng():
 def test_support_join_random(eng):
     """FP_filter_v1.eval_sig (FP:106-123)."""
     from oracle import oracle
-    rng = np.random.default_rng(101)
-    for case in range(80):
+    rng = np.random.default_rng(101 + SEED)
+    for case in range(80 * SCALE):
         nc, ns = int(rng.integers(1, 200)), int(rng.integers(0, 2000))
         span = int(rng.choice([2000, 20000, 200000]))
         cpos, clen = rng.integers(0, span, nc), rng.integers(1, 600, nc)
@@ -33,8 +38,8 @@ def test_support_join_random(eng):
 def test_signature_coverage_random(eng):
     """calc_ins_call_cov / calc_del_call_cov (calculate_signature_support.py:81-125, 138-280)."""
     from oracle import oracle
-    rng = np.random.default_rng(102)
-    for case in range(80):
+    rng = np.random.default_rng(102 + SEED)
+    for case in range(80 * SCALE):
         nc, ns = int(rng.integers(1, 150)), int(rng.integers(0, 1500))
         span = int(rng.choice([3000, 30000, 300000]))
         fl = int(rng.choice([1000, 0, 10, 5000]))
@@ -55,8 +60,8 @@ def test_signature_coverage_random(eng):
 def test_redundancy_pairs_random(eng):
     """remove_redundancy.py match_del_chr / match_ins_chr (RR:75-125): windowed pairs, DEL overlap / size tests, INS edit distance."""
     from oracle import oracle
-    rng = np.random.default_rng(103)
-    for case in range(60):
+    rng = np.random.default_rng(103 + SEED)
+    for case in range(60 * SCALE):
         n = int(rng.integers(1, 120))
         span = int(rng.choice([500, 5000, 50000]))
         pos = np.sort(rng.integers(0, span, n))
@@ -90,8 +95,8 @@ def test_cutesv_split_random(eng):
     strands, overlapping and gapped on the read and on the reference."""
     from oracle import oracle
     from volcanosv_amd.sig_extract import SplitSegments
-    rng = np.random.default_rng(104)
-    for case in range(60):
+    rng = np.random.default_rng(104 + SEED)
+    for case in range(60 * SCALE):
         reads = []
         for r in range(int(rng.integers(1, 80))):
             ql = int(rng.integers(2000, 30000))
@@ -136,9 +141,9 @@ def test_bnd_segments_and_pairing_random(eng):
     breakpoints near contig ends, partitions from singletons to more than ten members, every tolerance varied."""
     from oracle import oracle
     from volcanosv_amd import bnd
-    rng = np.random.default_rng(105)
+    rng = np.random.default_rng(105 + SEED)
     n_cand = n_calls = 0
-    for case in range(80):
+    for case in range(80 * SCALE):
         nt = int(rng.integers(1, 5))
         names = list(rng.permutation(["chr1", "chr2", "chr10", "chrX", "chr21"])[:nt])
         contigs = [(str(nm), int(rng.integers(50_000, 400_000))) for nm in names]
