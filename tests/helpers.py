@@ -185,7 +185,26 @@ def fuzz_case_collectors(case, rng):
     return soa, dtype, p
 
 
-FUZZ = {"basic": (fuzz_case_basic, 20250403, 240), "defects": (fuzz_case_defects, 77, 300), "collectors": (fuzz_case_collectors, 5, 200)}
+def fuzz_case_dense(case, rng):
+    """Contig-shaped records (thousands of ops each) piled on a short chromosome at recurring sites: sorted lists with runs of tens
+    to thousands of rows inside the cluster / pairing distance, which is what the wave-cooperative cluster_long / pair_long
+    kernels exist for; cluster and pairing distances varied."""
+    from volcanosv_amd import synth
+    from volcanosv_amd.abi import DTYPE_HIFI, DTYPE_ONT
+    from volcanosv_amd.engine import default_params
+    n = int(rng.integers(100, 500))
+    t, nq, _ = synth.generate(n, "contig", seed=17000 + case + _SOAK, chrom_len=int(rng.choice([200_000, 300_000, 1_000_000])),
+                              site_step=int(rng.choice([200, 1000])))
+    soa = synth.to_soa(t, nq)
+    dtype = (DTYPE_HIFI, DTYPE_ONT)[int(rng.integers(0, 2))]
+    p = default_params(dtype)
+    p.cluster_shift = int(rng.choice([100, 300, 1000]))
+    p.pair_shift = int(rng.choice([200, 1000, 2000]))
+    p.pair_window = int(rng.choice([1000, 300, 5000]))
+    return soa, dtype, p
+
+
+FUZZ = {"dense": (fuzz_case_dense, 9, 12), "basic": (fuzz_case_basic, 20250403, 240), "defects": (fuzz_case_defects, 77, 300), "collectors": (fuzz_case_collectors, 5, 200)}
 
 
 def fuzz_cases(kind, upto=None):

@@ -161,7 +161,7 @@ def test_tid_hint_trims_keys_without_changing_results(eng):
     assert_tables_equal(eng.tables(DTYPE_HIFI), base, list(base.keys()))
 
 
-@pytest.mark.parametrize("kind,min_ok,min_err", [("basic", 150, 5), ("defects", 150, 40), ("collectors", 190, 0)])
+@pytest.mark.parametrize("kind,min_ok,min_err", [("basic", 150, 5), ("defects", 150, 40), ("collectors", 190, 0), ("dense", 12, 0)])
 def test_random_small_inputs_statuses_and_tables(eng, kind, min_ok, min_err):
     """Hundreds of small random inputs (helpers.fuzz_case_basic / fuzz_case_defects: dense contigs where signatures collide,
     cluster and pair all the time; random tags, mapq, strands, data types, every threshold of vsv_params; planted defects that
