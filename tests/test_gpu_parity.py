@@ -192,6 +192,38 @@ def test_random_small_inputs_statuses_and_tables(eng, kind, min_ok, min_err):
         assert {0, -5, -6, -8} <= seen          # ok, reference_end assert, read-length assert, ZeroDivisionError
 
 
+def test_engines_in_flight_do_not_interfere():
+    """Three handles on three streams, each with a different input in flight at the same time (run_async, then finish): every
+    engine returns the tables of its own input. Handles share nothing (include/volcanosv.h: no global mutable state)."""
+    import torch
+    from helpers import fuzz_cases
+    from volcanosv_amd.engine import Engine
+    cases = [c for c in fuzz_cases("basic", upto=89)]
+    want = {}
+    for case, soa, dtype, p in cases:
+        want[case] = oracle_run(soa, dtype, p)
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    engs = [Engine(0, stream=s.cuda_stream) for s in streams]
+    try:
+        n_ok = 0
+        for i in range(0, len(cases), 3):
+            batch = cases[i:i + 3]
+            started = []
+            for e, (case, soa, dtype, p) in zip(engs, batch):
+                if want[case][0] == 0:
+                    e.run_async(soa, p)
+                    started.append((e, case, dtype))
+            for e, case, dtype in started:
+                e.finish()
+                got = e.tables(dtype)
+                assert_tables_equal(got, want[case][1], list(got.keys()))
+                n_ok += 1
+        assert n_ok > 60
+    finally:
+        for e in engs:
+            e.close()
+
+
 def test_long_records_with_both_haplotype_tags(eng):
     """Mb-scale records (every chunk of the scan lies inside one record) whose names carry hp1 AND hp2
     on every third record (two rows per signature), plus a low-mapq record and the reads / svim / collector op tables."""
