@@ -190,13 +190,13 @@ def fuzz_case_dense(case, rng):
     to thousands of rows inside the cluster / pairing distance, which is what the wave-cooperative cluster_long / pair_long
     kernels exist for; cluster and pairing distances varied."""
     from volcanosv_amd import synth
-    from volcanosv_amd.abi import DTYPE_HIFI, DTYPE_ONT
+    from volcanosv_amd.abi import DTYPE_CLR, DTYPE_HIFI, DTYPE_ONT
     from volcanosv_amd.engine import default_params
     n = int(rng.integers(100, 500))
     t, nq, _ = synth.generate(n, "contig", seed=17000 + case + _SOAK, chrom_len=int(rng.choice([200_000, 300_000, 1_000_000])),
                               site_step=int(rng.choice([200, 1000])))
     soa = synth.to_soa(t, nq)
-    dtype = (DTYPE_HIFI, DTYPE_ONT)[int(rng.integers(0, 2))]
+    dtype = (DTYPE_HIFI, DTYPE_ONT, DTYPE_CLR)[int(rng.integers(0, 3))]
     p = default_params(dtype)
     p.cluster_shift = int(rng.choice([100, 300, 1000]))
     p.pair_shift = int(rng.choice([200, 1000, 2000]))

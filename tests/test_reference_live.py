@@ -59,6 +59,14 @@ def test_contig_path_on_fresh_random_inputs(style):
         st, tabs = oracle.run(soa, dtype=DTYPE_BY_NAME[style])
         assert st == 0, (style, seed)
         compare_contig_tables({"expected": exp}, soa, tabs)
+        # the VCF text of write_vcf (H:678-714): REF / ALT from the same synthetic sequences, ids, INFO, genotype
+        import test_vcf_bam as tv
+        from volcanosv_amd import vcf
+        dc_contig = tv.fixture_inputs({"records": recs})
+        for t, chrom in enumerate(exp["chroms"]):
+            calls = tabs["calls"][tabs["calls"]["sig"]["tid"] == t]
+            lines = vcf.vcf_lines(soa, calls, tabs["merged"], tv.synth_seq(chrom), dc_contig)
+            assert tv.digest(lines) == [list(r) for r in mg.jsonable(exp["per_chrom"][chrom]["vcf"])], (style, seed, chrom)
         n_calls += len(tabs["calls"])
     assert n_calls > 100
 

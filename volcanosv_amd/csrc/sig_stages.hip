@@ -107,32 +107,40 @@ __global__ __launch_bounds__(256) void combine_kernel(vsv_sig* __restrict__ s, c
   }
 }
 
-// ---- CLR gate: one wave per haplotype-tagged record, BEFORE the scan ----------------------------------
+// ---- CLR gate: every haplotype-tagged record, BEFORE the scan -----------------------------------------
 // C:422-427 computes ins_pct / var_dist for every record whose name carries the haplotype tag (whatever its mapq: a record
 // without M ops raises ZeroDivisionError there) and only walks the CIGAR - and asserts reference_end - when the gate passes.
 // The scan therefore reads a gated copy of the flag bytes: haplotype bits cleared where the gate fails. The split stage
 // (C:453-457) is not gated and keeps the caller's flags.
+// G lanes per record: 64 for contig-like records (thousands of ops), 8 for read-like ones (tens of ops, eight records per wave).
+template <int G>
 __global__ __launch_bounds__(256) void clr_gate_records(RecView rv, uint8_t* __restrict__ gflag, Counters* ctr) {
-  const int lane = threadIdx.x & 63;
-  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
-  for (int64_t rec = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); rec < rv.n_records; rec += nwaves) {
-    const uint8_t fl = rv.flag[rec];
+  const int lane = threadIdx.x & 63, sub = lane & (G - 1);
+  constexpr int PER_WAVE = 64 / G;
+  const int64_t ngroups = (int64_t)gridDim.x * (blockDim.x >> 6) * PER_WAVE;
+  const int64_t g0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * PER_WAVE + lane / G;
+  const int64_t rounds = (rv.n_records + ngroups - 1) / ngroups;          // every lane of a wave takes the same number of rounds
+  for (int64_t r = 0; r < rounds; ++r) {
+    const int64_t rec = g0 + r * ngroups;
+    const bool live = rec < rv.n_records;
+    const uint8_t fl = live ? rv.flag[rec] : 0;
     uint8_t out = fl;
-    if (fl & (VSV_F_HP1 | VSV_F_HP2)) {
-      const uint64_t a = rv.cigar_off[rec], b = rv.cigar_off[rec + 1];
-      int64_t ins = 0, m = 0, nm = 0;
-      for (uint64_t k = a + lane; k < b; k += 64) {
-        const uint32_t w = rv.cigar[k], op = w & 15u;
-        if (op == 0) { m += w >> 4; nm++; } else if (op == 1) ins += w >> 4;
-      }
-      ins = wave_sum64(ins); m = wave_sum64(m); nm = wave_sum64(nm);
+    const bool tagged = live && (fl & (VSV_F_HP1 | VSV_F_HP2));
+    const uint64_t a = tagged ? rv.cigar_off[rec] : 0, b = tagged ? rv.cigar_off[rec + 1] : 0;
+    int64_t ins = 0, m = 0, nm = 0;
+    for (uint64_t k = a + sub; k < b; k += G) {
+      const uint32_t w = rv.cigar[k], op = w & 15u;
+      if (op == 0) { m += w >> 4; nm++; } else if (op == 1) ins += w >> 4;
+    }
+#pragma unroll
+    for (int d = G >> 1; d > 0; d >>= 1) { ins += __shfl_xor(ins, d, 64); m += __shfl_xor(m, d, 64); nm += __shfl_xor(nm, d, 64); }
+    if (tagged && b > a) {                                                // an empty CIGAR is the scan's error to report
       bool pass;
-      if (b <= a) pass = true;                                            // empty CIGAR: the scan reports it
-      else if (m + ins == 0 || nm == 0) { if (lane == 0) atomicOr(&ctr->err, ERRB_ZERODIV); pass = false; }
+      if (m + ins == 0 || nm == 0) { if (sub == 0) atomicOr(&ctr->err, ERRB_ZERODIV); pass = false; }
       else pass = (100 * ins <= 13 * (m + ins)) || (m >= 200 * nm);       // CLR.py:61, 70, 427 in exact integers
       if (!pass) out = fl & (uint8_t)~(VSV_F_HP1 | VSV_F_HP2);
     }
-    if (lane == 0) gflag[rec] = out;
+    if (live && sub == 0) gflag[rec] = out;
   }
 }
 
@@ -724,7 +732,9 @@ constexpr int LONG_GRID = 2048;   // wave-per-run kernels: enough waves to fill 
 
 // ======================================= host-side launchers ==========================================
 void vsv_launch_clr_gate(hipStream_t st, const RecView& rv, uint8_t* gflag, Counters* ctr) {
-  if (rv.n_records > 0) clr_gate_records<<<2048, 256, 0, st>>>(rv, gflag, ctr);
+  if (rv.n_records <= 0) return;
+  if (rv.n_ops / rv.n_records >= 256) clr_gate_records<64><<<2048, 256, 0, st>>>(rv, gflag, ctr);
+  else clr_gate_records<8><<<2048, 256, 0, st>>>(rv, gflag, ctr);
 }
 
 void vsv_launch_fold(hipStream_t st, vsv_sig* raw, vsv_sig* raw_copy, const RecView& rv, const vsv_params& p, Counters* ctr) {
