@@ -73,7 +73,9 @@ typedef struct vsv_records {
   const uint8_t* mapq;         /* [n]                                                              */
   const uint8_t* flag;         /* [n]   VSV_F_* bits                                               */
   const uint32_t* cigar;       /* [n_ops] BAM packing: len<<4 | op ; 16-byte aligned               */
-  int32_t on_device;           /* 0: host pointers (library uploads), 1: device pointers           */
+  int32_t on_device;           /* 0: host pointers (library uploads), 1: device pointers — their contents must be complete
+                                  before the call: the library reads them on the handle's stream and does not know the
+                                  stream that produced them                                          */
   int32_t n_qids;              /* max qid + 1 (required when n_records > 0)                            */
   int32_t n_tids;              /* max tid + 1; 0 = unknown (16 key bits are reserved for it)       */
   int32_t max_pos;             /* upper bound of pos (e.g. contig length); 0 = unknown. Only trims sort passes. */

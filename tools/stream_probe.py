@@ -9,14 +9,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 from volcanosv_amd import synth  # noqa: E402
-from volcanosv_amd.abi import DTYPE_HIFI  # noqa: E402
+from volcanosv_amd.abi import DTYPE_BY_NAME  # noqa: E402
 from volcanosv_amd.engine import DeviceRecords, Engine, default_params  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 t, nq, nt = synth.generate(n, "hifi", seed=5, device="cuda")
 dr = DeviceRecords(t, nq, nt)
-p = default_params(DTYPE_HIFI)
+p = default_params(DTYPE_BY_NAME[sys.argv[3] if len(sys.argv) > 3 else "Hifi"])
 for S in (1, 2, 3, 4, 6):
     streams = [torch.cuda.Stream() for _ in range(S)]
     engs = [Engine(0, stream=s.cuda_stream) for s in streams]

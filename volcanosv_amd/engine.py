@@ -32,6 +32,9 @@ class DeviceRecords:
     def __init__(self, tensors, n_qids=0, n_tids=0, max_pos=0, tid_lo=0):
         """max_pos / tid_lo are the sort-key hints of vsv_records: positions <= max_pos, tids in [tid_lo, n_tids)."""
         self.t = tensors
+        # the engine reads these arrays on ITS stream: whatever produced them (normally torch's current stream) must be done
+        import torch
+        torch.cuda.current_stream(tensors["pos"].device).synchronize()
         self.max_pos, self.tid_lo = int(max_pos), int(tid_lo)
         self.n_records = int(tensors["pos"].numel())
         self.n_ops = int(tensors["cigar"].numel())
