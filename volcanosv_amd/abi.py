@@ -24,6 +24,8 @@ STATUS = {
     -5: "VSV_E_REFEND", -6: "VSV_E_READLEN", -7: "VSV_E_UNSORTED", -8: "VSV_E_ZERODIV", -9: "VSV_E_NO_DEVICE",
 }
 
+E_CAPACITY = -3        # vsv_status values the wrappers act on (the rest only travel inside VsvError)
+
 SIG_DTYPE = np.dtype([
     ("pos", "<i4"), ("svlen", "<i4"), ("q_start", "<i4"), ("q_end", "<i4"),
     ("rec", "<u4"), ("rec2", "<u4"), ("meta", "<u4"), ("tid", "<i4"),

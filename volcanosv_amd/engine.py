@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .abi import (BND_DTYPE, T_BND_CALLS, T_BND_CAND, T_CUTESV_SPLIT, BndParams, RedundancyParams, SupportParams, CALL_DTYPE, SIG_DTYPE, T_CALLS, T_CIGAR, T_CLUSTER1, T_MERGED, T_RAW, T_READS, T_SPLIT, DTYPE_BY_NAME,
+from .abi import (BND_DTYPE, E_CAPACITY, T_BND_CALLS, T_BND_CAND, T_CUTESV_SPLIT, BndParams, RedundancyParams, SupportParams, CALL_DTYPE, SIG_DTYPE, T_CALLS, T_CIGAR, T_CLUSTER1, T_MERGED, T_RAW, T_READS, T_SPLIT, DTYPE_BY_NAME,
                   DTYPE_CUTESV, DTYPE_READS, DTYPE_SVIM, Params, Records, VsvError)
 
 _TABLE_IDS = {"raw": T_RAW, "cigar": T_CIGAR, "split": T_SPLIT, "cluster1": T_CLUSTER1, "merged": T_MERGED,
@@ -186,7 +186,7 @@ class Engine:
                                                None if is_del else seq.ctypes.data_as(C.c_void_p),
                                                None if is_del else seq_off.ctypes.data_as(C.c_void_p), len(pos), C.byref(p),
                                                out.ctypes.data_as(C.c_void_p), cap, C.byref(n))
-            if st == -3 and n.value > cap:          # VSV_E_CAPACITY: retry with the reported size
+            if st == E_CAPACITY and n.value > cap:  # retry with the reported size
                 cap = int(n.value)
                 continue
             self._check(st)
