@@ -398,6 +398,16 @@ def test_capacity_overflow_reports_required_count():
         assert np.array_equal(e.table("calls"), want["calls"])
     finally:
         e.close()
+    # grow=True (what the drivers use): the same overflow is answered by reserving the reported count and running again,
+    # synchronously or at finish() of an asynchronous run
+    for use_async in (False, True):
+        with Engine(0, max_sigs=2048, grow=True) as g:
+            if use_async:
+                g.run_async(soa, default_params(DTYPE_HIFI))
+                g.finish()
+            else:
+                g.run(soa, default_params(DTYPE_HIFI))
+            assert np.array_equal(g.table("calls"), want["calls"]) and np.array_equal(g.table("raw"), want["raw"])
 
 
 def test_full_size_config2_properties(eng):

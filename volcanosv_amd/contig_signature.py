@@ -27,7 +27,7 @@ def run(dtype_name, bam_path, contig_path, ref_path, output_dir, chr_number=None
     chroms = [chr_number] if chr_number is not None else list(range(1, 23))
     # two engines (handle + HIP stream each) alternate over the chromosomes: the GPU works on chromosome i+1 while the host
     # formats the VCF of chromosome i, and the latency-bound stages of one overlap the CIGAR scan of the other
-    engs = [engine] if engine is not None else [Engine(device), Engine(device, stream=_side_stream(device))]
+    engs = [engine] if engine is not None else [Engine(device, grow=True), Engine(device, stream=_side_stream(device), grow=True)]
     p = params or default_params(dtype)
     out = {}
 

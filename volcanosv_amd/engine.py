@@ -51,7 +51,11 @@ class DeviceRecords:
 
 
 class Engine:
-    def __init__(self, device=0, stream=None, max_sigs=None):
+    def __init__(self, device=0, stream=None, max_sigs=None, grow=False):
+        """grow: when a run needs more signature rows than reserved (VSV_E_CAPACITY), reserve what the library reports and run the
+        same input again instead of raising (the drivers use it; the reference has no such limit)."""
+        self.grow = bool(grow)
+        self._last = None
         self.lib = _lib.load()
         self.h = C.c_void_p()
         st = self.lib.vsv_create(int(device), C.c_void_p(stream or 0), C.byref(self.h))
@@ -109,16 +113,29 @@ class Engine:
     def pair_haplotypes(self, params=None):
         self._check(self.lib.vsv_pair_haplotypes(self.h, C.byref(params) if params is not None else None))
 
+    def _regrow(self, st):
+        """VSV_E_CAPACITY with grow=True: reserve 1.25 x the reported row count and run the last input synchronously."""
+        for _ in range(4):
+            if st != E_CAPACITY or not self.grow or self._last is None:
+                break
+            self.reserve(0, 0, int(self.last_count() * 1.25) + 1024)
+            soa, params = self._last
+            r = self._recs(soa)
+            st = self.lib.vsv_run_chromosome(self.h, C.byref(r), C.byref(params))
+        self._check(st)
+
     def run(self, soa, params):
         r = self._recs(soa)
-        self._check(self.lib.vsv_run_chromosome(self.h, C.byref(r), C.byref(params)))
+        self._last = (soa, params)
+        self._regrow(self.lib.vsv_run_chromosome(self.h, C.byref(r), C.byref(params)))
 
     def run_async(self, soa, params):
         r = self._recs(soa)
+        self._last = (soa, params)
         self._check(self.lib.vsv_run_chromosome_async(self.h, C.byref(r), C.byref(params)))
 
     def finish(self):
-        self._check(self.lib.vsv_finish(self.h))
+        self._regrow(self.lib.vsv_finish(self.h))
 
     # ---- Complex_SV breakend branch (svim_asm/SVIM_inter.py, SVIM_COMBINE.py) ----------------------------------------
     def bnd(self, seg, params=None):

@@ -14,7 +14,7 @@ def run(input_path, output_dir, chr_number, device=0, engine=None, params=None, 
     chrom = "chr%d" % chr_number
     out_dir = os.path.join(output_dir, "reads_signature")
     os.makedirs(out_dir, exist_ok=True)
-    eng = engine or Engine(device)
+    eng = engine or Engine(device, grow=True)
     p = params or default_params(DTYPE_READS)
     with BamFile(input_path) as bam:
         if device_ingest:

@@ -237,7 +237,7 @@ def run(input_bam, reference, work_dir, batches=10000000, max_split_parts=7, min
         raise FileNotFoundError("[Errno 2] No such file: '%s'" % reference)
     os.makedirs(work_dir, exist_ok=True)
     out_dir = work_dir if work_dir.endswith('/') else work_dir + '/'
-    eng = engine or Engine(device)
+    eng = engine or Engine(device, grow=True)
     p = params(min_siglength, min_mapq, merge_del_threshold, merge_ins_threshold)
     ins_lines, del_lines, task_reads = [], [], {}
     try:
