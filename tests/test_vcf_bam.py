@@ -141,6 +141,20 @@ def test_reads_signature_lines_column_wise_equal_row_wise():
     assert sigtable.reads_sig_lines(soa, tab[:0]) == []
 
 
+def test_host_reader_survives_corrupted_files():
+    """Semantically corrupted BAM streams (valid BGZF framing; random bytes, length-like fields, deleted stretches inside the
+    records, the header or a CG:B,I long CIGAR) either load or raise — the native reader never crashes or reads outside a record.
+    The worker runs in its own process so a crash is an exit code."""
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_corrupt_bam_worker.py")
+    for seed in (1, 2, 3):
+        r = subprocess.run([sys.executable, worker, str(seed), "120"], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (seed, r.returncode, r.stderr[-400:])
+        ok, err = int(r.stdout.split()[1]), int(r.stdout.split()[3])
+        assert ok + err == 120 and err > 20
+
+
 @pytest.mark.gpu
 def test_cli_reads_signature(tmp_path):
     import subprocess

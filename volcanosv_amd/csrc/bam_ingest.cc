@@ -162,13 +162,16 @@ bool read_header(vsv_bam* b) {
   if (!rd_bytes(b, magic, 4) || memcmp(magic, "BAM\1", 4) != 0) { b->err = "bad BAM magic"; return false; }
   int32_t l_text;
   if (!rd_bytes(b, &l_text, 4)) return false;
+  if (l_text < 0 || l_text > (1 << 30)) { b->err = "bad BAM header length"; return false; }
   b->header_text.resize(l_text);
   if (l_text && !rd_bytes(b, &b->header_text[0], l_text)) return false;
   int32_t n_ref;
   if (!rd_bytes(b, &n_ref, 4)) return false;
+  if (n_ref < 0 || n_ref > (1 << 24)) { b->err = "bad BAM reference count"; return false; }
   for (int i = 0; i < n_ref; ++i) {
     int32_t l_name, l_ref;
     if (!rd_bytes(b, &l_name, 4)) return false;
+    if (l_name < 1 || l_name > (1 << 16)) { b->err = "bad BAM reference name length"; return false; }
     std::string name(l_name, '\0');
     if (!rd_bytes(b, &name[0], l_name)) return false;
     if (!name.empty() && name.back() == '\0') name.pop_back();
@@ -221,7 +224,7 @@ namespace {
 struct RecRef { size_t off; uint32_t size; uint32_t n_cig_out; uint64_t cig_off; uint64_t seq_off; };
 struct RecAux { uint64_t name_hash; const char* sa; uint32_t sa_len; const uint8_t* cg_long; };
 
-// walks the tag area of one record; returns false on an unknown tag type
+// walks the tag area of one record; returns false on an unknown tag type or a tag that does not end inside the record
 bool walk_tags(const uint8_t* rec, size_t off, size_t block_size, const char** sa_p, uint32_t* sa_len, const uint8_t** cg_long, uint32_t* n_long) {
   while (off + 3 <= block_size) {
     const char t0 = rec[off], t1 = rec[off + 1], ty = rec[off + 2];
@@ -231,18 +234,22 @@ bool walk_tags(const uint8_t* rec, size_t off, size_t block_size, const char** s
       case 'A': case 'c': case 'C': len = 1; break;
       case 's': case 'S': len = 2; break;
       case 'i': case 'I': case 'f': len = 4; break;
-      case 'Z': case 'H': { size_t e = off; while (e < block_size && rec[e]) ++e; if (t0 == 'S' && t1 == 'A' && ty == 'Z') { *sa_p = (const char*)&rec[off]; *sa_len = (uint32_t)(e - off); } len = e - off + 1; break; }
+      case 'Z': case 'H': { size_t e = off; while (e < block_size && rec[e]) ++e; if (e >= block_size) return false; if (t0 == 'S' && t1 == 'A' && ty == 'Z') { *sa_p = (const char*)&rec[off]; *sa_len = (uint32_t)(e - off); } len = e - off + 1; break; }
       case 'B': {
+        if (off + 5 > block_size) return false;
         const char sub = rec[off]; uint32_t cnt; memcpy(&cnt, &rec[off + 1], 4);
         const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+        len = 5 + es * (size_t)cnt;
+        if (len > block_size - off) return false;          // the array must end inside the record
         if (t0 == 'C' && t1 == 'G' && sub == 'I') { *cg_long = &rec[off + 5]; *n_long = cnt; }
-        len = 5 + es * cnt; break;
+        break;
       }
       default: return false;
     }
+    if (len > block_size - off) return false;              // a value that runs past the record
     off += len;
   }
-  return true;
+  return off == block_size;                                  // 1-2 stray bytes after the last tag are malformed too
 }
 }  // namespace
 
@@ -300,6 +307,11 @@ int vsv_bam_load(vsv_bam* b, int tid, vsv_records* out) {
       if (rd + 4 + (size_t)bs > end) break;                       // partial record: next window
       const uint8_t* rec = base + rd + 4;
       int32_t refID; memcpy(&refID, &rec[0], 4);
+      {   // the variable-length fields must fit the record (every later access relies on it)
+        uint16_t nc; memcpy(&nc, &rec[12], 2);
+        int32_t ls; memcpy(&ls, &rec[16], 4);
+        if (ls < 0 || 32ull + rec[8] + 4ull * nc + (uint64_t)((ls + 1ll) / 2) + (uint64_t)ls > (uint64_t)bs) { b->err = "malformed BAM record"; return VSV_E_INVALID; }
+      }
       if (!(refID < 0 || (tid >= 0 && refID != tid))) {
         uint16_t n_cig; memcpy(&n_cig, &rec[12], 2);
         int32_t l_seq; memcpy(&l_seq, &rec[16], 4);
@@ -308,7 +320,7 @@ int vsv_bam_load(vsv_bam* b, int tid, vsv_records* out) {
           const uint8_t l_read_name = rec[8];
           const char* sp = nullptr; uint32_t sl = 0; const uint8_t* cgl = nullptr; uint32_t nl = 0;
           const size_t toff = 32 + (size_t)l_read_name + 8u + (size_t)((l_seq + 1) / 2) + (size_t)l_seq;
-          if (!walk_tags(rec, toff, (size_t)bs, &sp, &sl, &cgl, &nl)) { b->err = "unknown BAM tag type"; return VSV_E_INVALID; }
+          if (!walk_tags(rec, toff, (size_t)bs, &sp, &sl, &cgl, &nl)) { b->err = "unknown or malformed BAM tag"; return VSV_E_INVALID; }
           if (cgl) n_out = nl;
         }
         refs.push_back(RecRef{rd + 4, (uint32_t)bs, n_out, cig_total, seq_total});
@@ -371,7 +383,7 @@ int vsv_bam_load(vsv_bam* b, int tid, vsv_records* out) {
       for (int t = 1; t < use; ++t) pool.emplace_back(work);
       work();
       for (auto& th : pool) th.join();
-      if (!ok) { b->err = "unknown BAM tag type"; return VSV_E_INVALID; }
+      if (!ok) { b->err = "unknown or malformed BAM tag"; return VSV_E_INVALID; }
       t_par += now() - tq; tq = now();
       // ---- (3) sequential: name interning in file order, SA text -----------------------------------------------
       for (size_t k = 0; k < nw; ++k) {
