@@ -262,3 +262,19 @@ def test_device_reader_equals_host_reader_on_random_files(tmp_path, monkeypatch)
                         assert np.array_equal(getattr(host, name), getattr(dev, name)), (case, chrom, name)
                     assert list(host.qnames) == list(dev.qnames), (case, chrom)
         monkeypatch.delenv("VSV_BAM_WINDOW")
+
+
+@pytest.mark.gpu
+def test_device_reader_survives_corrupted_files():
+    """The corrupted streams of tests/_corrupt_bam_worker.py through the device reader (own process: a GPU fault is an exit code):
+    every file either parses to the host reader's arrays, or is handed to the host reader, or raises — no kernel reads outside a
+    record (rec_fields checks that name, CIGAR, SEQ and a CG:B,I array fit their record before anything dereferences them)."""
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_corrupt_bam_device_worker.py")
+    for seed in (5, 6):
+        r = subprocess.run([sys.executable, worker, str(seed), "100"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (seed, r.returncode, r.stderr[-600:])
+        f = r.stdout.split()
+        same, raised = int(f[1]), int(f[5])
+        assert same > 20 and raised > 20

@@ -105,6 +105,12 @@ __global__ __launch_bounds__(256) void rec_fields(const uint8_t* __restrict__ s,
   const uint32_t l_name = r[12], nc = ld16(r + 16), fl = ld16(r + 18);
   const int32_t ls = (int32_t)ld32(r + 20);
   pos[i] = (int32_t)ld32(r + 8); tid[i] = ref; mapq[i] = r[13]; l_seq[i] = (uint32_t)ls; sam_flag[i] = fl;
+  // the variable-length fields must fit the record: every later access (name, CIGAR, tags) relies on it
+  if (ls < 0 || 32ull + l_name + 4ull * nc + (uint64_t)((ls + 1ll) / 2) + (uint64_t)ls > (uint64_t)bs) {
+    atomicOr(err, 4u);
+    flag[i] = 0; hash[i] = 0; n_cig_out[i] = 0; cg_src[i] = 0; keep[i] = 0;
+    return;
+  }
   const uint8_t* name = r + 36;
   const uint32_t nlen = l_name ? l_name - 1u : 0u;
   uint64_t h = 1469598103934665603ull;
@@ -134,10 +140,12 @@ __global__ __launch_bounds__(256) void rec_fields(const uint8_t* __restrict__ s,
       else if (ty == 'i' || ty == 'I' || ty == 'f') len = 4;
       else if (ty == 'Z' || ty == 'H') { uint64_t e = off; while (e < end && r[e]) ++e; len = e - off + 1; }
       else if (ty == 'B') {
+        if (off + 5 > end) { atomicOr(err, 4u); break; }
         const uint8_t sub = r[off]; const uint32_t cnt = ld32(r + off + 1);
         const uint64_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
-        if (t0 == 'C' && t1 == 'G' && sub == 'I') { src = (uint64_t)(r + off + 5 - s); n_out = cnt; }
         len = 5 + es * cnt;
+        if (len > end - off) { atomicOr(err, 4u); break; }                        // the array must end inside the record
+        if (t0 == 'C' && t1 == 'G' && sub == 'I') { src = (uint64_t)(r + off + 5 - s); n_out = cnt; }
       } else { atomicOr(err, 1u); break; }
       off += len;
     }

@@ -846,6 +846,7 @@ int vsv_bam_parse_device(vsv_handle* h, const uint8_t* comp, const uint64_t* com
       HIPCHK(h, hipMemcpyAsync(&err, h->p_err.p, 4, hipMemcpyDeviceToHost, st));
       HIPCHK(h, hipStreamSynchronize(st));
       if (err & 1u) return fail(h, VSV_E_INVALID, "unknown BAM tag type");
+      if (err & 4u) return fail(h, VSV_E_INVALID, "malformed BAM record (a field runs past its record): use the host reader");
       const uint64_t nk = (uint64_t)last_k + last_keep;
       if (nk > 0) {
         const size_t K = (size_t)(K0 + nk);
