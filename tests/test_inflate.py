@@ -278,3 +278,17 @@ def test_device_reader_survives_corrupted_files():
         f = r.stdout.split()
         same, raised = int(f[1]), int(f[5])
         assert same > 20 and raised > 20
+
+
+@pytest.mark.gpu
+def test_inflate_survives_corrupted_payloads():
+    """Bit flips, truncations, garbage and lying sizes in raw-deflate payloads (tests/_corrupt_inflate_worker.py, own process): the
+    GPU decoder equals zlib whenever zlib decodes to exactly the announced size and reports the member otherwise."""
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_corrupt_inflate_worker.py")
+    for seed in (2, 3):
+        r = subprocess.run([sys.executable, worker, str(seed), "150"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (seed, r.returncode, r.stderr[-600:])
+        f = r.stdout.split()
+        assert int(f[1]) > 30 and int(f[3]) > 30
