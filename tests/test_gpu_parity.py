@@ -377,6 +377,22 @@ def test_error_statuses(eng):
     with pytest.raises(VsvError) as e:
         eng.run(soa, default_params(DTYPE_HIFI))
     assert e.value.status == -4
+    # caller bugs the kernels must survive: a query id beyond n_qids (the name table has no bit for it), CIGAR offsets that run
+    # past the array (CLR walks every tagged record's CIGAR before the scan reports them)
+    from volcanosv_amd import synth
+    t, nq, _ = synth.generate(5000, "hifi", seed=77, chrom_len=2_000_000)
+    good = synth.to_soa(t, nq)
+    good.n_qids = 100
+    with pytest.raises(VsvError) as e:
+        eng.run(good, default_params(DTYPE_HIFI))
+    assert e.value.status == -1 and "qid" in str(e.value)
+    good.n_qids = nq
+    off = good.cigar_off.copy()
+    off[1000:2000] += np.uint64(1 << 40)
+    good.cigar_off = off
+    for dt in (DTYPE_CLR, DTYPE_HIFI):
+        with pytest.raises(VsvError):
+            eng.run(good, default_params(dt))
 
 
 def test_capacity_overflow_reports_required_count():

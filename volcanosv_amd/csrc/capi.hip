@@ -301,7 +301,7 @@ int finish(vsv_handle* h) {
     return fail(h, VSV_E_CAPACITY, b);
   }
   if (e & ERRB_EMPTY_CIGAR) return fail(h, VSV_E_EMPTY_CIGAR, "record with no CIGAR ops / cigar_off not increasing");
-  if (e & ERRB_RANGE) return fail(h, VSV_E_INVALID, "a part spans >= 2^30 CIGAR ops, a position exceeds the max_pos hint, or a tid lies outside [tid_lo, n_tids)");
+  if (e & ERRB_RANGE) return fail(h, VSV_E_INVALID, "a part spans >= 2^30 CIGAR ops, a position exceeds the max_pos hint, a tid lies outside [tid_lo, n_tids), or a qid is >= n_qids");
   if (e & ERRB_REFEND) return fail(h, VSV_E_REFEND, "N/=/X op in an eligible record on the contig path (offset_ref != reference_end)");
   if (e & ERRB_ZERODIV) return fail(h, VSV_E_ZERODIV, "CLR gate on a record without M ops");
   if (e & ERRB_UNSORTED) return fail(h, VSV_E_UNSORTED, "split pair with pos1 > pos2");

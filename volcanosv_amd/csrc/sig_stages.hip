@@ -126,7 +126,8 @@ __global__ __launch_bounds__(256) void clr_gate_records(RecView rv, uint8_t* __r
     const uint8_t fl = live ? rv.flag[rec] : 0;
     uint8_t out = fl;
     const bool tagged = live && (fl & (VSV_F_HP1 | VSV_F_HP2));
-    const uint64_t a = tagged ? rv.cigar_off[rec] : 0, b = tagged ? rv.cigar_off[rec + 1] : 0;
+    uint64_t a = 0, b = 0;
+    if (tagged) vsv_op_range(rv, rec, a, b);
     int64_t ins = 0, m = 0, nm = 0;
     for (uint64_t k = a + sub; k < b; k += G) {
       const uint32_t w = rv.cigar[k], op = w & 15u;
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(1024) void qid_scan_max(uint32_t* __restrict__ tile
   }
 }
 __global__ __launch_bounds__(256) void qid_mark_dups(const uint32_t* __restrict__ qid, int64_t n, const uint32_t* __restrict__ tile_excl,
-                                                     uint32_t* __restrict__ dupbits, bool vec) {
+                                                     uint32_t* __restrict__ dupbits, bool vec, uint32_t n_qids, uint32_t* __restrict__ err) {
   __shared__ uint32_t sh[4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   uint32_t q[8], m = 0;
@@ -228,7 +229,8 @@ __global__ __launch_bounds__(256) void qid_mark_dups(const uint32_t* __restrict_
   for (int w = 0; w < wv; ++w) run = max(run, sh[w]);
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    if (q[k] != 0 && q[k] <= run) atomicOr(&dupbits[(q[k] - 1u) >> 5], 1u << ((q[k] - 1u) & 31u));
+    if (q[k] != 0 && q[k] - 1u >= n_qids) atomicOr(err, ERRB_RANGE);                 // qid outside [0, n_qids): the table has no bit for it
+    else if (q[k] != 0 && q[k] <= run) atomicOr(&dupbits[(q[k] - 1u) >> 5], 1u << ((q[k] - 1u) & 31u));
     run = max(run, q[k]);
   }
 }
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(256) void split_cand(RecView rv, SplitCfg c, const 
         const uint32_t fl = (fl4 >> (8 * j)) & 0xFFu, mq = (mq4 >> (8 * j)) & 0xFFu;
         e = (mq >= (uint32_t)c.min_mapq) ? (((fl & VSV_F_HP1) ? 1u : 0u) | ((fl & VSV_F_HP2) ? 2u : 0u)) : 0u;   // Hifi.py:425-427
       }
-      if (e && ((tab[q[k][j] >> 5] >> (q[k][j] & 31u)) & 1u)) m[k] |= e << (2 * j);
+      if (e && q[k][j] < (uint32_t)rv.n_qids && ((tab[q[k][j] >> 5] >> (q[k][j] & 31u)) & 1u)) m[k] |= e << (2 * j);
     }
     const uint32_t cc = (uint32_t)__popc(m[k]);
     uint32_t incl = cc;
@@ -354,7 +356,8 @@ __device__ __forceinline__ int64_t group_sum64(int64_t v) {
   return v;
 }
 __device__ __forceinline__ RecSum rec_summary(const RecView& rv, uint32_t r, bool reads, int lane) {
-  const uint64_t a = rv.cigar_off[r], b = rv.cigar_off[r + 1];
+  uint64_t a, b;
+  vsv_op_range(rv, r, a, b);
   int64_t rl = 0, rf = 0;
   for (uint64_t k = a + lane; k < b; k += SE_GROUP) {
     const uint32_t w = rv.cigar[k], op = w & 15u, len = w >> 4;
@@ -364,8 +367,8 @@ __device__ __forceinline__ RecSum rec_summary(const RecView& rv, uint32_t r, boo
   RecSum s;
   s.ref_len = group_sum64(rf);
   s.read_len = group_sum64(rl);
-  s.first = rv.cigar[a];
-  s.last = rv.cigar[b - 1];
+  s.first = b > a ? rv.cigar[a] : 0u;
+  s.last = b > a ? rv.cigar[b - 1] : 0u;
   return s;
 }
 
@@ -394,7 +397,10 @@ __global__ __launch_bounds__(256) void split_eval(RecView rv, const uint64_t* __
       else {
         const int minq = c.min_mapq;
         const uint32_t f1 = rv.flag[i1], f2 = rv.flag[i2];
-        const uint32_t last1 = rv.cigar[rv.cigar_off[i1 + 1] - 1], first2 = rv.cigar[rv.cigar_off[i2]];
+        uint64_t a1, b1, a2, b2;
+        vsv_op_range(rv, i1, a1, b1);
+        vsv_op_range(rv, i2, a2, b2);
+        const uint32_t last1 = b1 > a1 ? rv.cigar[b1 - 1] : 0u, first2 = b2 > a2 ? rv.cigar[a2] : 0u;
         const uint32_t lop = last1 & 15u, fop = first2 & 15u;
         if (((f1 ^ f2) & VSV_F_REVERSE) == 0 && rv.mapq[i1] >= minq && rv.mapq[i2] >= minq &&
             (lop == 4 || lop == 5) && (fop == 4 || fop == 5)) {                                  // Hifi.py:323-324
@@ -767,7 +773,7 @@ void vsv_launch_split(hipStream_t st, const RecView& rv, const vsv_params& p, in
     const bool vec = ((uintptr_t)rv.qid & 15u) == 0 && ((uintptr_t)rv.flag & 3u) == 0 && ((uintptr_t)rv.mapq & 3u) == 0;
     qid_tile_max<<<qtiles, 256, 0, st>>>(rv.qid, rv.n_records, blk_cnt, vec);
     qid_scan_max<<<1, 1024, 0, st>>>(blk_cnt, qtiles);
-    qid_mark_dups<<<qtiles, 256, 0, st>>>(rv.qid, rv.n_records, blk_cnt, tab, vec);
+    qid_mark_dups<<<qtiles, 256, 0, st>>>(rv.qid, rv.n_records, blk_cnt, tab, vec, (uint32_t)nq, &ctr->err);
     const int nblk = (int)(((uint64_t)rv.n_records + SC_TILE_REC - 1) / SC_TILE_REC);
     split_cand<false><<<nblk, 256, 0, st>>>(rv, c, tab, blk_cnt, ckey, crec, cap, vec, &ctr->err);
     vsv_scan_u32_exclusive(st, blk_cnt, nblk, blk_off, scan_tmp);

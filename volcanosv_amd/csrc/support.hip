@@ -212,7 +212,9 @@ __global__ __launch_bounds__(256) void ref_end_kernel(RecView rv, int32_t* __res
   uint32_t ms = 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rv.n_records; i += (int64_t)gridDim.x * blockDim.x) {
     int64_t span = 0;
-    for (uint64_t k = rv.cigar_off[i]; k < rv.cigar_off[i + 1]; ++k) {
+    uint64_t a, b;
+    vsv_op_range(rv, i, a, b);
+    for (uint64_t k = a; k < b; ++k) {
       const uint32_t w = rv.cigar[k], op = w & 15u;
       if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) span += w >> 4;
     }

@@ -50,6 +50,14 @@ struct RecView {
   int32_t tid_lo;   // keys carry tid - tid_lo
 };
 
+// CIGAR range [a, b) of record r, clamped to the caller's n_ops: offsets that do not ascend or run past the array are
+// reported by the scan (ERRB_EMPTY_CIGAR), and no other kernel follows them outside the array meanwhile.
+__device__ __forceinline__ void vsv_op_range(const RecView& rv, int64_t r, uint64_t& a, uint64_t& b) {
+  const uint64_t n = (uint64_t)rv.n_ops;
+  b = rv.cigar_off[r + 1]; if (b > n) b = n;
+  a = rv.cigar_off[r]; if (a > b) a = b;
+}
+
 // ---- sort keys: [tid | hap | type | source | pos], list id in the high bits ------------------------
 #define VSV_KEY_DEAD 0xFFFFFFFFFFFFFFFFull
 #define VSV_POS_BIAS 65536   // keys order positions >= -65536 (split DEL positions can dip slightly below 0)
