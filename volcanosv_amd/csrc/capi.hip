@@ -487,9 +487,24 @@ int vsv_default_bnd_params(vsv_bnd_params* p) {
   return 0;
 }
 
+// host-side segment tables: the offsets must tile [0, n_segs) and every reference id must index the contig tables
+static int validate_segments(vsv_handle* h, const vsv_segments* sg, bool check_tids) {
+  if (sg->on_device || sg->n_reads == 0) return 0;
+  if (!sg->seg_off || (sg->n_segs > 0 && (!sg->q_start || !sg->q_end || !sg->ref_id || !sg->ref_start || !sg->ref_end || !sg->is_reverse)))
+    return fail(h, VSV_E_INVALID, "segment arrays are NULL");
+  if (sg->seg_off[0] != 0 || sg->seg_off[sg->n_reads] != (uint64_t)sg->n_segs) return fail(h, VSV_E_INVALID, "seg_off does not span [0, n_segs)");
+  for (int64_t r = 0; r < sg->n_reads; ++r)
+    if (sg->seg_off[r + 1] < sg->seg_off[r]) return fail(h, VSV_E_INVALID, "seg_off does not ascend");
+  if (check_tids)
+    for (int64_t k = 0; k < sg->n_segs; ++k)
+      if (sg->ref_id[k] < 0 || sg->ref_id[k] >= sg->n_tids) return fail(h, VSV_E_INVALID, "segment reference id outside [0, n_tids)");
+  return 0;
+}
+
 int vsv_bnd_segments(vsv_handle* h, const vsv_segments* sg, const vsv_bnd_params* p) {
   if (!h || !sg || !p) return VSV_E_INVALID;
   if (sg->n_reads < 0 || sg->n_segs < sg->n_reads || sg->n_tids <= 0) return fail(h, VSV_E_INVALID, "bad segment counts");
+  { int vs = validate_segments(h, sg, true); if (vs) return vs; }
   HIPCHK(h, hipSetDevice(h->device));
   int st = reserve(h, 1, 1, h->cap_sigs > 0 ? h->cap_sigs : (1 << 22));
   if (st) return st;
@@ -526,6 +541,7 @@ int vsv_cutesv_split(vsv_handle* h, const vsv_segments* sg, const int32_t* read_
   if (!h || !sg) return VSV_E_INVALID;
   if (sg->n_reads < 0 || sg->n_segs < 0) return fail(h, VSV_E_INVALID, "bad segment counts");
   if (sg->n_reads > 0 && (!read_len || !read_rec || !sg->seg_off)) return fail(h, VSV_E_INVALID, "read arrays are NULL");
+  { int vs = validate_segments(h, sg, false); if (vs) return vs; }
   HIPCHK(h, hipSetDevice(h->device));
   const int64_t rows = 2 * sg->n_segs + sg->n_reads;    // upper bound of the rows a read can produce, summed
   int st = reserve(h, 1, 1, rows > h->cap_sigs ? rows : (h->cap_sigs > 0 ? h->cap_sigs : (1 << 22)));
