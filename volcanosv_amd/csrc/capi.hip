@@ -1031,8 +1031,11 @@ int vsv_redundancy_pairs(vsv_handle* h, int is_del, const int32_t* pos, const in
     if (i + 1 < n && pos[i] > pos[i + 1]) return fail(h, VSV_E_UNSORTED, "calls are not sorted by position");
     if (svlen[i] <= 0) return fail(h, VSV_E_ZERODIV, "call with |len(REF)-len(ALT)| == 0 (the reference divides by it, RR:88-90)");
   }
-  if (!is_del)
+  if (!is_del) {
+    if (seq_off[0] != 0) return fail(h, VSV_E_INVALID, "seq_off must start at 0");
+    for (int64_t i = 0; i < n; ++i) if (seq_off[i + 1] < seq_off[i]) return fail(h, VSV_E_INVALID, "seq_off does not ascend");
     for (uint64_t k = 0; k < seq_off[n]; ++k) if (seq[k] > 15) return fail(h, VSV_E_INVALID, "sequence symbols must be coded 0..15");
+  }
   HIPCHK(h, hipSetDevice(h->device));
   hipStream_t st = h->stream;
   int rc;
