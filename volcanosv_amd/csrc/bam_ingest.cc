@@ -13,6 +13,7 @@
 #include <zlib.h>
 
 #include <atomic>
+#include <exception>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -74,15 +75,18 @@ bool read_member(vsv_bam* b, Member& m, bool& got) {
   int bsize = -1;
   for (size_t o = 0; o + 4 <= extra.size();) {
     uint16_t slen = extra[o + 2] | (extra[o + 3] << 8);
+    if (o + 4 + slen > extra.size()) break;                      // subfield runs past the extra field
     if (extra[o] == 'B' && extra[o + 1] == 'C' && slen == 2) bsize = extra[o + 4] | (extra[o + 5] << 8);
     o += 4 + slen;
   }
   if (bsize < 0) { b->err = "BGZF block without BC field"; return false; }
+  if ((size_t)bsize + 1 < 12u + xlen + 8u) { b->err = "BGZF block smaller than its own header"; return false; }
   const size_t clen = (size_t)bsize + 1 - 12 - xlen - 8;
   m.comp.resize(clen + 8);
   if (fread(m.comp.data(), 1, clen + 8, b->f) != clen + 8) { b->err = "truncated BGZF block"; return false; }
   m.comp.resize(clen + 8);
   m.isize = m.comp[clen + 4] | (m.comp[clen + 5] << 8) | (m.comp[clen + 6] << 16) | ((uint32_t)m.comp[clen + 7] << 24);
+  if (m.isize > 65536u) { b->err = "BGZF block announces more than 64 KiB"; return false; }
   got = true;
   return true;
 }
@@ -96,7 +100,11 @@ bool inflate_member(const Member& m, uint8_t* dst) {
   zs.next_out = dst; zs.avail_out = m.isize;
   const int rc = inflate(&zs, Z_FINISH);
   inflateEnd(&zs);
-  return rc == Z_STREAM_END && zs.avail_out == 0;
+  if (!(rc == Z_STREAM_END && zs.avail_out == 0)) return false;
+  // the member's CRC-32 (htslib bgzf.c checks it too): a flipped bit that still inflates must not pass as data
+  const uint8_t* t = m.comp.data() + (m.comp.size() - 8);
+  const uint32_t want = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+  return (uint32_t)crc32(0L, dst, m.isize) == want;
 }
 
 bool fill(vsv_bam* b, size_t need) {
@@ -194,7 +202,9 @@ int vsv_bam_open(const char* path, vsv_bam** out) {
   vsv_bam* b = new vsv_bam();
   b->f = f;
   b->n_threads = 1;                      // header only: inflate the first members, not a whole window
-  if (!read_header(b)) { fclose(f); delete b; return VSV_E_INVALID; }
+  bool hdr_ok = false;
+  try { hdr_ok = read_header(b); } catch (const std::exception&) { hdr_ok = false; }
+  if (!hdr_ok) { fclose(f); delete b; return VSV_E_INVALID; }
   b->n_threads = 0;
   *out = b;
   return 0;
@@ -253,8 +263,14 @@ bool walk_tags(const uint8_t* rec, size_t off, size_t block_size, const char** s
 }
 }  // namespace
 
+static int bam_load_impl(vsv_bam* b, int tid, vsv_records* out);
+// no exception crosses the C boundary: a corrupt file that asks for an absurd allocation ends as an error like any other
 int vsv_bam_load(vsv_bam* b, int tid, vsv_records* out) {
   if (!b || !out) return VSV_E_INVALID;
+  try { return bam_load_impl(b, tid, out); }
+  catch (const std::exception& e) { b->err = std::string("BAM load failed: ") + e.what(); return VSV_E_INVALID; }
+}
+static int bam_load_impl(vsv_bam* b, int tid, vsv_records* out) {
   // rewind and skip the header again (simple and index-free)
   fseek(b->f, 0, SEEK_SET);
   b->buf.clear(); b->rd = 0; b->eof = false; b->err.clear();
@@ -429,8 +445,13 @@ int vsv_bam_load(vsv_bam* b, int tid, vsv_records* out) {
 
 /* Same records, but inflated and parsed on the GPU (vsv_bam_parse_device): `out` holds device pointers owned by `h`. The header
  * is read on the host (it is a few KB) to learn the reference table and where the first record starts. */
+static int bam_load_device_impl(vsv_bam* b, vsv_handle* h, int tid, vsv_records* out);
 int vsv_bam_load_device(vsv_bam* b, vsv_handle* h, int tid, vsv_records* out) {
   if (!b || !h || !out) return VSV_E_INVALID;
+  try { return bam_load_device_impl(b, h, tid, out); }
+  catch (const std::exception& e) { b->err = std::string("BAM load failed: ") + e.what(); return VSV_E_INVALID; }
+}
+static int bam_load_device_impl(vsv_bam* b, vsv_handle* h, int tid, vsv_records* out) {
   fseek(b->f, 0, SEEK_SET);
   b->buf.clear(); b->rd = 0; b->eof = false; b->inflated_total = 0; b->err.clear(); b->dev_names = nullptr; b->dev_names_len = 0;
   b->ref_names.clear(); b->ref_lens.clear();
@@ -467,14 +488,16 @@ int vsv_bam_load_device(vsv_bam* b, vsv_handle* h, int tid, vsv_records* out) {
     const uint8_t* hdr = comp + o;
     if (o + 18 > (size_t)fsize || hdr[0] != 31 || hdr[1] != 139 || hdr[2] != 8 || !(hdr[3] & 4)) { b->err = "not a BGZF block"; return VSV_E_INVALID; }
     const uint16_t xlen = hdr[10] | (hdr[11] << 8);
+    if (o + 12 + (size_t)xlen + 8 > (size_t)fsize) { b->err = "truncated BGZF block"; return VSV_E_INVALID; }
     int bsize = -1;
     for (size_t e = 0; e + 4 <= xlen;) {
       const uint8_t* x = hdr + 12 + e;
       const uint16_t slen = x[2] | (x[3] << 8);
+      if (e + 4 + slen > xlen) break;
       if (x[0] == 'B' && x[1] == 'C' && slen == 2) bsize = x[4] | (x[5] << 8);
       e += 4 + slen;
     }
-    if (bsize < 0 || o + (size_t)bsize + 1 > (size_t)fsize) { b->err = "truncated BGZF block"; return VSV_E_INVALID; }
+    if (bsize < 0 || o + (size_t)bsize + 1 > (size_t)fsize || (size_t)bsize + 1 < 12u + xlen + 8u) { b->err = "truncated or malformed BGZF block"; return VSV_E_INVALID; }
     const uint8_t* tr = hdr + bsize + 1 - 8;
     coff.push_back(o + 12 + xlen);
     isz.push_back((uint32_t)tr[4] | ((uint32_t)tr[5] << 8) | ((uint32_t)tr[6] << 16) | ((uint32_t)tr[7] << 24));
