@@ -337,6 +337,10 @@ int vsv_redundancy_pairs(vsv_handle* h, int is_del, const int32_t* pos, const in
  * per member. comp = the members' deflate payloads back to back (host), comp_off[n+1] their byte offsets, isize[n] the
  * uncompressed sizes from the member trailers; out (host) receives sum(isize) bytes in member order. A member that is not a
  * valid deflate stream of exactly isize bytes fails the call with VSV_E_INVALID (vsv_last_count = its index). */
+/* CRC-32 values of the members' gzip trailers (host array of n_members words, caller-owned, NULL / 0 clears): the next
+ * vsv_bgzf_inflate / vsv_bam_parse_device over exactly n_members members computes each member's CRC-32 on the GPU and fails
+ * on a mismatch, as htslib's bgzf.c does on the host. */
+int vsv_bgzf_set_expected_crc(vsv_handle* h, const uint32_t* crc, int64_t n_members);
 int vsv_bgzf_inflate(vsv_handle* h, const uint8_t* comp, const uint64_t* comp_off, const uint32_t* isize, int64_t n_members, uint8_t* out);
 
 /* BAM members -> device-resident record SoA, inflated AND parsed on the GPU (no byte of the records returns to the host except

@@ -292,3 +292,56 @@ def test_inflate_survives_corrupted_payloads():
         assert r.returncode == 0, (seed, r.returncode, r.stderr[-600:])
         f = r.stdout.split()
         assert int(f[1]) > 30 and int(f[3]) > 30
+
+
+@pytest.mark.gpu
+def test_member_crc32_is_checked_on_the_gpu(tmp_path):
+    """The gzip trailer's CRC-32 of every member computed on the GPU (bgzf_crc32: 64 slices per member, byte-wise table per lane,
+    zero-byte shift operators to combine): equal to zlib.crc32 for member sizes 0..65536, a wrong value names its member, and a
+    BAM whose payload was altered without touching the framing no longer loads through the device reader."""
+    import zlib
+    from volcanosv_amd import bam
+    from volcanosv_amd.abi import VsvError
+    from volcanosv_amd.engine import Engine
+    rng = np.random.default_rng(12)
+    sizes = [0, 1, 2, 63, 64, 65, 127, 128, 1000, 4095, 4096, 4097, 65535, 65536] + [int(x) for x in rng.integers(1, 65536, 40)]
+    datas = [rng.integers(0, 256, n).astype(np.uint8).tobytes() if i % 2 else (b"ACGT" * (n // 4 + 1))[:n] for i, n in enumerate(sizes)]
+    pay = []
+    for d in datas:
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        pay.append(c.compress(d) + c.flush())
+    crcs = [zlib.crc32(d) & 0xFFFFFFFF for d in datas]
+    with Engine(0) as eng:
+        assert eng.bgzf_inflate(pay, sizes, crcs) == datas
+        bad = list(crcs)
+        bad[17] ^= 0x10
+        with pytest.raises(VsvError, match="member 17 fails its CRC-32"):
+            eng.bgzf_inflate(pay, sizes, bad)
+        assert eng.bgzf_inflate(pay, sizes) == datas                        # without expectations nothing is checked
+        # a BAM with one payload byte changed and the member re-deflated under the OLD trailer
+        recs = [dict(tid=0, pos=100 * i, qname="r%d" % i, mapq=60, flag=0, cigar=[(0, 100)], seq_len=100) for i in range(2000)]
+        path = str(tmp_path / "x.bam")
+        bam.write_bam(path, [("chr1", 1_000_000)], recs, block_bytes=20000)
+        raw = bytearray(open(path, "rb").read())
+        import struct
+        o, k = 0, 0
+        while o < len(raw):
+            xlen = struct.unpack_from("<H", raw, o + 10)[0]
+            bsize = struct.unpack_from("<H", raw, o + 16)[0] + 1
+            if k == 3:
+                body = bytearray(zlib.decompress(bytes(raw[o + 12 + xlen:o + bsize - 8]), -15))
+                body[len(body) // 2 + 8] ^= 1                                 # inside a record's name / sequence bytes
+                c = zlib.compressobj(6, zlib.DEFLATED, -15)
+                new = c.compress(bytes(body)) + c.flush()
+                blk = bytes(raw[o:o + 16]) + struct.pack("<H", len(new) + 25) + new + bytes(raw[o + bsize - 8:o + bsize])   # old CRC, old size
+                raw[o:o + bsize] = blk
+                break
+            o += bsize
+            k += 1
+        open(path, "wb").write(bytes(raw))
+        with bam.BamFile(path) as bf:
+            with pytest.raises(VsvError, match="CRC"):
+                bf.fetch_device(eng, None)
+        with bam.BamFile(path) as bf:
+            with pytest.raises(VsvError):
+                bf.fetch_soa(None)                                           # the host reader checks it too

@@ -15,7 +15,7 @@ _lib = None
 
 # every symbol include/volcanosv.h declares
 SYMBOLS = [
-    "vsv_abi_version", "vsv_status_string", "vsv_create", "vsv_destroy", "vsv_last_error", "vsv_last_count",
+    "vsv_abi_version", "vsv_status_string", "vsv_create", "vsv_destroy", "vsv_bgzf_set_expected_crc", "vsv_last_error", "vsv_last_count",
     "vsv_default_params", "vsv_reserve", "vsv_cigar_scan", "vsv_split_pairs", "vsv_sort_cluster", "vsv_merge_sources",
     "vsv_pair_haplotypes", "vsv_run_chromosome", "vsv_run_chromosome_async", "vsv_finish", "vsv_table_count",
     "vsv_table_fill", "vsv_last_scan_ms", "vsv_default_bnd_params", "vsv_bnd_segments", "vsv_bnd_pair", "vsv_bnd_set_candidates",
@@ -78,6 +78,7 @@ def load():
     lib.vsv_span_count.argtypes = [H, C.POINTER(Records), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.vsv_copy_to_host.argtypes = [H, C.c_void_p, C.c_void_p, C.c_int64]
     lib.vsv_bgzf_inflate.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.vsv_bgzf_set_expected_crc.argtypes = [H, C.c_void_p, C.c_int64]
     lib.vsv_support_cov_ins.argtypes = [H, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int, C.c_void_p]
     lib.vsv_support_cov_del.argtypes = [H, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                         C.c_int, C.c_void_p]

@@ -133,7 +133,12 @@ bool fill(vsv_bam* b, size_t need) {
       for (size_t i = 0; i < win.size(); ++i) { coff[i + 1] = coff[i] + (win[i].comp.size() - 8); isz[i] = win[i].isize; }
       std::vector<uint8_t> comp((size_t)coff.back() + 1);
       for (size_t i = 0; i < win.size(); ++i) memcpy(comp.data() + coff[i], win[i].comp.data(), win[i].comp.size() - 8);
-      if (vsv_bgzf_inflate(b->gpu, comp.data(), coff.data(), isz.data(), (int64_t)win.size(), base) != 0) { b->err = std::string("GPU inflate failed: ") + vsv_last_error(b->gpu); return false; }
+      std::vector<uint32_t> want(win.size());
+      for (size_t i = 0; i < win.size(); ++i) { const uint8_t* t = win[i].comp.data() + (win[i].comp.size() - 8); want[i] = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24); }
+      vsv_bgzf_set_expected_crc(b->gpu, want.data(), (int64_t)want.size());
+      const int gs = vsv_bgzf_inflate(b->gpu, comp.data(), coff.data(), isz.data(), (int64_t)win.size(), base);
+      vsv_bgzf_set_expected_crc(b->gpu, nullptr, 0);
+      if (gs != 0) { b->err = std::string("GPU inflate failed: ") + vsv_last_error(b->gpu); return false; }
       continue;
     }
     int nt = b->n_threads > 0 ? b->n_threads : (int)std::thread::hardware_concurrency();
@@ -483,7 +488,7 @@ static int bam_load_device_impl(vsv_bam* b, vsv_handle* h, int tid, vsv_records*
   const uint8_t* comp = (const uint8_t*)map.p;
   const double t1 = now();
   std::vector<uint64_t> coff;
-  std::vector<uint32_t> isz;
+  std::vector<uint32_t> isz, crcs;
   for (size_t o = 0; o < (size_t)fsize;) {
     const uint8_t* hdr = comp + o;
     if (o + 18 > (size_t)fsize || hdr[0] != 31 || hdr[1] != 139 || hdr[2] != 8 || !(hdr[3] & 4)) { b->err = "not a BGZF block"; return VSV_E_INVALID; }
@@ -499,6 +504,7 @@ static int bam_load_device_impl(vsv_bam* b, vsv_handle* h, int tid, vsv_records*
     }
     if (bsize < 0 || o + (size_t)bsize + 1 > (size_t)fsize || (size_t)bsize + 1 < 12u + xlen + 8u) { b->err = "truncated or malformed BGZF block"; return VSV_E_INVALID; }
     const uint8_t* tr = hdr + bsize + 1 - 8;
+    crcs.push_back((uint32_t)tr[0] | ((uint32_t)tr[1] << 8) | ((uint32_t)tr[2] << 16) | ((uint32_t)tr[3] << 24));
     coff.push_back(o + 12 + xlen);
     isz.push_back((uint32_t)tr[4] | ((uint32_t)tr[5] << 8) | ((uint32_t)tr[6] << 16) | ((uint32_t)tr[7] << 24));
     o += (size_t)bsize + 1;
@@ -506,8 +512,10 @@ static int bam_load_device_impl(vsv_bam* b, vsv_handle* h, int tid, vsv_records*
   coff.push_back((uint64_t)fsize);
   const double t2 = now();
   const char* names = nullptr; int64_t names_len = 0;
+  vsv_bgzf_set_expected_crc(h, crcs.data(), (int64_t)crcs.size());     // the trailers' CRC-32s are checked on the GPU
   const int st = vsv_bam_parse_device(h, comp, coff.data(), isz.data(), (int64_t)isz.size(), first_record, (int32_t)b->ref_names.size(), tid, out,
                                       &names, &names_len, &b->dev_l_seq, &b->dev_sam_flag);
+  vsv_bgzf_set_expected_crc(h, nullptr, 0);
   if (st) { b->err = std::string("device BAM parse failed: ") + vsv_last_error(h); return st; }
   b->qname_blob.clear();
   b->dev_names = names; b->dev_names_len = names_len;     // valid until the handle's next device parse

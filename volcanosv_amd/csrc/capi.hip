@@ -40,6 +40,9 @@ struct vsv_handle {
   int64_t cutesv_rows = -1;   // rows of the last vsv_cutesv_split (c2 buffer)
   // workspace
   DevBuf part_rb, part_count, part_off, scan_tmp;
+  DevBuf z_crctab, z_crc;  // CRC-32 tables (uploaded once) and per-member results of the device inflate
+  const uint32_t* expect_crc = nullptr;   // vsv_bgzf_set_expected_crc: trailer CRCs of the members of the next inflate / parse
+  int64_t expect_crc_n = 0;
   DevBuf gflag;           // CLR: flag bytes with the haplotype bits cleared where the gate fails (input of the scan)
   DevBuf pool, pool_key, raw0, s1in, s1s, c1, s2s, c2, merged, calls_tmp, calls, reads;
   DevBuf tab, blk_cnt, blk_off, ckey, crec, okey, oval;
@@ -701,7 +704,8 @@ int vsv_support_cov_del(vsv_handle* h, const int32_t* call_start, const int32_t*
 }
 
 // inflate into h->z_out and leave it there (shared by vsv_bgzf_inflate's device half and the device parse)
-static int inflate_to_device(vsv_handle* h, const uint8_t* comp, const uint64_t* comp_off, const uint32_t* isize, int64_t n, std::vector<uint64_t>& ooff) {
+static int inflate_to_device(vsv_handle* h, const uint8_t* comp, const uint64_t* comp_off, const uint32_t* isize, int64_t n, std::vector<uint64_t>& ooff,
+                             const uint32_t* expect_crc = nullptr) {
   ooff.assign((size_t)n + 1, 0);
   for (int64_t i = 0; i < n; ++i) {
     if (comp_off[i + 1] < comp_off[i] || isize[i] > 65536u) return fail(h, VSV_E_INVALID, "bad BGZF member table");
@@ -721,11 +725,33 @@ static int inflate_to_device(vsv_handle* h, const uint8_t* comp, const uint64_t*
   vsv_launch_bgzf_inflate(h->stream, (const uint8_t*)h->z_comp.p, (const uint64_t*)h->z_coff.p, (const uint64_t*)h->z_ooff.p, n,
                           (uint8_t*)h->z_out.p, (int32_t*)h->z_stat.p);
   HIPCHK(h, hipGetLastError());
+  std::vector<uint32_t> crc;
+  if (expect_crc) {        // the gzip trailer's CRC-32 of every member, computed where the bytes are
+    if (!h->z_crctab.p) {
+      std::vector<uint32_t> t(256 + 17 * 32);
+      vsv_crc32_tables(t.data());
+      if ((st = upload(h, h->z_crctab, t.data(), t.size() * 4))) return st;
+    }
+    if ((st = ensure(h, h->z_crc, (size_t)n * 4))) return st;
+    vsv_launch_bgzf_crc32(h->stream, (const uint8_t*)h->z_out.p, (const uint64_t*)h->z_ooff.p, n, (const uint32_t*)h->z_crctab.p, (uint32_t*)h->z_crc.p);
+    crc.resize((size_t)n);
+    HIPCHK(h, hipMemcpyAsync(crc.data(), h->z_crc.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+  }
   std::vector<int32_t> stat((size_t)n);
   HIPCHK(h, hipMemcpyAsync(stat.data(), h->z_stat.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   for (int64_t i = 0; i < n; ++i)
     if (stat[i]) { h->last_count = i; char m[96]; snprintf(m, sizeof m, "BGZF member %lld is not a valid deflate stream (code %d)", (long long)i, stat[i]); return fail(h, VSV_E_INVALID, m); }
+  if (expect_crc)
+    for (int64_t i = 0; i < n; ++i)
+      if (crc[i] != expect_crc[i]) { h->last_count = i; char m[96]; snprintf(m, sizeof m, "BGZF member %lld fails its CRC-32", (long long)i); return fail(h, VSV_E_INVALID, m); }
+  return 0;
+}
+
+int vsv_bgzf_set_expected_crc(vsv_handle* h, const uint32_t* crc, int64_t n_members) {
+  if (!h || n_members < 0 || (n_members > 0 && !crc)) return VSV_E_INVALID;
+  h->expect_crc = n_members ? crc : nullptr;
+  h->expect_crc_n = n_members;
   return 0;
 }
 
@@ -736,7 +762,7 @@ int vsv_bgzf_inflate(vsv_handle* h, const uint8_t* comp, const uint64_t* comp_of
   if (!comp || !comp_off || !isize || !out) return fail(h, VSV_E_INVALID, "member arrays are NULL");
   HIPCHK(h, hipSetDevice(h->device));
   std::vector<uint64_t> ooff;
-  const int rc = inflate_to_device(h, comp, comp_off, isize, n, ooff);
+  const int rc = inflate_to_device(h, comp, comp_off, isize, n, ooff, (h->expect_crc && h->expect_crc_n == n) ? h->expect_crc : nullptr);
   if (rc) return rc;
   if (ooff[n]) HIPCHK(h, hipMemcpyAsync(out, h->z_out.p, (size_t)ooff[n], hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -795,7 +821,7 @@ int vsv_bam_parse_device(vsv_handle* h, const uint8_t* comp, const uint64_t* com
     const int64_t ma = (int64_t)(std::upper_bound(ginf.begin(), ginf.end(), carry) - ginf.begin()) - 1;
     const int64_t mb = ma + window_members < n_members ? ma + window_members : n_members;
     const bool last_window = mb == n_members;
-    rc = inflate_to_device(h, comp, comp_off + ma, isize + ma, mb - ma, moff);
+    rc = inflate_to_device(h, comp, comp_off + ma, isize + ma, mb - ma, moff, (h->expect_crc && h->expect_crc_n == n_members) ? h->expect_crc + ma : nullptr);
     if (rc == VSV_E_HIP) return fail(h, VSV_E_CAPACITY, "device memory exhausted in the device reader: use the host reader");
     if (rc) return rc;
     lap(t_inf); ++n_windows;

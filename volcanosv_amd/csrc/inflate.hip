@@ -288,8 +288,71 @@ __global__ __launch_bounds__(64) void bgzf_inflate(const uint8_t* __restrict__ c
 
 }  // namespace
 
+// ---- CRC-32 of the inflated members (the gzip trailer's check, as htslib's bgzf.c verifies it) --------------------------------
+// One wave per member. The member is cut into 64 equal slices (the message is thought of as zero-padded at the FRONT to 64 x S
+// bytes: leading zeros leave a zero state untouched); lane i runs the byte-wise table CRC over its slice from state 0, moves
+// the result across the (63 - i) x S bytes that follow it with the precomputed "2^k zero bytes" operators, the lanes' states
+// are XORed, and the initial state 0xFFFFFFFF is moved across the n real bytes the same way:
+//   state(I, D1 || D2) = shift_|D2|(state(I, D1)) ^ state(0, D2),   crc = ~state(0xFFFFFFFF, M).
+// tab[0..255] = the reflected CRC-32 table (polynomial 0xEDB88320), zop[k][b] = column b of the operator for 2^k zero bytes.
+__device__ __forceinline__ uint32_t crc_shift(uint32_t v, uint32_t nbytes, const uint32_t (*zop)[32]) {
+  for (int k = 0; nbytes; ++k, nbytes >>= 1) {
+    if (nbytes & 1u) {
+      uint32_t r = 0;
+      for (int b = 0; b < 32; ++b) r ^= ((v >> b) & 1u) ? zop[k][b] : 0u;
+      v = r;
+    }
+  }
+  return v;
+}
+__global__ __launch_bounds__(64) void bgzf_crc32(const uint8_t* __restrict__ data, const uint64_t* __restrict__ out_off, int64_t n,
+                                                 const uint32_t* __restrict__ tables, uint32_t* __restrict__ crc) {
+  __shared__ uint32_t tab[256];
+  __shared__ uint32_t zop[17][32];
+  const int lane = threadIdx.x;
+  for (int i = lane; i < 256; i += 64) tab[i] = tables[i];
+  for (int i = lane; i < 17 * 32; i += 64) zop[i / 32][i % 32] = tables[256 + i];
+  __syncthreads();
+  const int64_t m = blockIdx.x;
+  if (m >= n) return;
+  const uint8_t* p = data + out_off[m];
+  const uint32_t len = (uint32_t)(out_off[m + 1] - out_off[m]);
+  const uint32_t S = (len + 63u) / 64u, pad = 64u * S - len;          // slice length, zero bytes in front
+  uint32_t c = 0;
+  const uint32_t lo = (uint32_t)lane * S, hi = lo + S;                // slice in padded coordinates
+  for (uint32_t x = lo < pad ? pad : lo; x < hi; ++x) c = tab[(c ^ p[x - pad]) & 0xFFu] ^ (c >> 8);
+  c = crc_shift(c, (63u - (uint32_t)lane) * S, zop);
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) c ^= (uint32_t)__shfl_xor((int)c, d, 64);
+  if (lane == 0) crc[m] = ~(c ^ crc_shift(0xFFFFFFFFu, len, zop));
+}
+
 void vsv_launch_bgzf_inflate(hipStream_t st, const uint8_t* comp, const uint64_t* comp_off, const uint64_t* out_off, int64_t n, uint8_t* out,
                              int32_t* status) {
   if (n <= 0) return;
   bgzf_inflate<<<(int)n, 64, 0, st>>>(comp, comp_off, out_off, n, out, status);
+}
+
+// tables[0..255] = CRC-32 table, tables[256 + 32 k + b] = column b of the operator "2^k zero bytes" (k = 0..16)
+void vsv_crc32_tables(uint32_t* t) {
+  for (uint32_t i = 0; i < 256; ++i) {
+    uint32_t c = i;
+    for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+    t[i] = c;
+  }
+  uint32_t* z = t + 256;
+  for (int b = 0; b < 32; ++b) {                    // one zero byte: state -> tab[state & 0xFF] ^ (state >> 8), column by column
+    const uint32_t v = 1u << b;
+    z[b] = t[v & 0xFFu] ^ (v >> 8);
+  }
+  for (int k = 1; k < 17; ++k)                      // square: apply the previous operator to each of its own columns
+    for (int b = 0; b < 32; ++b) {
+      const uint32_t v = z[32 * (k - 1) + b];
+      uint32_t r = 0;
+      for (int j = 0; j < 32; ++j) if ((v >> j) & 1u) r ^= z[32 * (k - 1) + j];
+      z[32 * k + b] = r;
+    }
+}
+void vsv_launch_bgzf_crc32(hipStream_t st, const uint8_t* data, const uint64_t* out_off, int64_t n, const uint32_t* tables, uint32_t* crc) {
+  if (n > 0) bgzf_crc32<<<(int)n, 64, 0, st>>>(data, out_off, n, tables, crc);
 }

@@ -169,6 +169,8 @@ void vsv_launch_rr_edit_sim(hipStream_t st, const uint32_t* pairs, uint32_t n_pa
 // inflate.hip: BGZF members (raw deflate) -> bytes, one lane per member
 void vsv_launch_bgzf_inflate(hipStream_t st, const uint8_t* comp, const uint64_t* comp_off, const uint64_t* out_off, int64_t n, uint8_t* out,
                              int32_t* status);
+void vsv_crc32_tables(uint32_t* t);      // 256 + 17 x 32 words for vsv_launch_bgzf_crc32 (host-side construction)
+void vsv_launch_bgzf_crc32(hipStream_t st, const uint8_t* data, const uint64_t* out_off, int64_t n, const uint32_t* tables, uint32_t* crc);
 
 // bam_device.hip: BAM record parse on the device
 void vsv_bamdev_speculate(hipStream_t st, const uint8_t* s, const uint64_t* moff, int64_t n_members, uint64_t first, int32_t n_ref, uint64_t* spec);

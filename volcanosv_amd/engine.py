@@ -209,18 +209,29 @@ class Engine:
             self._check(st)
             return out[: n.value]
 
-    def bgzf_inflate(self, payloads, isizes):
-        """Raw-deflate payloads of BGZF members (list of bytes) -> list of their inflated bytes, decoded on the GPU."""
+    def bgzf_inflate(self, payloads, isizes, crcs=None):
+        """Raw-deflate payloads of BGZF members (list of bytes) -> list of their inflated bytes, decoded on the GPU. crcs: the
+        members' trailer CRC-32s; given, every member is checked on the GPU (a mismatch raises)."""
         n = len(payloads)
         off = np.zeros(n + 1, dtype=np.uint64)
         np.cumsum([len(p) for p in payloads], out=off[1:])
         comp = np.frombuffer(b"".join(payloads) or b"\0", dtype=np.uint8)
         isz = np.ascontiguousarray(isizes, dtype=np.uint32)
         out = np.zeros(max(1, int(isz.sum())), dtype=np.uint8)
-        self._check(self.lib.vsv_bgzf_inflate(self.h, comp.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p),
-                                              isz.ctypes.data_as(C.c_void_p), n, out.ctypes.data_as(C.c_void_p)))
+        want = np.ascontiguousarray(crcs, dtype=np.uint32) if crcs is not None else None
+        if want is not None:
+            self._check(self.lib.vsv_bgzf_set_expected_crc(self.h, want.ctypes.data_as(C.c_void_p), n))
+        try:
+            self._inflate_call(comp, off, isz, n, out)
+        finally:
+            if want is not None:
+                self.lib.vsv_bgzf_set_expected_crc(self.h, None, 0)
         o = np.concatenate(([0], np.cumsum(isz.astype(np.int64))))
         return [out[o[i]:o[i + 1]].tobytes() for i in range(n)]
+
+    def _inflate_call(self, comp, off, isz, n, out):
+        self._check(self.lib.vsv_bgzf_inflate(self.h, comp.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p),
+                                              isz.ctypes.data_as(C.c_void_p), n, out.ctypes.data_as(C.c_void_p)))
 
     def gt_support(self, var_pos, var_svlen, blk_lo, blk_hi, sig_pos, sig_svlen, sig_cnt, max_shift_ratio=2.3, min_size_sim=0.6):
         """Window sums of correct_gt_*_real_data.py (vsv_gt_support): (sum int64[n], lo int32[n], hi int32[n])."""
