@@ -146,6 +146,9 @@ def main():
     if isinstance(gathered, tuple):
         gathered = shard.finish_gather(gathered)     # host copy for the VCF writer, after the timed region
     n_raw = len(eng.table("raw"))
+    ceil_read = ceil_copy = None
+    if rank == 0:
+        ceil_read, ceil_copy = eng.stream_ceiling(t["cigar"], reps=5)
     alg_bytes = 24 * recs.n_records + 4 * recs.n_ops + 32 * n_raw      # SURVEY.md §8d, per launch
     scan_s = sum(scan_ms) / len(scan_ms) / 1e3
     achieved = alg_bytes / scan_s / 1e9
@@ -201,7 +204,10 @@ def main():
                        "streams_per_gpu": n_streams},
             "roofline": {"bound": "hbm", "kernel": "cigar_scan_emit", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": scan_s * 1e3},
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": scan_s * 1e3,
+                         # the library's own read-stream / copy kernels over the same CIGAR array, after the timed region
+                         "measured_read_stream": ceil_read, "measured_copy_stream": ceil_copy,
+                         "frac_of_measured_read_stream": achieved / ceil_read if ceil_read else None},
             "cpu_baseline": cpu,
         }
         print(json.dumps(line))

@@ -180,6 +180,9 @@ int vsv_run_chromosome(vsv_handle* h, const vsv_records* recs, const vsv_params*
 /* Asynchronous variant for benchmarking: enqueues the whole path on the handle's stream and does
  * not synchronise; errors and counts are picked up by vsv_finish().                              */
 int vsv_run_chromosome_async(vsv_handle* h, const vsv_records* recs, const vsv_params* p);
+/* Measurement aid: best of `reps` sweeps of the library's own 16-byte read-stream and copy kernels over a device
+ * buffer of the caller (>= 1 MiB), in GB/s; the copy figure counts bytes read + bytes written. */
+int vsv_stream_ceiling(vsv_handle* h, const void* dev_buf, int64_t bytes, int32_t reps, double* read_gbs, double* copy_gbs);
 int vsv_finish(vsv_handle* h);
 
 /* two-phase readback: count, then fill a caller buffer (host or device) */

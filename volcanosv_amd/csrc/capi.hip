@@ -470,6 +470,33 @@ int vsv_run_chromosome_async(vsv_handle* h, const vsv_records* recs, const vsv_p
   return 0;
 }
 
+int vsv_stream_ceiling(vsv_handle* h, const void* dev_buf, int64_t bytes, int32_t reps, double* read_gbs, double* copy_gbs) {
+  if (!h || !dev_buf || bytes < (1 << 20) || reps < 1 || !read_gbs || !copy_gbs) return VSV_E_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t n = (size_t)bytes & ~(size_t)15;
+  void* dst = nullptr; uint32_t* sink = nullptr;
+  HIPCHK(h, hipMalloc(&dst, n));
+  if (hipMalloc((void**)&sink, 1024) != hipSuccess) { (void)hipFree(dst); return fail(h, VSV_E_HIP, "hipMalloc failed"); }
+  hipEvent_t a, b;
+  (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+  float best_r = 1e30f, best_c = 1e30f;
+  for (int r = 0; r < reps + 1; ++r) {                       // first round warms up
+    float ms = 0;
+    (void)hipEventRecord(a, h->stream); vsv_launch_stream_read(h->stream, dev_buf, n, sink); (void)hipEventRecord(b, h->stream);
+    (void)hipEventSynchronize(b); (void)hipEventElapsedTime(&ms, a, b);
+    if (r && ms < best_r) best_r = ms;
+    (void)hipEventRecord(a, h->stream); vsv_launch_stream_copy(h->stream, dev_buf, dst, n); (void)hipEventRecord(b, h->stream);
+    (void)hipEventSynchronize(b); (void)hipEventElapsedTime(&ms, a, b);
+    if (r && ms < best_c) best_c = ms;
+  }
+  (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+  (void)hipFree(dst); (void)hipFree(sink);
+  HIPCHK(h, hipGetLastError());
+  *read_gbs = (double)n / (best_r * 1e-3) / 1e9;
+  *copy_gbs = 2.0 * (double)n / (best_c * 1e-3) / 1e9;      // bytes read + bytes written
+  return 0;
+}
+
 int vsv_finish(vsv_handle* h) {
   if (!h) return VSV_E_INVALID;
   return finish(h);

@@ -548,3 +548,47 @@ void vsv_launch_cigar_scan(hipStream_t st, const RecView& rv, const vsv_params& 
   vsv_scan_u32_exclusive(st, part_count, n_parts, part_off, scan_tmp);
   place_raw<<<K1_SHARDS, 256, 0, st>>>(pool, pool_key, shard_cnt, cap / K1_SHARDS, part_off, part_count, n_parts, raw, cap, ctr);
 }
+
+// ---- streaming ceiling of this part, measured with the library's own kernels -----------------------------------
+// read: every thread XORs its 16-byte loads (one word per block could leave the kernel, so nothing is elided);
+// copy: 16-byte load + store. The scan is a read stream with ~2 % of writes, so `read` is its ceiling; `copy` is the usual figure.
+// Same access shape as the scan: a wave owns a contiguous 16 KiB part and sweeps it with 1 KiB (64 x 16 B) loads, 4 in flight (16 in flight, 4096-65536-block grid-stride sweeps and strided unrolls measured lower).
+constexpr size_t STREAM_PART16 = 1024;      // 16-byte words per wave
+__global__ __launch_bounds__(256) void stream_read_kernel(const uint4* __restrict__ src, size_t n16, uint32_t* __restrict__ sink) {
+  const int lane = threadIdx.x & 63;
+  const size_t part = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), base = part * STREAM_PART16;
+  uint32_t acc = 0;
+  if (base + STREAM_PART16 <= n16) {
+#pragma unroll
+    for (int k = 0; k < 16; k += 4) {
+      const uint4 v0 = src[base + (k + 0) * 64 + lane], v1 = src[base + (k + 1) * 64 + lane];
+      const uint4 v2 = src[base + (k + 2) * 64 + lane], v3 = src[base + (k + 3) * 64 + lane];
+      acc ^= v0.x ^ v0.y ^ v0.z ^ v0.w ^ v1.x ^ v1.y ^ v1.z ^ v1.w ^ v2.x ^ v2.y ^ v2.z ^ v2.w ^ v3.x ^ v3.y ^ v3.z ^ v3.w;
+    }
+  } else {
+    for (size_t i = base + lane; i < n16; i += 64) { const uint4 v = src[i]; acc ^= v.x ^ v.y ^ v.z ^ v.w; }
+  }
+  if (acc == 0x9E3779B9u) sink[blockIdx.x & 255] = acc;     // practically never taken; keeps the loads alive
+}
+__global__ __launch_bounds__(256) void stream_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+  const int lane = threadIdx.x & 63;
+  const size_t part = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), base = part * STREAM_PART16;
+  if (base + STREAM_PART16 <= n16) {
+#pragma unroll
+    for (int k = 0; k < 16; k += 4) {
+      const uint4 v0 = src[base + (k + 0) * 64 + lane], v1 = src[base + (k + 1) * 64 + lane];
+      const uint4 v2 = src[base + (k + 2) * 64 + lane], v3 = src[base + (k + 3) * 64 + lane];
+      dst[base + (k + 0) * 64 + lane] = v0; dst[base + (k + 1) * 64 + lane] = v1;
+      dst[base + (k + 2) * 64 + lane] = v2; dst[base + (k + 3) * 64 + lane] = v3;
+    }
+  } else {
+    for (size_t i = base + lane; i < n16; i += 64) dst[i] = src[i];
+  }
+}
+static int stream_grid(size_t bytes) { return (int)((bytes / 16 + 4 * STREAM_PART16 - 1) / (4 * STREAM_PART16)); }
+void vsv_launch_stream_read(hipStream_t st, const void* src, size_t bytes, uint32_t* sink) {
+  stream_read_kernel<<<stream_grid(bytes), 256, 0, st>>>((const uint4*)src, bytes / 16, sink);
+}
+void vsv_launch_stream_copy(hipStream_t st, const void* src, void* dst, size_t bytes) {
+  stream_copy_kernel<<<stream_grid(bytes), 256, 0, st>>>((const uint4*)src, (uint4*)dst, bytes / 16);
+}

@@ -117,6 +117,8 @@ SortResult vsv_radix_sort_pairs(hipStream_t st, uint64_t* key, uint32_t* val, ui
 int64_t vsv_radix_hist_entries(int64_t max_n);
 
 // cigar_scan.hip
+void vsv_launch_stream_read(hipStream_t st, const void* src, size_t bytes, uint32_t* sink);
+void vsv_launch_stream_copy(hipStream_t st, const void* src, void* dst, size_t bytes);
 int vsv_cigar_parts(int64_t n_ops, int ops_per_part);
 void vsv_scan_u32_exclusive(hipStream_t st, const uint32_t* in, int n, uint32_t* out, uint32_t* tmp);
 void vsv_launch_cigar_scan(hipStream_t st, const RecView& rv, const vsv_params& p, uint32_t* part_rb, int n_parts,

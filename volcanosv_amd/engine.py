@@ -134,6 +134,13 @@ class Engine:
         self._last = (soa, params)
         self._check(self.lib.vsv_run_chromosome_async(self.h, C.byref(r), C.byref(params)))
 
+    def stream_ceiling(self, tensor, reps=5):
+        """(read GB/s, copy GB/s) of the library's own streaming kernels over a torch device tensor: the measured ceiling the scan
+        is compared with, next to the nominal 8 TB/s."""
+        r, c = C.c_double(), C.c_double()
+        self._check(self.lib.vsv_stream_ceiling(self.h, C.c_void_p(tensor.data_ptr()), tensor.numel() * tensor.element_size(), int(reps), C.byref(r), C.byref(c)))
+        return r.value, c.value
+
     def finish(self):
         self._regrow(self.lib.vsv_finish(self.h))
 
