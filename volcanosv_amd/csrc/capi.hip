@@ -43,6 +43,7 @@ struct vsv_handle {
   DevBuf z_crctab, z_crc;  // CRC-32 tables (uploaded once) and per-member results of the device inflate
   const uint32_t* expect_crc = nullptr;   // vsv_bgzf_set_expected_crc: trailer CRCs of the members of the next inflate / parse
   int64_t expect_crc_n = 0;
+  DevBuf cmask;           // split stage: item masks of the candidate count pass (1 byte per 4 records)
   DevBuf gflag;           // CLR: flag bytes with the haplotype bits cleared where the gate fails (input of the scan)
   DevBuf pool, pool_key, raw0, s1in, s1s, c1, s2s, c2, merged, calls_tmp, calls, reads;
   DevBuf tab, blk_cnt, blk_off, ckey, crec, okey, oval;
@@ -127,6 +128,7 @@ int reserve(vsv_handle* h, int64_t max_records, int64_t max_ops, int64_t max_sig
     if ((st = ensure(h, h->part_off, n_parts * 4))) return st;
     if ((st = ensure(h, h->blk_cnt, nblk * 4))) return st;
     if ((st = ensure(h, h->blk_off, nblk * 4))) return st;
+    if ((st = ensure(h, h->cmask, nblk * 512 + 1024))) return st;      // SC_ROUNDS (2) x 256 bytes per block of 2048 records
     const size_t m = n_parts > nblk ? n_parts : nblk;
     if ((st = ensure(h, h->scan_tmp, (m / 2048 + 2) * 4))) return st;
     h->cap_ops = ops;
@@ -237,7 +239,7 @@ int enq_split(vsv_handle* h) {
   vsv_launch_split(st, rv, p, h->n_tids, (uint32_t*)h->tab.p, h->tab_size, (uint32_t*)h->blk_cnt.p, (uint32_t*)h->blk_off.p,
                    (uint32_t*)h->scan_tmp.p, (uint64_t*)h->ckey.p, (uint32_t*)h->crec.p, (uint64_t*)h->okey.p,
                    (uint32_t*)h->oval.p, (uint64_t*)h->key2.p, (uint32_t*)h->idx2.p, sort_work(h), (vsv_sig*)h->s1in.p,
-                   (uint32_t)h->cap_sigs, dctr(h));
+                   (uint32_t)h->cap_sigs, dctr(h), (uint8_t*)h->cmask.p);
   if (p.dtype == VSV_DTYPE_READS) {
     // reads.py:281-286 merge_all: one stable sort of [del_cigar, ins_cigar, del_split, ins_split] by pos
     const int nbits = pos_bits(h) + 2 + tid_bits(h) + 1;
@@ -392,7 +394,7 @@ void vsv_destroy(vsv_handle* h) {
                     &h->g_re, &h->g_rev, &h->g_hap, &h->g_len, &h->g_rank, &h->j_cpos, &h->j_clen, &h->j_spos, &h->j_slen, &h->j_send, &h->j_out, &h->j_err, &h->z_comp, &h->z_coff, &h->z_ooff, &h->z_out, &h->z_stat, &h->p_spec, &h->p_cnt, &h->p_land, &h->p_base, &h->p_recoff, &h->p_pos, &h->p_tid,
                     &h->p_mapq, &h->p_flag, &h->p_lseq, &h->p_sflag, &h->p_ncig, &h->p_cgsrc, &h->p_hash, &h->p_keep, &h->p_kidx, &h->p_cigoff, &h->p_sums,
                     &h->p_tot, &h->p_err, &h->o_pos, &h->o_tid, &h->o_qid, &h->o_cigoff, &h->o_mapq, &h->o_flag, &h->o_cigar, &h->o_lseq, &h->o_sflag,
-                    &h->o_hash, &h->o_recoff, &h->o_first, &h->o_rank, &h->o_nlen, &h->o_noff, &h->o_blob, &h->o_n, &h->o_names, &h->o_nmoff, &h->o_nmlen, &h->gflag};
+                    &h->o_hash, &h->o_recoff, &h->o_first, &h->o_rank, &h->o_nlen, &h->o_noff, &h->o_blob, &h->o_n, &h->o_names, &h->o_nmoff, &h->o_nmlen, &h->gflag, &h->cmask};
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
   if (h->pinned) hipHostFree(h->pinned);
   if (h->ev0) hipEventDestroy(h->ev0);

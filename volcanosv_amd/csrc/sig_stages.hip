@@ -242,7 +242,10 @@ constexpr int SC_TILE_REC = 256 * 4 * SC_ROUNDS;    // records per block
 template <bool WRITE>
 __global__ __launch_bounds__(256) void split_cand(RecView rv, SplitCfg c, const uint32_t* __restrict__ tab,
                                                   uint32_t* __restrict__ blk, uint64_t* __restrict__ ckey,
-                                                  uint32_t* __restrict__ crec, uint32_t cap, bool vec, uint32_t* __restrict__ err) {
+                                                  uint32_t* __restrict__ crec, uint32_t cap, bool vec, uint32_t* __restrict__ err,
+                                                  uint8_t* __restrict__ masks) {
+  // masks[block][round][thread]: the 8-bit item mask of a thread's 4 records. The count pass writes it, the write pass reads it
+  // back instead of streaming qid / flag / mapq and probing the name table a second time.
   __shared__ uint32_t cnt[SC_ROUNDS][4];
   const uint64_t n = (uint64_t)rv.n_records;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -252,7 +255,10 @@ __global__ __launch_bounds__(256) void split_cand(RecView rv, SplitCfg c, const 
     const uint64_t r0 = (uint64_t)blockIdx.x * SC_TILE_REC + (uint64_t)k * 1024 + (uint64_t)threadIdx.x * 4;
     m[k] = 0;
     uint32_t fl4 = 0, mq4 = 0;
-    if (vec && r0 + 4 <= n) {
+    const size_t mi = ((size_t)blockIdx.x * SC_ROUNDS + k) * 256 + threadIdx.x;
+    if (WRITE) {
+      m[k] = masks[mi];
+    } else if (vec && r0 + 4 <= n) {
       const uint4 qq = *reinterpret_cast<const uint4*>(rv.qid + r0);
       q[k][0] = qq.x; q[k][1] = qq.y; q[k][2] = qq.z; q[k][3] = qq.w;
       if (c.contig) { fl4 = *reinterpret_cast<const uint32_t*>(rv.flag + r0); mq4 = *reinterpret_cast<const uint32_t*>(rv.mapq + r0); }
@@ -268,7 +274,7 @@ __global__ __launch_bounds__(256) void split_cand(RecView rv, SplitCfg c, const 
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      if (r0 + j >= n) continue;
+      if (WRITE || r0 + j >= n) continue;
       uint32_t e;                                                     // bit 0: hap 0 item, bit 1: hap 1 item
       if (!c.contig) e = 1u;
       else {
@@ -277,6 +283,7 @@ __global__ __launch_bounds__(256) void split_cand(RecView rv, SplitCfg c, const 
       }
       if (e && q[k][j] < (uint32_t)rv.n_qids && ((tab[q[k][j] >> 5] >> (q[k][j] & 31u)) & 1u)) m[k] |= e << (2 * j);
     }
+    if (!WRITE) masks[mi] = (uint8_t)m[k];
     const uint32_t cc = (uint32_t)__popc(m[k]);
     uint32_t incl = cc;
 #pragma unroll
@@ -305,7 +312,7 @@ __global__ __launch_bounds__(256) void split_cand(RecView rv, SplitCfg c, const 
       mm &= mm - 1;
       const uint32_t j = (uint32_t)it >> 1, hap = (uint32_t)it & 1u;
       if (dst < cap) {
-        const uint32_t qj = j == 0 ? q[k][0] : j == 1 ? q[k][1] : j == 2 ? q[k][2] : q[k][3];
+        const uint32_t qj = rv.qid[r0 + j];
         const uint32_t trel = (uint32_t)(rv.tid[r0 + j] - c.tid_lo);
         if (trel >> c.tid_bits) atomicOr(err, ERRB_RANGE);          // tid outside [tid_lo, n_tids)
         ckey[dst] = ((uint64_t)trel << c.tid_shift) | ((uint64_t)hap << c.qid_bits) | qj;
@@ -755,7 +762,7 @@ static int bits_for(uint64_t n) { int b = 1; while ((1ull << b) < n && b < 63) +
 void vsv_launch_split(hipStream_t st, const RecView& rv, const vsv_params& p, int n_tids, uint32_t* tab, uint32_t tab_size,
                       uint32_t* blk_cnt, uint32_t* blk_off, uint32_t* scan_tmp, uint64_t* ckey, uint32_t* crec,
                       uint64_t* okey, uint32_t* oval, uint64_t* key2, uint32_t* idx2, const SortWork& sw, vsv_sig* s1in,
-                      uint32_t cap, Counters* ctr) {
+                      uint32_t cap, Counters* ctr, uint8_t* cmask) {
   SplitCfg c;
   c.contig = p.dtype != VSV_DTYPE_READS;
   c.min_mapq = p.min_split_mapq;
@@ -775,9 +782,9 @@ void vsv_launch_split(hipStream_t st, const RecView& rv, const vsv_params& p, in
     qid_scan_max<<<1, 1024, 0, st>>>(blk_cnt, qtiles);
     qid_mark_dups<<<qtiles, 256, 0, st>>>(rv.qid, rv.n_records, blk_cnt, tab, vec, (uint32_t)nq, &ctr->err);
     const int nblk = (int)(((uint64_t)rv.n_records + SC_TILE_REC - 1) / SC_TILE_REC);
-    split_cand<false><<<nblk, 256, 0, st>>>(rv, c, tab, blk_cnt, ckey, crec, cap, vec, &ctr->err);
+    split_cand<false><<<nblk, 256, 0, st>>>(rv, c, tab, blk_cnt, ckey, crec, cap, vec, &ctr->err, cmask);
     vsv_scan_u32_exclusive(st, blk_cnt, nblk, blk_off, scan_tmp);
-    split_cand<true><<<nblk, 256, 0, st>>>(rv, c, tab, blk_off, ckey, crec, cap, vec, &ctr->err);
+    split_cand<true><<<nblk, 256, 0, st>>>(rv, c, tab, blk_off, ckey, crec, cap, vec, &ctr->err, cmask);
     split_set_ncand<<<1, 1, 0, st>>>(blk_off, blk_cnt, nblk, cap, ctr);
     // the first result may live in the shared scratch pair, so the second sort gets a scratch pair of its own
     const SortResult r1 = vsv_radix_sort_pairs(st, ckey, crec, sw.key_alt, sw.val_alt, &ctr->n_cand, cap, c.tid_shift + tid_bits, sw);
