@@ -242,7 +242,7 @@ constexpr int SC_TILE_REC = 256 * 4 * SC_ROUNDS;    // records per block
 template <bool WRITE>
 __global__ __launch_bounds__(256) void split_cand(RecView rv, SplitCfg c, const uint32_t* __restrict__ tab,
                                                   uint32_t* __restrict__ blk, uint64_t* __restrict__ ckey,
-                                                  uint32_t* __restrict__ crec, uint32_t cap, bool vec, uint32_t* __restrict__ err,
+                                                  uint32_t* __restrict__ crec, uint32_t cap, bool vec, Counters* __restrict__ ctr,
                                                   uint8_t* __restrict__ masks) {
   // masks[block][round][thread]: the 8-bit item mask of a thread's 4 records. The count pass writes it, the write pass reads it
   // back instead of streaming qid / flag / mapq and probing the name table a second time.
@@ -301,6 +301,15 @@ __global__ __launch_bounds__(256) void split_cand(RecView rv, SplitCfg c, const 
     return;
   }
   uint32_t off = blk[blockIdx.x];  // exclusive block offset
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {   // the last block knows the total: publish the candidate and row counts
+    uint32_t t = off;
+    for (int k = 0; k < SC_ROUNDS; ++k) for (int w = 0; w < 4; ++w) t += cnt[k][w];
+    const uint32_t nc = t < cap ? t : cap;
+    ctr->n_cand = nc;
+    if (t > cap) atomicOr(&ctr->err, ERRB_CAPACITY);
+    const uint32_t s1 = ctr->n_raw + nc;
+    ctr->n_s1 = s1 < cap ? s1 : cap;
+  }
 #pragma unroll
   for (int k = 0; k < SC_ROUNDS; ++k) {
     uint32_t dst = off + below[k];
@@ -314,7 +323,7 @@ __global__ __launch_bounds__(256) void split_cand(RecView rv, SplitCfg c, const 
       if (dst < cap) {
         const uint32_t qj = rv.qid[r0 + j];
         const uint32_t trel = (uint32_t)(rv.tid[r0 + j] - c.tid_lo);
-        if (trel >> c.tid_bits) atomicOr(err, ERRB_RANGE);          // tid outside [tid_lo, n_tids)
+        if (trel >> c.tid_bits) atomicOr(&ctr->err, ERRB_RANGE);     // tid outside [tid_lo, n_tids)
         ckey[dst] = ((uint64_t)trel << c.tid_shift) | ((uint64_t)hap << c.qid_bits) | qj;
         crec[dst] = (uint32_t)(r0 + j);
       }
@@ -322,16 +331,6 @@ __global__ __launch_bounds__(256) void split_cand(RecView rv, SplitCfg c, const 
     }
     off += cnt[k][0] + cnt[k][1] + cnt[k][2] + cnt[k][3];
   }
-}
-
-__global__ void split_set_ncand(const uint32_t* __restrict__ blk_off, const uint32_t* __restrict__ blk_cnt, int nblk,
-                                uint32_t cap, Counters* ctr) {
-  const uint32_t t = blk_off[nblk - 1] + blk_cnt[nblk - 1];
-  const uint32_t nc = t < cap ? t : cap;
-  ctr->n_cand = nc;
-  if (t > cap) atomicOr(&ctr->err, ERRB_CAPACITY);
-  const uint32_t s1 = ctr->n_raw + nc;
-  ctr->n_s1 = s1 < cap ? s1 : cap;
 }
 
 // slot j of the sorted candidate list starts a pair iff slot j+1 has the same (tid,hap,qid) key.
@@ -782,10 +781,9 @@ void vsv_launch_split(hipStream_t st, const RecView& rv, const vsv_params& p, in
     qid_scan_max<<<1, 1024, 0, st>>>(blk_cnt, qtiles);
     qid_mark_dups<<<qtiles, 256, 0, st>>>(rv.qid, rv.n_records, blk_cnt, tab, vec, (uint32_t)nq, &ctr->err);
     const int nblk = (int)(((uint64_t)rv.n_records + SC_TILE_REC - 1) / SC_TILE_REC);
-    split_cand<false><<<nblk, 256, 0, st>>>(rv, c, tab, blk_cnt, ckey, crec, cap, vec, &ctr->err, cmask);
+    split_cand<false><<<nblk, 256, 0, st>>>(rv, c, tab, blk_cnt, ckey, crec, cap, vec, ctr, cmask);
     vsv_scan_u32_exclusive(st, blk_cnt, nblk, blk_off, scan_tmp);
-    split_cand<true><<<nblk, 256, 0, st>>>(rv, c, tab, blk_off, ckey, crec, cap, vec, &ctr->err, cmask);
-    split_set_ncand<<<1, 1, 0, st>>>(blk_off, blk_cnt, nblk, cap, ctr);
+    split_cand<true><<<nblk, 256, 0, st>>>(rv, c, tab, blk_off, ckey, crec, cap, vec, ctr, cmask);
     // the first result may live in the shared scratch pair, so the second sort gets a scratch pair of its own
     const SortResult r1 = vsv_radix_sort_pairs(st, ckey, crec, sw.key_alt, sw.val_alt, &ctr->n_cand, cap, c.tid_shift + tid_bits, sw);
     split_mark_pairs<<<EW_GRID, 256, 0, st>>>(r1.key, r1.val, c, rec_bits, okey, oval, ctr);
