@@ -511,8 +511,29 @@ __global__ __launch_bounds__(256) void place_raw(const vsv_sig* __restrict__ poo
 
 }  // namespace
 
+// one block for small arrays (n <= 8192: the per-block candidate counts of a 10 M-record shard): thread t owns 8 consecutive items
+__global__ __launch_bounds__(1024) void scan_small(const uint32_t* __restrict__ in, int n, uint32_t* __restrict__ out) {
+  __shared__ uint32_t sh[1024];
+  const int base = threadIdx.x * 8;
+  uint32_t v[8], s = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { v[k] = (base + k < n) ? in[base + k] : 0; s += v[k]; }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const uint32_t t = (int)threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
+    __syncthreads();
+    sh[threadIdx.x] += t;
+    __syncthreads();
+  }
+  uint32_t run = sh[threadIdx.x] - s;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { if (base + k < n) out[base + k] = run; run += v[k]; }
+}
+
 void vsv_scan_u32_exclusive(hipStream_t st, const uint32_t* in, int n, uint32_t* out, uint32_t* tmp) {
   if (n <= 0) return;
+  if (n <= 8192) { scan_small<<<1, 1024, 0, st>>>(in, n, out); return; }
   const int tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
   scan_tile_sums<<<tiles, 256, 0, st>>>(in, n, tmp);
   scan_sums_inplace<<<1, 1024, 0, st>>>(tmp, tiles);
