@@ -240,3 +240,45 @@ def test_gt_correction_on_fresh_random_inputs(tmp_path):
         (tmp_path / ("t%d" % k)).mkdir()
         tg.test_oracle_scans_match_reference([case], tmp_path / ("s%d" % k))
         tg.test_host_replay_text_level([case], tmp_path / ("t%d" % k))
+
+
+def test_error_sites_match_the_reference():
+    """Where the reference raises, the oracle reports the matching status — and where it does not, neither does the oracle:
+    an '=' op in an eligible record trips `assert offset_ref == read.reference_end` (H:396) on Hifi; on CLR the same record passes
+    silently when the gate (C:425-427) rejects it first and raises when the gate lets it through; a haplotype-tagged CLR record
+    without M ops divides by zero (C:61) whatever its mapq."""
+    mg = _mg()
+    M, I, D, EQ, S = 0, 1, 2, 7, 4
+    base = [("chr1", 1000, "PS1_hp1_a", 60, False, [(M, 500), (D, 60), (M, 500)]),
+            ("chr1", 5000, "PS1_hp2_b", 60, False, [(M, 400), (I, 80), (M, 600)])]
+
+    def outcome(style, recs):
+        try:
+            exp = mg.run_contig(style, recs, stable=True)
+            ref = 0
+        except AssertionError:
+            ref = -5
+        except ZeroDivisionError:
+            ref = -8
+        chroms = ["chr1"]
+        st, _ = oracle.run(_soa(recs, chroms), dtype=DTYPE_BY_NAME[style])
+        return ref, st
+
+    eq_ok_gate = ("chr1", 9000, "PS1_hp1_c", 60, False, [(M, 300), (EQ, 50), (M, 300)])                 # ins_pct 0: gate passes
+    eq_gated = ("chr1", 9000, "PS1_hp1_c", 60, False, [(M, 50), (I, 40), (EQ, 50), (M, 50), (I, 40), (M, 50)])   # ins 80/230 > 0.13, mean M 50 < 200
+    no_m_lowq = ("chr1", 9000, "PS1_hp1_c", 10, False, [(S, 20), (I, 60), (S, 20)])                    # tagged, mapq 10, no M op
+    assert outcome("Hifi", base) == (0, 0)
+    assert outcome("Hifi", base + [eq_ok_gate]) == (-5, -5)
+    assert outcome("Hifi", base + [eq_gated]) == (-5, -5)              # Hifi has no gate
+    assert outcome("CLR", base + [eq_ok_gate]) == (-5, -5)
+    assert outcome("CLR", base + [eq_gated]) == (0, 0)                 # the gate rejects the record before the assert is reached
+    assert outcome("CLR", base + [no_m_lowq]) == (-8, -8)
+    assert outcome("Hifi", base + [no_m_lowq]) == (0, 0)               # mapq 10: not eligible, never walked
+    # split mates: `assert rl1 == rl2` (H:331) when the two alignments of one name disagree about the read length
+    mate1 = ("chr1", 20000, "PS2_hp1_s", 60, False, [(M, 400), (S, 300)])
+    mate2_ok = ("chr1", 21000, "PS2_hp1_s", 60, False, [(S, 400), (M, 300)])
+    mate2_bad = ("chr1", 21000, "PS2_hp1_s", 60, False, [(S, 400), (M, 310)])
+    for style in ("Hifi", "ONT", "CLR"):
+        assert outcome(style, base + [mate1, mate2_ok]) == (0, 0)
+        ref, st = outcome(style, base + [mate1, mate2_bad])
+        assert ref == -5 and st == -6                                  # an AssertionError there, VSV_E_READLEN here
