@@ -310,7 +310,7 @@ def vcf_digest(lines):
 SEQ_LEN = 410000
 
 
-def run_contig(style, recs, stable):
+def run_contig(style, recs, stable, dumps=False):
     tie_log = []
     ns = load_functions(SCRIPTS[style], stable, tie_log)
     chroms = []
@@ -341,6 +341,11 @@ def run_contig(style, recs, stable):
                 pc["cluster1_%s" % hp] = jsonable({"del_cigar": dc, "ins_cigar": ic, "del_split": ds, "ins_split": is_})
                 pc["split_raw_%s" % hp] = jsonable(split_raw)
                 finals[hp] = ns["merge_all"](dc, ic, ds, is_)
+                if dumps:   # the files write_sig_cigar / write_sig_split left in the output directory (H:404-405, 461-462)
+                    for typ in ("DEL", "INS"):
+                        for src in ("cigar", "split"):
+                            fn = "%s_%s_contig_%s_%s.txt" % (c, typ, src, hp)
+                            pc.setdefault("dumps", {})[fn] = open(os.path.join(td, fn)).read()
                 pc["merged_%s" % hp] = jsonable(finals[hp])
             paired = ns["pair_sig"](finals["hp1"], finals["hp2"], 1000, 200, 0.5, 0.5)
             pc["paired"] = jsonable(paired)

@@ -54,11 +54,16 @@ def test_contig_path_on_fresh_random_inputs(style):
         recs = mg.make_contig_records(seed, n_sites=int(rng.integers(5, 60)), n_chrom=int(rng.integers(1, 3)), contigs_per_hap=int(rng.integers(1, 5)),
                                       split_pairs=int(rng.integers(0, 20)), style=style, tie_rich=bool(rng.random() < 0.5))
         recs = _mutate(recs, rng)
-        exp = mg.run_contig(style, recs, stable=True)
+        exp = mg.run_contig(style, recs, stable=True, dumps=True)
         soa = _soa(recs, exp["chroms"])
         st, tabs = oracle.run(soa, dtype=DTYPE_BY_NAME[style])
         assert st == 0, (style, seed)
         compare_contig_tables({"expected": exp}, soa, tabs)
+        # the signature dump files of <out>/signature/ (write_sig_cigar / write_sig_split), byte for byte
+        from volcanosv_amd import sigtable
+        for t_, chrom_ in enumerate(exp["chroms"]):
+            got_d = sigtable.signature_dump_texts(soa, tabs["cigar"], tabs["split"], chrom_, tid=t_)
+            assert got_d == exp["per_chrom"][chrom_]["dumps"], (style, seed, chrom_)
         # the VCF text of write_vcf (H:678-714): REF / ALT from the same synthetic sequences, ids, INFO, genotype
         import test_vcf_bam as tv
         from volcanosv_amd import vcf

@@ -118,6 +118,14 @@ def test_cli_plumbing_config1(tmp_path, name, style):
         lines = open(tmp_path / "out" / ("volcano_variant_chr%d.vcf" % (i + 1))).readlines()
         assert lines[:35] == vcf.default_header()
         assert digest(lines[35:]) == doc["expected"]["per_chrom"][chrom]["vcf"]
+        # the per-source signature lists next to the VCF (H:402-405, 459-462): the rows of the fixture's pre-cluster lists are not
+        # stored, but their clustered survivors are a subset of the dumped rows (text pinned live in tests/test_reference_live.py)
+        pc = doc["expected"]["per_chrom"][chrom]
+        for hp in ("hp1", "hp2"):
+            for typ, key in (("DEL", "del_cigar"), ("INS", "ins_cigar")):
+                dumped = set(open(tmp_path / "out" / "signature" / ("%s_%s_contig_cigar_%s.txt" % (chrom, typ, hp))).read().splitlines())
+                for row in pc["cluster1_%s" % hp][key]:
+                    assert "\t".join(str(x) for x in row) in dumped
 
 
 def test_reads_signature_lines_column_wise_equal_row_wise():

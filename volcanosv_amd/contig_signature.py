@@ -4,7 +4,7 @@ import os
 
 import numpy as np
 
-from . import vcf
+from . import sigtable, vcf
 from .abi import DTYPE_BY_NAME
 from .bam import BamFile
 from .engine import Engine, default_params
@@ -37,6 +37,10 @@ def run(dtype_name, bam_path, contig_path, ref_path, output_dir, chr_number=None
         calls, merged = eng.table("calls"), eng.table("merged")
         ref_seq = dc_ref[name] if name in dc_ref else next(iter(dc_ref.values()))   # ONT/CLR: single-chromosome FASTA (O:653-662)
         lines = vcf.vcf_lines(soa, calls, merged, ref_seq, dc_contig)
+        # the per-source signature lists the reference leaves next to the VCF (H:402-405, 459-462); nothing in the pipeline reads them
+        for fname, text in sigtable.signature_dump_texts(soa, eng.table("cigar"), eng.table("split"), name).items():
+            with open(os.path.join(output_dir, "signature", fname), "w") as f:
+                f.write(text)
         vcf.write_vcf(os.path.join(output_dir, "volcano_variant_chr%d.vcf" % i), header, lines)
         log("%s: %d records -> %d calls (%d written)" % (name, soa.n_records, len(calls), len(lines)))
         out[name] = lines

@@ -88,3 +88,22 @@ def call_fields(soa, c, merged):
 
 def hap_of(s):
     return "hp2" if s["meta"] & M_HP2 else "hp1"
+
+
+def signature_dump_texts(soa, cigar_table, split_table, chrom, tid=None):
+    """The four per-haplotype dump files extract_signature_one_hap leaves in <out>/signature/ (H:402-405 write_sig_cigar, H:459-462
+    write_sig_split): for each haplotype and type the pre-cluster list, sorted by position (stable), one tab-joined 10-field row per
+    signature. Returns {file name: text} for `chrom`. cigar_table / split_table: the engine's "cigar" / "split" tables."""
+    import numpy as np
+    out = {}
+    for src_name, table in (("cigar", cigar_table), ("split", split_table)):
+        if tid is not None and len(table):
+            table = table[table["tid"] == tid]
+        for hp, want_hp2 in (("hp1", False), ("hp2", True)):
+            for typ, want_del in (("DEL", True), ("INS", False)):
+                m = (((table["meta"] & M_HP2) != 0) == want_hp2) & (((table["meta"] & M_DEL) != 0) == want_del)
+                rows = table[m]
+                rows = rows[np.argsort(rows["pos"], kind="stable")]
+                text = "".join("\t".join(str(x) for x in sig_fields(soa, r)) + "\n" for r in rows)
+                out["%s_%s_contig_%s_%s.txt" % (chrom, typ, src_name, hp)] = text
+    return out
