@@ -367,7 +367,7 @@ def run_contig(style, recs, stable, dumps=False):
     return out
 
 
-def run_reads(recs, stable):
+def run_reads(recs, stable, dumps=False):
     tie_log = []
     ns = load_functions(SCRIPTS["READS"], stable, tie_log)
     chroms = []
@@ -382,6 +382,9 @@ def run_reads(recs, stable):
             dss, iss = ns["extract_sig_from_split_reads"]("x.bam", c, td)
             merged = ns["merge_all"](dcs + ics + dss + iss, td, c)
             out["per_chrom"][c] = {"merged": jsonable(merged)}
+            if dumps:   # the four side files (RS:130-131, 242-243)
+                out["per_chrom"][c]["dumps"] = {fn % c: open(os.path.join(td, fn % c)).read() for fn in
+                                                ("%s_DEL_reads_cigar.txt", "%s_INS_reads_ciga.txt", "%s_DEL_reads_split.txt", "%s_INS_reads_split.txt")}
     out["had_ties"] = bool(tie_log)
     return out
 

@@ -82,13 +82,17 @@ def test_reads_path_on_fresh_random_inputs():
     n_rows = 0
     for seed in range(4000, 4006):
         recs = mg.make_read_records(seed, n=int(rng.integers(50, 500)), n_chrom=int(rng.integers(1, 3)), tie_rich=bool(rng.random() < 0.5))
-        exp = mg.run_reads(recs, stable=True)
+        exp = mg.run_reads(recs, stable=True, dumps=True)
         soa = _soa(recs, exp["chroms"])
         st, tabs = oracle.run(soa, dtype=DTYPE_READS)
         assert st == 0
+        from volcanosv_amd import sigtable
         for t, chrom in enumerate(exp["chroms"]):
             got = rows(soa, tabs["reads"], dtype=DTYPE_READS, where=sel(t))
             assert got == exp["per_chrom"][chrom]["merged"], (seed, chrom)
+            assert sigtable.reads_dump_texts(soa, tabs["cigar"], tabs["split"], chrom, tid=t) == exp["per_chrom"][chrom]["dumps"], (seed, chrom)
+            text = "".join(sigtable.reads_sig_lines(soa, tabs["reads"][tabs["reads"]["tid"] == t]))
+            assert text == "".join("\t".join(str(x) for x in r) + "\n" for r in exp["per_chrom"][chrom]["merged"]), (seed, chrom)
             n_rows += len(got)
     assert n_rows > 100
 

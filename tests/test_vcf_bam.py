@@ -180,6 +180,11 @@ def test_cli_reads_signature(tmp_path):
         got = [l.rstrip("\n").split("\t") for l in open(tmp_path / "out" / "reads_signature" / ("%s_reads_sig.txt" % chrom))]
         want = [[str(x) for x in row] for row in doc["expected"]["per_chrom"][chrom]["merged"]]
         assert got == want
+        # the four side files (RS:130-131, 242-243; text pinned live in tests/test_reference_live.py): together they hold the same rows
+        side = []
+        for fn in ("%s_DEL_reads_cigar.txt", "%s_INS_reads_ciga.txt", "%s_DEL_reads_split.txt", "%s_INS_reads_split.txt"):
+            side += [l.rstrip("\n").split("\t") for l in open(tmp_path / "out" / "reads_signature" / (fn % chrom))]
+        assert sorted(side) == sorted(want)
 
 
 def _cigar_for(seg, primary):

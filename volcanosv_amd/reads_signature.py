@@ -30,6 +30,9 @@ def run(input_path, output_dir, chr_number, device=0, engine=None, params=None, 
     if not device_ingest:
         eng.run(soa, p)
     lines = sigtable.reads_sig_lines(soa, eng.table("reads"))
+    for fname, text in sigtable.reads_dump_texts(soa, eng.table("cigar"), eng.table("split"), chrom).items():   # RS:130-131, 242-243
+        with open(os.path.join(out_dir, fname), "w") as f:
+            f.write(text)
     path = os.path.join(out_dir, chrom + "_reads_sig.txt")
     with open(path, "w") as f:
         f.writelines(lines)

@@ -107,3 +107,19 @@ def signature_dump_texts(soa, cigar_table, split_table, chrom, tid=None):
                 text = "".join("\t".join(str(x) for x in sig_fields(soa, r)) + "\n" for r in rows)
                 out["%s_%s_contig_%s_%s.txt" % (chrom, typ, src_name, hp)] = text
     return out
+
+
+def reads_dump_texts(soa, cigar_table, split_table, chrom, tid=None):
+    """The four side files of extract_reads_signature.py (RS:130-131, 242-243; the INS cigar file really is spelled `_reads_ciga.txt`
+    there): the CIGAR and split signature lists per type, sorted by position (stable), tab-joined str() fields."""
+    import numpy as np
+    out = {}
+    for (table, names) in ((cigar_table, {True: "%s_DEL_reads_cigar.txt", False: "%s_INS_reads_ciga.txt"}),
+                           (split_table, {True: "%s_DEL_reads_split.txt", False: "%s_INS_reads_split.txt"})):
+        if tid is not None and len(table):
+            table = table[table["tid"] == tid]
+        for want_del, pattern in names.items():
+            rows = table[((table["meta"] & M_DEL) != 0) == want_del]
+            rows = rows[np.argsort(rows["pos"], kind="stable")]
+            out[pattern % chrom] = "".join("\t".join(str(x) for x in sig_fields(soa, r, DTYPE_READS)) + "\n" for r in rows)
+    return out
