@@ -291,3 +291,45 @@ def test_error_sites_match_the_reference():
         assert outcome(style, base + [mate1, mate2_ok]) == (0, 0)
         ref, st = outcome(style, base + [mate1, mate2_bad])
         assert ref == -5 and st == -6                                  # an AssertionError there, VSV_E_READLEN here
+
+
+def test_filter_tra_merge_on_fresh_random_inputs(tmp_path):
+    """Complex_SV/filter_tra.py load_raw_vcf / cluster_bnd / merge_bnd (:32-116), AST-extracted: the merged VCF text of the host mirror
+    (bnd.merge_bnd_lines) on random breakend lines — dense positions, both bracket types, repeated keys, neighbours that share a
+    centre key through the reference's own avg_pos2 slip (:64)."""
+    import ast
+    from collections import defaultdict
+    from volcanosv_amd import bnd
+    src = open(os.path.join(REF, "bin/VolcanoSV-vc/Complex_SV/filter_tra.py")).read()
+    fdefs = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef)]
+    ns = {"np": np, "os": os, "defaultdict": defaultdict}
+    exec(compile(ast.Module(body=fdefs, type_ignores=[]), "filter_tra.py", "exec"), ns)
+    rng = np.random.default_rng(11)
+    n_merged = 0
+    for case in range(40):
+        lines = ["##fileformat=VCFv4.2\n", "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS\n"]
+        n = int(rng.integers(2, 80))
+        span = int(rng.choice([300, 3000, 100000]))
+        body = []
+        for k in range(n):
+            c1, c2 = "chr%d" % rng.integers(1, 3), "chr%d" % rng.integers(1, 4)
+            p1, p2 = int(rng.integers(1, span)), int(rng.integers(1, span))
+            alt = [("N[%s:%d[", "["), ("]%s:%d]N", "]"), ("[%s:%d[N", "["), ("N]%s:%d]", "]")][int(rng.integers(0, 4))][0] % (c2, p2)
+            body.append((c1, p1, "%s\t%d\tsvim_asm.BND.%d\tN\t%s\t.\tPASS\tSVTYPE=BND;READS=PS%d_hp1_x\tGT\t%s\n" %
+                         (c1, p1, k, alt, k, rng.choice(["0/1", "1/0", "1/1"]))))
+        if rng.random() < 0.5:
+            body += body[: max(1, n // 10)]                                   # repeated keys
+        body.sort(key=lambda x: (x[0], x[1]))                                 # the svim VCF is position-sorted
+        lines += [b[2] for b in body]
+        lines.insert(5, "chr1\t50\tsvim_asm.INS.1\tN\t<INS>\t.\tPASS\tSVTYPE=INS\tGT\t0/1\n")      # non-BND lines are dropped
+        vp = tmp_path / ("t%d.vcf" % case)
+        vp.write_text("".join(lines))
+        dc, header, l1, l2 = ns["load_raw_vcf"](str(vp))
+        if not l1 or not l2:
+            continue                                                          # the reference indexes bnd_list[0] of an empty list
+        outp = tmp_path / ("o%d.vcf" % case)
+        ns["merge_bnd"](dc, str(outp), header, 100, l1, l2)
+        hdr, got = bnd.merge_bnd_lines(lines, 100)
+        assert "".join(hdr + got) == outp.read_text(), case
+        n_merged += sum(1 for g in got if g.rstrip().endswith("1/1"))
+    assert n_merged > 20
