@@ -333,3 +333,30 @@ def test_filter_tra_merge_on_fresh_random_inputs(tmp_path):
         assert "".join(hdr + got) == outp.read_text(), case
         n_merged += sum(1 for g in got if g.rstrip().endswith("1/1"))
     assert n_merged > 20
+
+
+def test_svim_vcf_header_equals_write_final_vcf(tmp_path):
+    """The header of variants.vcf: svim-asm's write_final_vcf (SVIM_COMBINE.py:379-425, AST-extracted, default type list, no
+    candidates) against bnd.vcf_header, line for line except the time stamp."""
+    import ast
+    import re
+    import time
+    import types
+    from volcanosv_amd import bnd
+    sv = os.path.join(REF, "bin/VolcanoSV-vc/Complex_SV/svim-asm-1.0.2/src/svim_asm")
+    tree = ast.parse(open(os.path.join(sv, "SVIM_COMBINE.py")).read())
+    fdefs = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ("write_final_vcf", "sorted_nicely")]
+    from collections import defaultdict
+    ns = {"time": time, "re": re, "defaultdict": defaultdict}
+    exec(compile(ast.Module(body=fdefs, type_ignores=[]), "SVIM_COMBINE.py", "exec"), ns)
+    contigs = [("chr1", 248956422), ("chr10", 133797422), ("chrX", 156040895)]
+    for qn in (True, False):
+        opts = types.SimpleNamespace(working_dir=str(tmp_path), tandem_duplications_as_insertions=False, interspersed_duplications_as_insertions=False,
+                                     query_names=qn, sample="Sample", symbolic_alleles=False)
+        ns["write_final_vcf"]([], [], [], [], [], [], "1.0.2", [c[0] for c in contigs], [c[1] for c in contigs],
+                              ["DEL", "INS", "INV", "DUP:TANDEM", "DUP:INT", "BND"], types.SimpleNamespace(close=lambda: None), opts)
+        want = open(tmp_path / "variants.vcf").read().splitlines(True)
+        got = bnd.vcf_header(contigs, qn, "Sample")
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            assert g == w or (g.startswith("##fileDate=") and w.startswith("##fileDate="))

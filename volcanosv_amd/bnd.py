@@ -225,3 +225,27 @@ def merge_bnd_lines(lines, max_dist=100):
             d[-1] = "1/1"
             body.append("\t".join(d) + "\n")
     return header, body
+
+
+def vcf_header(contigs, query_names=True, sample="Sample"):
+    """Header lines of variants.vcf exactly as `svim-asm diploid` writes them with its default type list
+    (DEL,INS,INV,DUP:TANDEM,DUP:INT,BND; SVIM_COMBINE.py:394-425) — the breakend branch only emits BND records, but the caller
+    (volcanosv-vc-complex-sv.py phase_vcf, :78) indexes the header from its end, so the line set is kept whole."""
+    import time
+    h = ["##fileformat=VCFv4.2", "##fileDate=%s" % time.strftime("%Y-%m-%d|%I:%M:%S%p|%Z|%z"), "##source=SVIM-asm-v1.0.2"]
+    h += ["##contig=<ID=%s,length=%d>" % (n, l) for n, l in contigs]
+    h += ['##ALT=<ID=DEL,Description="Deletion">', '##ALT=<ID=INV,Description="Inversion">', '##ALT=<ID=DUP,Description="Duplication">',
+          '##ALT=<ID=DUP:TANDEM,Description="Tandem Duplication">', '##ALT=<ID=DUP:INT,Description="Interspersed Duplication">',
+          '##ALT=<ID=INS,Description="Insertion">', '##ALT=<ID=BND,Description="Breakend">',
+          '##INFO=<ID=SVTYPE,Number=1,Type=String,Description="Type of structural variant">',
+          '##INFO=<ID=CUTPASTE,Number=0,Type=Flag,Description="Genomic origin of interspersed duplication seems to be deleted">',
+          '##INFO=<ID=END,Number=1,Type=Integer,Description="End position of the variant described in this record">',
+          '##INFO=<ID=SVLEN,Number=1,Type=Integer,Description="Difference in length between REF and ALT alleles">']
+    if query_names:
+        h.append('##INFO=<ID=READS,Number=.,Type=String,Description="Names of all supporting reads">')
+    h += ['##FILTER=<ID=not_fully_covered,Description="Tandem duplication is not fully covered by a contig">',
+          '##FILTER=<ID=incomplete_inversion,Description="Only one inversion breakpoint is supported">',
+          '##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">',
+          '##FORMAT=<ID=CN,Number=1,Type=Integer,Description="Copy number of tandem duplication (e.g. 2 for one additional copy)">',
+          "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + sample]
+    return [x + "\n" for x in h]

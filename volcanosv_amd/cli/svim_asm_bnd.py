@@ -37,14 +37,8 @@ eng = Engine(0)
 cand, calls = eng.bnd(seg)
 eng.close()
 os.makedirs(args.working_dir, exist_ok=True)
-with open(os.path.join(args.working_dir, "variants.vcf"), "w") as f:   # header: SVIM_COMBINE.py:394-425 (BND-relevant lines)
-    f.write("##fileformat=VCFv4.2\n##fileDate=%s\n##source=SVIM-asm-v1.0.2\n" % time.strftime("%Y-%m-%d|%I:%M:%S%p|%Z|%z"))
-    for n, l in contigs:
-        f.write("##contig=<ID=%s,length=%d>\n" % (n, l))
-    f.write('##ALT=<ID=BND,Description="Breakend">\n##INFO=<ID=SVTYPE,Number=1,Type=String,Description="Type of structural variant">\n')
-    if args.query_names:
-        f.write('##INFO=<ID=READS,Number=.,Type=String,Description="Names of all supporting reads">\n')
-    f.write('##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t%s\n' % args.sample)
+with open(os.path.join(args.working_dir, "variants.vcf"), "w") as f:   # header: SVIM_COMBINE.py:394-425
+    f.writelines(bnd.vcf_header(contigs, args.query_names, args.sample))
     for line in bnd.vcf_lines(seg, calls, args.query_names):
         f.write(line + "\n")
 print("%d split contigs -> %d breakend candidates -> %d calls" % (len(reads), len(cand), len(calls)))
