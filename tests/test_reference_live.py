@@ -360,3 +360,44 @@ def test_svim_vcf_header_equals_write_final_vcf(tmp_path):
         assert len(got) == len(want)
         for g, w in zip(got, want):
             assert g == w or (g.startswith("##fileDate=") and w.startswith("##fileDate="))
+
+
+def test_phase_vcf_of_both_drivers(tmp_path):
+    """phase_vcf of volcanosv-vc-large-indel.py (:202-231) and of volcanosv-vc-complex-sv.py (:67-97), AST-extracted, against
+    pipeline.phase_large_indel / phase_complex on random VCF text: PS ids from contig names, '/' -> '|' genotypes, the PS INFO
+    line spliced six lines before the header's end."""
+    import ast
+    from volcanosv_amd import bnd, pipeline
+
+    def extract(path, name):
+        tree = ast.parse(open(path).read())
+        ns = {}
+        exec(compile(ast.Module(body=[n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == name], type_ignores=[]), path, "exec"), ns)
+        return ns[name]
+
+    rng = np.random.default_rng(12)
+    # large indel
+    ref_fn = extract(os.path.join(REF, "bin/VolcanoSV-vc/Large_INDEL/volcanosv-vc-large-indel.py"), "phase_vcf")
+    header = ["##fileformat=VCFv4.2\n", "##source=x\n", "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS\n"]
+    lines = list(header)
+    for k in range(200):
+        hp = int(rng.integers(1, 3))
+        reg = "PS%d_hp%d_ctg%d:%d-%d" % (rng.integers(1, 99999), hp, rng.integers(0, 9), rng.integers(1, 9999), rng.integers(1, 9999))
+        gt = str(rng.choice(["0/1", "1/1"]))
+        if gt == "1/1":
+            reg += ",PS%d_hp%d_ctg1:5-6" % (rng.integers(1, 99999), 3 - hp)
+        lines.append("chr1\t%d\tvolcano.chr1.INS.%d\tA\tAC\t20\tPASS\tSVLEN=1;SVTYPE=INS;TIG_REGION=%s;QUERY_STRAND=+\tGT\t%s\n" % (rng.integers(1, 10**8), k, reg, gt))
+    (tmp_path / "in.vcf").write_text("".join(lines))
+    (tmp_path / "hdr").write_text("".join(header))
+    ref_fn(str(tmp_path / "in.vcf"), str(tmp_path / "out.vcf"), str(tmp_path / "hdr"))
+    assert "".join(pipeline.phase_large_indel(lines, header)) == (tmp_path / "out.vcf").read_text()
+    # complex
+    ref_fn = extract(os.path.join(REF, "bin/VolcanoSV-vc/Complex_SV/volcanosv-vc-complex-sv.py"), "phase_vcf")
+    lines = bnd.vcf_header([("chr1", 1000), ("chr2", 2000)], True, "Sample")
+    for k in range(200):
+        gt = str(rng.choice(["0/1", "1/0", "1/1", "./."]))
+        lines.append("chr1\t%d\tvolcanosv.BND.%d\tN\tN[chr2:%d[\t.\tPASS\tSVTYPE=BND;READS=PS%d_hp1_c,PS%d_hp2_d\tGT\t%s\n" %
+                     (rng.integers(1, 999), k, rng.integers(1, 1999), rng.integers(1, 99999), rng.integers(1, 99999), gt))
+    (tmp_path / "c.vcf").write_text("".join(lines))
+    ref_fn(str(tmp_path / "c.vcf"), str(tmp_path / "c_out.vcf"))
+    assert "".join(pipeline.phase_complex(lines)) == (tmp_path / "c_out.vcf").read_text()
