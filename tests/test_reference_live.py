@@ -401,3 +401,23 @@ def test_phase_vcf_of_both_drivers(tmp_path):
     (tmp_path / "c.vcf").write_text("".join(lines))
     ref_fn(str(tmp_path / "c.vcf"), str(tmp_path / "c_out.vcf"))
     assert "".join(pipeline.phase_complex(lines)) == (tmp_path / "c_out.vcf").read_text()
+
+
+def test_generate_vcf_header_of_the_large_indel_driver(tmp_path):
+    """generate_vcf_header of volcanosv-vc-large-indel.py (:104-131, with the reference's own header_info data file) against
+    pipeline.generate_vcf_header: the per-run VCF header, for one chromosome and for all."""
+    import ast
+    import subprocess
+    from volcanosv_amd import pipeline
+    li = os.path.join(REF, "bin/VolcanoSV-vc/Large_INDEL")
+    tree = ast.parse(open(os.path.join(li, "volcanosv-vc-large-indel.py")).read())
+    keep = ("create_fai", "extract_contigs_from_fai", "generate_vcf_header")
+    fa = tmp_path / "ref.fa"
+    fa.write_text(">chr1 some description\n" + "ACGT" * 30 + "\nAC\n>chr2\n" + "G" * 77 + "\n>chr10\nACGTACGT\n")
+    pipeline.write_fai(str(fa))                                   # the reference shells out to samtools faidx for this file
+    for chr_num, prefix in ((None, "Sample"), (2, "HG002"), (10, "x")):
+        ns = {"os": os, "subprocess": subprocess, "code_dir": li, "prefix": prefix}
+        exec(compile(ast.Module(body=[n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in keep], type_ignores=[]), "d.py", "exec"), ns)
+        ns["generate_vcf_header"](str(fa), str(tmp_path / "ref_hdr"), chr_num)
+        pipeline.generate_vcf_header(str(fa), str(tmp_path / "my_hdr"), chr_num, prefix)
+        assert (tmp_path / "my_hdr").read_text() == (tmp_path / "ref_hdr").read_text(), (chr_num, prefix)
