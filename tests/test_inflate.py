@@ -192,7 +192,7 @@ def test_device_reader_equals_host_reader_on_random_files(tmp_path, monkeypatch)
     import struct
     from volcanosv_amd import bam
     from volcanosv_amd.engine import Engine
-    rng = np.random.default_rng(606)
+    rng = np.random.default_rng(606 + int(os.environ.get("VSV_FUZZ_SEED", "0")))          # soak runs: other seeds, more files
 
     def random_aux():
         out = b""
@@ -222,7 +222,7 @@ def test_device_reader_equals_host_reader_on_random_files(tmp_path, monkeypatch)
         return out
 
     with Engine(0) as eng:
-        for case in range(12):
+        for case in range(12 * int(os.environ.get("VSV_FUZZ_SCALE", "1"))):
             nref = int(rng.integers(1, 4))
             refs = [("chr%d" % (i + 1), 5_000_000) for i in range(nref)]
             recs = []
