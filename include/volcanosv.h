@@ -340,6 +340,11 @@ int vsv_redundancy_pairs(vsv_handle* h, int is_del, const int32_t* pos, const in
  * per member. comp = the members' deflate payloads back to back (host), comp_off[n+1] their byte offsets, isize[n] the
  * uncompressed sizes from the member trailers; out (host) receives sum(isize) bytes in member order. A member that is not a
  * valid deflate stream of exactly isize bytes fails the call with VSV_E_INVALID (vsv_last_count = its index). */
+/* The device parse also collects the SA:Z tag text of every kept record (what svim-asm's retrieve_other_alignments and
+ * sig_extract's split-read branch read, SVIM_COLLECT.py:12, SE:479): '\n'-joined in record order, empty for records without the
+ * tag; valid until the handle's next device parse. */
+int vsv_bam_device_want_sa(vsv_handle* h, int want);
+const char* vsv_bam_device_sa_tags(vsv_handle* h, int64_t* len);
 /* CRC-32 values of the members' gzip trailers (host array of n_members words, caller-owned, NULL / 0 clears): the next
  * vsv_bgzf_inflate / vsv_bam_parse_device over exactly n_members members computes each member's CRC-32 on the GPU and fails
  * on a mismatch, as htslib's bgzf.c does on the host. */

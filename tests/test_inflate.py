@@ -254,10 +254,11 @@ def test_device_reader_equals_host_reader_on_random_files(tmp_path, monkeypatch)
             with bam.BamFile(path) as bf:
                 for chrom in [None] + [refs[int(rng.integers(0, nref))][0]]:
                     host = bf.fetch_soa(chrom)
-                    view = bf.fetch_device(eng, chrom)
+                    view = bf.fetch_device(eng, chrom, sa=True)
                     assert isinstance(view, bam.DeviceRecordView), (case, chrom)
                     dev = view.to_host()
                     assert dev.n_records == host.n_records and dev.n_ops == host.n_ops and view.n_qids == host.n_qids, (case, chrom)
+                    assert list(view.sa_tags) == list(host.sa_tags), (case, chrom)
                     for name in ("pos", "tid", "qid", "cigar_off", "mapq", "flag", "cigar", "l_seq", "sam_flags"):
                         assert np.array_equal(getattr(host, name), getattr(dev, name)), (case, chrom, name)
                     assert list(host.qnames) == list(dev.qnames), (case, chrom)

@@ -190,14 +190,15 @@ class BamFile:
     def get_tid(self, name):
         return self.references.index(name) if name in self.references else -1
 
-    def fetch_device(self, engine, chrom=None):
+    def fetch_device(self, engine, chrom=None, sa=False):
         """All records of `chrom` (or of every reference) inflated and parsed on the GPU: returns a DeviceRecordView whose arrays
-        live in `engine`'s handle (valid until its next fetch_device). Query names come back to the host (lazily split); SA
-        tags and sequences are not extracted by this path."""
+        live in `engine`'s handle (valid until its next fetch_device). Query names come back to the host (lazily split); with
+        sa=True the SA:Z tag texts too (`view.sa_tags`, '' where absent). Sequences are not extracted by this path."""
         tid = -1 if chrom is None else self.get_tid(chrom)
         if chrom is not None and tid < 0:
             raise KeyError("reference %r not in BAM header" % chrom)
         r = Records()
+        self.lib.vsv_bam_device_want_sa(engine.h, 1 if sa else 0)
         st = self.lib.vsv_bam_load_device(self.h, engine.h, tid, C.byref(r))
         if st:
             msg = self.lib.vsv_bam_error(self.h).decode()
@@ -209,7 +210,11 @@ class BamFile:
         ln = C.c_int64()
         p = self.lib.vsv_bam_qnames(self.h, C.byref(ln))
         names = LazyLines(C.string_at(p, ln.value), int(r.n_qids))
-        return DeviceRecordView(r, names, self.references, self.lib.vsv_bam_l_seq_device(self.h), self.lib.vsv_bam_sam_flags_device(self.h), engine)
+        view = DeviceRecordView(r, names, self.references, self.lib.vsv_bam_l_seq_device(self.h), self.lib.vsv_bam_sam_flags_device(self.h), engine)
+        if sa:
+            p = self.lib.vsv_bam_device_sa_tags(engine.h, C.byref(ln))
+            view.sa_tags = LazyLines(C.string_at(p, ln.value), int(r.n_records))
+        return view
 
     def use_gpu_inflate(self, engine):
         """Inflate the BGZF windows of the following loads on the GPU (engine = volcanosv_amd.engine.Engine; None: host zlib)."""

@@ -26,14 +26,19 @@ args = ap.parse_args()
 
 reads = []
 contigs = None
+eng = Engine(0)
 for hap, path in ((1, args.bam_file1), (2, args.bam_file2)):
     with BamFile(path) as b:
         if contigs is None:
             contigs = list(zip(b.references, b.lengths))
-        soa = b.fetch_soa(None)
+        view = b.fetch_device(eng, None, sa=True)          # inflated and parsed on the GPU, SA:Z texts included
+        if hasattr(view, "to_host"):
+            soa = view.to_host()
+            soa.sa_tags = view.sa_tags
+        else:
+            soa = view                                       # the device reader gave up: this is the host reader's table
     reads += bnd.segments_from_soa(soa, hap, args.min_mapq)
 seg = bnd.SegmentSoA(reads, contigs)
-eng = Engine(0)
 cand, calls = eng.bnd(seg)
 eng.close()
 os.makedirs(args.working_dir, exist_ok=True)

@@ -265,6 +265,50 @@ __global__ __launch_bounds__(256) void win_name_store(const uint8_t* __restrict_
     nm_len[k0 + k] = l;
   }
 }
+// SA:Z tag of every kept record of the window (SVIM_COLLECT.py:12, SE:479): one lane per record walks the aux fields (whose extent
+// rec_fields has validated) and reports the text's stream offset and length (0: no SA tag); sa_store copies the texts, each followed
+// by '\n', into the compact store in record order.
+__global__ __launch_bounds__(256) void win_sa_find(const uint8_t* __restrict__ s, const uint64_t* __restrict__ w_rec_off, int64_t nk,
+                                                   uint64_t* __restrict__ sa_off, uint32_t* __restrict__ sa_len) {
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nk; k += (int64_t)gridDim.x * blockDim.x) {
+    const uint8_t* r = s + w_rec_off[k];
+    const uint32_t bs = ld32(r), l_name = r[12], nc = ld16(r + 16);
+    const int32_t ls = (int32_t)ld32(r + 20);
+    uint64_t off = 36ull + l_name + 4ull * nc + (uint64_t)((ls + 1) / 2) + (uint64_t)ls;
+    const uint64_t end = 4ull + bs;
+    uint64_t so = 0; uint32_t sl = 0;
+    while (off + 3 <= end) {
+      const uint8_t t0 = r[off], t1 = r[off + 1], ty = r[off + 2];
+      off += 3;
+      uint64_t len = 0;
+      if (ty == 'A' || ty == 'c' || ty == 'C') len = 1;
+      else if (ty == 's' || ty == 'S') len = 2;
+      else if (ty == 'i' || ty == 'I' || ty == 'f') len = 4;
+      else if (ty == 'Z' || ty == 'H') {
+        uint64_t e = off; while (e < end && r[e]) ++e;
+        if (t0 == 'S' && t1 == 'A' && ty == 'Z') { so = (uint64_t)(r + off - s); sl = (uint32_t)(e - off); }
+        len = e - off + 1;
+      } else if (ty == 'B') {
+        if (off + 5 > end) break;
+        const uint8_t sub = r[off]; const uint32_t cnt = ld32(r + off + 1);
+        len = 5 + ((sub == 'c' || sub == 'C') ? 1ull : (sub == 's' || sub == 'S') ? 2ull : 4ull) * cnt;
+      } else break;
+      if (len > end - off) break;
+      off += len;
+    }
+    sa_off[k] = so; sa_len[k] = sl + 1u;          // + the separator
+  }
+}
+__global__ __launch_bounds__(256) void win_sa_store(const uint8_t* __restrict__ s, const uint64_t* __restrict__ sa_off, const uint32_t* __restrict__ sa_len,
+                                                    const uint32_t* __restrict__ loff, int64_t nk, uint64_t s0, uint8_t* __restrict__ blob) {
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nk; k += (int64_t)gridDim.x * blockDim.x) {
+    uint8_t* d = blob + s0 + loff[k];
+    const uint32_t l = sa_len[k] - 1u;
+    const uint8_t* p = s + sa_off[k];
+    for (uint32_t c = 0; c < l; ++c) d[c] = p[c];
+    d[l] = '\n';
+  }
+}
 // name table for the host: the first occurrences in id order, '\n'-separated (the stored NUL becomes the separator)
 __global__ __launch_bounds__(256) void name_lens(const uint32_t* __restrict__ nm_len, const uint32_t* __restrict__ is_first, int64_t n, uint32_t* __restrict__ len) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) len[i] = is_first[i] ? nm_len[i] : 0u;
@@ -338,4 +382,12 @@ void vsv_bamdev_name_lens(hipStream_t st, const uint32_t* nm_len, const uint32_t
 void vsv_bamdev_name_copy(hipStream_t st, const uint8_t* names, const uint64_t* nm_off, const uint32_t* nm_len, const uint32_t* is_first, const uint32_t* noff,
                           int64_t n, uint8_t* blob) {
   if (n > 0) name_copy<<<1024, 256, 0, st>>>(names, nm_off, nm_len, is_first, noff, n, blob);
+}
+
+void vsv_bamdev_win_sa_find(hipStream_t st, const uint8_t* s, const uint64_t* w_rec_off, int64_t nk, uint64_t* sa_off, uint32_t* sa_len) {
+  if (nk > 0) win_sa_find<<<1024, 256, 0, st>>>(s, w_rec_off, nk, sa_off, sa_len);
+}
+void vsv_bamdev_win_sa_store(hipStream_t st, const uint8_t* s, const uint64_t* sa_off, const uint32_t* sa_len, const uint32_t* loff, int64_t nk,
+                             uint64_t s0, uint8_t* blob) {
+  if (nk > 0) win_sa_store<<<1024, 256, 0, st>>>(s, sa_off, sa_len, loff, nk, s0, blob);
 }

@@ -54,7 +54,10 @@ struct vsv_handle {
   DevBuf p_spec, p_cnt, p_land, p_base, p_recoff, p_pos, p_tid, p_mapq, p_flag, p_lseq, p_sflag, p_ncig, p_cgsrc, p_hash, p_keep, p_kidx,
       p_cigoff, p_sums, p_tot, p_err;                     // device BAM parse: per input record
   DevBuf o_pos, o_tid, o_qid, o_cigoff, o_mapq, o_flag, o_cigar, o_lseq, o_sflag, o_hash, o_recoff, o_first, o_rank, o_nlen, o_noff, o_blob, o_n, o_names, o_nmoff, o_nmlen;
-  std::string names_blob;   // support join (post-filter)
+  std::string names_blob, sa_text;     // name table / SA tag texts of the last device parse (host copies)
+  bool want_sa = false;                // vsv_bam_set_want_sa: the device parse also collects the SA:Z texts
+  DevBuf o_saoff, o_salen, o_saloc, o_sa;
+  std::string names_blob_unused;   // support join (post-filter)
   int pass_cursor = 0;
   const uint64_t* sorted_key = nullptr;   // sorted keys of the stage just sorted (cluster / pair read them)
   bool small_sort_tiles = true;    // radix tile size, re-decided after every run from its row counts
@@ -394,7 +397,7 @@ void vsv_destroy(vsv_handle* h) {
                     &h->g_re, &h->g_rev, &h->g_hap, &h->g_len, &h->g_rank, &h->j_cpos, &h->j_clen, &h->j_spos, &h->j_slen, &h->j_send, &h->j_out, &h->j_err, &h->z_comp, &h->z_coff, &h->z_ooff, &h->z_out, &h->z_stat, &h->p_spec, &h->p_cnt, &h->p_land, &h->p_base, &h->p_recoff, &h->p_pos, &h->p_tid,
                     &h->p_mapq, &h->p_flag, &h->p_lseq, &h->p_sflag, &h->p_ncig, &h->p_cgsrc, &h->p_hash, &h->p_keep, &h->p_kidx, &h->p_cigoff, &h->p_sums,
                     &h->p_tot, &h->p_err, &h->o_pos, &h->o_tid, &h->o_qid, &h->o_cigoff, &h->o_mapq, &h->o_flag, &h->o_cigar, &h->o_lseq, &h->o_sflag,
-                    &h->o_hash, &h->o_recoff, &h->o_first, &h->o_rank, &h->o_nlen, &h->o_noff, &h->o_blob, &h->o_n, &h->o_names, &h->o_nmoff, &h->o_nmlen, &h->gflag, &h->cmask};
+                    &h->o_hash, &h->o_recoff, &h->o_first, &h->o_rank, &h->o_nlen, &h->o_noff, &h->o_blob, &h->o_n, &h->o_names, &h->o_nmoff, &h->o_nmlen, &h->gflag, &h->cmask, &h->o_saoff, &h->o_salen, &h->o_saloc, &h->o_sa};
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
   if (h->pinned) hipHostFree(h->pinned);
   if (h->ev0) hipEventDestroy(h->ev0);
@@ -777,6 +780,16 @@ static int inflate_to_device(vsv_handle* h, const uint8_t* comp, const uint64_t*
   return 0;
 }
 
+int vsv_bam_device_want_sa(vsv_handle* h, int want) {
+  if (!h) return VSV_E_INVALID;
+  h->want_sa = want != 0;
+  return 0;
+}
+const char* vsv_bam_device_sa_tags(vsv_handle* h, int64_t* len) {
+  if (len) *len = h ? (int64_t)h->sa_text.size() : 0;
+  return h ? h->sa_text.c_str() : "";
+}
+
 int vsv_bgzf_set_expected_crc(vsv_handle* h, const uint32_t* crc, int64_t n_members) {
   if (!h || n_members < 0 || (n_members > 0 && !crc)) return VSV_E_INVALID;
   h->expect_crc = n_members ? crc : nullptr;
@@ -836,7 +849,8 @@ int vsv_bam_parse_device(vsv_handle* h, const uint8_t* comp, const uint64_t* com
 #define DEVMEM(expr) do { if ((rc = (expr))) return rc == VSV_E_HIP ? fail(h, VSV_E_CAPACITY, "device memory exhausted in the device reader: use the host reader") : rc; } while (0)
   DEVMEM(ensure(h, h->p_err, 256)); DEVMEM(ensure(h, h->p_tot, 256)); DEVMEM(ensure(h, h->o_n, 256));
   HIPCHK(h, hipMemsetAsync(h->p_err.p, 0, 4, st));
-  uint64_t carry = first_record, K0 = 0, C0 = 0, N0 = 0;
+  uint64_t carry = first_record, K0 = 0, C0 = 0, N0 = 0, S0 = 0;
+  h->sa_text.clear();
   const bool timing = getenv("VSV_BAM_TIMING") != nullptr;
   double t_inf = 0, t_chain = 0, t_rec = 0, t_names = 0, t_qid = 0;
   int n_windows = 0, n_rounds = 0;
@@ -945,6 +959,21 @@ int vsv_bam_parse_device(vsv_handle* h, const uint8_t* comp, const uint64_t* com
         vsv_bamdev_win_name_store(st, s, (const uint64_t*)h->o_recoff.p, (const uint32_t*)h->o_noff.p, (int64_t)nk, K0, N0, (uint8_t*)h->o_names.p,
                                   (uint64_t*)h->o_nmoff.p, (uint32_t*)h->o_nmlen.p);
         HIPCHK(h, hipStreamSynchronize(st));
+        if (h->want_sa) {   // SA:Z texts of the kept records, '\n' after each, appended in record order
+          DEVMEM(ensure(h, h->o_saoff, (size_t)nk * 8)); DEVMEM(ensure(h, h->o_salen, (size_t)nk * 4 + 16)); DEVMEM(ensure(h, h->o_saloc, (size_t)nk * 4 + 16));
+          vsv_bamdev_win_sa_find(st, s, (const uint64_t*)h->o_recoff.p, (int64_t)nk, (uint64_t*)h->o_saoff.p, (uint32_t*)h->o_salen.p);
+          vsv_scan_u32_exclusive(st, (const uint32_t*)h->o_salen.p, (int)nk, (uint32_t*)h->o_saloc.p, (uint32_t*)h->p_sums.p);
+          uint32_t so_ = 0, sl_ = 0;
+          HIPCHK(h, hipMemcpyAsync(&so_, (uint32_t*)h->o_saloc.p + (nk - 1), 4, hipMemcpyDeviceToHost, st));
+          HIPCHK(h, hipMemcpyAsync(&sl_, (uint32_t*)h->o_salen.p + (nk - 1), 4, hipMemcpyDeviceToHost, st));
+          HIPCHK(h, hipStreamSynchronize(st));
+          const uint64_t sb_w = (uint64_t)so_ + sl_;
+          DEVMEM(ensure_keep(h, h->o_sa, (size_t)(S0 + sb_w) + 16, (size_t)S0));
+          vsv_bamdev_win_sa_store(st, s, (const uint64_t*)h->o_saoff.p, (const uint32_t*)h->o_salen.p, (const uint32_t*)h->o_saloc.p, (int64_t)nk, S0,
+                                  (uint8_t*)h->o_sa.p);
+          HIPCHK(h, hipStreamSynchronize(st));
+          S0 += sb_w;
+        }
         K0 += nk; C0 += ops_w; N0 += nb_w;
         lap(t_names);
       }
@@ -955,6 +984,12 @@ int vsv_bam_parse_device(vsv_handle* h, const uint8_t* comp, const uint64_t* com
   const int64_t nk = (int64_t)K0;
   out->n_records = nk; out->n_ops = (int64_t)C0; out->n_tids = n_ref;
   if (nk == 0) return 0;
+  if (h->want_sa && S0 > 0) {      // one text per record, '\n' between them (the last separator is dropped)
+    h->sa_text.resize((size_t)S0);
+    HIPCHK(h, hipMemcpyAsync(&h->sa_text[0], h->o_sa.p, (size_t)S0, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    h->sa_text.pop_back();
+  }
   const size_t K = (size_t)nk;
   HIPCHK(h, hipMemcpyAsync((uint64_t*)h->o_cigoff.p + K, &C0, 8, hipMemcpyHostToDevice, st));
   // ---- dense first-appearance query ids: stable sort of (name hash, record), group heads, ranks of the first occurrences ---

@@ -193,6 +193,9 @@ void vsv_bamdev_assign(hipStream_t st, const uint64_t* skey, const uint32_t* sva
 void vsv_bamdev_win_name_lens(hipStream_t st, const uint8_t* s, const uint64_t* w_rec_off, int64_t nk, uint32_t* len);
 void vsv_bamdev_win_name_store(hipStream_t st, const uint8_t* s, const uint64_t* w_rec_off, const uint32_t* loff, int64_t nk, uint64_t k0, uint64_t n0,
                                uint8_t* names, uint64_t* nm_off, uint32_t* nm_len);
+void vsv_bamdev_win_sa_find(hipStream_t st, const uint8_t* s, const uint64_t* w_rec_off, int64_t nk, uint64_t* sa_off, uint32_t* sa_len);
+void vsv_bamdev_win_sa_store(hipStream_t st, const uint8_t* s, const uint64_t* sa_off, const uint32_t* sa_len, const uint32_t* loff, int64_t nk,
+                             uint64_t s0, uint8_t* blob);
 void vsv_bamdev_name_lens(hipStream_t st, const uint32_t* nm_len, const uint32_t* is_first, int64_t n, uint32_t* len);
 void vsv_bamdev_name_copy(hipStream_t st, const uint8_t* names, const uint64_t* nm_off, const uint32_t* nm_len, const uint32_t* is_first, const uint32_t* noff,
                           int64_t n, uint8_t* blob);
