@@ -32,7 +32,7 @@ if __name__ == "__main__":
                 pass
             try:
                 with bam.BamFile(p) as bf:
-                    view = bf.fetch_device(eng, None)
+                    view = bf.fetch_device(eng, None, sa=bool(it % 2))      # every other file also collects the SA:Z texts
                     if isinstance(view, bam.DeviceRecordView):
                         dev = view.to_host()
                         if host is None:
@@ -40,6 +40,8 @@ if __name__ == "__main__":
                         else:
                             for name in ("pos", "tid", "qid", "cigar_off", "mapq", "flag", "cigar"):
                                 assert np.array_equal(getattr(host, name), getattr(dev, name)), (it, name)
+                            if it % 2:
+                                assert list(view.sa_tags) == list(host.sa_tags), it
                             same += 1
                     else:
                         fell_back += 1
