@@ -28,8 +28,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--records", type=int, default=10_000_000, help="records per GPU (config 2: 10 M)")
     ap.add_argument("--shape", default="hifi", choices=["hifi", "ont", "contig"])
     ap.add_argument("--dtype", default=None, help="Hifi | ONT | CLR | READS (default by shape)")
