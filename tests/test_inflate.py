@@ -184,6 +184,32 @@ def test_device_reader_rejects_damaged_files(tmp_path):
 
 
 @pytest.mark.gpu
+def test_device_reader_rejects_an_empty_read_name(tmp_path):
+    """l_read_name counts the NUL, so 0 is malformed (htslib rejects it). The device reader used to accept it and then stored the
+    name table's separator one byte in front of the blob (d[l - 1] with l = 0): now the record is reported and the caller
+    falls back to the host reader."""
+    from volcanosv_amd import bam
+    from volcanosv_amd.engine import Engine
+    recs = [dict(tid=0, pos=100 + 10 * i, qname="PS1_hp%d_%d" % (1 + i % 2, i), mapq=60, flag=0, cigar=[(0, 50), (1, 40), (0, 50)]) for i in range(200)]
+
+    def zero_name_len(stream, offs):
+        stream[offs[77] + 12] = 0          # block_size(4) refID(4) pos(4) l_read_name(1)
+
+    path = str(tmp_path / "noname.bam")
+    bam.write_bam(path, [("chr10", 1_000_000)], recs, mutate=zero_name_len)
+    from volcanosv_amd.abi import VsvError
+    with Engine(0) as eng, bam.BamFile(path) as bf:
+        # the device reader reports the record and hands over to the host reader, which (the name's bytes now read as CIGAR and
+        # tags) rejects the file as well: an error, never a store in front of the name table
+        with pytest.warns(UserWarning, match="use the host reader"), pytest.raises(VsvError):
+            bf.fetch_device(eng, "chr10")
+        good = str(tmp_path / "named.bam")
+        bam.write_bam(good, [("chr10", 1_000_000)], recs)
+        with bam.BamFile(good) as bg:                          # the engine is still usable afterwards
+            assert bg.fetch_device(eng, "chr10").n_records == 200
+
+
+@pytest.mark.gpu
 def test_device_reader_equals_host_reader_on_random_files(tmp_path, monkeypatch):
     """Random BAM files: 1-3 references, unmapped-placed and reference-less records, names up to 250 characters with 'hp1' / 'hp2'
     anywhere, repeated names, empty CIGARs, > 65535-op CIGARs in CG:B,I behind aux fields of every type, SA tags, members of

@@ -284,11 +284,12 @@ for _i, _ch in enumerate("=ACMGRSVTWYHKDBN"):
     _NIBBLE[ord(_ch)] = _i
 
 
-def write_bam(path, references, records, header_text=None, block_bytes=60000, level=6):
+def write_bam(path, references, records, header_text=None, block_bytes=60000, level=6, mutate=None):
     """references: [(name, length)]; records: iterable of dicts with keys tid, pos, qname, mapq, flag (SAM flag),
     cigar [(op,len)], optional seq (bases) or seq_len (bases are written as 'N'; 0 => '*'), optional tags {b'SA': 'text'},
     optional aux (raw, already encoded aux fields written before the CG / Z tags). block_bytes: uncompressed bytes per BGZF
-    member (an int, or a callable returning the size of the next member); level: zlib level (0 = stored blocks)."""
+    member (an int, or a callable returning the size of the next member); level: zlib level (0 = stored blocks); mutate(stream,
+    record_offsets): optional hook that edits the uncompressed BAM stream in place before it is framed (malformed-input tests)."""
     if header_text is None:
         header_text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % (n, l) for n, l in references)
     out = bytearray()
@@ -297,7 +298,9 @@ def write_bam(path, references, records, header_text=None, block_bytes=60000, le
     for name, length in references:
         nm = name.encode() + b"\x00"
         out += struct.pack("<i", len(nm)) + nm + struct.pack("<i", length)
+    rec_offsets = []
     for r in records:
+        rec_offsets.append(len(out))
         qn = r["qname"].encode() + b"\x00"
         cig = r["cigar"]
         ref_len = sum(l for op, l in cig if op in (0, 2, 3, 7, 8))
@@ -321,6 +324,8 @@ def write_bam(path, references, records, header_text=None, block_bytes=60000, le
             packed = b"\xff" * ((l_seq + 1) // 2)
         body += packed + b"\xff" * l_seq + tags
         out += struct.pack("<i", len(body)) + body
+    if mutate is not None:
+        mutate(out, rec_offsets)
     with open(path, "wb") as f:
         i = 0
         while i < len(out):

@@ -106,7 +106,9 @@ __global__ __launch_bounds__(256) void rec_fields(const uint8_t* __restrict__ s,
   const int32_t ls = (int32_t)ld32(r + 20);
   pos[i] = (int32_t)ld32(r + 8); tid[i] = ref; mapq[i] = r[13]; l_seq[i] = (uint32_t)ls; sam_flag[i] = fl;
   // the variable-length fields must fit the record: every later access (name, CIGAR, tags) relies on it
-  if (ls < 0 || 32ull + l_name + 4ull * nc + (uint64_t)((ls + 1ll) / 2) + (uint64_t)ls > (uint64_t)bs) {
+  // l_read_name counts the terminating NUL, so 0 is malformed (htslib's bam_read1 rejects it too); accepting it would make
+  // name_copy's separator store land at d[-1]
+  if (l_name == 0 || ls < 0 || 32ull + l_name + 4ull * nc + (uint64_t)((ls + 1ll) / 2) + (uint64_t)ls > (uint64_t)bs) {
     atomicOr(err, 4u);
     flag[i] = 0; hash[i] = 0; n_cig_out[i] = 0; cg_src[i] = 0; keep[i] = 0;
     return;
@@ -319,6 +321,7 @@ __global__ __launch_bounds__(256) void name_copy(const uint8_t* __restrict__ nam
     if (!is_first[i]) continue;
     const uint8_t* nm = names + nm_off[i];
     const uint32_t l = nm_len[i];
+    if (l == 0) continue;                      // rec_fields rejects empty names; never store at d[-1]
     uint8_t* d = blob + noff[i];
     for (uint32_t c = 0; c + 1 < l; ++c) d[c] = nm[c];
     d[l - 1] = '\n';

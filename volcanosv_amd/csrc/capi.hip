@@ -203,7 +203,16 @@ int reset_run_state(vsv_handle* h) {
   return 0;
 }
 int tid_bits(vsv_handle* h);
-StageBufs stage_bufs(vsv_handle* h) { return StageBufs{(uint64_t*)h->key.p, (uint32_t*)h->idx.p, (int32_t*)h->cl.p, h->rv.tid_lo, tid_bits(h)}; }
+// blocks of the row-parallel kernels: one row per thread for the largest table of the handle's previous run (+25 %), between 128
+// and 4096 blocks; a first run sizes for the row capacity. Every such kernel grid-strides, so this is speed only.
+int ew_grid(vsv_handle* h) {
+  const Counters& c = h->host_ctr;
+  uint64_t rows = c.n_s1 > c.n_cand ? c.n_s1 : c.n_cand;
+  rows = rows ? rows + rows / 4 : (uint64_t)h->cap_sigs;
+  const uint64_t g = (rows + 255) / 256;
+  return (int)(g < 128 ? 128 : g > 4096 ? 4096 : g);
+}
+StageBufs stage_bufs(vsv_handle* h) { return StageBufs{(uint64_t*)h->key.p, (uint32_t*)h->idx.p, (int32_t*)h->cl.p, h->rv.tid_lo, tid_bits(h), ew_grid(h)}; }
 Counters* dctr(vsv_handle* h) { return (Counters*)h->ctr.p; }
 int pos_bits(vsv_handle* h) { return h->max_pos > 0 ? bits_for((uint64_t)h->max_pos + VSV_POS_BIAS + 2) : 32; }
 int tid_bits(vsv_handle* h) { return bits_for((uint64_t)(h->n_tids > 0 ? h->n_tids - h->rv.tid_lo : 65536) + 1); }
@@ -226,9 +235,9 @@ int enq_scan(vsv_handle* h) {
   }
   vsv_launch_cigar_scan(st, srv, h->prm, (uint32_t*)h->part_rb.p, n_parts, OPS_PER_PART, (vsv_sig*)h->pool.p,
                         (uint64_t*)h->pool_key.p, (uint32_t)h->cap_sigs, (uint32_t*)h->part_count.p, (uint32_t*)h->part_off.p,
-                        (uint32_t*)h->scan_tmp.p, (vsv_sig*)h->s1in.p, dctr(h), (uint32_t*)h->shard_cnt.p, h->ev0, h->ev1);
+                        (uint32_t*)h->scan_tmp.p, (vsv_sig*)h->raw0.p, dctr(h), (uint32_t*)h->shard_cnt.p, h->ev0, h->ev1);
   h->have_scan_ev = n_parts > 0;
-  vsv_launch_fold(st, (vsv_sig*)h->s1in.p, (vsv_sig*)h->raw0.p, h->rv, h->prm, dctr(h));
+  vsv_launch_fold(st, (const vsv_sig*)h->raw0.p, (vsv_sig*)h->s1in.p, h->rv, h->prm, dctr(h), ew_grid(h));
   HIPCHK(h, hipGetLastError());
   h->stage_done = 1;
   return 0;
@@ -242,7 +251,7 @@ int enq_split(vsv_handle* h) {
   vsv_launch_split(st, rv, p, h->n_tids, (uint32_t*)h->tab.p, h->tab_size, (uint32_t*)h->blk_cnt.p, (uint32_t*)h->blk_off.p,
                    (uint32_t*)h->scan_tmp.p, (uint64_t*)h->ckey.p, (uint32_t*)h->crec.p, (uint64_t*)h->okey.p,
                    (uint32_t*)h->oval.p, (uint64_t*)h->key2.p, (uint32_t*)h->idx2.p, sort_work(h), (vsv_sig*)h->s1in.p,
-                   (uint32_t)h->cap_sigs, dctr(h), (uint8_t*)h->cmask.p);
+                   (uint32_t)h->cap_sigs, dctr(h), (uint8_t*)h->cmask.p, ew_grid(h));
   if (p.dtype == VSV_DTYPE_READS) {
     // reads.py:281-286 merge_all: one stable sort of [del_cigar, ins_cigar, del_split, ins_split] by pos
     const int nbits = pos_bits(h) + 2 + tid_bits(h) + 1;

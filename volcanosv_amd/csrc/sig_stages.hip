@@ -28,43 +28,56 @@ __device__ __forceinline__ int64_t wave_sum64(int64_t v) {
 }
 
 // ---- intra-read fold ------------------------------------------------------------------------------
-// One thread per record's group of consecutive raw rows (T_RAW order is (record, op, hap)); left fold in op
-// order, independently for each hap pass and type.
-__global__ __launch_bounds__(256) void fold_kernel(vsv_sig* __restrict__ s, const Counters* ctr) {
+// T_RAW order is (record, op, hap). The reference folds a record's signatures left to right per hap pass and type
+// (cluster_ins_one_read / cluster_del_one_read, Hifi.py:91-161): the running "last kept" signature s1 absorbs s2 when both are
+// long and close. Positions never decrease along a record, and s1 lies at or before the previous signature of its list, so a
+// signature at least T (150 DEL / 380 INS: the widest test) behind its list predecessor can merge with nothing: the lists are cut
+// into independent CHAINS at such gaps and one thread folds one chain, whatever the record's length (a Mb contig carries
+// thousands of signatures; one thread per RECORD made this the slowest kernel of the contig-like shape). Out of place: every
+// row is written once, by the thread that owns its chain.
+__device__ __forceinline__ int fold_slot(uint32_t meta) { return ((meta & VSV_M_HP2) ? 2 : 0) + ((meta & VSV_M_DEL) ? 1 : 0); }
+__global__ __launch_bounds__(256) void fold_kernel(const vsv_sig* __restrict__ in, vsv_sig* __restrict__ out, const Counters* ctr) {
   const uint32_t n = ctr->n_raw;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const uint32_t rec = s[i].rec;
-    if (i > 0 && s[i - 1].rec == rec) continue;  // not a group head
-    int64_t last[4] = {-1, -1, -1, -1};          // [hap*2 + is_del]
-    for (uint32_t k = i; k < n && s[k].rec == rec; ++k) {
-      vsv_sig s2 = s[k];
-      if (s2.meta & VSV_M_DEAD) continue;        // gated out (CLR)
-      const int slot = ((s2.meta & VSV_M_HP2) ? 2 : 0) + ((s2.meta & VSV_M_DEL) ? 1 : 0);
-      const int64_t lk = slot == 0 ? last[0] : slot == 1 ? last[1] : slot == 2 ? last[2] : last[3];
-      bool merged = false;
-      if (lk >= 0) {
-        vsv_sig s1 = s[lk];
-        int64_t d = (int64_t)s2.pos - s1.pos; if (d < 0) d = -d;
-        if (s2.meta & VSV_M_DEL) {
-          if (s1.svlen > 150 && s2.svlen > 150 && d < 150) {            // Hifi.py:148-150
-            s1.svlen = s2.pos + s2.svlen - s1.pos;                       // Hifi.py:104
-            s1.q_end = s1.q_start + 1;
-            merged = true;
-          }
-        } else {
-          if ((s1.svlen > 100 && s2.svlen > 100 && d < 250) ||           // Hifi.py:115-117 (subset), 126-128
-              (s1.svlen > 320 && s2.svlen > 320 && d < 380)) {           // Hifi.py:120-122
-            s1.q_end = s2.q_end;                                          // Hifi.py:94
-            s1.svlen = s1.q_end - s1.q_start;                             // Hifi.py:96
-            merged = true;
-          }
-        }
-        if (merged) { s[lk] = s1; s[k].meta = s2.meta | VSV_M_DEAD; }
-      }
-      if (!merged) {
-        if (slot == 0) last[0] = k; else if (slot == 1) last[1] = k; else if (slot == 2) last[2] = k; else last[3] = k;
-      }
+    const vsv_sig me = in[i];
+    if (me.meta & VSV_M_DEAD) { out[i] = me; continue; }
+    const int slot = fold_slot(me.meta);
+    const int64_t T = (me.meta & VSV_M_DEL) ? 150 : 380;
+    bool head = true;
+    for (uint32_t j = i; j-- > 0;) {                       // nearest earlier row of the same list within T
+      const vsv_sig p = in[j];
+      if (p.rec != me.rec || (int64_t)me.pos - p.pos >= T) break;
+      if (!(p.meta & VSV_M_DEAD) && fold_slot(p.meta) == slot) { head = false; break; }
     }
+    if (!head) continue;
+    vsv_sig s1 = me;
+    uint32_t last = i;
+    int32_t prev_pos = me.pos;                             // position of the list's previous row
+    for (uint32_t k = i + 1; k < n; ++k) {
+      const vsv_sig s2 = in[k];
+      if (s2.rec != me.rec || (int64_t)s2.pos - prev_pos >= T) break;   // whatever follows in this list starts a new chain
+      if ((s2.meta & VSV_M_DEAD) || fold_slot(s2.meta) != slot) continue;
+      prev_pos = s2.pos;
+      int64_t d = (int64_t)s2.pos - s1.pos; if (d < 0) d = -d;
+      bool merged = false;
+      if (s2.meta & VSV_M_DEL) {
+        if (s1.svlen > 150 && s2.svlen > 150 && d < 150) {              // Hifi.py:148-150
+          s1.svlen = s2.pos + s2.svlen - s1.pos;                         // Hifi.py:104
+          s1.q_end = s1.q_start + 1;
+          merged = true;
+        }
+      } else {
+        if ((s1.svlen > 100 && s2.svlen > 100 && d < 250) ||             // Hifi.py:115-117 (subset), 126-128
+            (s1.svlen > 320 && s2.svlen > 320 && d < 380)) {             // Hifi.py:120-122
+          s1.q_end = s2.q_end;                                            // Hifi.py:94
+          s1.svlen = s1.q_end - s1.q_start;                               // Hifi.py:96
+          merged = true;
+        }
+      }
+      if (merged) { vsv_sig dd = s2; dd.meta |= VSV_M_DEAD; out[k] = dd; }
+      else { out[last] = s1; last = k; s1 = s2; }
+    }
+    out[last] = s1;
   }
 }
 
@@ -354,38 +367,42 @@ __global__ __launch_bounds__(256) void split_mark_pairs(const uint64_t* __restri
   }
 }
 
-struct RecSum { int64_t ref_len, read_len; uint32_t first, last; };
-constexpr int SE_GROUP = 8;   // lanes cooperating on one pair slot
+constexpr int SE_GROUP = 8;          // lanes cooperating on one pair slot
+constexpr uint32_t SE_LONG_OPS = 1024;   // a pair whose two CIGARs hold more ops than this is summed by the whole wave
 __device__ __forceinline__ int64_t group_sum64(int64_t v) {
 #pragma unroll
   for (int d = SE_GROUP / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
   return v;
 }
-__device__ __forceinline__ RecSum rec_summary(const RecView& rv, uint32_t r, bool reads, int lane) {
-  uint64_t a, b;
-  vsv_op_range(rv, r, a, b);
-  int64_t rl = 0, rf = 0;
-  for (uint64_t k = a + lane; k < b; k += SE_GROUP) {
-    const uint32_t w = rv.cigar[k], op = w & 15u, len = w >> 4;
-    if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rf += len;           // pysam reference_end
-    if (op == 0 || op == 1 || op == 4 || op == 5 || (reads && (op == 7 || op == 8))) rl += len;  // get_readlen
+// reference span (pysam reference_end - pos) and read length (get_readlen, Hifi.py:290-305 / reads.py) of the ops [a, b):
+// lane `l` of `width` lanes takes every width-th op; the caller reduces.
+__device__ __forceinline__ void op_add(uint32_t w, bool reads, int64_t& rf, int64_t& rl) {
+  const uint32_t op = w & 15u, len = w >> 4;
+  if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rf += len;           // pysam reference_end
+  if (op == 0 || op == 1 || op == 4 || op == 5 || (reads && (op == 7 || op == 8))) rl += len;  // get_readlen
+}
+__device__ __forceinline__ void op_sums(const uint32_t* __restrict__ cigar, uint64_t a, uint64_t b, bool reads, uint32_t l, uint32_t width,
+                                        int64_t& rf, int64_t& rl) {
+  uint64_t k = a + l;
+  for (; k + 7ull * width < b; k += 8ull * width) {       // eight loads in flight: a Mb contig's CIGAR is 10^4-10^6 ops
+    uint32_t w[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) w[u] = cigar[k + (uint64_t)u * width];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) op_add(w[u], reads, rf, rl);
   }
-  RecSum s;
-  s.ref_len = group_sum64(rf);
-  s.read_len = group_sum64(rl);
-  s.first = b > a ? rv.cigar[a] : 0u;
-  s.last = b > a ? rv.cigar[b - 1] : 0u;
-  return s;
+  for (; k < b; k += width) op_add(cigar[k], reads, rf, rl);
 }
 
-// SE_GROUP lanes per pair slot (in okey order); writes one signature row (possibly dead) per slot. All lanes of a
-// group take the same branches (the conditions depend only on the slot), so the shuffles inside rec_summary are safe.
+// SE_GROUP lanes per pair slot (in okey order); writes one signature row (possibly dead) per slot. Control flow is uniform
+// per group up to the sums (the group shuffles need every lane of the group), and the few pairs of long records (contig
+// alignments: 10^4-10^6 ops per CIGAR) are summed by all 64 lanes of the wave, one pair after the other.
 __global__ __launch_bounds__(256) void split_eval(RecView rv, const uint64_t* __restrict__ okey, const uint32_t* __restrict__ oval,
                                                   const uint64_t* __restrict__ ckey, const uint32_t* __restrict__ crec,
                                                   SplitCfg c, int dtype, int max_svlen, vsv_sig* __restrict__ s1in,
                                                   uint32_t cap, Counters* ctr) {
   const uint32_t n = ctr->n_cand, n_raw = ctr->n_raw;
-  const int lane = threadIdx.x & (SE_GROUP - 1);
+  const int lane = threadIdx.x & (SE_GROUP - 1), wlane = threadIdx.x & 63;
   const uint32_t ngroups = gridDim.x * (blockDim.x / SE_GROUP);
   const bool reads = dtype == VSV_DTYPE_READS;
   // whole waves iterate together (uniform trip count) so that every shuffle sees all its lanes active
@@ -393,89 +410,111 @@ __global__ __launch_bounds__(256) void split_eval(RecView rv, const uint64_t* __
   for (uint32_t q0 = blockIdx.x * (blockDim.x / SE_GROUP) + (threadIdx.x / SE_GROUP); q0 < n_pad; q0 += ngroups) {
     const bool live = q0 < n;
     const uint32_t q = live ? q0 : n - 1;   // padding groups recompute the last slot and do not store
-    if (n_raw + q >= cap) { if (lane == 0) atomicOr(&ctr->err, ERRB_CAPACITY); continue; }   // uniform per group; shuffles below are group-local
-    vsv_sig out = dead_sig();
-    if (okey[q] != VSV_KEY_DEAD) {
+    const bool room = n_raw + q < cap;
+    if (!room && lane == 0) atomicOr(&ctr->err, ERRB_CAPACITY);
+    // ---- phase 1: which pair, and does it reach the length test (Hifi.py:315-324)? ------------------------------------
+    bool need = false;
+    uint32_t i1 = 0, i2 = 0, hap = 0, last1 = 0, first2 = 0;
+    uint64_t a1 = 0, b1 = 0, a2 = 0, b2 = 0;
+    if (room && okey[q] != VSV_KEY_DEAD) {
       const uint32_t j = oval[q];
-      const uint32_t i1 = crec[j], i2 = crec[j + 1];
-      const uint32_t hap = (uint32_t)(ckey[j] >> c.qid_bits) & 1u;
+      i1 = crec[j]; i2 = crec[j + 1];
+      hap = (uint32_t)(ckey[j] >> c.qid_bits) & 1u;
       if (rv.pos[i1] > rv.pos[i2]) { if (lane == 0) atomicOr(&ctr->err, ERRB_UNSORTED); }   // Hifi.py:315
       else {
         const int minq = c.min_mapq;
         const uint32_t f1 = rv.flag[i1], f2 = rv.flag[i2];
-        uint64_t a1, b1, a2, b2;
         vsv_op_range(rv, i1, a1, b1);
         vsv_op_range(rv, i2, a2, b2);
-        const uint32_t last1 = b1 > a1 ? rv.cigar[b1 - 1] : 0u, first2 = b2 > a2 ? rv.cigar[a2] : 0u;
+        last1 = b1 > a1 ? rv.cigar[b1 - 1] : 0u; first2 = b2 > a2 ? rv.cigar[a2] : 0u;
         const uint32_t lop = last1 & 15u, fop = first2 & 15u;
-        if (((f1 ^ f2) & VSV_F_REVERSE) == 0 && rv.mapq[i1] >= minq && rv.mapq[i2] >= minq &&
-            (lop == 4 || lop == 5) && (fop == 4 || fop == 5)) {                                  // Hifi.py:323-324
-          const RecSum a = rec_summary(rv, i1, reads, lane), b = rec_summary(rv, i2, reads, lane);
-          if (a.read_len != b.read_len) { if (lane == 0) atomicOr(&ctr->err, ERRB_READLEN); }  // Hifi.py:331
-          else {
-            const int64_t Ref1e = (int64_t)rv.pos[i1] + a.ref_len, Ref2s = rv.pos[i2];
-            const int64_t Read1e = a.read_len - (int64_t)(last1 >> 4), Read2s = first2 >> 4;
-            const int64_t Diffdis = (Ref2s - Ref1e) - (Read2s - Read1e);
-            const int64_t absd = Diffdis < 0 ? -Diffdis : Diffdis;
-            if (absd <= max_svlen) {                                                             // Hifi.py:354
-              vsv_sig s = dead_sig();
-              s.rec = i1; s.rec2 = i2; s.tid = rv.tid[i1];
-              uint32_t meta = VSV_M_SPLIT | (hap ? VSV_M_HP2 : 0u);
-              bool emit = false;
-              if (dtype == VSV_DTYPE_HIFI) {
-                if (Diffdis >= 30) {
-                  const int64_t Diffolp = Read1e - Read2s, ao = Diffolp < 0 ? -Diffolp : Diffolp;
-                  if (ao <= 3000) {                                                             // Hifi.py:357
-                    const int64_t h = Diffolp / 2;                                              // int(Diffolp/2)
-                    s.pos = (int32_t)(Ref1e - h); s.svlen = (int32_t)Diffdis;
-                    s.q_start = (int32_t)(Read1e - h); s.q_end = s.q_start + 1; meta |= VSV_M_DEL; emit = true;
-                  }
-                } else if (Diffdis <= -30) {
-                  const int64_t Diffolp = Ref1e - Ref2s, ao = Diffolp < 0 ? -Diffolp : Diffolp;
-                  if (Diffolp < 3000) {                                                         // Hifi.py:362
-                    int64_t sv = Read2s - Read1e + Diffolp; if (sv < 0) sv = -sv;
-                    s.pos = (int32_t)(ao > 400 ? (Ref1e + Ref2s) / 2 : Ref2s);
-                    s.svlen = (int32_t)sv; s.q_start = (int32_t)(Read1e - Diffolp); s.q_end = (int32_t)Read2s; emit = true;
-                  }
-                }
-              } else if (dtype == VSV_DTYPE_ONT || dtype == VSV_DTYPE_CLR) {
-                // fp64 products exactly as CPython evaluates them (ONT.py:348-373, CLR.py:369-377); this
-                // file is compiled with -ffp-contract=off.
-                const double r_ = dtype == VSV_DTYPE_ONT ? 0.5 : 0.3;
-                const double lo_f = dtype == VSV_DTYPE_ONT ? 0.8 : 0.3;
-                if (Diffdis >= 30) {
-                  const int64_t Diffolp = Read1e - Read2s;
-                  const double dr = (double)Diffdis * r_;
-                  if (-dr <= (double)Diffolp && (double)Diffolp <= dr) {
-                    s.pos = (int32_t)Ref1e; s.svlen = (int32_t)Diffdis; s.q_start = (int32_t)Read1e; s.q_end = (int32_t)Read2s;
-                    meta |= VSV_M_DEL; emit = true;
-                  }
-                } else {
-                  const int64_t Diffolp = Ref1e - Ref2s, ao = Diffolp < 0 ? -Diffolp : Diffolp;
-                  const double lo = (double)Diffdis * lo_f, hi = (double)absd * r_;
-                  if (lo <= (double)Diffolp && (double)Diffolp <= hi && Diffdis <= -30) {
-                    int64_t sv = Read2s - Read1e + Diffolp; if (sv < 0) sv = -sv;
-                    s.pos = (int32_t)(ao > 400 ? (Ref1e + Ref2s) / 2 : Ref2s);
-                    s.svlen = (int32_t)sv; s.q_start = (int32_t)(Read1e - Diffolp); s.q_end = (int32_t)Read2s; emit = true;
-                  }
-                }
-              } else {  // READS: reads.py:179-196
-                const int64_t Diffolp = Ref1e - Ref2s;
-                if (Diffolp < 30 && Diffdis >= 30) {
-                  s.pos = (int32_t)Ref1e; s.svlen = (int32_t)Diffdis; s.q_start = (int32_t)Read1e; s.q_end = (int32_t)Read2s;
-                  meta |= VSV_M_DEL; emit = true;
-                } else if (Diffolp < 30 && Diffdis <= -30) {
-                  s.pos = (int32_t)((Ref1e + Ref2s) / 2); s.svlen = (int32_t)absd;
-                  s.q_start = (int32_t)Read1e; s.q_end = (int32_t)Read2s; emit = true;
-                }
+        need = ((f1 ^ f2) & VSV_F_REVERSE) == 0 && rv.mapq[i1] >= minq && rv.mapq[i2] >= minq &&
+               (lop == 4 || lop == 5) && (fop == 4 || fop == 5);                                  // Hifi.py:323-324
+      }
+    }
+    // ---- phase 2: reference span of record 1, read lengths of both --------------------------------------------------
+    const bool is_long = need && (b1 - a1) + (b2 - a2) > SE_LONG_OPS;
+    int64_t rf1 = 0, rl1 = 0, rf2 = 0, rl2 = 0;
+    if (need && !is_long) { op_sums(rv.cigar, a1, b1, reads, lane, SE_GROUP, rf1, rl1); op_sums(rv.cigar, a2, b2, reads, lane, SE_GROUP, rf2, rl2); }
+    rf1 = group_sum64(rf1); rl1 = group_sum64(rl1); rl2 = group_sum64(rl2);
+    uint64_t lm = __ballot(is_long && lane == 0);
+    while (lm) {                                       // wave-uniform: one long pair at a time, 64 lanes on its two CIGARs
+      const int src = __builtin_ctzll(lm);
+      lm &= lm - 1;
+      const uint64_t xa1 = __shfl(a1, src, 64), xb1 = __shfl(b1, src, 64), xa2 = __shfl(a2, src, 64), xb2 = __shfl(b2, src, 64);
+      int64_t f1 = 0, l1 = 0, f2 = 0, l2 = 0;
+      op_sums(rv.cigar, xa1, xb1, reads, (uint32_t)wlane, 64, f1, l1);
+      op_sums(rv.cigar, xa2, xb2, reads, (uint32_t)wlane, 64, f2, l2);
+      f1 = wave_sum64(f1); l1 = wave_sum64(l1); l2 = wave_sum64(l2);
+      if ((wlane & ~(SE_GROUP - 1)) == src) { rf1 = f1; rl1 = l1; rl2 = l2; }
+    }
+    // ---- phase 3: the pair rules, one lane per slot -------------------------------------------------------------------
+    if (lane != 0 || !live || !room) continue;
+    vsv_sig out = dead_sig();
+    if (need) {
+      if (rl1 != rl2) atomicOr(&ctr->err, ERRB_READLEN);                                          // Hifi.py:331
+      else {
+        const int64_t Ref1e = (int64_t)rv.pos[i1] + rf1, Ref2s = rv.pos[i2];
+        const int64_t Read1e = rl1 - (int64_t)(last1 >> 4), Read2s = first2 >> 4;
+        const int64_t Diffdis = (Ref2s - Ref1e) - (Read2s - Read1e);
+        const int64_t absd = Diffdis < 0 ? -Diffdis : Diffdis;
+        if (absd <= max_svlen) {                                                                 // Hifi.py:354
+          vsv_sig s = dead_sig();
+          s.rec = i1; s.rec2 = i2; s.tid = rv.tid[i1];
+          uint32_t meta = VSV_M_SPLIT | (hap ? VSV_M_HP2 : 0u);
+          bool emit = false;
+          if (dtype == VSV_DTYPE_HIFI) {
+            if (Diffdis >= 30) {
+              const int64_t Diffolp = Read1e - Read2s, ao = Diffolp < 0 ? -Diffolp : Diffolp;
+              if (ao <= 3000) {                                                                 // Hifi.py:357
+                const int64_t h = Diffolp / 2;                                                  // int(Diffolp/2)
+                s.pos = (int32_t)(Ref1e - h); s.svlen = (int32_t)Diffdis;
+                s.q_start = (int32_t)(Read1e - h); s.q_end = s.q_start + 1; meta |= VSV_M_DEL; emit = true;
               }
-              if (emit) { s.meta = meta; out = s; }
+            } else if (Diffdis <= -30) {
+              const int64_t Diffolp = Ref1e - Ref2s, ao = Diffolp < 0 ? -Diffolp : Diffolp;
+              if (Diffolp < 3000) {                                                             // Hifi.py:362
+                int64_t sv = Read2s - Read1e + Diffolp; if (sv < 0) sv = -sv;
+                s.pos = (int32_t)(ao > 400 ? (Ref1e + Ref2s) / 2 : Ref2s);
+                s.svlen = (int32_t)sv; s.q_start = (int32_t)(Read1e - Diffolp); s.q_end = (int32_t)Read2s; emit = true;
+              }
+            }
+          } else if (dtype == VSV_DTYPE_ONT || dtype == VSV_DTYPE_CLR) {
+            // fp64 products exactly as CPython evaluates them (ONT.py:348-373, CLR.py:369-377); this
+            // file is compiled with -ffp-contract=off.
+            const double r_ = dtype == VSV_DTYPE_ONT ? 0.5 : 0.3;
+            const double lo_f = dtype == VSV_DTYPE_ONT ? 0.8 : 0.3;
+            if (Diffdis >= 30) {
+              const int64_t Diffolp = Read1e - Read2s;
+              const double dr = (double)Diffdis * r_;
+              if (-dr <= (double)Diffolp && (double)Diffolp <= dr) {
+                s.pos = (int32_t)Ref1e; s.svlen = (int32_t)Diffdis; s.q_start = (int32_t)Read1e; s.q_end = (int32_t)Read2s;
+                meta |= VSV_M_DEL; emit = true;
+              }
+            } else {
+              const int64_t Diffolp = Ref1e - Ref2s, ao = Diffolp < 0 ? -Diffolp : Diffolp;
+              const double lo = (double)Diffdis * lo_f, hi = (double)absd * r_;
+              if (lo <= (double)Diffolp && (double)Diffolp <= hi && Diffdis <= -30) {
+                int64_t sv = Read2s - Read1e + Diffolp; if (sv < 0) sv = -sv;
+                s.pos = (int32_t)(ao > 400 ? (Ref1e + Ref2s) / 2 : Ref2s);
+                s.svlen = (int32_t)sv; s.q_start = (int32_t)(Read1e - Diffolp); s.q_end = (int32_t)Read2s; emit = true;
+              }
+            }
+          } else {  // READS: reads.py:179-196
+            const int64_t Diffolp = Ref1e - Ref2s;
+            if (Diffolp < 30 && Diffdis >= 30) {
+              s.pos = (int32_t)Ref1e; s.svlen = (int32_t)Diffdis; s.q_start = (int32_t)Read1e; s.q_end = (int32_t)Read2s;
+              meta |= VSV_M_DEL; emit = true;
+            } else if (Diffolp < 30 && Diffdis <= -30) {
+              s.pos = (int32_t)((Ref1e + Ref2s) / 2); s.svlen = (int32_t)absd;
+              s.q_start = (int32_t)Read1e; s.q_end = (int32_t)Read2s; emit = true;
             }
           }
+          if (emit) { s.meta = meta; out = s; }
         }
       }
     }
-    if (lane == 0 && live) s1in[n_raw + q] = out;
+    s1in[n_raw + q] = out;
   }
 }
 
@@ -749,11 +788,12 @@ void vsv_launch_clr_gate(hipStream_t st, const RecView& rv, uint8_t* gflag, Coun
   else clr_gate_records<8><<<2048, 256, 0, st>>>(rv, gflag, ctr);
 }
 
-void vsv_launch_fold(hipStream_t st, vsv_sig* raw, vsv_sig* raw_copy, const RecView& rv, const vsv_params& p, Counters* ctr) {
+// raw (T_RAW, written by place_raw) -> s1in: folded on the contig path, combined for sig_extract, a plain copy otherwise
+void vsv_launch_fold(hipStream_t st, const vsv_sig* raw, vsv_sig* s1in, const RecView& rv, const vsv_params& p, Counters* ctr, int grid) {
   const int dtype = p.dtype;
-  copy_rows<vsv_sig><<<EW_GRID, 256, 0, st>>>(raw, &ctr->n_raw, raw_copy);
-  if (dtype == VSV_DTYPE_HIFI || dtype == VSV_DTYPE_ONT || dtype == VSV_DTYPE_CLR) fold_kernel<<<EW_GRID, 256, 0, st>>>(raw, ctr);
-  if (dtype == VSV_DTYPE_CUTESV) combine_kernel<<<EW_GRID, 256, 0, st>>>(raw, ctr, p.merge_ins_threshold, p.merge_del_threshold);
+  if (dtype == VSV_DTYPE_HIFI || dtype == VSV_DTYPE_ONT || dtype == VSV_DTYPE_CLR) { fold_kernel<<<grid, 256, 0, st>>>(raw, s1in, ctr); return; }
+  copy_rows<vsv_sig><<<grid, 256, 0, st>>>(raw, &ctr->n_raw, s1in);
+  if (dtype == VSV_DTYPE_CUTESV) combine_kernel<<<EW_GRID, 256, 0, st>>>(s1in, ctr, p.merge_ins_threshold, p.merge_del_threshold);
 }
 
 static int bits_for(uint64_t n) { int b = 1; while ((1ull << b) < n && b < 63) ++b; return b; }
@@ -761,7 +801,7 @@ static int bits_for(uint64_t n) { int b = 1; while ((1ull << b) < n && b < 63) +
 void vsv_launch_split(hipStream_t st, const RecView& rv, const vsv_params& p, int n_tids, uint32_t* tab, uint32_t tab_size,
                       uint32_t* blk_cnt, uint32_t* blk_off, uint32_t* scan_tmp, uint64_t* ckey, uint32_t* crec,
                       uint64_t* okey, uint32_t* oval, uint64_t* key2, uint32_t* idx2, const SortWork& sw, vsv_sig* s1in,
-                      uint32_t cap, Counters* ctr, uint8_t* cmask) {
+                      uint32_t cap, Counters* ctr, uint8_t* cmask, int grid) {
   SplitCfg c;
   c.contig = p.dtype != VSV_DTYPE_READS;
   c.min_mapq = p.min_split_mapq;
@@ -786,9 +826,9 @@ void vsv_launch_split(hipStream_t st, const RecView& rv, const vsv_params& p, in
     split_cand<true><<<nblk, 256, 0, st>>>(rv, c, tab, blk_off, ckey, crec, cap, vec, ctr, cmask);
     // the first result may live in the shared scratch pair, so the second sort gets a scratch pair of its own
     const SortResult r1 = vsv_radix_sort_pairs(st, ckey, crec, sw.key_alt, sw.val_alt, &ctr->n_cand, cap, c.tid_shift + tid_bits, sw);
-    split_mark_pairs<<<EW_GRID, 256, 0, st>>>(r1.key, r1.val, c, rec_bits, okey, oval, ctr);
+    split_mark_pairs<<<grid, 256, 0, st>>>(r1.key, r1.val, c, rec_bits, okey, oval, ctr);
     const SortResult r2 = vsv_radix_sort_pairs(st, okey, oval, key2, idx2, &ctr->n_cand, cap, rec_bits + 1 + tid_bits + 1, sw);
-    split_eval<<<1024, 256, 0, st>>>(rv, r2.key, r2.val, r1.key, r1.val, c, p.dtype, p.max_split_svlen, s1in, cap, ctr);
+    split_eval<<<grid * 8 < 1024 ? 1024 : (grid * 8 > 8192 ? 8192 : grid * 8), 256, 0, st>>>(rv, r2.key, r2.val, r1.key, r1.val, c, p.dtype, p.max_split_svlen, s1in, cap, ctr);
   } else {
     set_n_s1<<<1, 1, 0, st>>>(ctr, cap);
   }
@@ -798,27 +838,27 @@ void vsv_launch_split(hipStream_t st, const RecView& rv, const vsv_params& p, in
 const uint64_t* vsv_launch_sort_stage(hipStream_t st, const vsv_sig* in, const uint32_t* d_n, int stage, int pb, int nbits,
                                       vsv_sig* sorted, uint32_t* d_alive, const StageBufs& b, const SortWork& sw, int64_t cap,
                                       Counters* ctr) {
-  build_keys<<<EW_GRID, 256, 0, st>>>(in, d_n, stage, pb, b.tid_lo, b.tid_bits, b.key, b.idx, ctr);
+  build_keys<<<b.grid, 256, 0, st>>>(in, d_n, stage, pb, b.tid_lo, b.tid_bits, b.key, b.idx, ctr);
   const SortResult r = vsv_radix_sort_pairs(st, b.key, b.idx, sw.key_alt, sw.val_alt, d_n, cap, nbits, sw);
-  gather_rows<vsv_sig><<<EW_GRID, 256, 0, st>>>(in, r.val, r.key, d_n, sorted, d_alive, &ctr->n_long);
+  gather_rows<vsv_sig><<<b.grid, 256, 0, st>>>(in, r.val, r.key, d_n, sorted, d_alive, &ctr->n_long);
   return r.key;
 }
 
 void vsv_launch_cluster(hipStream_t st, const vsv_sig* sorted, const uint64_t* sorted_key, const uint32_t* d_alive, int max_shift,
                         int pb, vsv_sig* out, const StageBufs& b, uint64_t* long_list, Counters* ctr) {
-  cluster_kernel<<<EW_GRID, 256, 0, st>>>(sorted, sorted_key, d_alive, max_shift, pb, b.cl, out, long_list, &ctr->n_long);
+  cluster_kernel<<<b.grid, 256, 0, st>>>(sorted, sorted_key, d_alive, max_shift, pb, b.cl, out, long_list, &ctr->n_long);
   cluster_long_kernel<<<LONG_GRID, 256, 0, st>>>(sorted, max_shift, b.cl, out, long_list, &ctr->n_long);
 }
 
 void vsv_launch_pair(hipStream_t st, const vsv_sig* merged, const uint64_t* merged_key, const uint32_t* d_alive3, int pair_shift, int pair_window,
                      vsv_call* calls_tmp, vsv_call* calls, uint32_t* d_ncalls, const StageBufs& b, uint64_t* key2, uint32_t* idx2,
                      const SortWork& sw, int pb, int nbits, int64_t cap, Counters* ctr) {
-  fill_i32<<<EW_GRID, 256, 0, st>>>(b.cl, -1, d_alive3);   // (n_long was cleared by the stage-3 gather)
+  fill_i32<<<b.grid, 256, 0, st>>>(b.cl, -1, d_alive3);   // (n_long was cleared by the stage-3 gather)
   const int right = pair_shift < pair_window ? pair_shift : pair_window;
-  pair_kernel<<<EW_GRID, 256, 0, st>>>(merged, merged_key, d_alive3, pair_shift, right, pb, b.cl, calls_tmp, key2, &ctr->n_long);
+  pair_kernel<<<b.grid, 256, 0, st>>>(merged, merged_key, d_alive3, pair_shift, right, pb, b.cl, calls_tmp, key2, &ctr->n_long);
   pair_long_kernel<<<LONG_GRID, 256, 0, st>>>(merged, merged_key, d_alive3, pair_shift, right, pb, b.cl, calls_tmp, key2, &ctr->n_long);
-  pair_finish<<<EW_GRID, 256, 0, st>>>(merged, d_alive3, b.cl, calls_tmp);
-  build_call_keys<<<EW_GRID, 256, 0, st>>>(calls_tmp, d_alive3, pb, b.tid_lo, key2, idx2);
+  pair_finish<<<b.grid, 256, 0, st>>>(merged, d_alive3, b.cl, calls_tmp);
+  build_call_keys<<<b.grid, 256, 0, st>>>(calls_tmp, d_alive3, pb, b.tid_lo, key2, idx2);
   const SortResult r = vsv_radix_sort_pairs(st, key2, idx2, sw.key_alt, sw.val_alt, d_alive3, cap, nbits, sw);
-  gather_rows<vsv_call><<<EW_GRID, 256, 0, st>>>(calls_tmp, r.val, r.key, d_alive3, calls, d_ncalls, &ctr->n_long);
+  gather_rows<vsv_call><<<b.grid, 256, 0, st>>>(calls_tmp, r.val, r.key, d_alive3, calls, d_ncalls, &ctr->n_long);
 }

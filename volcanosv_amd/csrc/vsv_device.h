@@ -107,6 +107,7 @@ struct StageBufs {
   uint32_t* idx;
   int32_t* cl;          // cluster ids / pairing state
   int tid_lo, tid_bits; // keys carry tid - tid_lo on tid_bits bits
+  int grid;             // blocks of the row-parallel kernels (sized from the row counts of the handle's previous run; the kernels grid-stride)
 };
 
 // radix_sort.hip: stable LSD radix sort of (key,val) pairs on bits [0,nbits); n on the device. The result is left in
@@ -128,11 +129,11 @@ void vsv_launch_cigar_scan(hipStream_t st, const RecView& rv, const vsv_params& 
 
 // sig_stages.hip
 void vsv_launch_clr_gate(hipStream_t st, const RecView& rv, uint8_t* gflag, Counters* ctr);   // CLR: gated flag bytes for the scan
-void vsv_launch_fold(hipStream_t st, vsv_sig* raw, vsv_sig* raw_copy, const RecView& rv, const vsv_params& p, Counters* ctr);
+void vsv_launch_fold(hipStream_t st, const vsv_sig* raw, vsv_sig* s1in, const RecView& rv, const vsv_params& p, Counters* ctr, int grid);
 void vsv_launch_split(hipStream_t st, const RecView& rv, const vsv_params& p, int n_tids, uint32_t* tab, uint32_t tab_size,
                       uint32_t* blk_cnt, uint32_t* blk_off, uint32_t* scan_tmp, uint64_t* ckey, uint32_t* crec,
                       uint64_t* okey, uint32_t* oval, uint64_t* key2, uint32_t* idx2, const SortWork& sw, vsv_sig* s1in,
-                      uint32_t cap, Counters* ctr, uint8_t* cmask);
+                      uint32_t cap, Counters* ctr, uint8_t* cmask, int grid);
 // returns the sorted key array (kept for the cluster / pair kernel that follows)
 const uint64_t* vsv_launch_sort_stage(hipStream_t st, const vsv_sig* in, const uint32_t* d_n, int stage, int pb, int nbits,
                                       vsv_sig* sorted, uint32_t* d_alive, const StageBufs& b, const SortWork& sw, int64_t cap,
