@@ -97,8 +97,14 @@ typedef struct vsv_params {
   int32_t enable_split;     /* 1: run the split-alignment stage                                   */
   int32_t merge_ins_threshold; /* CUTESV only: 100 (SE -mi): INS signals of one read at most this far apart are merged */
   int32_t merge_del_threshold; /* CUTESV only: 0   (SE -md)                                           */
-  int32_t reserved[5];
+  int32_t scan_layout;      /* VSV_SCAN_*: work mapping of the CIGAR scan; results are identical, only the speed differs  */
+  int32_t reserved[4];
 } vsv_params;
+enum {
+  VSV_SCAN_AUTO = 0,    /* by the mean CIGAR length of the call's records                                             */
+  VSV_SCAN_READS = 1,   /* record-aligned parts, lazily evaluated offsets: reads, tens to hundreds of ops per record  */
+  VSV_SCAN_CONTIGS = 2  /* fixed 8192-op parts, a record may span parts: contig alignments, 10^3-10^6 ops per record  */
+};
 
 /* ---- signature row (32 bytes) ---------------------------------------------------------------
  * Mirrors the reference 10-field list (H:80,84): chrom->tid, type/source/hap in meta, pos, svlen,

@@ -37,13 +37,25 @@ def assert_tables_equal(got, want, names):
 
 
 def run_both(eng, soa, dtype, params=None):
+    """HIP path vs oracle, once per work mapping of the CIGAR scan (vsv_params.scan_layout: record-aligned parts for reads,
+    fixed-size parts with carried offsets for contigs): whatever the records look like, both are exact."""
+    from volcanosv_amd.abi import SCAN_CONTIGS, SCAN_READS
     from volcanosv_amd.engine import default_params
     p = params if params is not None else default_params(dtype)
-    eng.run(soa, p)
-    got = eng.tables(dtype)
     st, want = oracle_run(soa, dtype, p)
     assert st == 0
-    assert_tables_equal(got, want, list(got.keys()))
+    keep = p.scan_layout
+    try:
+        for layout in (SCAN_CONTIGS, SCAN_READS):
+            p.scan_layout = layout
+            eng.run(soa, p)
+            got = eng.tables(dtype)
+            try:
+                assert_tables_equal(got, want, list(got.keys()))
+            except AssertionError as e:
+                raise AssertionError("scan_layout %d: %s" % (layout, e))
+    finally:
+        p.scan_layout = keep
     return got
 
 
@@ -171,19 +183,22 @@ def test_random_small_inputs_statuses_and_tables(eng, kind, min_ok, min_err):
     seen = set()
     for case, soa, dtype, p in fuzz_cases(kind):
         st_o, want = oracle_run(soa, dtype, p)
-        try:
-            eng.run(soa, p)
-            st_g = 0
-        except VsvError as e:
-            st_g = e.status
-        assert st_g == st_o, (kind, case, dtype, st_g, st_o)
+        for layout in (1, 2):                   # both work mappings of the scan (vsv_params.scan_layout)
+            p.scan_layout = layout
+            try:
+                eng.run(soa, p)
+                st_g = 0
+            except VsvError as e:
+                st_g = e.status
+            assert st_g == st_o, (kind, case, dtype, layout, st_g, st_o)
+            if st_o == 0:
+                got = eng.tables(dtype)
+                try:
+                    assert_tables_equal(got, want, list(got.keys()))
+                except AssertionError as e:
+                    raise AssertionError("%s case %d dtype %d layout %d: %s" % (kind, case, dtype, layout, e))
         seen.add(st_o)
         if st_o == 0:
-            got = eng.tables(dtype)
-            try:
-                assert_tables_equal(got, want, list(got.keys()))
-            except AssertionError as e:
-                raise AssertionError("%s case %d dtype %d: %s" % (kind, case, dtype, e))
             n_ok += 1
         else:
             n_err += 1

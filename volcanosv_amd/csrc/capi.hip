@@ -40,6 +40,7 @@ struct vsv_handle {
   int64_t cutesv_rows = -1;   // rows of the last vsv_cutesv_split (c2 buffer)
   // workspace
   DevBuf part_rb, part_count, part_off, scan_tmp;
+  DevBuf l_agg, l_carry_r, l_carry_q, l_tiles;   // long-record scan: per-part aggregates, carries, tile sums
   DevBuf z_crctab, z_crc;  // CRC-32 tables (uploaded once) and per-member results of the device inflate
   const uint32_t* expect_crc = nullptr;   // vsv_bgzf_set_expected_crc: trailer CRCs of the members of the next inflate / parse
   int64_t expect_crc_n = 0;
@@ -129,6 +130,10 @@ int reserve(vsv_handle* h, int64_t max_records, int64_t max_ops, int64_t max_sig
     if ((st = ensure(h, h->part_rb, (n_parts + 1) * 4))) return st;
     if ((st = ensure(h, h->part_count, n_parts * 4))) return st;
     if ((st = ensure(h, h->part_off, n_parts * 4))) return st;
+    if ((st = ensure(h, h->l_agg, vsv_long_scan_bytes(ops, 0)))) return st;
+    if ((st = ensure(h, h->l_carry_r, vsv_long_scan_bytes(ops, 1)))) return st;
+    if ((st = ensure(h, h->l_carry_q, vsv_long_scan_bytes(ops, 1)))) return st;
+    if ((st = ensure(h, h->l_tiles, vsv_long_scan_bytes(ops, 2)))) return st;
     if ((st = ensure(h, h->blk_cnt, nblk * 4))) return st;
     if ((st = ensure(h, h->blk_off, nblk * 4))) return st;
     if ((st = ensure(h, h->cmask, nblk * 512 + 1024))) return st;      // SC_ROUNDS (2) x 256 bytes per block of 2048 records
@@ -235,7 +240,8 @@ int enq_scan(vsv_handle* h) {
   }
   vsv_launch_cigar_scan(st, srv, h->prm, (uint32_t*)h->part_rb.p, n_parts, OPS_PER_PART, (vsv_sig*)h->pool.p,
                         (uint64_t*)h->pool_key.p, (uint32_t)h->cap_sigs, (uint32_t*)h->part_count.p, (uint32_t*)h->part_off.p,
-                        (uint32_t*)h->scan_tmp.p, (vsv_sig*)h->raw0.p, dctr(h), (uint32_t*)h->shard_cnt.p, h->ev0, h->ev1);
+                        (uint32_t*)h->scan_tmp.p, (vsv_sig*)h->raw0.p, dctr(h), (uint32_t*)h->shard_cnt.p, h->ev0, h->ev1,
+                        LongScanBufs{h->l_agg.p, (uint32_t*)h->l_carry_r.p, (uint32_t*)h->l_carry_q.p, h->l_tiles.p});
   h->have_scan_ev = n_parts > 0;
   vsv_launch_fold(st, (const vsv_sig*)h->raw0.p, (vsv_sig*)h->s1in.p, h->rv, h->prm, dctr(h), ew_grid(h));
   HIPCHK(h, hipGetLastError());
@@ -329,6 +335,7 @@ int finish(vsv_handle* h) {
 int start(vsv_handle* h, const vsv_records* recs, const vsv_params* p) {
   if (!h || !p) return VSV_E_INVALID;
   if (p->dtype < 0 || p->dtype > VSV_DTYPE_CUTESV) return fail(h, VSV_E_INVALID, "bad dtype");
+  if (p->scan_layout < VSV_SCAN_AUTO || p->scan_layout > VSV_SCAN_CONTIGS) return fail(h, VSV_E_INVALID, "bad scan_layout");
   HIPCHK(h, hipSetDevice(h->device));
   h->prm = *p;
   return bind_records(h, recs);
@@ -400,7 +407,7 @@ void vsv_destroy(vsv_handle* h) {
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
   DevBuf* bufs[] = {&h->r_pos, &h->r_tid, &h->r_qid, &h->r_off, &h->r_mapq, &h->r_flag, &h->r_cigar, &h->part_rb, &h->part_count,
-                    &h->part_off, &h->scan_tmp, &h->pool, &h->pool_key, &h->raw0, &h->s1in, &h->s1s, &h->c1, &h->s2s, &h->c2,
+                    &h->part_off, &h->scan_tmp, &h->l_agg, &h->l_carry_r, &h->l_carry_q, &h->l_tiles, &h->z_crctab, &h->z_crc, &h->pool, &h->pool_key, &h->raw0, &h->s1in, &h->s1s, &h->c1, &h->s2s, &h->c2,
                     &h->merged, &h->calls_tmp, &h->calls, &h->reads, &h->tab, &h->blk_cnt, &h->blk_off, &h->ckey, &h->crec,
                     &h->okey, &h->oval, &h->key, &h->idx, &h->cl, &h->key2, &h->idx2, &h->key_alt, &h->val_alt, &h->hist, &h->ctr, &h->shard_cnt, &h->totals, &h->g_off, &h->g_qs, &h->g_qe, &h->g_rid, &h->g_rs,
                     &h->g_re, &h->g_rev, &h->g_hap, &h->g_len, &h->g_rank, &h->j_cpos, &h->j_clen, &h->j_spos, &h->j_slen, &h->j_send, &h->j_out, &h->j_err, &h->z_comp, &h->z_coff, &h->z_ooff, &h->z_out, &h->z_stat, &h->p_spec, &h->p_cnt, &h->p_land, &h->p_base, &h->p_recoff, &h->p_pos, &h->p_tid,

@@ -429,6 +429,334 @@ __global__ __launch_bounds__(256) void cigar_scan_emit(RecView rv, const uint32_
   if (lane == 0) part_count[part] = ord;
 }
 
+// ---- K1L: the scan for LONG records (contig alignments: 10^3-10^6 ops per CIGAR) ---------------------------------
+// cigar_scan_emit above is built for read-shaped input: parts are cut at record boundaries (a record is never shared by two
+// waves) and the streaming path keeps no prefix, because a 256-op chunk holds several records. With Mb contigs both choices turn
+// around: a record-aligned part is one whole CIGAR per wave (a 10^6-op alignment = 4 MB streamed by ONE wave while the chip
+// idles), and a chunk almost always lies inside one record, so the lazily walked prefix re-reads and re-decodes what was just
+// streamed and every signature pays the scalar lookup / checkpoint bookkeeping (0.35 of the roofline on the dense contig shape).
+// Here instead
+//  * parts are fixed 8192-op slices of the flat op stream, whatever the records do: perfect balance, a record may span parts;
+//  * every chunk is decoded (two bit-field extracts against duplicated 32-bit op masks and two ANDs per op) and ONE pair of DPP
+//    prefix sums gives both the chunk totals (lane 63) and, when the chunk holds candidates, every op's prefix: the wave carries
+//    (run_r, run_q) = advance since the current record's start (or since the part's start while the record that was open there
+//    continues);
+//  * a chunk without a record start lies in one record: all its candidate ops build their rows at once (ballot ordinals,
+//    ONE slot allocation, vector stores), with the record's header cached in SGPRs; chunks that hold record starts are cut into
+//    segments at the starts and run the same emission per segment;
+//  * rows of the record that was open at the part's start are relative to the part's start and flagged; every part
+//    publishes (has_start, advance since its last start); a segmented scan over the parts (k1l_scan_*) turns that into the
+//    carry each part's head rows still miss, and place_raw adds it while it puts the rows in order. No spinning, no inter-wave
+//    communication inside the kernel, one extra 12-byte record per 32 KiB of CIGAR.
+constexpr int K1L_PART = 8192;            // ops per part (32 KiB), a multiple of the 256-op chunk
+constexpr uint32_t K1L_CARRY = 0x80000000u;   // pool_key ordinal bit: the row still misses the carry of its part
+struct PartAgg { uint32_t has_start, run_r, run_q; };
+
+constexpr uint32_t dup16(uint32_t t) { return t | (t << 16); }
+
+template <int CLS>
+__global__ __launch_bounds__(256) void cigar_scan_long(RecView rv, const uint32_t* __restrict__ rb, int n_parts,
+                                                        int min_svlen, int min_mapq, EmitCtx ec,
+                                                        uint32_t* __restrict__ part_count, PartAgg* __restrict__ agg, int ablate) {
+  using T = OpTab<CLS>;
+  __shared__ uint32_t sh_off[K1_WAVES][K1_RMAX + 1];
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const int part = blockIdx.x * K1_WAVES + wv;
+  if (part >= n_parts) return;
+  const uint64_t n_rec = (uint64_t)rv.n_records;
+  uint64_t end_all = rv.cigar_off[n_rec];                       // ops behind the last record belong to nobody
+  if (end_all > (uint64_t)rv.n_ops) end_all = (uint64_t)rv.n_ops;
+  const uint64_t e0 = (uint64_t)part * K1L_PART;
+  uint32_t ord = 0;
+  auto finish_part = [&](uint32_t has_start, uint32_t rr, uint32_t rq) {
+    if (lane == 0) { part_count[part] = ord; PartAgg a; a.has_start = has_start; a.run_r = rr; a.run_q = rq; agg[part] = a; }
+  };
+  uint32_t r0 = __builtin_amdgcn_readfirstlane(rb[part]), r1 = __builtin_amdgcn_readfirstlane(rb[part + 1]);
+  if (r1 < r0) r1 = r0;                                          // offsets that do not ascend: reported below, never followed
+  const uint32_t part_len = e0 >= end_all ? 0u : (uint32_t)((end_all - e0) < (uint64_t)K1L_PART ? (end_all - e0) : (uint64_t)K1L_PART);
+
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const uint32_t* part_base = rv.cigar + e0;
+  const uint32_t base_lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)part_base);
+  const uint32_t base_hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)part_base >> 32));
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)base_hi << 32) | (uintptr_t)base_lo), (short)0,
+                                                      (int)(part_len * 4u), 0x00020000);
+  auto load_chunk = [&](uint32_t cb) -> uint4 {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((cb + 4u * (uint32_t)lane) * 4u), 0, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+  };
+  uint4 wa = load_chunk(0), wb = load_chunk(256), wc = load_chunk(512), wd = load_chunk(768);
+
+  // ---- record starts of this part, relative to e0, staged K1_RMAX at a time; every record is checked by the part that holds
+  // its start (an empty CIGAR must raise: H:63 IndexError) -------------------------------------------------------------------
+  const uint32_t* __restrict__ off_lo = reinterpret_cast<const uint32_t*>(rv.cigar_off);
+  const uint32_t e0_lo = (uint32_t)e0;
+  uint32_t* my_off = sh_off[wv];
+  uint32_t tbase = r0, n_tab = 0, ti = 0;       // staged records [tbase, tbase + n_tab), next unconsumed entry ti
+  bool bad = false;
+  auto stage = [&](uint32_t first) {
+    tbase = first; ti = 0;
+    n_tab = min((uint32_t)K1_RMAX, r1 - first);
+    bool ok = true;
+    for (uint32_t i = lane; i < n_tab; i += 64) {
+      const uint64_t o = rv.cigar_off[first + i], nx = rv.cigar_off[(uint64_t)first + i + 1];
+      my_off[i] = (uint32_t)o - e0_lo;
+      ok = ok && nx > o && o >= e0 && o - e0 < (uint64_t)part_len;      // ascending, inside this part
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (__ballot(!ok)) { if (lane == 0) atomicOr(&ec.ctr->err, ERRB_EMPTY_CIGAR); bad = true; }
+  };
+  if (r1 > r0) stage(r0);
+  (void)off_lo;
+  auto next_start = [&]() -> uint32_t {         // relative op index of the next record start of the part (wave-uniform)
+    if (ti >= n_tab) {
+      if (tbase + n_tab >= r1 || bad) return 0xFFFFFFFFu;
+      stage(tbase + n_tab);
+      if (bad || n_tab == 0) return 0xFFFFFFFFu;
+    }
+    return __builtin_amdgcn_readfirstlane(my_off[ti]);
+  };
+  uint32_t nxt = (r1 > r0 && !bad) ? next_start() : 0xFFFFFFFFu;
+  // the record that is open at the part's start: r0 - 1, unless a record starts exactly there
+  uint32_t cur_rec = (r0 > 0 && !(nxt == 0u)) ? r0 - 1u : 0xFFFFFFFFu;
+  bool in_head = true;                          // no record start seen yet: rows miss the carry of the part
+  uint32_t has_start = 0;
+  uint32_t run_r = 0, run_q = 0;                // advance since the current record's start (or since e0 while in_head)
+
+  // slot allocator of this wave inside its shard (all wave-uniform); a request may exceed the batch size
+  const uint32_t shard = (uint32_t)part % K1_SHARDS;
+  const uint32_t shard_off = shard * ec.shard_cap;
+  uint32_t al_base = 0, al_left = 0, al_next = 8;
+  auto release_left = [&]() {
+    if ((uint32_t)lane < al_left && al_base + (uint32_t)lane < ec.shard_cap) ec.pool_key[shard_off + al_base + lane] = K1_SENTINEL;
+  };
+  auto alloc = [&](uint32_t n) -> uint32_t {
+    if (al_left < n) {
+      release_left();
+      const uint32_t want = n > al_next ? n : al_next;            // al_left stays <= 64 afterwards (release_left is lane-indexed)
+      uint32_t b = 0;
+      if (lane == 0) b = atomicAdd(&ec.shard_cnt[shard * 16], want);
+      al_base = __builtin_amdgcn_readfirstlane(b);
+      al_left = want;
+      al_next = al_next < 64u ? al_next * 2u : 64u;
+    }
+    const uint32_t sl = al_base;
+    al_base += n;
+    al_left -= n;
+    return sl;
+  };
+
+  const uint32_t thr = (uint32_t)min_svlen;
+  const uint32_t thr16 = thr >= (1u << 28) ? 0xFFFFFFFFu : thr << 4;
+  constexpr uint32_t EMIT_R = rev32(EMIT_MASK | (EMIT_MASK << 16));
+  constexpr uint32_t BAD_R = rev32(T::BAD | (T::BAD << 16));
+  constexpr uint32_t REF2 = dup16(T::REF), QRY2 = dup16(T::QRY);   // bit (w & 31) of these = bit (op) of the table
+  uint32_t hd_rec = 0xFFFFFFFFu, hd_fl = 0, hd_mq = 0, hd_tid = 0, hd_first = 0, hd_pos = 0;   // cached record header (SGPRs)
+
+  // rows of the candidate ops [lo, hi) of the current chunk, which all belong to record `rec`; op at in-chunk prefix px lies
+  // base + px behind the record's start (behind e0 when `carry`).
+  auto emit_segment = [&](const uint32_t (&w)[4], const uint32_t (&pr)[4], const uint32_t (&pq)[4], uint32_t cb, uint32_t lo, uint32_t hi,
+                          uint32_t rec_, uint32_t base_r, uint32_t base_q, bool carry) {
+    const uint32_t rec = __builtin_amdgcn_readfirstlane(rec_);   // wave-uniform by construction; the scalar loads need it in an SGPR
+    const uint32_t x = cb + 4u * (uint32_t)lane;
+    uint32_t emv = 0, badv = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool in = x + k >= lo && x + k < hi;
+      const bool e = in && (int32_t)(EMIT_R << (w[k] & 31u)) < 0 && w[k] >= thr16;
+      const bool b = T::BAD != 0 && in && (int32_t)(BAD_R << (w[k] & 31u)) < 0 && w[k] >= 16u;
+      emv |= (e ? 1u : 0u) << k;
+      badv |= (b ? 1u : 0u) << k;
+    }
+    const uint64_t any_e = __ballot(emv != 0), any_b = __ballot(badv != 0);
+    if (!(any_e | any_b)) return;
+    if (rec != hd_rec) {                                       // header through the scalar cache, once per record and part
+      const uint64_t* po = rv.cigar_off + rec;
+      uint64_t fo;
+      asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(fo) : "s"(po) : "memory");
+      if (fo >= (uint64_t)rv.n_ops) fo = 0;                    // garbage offsets are reported by the part that stages them
+      sload5(align4(rv.flag + rec), align4(rv.mapq + rec), rv.tid + rec, rv.cigar + fo, rv.pos + rec, hd_fl, hd_mq, hd_tid, hd_first, hd_pos);
+      hd_rec = rec;
+    }
+    const uint32_t fl = byte_of(hd_fl, rv.flag + rec), mq = byte_of(hd_mq, rv.mapq + rec);
+    uint32_t hapbits;
+    if (CLS == 0) hapbits = (mq >= (uint32_t)min_mapq) ? ((fl >> 2) & 3u) : 0u;               // H:392-394
+    else if (CLS == 1) hapbits = (mq >= (uint32_t)min_mapq) ? 1u : 0u;                        // RS:120
+    else if (CLS == 3) hapbits = (!(fl & VSV_F_SKIP) && mq >= (uint32_t)min_mapq) ? 1u : 0u; // SE:439, 446
+    else hapbits = (!(fl & (VSV_F_UNMAPPED | VSV_F_SECONDARY)) && mq >= (uint32_t)min_mapq) ? 1u : 0u;
+    if (!hapbits) return;
+    if (any_b) { if (lane == 0) atomicOr(&ec.ctr->err, ERRB_REFEND); }   // N/=/X on the contig table: H:396 assert
+    if (!any_e) return;
+    const uint32_t hc = (T::HC && (hd_first & 15u) == 5u) ? (hd_first >> 4) : 0u;             // H:63-65
+    const uint32_t nemit = (hapbits == 3u) ? 2u : 1u;
+    const uint32_t cnt = (uint32_t)__popc(emv);
+    const uint32_t incl = wave_incl_scan(cnt);
+    const uint32_t below = incl - cnt;                         // signatures of lower lanes
+    const uint32_t nsig = rdlane(incl, 63);
+    const uint32_t slot = alloc(nsig * nemit);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (__ballot((emv >> k) & 1u) == 0ull) continue;
+      if ((emv >> k) & 1u) {
+        const uint32_t o = (below + (uint32_t)__popc(emv & ((1u << k) - 1u))) * nemit;   // ordinal inside the segment
+        const uint32_t op = w[k] & 15u, len = w[k] >> 4;
+        vsv_sig sg;
+        sg.pos = (int32_t)(hd_pos + base_r + pr[k]);
+        sg.svlen = (int32_t)len;
+        sg.q_start = (int32_t)(base_q + pq[k] + hc);
+        sg.q_end = (CLS == 1 || CLS == 3) ? 0 : sg.q_start + (op == 2u ? 1 : (int32_t)len);
+        sg.rec = rec;
+        sg.rec2 = 0xFFFFFFFFu;
+        sg.tid = (int32_t)hd_tid;
+        const uint32_t cbit = carry ? K1L_CARRY : 0u;
+#pragma unroll
+        for (uint32_t e = 0; e < 2; ++e) {
+          if (e >= nemit) break;
+          const uint32_t hp2 = (CLS == 0) ? ((hapbits == 3u) ? e : (hapbits >> 1)) : 0u;
+          sg.meta = (op == 2u ? VSV_M_DEL : 0u) | (hp2 ? VSV_M_HP2 : 0u);
+          if (slot + o + e < ec.shard_cap) {
+            ec.pool[shard_off + slot + o + e] = sg;
+            ec.pool_key[shard_off + slot + o + e] = ((uint64_t)(uint32_t)part << 32) | (uint64_t)(cbit | (ord + o + e));
+          }
+        }
+      }
+    }
+    ord += nsig * nemit;
+  };
+
+  auto process_chunk = [&](const uint4& wcur, const uint32_t cb) {
+    if (cb >= part_len || bad) return;
+    const uint32_t w[4] = {wcur.x, wcur.y, wcur.z, wcur.w};
+    // candidate test (superset of the emit predicate, as in cigar_scan_emit)
+    bool cand = ((int32_t)(EMIT_R << (w[0] & 31u)) < 0 && w[0] >= thr16) | ((int32_t)(EMIT_R << (w[1] & 31u)) < 0 && w[1] >= thr16) |
+                ((int32_t)(EMIT_R << (w[2] & 31u)) < 0 && w[2] >= thr16) | ((int32_t)(EMIT_R << (w[3] & 31u)) < 0 && w[3] >= thr16);
+    if (T::BAD != 0) {
+      const uint32_t t = (BAD_R << (w[0] & 31u)) | (BAD_R << (w[1] & 31u)) | (BAD_R << (w[2] & 31u)) | (BAD_R << (w[3] & 31u));
+      cand |= (int32_t)t < 0;
+    }
+    // decode + ONE pair of prefix sums: totals for the running offsets, prefixes for the candidates
+    uint32_t ar[4], aq[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t len = w[k] >> 4;
+      ar[k] = len & (uint32_t)__builtin_amdgcn_sbfe(REF2, w[k], 1);
+      aq[k] = len & (uint32_t)__builtin_amdgcn_sbfe(QRY2, w[k], 1);
+    }
+    const uint32_t sum_r = ar[0] + ar[1] + ar[2] + ar[3], sum_q = aq[0] + aq[1] + aq[2] + aq[3];
+    const uint32_t incl_r = wave_incl_scan(sum_r), incl_q = wave_incl_scan(sum_q);
+    const uint32_t tot_r = rdlane(incl_r, 63), tot_q = rdlane(incl_q, 63);
+    const bool any_cand = __ballot(cand) != 0ull && !(ablate & 1);
+    const bool boundary = nxt < cb + 256u;
+    if (!any_cand && !boundary) { run_r += tot_r; run_q += tot_q; return; }
+    uint32_t pr[4], pq[4];                       // exclusive in-chunk prefix in front of each of the lane's ops
+    pr[0] = incl_r - sum_r; pq[0] = incl_q - sum_q;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) { pr[k] = pr[k - 1] + ar[k - 1]; pq[k] = pq[k - 1] + aq[k - 1]; }
+    uint32_t base_r = run_r, base_q = run_q, lo = cb;
+    while (nxt < cb + 256u) {                    // a record starts inside this chunk: close the segment in front of it
+      if (any_cand && cur_rec != 0xFFFFFFFFu && nxt > lo) emit_segment(w, pr, pq, cb, lo, nxt, cur_rec, base_r, base_q, in_head);
+      const uint32_t ls = (nxt - cb) >> 2, ss = (nxt - cb) & 3u;
+      const uint32_t p_r = rdlane(ss == 0 ? pr[0] : ss == 1 ? pr[1] : ss == 2 ? pr[2] : pr[3], ls);
+      const uint32_t p_q = rdlane(ss == 0 ? pq[0] : ss == 1 ? pq[1] : ss == 2 ? pq[2] : pq[3], ls);
+      base_r = 0u - p_r; base_q = 0u - p_q;      // ops of the new record: offset = px - P(start)
+      cur_rec = tbase + ti; in_head = false; has_start = 1;
+      lo = nxt;
+      ++ti;
+      nxt = next_start();
+      if (bad) return;
+    }
+    if (any_cand && cur_rec != 0xFFFFFFFFu) emit_segment(w, pr, pq, cb, lo, cb + 256u, cur_rec, base_r, base_q, in_head);
+    run_r = base_r + tot_r; run_q = base_q + tot_q;
+  };
+
+  for (uint32_t cb = 0; cb < part_len && !bad; cb += 1024) {
+    process_chunk(wa, cb);
+    wa = load_chunk(cb + 1024);
+    process_chunk(wb, cb + 256);
+    wb = load_chunk(cb + 1280);
+    process_chunk(wc, cb + 512);
+    wc = load_chunk(cb + 1536);
+    process_chunk(wd, cb + 768);
+    wd = load_chunk(cb + 1792);
+  }
+  // records whose starts were never reached (offsets beyond the part, part cut short by end_all): still validate them
+  while (!bad && tbase + n_tab < r1) stage(tbase + n_tab);
+  release_left();
+  finish_part(has_start, run_r, run_q);
+}
+
+// ---- carry of the long-record scan: segmented exclusive scan over the parts --------------------------------------------
+// x[p] = (has_start, run): S = x[0] (+) ... (+) x[p-1] with (f1,v1) (+) (f2,v2) = (f1|f2, f2 ? v2 : v1+v2); carry[p] = S.v.
+// Same three-kernel shape as the count scan below; the counts' exclusive sum (part_off) rides along.
+struct CarryItem { uint32_t f, r, q, cnt; };
+__device__ __forceinline__ CarryItem carry_op(const CarryItem& a, const CarryItem& b) {
+  CarryItem c;
+  c.f = a.f | b.f; c.r = b.f ? b.r : a.r + b.r; c.q = b.f ? b.q : a.q + b.q; c.cnt = a.cnt + b.cnt;
+  return c;
+}
+constexpr int K1L_SCAN_TILE = 2048;   // 256 threads x 8 parts
+__device__ __forceinline__ CarryItem k1l_load(const PartAgg* agg, const uint32_t* cnt, int i, int n) {
+  CarryItem c{0, 0, 0, 0};
+  if (i < n) { const PartAgg a = agg[i]; c.f = a.has_start; c.r = a.run_r; c.q = a.run_q; c.cnt = cnt[i]; }
+  return c;
+}
+// block-wide inclusive scan of one item per thread (Hillis-Steele in LDS, 256 threads)
+__device__ __forceinline__ CarryItem k1l_block_scan(CarryItem v, CarryItem* sh) {
+  sh[threadIdx.x] = v;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    CarryItem t = sh[threadIdx.x];
+    if ((int)threadIdx.x >= d) t = carry_op(sh[threadIdx.x - d], t);
+    __syncthreads();
+    sh[threadIdx.x] = t;
+    __syncthreads();
+  }
+  return sh[threadIdx.x];
+}
+__global__ __launch_bounds__(256) void k1l_scan_tiles(const PartAgg* __restrict__ agg, const uint32_t* __restrict__ cnt, int n, CarryItem* __restrict__ tile_sum) {
+  __shared__ CarryItem sh[256];
+  const int base = blockIdx.x * K1L_SCAN_TILE + threadIdx.x * 8;
+  CarryItem acc = k1l_load(agg, cnt, base, n);
+  for (int k = 1; k < 8; ++k) acc = carry_op(acc, k1l_load(agg, cnt, base + k, n));
+  const CarryItem incl = k1l_block_scan(acc, sh);
+  if (threadIdx.x == 255) tile_sum[blockIdx.x] = incl;
+}
+__global__ __launch_bounds__(256) void k1l_scan_tile_sums(CarryItem* __restrict__ tile_sum, int ntiles) {
+  // single block: exclusive scan of the tile aggregates in place, 256 at a time with a running carry
+  __shared__ CarryItem sh[256];
+  __shared__ CarryItem run;
+  if (threadIdx.x == 0) run = CarryItem{0, 0, 0, 0};
+  __syncthreads();
+  for (int base = 0; base < ntiles; base += 256) {
+    const int i = base + threadIdx.x;
+    const CarryItem v = i < ntiles ? tile_sum[i] : CarryItem{0, 0, 0, 0};
+    const CarryItem incl = k1l_block_scan(v, sh);
+    const CarryItem before = carry_op(run, threadIdx.x > 0 ? sh[threadIdx.x - 1] : CarryItem{0, 0, 0, 0});
+    const CarryItem total = carry_op(run, sh[255]);
+    (void)incl;
+    __syncthreads();
+    if (i < ntiles) tile_sum[i] = before;
+    if (threadIdx.x == 0) run = total;
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void k1l_scan_apply(const PartAgg* __restrict__ agg, const uint32_t* __restrict__ cnt, int n,
+                                                      const CarryItem* __restrict__ tile_sum, uint32_t* __restrict__ part_off,
+                                                      uint32_t* __restrict__ carry_r, uint32_t* __restrict__ carry_q) {
+  __shared__ CarryItem sh[256];
+  const int base = blockIdx.x * K1L_SCAN_TILE + threadIdx.x * 8;
+  CarryItem it[8];
+  CarryItem acc = it[0] = k1l_load(agg, cnt, base, n);
+  for (int k = 1; k < 8; ++k) { it[k] = k1l_load(agg, cnt, base + k, n); acc = carry_op(acc, it[k]); }
+  k1l_block_scan(acc, sh);
+  CarryItem run = carry_op(tile_sum[blockIdx.x], threadIdx.x > 0 ? sh[threadIdx.x - 1] : CarryItem{0, 0, 0, 0});
+  for (int k = 0; k < 8; ++k) {
+    if (base + k < n) { part_off[base + k] = run.cnt; carry_r[base + k] = run.r; carry_q[base + k] = run.q; }
+    run = carry_op(run, it[k]);
+  }
+}
+
 // ---- exclusive scan of part_count (3 tiny kernels) -------------------------------------------------
 constexpr int SCAN_TILE = 2048;  // 256 threads x 8
 __global__ __launch_bounds__(256) void scan_tile_sums(const uint32_t* __restrict__ in, int n, uint32_t* __restrict__ sums) {
@@ -488,7 +816,8 @@ __global__ __launch_bounds__(256) void scan_tile_apply(const uint32_t* __restric
 __global__ __launch_bounds__(256) void place_raw(const vsv_sig* __restrict__ pool, const uint64_t* __restrict__ pool_key,
                                                  const uint32_t* __restrict__ shard_cnt, uint32_t shard_cap,
                                                  const uint32_t* __restrict__ part_off, const uint32_t* __restrict__ part_count,
-                                                 int n_parts, vsv_sig* __restrict__ raw, uint32_t cap, Counters* ctr) {
+                                                 int n_parts, vsv_sig* __restrict__ raw, uint32_t cap, Counters* ctr,
+                                                 const uint32_t* __restrict__ carry_r, const uint32_t* __restrict__ carry_q, bool add_qend) {
   const uint32_t s = blockIdx.x;
   const uint32_t used = shard_cnt[s * 16];
   if (threadIdx.x == 0) {
@@ -504,8 +833,17 @@ __global__ __launch_bounds__(256) void place_raw(const vsv_sig* __restrict__ poo
   for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
     const uint64_t k = pool_key[(size_t)s * shard_cap + e];
     if (k == K1_SENTINEL) continue;
-    const uint32_t dst = part_off[(uint32_t)(k >> 32)] + (uint32_t)k;
-    if (dst < cap) raw[dst] = pool[(size_t)s * shard_cap + e];
+    const uint32_t part = (uint32_t)(k >> 32);
+    const uint32_t dst = part_off[part] + ((uint32_t)k & ~K1L_CARRY);
+    if (dst >= cap) continue;
+    vsv_sig row = pool[(size_t)s * shard_cap + e];
+    if ((uint32_t)k & K1L_CARRY) {        // long-record scan: the record was open at the part's start (k1l_scan_*)
+      const uint32_t cr = carry_r[part], cq = carry_q[part];
+      row.pos = (int32_t)((uint32_t)row.pos + cr);
+      row.q_start = (int32_t)((uint32_t)row.q_start + cq);
+      if (add_qend) row.q_end = (int32_t)((uint32_t)row.q_end + cq);
+    }
+    raw[dst] = row;
   }
 }
 
@@ -542,11 +880,22 @@ void vsv_scan_u32_exclusive(hipStream_t st, const uint32_t* in, int n, uint32_t*
 
 int vsv_cigar_parts(int64_t n_ops, int ops_per_part) { return (int)((n_ops + ops_per_part - 1) / ops_per_part); }
 
+bool vsv_scan_is_long(const RecView& rv, const vsv_params& p) {
+  static const char* force = getenv("VSV_K1_MODE");              // timing experiments: "long" / "short"
+  if (force) return force[0] == 'l';
+  if (p.scan_layout == VSV_SCAN_READS) return false;
+  if (p.scan_layout == VSV_SCAN_CONTIGS) return true;
+  return rv.n_records > 0 && rv.n_ops / rv.n_records >= 512;    // Mb contigs: 10^3-10^6 ops per record; reads: tens to hundreds
+}
+int vsv_cigar_parts_long(int64_t n_ops) { return (int)((n_ops + K1L_PART - 1) / K1L_PART); }
+
 void vsv_launch_cigar_scan(hipStream_t st, const RecView& rv, const vsv_params& p, uint32_t* part_rb, int n_parts,
                            int ops_per_part, vsv_sig* pool, uint64_t* pool_key, uint32_t cap, uint32_t* part_count,
                            uint32_t* part_off, uint32_t* scan_tmp, vsv_sig* raw, Counters* ctr, uint32_t* shard_cnt,
-                           hipEvent_t ev0, hipEvent_t ev1) {
+                           hipEvent_t ev0, hipEvent_t ev1, const LongScanBufs& lb) {
   if (n_parts <= 0) return;
+  const bool long_mode = vsv_scan_is_long(rv, p);
+  if (long_mode) { n_parts = vsv_cigar_parts_long(rv.n_ops); ops_per_part = K1L_PART; }
   (void)hipMemsetAsync(shard_cnt, 0, K1_SHARDS * 16 * sizeof(uint32_t), st);
   partition_kernel<<<(n_parts + 1 + 255) / 256, 256, 0, st>>>(rv.cigar_off, rv.n_records, part_rb, n_parts, ops_per_part);
   EmitCtx ec{pool, pool_key, shard_cnt, cap / K1_SHARDS, ctr};
@@ -557,7 +906,8 @@ void vsv_launch_cigar_scan(hipStream_t st, const RecView& rv, const vsv_params& 
   static const int depth = getenv("VSV_K1_DEPTH") ? atoi(getenv("VSV_K1_DEPTH")) : 4;     // chunks in flight per wave (3 or 4)
 #define K1_LAUNCH(CLS)                                                                                                          \
   do {                                                                                                                          \
-    if (depth == 4) cigar_scan_emit<CLS, 4><<<grid, 256, 0, st>>>(rv, part_rb, n_parts, p.min_svlen, p.min_cigar_mapq, ec, part_count, ablate); \
+    if (long_mode) cigar_scan_long<CLS><<<grid, 256, 0, st>>>(rv, part_rb, n_parts, p.min_svlen, p.min_cigar_mapq, ec, part_count, (PartAgg*)lb.agg, ablate); \
+    else if (depth == 4) cigar_scan_emit<CLS, 4><<<grid, 256, 0, st>>>(rv, part_rb, n_parts, p.min_svlen, p.min_cigar_mapq, ec, part_count, ablate); \
     else cigar_scan_emit<CLS, 3><<<grid, 256, 0, st>>>(rv, part_rb, n_parts, p.min_svlen, p.min_cigar_mapq, ec, part_count, ablate);            \
   } while (0)
   if (p.dtype == VSV_DTYPE_READS) K1_LAUNCH(1);
@@ -566,8 +916,21 @@ void vsv_launch_cigar_scan(hipStream_t st, const RecView& rv, const vsv_params& 
   else K1_LAUNCH(0);
 #undef K1_LAUNCH
   if (ev1) (void)hipEventRecord(ev1, st);
-  vsv_scan_u32_exclusive(st, part_count, n_parts, part_off, scan_tmp);
-  place_raw<<<K1_SHARDS, 256, 0, st>>>(pool, pool_key, shard_cnt, cap / K1_SHARDS, part_off, part_count, n_parts, raw, cap, ctr);
+  const bool add_qend = !(p.dtype == VSV_DTYPE_READS || p.dtype == VSV_DTYPE_CUTESV);
+  if (long_mode) {
+    const int tiles = (n_parts + K1L_SCAN_TILE - 1) / K1L_SCAN_TILE;
+    k1l_scan_tiles<<<tiles, 256, 0, st>>>((const PartAgg*)lb.agg, part_count, n_parts, (CarryItem*)lb.tile_sum);
+    k1l_scan_tile_sums<<<1, 256, 0, st>>>((CarryItem*)lb.tile_sum, tiles);
+    k1l_scan_apply<<<tiles, 256, 0, st>>>((const PartAgg*)lb.agg, part_count, n_parts, (const CarryItem*)lb.tile_sum, part_off, lb.carry_r, lb.carry_q);
+  } else {
+    vsv_scan_u32_exclusive(st, part_count, n_parts, part_off, scan_tmp);
+  }
+  place_raw<<<K1_SHARDS, 256, 0, st>>>(pool, pool_key, shard_cnt, cap / K1_SHARDS, part_off, part_count, n_parts, raw, cap, ctr,
+                                       lb.carry_r, lb.carry_q, add_qend);
+}
+size_t vsv_long_scan_bytes(int64_t n_ops, int which) {   // 0: PartAgg[], 1: carry (u32 per part), 2: tile sums
+  const size_t n_parts = (size_t)vsv_cigar_parts_long(n_ops) + 2;
+  return which == 0 ? n_parts * sizeof(PartAgg) : which == 1 ? n_parts * sizeof(uint32_t) : (n_parts / K1L_SCAN_TILE + 2) * sizeof(CarryItem);
 }
 
 // ---- streaming ceiling of this part, measured with the library's own kernels -----------------------------------

@@ -122,10 +122,13 @@ void vsv_launch_stream_read(hipStream_t st, const void* src, size_t bytes, uint3
 void vsv_launch_stream_copy(hipStream_t st, const void* src, void* dst, size_t bytes);
 int vsv_cigar_parts(int64_t n_ops, int ops_per_part);
 void vsv_scan_u32_exclusive(hipStream_t st, const uint32_t* in, int n, uint32_t* out, uint32_t* tmp);
+struct LongScanBufs { void* agg; uint32_t* carry_r; uint32_t* carry_q; void* tile_sum; };   // long-record scan (cigar_scan_long)
+bool vsv_scan_is_long(const RecView& rv, const vsv_params& p);
+size_t vsv_long_scan_bytes(int64_t n_ops, int which);
 void vsv_launch_cigar_scan(hipStream_t st, const RecView& rv, const vsv_params& p, uint32_t* part_rb, int n_parts,
                            int ops_per_part, vsv_sig* pool, uint64_t* pool_key, uint32_t cap, uint32_t* part_count,
                            uint32_t* part_off, uint32_t* scan_tmp, vsv_sig* raw, Counters* ctr, uint32_t* shard_cnt,
-                           hipEvent_t ev0, hipEvent_t ev1);
+                           hipEvent_t ev0, hipEvent_t ev1, const LongScanBufs& lb);
 
 // sig_stages.hip
 void vsv_launch_clr_gate(hipStream_t st, const RecView& rv, uint8_t* gflag, Counters* ctr);   // CLR: gated flag bytes for the scan
