@@ -454,12 +454,15 @@ struct PartAgg { uint32_t has_start, run_r, run_q; };
 
 constexpr uint32_t dup16(uint32_t t) { return t | (t << 16); }
 
+constexpr int K1L_STAGE = 64;             // rows a wave stages in LDS before it flushes them to the pool (one per lane)
+
 template <int CLS>
 __global__ __launch_bounds__(256) void cigar_scan_long(RecView rv, const uint32_t* __restrict__ rb, int n_parts,
                                                         int min_svlen, int min_mapq, EmitCtx ec,
                                                         uint32_t* __restrict__ part_count, PartAgg* __restrict__ agg, int ablate) {
   using T = OpTab<CLS>;
   __shared__ uint32_t sh_off[K1_WAVES][K1_RMAX + 1];
+  __shared__ uint4 sh_rows[K1_WAVES][K1L_STAGE * 2];           // staged rows (32 B each), wave-private
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const int part = blockIdx.x * K1_WAVES + wv;
@@ -468,29 +471,35 @@ __global__ __launch_bounds__(256) void cigar_scan_long(RecView rv, const uint32_
   uint64_t end_all = rv.cigar_off[n_rec];                       // ops behind the last record belong to nobody
   if (end_all > (uint64_t)rv.n_ops) end_all = (uint64_t)rv.n_ops;
   const uint64_t e0 = (uint64_t)part * K1L_PART;
-  uint32_t ord = 0;
-  auto finish_part = [&](uint32_t has_start, uint32_t rr, uint32_t rq) {
-    if (lane == 0) { part_count[part] = ord; PartAgg a; a.has_start = has_start; a.run_r = rr; a.run_q = rq; agg[part] = a; }
-  };
+  uint32_t ord = 0;                                             // rows emitted by this part so far (staged ones included)
   uint32_t r0 = __builtin_amdgcn_readfirstlane(rb[part]), r1 = __builtin_amdgcn_readfirstlane(rb[part + 1]);
   if (r1 < r0) r1 = r0;                                          // offsets that do not ascend: reported below, never followed
-  const uint32_t part_len = e0 >= end_all ? 0u : (uint32_t)((end_all - e0) < (uint64_t)K1L_PART ? (end_all - e0) : (uint64_t)K1L_PART);
+  // (read with a vector load, so the compiler must be told that it is wave-uniform: every loop below is bounded by it)
+  const uint32_t part_len = __builtin_amdgcn_readfirstlane(e0 >= end_all ? 0u : (uint32_t)((end_all - e0) < (uint64_t)K1L_PART ? (end_all - e0) : (uint64_t)K1L_PART));
 
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   const uint32_t* part_base = rv.cigar + e0;
   const uint32_t base_lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)part_base);
   const uint32_t base_hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)part_base >> 32));
-  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)base_hi << 32) | (uintptr_t)base_lo), (short)0,
-                                                      (int)(part_len * 4u), 0x00020000);
-  auto load_chunk = [&](uint32_t cb) -> uint4 {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((cb + 4u * (uint32_t)lane) * 4u), 0, 0);
-    return make_uint4(v.x, v.y, v.z, v.w);
+  // The ring loads are issued and awaited by hand (inline asm): the loop below reaches each streaming block over several paths
+  // (straight from the previous block, or through the emission block), and hipcc's wait-count insertion answers such merges with
+  // vmcnt(0), i.e. no load would ever stay in flight across a chunk. Four ring loads are outstanding whenever a block consumes
+  // the oldest one, so "at most three younger operations outstanding" is exact in the streaming loop and merely conservative
+  // (the flush's stores and atomics count too) behind the emission block. Raw buffer descriptor clipped to the part: the
+  // prefetch that runs past its end returns zeros without touching memory.
+  u32x4 rsrc;
+  rsrc.x = base_lo; rsrc.y = base_hi & 0xFFFFu; rsrc.z = __builtin_amdgcn_readfirstlane(part_len * 4u); rsrc.w = 0x00020000u;
+  const uint32_t lane16 = 16u * (uint32_t)lane;
+  auto issue = [&](u32x4& dst, uint32_t cb) {
+    const uint32_t voff = cb * 4u + lane16;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(voff), "s"(rsrc) : "memory");
   };
-  uint4 wa = load_chunk(0), wb = load_chunk(256), wc = load_chunk(512), wd = load_chunk(768);
+  u32x4 wa, wb, wc, wd;
+  issue(wa, 0); issue(wb, 256); issue(wc, 512); issue(wd, 768);
+#define K1L_ARRIVE(reg) asm volatile("s_waitcnt vmcnt(3)" : "+v"(reg) : : "memory")
 
   // ---- record starts of this part, relative to e0, staged K1_RMAX at a time; every record is checked by the part that holds
   // its start (an empty CIGAR must raise: H:63 IndexError) -------------------------------------------------------------------
-  const uint32_t* __restrict__ off_lo = reinterpret_cast<const uint32_t*>(rv.cigar_off);
   const uint32_t e0_lo = (uint32_t)e0;
   uint32_t* my_off = sh_off[wv];
   uint32_t tbase = r0, n_tab = 0, ti = 0;       // staged records [tbase, tbase + n_tab), next unconsumed entry ti
@@ -508,7 +517,6 @@ __global__ __launch_bounds__(256) void cigar_scan_long(RecView rv, const uint32_
     if (__ballot(!ok)) { if (lane == 0) atomicOr(&ec.ctr->err, ERRB_EMPTY_CIGAR); bad = true; }
   };
   if (r1 > r0) stage(r0);
-  (void)off_lo;
   auto next_start = [&]() -> uint32_t {         // relative op index of the next record start of the part (wave-uniform)
     if (ti >= n_tab) {
       if (tbase + n_tab >= r1 || bad) return 0xFFFFFFFFu;
@@ -524,27 +532,27 @@ __global__ __launch_bounds__(256) void cigar_scan_long(RecView rv, const uint32_
   uint32_t has_start = 0;
   uint32_t run_r = 0, run_q = 0;                // advance since the current record's start (or since e0 while in_head)
 
-  // slot allocator of this wave inside its shard (all wave-uniform); a request may exceed the batch size
+  // ---- row staging: rows collect in LDS (wave-private, row order) and leave K1L_STAGE at a time: one exact slot allocation per
+  // flush (no unused slots), coalesced 32-byte stores from every lane instead of three 1-2-lane stores per signature ----------
   const uint32_t shard = (uint32_t)part % K1_SHARDS;
   const uint32_t shard_off = shard * ec.shard_cap;
-  uint32_t al_base = 0, al_left = 0, al_next = 8;
-  auto release_left = [&]() {
-    if ((uint32_t)lane < al_left && al_base + (uint32_t)lane < ec.shard_cap) ec.pool_key[shard_off + al_base + lane] = K1_SENTINEL;
-  };
-  auto alloc = [&](uint32_t n) -> uint32_t {
-    if (al_left < n) {
-      release_left();
-      const uint32_t want = n > al_next ? n : al_next;            // al_left stays <= 64 afterwards (release_left is lane-indexed)
-      uint32_t b = 0;
-      if (lane == 0) b = atomicAdd(&ec.shard_cnt[shard * 16], want);
-      al_base = __builtin_amdgcn_readfirstlane(b);
-      al_left = want;
-      al_next = al_next < 64u ? al_next * 2u : 64u;
+  uint4* my_rows = sh_rows[wv];
+  uint32_t n_staged = 0;
+  auto flush = [&]() {
+    if (n_staged == 0) return;
+    uint32_t b = 0;
+    if (lane == 0) b = atomicAdd(&ec.shard_cnt[shard * 16], n_staged);
+    const uint32_t slot = __builtin_amdgcn_readfirstlane(b);
+    if ((uint32_t)lane < n_staged && slot + (uint32_t)lane < ec.shard_cap) {
+      uint4 lo4 = my_rows[2 * lane], hi4 = my_rows[2 * lane + 1];
+      const uint32_t cbit = hi4.y == 0xFFFFFFFEu ? K1L_CARRY : 0u;      // rec2 doubles as the carry flag while staged
+      hi4.y = 0xFFFFFFFFu;
+      uint4* dst = reinterpret_cast<uint4*>(ec.pool + shard_off + slot + lane);
+      dst[0] = lo4; dst[1] = hi4;
+      ec.pool_key[shard_off + slot + lane] = ((uint64_t)(uint32_t)part << 32) | (uint64_t)(cbit | (ord - n_staged + (uint32_t)lane));
     }
-    const uint32_t sl = al_base;
-    al_base += n;
-    al_left -= n;
-    return sl;
+    __builtin_amdgcn_wave_barrier();
+    n_staged = 0;
   };
 
   const uint32_t thr = (uint32_t)min_svlen;
@@ -554,136 +562,194 @@ __global__ __launch_bounds__(256) void cigar_scan_long(RecView rv, const uint32_
   constexpr uint32_t REF2 = dup16(T::REF), QRY2 = dup16(T::QRY);   // bit (w & 31) of these = bit (op) of the table
   uint32_t hd_rec = 0xFFFFFFFFu, hd_fl = 0, hd_mq = 0, hd_tid = 0, hd_first = 0, hd_pos = 0;   // cached record header (SGPRs)
 
-  // rows of the candidate ops [lo, hi) of the current chunk, which all belong to record `rec`; op at in-chunk prefix px lies
-  // base + px behind the record's start (behind e0 when `carry`).
-  auto emit_segment = [&](const uint32_t (&w)[4], const uint32_t (&pr)[4], const uint32_t (&pq)[4], uint32_t cb, uint32_t lo, uint32_t hi,
-                          uint32_t rec_, uint32_t base_r, uint32_t base_q, bool carry) {
-    const uint32_t rec = __builtin_amdgcn_readfirstlane(rec_);   // wave-uniform by construction; the scalar loads need it in an SGPR
-    const uint32_t x = cb + 4u * (uint32_t)lane;
-    uint32_t emv = 0, badv = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const bool in = x + k >= lo && x + k < hi;
-      const bool e = in && (int32_t)(EMIT_R << (w[k] & 31u)) < 0 && w[k] >= thr16;
-      const bool b = T::BAD != 0 && in && (int32_t)(BAD_R << (w[k] & 31u)) < 0 && w[k] >= 16u;
-      emv |= (e ? 1u : 0u) << k;
-      badv |= (b ? 1u : 0u) << k;
-    }
-    const uint64_t any_e = __ballot(emv != 0), any_b = __ballot(badv != 0);
-    if (!(any_e | any_b)) return;
-    if (rec != hd_rec) {                                       // header through the scalar cache, once per record and part
-      const uint64_t* po = rv.cigar_off + rec;
-      uint64_t fo;
-      asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(fo) : "s"(po) : "memory");
-      if (fo >= (uint64_t)rv.n_ops) fo = 0;                    // garbage offsets are reported by the part that stages them
-      sload5(align4(rv.flag + rec), align4(rv.mapq + rec), rv.tid + rec, rv.cigar + fo, rv.pos + rec, hd_fl, hd_mq, hd_tid, hd_first, hd_pos);
-      hd_rec = rec;
-    }
-    const uint32_t fl = byte_of(hd_fl, rv.flag + rec), mq = byte_of(hd_mq, rv.mapq + rec);
-    uint32_t hapbits;
-    if (CLS == 0) hapbits = (mq >= (uint32_t)min_mapq) ? ((fl >> 2) & 3u) : 0u;               // H:392-394
-    else if (CLS == 1) hapbits = (mq >= (uint32_t)min_mapq) ? 1u : 0u;                        // RS:120
-    else if (CLS == 3) hapbits = (!(fl & VSV_F_SKIP) && mq >= (uint32_t)min_mapq) ? 1u : 0u; // SE:439, 446
-    else hapbits = (!(fl & (VSV_F_UNMAPPED | VSV_F_SECONDARY)) && mq >= (uint32_t)min_mapq) ? 1u : 0u;
-    if (!hapbits) return;
-    if (any_b) { if (lane == 0) atomicOr(&ec.ctr->err, ERRB_REFEND); }   // N/=/X on the contig table: H:396 assert
-    if (!any_e) return;
-    const uint32_t hc = (T::HC && (hd_first & 15u) == 5u) ? (hd_first >> 4) : 0u;             // H:63-65
-    const uint32_t nemit = (hapbits == 3u) ? 2u : 1u;
-    const uint32_t cnt = (uint32_t)__popc(emv);
-    const uint32_t incl = wave_incl_scan(cnt);
-    const uint32_t below = incl - cnt;                         // signatures of lower lanes
-    const uint32_t nsig = rdlane(incl, 63);
-    const uint32_t slot = alloc(nsig * nemit);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (__ballot((emv >> k) & 1u) == 0ull) continue;
-      if ((emv >> k) & 1u) {
-        const uint32_t o = (below + (uint32_t)__popc(emv & ((1u << k) - 1u))) * nemit;   // ordinal inside the segment
-        const uint32_t op = w[k] & 15u, len = w[k] >> 4;
-        vsv_sig sg;
-        sg.pos = (int32_t)(hd_pos + base_r + pr[k]);
-        sg.svlen = (int32_t)len;
-        sg.q_start = (int32_t)(base_q + pq[k] + hc);
-        sg.q_end = (CLS == 1 || CLS == 3) ? 0 : sg.q_start + (op == 2u ? 1 : (int32_t)len);
-        sg.rec = rec;
-        sg.rec2 = 0xFFFFFFFFu;
-        sg.tid = (int32_t)hd_tid;
-        const uint32_t cbit = carry ? K1L_CARRY : 0u;
-#pragma unroll
-        for (uint32_t e = 0; e < 2; ++e) {
-          if (e >= nemit) break;
-          const uint32_t hp2 = (CLS == 0) ? ((hapbits == 3u) ? e : (hapbits >> 1)) : 0u;
-          sg.meta = (op == 2u ? VSV_M_DEL : 0u) | (hp2 ? VSV_M_HP2 : 0u);
-          if (slot + o + e < ec.shard_cap) {
-            ec.pool[shard_off + slot + o + e] = sg;
-            ec.pool_key[shard_off + slot + o + e] = ((uint64_t)(uint32_t)part << 32) | (uint64_t)(cbit | (ord + o + e));
-          }
-        }
-      }
-    }
-    ord += nsig * nemit;
-  };
+  // ---- the chunk handed from the streaming blocks to the (single) emission block -----------------------------------------
+  uint32_t pw[4] = {0, 0, 0, 0}, p_pr0 = 0, p_pq0 = 0;          // its ops and each lane's exclusive in-chunk prefix
+  bool p_badany = false;
+  uint32_t p_cb = 0, p_tot_r = 0, p_tot_q = 0;
+  bool pending = false;
 
-  auto process_chunk = [&](const uint4& wcur, const uint32_t cb) {
+  // streaming block: candidate test, decode, ONE pair of prefix sums; hands the chunk over when it holds a candidate or a start
+  auto stream = [&](const u32x4& wcur, const uint32_t cb) {
     if (cb >= part_len || bad) return;
     const uint32_t w[4] = {wcur.x, wcur.y, wcur.z, wcur.w};
-    // candidate test (superset of the emit predicate, as in cigar_scan_emit)
-    bool cand = ((int32_t)(EMIT_R << (w[0] & 31u)) < 0 && w[0] >= thr16) | ((int32_t)(EMIT_R << (w[1] & 31u)) < 0 && w[1] >= thr16) |
-                ((int32_t)(EMIT_R << (w[2] & 31u)) < 0 && w[2] >= thr16) | ((int32_t)(EMIT_R << (w[3] & 31u)) < 0 && w[3] >= thr16);
+    const bool e0 = (int32_t)(EMIT_R << (w[0] & 31u)) < 0 && w[0] >= thr16, e1 = (int32_t)(EMIT_R << (w[1] & 31u)) < 0 && w[1] >= thr16;
+    const bool e2 = (int32_t)(EMIT_R << (w[2] & 31u)) < 0 && w[2] >= thr16, e3 = (int32_t)(EMIT_R << (w[3] & 31u)) < 0 && w[3] >= thr16;
+    bool bd = false;
     if (T::BAD != 0) {
       const uint32_t t = (BAD_R << (w[0] & 31u)) | (BAD_R << (w[1] & 31u)) | (BAD_R << (w[2] & 31u)) | (BAD_R << (w[3] & 31u));
-      cand |= (int32_t)t < 0;
+      bd = (int32_t)t < 0;
     }
-    // decode + ONE pair of prefix sums: totals for the running offsets, prefixes for the candidates
-    uint32_t ar[4], aq[4];
+    uint32_t sum_r = 0, sum_q = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const uint32_t len = w[k] >> 4;
-      ar[k] = len & (uint32_t)__builtin_amdgcn_sbfe(REF2, w[k], 1);
-      aq[k] = len & (uint32_t)__builtin_amdgcn_sbfe(QRY2, w[k], 1);
+      sum_r += len & (uint32_t)__builtin_amdgcn_sbfe(REF2, w[k], 1);
+      sum_q += len & (uint32_t)__builtin_amdgcn_sbfe(QRY2, w[k], 1);
     }
-    const uint32_t sum_r = ar[0] + ar[1] + ar[2] + ar[3], sum_q = aq[0] + aq[1] + aq[2] + aq[3];
     const uint32_t incl_r = wave_incl_scan(sum_r), incl_q = wave_incl_scan(sum_q);
     const uint32_t tot_r = rdlane(incl_r, 63), tot_q = rdlane(incl_q, 63);
-    const bool any_cand = __ballot(cand) != 0ull && !(ablate & 1);
-    const bool boundary = nxt < cb + 256u;
-    if (!any_cand && !boundary) { run_r += tot_r; run_q += tot_q; return; }
-    uint32_t pr[4], pq[4];                       // exclusive in-chunk prefix in front of each of the lane's ops
-    pr[0] = incl_r - sum_r; pq[0] = incl_q - sum_q;
+    const bool any_cand = __ballot(e0 | e1 | e2 | e3 | bd) != 0ull && !(ablate & 1);
+    if (!any_cand && !(nxt < cb + 256u)) { run_r += tot_r; run_q += tot_q; return; }
+    pw[0] = w[0]; pw[1] = w[1]; pw[2] = w[2]; pw[3] = w[3];
+    p_pr0 = incl_r - sum_r; p_pq0 = incl_q - sum_q;
+    p_badany = any_cand && __ballot(bd) != 0ull;
+    p_cb = cb; p_tot_r = tot_r; p_tot_q = tot_q;
+    pending = true;
+  };
+
+  // emission block: the pending chunk is cut into segments at the record starts it holds (usually none: one segment); the
+  // candidate ops of a segment belong to one record and build their rows together. Counting runs on the scalar unit (the
+  // candidate predicates are lane masks), the vector unit only builds rows for the sub-slots that hold a candidate.
+  auto emit_pending = [&]() {
+    const uint32_t cb = p_cb;
+    const uint32_t x = cb + 4u * (uint32_t)lane;
+    uint32_t base_r = run_r, base_q = run_q, lo = cb, hi_cap = 0xFFFFFFFFu;
+    for (;;) {
+      uint32_t hi = nxt < cb + 256u ? nxt : cb + 256u;
+      if (hi_cap < hi) hi = hi_cap;
+      // ---- segment [lo, hi) of record cur_rec ----
+      if (hi > lo && cur_rec != 0xFFFFFFFFu) {
+        bool e[4];
 #pragma unroll
-    for (int k = 1; k < 4; ++k) { pr[k] = pr[k - 1] + ar[k - 1]; pq[k] = pq[k - 1] + aq[k - 1]; }
-    uint32_t base_r = run_r, base_q = run_q, lo = cb;
-    while (nxt < cb + 256u) {                    // a record starts inside this chunk: close the segment in front of it
-      if (any_cand && cur_rec != 0xFFFFFFFFu && nxt > lo) emit_segment(w, pr, pq, cb, lo, nxt, cur_rec, base_r, base_q, in_head);
-      const uint32_t ls = (nxt - cb) >> 2, ss = (nxt - cb) & 3u;
-      const uint32_t p_r = rdlane(ss == 0 ? pr[0] : ss == 1 ? pr[1] : ss == 2 ? pr[2] : pr[3], ls);
-      const uint32_t p_q = rdlane(ss == 0 ? pq[0] : ss == 1 ? pq[1] : ss == 2 ? pq[2] : pq[3], ls);
-      base_r = 0u - p_r; base_q = 0u - p_q;      // ops of the new record: offset = px - P(start)
+        for (int k = 0; k < 4; ++k) e[k] = (int32_t)(EMIT_R << (pw[k] & 31u)) < 0 && pw[k] >= thr16 && !(ablate & 1);
+        const bool whole = lo == cb && hi == cb + 256u;
+        if (!whole) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) e[k] = e[k] && x + k >= lo && x + k < hi;
+        }
+        const uint64_t m0 = __ballot(e[0]), m1 = __ballot(e[1]), m2 = __ballot(e[2]), m3 = __ballot(e[3]);
+        const uint32_t n = (uint32_t)(__popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3));
+        bool any_b = false;
+        if (T::BAD != 0 && p_badany) {
+          bool b = false;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            uint32_t wk = pw[k];
+            asm volatile("" : "+v"(wk));       // keep the test behind its guard (the optimizer hoists loop-invariant arithmetic)
+            b = b || ((int32_t)(BAD_R << (wk & 31u)) < 0 && wk >= 16u && x + k >= lo && x + k < hi);
+          }
+          any_b = __ballot(b) != 0ull;
+        }
+        if (n != 0 || any_b) {
+          const uint32_t rec = __builtin_amdgcn_readfirstlane(cur_rec);
+          if (rec != hd_rec) {                                   // header through the scalar cache, once per record and part
+            const uint64_t* po = rv.cigar_off + rec;
+            uint64_t fo;
+            asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(fo) : "s"(po) : "memory");
+            if (fo >= (uint64_t)rv.n_ops) fo = 0;                // garbage offsets are reported by the part that stages them
+            sload5(align4(rv.flag + rec), align4(rv.mapq + rec), rv.tid + rec, rv.cigar + fo, rv.pos + rec, hd_fl, hd_mq, hd_tid, hd_first, hd_pos);
+            hd_rec = rec;
+          }
+          const uint32_t fl = byte_of(hd_fl, rv.flag + rec), mq = byte_of(hd_mq, rv.mapq + rec);
+          uint32_t hapbits;
+          if (CLS == 0) hapbits = (mq >= (uint32_t)min_mapq) ? ((fl >> 2) & 3u) : 0u;               // H:392-394
+          else if (CLS == 1) hapbits = (mq >= (uint32_t)min_mapq) ? 1u : 0u;                        // RS:120
+          else if (CLS == 3) hapbits = (!(fl & VSV_F_SKIP) && mq >= (uint32_t)min_mapq) ? 1u : 0u; // SE:439, 446
+          else hapbits = (!(fl & (VSV_F_UNMAPPED | VSV_F_SECONDARY)) && mq >= (uint32_t)min_mapq) ? 1u : 0u;
+          if (hapbits && any_b && lane == 0) atomicOr(&ec.ctr->err, ERRB_REFEND);   // N/=/X on the contig table: H:396 assert
+          if (hapbits && n != 0) {
+            const uint32_t sh = (hapbits == 3u) ? 1u : 0u;       // two rows per signature when the name carries both tags
+            const uint32_t nrows = n << sh;
+            if (nrows > (uint32_t)K1L_STAGE) { hi_cap = lo + (uint32_t)K1L_STAGE / 2u; continue; }   // 32 ops hold at most 64 rows: cut the segment
+            if (n_staged + nrows > (uint32_t)K1L_STAGE) flush();
+            const uint32_t hc = (T::HC && (hd_first & 15u) == 5u) ? (hd_first >> 4) : 0u;           // H:63-65
+            const uint32_t rec2 = in_head ? 0xFFFFFFFEu : 0xFFFFFFFFu;   // staged rows: rec2 carries the "misses the part's carry" flag
+            const uint32_t pos0 = hd_pos + base_r, q0 = base_q + hc;
+            const uint32_t hapmeta = (CLS == 0 && hapbits == 2u) ? VSV_M_HP2 : 0u;
+            // candidates of lower lanes (mbcnt of each non-empty mask)
+            uint32_t below = 0;
+            if (m0) below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, below));
+            if (m1) below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, below));
+            if (m2) below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, below));
+            if (m3) below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m3, below));
+            uint32_t pr = p_pr0, pq = p_pq0;                     // prefix in front of sub-slot k, advanced as k goes up
+            auto put = [&](int k, uint32_t own) {
+              const uint32_t idx = n_staged + ((below + own) << sh);
+              uint32_t wk = pw[k];
+              asm volatile("" : "+v"(wk));     // rows are built only for sub-slots that hold a candidate: keep the arithmetic here
+              const uint32_t op = wk & 15u, len = wk >> 4;
+              uint4 lo4, hi4;
+              lo4.x = pos0 + pr;                                                   // pos
+              lo4.y = len;                                                         // svlen
+              lo4.z = q0 + pq;                                                     // q_start
+              lo4.w = (CLS == 1 || CLS == 3) ? 0u : lo4.z + (op == 2u ? 1u : len); // q_end
+              hi4.x = rec; hi4.y = rec2; hi4.w = hd_tid;
+              const uint32_t del = op == 2u ? VSV_M_DEL : 0u;
+              hi4.z = del | hapmeta;
+              my_rows[2 * idx] = lo4; my_rows[2 * idx + 1] = hi4;
+              if (sh) { hi4.z = del | VSV_M_HP2; my_rows[2 * idx + 2] = lo4; my_rows[2 * idx + 3] = hi4; }
+            };
+            auto advance = [&](int k) {
+              uint32_t wk = pw[k];
+              asm volatile("" : "+v"(wk));
+              const uint32_t len = wk >> 4;
+              pr += len & (uint32_t)__builtin_amdgcn_sbfe(REF2, wk, 1);
+              pq += len & (uint32_t)__builtin_amdgcn_sbfe(QRY2, wk, 1);
+            };
+            if (m0) { if (e[0]) put(0, 0u); }
+            if (m1 | m2 | m3) {
+              advance(0);
+              uint32_t own = e[0] ? 1u : 0u;
+              if (m1) { if (e[1]) put(1, own); }
+              if (m2 | m3) {
+                advance(1);
+                own += e[1] ? 1u : 0u;
+                if (m2) { if (e[2]) put(2, own); }
+                if (m3) {
+                  advance(2);
+                  own += e[2] ? 1u : 0u;
+                  if (e[3]) put(3, own);
+                }
+              }
+            }
+            __builtin_amdgcn_wave_barrier();
+            n_staged += nrows; ord += nrows;
+          }
+        }
+      }
+      lo = hi; hi_cap = 0xFFFFFFFFu;
+      if (lo >= cb + 256u) break;
+      if (lo != nxt) continue;                                   // a cut segment: same record, next slice
+      // ---- a record starts at nxt: ops from there on lie px - P(start) behind their record's start ----
+      {
+        const uint32_t ls = (nxt - cb) >> 2, ss = (nxt - cb) & 3u;
+        uint32_t pr = p_pr0, pq = p_pq0;
+        for (uint32_t k = 0; k < ss; ++k) {                      // prefix in front of sub-slot ss of lane ls (wave-uniform trip count)
+          uint32_t wk = k == 0 ? pw[0] : k == 1 ? pw[1] : pw[2];
+          asm volatile("" : "+v"(wk));
+          const uint32_t len = wk >> 4;
+          pr += len & (uint32_t)__builtin_amdgcn_sbfe(REF2, wk, 1);
+          pq += len & (uint32_t)__builtin_amdgcn_sbfe(QRY2, wk, 1);
+        }
+        base_r = 0u - rdlane(pr, ls); base_q = 0u - rdlane(pq, ls);
+      }
       cur_rec = tbase + ti; in_head = false; has_start = 1;
-      lo = nxt;
       ++ti;
       nxt = next_start();
       if (bad) return;
     }
-    if (any_cand && cur_rec != 0xFFFFFFFFu) emit_segment(w, pr, pq, cb, lo, cb + 256u, cur_rec, base_r, base_q, in_head);
-    run_r = base_r + tot_r; run_q = base_q + tot_q;
+    run_r = base_r + p_tot_r; run_q = base_q + p_tot_q;
   };
 
-  for (uint32_t cb = 0; cb < part_len && !bad; cb += 1024) {
-    process_chunk(wa, cb);
-    wa = load_chunk(cb + 1024);
-    process_chunk(wb, cb + 256);
-    wb = load_chunk(cb + 1280);
-    process_chunk(wc, cb + 512);
-    wc = load_chunk(cb + 1536);
-    process_chunk(wd, cb + 768);
-    wd = load_chunk(cb + 1792);
+  // Four chunks in flight. The ring register a block reads is the oldest load (it has arrived when the block tests it) and is
+  // re-issued right away; the blocks are guarded by the (wave-uniform) slot so that the emission code exists ONCE, behind them.
+  uint32_t cb = 0, slot = 0;
+  while (cb < part_len && !bad) {
+    if (slot == 0 && !pending) { K1L_ARRIVE(wa); stream(wa, cb); issue(wa, cb + 1024); cb += 256; slot = 1; }
+    if (slot == 1 && !pending) { K1L_ARRIVE(wb); stream(wb, cb); issue(wb, cb + 1024); cb += 256; slot = 2; }
+    if (slot == 2 && !pending) { K1L_ARRIVE(wc); stream(wc, cb); issue(wc, cb + 1024); cb += 256; slot = 3; }
+    if (slot == 3 && !pending) { K1L_ARRIVE(wd); stream(wd, cb); issue(wd, cb + 1024); cb += 256; slot = 0; }
+    if (pending) { emit_pending(); pending = false; }
   }
+  // the last prefetches are still in flight and will write their (clipped, zero) data into the ring registers: the registers stay
+  // reserved until everything has landed — the compiler does not know about loads issued by inline asm
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(wa), "+v"(wb), "+v"(wc), "+v"(wd) : : "memory");
+  if (pending && !bad) emit_pending();
+#undef K1L_ARRIVE
   // records whose starts were never reached (offsets beyond the part, part cut short by end_all): still validate them
   while (!bad && tbase + n_tab < r1) stage(tbase + n_tab);
-  release_left();
-  finish_part(has_start, run_r, run_q);
+  flush();
+  if (lane == 0) { part_count[part] = ord; PartAgg a; a.has_start = has_start; a.run_r = run_r; a.run_q = run_q; agg[part] = a; }
 }
 
 // ---- carry of the long-record scan: segmented exclusive scan over the parts --------------------------------------------
