@@ -62,6 +62,19 @@ def parse_sa(sa_text, tid_of):
     return out
 
 
+class _NoNames:
+    """len()-only stand-in for the read names of a synthetic segment table."""
+
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        return "read%d" % i
+
+
 class SegmentSoA:
     """vsv_segments on the host. reads: [{'hap': 1|2, 'name': str, 'segs': [[ref_id, ref_start, ref_end,
     query_alignment_start, query_alignment_end, read_length, is_reverse], ...]}] with the primary alignment first."""
@@ -88,6 +101,19 @@ class SegmentSoA:
         rank = np.zeros(len(contigs), np.int32)
         rank[order] = np.arange(len(contigs), dtype=np.int32)
         self.contig_rank = rank
+
+    @classmethod
+    def from_arrays(cls, contigs, seg_off, q_start, q_end, ref_id, ref_start, ref_end, is_reverse, hap, names=None):
+        """Segment tables built elsewhere (synthetic streams): the arrays of `as_struct`, query coordinates already flipped
+        for reverse strands."""
+        self = cls([], contigs)
+        self.seg_off = np.ascontiguousarray(seg_off, np.uint64)
+        self.q_start, self.q_end = np.ascontiguousarray(q_start, np.int32), np.ascontiguousarray(q_end, np.int32)
+        self.ref_id, self.ref_start, self.ref_end = (np.ascontiguousarray(a, np.int32) for a in (ref_id, ref_start, ref_end))
+        self.is_reverse, self.hap = np.ascontiguousarray(is_reverse, np.uint8), np.ascontiguousarray(hap, np.uint8)
+        self.n_reads = len(self.hap)
+        self.names = names if names is not None else _NoNames(self.n_reads)
+        return self
 
     def as_struct(self):
         s = Segments()

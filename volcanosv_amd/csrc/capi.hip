@@ -1265,7 +1265,12 @@ int vsv_table_fill(vsv_handle* h, int table, void* dst, int64_t cap_rows, int ds
   if (st) return fail(h, st, "table not available at this stage");
   if (!filter) {                                 // straight copy, no staging
     if (n > cap_rows) { h->last_count = n; return fail(h, VSV_E_CAPACITY, "destination too small"); }
-    if (n) HIPCHK(h, hipMemcpy(dst, src, (size_t)n * row, dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+    // on the handle's stream, then a wait on THAT stream only: a device-wide synchronisation here would stall the other engines of
+    // a rank that keeps several chromosomes in flight
+    if (n) {
+      HIPCHK(h, hipMemcpyAsync(dst, src, (size_t)n * row, dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
     return 0;
   }
   std::vector<char> host;

@@ -367,8 +367,8 @@ __global__ __launch_bounds__(256) void split_mark_pairs(const uint64_t* __restri
   }
 }
 
-constexpr int SE_GROUP = 8;          // lanes cooperating on one pair slot
 constexpr uint32_t SE_LONG_OPS = 1024;   // a pair whose two CIGARs hold more ops than this is summed by the whole wave
+template <int SE_GROUP>
 __device__ __forceinline__ int64_t group_sum64(int64_t v) {
 #pragma unroll
   for (int d = SE_GROUP / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
@@ -395,8 +395,10 @@ __device__ __forceinline__ void op_sums(const uint32_t* __restrict__ cigar, uint
 }
 
 // SE_GROUP lanes per pair slot (in okey order); writes one signature row (possibly dead) per slot. Control flow is uniform
-// per group up to the sums (the group shuffles need every lane of the group), and the few pairs of long records (contig
-// alignments: 10^4-10^6 ops per CIGAR) are summed by all 64 lanes of the wave, one pair after the other.
+// per group up to the sums (the group shuffles need every lane of the group). SE_GROUP = 8 for reads (tens to hundreds of ops per
+// CIGAR; a stray pair of long records is summed by all 64 lanes of the wave, one such pair after the other), SE_GROUP = 64 for
+// contig alignments (10^4-10^6 ops per CIGAR): one pair per wave, so the pairs of a chromosome spread over the chip.
+template <int SE_GROUP>
 __global__ __launch_bounds__(256) void split_eval(RecView rv, const uint64_t* __restrict__ okey, const uint32_t* __restrict__ oval,
                                                   const uint64_t* __restrict__ ckey, const uint32_t* __restrict__ crec,
                                                   SplitCfg c, int dtype, int max_svlen, vsv_sig* __restrict__ s1in,
@@ -433,10 +435,10 @@ __global__ __launch_bounds__(256) void split_eval(RecView rv, const uint64_t* __
       }
     }
     // ---- phase 2: reference span of record 1, read lengths of both --------------------------------------------------
-    const bool is_long = need && (b1 - a1) + (b2 - a2) > SE_LONG_OPS;
+    const bool is_long = SE_GROUP < 64 && need && (b1 - a1) + (b2 - a2) > SE_LONG_OPS;
     int64_t rf1 = 0, rl1 = 0, rf2 = 0, rl2 = 0;
     if (need && !is_long) { op_sums(rv.cigar, a1, b1, reads, lane, SE_GROUP, rf1, rl1); op_sums(rv.cigar, a2, b2, reads, lane, SE_GROUP, rf2, rl2); }
-    rf1 = group_sum64(rf1); rl1 = group_sum64(rl1); rl2 = group_sum64(rl2);
+    rf1 = group_sum64<SE_GROUP>(rf1); rl1 = group_sum64<SE_GROUP>(rl1); rl2 = group_sum64<SE_GROUP>(rl2);
     uint64_t lm = __ballot(is_long && lane == 0);
     while (lm) {                                       // wave-uniform: one long pair at a time, 64 lanes on its two CIGARs
       const int src = __builtin_ctzll(lm);
@@ -678,11 +680,10 @@ __global__ __launch_bounds__(256) void pair_kernel(const vsv_sig* __restrict__ m
     const int sh_hap = pb + 2, sh_tid = pb + 3;
     const uint64_t tk = key[i] >> sh_tid;
     if (i > 0 && (key[i - 1] >> sh_hap) == (key[i] >> sh_hap) && (int64_t)me.pos - m[i - 1].pos <= 2 * (int64_t)pair_shift) continue;
-    const uint32_t b0 = lower_bound_key(key, n, (tk << sh_tid) | (1ull << sh_hap));
-    const uint32_t b1 = lower_bound_key(key, n, (tk + 1) << sh_tid);
-    // first hp2 row of this tid with pos >= pos_i - pair_shift (rows further left can never match)
+    // first hp2 row of this tid with pos >= pos_i - pair_shift (rows further left can never match); the hp2 block ends where
+    // the (tid, hap) prefix of the key changes, so no search for its bounds is needed
+    const uint64_t hp2_prefix = (tk << 1) | 1ull;
     uint32_t jlo = lower_bound_key(key, n, (tk << sh_tid) | (1ull << sh_hap) | vsv_kpos((int32_t)max((int64_t)me.pos - pair_shift, (int64_t)-VSV_POS_BIAS)));
-    if (jlo < b0) jlo = b0;
     {   // dense stretch: hand it to pair_long_kernel
       uint32_t e = i + 1;
       while (e < n && e - i <= LONG_RUN && (key[e] >> sh_hap) == (key[i] >> sh_hap) && (int64_t)m[e].pos - m[e - 1].pos <= 2 * (int64_t)pair_shift) ++e;
@@ -692,9 +693,9 @@ __global__ __launch_bounds__(256) void pair_kernel(const vsv_sig* __restrict__ m
       const vsv_sig s1 = m[a];
       if ((key[a] >> sh_hap) != (key[i] >> sh_hap)) break;
       if (a > i && (int64_t)s1.pos - m[a - 1].pos > 2 * (int64_t)pair_shift) break;
-      while (jlo < b1 && (int64_t)s1.pos - m[jlo].pos > pair_shift) ++jlo;
+      while (jlo < n && (key[jlo] >> sh_hap) == hp2_prefix && (int64_t)s1.pos - m[jlo].pos > pair_shift) ++jlo;
       int32_t mate = -1;
-      for (uint32_t j = jlo; j < b1; ++j) {
+      for (uint32_t j = jlo; j < n && (key[j] >> sh_hap) == hp2_prefix; ++j) {
         const vsv_sig s2 = m[j];
         if ((int64_t)s2.pos - s1.pos > right) break;
         if (((s1.meta ^ s2.meta) & VSV_M_DEL) == 0 && st2[j] == -1 && vsv_match(s1, s2, pair_shift)) {
@@ -828,7 +829,9 @@ void vsv_launch_split(hipStream_t st, const RecView& rv, const vsv_params& p, in
     const SortResult r1 = vsv_radix_sort_pairs(st, ckey, crec, sw.key_alt, sw.val_alt, &ctr->n_cand, cap, c.tid_shift + tid_bits, sw);
     split_mark_pairs<<<grid, 256, 0, st>>>(r1.key, r1.val, c, rec_bits, okey, oval, ctr);
     const SortResult r2 = vsv_radix_sort_pairs(st, okey, oval, key2, idx2, &ctr->n_cand, cap, rec_bits + 1 + tid_bits + 1, sw);
-    split_eval<<<grid * 8 < 1024 ? 1024 : (grid * 8 > 8192 ? 8192 : grid * 8), 256, 0, st>>>(rv, r2.key, r2.val, r1.key, r1.val, c, p.dtype, p.max_split_svlen, s1in, cap, ctr);
+    const int eg = grid * 8 < 1024 ? 1024 : (grid * 8 > 8192 ? 8192 : grid * 8);
+    if (vsv_scan_is_long(rv, p)) split_eval<64><<<eg, 256, 0, st>>>(rv, r2.key, r2.val, r1.key, r1.val, c, p.dtype, p.max_split_svlen, s1in, cap, ctr);
+    else split_eval<8><<<eg, 256, 0, st>>>(rv, r2.key, r2.val, r1.key, r1.val, c, p.dtype, p.max_split_svlen, s1in, cap, ctr);
   } else {
     set_n_s1<<<1, 1, 0, st>>>(ctr, cap);
   }

@@ -48,7 +48,53 @@ def generate(n_records, shape="hifi", seed=20250330, tid=0, chrom_len=CHR10_LEN,
             parts.append((t, nq))
         t, nq = concat(parts)
         return t, nq, int(tid) + 1
+    if n_chunks > 1:
+        # contig shape: a record spans megabases, so position slices cannot keep split mates apart. Independent batches over the
+        # whole chromosome instead (the ragged-array temporaries of one batch fit in HBM), merged by one stable sort on pos.
+        parts, per = [], n_records // n_chunks
+        for c in range(n_chunks):
+            n_c = per if c < n_chunks - 1 else n_records - per * (n_chunks - 1)
+            t, nq, _ = _generate_slice(n_c, shape, seed + 7919 * c, tid, 0, chrom_len, chrom_len, device, events_per_record, site_step)
+            parts.append((t, nq))
+        t, nq = concat(parts)
+        del parts
+        return _sort_records(t), nq, int(tid) + 1
     return _generate_slice(n_records, shape, seed, tid, 0, chrom_len, chrom_len, device, events_per_record, site_step)
+
+
+def _sort_records(t, block_ops=200_000_000):
+    """Stable sort of a record SoA by pos (one tid): scalars are permuted, the ragged CIGAR array is gathered in blocks of output
+    records so that the int64 index temporaries stay bounded; query ids are renumbered in first-appearance order (the ingest's
+    numbering, which the split stage's repeat test is exact and cheapest for)."""
+    dev = t["pos"].device
+    n = int(t["pos"].numel())
+    order = torch.sort(t["pos"], stable=True).indices
+    off = t["cigar_off"]
+    nops = (off[1:] - off[:-1])[order]
+    new_off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    new_off[1:] = torch.cumsum(nops, 0)
+    src_start = off[:-1][order]
+    cigar = torch.empty_like(t["cigar"])
+    a = 0
+    while a < n:
+        # largest b with new_off[b] - new_off[a] <= block_ops (at least one record)
+        b = int(torch.searchsorted(new_off, new_off[a] + block_ops, right=True)) - 1
+        b = min(max(b, a + 1), n)
+        lo, hi = int(new_off[a]), int(new_off[b])
+        rec = torch.repeat_interleave(torch.arange(a, b, device=dev), nops[a:b])
+        src = src_start[rec] + (torch.arange(lo, hi, device=dev) - new_off[rec])
+        cigar[lo:hi] = t["cigar"][src]
+        del rec, src
+        a = b
+    out = {k: t[k][order] for k in ("pos", "tid", "mapq", "flag")}
+    q = t["qid"][order].to(torch.int64)
+    first = torch.full((int(q.max()) + 1,), n, dtype=torch.int64, device=dev).scatter_reduce_(0, q, torch.arange(n, device=dev), "amin")
+    rank = torch.empty_like(first)
+    rank[torch.sort(first, stable=True).indices] = torch.arange(first.numel(), device=dev)
+    out["qid"] = rank[q].to(torch.int32)
+    out["cigar_off"] = new_off
+    out["cigar"] = cigar
+    return out
 
 
 def _generate_slice(n_records, shape, seed, tid, pos_lo, pos_hi, chrom_len, device, events_per_record, site_step):
@@ -211,3 +257,65 @@ def concat(parts):
     out["qid"] = torch.cat(qs)
     out["cigar_off"] = torch.cat(offs + [last])
     return out, qshift
+
+
+# ---- BASELINE config 5: Complex_SV split-contig stream ----------------------------------------------------------------
+HG19_LEN = [249250621, 243199373, 198022430, 191154276, 180915260, 171115067, 159138663, 146364022, 141213431, 135534747, 135006516,
+            133851895, 115169878, 107349540, 102531392, 90354753, 81195210, 78077248, 59128983, 63025520, 48129895, 51304566]   # chr1..22 (Large_INDEL/header:5-26)
+
+
+def generate_bnd(n_events, seed=20250333, n_tids=22, dense_frac=0.01):
+    """Split contigs of SURVEY §8d config 5 as a bnd.SegmentSoA in collection order (hp1 reads, then hp2 reads): every event
+    is a contig of 2-4 aligned segments (each junction a breakend: half of them inter-chromosomal, the others > 1 Mb apart on
+    one chromosome), its hp2 copy jittered by U[-900,900] on every segment (SURVEY writes U[-300,300] "so that about half pair": with
+    the reference's rule |d1| + |d2| <= 900 it takes +-900 for half of the junctions to pair), and 1 % of the events replicated 12 times within a
+    few bp (partitions of more than 10 members, which the reference drops, SVIM_COMBINE.py:151-152).
+    Returns (SegmentSoA, primary_tid[n_reads])."""
+    from . import bnd
+    rng = np.random.default_rng(seed)
+    contigs = [("chr%d" % (i + 1), HG19_LEN[i]) for i in range(n_tids)]
+    lens = np.array([c[1] for c in contigs], np.int64)
+    n_dense = int(n_events * dense_frac)
+    k = rng.integers(2, 5, n_events)                                  # segments per contig
+    reps = np.ones(n_events, np.int64)
+    reps[:n_dense] = 12
+    # one row per (event, segment)
+    ev_of = np.repeat(np.arange(n_events), k)
+    j = np.arange(len(ev_of)) - np.repeat(np.cumsum(k) - k, k)          # segment index inside the event
+    t0 = rng.integers(0, n_tids, n_events)
+    tid = t0[ev_of].copy()
+    inter = rng.random(len(ev_of)) < 0.5
+    hop = rng.integers(1, n_tids, len(ev_of))
+    # segment j > 0 jumps to another chromosome (inter) or stays on the previous one
+    for step in range(1, 4):
+        m = j == step
+        prev = np.flatnonzero(m) - 1
+        tid[m] = np.where(inter[m], (tid[prev] + hop[m]) % n_tids, tid[prev])
+    span = 20000
+    pos = (rng.random(len(ev_of)) * (lens[tid] - 4 * span - 2_000_000)).astype(np.int64) + span + 1_000_000
+    rev = rng.random(len(ev_of)) < 0.5
+
+    def reads_of(hap, jit_seed):
+        r2 = np.random.default_rng(jit_seed)
+        # replicate events: copy c of a dense event is shifted by c bp
+        rep_ev = np.repeat(np.arange(n_events), reps)
+        copy = np.arange(len(rep_ev)) - np.repeat(np.cumsum(reps) - reps, reps)
+        first_seg = np.cumsum(k) - k
+        seg_idx = np.repeat(first_seg[rep_ev], k[rep_ev]) + (np.arange(int(k[rep_ev].sum())) - np.repeat(np.cumsum(k[rep_ev]) - k[rep_ev], k[rep_ev]))
+        shift = np.repeat(copy, k[rep_ev])
+        jitter = r2.integers(-900, 901, len(seg_idx)) if hap == 2 else 0
+        p = pos[seg_idx] + shift + jitter
+        return dict(k=k[rep_ev], tid=tid[seg_idx], start=p, rev=rev[seg_idx], j=j[seg_idx])
+
+    parts = [reads_of(1, seed + 1), reads_of(2, seed + 2)]
+    kk = np.concatenate([p["k"] for p in parts])
+    seg_off = np.zeros(len(kk) + 1, np.uint64)
+    seg_off[1:] = np.cumsum(kk)
+    jj = np.concatenate([p["j"] for p in parts])
+    start = np.concatenate([p["start"] for p in parts])
+    seg = bnd.SegmentSoA.from_arrays(
+        contigs, seg_off, q_start=jj * span, q_end=(jj + 1) * span, ref_id=np.concatenate([p["tid"] for p in parts]),
+        ref_start=start, ref_end=start + span, is_reverse=np.concatenate([p["rev"] for p in parts]).astype(np.uint8),
+        hap=np.concatenate([np.full(len(parts[0]["k"]), 1, np.uint8), np.full(len(parts[1]["k"]), 2, np.uint8)]))
+    primary_tid = seg.ref_id[seg.seg_off[:-1].astype(np.int64)]
+    return seg, primary_tid
