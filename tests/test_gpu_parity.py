@@ -576,3 +576,58 @@ def test_dense_runs_use_the_wave_cooperative_kernels(eng):
         run_both(e, soa, DTYPE_ONT)
     finally:
         e.close()
+
+
+def test_config4_shape_22_chromosomes(eng):
+    """BASELINE config 4 in miniature: 22 tids with records on every one of them (hg19-ordered lengths scaled down) through the
+    HIP path — (a) the whole multi-chromosome SoA in one call against the oracle, (b) sharded like bench.py --config 4 / the WGS
+    driver: shard.lpt_assign gives every rank its chromosomes, a rank runs them one at a time with the tid_lo / n_tids key hints,
+    and the union of the per-chromosome call tables is the unsharded call table."""
+    from volcanosv_amd import shard, synth
+    from volcanosv_amd.engine import default_params
+    parts, lens = [], [int(l // 60) + 60_000 for l in synth.HG19_LEN]
+    for tid in range(22):
+        t, nq, _ = synth.generate(4000 + 150 * (tid % 5), "hifi", seed=400 + tid, tid=tid, chrom_len=lens[tid], events_per_record=0.15, site_step=1000)
+        parts.append((t, nq))
+    t, nq = synth.concat(parts)
+    soa = synth.to_soa(t, nq)
+    soa.n_tids = 22
+    want = run_both(eng, soa, DTYPE_HIFI)
+    assert len(np.unique(want["calls"]["sig"]["tid"])) == 22
+    run_both(eng, soa, DTYPE_READS)
+    p = default_params(DTYPE_HIFI)
+    for world in (3, 8):
+        owner = shard.lpt_assign([int(pt[0]["pos"].numel()) for pt in parts], world)
+        assert max(np.bincount(owner, minlength=world)) == -(-22 // world)          # equal-sized chromosomes: 3 on the busiest of 8 ranks
+        got = []
+        first_rec = np.concatenate(([0], np.cumsum([int(pt[0]["pos"].numel()) for pt in parts])))
+        for rank in range(world):
+            for tid in [c for c in range(22) if owner[c] == rank]:
+                one = synth.to_soa(parts[tid][0], parts[tid][1])
+                one.n_tids, one.only_tid, one.max_pos = 22, tid, lens[tid] + 100000
+                eng.run(one, p)
+                c = eng.table("calls").copy()
+                c["sig"]["rec"] += np.uint32(first_rec[tid])                      # record indices of the shard -> of the whole input
+                split = c["sig"]["rec2"] != 0xFFFFFFFF
+                c["sig"]["rec2"][split] += np.uint32(first_rec[tid])
+                got.append(c)
+        allc = np.concatenate(got)
+        allc = allc[np.argsort((allc["sig"]["tid"].astype(np.int64) << 32) | (allc["sig"]["pos"].astype(np.int64) + 65536), kind="stable")]
+        # a/b index the merged table of the call's own run: compare the signature, genotype and member counts
+        assert np.array_equal(allc["sig"], want["calls"]["sig"]) and np.array_equal(allc["gt"], want["calls"]["gt"])
+
+
+def test_config5_exchange_with_the_hip_engine(tmp_path):
+    """BASELINE config 5 over two ranks (gloo rendezvous, both ranks on cuda:0), HIP kernels as the compute on every rank:
+    candidates on the owner of the primary alignment (vsv_bnd_segments), shard.exchange_bnd to the owner of the source contig,
+    vsv_bnd_set_candidates + vsv_bnd_pair there, gather — equal to the single-process HIP run and to the oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+           os.path.join(root, "tests", "_bnd_shard_worker.py"), "--engine", "hip", "--events", "6000"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "BND_SHARD_OK" in r.stdout

@@ -372,3 +372,41 @@ def test_member_crc32_is_checked_on_the_gpu(tmp_path):
         with bam.BamFile(path) as bf:
             with pytest.raises(VsvError):
                 bf.fetch_soa(None)                                           # the host reader checks it too
+
+
+@pytest.mark.gpu
+def test_device_reader_on_the_reference_held_bam_fixtures():
+    """svim-asm's own htslib-written fixtures (tests/golden/chimeric_read.bam, chimeric_read_errors.bam = the data files of
+    svim-asm tests/test_satag.py) through BamFile.fetch_device(sa=True): files this repo's writer did not produce. Every array,
+    the name table and the SA:Z texts equal the host reader's, and the SA texts satisfy test_satag.py:13-54 (the primary's tag
+    reconstructs the three other alignments; an entry with too many fields is skipped; a negative MAPQ becomes 0)."""
+    from volcanosv_amd import bam, bnd
+    from volcanosv_amd.engine import Engine
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    with Engine(0) as eng:
+        for name in ("chimeric_read.bam", "chimeric_read_errors.bam"):
+            with bam.BamFile(os.path.join(golden, name)) as bf:
+                host = bf.fetch_soa(None)
+                view = bf.fetch_device(eng, None, sa=True)
+                assert isinstance(view, bam.DeviceRecordView)
+                dev = view.to_host()
+                assert dev.n_records == host.n_records > 0 and view.n_qids == host.n_qids
+                for field in ("pos", "tid", "qid", "cigar_off", "mapq", "flag", "cigar", "l_seq", "sam_flags"):
+                    assert np.array_equal(getattr(host, field), getattr(dev, field)), (name, field)
+                assert list(host.qnames) == list(dev.qnames)
+                assert list(view.sa_tags) == list(host.sa_tags), name
+                tid_of = lambda n: host.tid_names.index(n)
+                if name == "chimeric_read.bam":
+                    assert host.n_records == 4
+                    prim = [i for i in range(4) if not (dev.flag[i] & 2)]
+                    sa = bnd.parse_sa(view.sa_tags[prim[0]], tid_of)
+                    others = [i for i in range(4) if i != prim[0]]
+                    assert len(sa) == 3
+                    for (tid, pos0, rev, c2, mq), i in zip(sa, others):                 # test_satag.py:25-35
+                        cig = [(int(w) & 15, int(w) >> 4) for w in dev.cigar[int(dev.cigar_off[i]):int(dev.cigar_off[i + 1])]]
+                        assert int(dev.tid[i]) == tid and int(dev.pos[i]) == pos0 and c2 == cig
+                        assert bool(dev.flag[i] & 1) == rev and int(dev.mapq[i]) == mq
+                else:
+                    assert len(bnd.parse_sa(view.sa_tags[0], tid_of)) == 2               # test_satag.py:36-45
+                    neg = bnd.parse_sa(view.sa_tags[1], tid_of)
+                    assert len(neg) == 1 and neg[0][4] == 0                              # test_satag.py:46-54
