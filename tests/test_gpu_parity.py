@@ -631,3 +631,32 @@ def test_config5_exchange_with_the_hip_engine(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "BND_SHARD_OK" in r.stdout
+
+
+def test_bucket_sort_overflow_falls_back_to_the_lsd_passes():
+    """The signature tables are sorted by one counting pass into key-range buckets + an LDS sort per bucket; a bucket that does not
+    fit (here: VSV_BK_CAP=48 rows instead of 4096) raises a device flag and the run is repeated through the LSD radix passes. The
+    result must not depend on which of the two happened; VSV_SORT=lsd never uses the buckets."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "from test_gpu_parity import run_both\n"
+            "from volcanosv_amd import synth\n"
+            "from volcanosv_amd.engine import Engine\n"
+            "from volcanosv_amd.abi import DTYPE_HIFI, DTYPE_READS\n"
+            "t, nq, _ = synth.generate(60000, 'hifi', seed=3, chrom_len=3000000, events_per_record=0.3, site_step=1000)\n"
+            "soa = synth.to_soa(t, nq)\n"
+            "with Engine(0) as e:\n"
+            "    for k in range(3):\n"
+            "        g = run_both(e, soa, DTYPE_HIFI)\n"
+            "    run_both(e, soa, DTYPE_READS)\n"
+            "print('SORT_OK', len(g['calls']))\n") % (root, os.path.join(root, "tests"))
+    outs = []
+    for env_extra in ({"VSV_BK_CAP": "48"}, {"VSV_SORT": "lsd"}, {}):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env_extra), cwd=root)
+        assert r.returncode == 0 and "SORT_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1] == outs[2]

@@ -62,6 +62,9 @@ struct vsv_handle {
   int pass_cursor = 0;
   const uint64_t* sorted_key = nullptr;   // sorted keys of the stage just sorted (cluster / pair read them)
   bool small_sort_tiles = true;    // radix tile size, re-decided after every run from its row counts
+  int lsd_runs = 0;                // > 0: the bucket sort overflowed recently, the next runs use the LSD passes
+  bool in_rerun = false;
+  vsv_bnd_params bnd_prm{};
   Counters host_ctr;
   Counters* pinned = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -198,6 +201,15 @@ SortWork sort_work(vsv_handle* h) {
   w.totals = (uint32_t*)h->totals.p; w.pass_cursor = &h->pass_cursor; w.max_passes = MAX_SORT_PASSES; w.small_tiles = h->small_sort_tiles;
   static const char* force = getenv("VSV_SORT_TILE");   // timing experiments: "big" / "small"
   if (force) w.small_tiles = force[0] == 's';
+  // bucket sort: ~256-512 rows per occupied bucket (about half of the key range is populated) for the largest table of the
+  // previous run; tables beyond ~4 M rows, a handle whose last bucket sort overflowed, and VSV_SORT=lsd take the LSD passes
+  static const char* mode = getenv("VSV_SORT");
+  const Counters& c = h->host_ctr;
+  const uint64_t rows = c.n_s1 > c.n_cand ? c.n_s1 : c.n_cand;
+  int bb = 8;
+  while (bb < 11 && (rows >> bb) > 256) ++bb;
+  w.bucket_bits = (h->lsd_runs > 0 || (mode && mode[0] == 'l') || rows > (4u << 20)) ? 0 : bb;
+  w.err = h->ctr.p ? &((Counters*)h->ctr.p)->err : nullptr;
   return w;
 }
 // zero the device counters and the per-pass sort totals: start of every run
@@ -217,7 +229,11 @@ int ew_grid(vsv_handle* h) {
   const uint64_t g = (rows + 255) / 256;
   return (int)(g < 128 ? 128 : g > 4096 ? 4096 : g);
 }
-StageBufs stage_bufs(vsv_handle* h) { return StageBufs{(uint64_t*)h->key.p, (uint32_t*)h->idx.p, (int32_t*)h->cl.p, h->rv.tid_lo, tid_bits(h), ew_grid(h)}; }
+int pos_bits(vsv_handle* h);
+StageBufs stage_bufs(vsv_handle* h) {
+  const uint64_t kmax = h->n_tids > h->rv.tid_lo ? (uint64_t)(h->n_tids - h->rv.tid_lo) << (pos_bits(h) + 3) : 0;
+  return StageBufs{(uint64_t*)h->key.p, (uint32_t*)h->idx.p, (int32_t*)h->cl.p, h->rv.tid_lo, tid_bits(h), kmax, ew_grid(h)};
+}
 Counters* dctr(vsv_handle* h) { return (Counters*)h->ctr.p; }
 int pos_bits(vsv_handle* h) { return h->max_pos > 0 ? bits_for((uint64_t)h->max_pos + VSV_POS_BIAS + 2) : 32; }
 int tid_bits(vsv_handle* h) { return bits_for((uint64_t)(h->n_tids > 0 ? h->n_tids - h->rv.tid_lo : 65536) + 1); }
@@ -229,6 +245,7 @@ bool is_contig(int dtype) { return dtype == VSV_DTYPE_HIFI || dtype == VSV_DTYPE
 int enq_scan(vsv_handle* h) {
   hipStream_t st = h->stream;
   { int rs = reset_run_state(h); if (rs) return rs; }
+  if (h->lsd_runs > 0 && !h->in_rerun) --h->lsd_runs;
   h->cutesv_rows = -1;   // the split-candidate table shares a buffer with the merge stage
   const int n_parts = vsv_cigar_parts(h->rv.n_ops, OPS_PER_PART);
   RecView srv = h->rv;
@@ -303,6 +320,7 @@ int enq_pair(vsv_handle* h) {
   return 0;
 }
 
+int rerun(vsv_handle* h);
 int finish(vsv_handle* h) {
   HIPCHK(h, hipSetDevice(h->device));   // the current device is per host thread
   HIPCHK(h, hipMemcpyAsync(h->pinned, h->ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
@@ -315,6 +333,16 @@ int finish(vsv_handle* h) {
   }
   const uint32_t e = h->host_ctr.err;
   h->last_count = h->host_ctr.n_pool;
+  if ((e & ERRB_SORT_FALLBACK) && !(e & ~(uint32_t)ERRB_SORT_FALLBACK) && !h->in_rerun) {
+    // a bucket of the bucket sort did not fit in LDS (tables far from uniform, or much larger than the previous run's): the
+    // stages ran on a partly sorted table. Same input again through the LSD passes; this handle keeps them for a while.
+    h->lsd_runs = 16;
+    h->in_rerun = true;
+    const int st = rerun(h);
+    h->in_rerun = false;
+    return st;
+  }
+  if (e & ERRB_SORT_FALLBACK) h->lsd_runs = 16;      // together with a real error: report that one
   if (e & ERRB_CAPACITY) {
     char b[160];
     snprintf(b, sizeof b, "signature capacity %lld exceeded (cigar signatures emitted: %u, split candidates: %u)",
@@ -330,6 +358,28 @@ int finish(vsv_handle* h) {
   if (e & ERRB_UNSORTED) return fail(h, VSV_E_UNSORTED, "split pair with pos1 > pos2");
   if (e & ERRB_READLEN) return fail(h, VSV_E_READLEN, "split pair with unequal read lengths");
   return 0;
+}
+
+// the stages of the last call again (bucket-sort fallback): the records are still bound, every stage recomputes its tables
+int rerun(vsv_handle* h) {
+  int st;
+  if (h->stage_done == 0 && h->bnd_stage == 2) {
+    HIPCHK(h, hipMemsetAsync(&dctr(h)->err, 0, sizeof(uint32_t), h->stream));     // the other counters describe the candidates
+    if (h->totals.p) HIPCHK(h, hipMemsetAsync(h->totals.p, 0, (size_t)MAX_SORT_PASSES * 2048 * sizeof(uint32_t), h->stream));
+    h->pass_cursor = 0;
+    vsv_launch_bnd_pair(h->stream, (const vsv_bnd*)h->s1in.p, h->segs.contig_rank, bits_for((uint64_t)h->segs.n_tids + 1), h->bnd_prm,
+                        (vsv_bnd*)h->s1s.p, (vsv_bnd*)h->c1.p, dctr(h), stage_bufs(h), sort_work(h), h->cap_sigs);
+    HIPCHK(h, hipGetLastError());
+    return finish(h);
+  }
+  const int upto = h->stage_done;
+  if (upto < 1) return fail(h, VSV_E_HIP, "bucket sort overflow outside a signature run");
+  if ((st = enq_scan(h))) return st;
+  if (upto >= 2 && (st = enq_split(h))) return st;
+  if (upto >= 3 && (st = enq_stage1(h))) return st;
+  if (upto >= 4 && (st = enq_merge(h))) return st;
+  if (upto >= 5 && (st = enq_pair(h))) return st;
+  return finish(h);
 }
 
 int start(vsv_handle* h, const vsv_records* recs, const vsv_params* p) {
@@ -656,6 +706,7 @@ int vsv_bnd_pair(vsv_handle* h, const vsv_bnd_params* p) {
   if (!h || !p || h->bnd_stage < 1) return fail(h, VSV_E_INVALID, "vsv_bnd_segments must run first");
   if (p->max_partition < 0 || p->max_partition > 16) return fail(h, VSV_E_INVALID, "max_partition must lie in [0, 16] (the pairing kernel holds a partition in registers)");
   HIPCHK(h, hipSetDevice(h->device));
+  h->bnd_prm = *p;
   vsv_launch_bnd_pair(h->stream, (const vsv_bnd*)h->s1in.p, h->segs.contig_rank, bits_for((uint64_t)h->segs.n_tids + 1), *p,
                       (vsv_bnd*)h->s1s.p, (vsv_bnd*)h->c1.p, dctr(h), stage_bufs(h), sort_work(h), h->cap_sigs);
   HIPCHK(h, hipGetLastError());

@@ -8,6 +8,8 @@
 // 4 waves x 16 rounds x 64 items; inside a wave the stable rank of an item among equal digits is
 // popcount(match_mask & lanes_below) where match_mask comes from 8 wave64 ballots, plus a per-wave LDS
 // running counter across rounds — no atomics, fully deterministic.
+#include <stdlib.h>
+
 #include "vsv_device.h"
 
 namespace {
@@ -33,9 +35,26 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid) {
 
 template <int ROUNDS> __device__ __forceinline__ uint32_t n_tiles_of(uint32_t n) { return (n + rs_tile<ROUNDS>() - 1) / rs_tile<ROUNDS>(); }
 
+// digit of a key: LSD passes take BITS bits at `shift`; the bucket pass (below) maps the whole key range [0, kmax) linearly onto
+// BINS - 1 buckets (monotone, so the buckets are contiguous key ranges) and the all-ones "dead" key onto the last one
+struct LsdDigit {
+  int shift;
+  template <int BITS> __device__ __forceinline__ uint32_t get(uint64_t k) const { return (uint32_t)(k >> shift) & ((1u << BITS) - 1u); }
+};
+struct BucketDigit {
+  int s;          // k >> s fits 32 bits
+  uint32_t M;     // bucket = umulhi(k >> s, M) < BINS - 1 for k < kmax
+  template <int BITS> __device__ __forceinline__ uint32_t get(uint64_t k) const {
+    if (k == VSV_KEY_DEAD) return (1u << BITS) - 1u;
+    const uint64_t kk = k >> s;
+    const uint32_t b = __umulhi(kk > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)kk, M);
+    return b < (1u << BITS) - 2u ? b : (1u << BITS) - 2u;
+  }
+};
+
 // hist[tile * BINS + d] = number of items of this tile with digit d
-template <int BITS, int ROUNDS>
-__global__ __launch_bounds__(256) void rs_hist(const uint64_t* __restrict__ key, const uint32_t* __restrict__ d_n, int shift,
+template <int BITS, int ROUNDS, typename DIGIT>
+__global__ __launch_bounds__(256) void rs_hist(const uint64_t* __restrict__ key, const uint32_t* __restrict__ d_n, DIGIT dg,
                                                uint32_t* __restrict__ hist, uint32_t* __restrict__ totals) {
   constexpr int BINS = 1 << BITS;
   __shared__ uint32_t cnt[BINS];
@@ -46,7 +65,7 @@ __global__ __launch_bounds__(256) void rs_hist(const uint64_t* __restrict__ key,
     const uint32_t base = tile * rs_tile<ROUNDS>();
     for (int k = 0; k < (int)rs_tile<ROUNDS>() / 256; ++k) {
       const uint32_t i = base + k * 256 + threadIdx.x;
-      if (i < n) atomicAdd(&cnt[(uint32_t)(key[i] >> shift) & (BINS - 1)], 1u);
+      if (i < n) atomicAdd(&cnt[dg.template get<BITS>(key[i])], 1u);
     }
     __syncthreads();
     for (int d = threadIdx.x; d < BINS; d += 256) {
@@ -167,9 +186,9 @@ __global__ __launch_bounds__(1024) void rs_scan_mb(uint32_t* __restrict__ hist, 
   }
 }
 
-template <int BITS, int RS_ROUNDS>
+template <int BITS, int RS_ROUNDS, typename DIGIT>
 __global__ __launch_bounds__(256) void rs_scatter(const uint64_t* __restrict__ key, const uint32_t* __restrict__ val,
-                                                  const uint32_t* __restrict__ d_n, int shift,
+                                                  const uint32_t* __restrict__ d_n, DIGIT dg,
                                                   const uint32_t* __restrict__ hist, uint64_t* __restrict__ key_out,
                                                   uint32_t* __restrict__ val_out, const uint32_t* __restrict__ totals) {
   constexpr int BINS = 1 << BITS;
@@ -193,7 +212,7 @@ __global__ __launch_bounds__(256) void rs_scatter(const uint64_t* __restrict__ k
       const bool ok = i < n;
       k_[r] = ok ? key[i] : 0;
       v_[r] = ok ? val[i] : 0;
-      const uint32_t d = (uint32_t)(k_[r] >> shift) & (BINS - 1);
+      const uint32_t d = dg.template get<BITS>(k_[r]);
       const uint64_t m = match_digit<BITS>(d, ok);
       // every lane of the match group reads the counter, then the group's lowest lane bumps it;
       // LDS operations of one wave execute in order.
@@ -213,7 +232,7 @@ __global__ __launch_bounds__(256) void rs_scatter(const uint64_t* __restrict__ k
 #pragma unroll
     for (int r = 0; r < RS_ROUNDS; ++r) {
       if (rk[r] != 0xFFFFFFFFu) {
-        const uint32_t d = (uint32_t)(k_[r] >> shift) & (BINS - 1);
+        const uint32_t d = dg.template get<BITS>(k_[r]);
         const uint32_t dst = wcnt[wv][d] + rk[r];
         key_out[dst] = k_[r];
         val_out[dst] = v_[r];
@@ -228,10 +247,126 @@ void one_pass(hipStream_t st, int64_t max_n, const uint64_t* kin, const uint32_t
               uint64_t* kout, uint32_t* vout, uint32_t* totals) {
   const int64_t max_tiles = (max_n + rs_tile<ROUNDS>() - 1) / rs_tile<ROUNDS>();
   const int grid = (int)(max_tiles < 1024 ? (max_tiles < 1 ? 1 : max_tiles) : 1024);
-  rs_hist<BITS, ROUNDS><<<grid, 256, 0, st>>>(kin, d_n, shift, hist, totals);
+  const LsdDigit dg{shift};
+  rs_hist<BITS, ROUNDS, LsdDigit><<<grid, 256, 0, st>>>(kin, d_n, dg, hist, totals);
   if (totals) rs_scan_mb<BITS, ROUNDS><<<(1 << BITS) / SCAN_DG, 1024, 0, st>>>(hist, totals, d_n);
   else rs_scan<BITS, ROUNDS><<<1, 1024, 0, st>>>(hist, d_n);
-  rs_scatter<BITS, ROUNDS><<<grid, 256, 0, st>>>(kin, vin, d_n, shift, hist, kout, vout, totals);
+  rs_scatter<BITS, ROUNDS, LsdDigit><<<grid, 256, 0, st>>>(kin, vin, d_n, dg, hist, kout, vout, totals);
+}
+
+// ---- bucket sort: ONE counting pass into <= 2048 key-range buckets, then one workgroup sorts each bucket in LDS -----------
+// The signature tables of a chromosome hold 10^4-10^6 rows: an LSD sort of their 33-bit keys is 3-4 passes x 3 launches over a table
+// that fits the chip's LDS many times. Here the keys are cut into BINS - 1 contiguous key ranges by a linear (monotone) map, the
+// (stable) counting pass moves every row to its range, and a workgroup then sorts its range completely in LDS: 32-bit keys
+// relative to the range's smallest key, stable LSD passes of 8 bits over the bits that actually differ (2-3 passes), ranks from
+// wave ballots as in rs_scatter. 4 launches instead of 9-12. A range that does not fit (more than BK_CAP rows, or keys more than
+// 2^32 apart) raises ERRB_SORT_FALLBACK: the caller runs the table again through the LSD passes (same result, the usual speed).
+constexpr int BK_CAP = 4096;        // rows a workgroup sorts in LDS
+constexpr int BK_THREADS = 512;
+constexpr int BK_WAVES = BK_THREADS / 64;
+__global__ __launch_bounds__(BK_THREADS) void bk_lds_sort(const uint64_t* __restrict__ key, const uint32_t* __restrict__ val,
+                                                           const uint32_t* __restrict__ base, int nbuckets, const uint32_t* __restrict__ d_n,
+                                                           uint64_t* __restrict__ key_out, uint32_t* __restrict__ val_out, uint32_t* __restrict__ err, uint32_t cap) {
+  __shared__ uint32_t sk[2][BK_CAP], sv[2][BK_CAP];
+  __shared__ uint32_t wcnt[BK_WAVES][256];
+  __shared__ uint32_t tot[256];
+  __shared__ unsigned long long s_min, s_max;
+  const uint32_t n = *d_n;
+  const int b = blockIdx.x;
+  uint32_t lo = base[b], hi = b + 1 < nbuckets ? base[b + 1] : n;
+  if (lo > n) lo = n;
+  if (hi > n) hi = n;
+  if (hi <= lo) return;
+  const uint32_t m = hi - lo;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  if (b == nbuckets - 1 || m == 1) {                      // dead rows (all keys equal) / a single row: nothing to sort
+    for (uint32_t i = t; i < m; i += BK_THREADS) { key_out[lo + i] = key[lo + i]; val_out[lo + i] = val[lo + i]; }
+    return;
+  }
+  if (m > cap) { if (t == 0) atomicOr(err, ERRB_SORT_FALLBACK); return; }
+  if (t == 0) { s_min = ~0ull; s_max = 0ull; }
+  __syncthreads();
+  uint64_t kmin = ~0ull, kmax = 0;
+  for (uint32_t i = t; i < m; i += BK_THREADS) { const uint64_t k = key[lo + i]; kmin = k < kmin ? k : kmin; kmax = k > kmax ? k : kmax; }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    const uint64_t a = __shfl_xor(kmin, d, 64), c = __shfl_xor(kmax, d, 64);
+    kmin = a < kmin ? a : kmin; kmax = c > kmax ? c : kmax;
+  }
+  if (lane == 0) { atomicMin(&s_min, (unsigned long long)kmin); atomicMax(&s_max, (unsigned long long)kmax); }
+  __syncthreads();
+  kmin = s_min; kmax = s_max;
+  const uint64_t width = kmax - kmin;
+  if (width > 0xFFFFFFFFull) { if (t == 0) atomicOr(err, ERRB_SORT_FALLBACK); return; }
+  for (uint32_t i = t; i < m; i += BK_THREADS) { sk[0][i] = (uint32_t)(key[lo + i] - kmin); sv[0][i] = val[lo + i]; }
+  // rows of wave w: [w * per, (w + 1) * per) — wave-major chunks keep the input order inside equal digits
+  const uint32_t per = ((m + BK_WAVES - 1) / BK_WAVES + 63u) & ~63u;
+  const uint32_t c0 = min(m, (uint32_t)wv * per), c1 = min(m, c0 + per);
+  const uint64_t lt = (1ull << lane) - 1ull;
+  int src = 0;
+  for (int shift = 0; shift < 32 && (width >> shift) != 0; shift += 8) {
+    for (int d = t; d < BK_WAVES * 256; d += BK_THREADS) (&wcnt[0][0])[d] = 0;
+    __syncthreads();
+    for (uint32_t i = c0 + lane; i < c1; i += 64) atomicAdd(&wcnt[wv][(sk[src][i] >> shift) & 255u], 1u);
+    __syncthreads();
+    if (t < 256) {                                         // per-digit totals, exclusive scan over the digits, (wave, digit) bases
+      uint32_t s = 0;
+#pragma unroll
+      for (int w = 0; w < BK_WAVES; ++w) s += wcnt[w][t];
+      tot[t] = s;
+    }
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+      uint32_t v = 0;
+      if (t < 256 && t >= d) v = tot[t - d];
+      __syncthreads();
+      if (t < 256) tot[t] += v;
+      __syncthreads();
+    }
+    if (t < 256) {
+      uint32_t run = t > 0 ? tot[t - 1] : 0u;
+#pragma unroll
+      for (int w = 0; w < BK_WAVES; ++w) { const uint32_t c = wcnt[w][t]; wcnt[w][t] = run; run += c; }
+    }
+    __syncthreads();
+    for (uint32_t i0 = c0; i0 < c1; i0 += 64) {            // whole waves iterate together (c0, c1 are wave-uniform)
+      const uint32_t i = i0 + lane;
+      const bool ok = i < c1;
+      const uint32_t k = ok ? sk[src][i] : 0u, v = ok ? sv[src][i] : 0u;
+      const uint32_t d = (k >> shift) & 255u;
+      const uint64_t mm = match_digit<8>(d, ok);
+      const uint32_t old = ok ? wcnt[wv][d] : 0u;
+      __builtin_amdgcn_wave_barrier();
+      if (ok && (mm & lt) == 0) wcnt[wv][d] = old + (uint32_t)__popcll(mm);
+      __builtin_amdgcn_wave_barrier();
+      if (ok) { const uint32_t dst = old + (uint32_t)__popcll(mm & lt); sk[src ^ 1][dst] = k; sv[src ^ 1][dst] = v; }
+    }
+    __syncthreads();
+    src ^= 1;
+  }
+  for (uint32_t i = t; i < m; i += BK_THREADS) { key_out[lo + i] = kmin + sk[src][i]; val_out[lo + i] = sv[src][i]; }
+}
+
+template <int BITS, int ROUNDS>
+SortResult bucket_sort(hipStream_t st, uint64_t* key, uint32_t* val, uint64_t* key_scratch, uint32_t* val_scratch, const uint32_t* d_n,
+                       int64_t max_n, uint64_t kmax, const SortWork& w) {
+  int s = 0;
+  while ((kmax >> s) > 0xFFFFFFFFull) ++s;
+  BucketDigit dg;
+  dg.s = s;
+  dg.M = (uint32_t)((((uint64_t)((1u << BITS) - 1u)) << 32) / ((kmax >> s) + 1ull));
+  uint32_t* totals = w.totals + (size_t)(*w.pass_cursor) * 2048;
+  ++*w.pass_cursor;
+  const int64_t max_tiles = (max_n + rs_tile<ROUNDS>() - 1) / rs_tile<ROUNDS>();
+  const int grid = (int)(max_tiles < 1024 ? (max_tiles < 1 ? 1 : max_tiles) : 1024);
+  rs_hist<BITS, ROUNDS, BucketDigit><<<grid, 256, 0, st>>>(key, d_n, dg, w.hist, totals);
+  rs_scan_mb<BITS, ROUNDS><<<(1 << BITS) / SCAN_DG, 1024, 0, st>>>(w.hist, totals, d_n);
+  rs_scatter<BITS, ROUNDS, BucketDigit><<<grid, 256, 0, st>>>(key, val, d_n, dg, w.hist, key_scratch, val_scratch, totals);
+  // bucket bases = the scanned histogram row of tile 0 (offset of the first tile's rows of every bucket)
+  static const int cap_env = getenv("VSV_BK_CAP") ? atoi(getenv("VSV_BK_CAP")) : BK_CAP;      // tests force the fallback with a tiny capacity
+  const uint32_t cap = (uint32_t)(cap_env < 2 ? 2 : cap_env > BK_CAP ? BK_CAP : cap_env);
+  bk_lds_sort<<<1 << BITS, BK_THREADS, 0, st>>>(key_scratch, val_scratch, w.hist, 1 << BITS, d_n, key, val, w.err, cap);
+  return SortResult{key, val};
 }
 
 template <int ROUNDS>
@@ -265,7 +400,25 @@ SortResult sort_pairs(hipStream_t st, uint64_t* key, uint32_t* val, uint64_t* ke
 // Digit widths are chosen per sort so that the pass count is minimal with digits of at most 11 bits
 // (e.g. 33 key bits -> 3 passes of 11; 26 bits -> 3 passes of 9). SortWork::small picks the tile size (both exact).
 SortResult vsv_radix_sort_pairs(hipStream_t st, uint64_t* key, uint32_t* val, uint64_t* key_scratch, uint32_t* val_scratch,
-                                const uint32_t* d_n, int64_t max_n, int nbits, const SortWork& w) {
+                                const uint32_t* d_n, int64_t max_n, int nbits, const SortWork& w, uint64_t kmax) {
+  // bucket sort when the caller allows it (bucket_bits from the row counts of the handle's previous run), the keys of one bucket
+  // can fit 32 bits and a zeroed totals slot is left; anything else takes the LSD passes
+  if (w.bucket_bits >= 8 && w.err && w.totals && *w.pass_cursor < w.max_passes && nbits > 12 && nbits - 1 <= 63) {
+    if (kmax == 0) kmax = 1ull << (nbits - 1);      // unless the caller knows better: the top key bit is the dead flag
+    const int b = w.bucket_bits > 11 ? 11 : w.bucket_bits;
+    if ((kmax >> b) < 0xFFFFFFFFull) {
+      switch (b) {
+        case 8: return w.small_tiles ? bucket_sort<8, RS_ROUNDS_SMALL>(st, key, val, key_scratch, val_scratch, d_n, max_n, kmax, w)
+                                     : bucket_sort<8, RS_ROUNDS_BIG>(st, key, val, key_scratch, val_scratch, d_n, max_n, kmax, w);
+        case 9: return w.small_tiles ? bucket_sort<9, RS_ROUNDS_SMALL>(st, key, val, key_scratch, val_scratch, d_n, max_n, kmax, w)
+                                     : bucket_sort<9, RS_ROUNDS_BIG>(st, key, val, key_scratch, val_scratch, d_n, max_n, kmax, w);
+        case 10: return w.small_tiles ? bucket_sort<10, RS_ROUNDS_SMALL>(st, key, val, key_scratch, val_scratch, d_n, max_n, kmax, w)
+                                      : bucket_sort<10, RS_ROUNDS_BIG>(st, key, val, key_scratch, val_scratch, d_n, max_n, kmax, w);
+        default: return w.small_tiles ? bucket_sort<11, RS_ROUNDS_SMALL>(st, key, val, key_scratch, val_scratch, d_n, max_n, kmax, w)
+                                      : bucket_sort<11, RS_ROUNDS_BIG>(st, key, val, key_scratch, val_scratch, d_n, max_n, kmax, w);
+      }
+    }
+  }
   return w.small_tiles ? sort_pairs<RS_ROUNDS_SMALL>(st, key, val, key_scratch, val_scratch, d_n, max_n, nbits, w)
                  : sort_pairs<RS_ROUNDS_BIG>(st, key, val, key_scratch, val_scratch, d_n, max_n, nbits, w);
 }

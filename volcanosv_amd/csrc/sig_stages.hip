@@ -826,7 +826,8 @@ void vsv_launch_split(hipStream_t st, const RecView& rv, const vsv_params& p, in
     vsv_scan_u32_exclusive(st, blk_cnt, nblk, blk_off, scan_tmp);
     split_cand<true><<<nblk, 256, 0, st>>>(rv, c, tab, blk_off, ckey, crec, cap, vec, ctr, cmask);
     // the first result may live in the shared scratch pair, so the second sort gets a scratch pair of its own
-    const SortResult r1 = vsv_radix_sort_pairs(st, ckey, crec, sw.key_alt, sw.val_alt, &ctr->n_cand, cap, c.tid_shift + tid_bits, sw);
+    const SortResult r1 = vsv_radix_sort_pairs(st, ckey, crec, sw.key_alt, sw.val_alt, &ctr->n_cand, cap, c.tid_shift + tid_bits, sw,
+                                               1ull << (c.tid_shift + tid_bits));     // no dead keys in this table: the whole range is alive
     split_mark_pairs<<<grid, 256, 0, st>>>(r1.key, r1.val, c, rec_bits, okey, oval, ctr);
     const SortResult r2 = vsv_radix_sort_pairs(st, okey, oval, key2, idx2, &ctr->n_cand, cap, rec_bits + 1 + tid_bits + 1, sw);
     const int eg = grid * 8 < 1024 ? 1024 : (grid * 8 > 8192 ? 8192 : grid * 8);
@@ -842,7 +843,7 @@ const uint64_t* vsv_launch_sort_stage(hipStream_t st, const vsv_sig* in, const u
                                       vsv_sig* sorted, uint32_t* d_alive, const StageBufs& b, const SortWork& sw, int64_t cap,
                                       Counters* ctr) {
   build_keys<<<b.grid, 256, 0, st>>>(in, d_n, stage, pb, b.tid_lo, b.tid_bits, b.key, b.idx, ctr);
-  const SortResult r = vsv_radix_sort_pairs(st, b.key, b.idx, sw.key_alt, sw.val_alt, d_n, cap, nbits, sw);
+  const SortResult r = vsv_radix_sort_pairs(st, b.key, b.idx, sw.key_alt, sw.val_alt, d_n, cap, nbits, sw, stage == 5 ? 0 : b.kmax);
   gather_rows<vsv_sig><<<b.grid, 256, 0, st>>>(in, r.val, r.key, d_n, sorted, d_alive, &ctr->n_long);
   return r.key;
 }
@@ -862,6 +863,6 @@ void vsv_launch_pair(hipStream_t st, const vsv_sig* merged, const uint64_t* merg
   pair_long_kernel<<<LONG_GRID, 256, 0, st>>>(merged, merged_key, d_alive3, pair_shift, right, pb, b.cl, calls_tmp, key2, &ctr->n_long);
   pair_finish<<<b.grid, 256, 0, st>>>(merged, d_alive3, b.cl, calls_tmp);
   build_call_keys<<<b.grid, 256, 0, st>>>(calls_tmp, d_alive3, pb, b.tid_lo, key2, idx2);
-  const SortResult r = vsv_radix_sort_pairs(st, key2, idx2, sw.key_alt, sw.val_alt, d_alive3, cap, nbits, sw);
+  const SortResult r = vsv_radix_sort_pairs(st, key2, idx2, sw.key_alt, sw.val_alt, d_alive3, cap, nbits, sw, b.kmax);
   gather_rows<vsv_call><<<b.grid, 256, 0, st>>>(calls_tmp, r.val, r.key, d_alive3, calls, d_ncalls, &ctr->n_long);
 }

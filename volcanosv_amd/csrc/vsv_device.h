@@ -17,6 +17,7 @@ enum : uint32_t {
   ERRB_ZERODIV = 1u << 4,
   ERRB_CAPACITY = 1u << 5,
   ERRB_RANGE = 1u << 6,  // a 64-record batch spans >= 2^31 CIGAR ops
+  ERRB_SORT_FALLBACK = 1u << 7,  // a bucket of the bucket sort did not fit in LDS: the run is repeated with the LSD passes
 };
 
 // One cache line of device counters, zeroed at the start of every run.
@@ -101,12 +102,15 @@ struct SortWork {       // scratch for vsv_radix_sort_pairs
   int* pass_cursor;     // host-side index of the next free totals slot (reset per run)
   int max_passes;
   bool small_tiles;     // 1024-row instead of 4096-row tiles; chosen by the caller from the row count of the previous run (both exact)
+  int bucket_bits;      // 8..11: bucket sort (one counting pass + LDS sort per bucket) with 2^bits buckets; 0: LSD passes only
+  uint32_t* err;        // device error word (ERRB_SORT_FALLBACK)
 };
 struct StageBufs {
   uint64_t* key;        // sort keys of the current stage (kept sorted for cluster / pair kernels)
   uint32_t* idx;
   int32_t* cl;          // cluster ids / pairing state
   int tid_lo, tid_bits; // keys carry tid - tid_lo on tid_bits bits
+  uint64_t kmax;        // exclusive upper bound of the alive stage keys (0 = unknown): balances the bucket sort
   int grid;             // blocks of the row-parallel kernels (sized from the row counts of the handle's previous run; the kernels grid-stride)
 };
 
@@ -114,7 +118,7 @@ struct StageBufs {
 // whichever of the two buffer pairs the last pass wrote (returned); nothing is copied back.
 struct SortResult { uint64_t* key; uint32_t* val; };
 SortResult vsv_radix_sort_pairs(hipStream_t st, uint64_t* key, uint32_t* val, uint64_t* key_scratch, uint32_t* val_scratch,
-                                const uint32_t* d_n, int64_t max_n, int nbits, const SortWork& w);
+                                const uint32_t* d_n, int64_t max_n, int nbits, const SortWork& w, uint64_t kmax = 0);
 int64_t vsv_radix_hist_entries(int64_t max_n);
 
 // cigar_scan.hip
