@@ -201,14 +201,15 @@ SortWork sort_work(vsv_handle* h) {
   w.totals = (uint32_t*)h->totals.p; w.pass_cursor = &h->pass_cursor; w.max_passes = MAX_SORT_PASSES; w.small_tiles = h->small_sort_tiles;
   static const char* force = getenv("VSV_SORT_TILE");   // timing experiments: "big" / "small"
   if (force) w.small_tiles = force[0] == 's';
-  // bucket sort: ~256-512 rows per occupied bucket (about half of the key range is populated) for the largest table of the
-  // previous run; tables beyond ~4 M rows, a handle whose last bucket sort overflowed, and VSV_SORT=lsd take the LSD passes
+  // bucket sort: the fewest buckets (256..2048) that keep the largest table of the previous run at <= 640 rows per bucket, i.e.
+  // ~1300 per occupied one with half of the key range populated (a workgroup sorts up to 4096); tables beyond ~1.3 M rows, a
+  // handle whose last bucket sort overflowed, and VSV_SORT=lsd take the LSD passes
   static const char* mode = getenv("VSV_SORT");
   const Counters& c = h->host_ctr;
   const uint64_t rows = c.n_s1 > c.n_cand ? c.n_s1 : c.n_cand;
   int bb = 8;
-  while (bb < 11 && (rows >> bb) > 256) ++bb;
-  w.bucket_bits = (h->lsd_runs > 0 || (mode && mode[0] == 'l') || rows > (4u << 20)) ? 0 : bb;
+  while (bb < 11 && (rows >> bb) > 640) ++bb;
+  w.bucket_bits = (h->lsd_runs > 0 || (mode && mode[0] == 'l') || (rows >> 11) > 640) ? 0 : bb;
   w.err = h->ctr.p ? &((Counters*)h->ctr.p)->err : nullptr;
   return w;
 }

@@ -264,30 +264,55 @@ void one_pass(hipStream_t st, int64_t max_n, const uint64_t* kin, const uint32_t
 constexpr int BK_CAP = 4096;        // rows a workgroup sorts in LDS
 constexpr int BK_THREADS = 512;
 constexpr int BK_WAVES = BK_THREADS / 64;
+constexpr int BK_PER = BK_CAP / BK_THREADS;   // rows a thread holds while the bucket is loaded
+constexpr int BK_DBITS = 9;         // widest digit of the in-LDS passes
+__device__ __forceinline__ uint64_t match_digit_rt(uint32_t d, bool valid, int bits) {
+  uint64_t m = __ballot(valid);
+  for (int b = 0; b < bits; ++b) {
+    const uint64_t bal = __ballot((d >> b) & 1u);
+    m &= ((d >> b) & 1u) ? bal : ~bal;
+  }
+  return m;
+}
 __global__ __launch_bounds__(BK_THREADS) void bk_lds_sort(const uint64_t* __restrict__ key, const uint32_t* __restrict__ val,
                                                            const uint32_t* __restrict__ base, int nbuckets, const uint32_t* __restrict__ d_n,
                                                            uint64_t* __restrict__ key_out, uint32_t* __restrict__ val_out, uint32_t* __restrict__ err, uint32_t cap) {
   __shared__ uint32_t sk[2][BK_CAP], sv[2][BK_CAP];
-  __shared__ uint32_t wcnt[BK_WAVES][256];
-  __shared__ uint32_t tot[256];
+  __shared__ uint32_t wcnt[BK_WAVES][1 << BK_DBITS];
+  __shared__ uint32_t tot[BK_WAVES];
   __shared__ unsigned long long s_min, s_max;
   const uint32_t n = *d_n;
   const int b = blockIdx.x;
-  uint32_t lo = base[b], hi = b + 1 < nbuckets ? base[b + 1] : n;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  {  // the last bucket holds the dead rows (all keys equal, nothing to sort): every workgroup moves a slice of it
+    uint32_t dlo = base[nbuckets - 1];
+    if (dlo > n) dlo = n;
+    const uint32_t dm = n - dlo, per = (dm + gridDim.x - 1) / gridDim.x;
+    const uint32_t a = dlo + min(dm, (uint32_t)b * per), e = dlo + min(dm, (uint32_t)(b + 1) * per);
+    for (uint32_t i = a + t; i < e; i += BK_THREADS) { key_out[i] = VSV_KEY_DEAD; val_out[i] = val[i]; }
+  }
+  if (b == nbuckets - 1) return;
+  uint32_t lo = base[b], hi = base[b + 1];
   if (lo > n) lo = n;
   if (hi > n) hi = n;
   if (hi <= lo) return;
   const uint32_t m = hi - lo;
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  if (b == nbuckets - 1 || m == 1) {                      // dead rows (all keys equal) / a single row: nothing to sort
-    for (uint32_t i = t; i < m; i += BK_THREADS) { key_out[lo + i] = key[lo + i]; val_out[lo + i] = val[lo + i]; }
-    return;
-  }
   if (m > cap) { if (t == 0) atomicOr(err, ERRB_SORT_FALLBACK); return; }
   if (t == 0) { s_min = ~0ull; s_max = 0ull; }
   __syncthreads();
+  uint64_t kr[BK_PER];
+  uint32_t vr[BK_PER];
   uint64_t kmin = ~0ull, kmax = 0;
-  for (uint32_t i = t; i < m; i += BK_THREADS) { const uint64_t k = key[lo + i]; kmin = k < kmin ? k : kmin; kmax = k > kmax ? k : kmax; }
+#pragma unroll
+  for (int j = 0; j < BK_PER; ++j) {
+    const uint32_t i = (uint32_t)t + (uint32_t)j * BK_THREADS;
+    kr[j] = i < m ? key[lo + i] : 0ull;
+    vr[j] = i < m ? val[lo + i] : 0u;
+  }
+#pragma unroll
+  for (int j = 0; j < BK_PER; ++j) {
+    if ((uint32_t)t + (uint32_t)j * BK_THREADS < m) { kmin = kr[j] < kmin ? kr[j] : kmin; kmax = kr[j] > kmax ? kr[j] : kmax; }
+  }
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) {
     const uint64_t a = __shfl_xor(kmin, d, 64), c = __shfl_xor(kmax, d, 64);
@@ -298,33 +323,42 @@ __global__ __launch_bounds__(BK_THREADS) void bk_lds_sort(const uint64_t* __rest
   kmin = s_min; kmax = s_max;
   const uint64_t width = kmax - kmin;
   if (width > 0xFFFFFFFFull) { if (t == 0) atomicOr(err, ERRB_SORT_FALLBACK); return; }
-  for (uint32_t i = t; i < m; i += BK_THREADS) { sk[0][i] = (uint32_t)(key[lo + i] - kmin); sv[0][i] = val[lo + i]; }
+  if (m == 1 || width == 0) {                            // one row, or all keys equal: already in order
+#pragma unroll
+    for (int j = 0; j < BK_PER; ++j) { const uint32_t i = (uint32_t)t + (uint32_t)j * BK_THREADS; if (i < m) { key_out[lo + i] = kr[j]; val_out[lo + i] = vr[j]; } }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < BK_PER; ++j) { const uint32_t i = (uint32_t)t + (uint32_t)j * BK_THREADS; if (i < m) { sk[0][i] = (uint32_t)(kr[j] - kmin); sv[0][i] = vr[j]; } }
+  // stable LSD passes over the bits that differ inside the bucket, digits as equal as possible and at most BK_DBITS wide
+  const int wbits = 64 - __builtin_clzll(width);
+  const int passes = (wbits + BK_DBITS - 1) / BK_DBITS;
+  const int db = (wbits + passes - 1) / passes;
+  const uint32_t dmask = (1u << db) - 1u, nbins = 1u << db;
   // rows of wave w: [w * per, (w + 1) * per) — wave-major chunks keep the input order inside equal digits
   const uint32_t per = ((m + BK_WAVES - 1) / BK_WAVES + 63u) & ~63u;
   const uint32_t c0 = min(m, (uint32_t)wv * per), c1 = min(m, c0 + per);
   const uint64_t lt = (1ull << lane) - 1ull;
   int src = 0;
-  for (int shift = 0; shift < 32 && (width >> shift) != 0; shift += 8) {
-    for (int d = t; d < BK_WAVES * 256; d += BK_THREADS) (&wcnt[0][0])[d] = 0;
+  for (int pass = 0, shift = 0; pass < passes; ++pass, shift += db) {
+    for (uint32_t d = t; d < BK_WAVES * nbins; d += BK_THREADS) wcnt[d / nbins][d % nbins] = 0;
     __syncthreads();
-    for (uint32_t i = c0 + lane; i < c1; i += 64) atomicAdd(&wcnt[wv][(sk[src][i] >> shift) & 255u], 1u);
+    for (uint32_t i = c0 + lane; i < c1; i += 64) atomicAdd(&wcnt[wv][(sk[src][i] >> shift) & dmask], 1u);
     __syncthreads();
-    if (t < 256) {                                         // per-digit totals, exclusive scan over the digits, (wave, digit) bases
-      uint32_t s = 0;
+    // per-digit totals -> exclusive scan over the digits (thread t owns digit t: in-wave shuffle scan + wave sums) -> (wave, digit) bases
+    uint32_t mine = 0, incl = 0;
+    if ((uint32_t)t < nbins) {
 #pragma unroll
-      for (int w = 0; w < BK_WAVES; ++w) s += wcnt[w][t];
-      tot[t] = s;
+      for (int w = 0; w < BK_WAVES; ++w) mine += wcnt[w][t];
     }
+    incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += o; }
+    if (lane == 63) tot[wv] = incl;
     __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {
-      uint32_t v = 0;
-      if (t < 256 && t >= d) v = tot[t - d];
-      __syncthreads();
-      if (t < 256) tot[t] += v;
-      __syncthreads();
-    }
-    if (t < 256) {
-      uint32_t run = t > 0 ? tot[t - 1] : 0u;
+    if ((uint32_t)t < nbins) {
+      uint32_t run = incl - mine;
+      for (int w = 0; w < wv; ++w) run += tot[w];
 #pragma unroll
       for (int w = 0; w < BK_WAVES; ++w) { const uint32_t c = wcnt[w][t]; wcnt[w][t] = run; run += c; }
     }
@@ -333,8 +367,8 @@ __global__ __launch_bounds__(BK_THREADS) void bk_lds_sort(const uint64_t* __rest
       const uint32_t i = i0 + lane;
       const bool ok = i < c1;
       const uint32_t k = ok ? sk[src][i] : 0u, v = ok ? sv[src][i] : 0u;
-      const uint32_t d = (k >> shift) & 255u;
-      const uint64_t mm = match_digit<8>(d, ok);
+      const uint32_t d = (k >> shift) & dmask;
+      const uint64_t mm = match_digit_rt(d, ok, db);
       const uint32_t old = ok ? wcnt[wv][d] : 0u;
       __builtin_amdgcn_wave_barrier();
       if (ok && (mm & lt) == 0) wcnt[wv][d] = old + (uint32_t)__popcll(mm);
