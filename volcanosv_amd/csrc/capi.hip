@@ -49,7 +49,9 @@ struct vsv_handle {
   DevBuf pool, pool_key, raw0, s1in, s1s, c1, s2s, c2, merged, calls_tmp, calls, reads;
   DevBuf tab, blk_cnt, blk_off, ckey, crec, okey, oval;
   DevBuf key, idx, cl, key2, idx2, key_alt, val_alt, hist;
-  DevBuf ctr, shard_cnt, totals;
+  DevBuf ctr, shard_cnt, totals;   // views into `arena`
+  DevBuf arena;                    // Counters | emit-pool cursors | part-count tile sums | sort digit totals: zeroed by ONE fill per run
+  uint32_t* tile_cnt = nullptr;
   DevBuf j_cpos, j_clen, j_spos, j_slen, j_send, j_out, j_err;
   DevBuf z_comp, z_coff, z_ooff, z_out, z_stat;          // BGZF inflate
   DevBuf p_spec, p_cnt, p_land, p_base, p_recoff, p_pos, p_tid, p_mapq, p_flag, p_lseq, p_sflag, p_ncig, p_cgsrc, p_hash, p_keep, p_kidx,
@@ -214,9 +216,10 @@ SortWork sort_work(vsv_handle* h) {
   return w;
 }
 // zero the device counters and the per-pass sort totals: start of every run
+constexpr size_t ARENA_CTR = 256, ARENA_SHARD = 256 * 16 * sizeof(uint32_t), ARENA_TILES = 4096 * sizeof(uint32_t),
+                 ARENA_TOTALS = (size_t)MAX_SORT_PASSES * 2048 * sizeof(uint32_t), ARENA_BYTES = ARENA_CTR + ARENA_SHARD + ARENA_TILES + ARENA_TOTALS;
 int reset_run_state(vsv_handle* h) {
-  HIPCHK(h, hipMemsetAsync(h->ctr.p, 0, sizeof(Counters), h->stream));
-  if (h->totals.p) HIPCHK(h, hipMemsetAsync(h->totals.p, 0, (size_t)MAX_SORT_PASSES * 2048 * sizeof(uint32_t), h->stream));
+  HIPCHK(h, hipMemsetAsync(h->arena.p, 0, ARENA_BYTES, h->stream));
   h->pass_cursor = 0;
   return 0;
 }
@@ -259,7 +262,7 @@ int enq_scan(vsv_handle* h) {
   vsv_launch_cigar_scan(st, srv, h->prm, (uint32_t*)h->part_rb.p, n_parts, OPS_PER_PART, (vsv_sig*)h->pool.p,
                         (uint64_t*)h->pool_key.p, (uint32_t)h->cap_sigs, (uint32_t*)h->part_count.p, (uint32_t*)h->part_off.p,
                         (uint32_t*)h->scan_tmp.p, (vsv_sig*)h->raw0.p, dctr(h), (uint32_t*)h->shard_cnt.p, h->ev0, h->ev1,
-                        LongScanBufs{h->l_agg.p, (uint32_t*)h->l_carry_r.p, (uint32_t*)h->l_carry_q.p, h->l_tiles.p});
+                        LongScanBufs{h->l_agg.p, (uint32_t*)h->l_carry_r.p, (uint32_t*)h->l_carry_q.p, h->l_tiles.p, h->tile_cnt, 4096, true});
   h->have_scan_ev = n_parts > 0;
   vsv_launch_fold(st, (const vsv_sig*)h->raw0.p, (vsv_sig*)h->s1in.p, h->rv, h->prm, dctr(h), ew_grid(h));
   HIPCHK(h, hipGetLastError());
@@ -305,7 +308,7 @@ int enq_merge(vsv_handle* h) {
                         sort_work(h), h->cap_sigs, dctr(h));
   vsv_launch_cluster(st, (vsv_sig*)h->s2s.p, h->sorted_key, &c->n_alive2, h->prm.cluster_shift, pos_bits(h), (vsv_sig*)h->c2.p, stage_bufs(h), (uint64_t*)h->key2.p, dctr(h));
   h->sorted_key = vsv_launch_sort_stage(st, (vsv_sig*)h->c2.p, &c->n_alive2, 3, pos_bits(h), key_bits(h), (vsv_sig*)h->merged.p, &c->n_alive3, stage_bufs(h),
-                        sort_work(h), h->cap_sigs, dctr(h));
+                        sort_work(h), h->cap_sigs, dctr(h), (int32_t*)h->cl.p);     // + pairing state of vsv_launch_pair = -1
   HIPCHK(h, hipGetLastError());
   h->stage_done = 4;
   return 0;
@@ -443,9 +446,14 @@ int vsv_create(int device_id, void* hip_stream, vsv_handle** out) {
   h->device = device_id;
   h->stream = (hipStream_t)hip_stream;
   if (hipSetDevice(device_id) != hipSuccess) { delete h; return VSV_E_NO_DEVICE; }
-  if (hipMalloc(&h->ctr.p, 256) != hipSuccess) { delete h; return VSV_E_HIP; }
-  h->ctr.bytes = 256;
-  if (hipHostMalloc((void**)&h->pinned, sizeof(Counters)) != hipSuccess) { hipFree(h->ctr.p); delete h; return VSV_E_HIP; }
+  if (hipMalloc(&h->arena.p, ARENA_BYTES) != hipSuccess) { delete h; return VSV_E_HIP; }
+  h->arena.bytes = ARENA_BYTES;
+  char* ar = (char*)h->arena.p;
+  h->ctr.p = ar; h->ctr.bytes = ARENA_CTR;
+  h->shard_cnt.p = ar + ARENA_CTR; h->shard_cnt.bytes = ARENA_SHARD;
+  h->tile_cnt = (uint32_t*)(ar + ARENA_CTR + ARENA_SHARD);
+  h->totals.p = ar + ARENA_CTR + ARENA_SHARD + ARENA_TILES; h->totals.bytes = ARENA_TOTALS;
+  if (hipHostMalloc((void**)&h->pinned, sizeof(Counters)) != hipSuccess) { hipFree(h->arena.p); delete h; return VSV_E_HIP; }
   hipEventCreate(&h->ev0);
   hipEventCreate(&h->ev1);
   memset(&h->host_ctr, 0, sizeof h->host_ctr);
@@ -460,7 +468,7 @@ void vsv_destroy(vsv_handle* h) {
   DevBuf* bufs[] = {&h->r_pos, &h->r_tid, &h->r_qid, &h->r_off, &h->r_mapq, &h->r_flag, &h->r_cigar, &h->part_rb, &h->part_count,
                     &h->part_off, &h->scan_tmp, &h->l_agg, &h->l_carry_r, &h->l_carry_q, &h->l_tiles, &h->z_crctab, &h->z_crc, &h->pool, &h->pool_key, &h->raw0, &h->s1in, &h->s1s, &h->c1, &h->s2s, &h->c2,
                     &h->merged, &h->calls_tmp, &h->calls, &h->reads, &h->tab, &h->blk_cnt, &h->blk_off, &h->ckey, &h->crec,
-                    &h->okey, &h->oval, &h->key, &h->idx, &h->cl, &h->key2, &h->idx2, &h->key_alt, &h->val_alt, &h->hist, &h->ctr, &h->shard_cnt, &h->totals, &h->g_off, &h->g_qs, &h->g_qe, &h->g_rid, &h->g_rs,
+                    &h->okey, &h->oval, &h->key, &h->idx, &h->cl, &h->key2, &h->idx2, &h->key_alt, &h->val_alt, &h->hist, &h->arena, &h->g_off, &h->g_qs, &h->g_qe, &h->g_rid, &h->g_rs,
                     &h->g_re, &h->g_rev, &h->g_hap, &h->g_len, &h->g_rank, &h->j_cpos, &h->j_clen, &h->j_spos, &h->j_slen, &h->j_send, &h->j_out, &h->j_err, &h->z_comp, &h->z_coff, &h->z_ooff, &h->z_out, &h->z_stat, &h->p_spec, &h->p_cnt, &h->p_land, &h->p_base, &h->p_recoff, &h->p_pos, &h->p_tid,
                     &h->p_mapq, &h->p_flag, &h->p_lseq, &h->p_sflag, &h->p_ncig, &h->p_cgsrc, &h->p_hash, &h->p_keep, &h->p_kidx, &h->p_cigoff, &h->p_sums,
                     &h->p_tot, &h->p_err, &h->o_pos, &h->o_tid, &h->o_qid, &h->o_cigoff, &h->o_mapq, &h->o_flag, &h->o_cigar, &h->o_lseq, &h->o_sflag,

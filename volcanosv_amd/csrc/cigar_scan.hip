@@ -74,17 +74,29 @@ __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t lane) {
 // ---- K0: part boundaries -----------------------------------------------------------------------
 // rb[p] = first record whose start offset >= p*ops_per_part; rb[n_parts] = n_records.
 __global__ void partition_kernel(const uint64_t* __restrict__ cigar_off, int64_t n_records, uint32_t* __restrict__ rb,
-                                 int n_parts, int ops_per_part) {
+                                 int n_parts, int ops_per_part, int64_t n_ops) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p > n_parts) return;
   if (p == n_parts) { rb[p] = (uint32_t)n_records; return; }
-  uint64_t target = (uint64_t)p * (uint64_t)ops_per_part;
-  int64_t lo = 0, hi = n_records;  // first r in [0,n] with cigar_off[r] >= target
-  while (lo < hi) {
-    int64_t mid = (lo + hi) >> 1;
-    if (cigar_off[mid] >= target) hi = mid; else lo = mid + 1;
+  const uint64_t target = (uint64_t)p * (uint64_t)ops_per_part;
+  // first r in [0, n] with cigar_off[r] >= target. Interpolated guess (records are about equally long), a galloping bracket around
+  // it, then the bisection: ~12 dependent loads instead of log2(n) = 23 on a 10 M-record shard. Invariant: cigar_off[lo] < target
+  // (or lo = -1) and cigar_off[hi] >= target (or hi = n); whatever the offsets are, the result lies in [0, n].
+  int64_t g = n_ops > 0 ? (int64_t)((double)target / (double)n_ops * (double)n_records) : 0;
+  g = g < 0 ? 0 : g > n_records ? n_records : g;
+  int64_t lo, hi;
+  if (cigar_off[g] >= target) {
+    hi = g; lo = g;
+    for (int64_t step = 64; ; step *= 8) { lo = hi - step; if (lo < 0) { lo = -1; break; } if (cigar_off[lo] < target) break; hi = lo; }
+  } else {
+    lo = g; hi = g;
+    for (int64_t step = 64; ; step *= 8) { hi = lo + step; if (hi >= n_records) { hi = n_records; break; } if (cigar_off[hi] >= target) break; lo = hi; }
   }
-  rb[p] = (uint32_t)lo;
+  while (hi - lo > 1) {
+    const int64_t mid = lo + ((hi - lo) >> 1);
+    if (cigar_off[mid] >= target) hi = mid; else lo = mid;
+  }
+  rb[p] = (uint32_t)hi;
 }
 
 // Emit pool = K1_SHARDS independent sub-pools (cursor s on its own 64-byte line). A single cursor word saturates at
@@ -130,7 +142,7 @@ constexpr int K1_WAVES = 4;
 template <int CLS, int DEPTH>
 __global__ __launch_bounds__(256) void cigar_scan_emit(RecView rv, const uint32_t* __restrict__ rb, int n_parts,
                                                         int min_svlen, int min_mapq, EmitCtx ec,
-                                                        uint32_t* __restrict__ part_count, int ablate) {
+                                                        uint32_t* __restrict__ part_count, int ablate, uint32_t* __restrict__ tile_sum) {
   using T = OpTab<CLS>;
   __shared__ uint32_t sh_off[K1_WAVES][K1_RMAX + 1];
   const int lane = threadIdx.x & 63;
@@ -426,6 +438,9 @@ __global__ __launch_bounds__(256) void cigar_scan_emit(RecView rv, const uint32_
   // every record start of the part goes through stage() once: an empty CIGAR must raise (H:63 IndexError)
   while (!bad && tbase + n_tab < r1) stage(tbase + n_tab);
   release_left();
+  // (per-tile sums of these counts through atomics were tried: the parts of a tile finish together, so ~2000 adds queue up on
+  // one word at a time and the scan took 540 instead of 250 us)
+  (void)tile_sum;
   if (lane == 0) part_count[part] = ord;
 }
 
@@ -878,6 +893,34 @@ __global__ __launch_bounds__(256) void scan_tile_apply(const uint32_t* __restric
   for (int k = 0; k < 8; ++k) { if (base + k < n) out[base + k] = run; run += v[k]; }
 }
 
+// second half of a two-launch exclusive scan: the tile sums exist (scan_tile_sums); every block adds up the sums in front of its
+// own tile itself (a few dozen to a few thousand words from L2) instead of waiting for a single-block scan of them
+__global__ __launch_bounds__(256) void scan_tile_apply_sums(const uint32_t* __restrict__ in, int n, const uint32_t* __restrict__ tile_sum,
+                                                            uint32_t* __restrict__ out) {
+  __shared__ uint32_t sh[256];
+  __shared__ uint32_t s_before;
+  uint32_t before = 0;
+  for (int j = threadIdx.x; j < (int)blockIdx.x; j += 256) before += tile_sum[j];
+  sh[threadIdx.x] = before;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) { if ((int)threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d]; __syncthreads(); }
+  if (threadIdx.x == 0) s_before = sh[0];
+  __syncthreads();
+  const int base = blockIdx.x * SCAN_TILE + threadIdx.x * 8;
+  uint32_t v[8], s = 0;
+  for (int k = 0; k < 8; ++k) { v[k] = (base + k < n) ? in[base + k] : 0; s += v[k]; }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    uint32_t t = (int)threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
+    __syncthreads();
+    sh[threadIdx.x] += t;
+    __syncthreads();
+  }
+  uint32_t run = s_before + sh[threadIdx.x] - s;
+  for (int k = 0; k < 8; ++k) { if (base + k < n) out[base + k] = run; run += v[k]; }
+}
+
 // ---- ordered placement: raw[part_off[part] + ordinal] = pool row; one block per shard --------------
 __global__ __launch_bounds__(256) void place_raw(const vsv_sig* __restrict__ pool, const uint64_t* __restrict__ pool_key,
                                                  const uint32_t* __restrict__ shard_cnt, uint32_t shard_cap,
@@ -962,19 +1005,21 @@ void vsv_launch_cigar_scan(hipStream_t st, const RecView& rv, const vsv_params& 
   if (n_parts <= 0) return;
   const bool long_mode = vsv_scan_is_long(rv, p);
   if (long_mode) { n_parts = vsv_cigar_parts_long(rv.n_ops); ops_per_part = K1L_PART; }
-  (void)hipMemsetAsync(shard_cnt, 0, K1_SHARDS * 16 * sizeof(uint32_t), st);
-  partition_kernel<<<(n_parts + 1 + 255) / 256, 256, 0, st>>>(rv.cigar_off, rv.n_records, part_rb, n_parts, ops_per_part);
+  if (!lb.arena_zeroed) (void)hipMemsetAsync(shard_cnt, 0, K1_SHARDS * 16 * sizeof(uint32_t), st);
+  partition_kernel<<<(n_parts + 1 + 255) / 256, 256, 0, st>>>(rv.cigar_off, rv.n_records, part_rb, n_parts, ops_per_part, rv.n_ops);
   EmitCtx ec{pool, pool_key, shard_cnt, cap / K1_SHARDS, ctr};
   const int waves_per_block = 4;
   const int grid = (n_parts + waves_per_block - 1) / waves_per_block;
   if (ev0) (void)hipEventRecord(ev0, st);
   static const int ablate = getenv("VSV_K1_ABLATE") ? atoi(getenv("VSV_K1_ABLATE")) : 0;  // timing experiments only
   static const int depth = getenv("VSV_K1_DEPTH") ? atoi(getenv("VSV_K1_DEPTH")) : 4;     // chunks in flight per wave (3 or 4)
+  const int n_tiles = (n_parts + SCAN_TILE - 1) / SCAN_TILE;
+  uint32_t* tsum = nullptr;
 #define K1_LAUNCH(CLS)                                                                                                          \
   do {                                                                                                                          \
     if (long_mode) cigar_scan_long<CLS><<<grid, 256, 0, st>>>(rv, part_rb, n_parts, p.min_svlen, p.min_cigar_mapq, ec, part_count, (PartAgg*)lb.agg, ablate); \
-    else if (depth == 4) cigar_scan_emit<CLS, 4><<<grid, 256, 0, st>>>(rv, part_rb, n_parts, p.min_svlen, p.min_cigar_mapq, ec, part_count, ablate); \
-    else cigar_scan_emit<CLS, 3><<<grid, 256, 0, st>>>(rv, part_rb, n_parts, p.min_svlen, p.min_cigar_mapq, ec, part_count, ablate);            \
+    else if (depth == 4) cigar_scan_emit<CLS, 4><<<grid, 256, 0, st>>>(rv, part_rb, n_parts, p.min_svlen, p.min_cigar_mapq, ec, part_count, ablate, tsum); \
+    else cigar_scan_emit<CLS, 3><<<grid, 256, 0, st>>>(rv, part_rb, n_parts, p.min_svlen, p.min_cigar_mapq, ec, part_count, ablate, tsum);            \
   } while (0)
   if (p.dtype == VSV_DTYPE_READS) K1_LAUNCH(1);
   else if (p.dtype == VSV_DTYPE_SVIM) K1_LAUNCH(2);
@@ -988,6 +1033,9 @@ void vsv_launch_cigar_scan(hipStream_t st, const RecView& rv, const vsv_params& 
     k1l_scan_tiles<<<tiles, 256, 0, st>>>((const PartAgg*)lb.agg, part_count, n_parts, (CarryItem*)lb.tile_sum);
     k1l_scan_tile_sums<<<1, 256, 0, st>>>((CarryItem*)lb.tile_sum, tiles);
     k1l_scan_apply<<<tiles, 256, 0, st>>>((const PartAgg*)lb.agg, part_count, n_parts, (const CarryItem*)lb.tile_sum, part_off, lb.carry_r, lb.carry_q);
+  } else if (n_parts > 8192 && n_tiles <= 16384) {
+    scan_tile_sums<<<n_tiles, 256, 0, st>>>(part_count, n_parts, scan_tmp);
+    scan_tile_apply_sums<<<n_tiles, 256, 0, st>>>(part_count, n_parts, scan_tmp, part_off);
   } else {
     vsv_scan_u32_exclusive(st, part_count, n_parts, part_off, scan_tmp);
   }

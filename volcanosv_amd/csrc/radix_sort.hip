@@ -130,16 +130,18 @@ __global__ __launch_bounds__(1024) void rs_scan(uint32_t* __restrict__ hist, con
 // (g, d) sums digit d over its tile group, the group sums are exchanged through LDS, and a second sweep over the same
 // (L2-hot) column entries writes the offsets. The sequential depth is ntiles / SCAN_TG loads in batches of 16; the
 // single-group version was the slowest kernel of a pass once the tiles became small (~100 tiles: 14 us -> see DESIGN).
-constexpr int SCAN_DG = 128, SCAN_TG = 8;
-template <int BITS, int ROUNDS>
+// SCAN_DG digits x SCAN_TG tile groups = 1024 threads: 128 x 8 for the 11-bit LSD passes; the bucket pass (256-2048 buckets over
+// a few hundred small tiles) takes 32 x 32, i.e. four times the blocks and a quarter of the sequential tile walk per thread.
+template <int BITS, int ROUNDS, int SCAN_DG, int SCAN_TG>
 __global__ __launch_bounds__(1024) void rs_scan_mb(uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals,
                                                    const uint32_t* __restrict__ d_n) {
+  static_assert(SCAN_DG * SCAN_TG == 1024, "one thread per (digit, tile group)");
   constexpr int BINS = 1 << BITS;
   __shared__ uint32_t red[1024];
   __shared__ uint32_t dig[SCAN_DG];
   __shared__ uint32_t part[SCAN_TG][SCAN_DG];
   const uint32_t ntiles = n_tiles_of<ROUNDS>(*d_n);
-  const int t = threadIdx.x, dl = t & (SCAN_DG - 1), g = t >> 7;
+  const int t = threadIdx.x, dl = t & (SCAN_DG - 1), g = t / SCAN_DG;
   const int d0 = blockIdx.x * SCAN_DG, d = d0 + dl;
   uint32_t before = 0;
   for (int i = t; i < d0; i += 1024) before += totals[i];
@@ -249,7 +251,7 @@ void one_pass(hipStream_t st, int64_t max_n, const uint64_t* kin, const uint32_t
   const int grid = (int)(max_tiles < 1024 ? (max_tiles < 1 ? 1 : max_tiles) : 1024);
   const LsdDigit dg{shift};
   rs_hist<BITS, ROUNDS, LsdDigit><<<grid, 256, 0, st>>>(kin, d_n, dg, hist, totals);
-  if (totals) rs_scan_mb<BITS, ROUNDS><<<(1 << BITS) / SCAN_DG, 1024, 0, st>>>(hist, totals, d_n);
+  if (totals) rs_scan_mb<BITS, ROUNDS, 128, 8><<<(1 << BITS) / 128, 1024, 0, st>>>(hist, totals, d_n);
   else rs_scan<BITS, ROUNDS><<<1, 1024, 0, st>>>(hist, d_n);
   rs_scatter<BITS, ROUNDS, LsdDigit><<<grid, 256, 0, st>>>(kin, vin, d_n, dg, hist, kout, vout, totals);
 }
@@ -394,7 +396,7 @@ SortResult bucket_sort(hipStream_t st, uint64_t* key, uint32_t* val, uint64_t* k
   const int64_t max_tiles = (max_n + rs_tile<ROUNDS>() - 1) / rs_tile<ROUNDS>();
   const int grid = (int)(max_tiles < 1024 ? (max_tiles < 1 ? 1 : max_tiles) : 1024);
   rs_hist<BITS, ROUNDS, BucketDigit><<<grid, 256, 0, st>>>(key, d_n, dg, w.hist, totals);
-  rs_scan_mb<BITS, ROUNDS><<<(1 << BITS) / SCAN_DG, 1024, 0, st>>>(w.hist, totals, d_n);
+  rs_scan_mb<BITS, ROUNDS, 32, 32><<<(1 << BITS) / 32, 1024, 0, st>>>(w.hist, totals, d_n);
   rs_scatter<BITS, ROUNDS, BucketDigit><<<grid, 256, 0, st>>>(key, val, d_n, dg, w.hist, key_scratch, val_scratch, totals);
   // bucket bases = the scanned histogram row of tile 0 (offset of the first tile's rows of every bucket)
   static const int cap_env = getenv("VSV_BK_CAP") ? atoi(getenv("VSV_BK_CAP")) : BK_CAP;      // tests force the fallback with a tiny capacity

@@ -555,11 +555,13 @@ __global__ __launch_bounds__(256) void build_call_keys(const vsv_call* __restric
 template <typename T>
 __global__ __launch_bounds__(256) void gather_rows(const T* __restrict__ in, const uint32_t* __restrict__ idx,
                                                    const uint64_t* __restrict__ key, const uint32_t* __restrict__ d_n,
-                                                   T* __restrict__ out, uint32_t* __restrict__ d_alive, uint32_t* __restrict__ n_long) {
+                                                   T* __restrict__ out, uint32_t* __restrict__ d_alive, uint32_t* __restrict__ n_long,
+                                                   int32_t* __restrict__ fill) {
   const uint32_t n = *d_n;
   if (blockIdx.x == 0 && threadIdx.x == 0) *n_long = 0;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     out[i] = in[idx[i]];
+    if (fill) fill[i] = -1;                // pairing state of the stage that follows (pair_kernel: -1 = unpaired)
     if (key[i] != VSV_KEY_DEAD && (i + 1 == n || key[i + 1] == VSV_KEY_DEAD)) *d_alive = i + 1;
   }
 }
@@ -754,17 +756,25 @@ __global__ __launch_bounds__(256) void pair_long_kernel(const vsv_sig* __restric
   }
 }
 
-// hp2 rows: unpaired -> 0/1 call (Hifi.py:588-592), paired -> dead slot
+// hp2 rows: unpaired -> 0/1 call (Hifi.py:588-592), paired -> dead slot; and the final sort's (tid, pos) key of every call
 __global__ __launch_bounds__(256) void pair_finish(const vsv_sig* __restrict__ m, const uint32_t* __restrict__ d_n,
-                                                   const int32_t* __restrict__ st2, vsv_call* __restrict__ out) {
+                                                   const int32_t* __restrict__ st2, vsv_call* __restrict__ out, int pb, int tid_lo,
+                                                   uint64_t* __restrict__ key, uint32_t* __restrict__ idx) {
   const uint32_t n = *d_n;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const vsv_sig me = m[i];
-    if (!(me.meta & VSV_M_HP2)) continue;
-    vsv_call c;
-    c.pad = 0; c.a = -1; c.b = (int32_t)i; c.gt = 1;
-    c.sig = (st2[i] == -1) ? me : dead_sig();
-    out[i] = c;
+    vsv_sig kept;
+    if (me.meta & VSV_M_HP2) {
+      vsv_call c;
+      c.pad = 0; c.a = -1; c.b = (int32_t)i; c.gt = 1;
+      c.sig = (st2[i] == -1) ? me : dead_sig();
+      out[i] = c;
+      kept = c.sig;
+    } else {
+      kept = out[i].sig;                   // written by pair_kernel / pair_long_kernel
+    }
+    key[i] = vsv_key_stage(kept, 4, pb, tid_lo);
+    idx[i] = i;
   }
 }
 __global__ void fill_i32(int32_t* p, int32_t v, const uint32_t* d_n) {
@@ -841,10 +851,10 @@ void vsv_launch_split(hipStream_t st, const RecView& rv, const vsv_params& p, in
 // sort rows `in[0,n)` by the stage key into `sorted`, publish the alive count
 const uint64_t* vsv_launch_sort_stage(hipStream_t st, const vsv_sig* in, const uint32_t* d_n, int stage, int pb, int nbits,
                                       vsv_sig* sorted, uint32_t* d_alive, const StageBufs& b, const SortWork& sw, int64_t cap,
-                                      Counters* ctr) {
+                                      Counters* ctr, int32_t* fill_minus1) {
   build_keys<<<b.grid, 256, 0, st>>>(in, d_n, stage, pb, b.tid_lo, b.tid_bits, b.key, b.idx, ctr);
   const SortResult r = vsv_radix_sort_pairs(st, b.key, b.idx, sw.key_alt, sw.val_alt, d_n, cap, nbits, sw, stage == 5 ? 0 : b.kmax);
-  gather_rows<vsv_sig><<<b.grid, 256, 0, st>>>(in, r.val, r.key, d_n, sorted, d_alive, &ctr->n_long);
+  gather_rows<vsv_sig><<<b.grid, 256, 0, st>>>(in, r.val, r.key, d_n, sorted, d_alive, &ctr->n_long, fill_minus1);
   return r.key;
 }
 
@@ -857,12 +867,11 @@ void vsv_launch_cluster(hipStream_t st, const vsv_sig* sorted, const uint64_t* s
 void vsv_launch_pair(hipStream_t st, const vsv_sig* merged, const uint64_t* merged_key, const uint32_t* d_alive3, int pair_shift, int pair_window,
                      vsv_call* calls_tmp, vsv_call* calls, uint32_t* d_ncalls, const StageBufs& b, uint64_t* key2, uint32_t* idx2,
                      const SortWork& sw, int pb, int nbits, int64_t cap, Counters* ctr) {
-  fill_i32<<<b.grid, 256, 0, st>>>(b.cl, -1, d_alive3);   // (n_long was cleared by the stage-3 gather)
+  // (the stage-3 gather cleared n_long and set the pairing state b.cl to -1)
   const int right = pair_shift < pair_window ? pair_shift : pair_window;
   pair_kernel<<<b.grid, 256, 0, st>>>(merged, merged_key, d_alive3, pair_shift, right, pb, b.cl, calls_tmp, key2, &ctr->n_long);
   pair_long_kernel<<<LONG_GRID, 256, 0, st>>>(merged, merged_key, d_alive3, pair_shift, right, pb, b.cl, calls_tmp, key2, &ctr->n_long);
-  pair_finish<<<b.grid, 256, 0, st>>>(merged, d_alive3, b.cl, calls_tmp);
-  build_call_keys<<<b.grid, 256, 0, st>>>(calls_tmp, d_alive3, pb, b.tid_lo, key2, idx2);
+  pair_finish<<<b.grid, 256, 0, st>>>(merged, d_alive3, b.cl, calls_tmp, pb, b.tid_lo, key2, idx2);
   const SortResult r = vsv_radix_sort_pairs(st, key2, idx2, sw.key_alt, sw.val_alt, d_alive3, cap, nbits, sw, b.kmax);
-  gather_rows<vsv_call><<<b.grid, 256, 0, st>>>(calls_tmp, r.val, r.key, d_alive3, calls, d_ncalls, &ctr->n_long);
+  gather_rows<vsv_call><<<b.grid, 256, 0, st>>>(calls_tmp, r.val, r.key, d_alive3, calls, d_ncalls, &ctr->n_long, nullptr);
 }

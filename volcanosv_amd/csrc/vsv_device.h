@@ -126,7 +126,11 @@ void vsv_launch_stream_read(hipStream_t st, const void* src, size_t bytes, uint3
 void vsv_launch_stream_copy(hipStream_t st, const void* src, void* dst, size_t bytes);
 int vsv_cigar_parts(int64_t n_ops, int ops_per_part);
 void vsv_scan_u32_exclusive(hipStream_t st, const uint32_t* in, int n, uint32_t* out, uint32_t* tmp);
-struct LongScanBufs { void* agg; uint32_t* carry_r; uint32_t* carry_q; void* tile_sum; };   // long-record scan (cigar_scan_long)
+struct LongScanBufs {   // scratch of the scan launcher beyond the part tables
+  void* agg; uint32_t* carry_r; uint32_t* carry_q; void* tile_sum;   // long-record scan (cigar_scan_long): aggregates, carries, tile sums
+  uint32_t* tile_cnt; int tile_cnt_cap;    // read-shaped scan: zeroed per run, the waves add their part counts per 2048-part tile
+  bool arena_zeroed;                       // the caller zeroed shard_cnt together with the counters
+};
 bool vsv_scan_is_long(const RecView& rv, const vsv_params& p);
 size_t vsv_long_scan_bytes(int64_t n_ops, int which);
 void vsv_launch_cigar_scan(hipStream_t st, const RecView& rv, const vsv_params& p, uint32_t* part_rb, int n_parts,
@@ -144,7 +148,7 @@ void vsv_launch_split(hipStream_t st, const RecView& rv, const vsv_params& p, in
 // returns the sorted key array (kept for the cluster / pair kernel that follows)
 const uint64_t* vsv_launch_sort_stage(hipStream_t st, const vsv_sig* in, const uint32_t* d_n, int stage, int pb, int nbits,
                                       vsv_sig* sorted, uint32_t* d_alive, const StageBufs& b, const SortWork& sw, int64_t cap,
-                                      Counters* ctr);
+                                      Counters* ctr, int32_t* fill_minus1 = nullptr);
 void vsv_launch_cluster(hipStream_t st, const vsv_sig* sorted, const uint64_t* sorted_key, const uint32_t* d_alive, int max_shift,
                         int pb, vsv_sig* out, const StageBufs& b, uint64_t* long_list, Counters* ctr);
 void vsv_launch_pair(hipStream_t st, const vsv_sig* merged, const uint64_t* merged_key, const uint32_t* d_alive3, int pair_shift, int pair_window,
