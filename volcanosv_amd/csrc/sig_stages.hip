@@ -577,85 +577,96 @@ constexpr uint32_t LONG_RUN = 48;   // runs / stretches longer than this go to t
 __device__ __forceinline__ int32_t ld_i32(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_i32(int32_t* p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-__global__ __launch_bounds__(256) void cluster_kernel(const vsv_sig* __restrict__ s, const uint64_t* __restrict__ key,
-                                                      const uint32_t* __restrict__ d_n, int max_shift, int pb,
-                                                      int32_t* __restrict__ cl, vsv_sig* __restrict__ out,
-                                                      uint64_t* __restrict__ long_list, uint32_t* __restrict__ n_long) {
-  const uint32_t n = *d_n;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const uint64_t lk = key[i] >> pb;
-    if (i > 0 && (key[i - 1] >> pb) == lk && (int64_t)s[i].pos - s[i - 1].pos <= max_shift) continue;  // not a run head
-    uint32_t e = i + 1;
-    while (e < n && (key[e] >> pb) == lk && (int64_t)s[e].pos - s[e - 1].pos <= max_shift) ++e;
-    if (e - i > LONG_RUN) {   // dense region: one wave works on it (cluster_long_kernel)
-      long_list[atomicAdd(n_long, 1u)] = ((uint64_t)i << 32) | e;
-      continue;
-    }
-    for (uint32_t k = i; k < e; ++k) cl[k] = -1;
-    for (uint32_t a = i; a < e; ++a) {
-      if (cl[a] != -1) { out[a] = dead_sig(); continue; }
-      cl[a] = (int32_t)a;
-      const vsv_sig s1 = s[a];
-      uint32_t best = a;
-      int32_t best_len = s1.svlen;
-      for (uint32_t b = a + 1; b < e; ++b) {
-        const vsv_sig s2 = s[b];
-        if ((int64_t)s2.pos - s1.pos > max_shift) break;
-        if (cl[b] != -1) continue;
-        if (vsv_match(s1, s2, max_shift)) {
-          cl[b] = (int32_t)a;
-          if (s2.svlen > best_len) { best = b; best_len = s2.svlen; }
-        }
+// One wave on a long run: seeds stay sequential (the greedy is order dependent), the scan of a seed's window and the
+// search for the next seed are 64-wide. cl[] is accessed with agent-scope relaxed atomics (L2), so the wave sees its
+// own earlier stores whatever the L1 holds. Called by ALL 64 lanes with wave-uniform (i, e).
+__device__ __forceinline__ void cluster_long_run(const vsv_sig* __restrict__ s, int max_shift, int32_t* __restrict__ cl,
+                                                 vsv_sig* __restrict__ out, const uint32_t i, const uint32_t e, const int lane) {
+  for (uint32_t k = i + lane; k < e; k += 64) st_i32(&cl[k], -1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the wave's (L2, sc1) stores are acknowledged before its next loads
+  uint32_t a = i;
+  while (a < e) {
+    const vsv_sig s1 = s[a];
+    if (lane == 0) st_i32(&cl[a], (int32_t)a);
+    uint64_t best = ((uint64_t)(uint32_t)s1.svlen << 32) | (0xFFFFFFFFu - a);   // max length, then lowest index
+    for (uint32_t b0 = a + 1; b0 < e; b0 += 64) {
+      const uint32_t b = b0 + lane;
+      const bool valid = b < e;
+      vsv_sig s2 = s1;
+      if (valid) s2 = s[b];
+      const bool inwin = valid && (int64_t)s2.pos - s1.pos <= max_shift;
+      if (__ballot(inwin) == 0) break;          // positions ascend: the whole tile is beyond the window
+      if (inwin && ld_i32(&cl[b]) == -1 && vsv_match(s1, s2, max_shift)) {
+        st_i32(&cl[b], (int32_t)a);
+        const uint64_t c = ((uint64_t)(uint32_t)s2.svlen << 32) | (0xFFFFFFFFu - b);
+        if (c > best) best = c;
       }
-      out[a] = s[best];
     }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { const uint64_t o = __shfl_xor(best, d, 64); if (o > best) best = o; }
+    if (lane == 0) out[a] = s[0xFFFFFFFFu - (uint32_t)best];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // next seed: first unassigned row after a
+    uint32_t nxt = e;
+    for (uint32_t b0 = a + 1; b0 < e; b0 += 64) {
+      const uint32_t b = b0 + lane;
+      const uint64_t free_m = __ballot(b < e && ld_i32(&cl[b]) == -1);
+      if (free_m) { nxt = b0 + (uint32_t)__builtin_ctzll(free_m); break; }
+    }
+    a = nxt;
   }
+  for (uint32_t k = i + lane; k < e; k += 64) if (ld_i32(&cl[k]) != (int32_t)k) out[k] = dead_sig();
 }
 
-// One wave per long run: seeds stay sequential (the greedy is order dependent), the scan of a seed's window and the
-// search for the next seed are 64-wide. cl[] is accessed with agent-scope relaxed atomics (L2), so the wave sees its
-// own earlier stores whatever the L1 holds.
-__global__ __launch_bounds__(256) void cluster_long_kernel(const vsv_sig* __restrict__ s, int max_shift, int32_t* __restrict__ cl,
-                                                           vsv_sig* __restrict__ out, const uint64_t* __restrict__ long_list,
-                                                           const uint32_t* __restrict__ n_long) {
+// A lane owns the run that starts at its row (short runs: the sequential greedy, exactly); runs of more than LONG_RUN rows are
+// taken over by the lane's whole wave right away, one after the other (no queue, no second launch: the waves that find dense
+// regions are spread over the grid like the regions over the table).
+__global__ __launch_bounds__(256) void cluster_kernel(const vsv_sig* __restrict__ s, const uint64_t* __restrict__ key,
+                                                      const uint32_t* __restrict__ d_n, int max_shift, int pb,
+                                                      int32_t* __restrict__ cl, vsv_sig* __restrict__ out) {
+  const uint32_t n = *d_n;
   const int lane = threadIdx.x & 63;
-  const uint32_t nwaves = gridDim.x * (blockDim.x >> 6), nl = *n_long;
-  for (uint32_t r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r < nl; r += nwaves) {
-    const uint32_t i = (uint32_t)(long_list[r] >> 32), e = (uint32_t)long_list[r];
-    for (uint32_t k = i + lane; k < e; k += 64) st_i32(&cl[k], -1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the wave's (L2, sc1) stores are acknowledged before its next loads
-    uint32_t a = i;
-    while (a < e) {
-      const vsv_sig s1 = s[a];
-      if (lane == 0) st_i32(&cl[a], (int32_t)a);
-      uint64_t best = ((uint64_t)(uint32_t)s1.svlen << 32) | (0xFFFFFFFFu - a);   // max length, then lowest index
-      for (uint32_t b0 = a + 1; b0 < e; b0 += 64) {
-        const uint32_t b = b0 + lane;
-        const bool valid = b < e;
-        vsv_sig s2 = s1;
-        if (valid) s2 = s[b];
-        const bool inwin = valid && (int64_t)s2.pos - s1.pos <= max_shift;
-        if (__ballot(inwin) == 0) break;          // positions ascend: the whole tile is beyond the window
-        if (inwin && ld_i32(&cl[b]) == -1 && vsv_match(s1, s2, max_shift)) {
-          st_i32(&cl[b], (int32_t)a);
-          const uint64_t c = ((uint64_t)(uint32_t)s2.svlen << 32) | (0xFFFFFFFFu - b);
-          if (c > best) best = c;
+  for (uint32_t i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += gridDim.x * blockDim.x) {   // wave-uniform trip count
+    const uint32_t i = i0 + (uint32_t)lane;
+    bool is_long = false;
+    uint32_t e = 0;
+    if (i < n) {
+      const uint64_t lk = key[i] >> pb;
+      const bool head = !(i > 0 && (key[i - 1] >> pb) == lk && (int64_t)s[i].pos - s[i - 1].pos <= max_shift);
+      if (head) {
+        e = i + 1;
+        while (e < n && e - i <= LONG_RUN && (key[e] >> pb) == lk && (int64_t)s[e].pos - s[e - 1].pos <= max_shift) ++e;
+        if (e - i > LONG_RUN) {
+          is_long = true;
+          while (e < n && (key[e] >> pb) == lk && (int64_t)s[e].pos - s[e - 1].pos <= max_shift) ++e;
+        } else {
+          for (uint32_t k = i; k < e; ++k) cl[k] = -1;
+          for (uint32_t a = i; a < e; ++a) {
+            if (cl[a] != -1) { out[a] = dead_sig(); continue; }
+            cl[a] = (int32_t)a;
+            const vsv_sig s1 = s[a];
+            uint32_t best = a;
+            int32_t best_len = s1.svlen;
+            for (uint32_t b = a + 1; b < e; ++b) {
+              const vsv_sig s2 = s[b];
+              if ((int64_t)s2.pos - s1.pos > max_shift) break;
+              if (cl[b] != -1) continue;
+              if (vsv_match(s1, s2, max_shift)) {
+                cl[b] = (int32_t)a;
+                if (s2.svlen > best_len) { best = b; best_len = s2.svlen; }
+              }
+            }
+            out[a] = s[best];
+          }
         }
       }
-#pragma unroll
-      for (int d = 32; d > 0; d >>= 1) { const uint64_t o = __shfl_xor(best, d, 64); if (o > best) best = o; }
-      if (lane == 0) out[a] = s[0xFFFFFFFFu - (uint32_t)best];
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      // next seed: first unassigned row after a
-      uint32_t nxt = e;
-      for (uint32_t b0 = a + 1; b0 < e; b0 += 64) {
-        const uint32_t b = b0 + lane;
-        const uint64_t free_m = __ballot(b < e && ld_i32(&cl[b]) == -1);
-        if (free_m) { nxt = b0 + (uint32_t)__builtin_ctzll(free_m); break; }
-      }
-      a = nxt;
     }
-    for (uint32_t k = i + lane; k < e; k += 64) if (ld_i32(&cl[k]) != (int32_t)k) out[k] = dead_sig();
+    uint64_t lm = __ballot(is_long);
+    while (lm) {
+      const int src = __builtin_ctzll(lm);
+      lm &= lm - 1;
+      cluster_long_run(s, max_shift, cl, out, (uint32_t)__shfl((int)i, src, 64), (uint32_t)__shfl((int)e, src, 64), lane);
+    }
   }
 }
 
@@ -671,87 +682,91 @@ __device__ __forceinline__ uint32_t lower_bound_key(const uint64_t* __restrict__
   while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (key[mid] >= target) hi = mid; else lo = mid + 1; }
   return lo;
 }
-__global__ __launch_bounds__(256) void pair_kernel(const vsv_sig* __restrict__ m, const uint64_t* __restrict__ key,
-                                                   const uint32_t* __restrict__ d_n, int pair_shift, int right, int pb,
-                                                   int32_t* __restrict__ st2, vsv_call* __restrict__ out,
-                                                   uint64_t* __restrict__ long_list, uint32_t* __restrict__ n_long) {
-  const uint32_t n = *d_n;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const vsv_sig me = m[i];
-    if (me.meta & VSV_M_HP2) continue;                                  // stretches are led by hp1 rows
-    const int sh_hap = pb + 2, sh_tid = pb + 3;
-    const uint64_t tk = key[i] >> sh_tid;
-    if (i > 0 && (key[i - 1] >> sh_hap) == (key[i] >> sh_hap) && (int64_t)me.pos - m[i - 1].pos <= 2 * (int64_t)pair_shift) continue;
-    // first hp2 row of this tid with pos >= pos_i - pair_shift (rows further left can never match); the hp2 block ends where
-    // the (tid, hap) prefix of the key changes, so no search for its bounds is needed
-    const uint64_t hp2_prefix = (tk << 1) | 1ull;
-    uint32_t jlo = lower_bound_key(key, n, (tk << sh_tid) | (1ull << sh_hap) | vsv_kpos((int32_t)max((int64_t)me.pos - pair_shift, (int64_t)-VSV_POS_BIAS)));
-    {   // dense stretch: hand it to pair_long_kernel
-      uint32_t e = i + 1;
-      while (e < n && e - i <= LONG_RUN && (key[e] >> sh_hap) == (key[i] >> sh_hap) && (int64_t)m[e].pos - m[e - 1].pos <= 2 * (int64_t)pair_shift) ++e;
-      if (e - i > LONG_RUN) { long_list[atomicAdd(n_long, 1u)] = ((uint64_t)i << 32) | jlo; continue; }
+// One wave on a long hp1 stretch: hp1 rows stay sequential (first come, first served), the candidate window of a row is
+// scanned 64 hp2 rows at a time and the first match is the lowest set ballot bit. Called by all 64 lanes, (i, jlo) wave-uniform.
+__device__ __forceinline__ void pair_long_stretch(const vsv_sig* __restrict__ m, const uint64_t* __restrict__ key, const uint32_t n,
+                                                  int pair_shift, int right, int sh_hap, int32_t* __restrict__ st2,
+                                                  vsv_call* __restrict__ out, const uint32_t i, uint32_t jlo, const int lane) {
+  const uint64_t hp1_prefix = key[i] >> sh_hap, hp2_prefix = hp1_prefix | 1ull;
+  for (uint32_t a = i; a < n; ++a) {
+    const vsv_sig s1 = m[a];
+    if ((key[a] >> sh_hap) != hp1_prefix) break;
+    if (a > i && (int64_t)s1.pos - m[a - 1].pos > 2 * (int64_t)pair_shift) break;
+    while (jlo < n && (key[jlo] >> sh_hap) == hp2_prefix && (int64_t)s1.pos - m[jlo].pos > pair_shift) ++jlo;
+    int32_t mate = -1;
+    for (uint32_t j0 = jlo; j0 < n; j0 += 64) {
+      const uint32_t j = j0 + lane;
+      const bool valid = j < n && (key[j] >> sh_hap) == hp2_prefix;
+      vsv_sig s2 = s1;
+      if (valid) s2 = m[j];
+      const bool inwin = valid && (int64_t)s2.pos - s1.pos <= right;
+      if (__ballot(inwin) == 0) break;
+      const bool ok = inwin && ((s1.meta ^ s2.meta) & VSV_M_DEL) == 0 && ld_i32(&st2[j]) == -1 && vsv_match(s1, s2, pair_shift);
+      const uint64_t bal = __ballot(ok);
+      if (bal) { mate = (int32_t)(j0 + (uint32_t)__builtin_ctzll(bal)); break; }
     }
-    for (uint32_t a = i; a < n; ++a) {
-      const vsv_sig s1 = m[a];
-      if ((key[a] >> sh_hap) != (key[i] >> sh_hap)) break;
-      if (a > i && (int64_t)s1.pos - m[a - 1].pos > 2 * (int64_t)pair_shift) break;
-      while (jlo < n && (key[jlo] >> sh_hap) == hp2_prefix && (int64_t)s1.pos - m[jlo].pos > pair_shift) ++jlo;
-      int32_t mate = -1;
-      for (uint32_t j = jlo; j < n && (key[j] >> sh_hap) == hp2_prefix; ++j) {
-        const vsv_sig s2 = m[j];
-        if ((int64_t)s2.pos - s1.pos > right) break;
-        if (((s1.meta ^ s2.meta) & VSV_M_DEL) == 0 && st2[j] == -1 && vsv_match(s1, s2, pair_shift)) {
-          mate = (int32_t)j; st2[j] = (int32_t)a; break;                 // Hifi.py:560-569
-        }
-      }
+    if (lane == 0) {
       vsv_call c;
       c.a = (int32_t)a; c.pad = 0;
-      if (mate < 0) { c.sig = s1; c.b = -1; c.gt = 1; }                  // Hifi.py:575-576
-      else { const vsv_sig s2 = m[mate]; c.sig = (s1.svlen > s2.svlen) ? s1 : s2; c.b = mate; c.gt = 2; }  // Hifi.py:583-586
+      if (mate < 0) { c.sig = s1; c.b = -1; c.gt = 1; }
+      else { st_i32(&st2[mate], (int32_t)a); const vsv_sig s2 = m[mate]; c.sig = (s1.svlen > s2.svlen) ? s1 : s2; c.b = mate; c.gt = 2; }
       out[a] = c;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
 }
-// One wave per long hp1 stretch: hp1 rows stay sequential (first come, first served), the candidate window of a row is
-// scanned 64 hp2 rows at a time and the first match is the lowest set ballot bit.
-__global__ __launch_bounds__(256) void pair_long_kernel(const vsv_sig* __restrict__ m, const uint64_t* __restrict__ key,
-                                                        const uint32_t* __restrict__ d_n, int pair_shift, int right, int pb,
-                                                        int32_t* __restrict__ st2, vsv_call* __restrict__ out,
-                                                        const uint64_t* __restrict__ long_list, const uint32_t* __restrict__ n_long) {
+
+// A lane owns the stretch its hp1 row leads; stretches of more than LONG_RUN rows are taken over by the lane's whole wave.
+__global__ __launch_bounds__(256) void pair_kernel(const vsv_sig* __restrict__ m, const uint64_t* __restrict__ key,
+                                                   const uint32_t* __restrict__ d_n, int pair_shift, int right, int pb,
+                                                   int32_t* __restrict__ st2, vsv_call* __restrict__ out) {
   const uint32_t n = *d_n;
   const int lane = threadIdx.x & 63;
   const int sh_hap = pb + 2, sh_tid = pb + 3;
-  const uint32_t nwaves = gridDim.x * (blockDim.x >> 6), nl = *n_long;
-  for (uint32_t r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r < nl; r += nwaves) {
-    const uint32_t i = (uint32_t)(long_list[r] >> 32);
-    uint32_t jlo = (uint32_t)long_list[r];
-    const uint64_t tk = key[i] >> sh_tid;
-    const uint32_t b1 = lower_bound_key(key, n, (tk + 1) << sh_tid);
-    for (uint32_t a = i; a < n; ++a) {
-      const vsv_sig s1 = m[a];
-      if ((key[a] >> sh_hap) != (key[i] >> sh_hap)) break;
-      if (a > i && (int64_t)s1.pos - m[a - 1].pos > 2 * (int64_t)pair_shift) break;
-      while (jlo < b1 && (int64_t)s1.pos - m[jlo].pos > pair_shift) ++jlo;
-      int32_t mate = -1;
-      for (uint32_t j0 = jlo; j0 < b1; j0 += 64) {
-        const uint32_t j = j0 + lane;
-        const bool valid = j < b1;
-        vsv_sig s2 = s1;
-        if (valid) s2 = m[j];
-        const bool inwin = valid && (int64_t)s2.pos - s1.pos <= right;
-        if (__ballot(inwin) == 0) break;
-        const bool ok = inwin && ((s1.meta ^ s2.meta) & VSV_M_DEL) == 0 && ld_i32(&st2[j]) == -1 && vsv_match(s1, s2, pair_shift);
-        const uint64_t bal = __ballot(ok);
-        if (bal) { mate = (int32_t)(j0 + (uint32_t)__builtin_ctzll(bal)); break; }
+  for (uint32_t i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += gridDim.x * blockDim.x) {   // wave-uniform trip count
+    const uint32_t i = i0 + (uint32_t)lane;
+    bool is_long = false;
+    uint32_t jlo = 0;
+    if (i < n) {
+      const vsv_sig me = m[i];
+      // stretches are led by hp1 rows
+      const bool head = !(me.meta & VSV_M_HP2) &&
+                        !(i > 0 && (key[i - 1] >> sh_hap) == (key[i] >> sh_hap) && (int64_t)me.pos - m[i - 1].pos <= 2 * (int64_t)pair_shift);
+      if (head) {
+        const uint64_t tk = key[i] >> sh_tid;
+        // first hp2 row of this tid with pos >= pos_i - pair_shift (rows further left can never match); the hp2 block ends where
+        // the (tid, hap) prefix of the key changes, so no search for its bounds is needed
+        const uint64_t hp2_prefix = (tk << 1) | 1ull;
+        jlo = lower_bound_key(key, n, (tk << sh_tid) | (1ull << sh_hap) | vsv_kpos((int32_t)max((int64_t)me.pos - pair_shift, (int64_t)-VSV_POS_BIAS)));
+        uint32_t e = i + 1;
+        while (e < n && e - i <= LONG_RUN && (key[e] >> sh_hap) == (key[i] >> sh_hap) && (int64_t)m[e].pos - m[e - 1].pos <= 2 * (int64_t)pair_shift) ++e;
+        if (e - i > LONG_RUN) is_long = true;
+        else {
+          for (uint32_t a = i; a < e; ++a) {
+            const vsv_sig s1 = m[a];
+            while (jlo < n && (key[jlo] >> sh_hap) == hp2_prefix && (int64_t)s1.pos - m[jlo].pos > pair_shift) ++jlo;
+            int32_t mate = -1;
+            for (uint32_t j = jlo; j < n && (key[j] >> sh_hap) == hp2_prefix; ++j) {
+              const vsv_sig s2 = m[j];
+              if ((int64_t)s2.pos - s1.pos > right) break;
+              if (((s1.meta ^ s2.meta) & VSV_M_DEL) == 0 && st2[j] == -1 && vsv_match(s1, s2, pair_shift)) {
+                mate = (int32_t)j; st2[j] = (int32_t)a; break;                 // Hifi.py:560-569
+              }
+            }
+            vsv_call c;
+            c.a = (int32_t)a; c.pad = 0;
+            if (mate < 0) { c.sig = s1; c.b = -1; c.gt = 1; }                  // Hifi.py:575-576
+            else { const vsv_sig s2 = m[mate]; c.sig = (s1.svlen > s2.svlen) ? s1 : s2; c.b = mate; c.gt = 2; }  // Hifi.py:583-586
+            out[a] = c;
+          }
+        }
       }
-      if (lane == 0) {
-        vsv_call c;
-        c.a = (int32_t)a; c.pad = 0;
-        if (mate < 0) { c.sig = s1; c.b = -1; c.gt = 1; }
-        else { st_i32(&st2[mate], (int32_t)a); const vsv_sig s2 = m[mate]; c.sig = (s1.svlen > s2.svlen) ? s1 : s2; c.b = mate; c.gt = 2; }
-        out[a] = c;
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    uint64_t lm = __ballot(is_long);
+    while (lm) {
+      const int src = __builtin_ctzll(lm);
+      lm &= lm - 1;
+      pair_long_stretch(m, key, n, pair_shift, right, sh_hap, st2, out, (uint32_t)__shfl((int)i, src, 64), (uint32_t)__shfl((int)jlo, src, 64), lane);
     }
   }
 }
@@ -788,7 +803,6 @@ __global__ void copy_rows(const T* __restrict__ in, const uint32_t* __restrict__
 }
 
 constexpr int EW_GRID = 128;
-constexpr int LONG_GRID = 2048;   // wave-per-run kernels: enough waves to fill the chip when dense regions are many
 
 }  // namespace
 
@@ -860,8 +874,8 @@ const uint64_t* vsv_launch_sort_stage(hipStream_t st, const vsv_sig* in, const u
 
 void vsv_launch_cluster(hipStream_t st, const vsv_sig* sorted, const uint64_t* sorted_key, const uint32_t* d_alive, int max_shift,
                         int pb, vsv_sig* out, const StageBufs& b, uint64_t* long_list, Counters* ctr) {
-  cluster_kernel<<<b.grid, 256, 0, st>>>(sorted, sorted_key, d_alive, max_shift, pb, b.cl, out, long_list, &ctr->n_long);
-  cluster_long_kernel<<<LONG_GRID, 256, 0, st>>>(sorted, max_shift, b.cl, out, long_list, &ctr->n_long);
+  (void)long_list; (void)ctr;
+  cluster_kernel<<<b.grid, 256, 0, st>>>(sorted, sorted_key, d_alive, max_shift, pb, b.cl, out);
 }
 
 void vsv_launch_pair(hipStream_t st, const vsv_sig* merged, const uint64_t* merged_key, const uint32_t* d_alive3, int pair_shift, int pair_window,
@@ -869,8 +883,7 @@ void vsv_launch_pair(hipStream_t st, const vsv_sig* merged, const uint64_t* merg
                      const SortWork& sw, int pb, int nbits, int64_t cap, Counters* ctr) {
   // (the stage-3 gather cleared n_long and set the pairing state b.cl to -1)
   const int right = pair_shift < pair_window ? pair_shift : pair_window;
-  pair_kernel<<<b.grid, 256, 0, st>>>(merged, merged_key, d_alive3, pair_shift, right, pb, b.cl, calls_tmp, key2, &ctr->n_long);
-  pair_long_kernel<<<LONG_GRID, 256, 0, st>>>(merged, merged_key, d_alive3, pair_shift, right, pb, b.cl, calls_tmp, key2, &ctr->n_long);
+  pair_kernel<<<b.grid, 256, 0, st>>>(merged, merged_key, d_alive3, pair_shift, right, pb, b.cl, calls_tmp);
   pair_finish<<<b.grid, 256, 0, st>>>(merged, d_alive3, b.cl, calls_tmp, pb, b.tid_lo, key2, idx2);
   const SortResult r = vsv_radix_sort_pairs(st, key2, idx2, sw.key_alt, sw.val_alt, d_alive3, cap, nbits, sw, b.kmax);
   gather_rows<vsv_call><<<b.grid, 256, 0, st>>>(calls_tmp, r.val, r.key, d_alive3, calls, d_ncalls, &ctr->n_long, nullptr);
