@@ -337,16 +337,16 @@ int finish(vsv_handle* h) {
   }
   const uint32_t e = h->host_ctr.err;
   h->last_count = h->host_ctr.n_pool;
-  if ((e & ERRB_SORT_FALLBACK) && !(e & ~(uint32_t)ERRB_SORT_FALLBACK) && !h->in_rerun) {
+  if ((e & ERRB_SORT_FALLBACK) && !h->in_rerun) {
     // a bucket of the bucket sort did not fit in LDS (tables far from uniform, or much larger than the previous run's): the
-    // stages ran on a partly sorted table. Same input again through the LSD passes; this handle keeps them for a while.
+    // stages behind it ran on a table that was not written completely, so whatever else they reported means nothing.
+    // Same input again through the LSD passes (real errors show up there); this handle keeps them for a while.
     h->lsd_runs = 16;
     h->in_rerun = true;
     const int st = rerun(h);
     h->in_rerun = false;
     return st;
   }
-  if (e & ERRB_SORT_FALLBACK) h->lsd_runs = 16;      // together with a real error: report that one
   if (e & ERRB_CAPACITY) {
     char b[160];
     snprintf(b, sizeof b, "signature capacity %lld exceeded (cigar signatures emitted: %u, split candidates: %u)",

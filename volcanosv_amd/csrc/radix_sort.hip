@@ -10,6 +10,8 @@
 // running counter across rounds — no atomics, fully deterministic.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "vsv_device.h"
 
 namespace {
@@ -53,8 +55,36 @@ struct BucketDigit {
 };
 
 // hist[tile * BINS + d] = number of items of this tile with digit d
-template <int BITS, int ROUNDS, typename DIGIT>
-__global__ __launch_bounds__(256) void rs_hist(const uint64_t* __restrict__ key, const uint32_t* __restrict__ d_n, DIGIT dg,
+// where the (key, value) pairs of a pass come from: arrays, or straight from the rows of a signature / call table (the keys of
+// the bucket pass are then never materialised before the scatter: no key-building launch)
+struct KeyArr {
+  const uint64_t* key; const uint32_t* val;
+  __device__ __forceinline__ uint64_t key_at(uint32_t i, bool) const { return key[i]; }
+  __device__ __forceinline__ uint32_t val_at(uint32_t i) const { return val[i]; }
+};
+struct SigKey {      // stage key of a signature row (vsv_key_stage; stage 5 = the READS final order, reads.py:281-286)
+  const vsv_sig* rows; int stage, pb, tid_lo, tid_bits; uint32_t* err;
+  __device__ __forceinline__ uint64_t key_at(uint32_t i, bool check) const {
+    const vsv_sig v = rows[i];
+    uint64_t k;
+    if (stage == 5) {
+      k = (v.meta & VSV_M_DEAD) ? VSV_KEY_DEAD
+          : ((uint64_t)(uint32_t)(v.tid - tid_lo) << (pb + 2)) | (vsv_kpos(v.pos) << 2) | ((v.meta & VSV_M_SPLIT) ? 2u : 0u) | ((v.meta & VSV_M_DEL) ? 0u : 1u);
+    } else k = vsv_key_stage(v, stage, pb, tid_lo);
+    if (check && !(v.meta & VSV_M_DEAD) && ((pb < 32 && (vsv_kpos(v.pos) >> pb) != 0) || ((uint32_t)(v.tid - tid_lo) >> tid_bits) != 0))
+      atomicOr(err, ERRB_RANGE);            // max_pos hint too small / tid outside [tid_lo, n_tids)
+    return k;
+  }
+  __device__ __forceinline__ uint32_t val_at(uint32_t i) const { return i; }
+};
+struct CallKey {     // (tid, pos) key of a call row: the final order of pair_sig's output (H:594)
+  const vsv_call* rows; int pb, tid_lo;
+  __device__ __forceinline__ uint64_t key_at(uint32_t i, bool) const { return vsv_key_stage(rows[i].sig, 4, pb, tid_lo); }
+  __device__ __forceinline__ uint32_t val_at(uint32_t i) const { return i; }
+};
+
+template <int BITS, int ROUNDS, typename DIGIT, typename SRC>
+__global__ __launch_bounds__(256) void rs_hist(SRC src, const uint32_t* __restrict__ d_n, DIGIT dg,
                                                uint32_t* __restrict__ hist, uint32_t* __restrict__ totals) {
   constexpr int BINS = 1 << BITS;
   __shared__ uint32_t cnt[BINS];
@@ -65,7 +95,7 @@ __global__ __launch_bounds__(256) void rs_hist(const uint64_t* __restrict__ key,
     const uint32_t base = tile * rs_tile<ROUNDS>();
     for (int k = 0; k < (int)rs_tile<ROUNDS>() / 256; ++k) {
       const uint32_t i = base + k * 256 + threadIdx.x;
-      if (i < n) atomicAdd(&cnt[dg.template get<BITS>(key[i])], 1u);
+      if (i < n) atomicAdd(&cnt[dg.template get<BITS>(src.key_at(i, true))], 1u);
     }
     __syncthreads();
     for (int d = threadIdx.x; d < BINS; d += 256) {
@@ -188,8 +218,8 @@ __global__ __launch_bounds__(1024) void rs_scan_mb(uint32_t* __restrict__ hist, 
   }
 }
 
-template <int BITS, int RS_ROUNDS, typename DIGIT>
-__global__ __launch_bounds__(256) void rs_scatter(const uint64_t* __restrict__ key, const uint32_t* __restrict__ val,
+template <int BITS, int RS_ROUNDS, typename DIGIT, typename SRC>
+__global__ __launch_bounds__(256) void rs_scatter(SRC src,
                                                   const uint32_t* __restrict__ d_n, DIGIT dg,
                                                   const uint32_t* __restrict__ hist, uint64_t* __restrict__ key_out,
                                                   uint32_t* __restrict__ val_out, const uint32_t* __restrict__ totals) {
@@ -212,8 +242,8 @@ __global__ __launch_bounds__(256) void rs_scatter(const uint64_t* __restrict__ k
     for (int r = 0; r < RS_ROUNDS; ++r) {
       const uint32_t i = wbase + r * 64 + lane;
       const bool ok = i < n;
-      k_[r] = ok ? key[i] : 0;
-      v_[r] = ok ? val[i] : 0;
+      k_[r] = ok ? src.key_at(i, false) : 0;
+      v_[r] = ok ? src.val_at(i) : 0;
       const uint32_t d = dg.template get<BITS>(k_[r]);
       const uint64_t m = match_digit<BITS>(d, ok);
       // every lane of the match group reads the counter, then the group's lowest lane bumps it;
@@ -250,10 +280,10 @@ void one_pass(hipStream_t st, int64_t max_n, const uint64_t* kin, const uint32_t
   const int64_t max_tiles = (max_n + rs_tile<ROUNDS>() - 1) / rs_tile<ROUNDS>();
   const int grid = (int)(max_tiles < 1024 ? (max_tiles < 1 ? 1 : max_tiles) : 1024);
   const LsdDigit dg{shift};
-  rs_hist<BITS, ROUNDS, LsdDigit><<<grid, 256, 0, st>>>(kin, d_n, dg, hist, totals);
+  rs_hist<BITS, ROUNDS, LsdDigit, KeyArr><<<grid, 256, 0, st>>>(KeyArr{kin, vin}, d_n, dg, hist, totals);
   if (totals) rs_scan_mb<BITS, ROUNDS, 128, 8><<<(1 << BITS) / 128, 1024, 0, st>>>(hist, totals, d_n);
   else rs_scan<BITS, ROUNDS><<<1, 1024, 0, st>>>(hist, d_n);
-  rs_scatter<BITS, ROUNDS, LsdDigit><<<grid, 256, 0, st>>>(kin, vin, d_n, dg, hist, kout, vout, totals);
+  rs_scatter<BITS, ROUNDS, LsdDigit, KeyArr><<<grid, 256, 0, st>>>(KeyArr{kin, vin}, d_n, dg, hist, kout, vout, totals);
 }
 
 // ---- bucket sort: ONE counting pass into <= 2048 key-range buckets, then one workgroup sorts each bucket in LDS -----------
@@ -276,9 +306,19 @@ __device__ __forceinline__ uint64_t match_digit_rt(uint32_t d, bool valid, int b
   }
   return m;
 }
+// ROW = void: the sorted (key, value) pairs are the result. ROW = vsv_sig / vsv_call: the values index `rows_in` and the sorted ROWS
+// are the result (plus their keys): rows_out[i] = rows_in[value_i] for the alive rows, *d_alive = their count, *n_long = 0 and,
+// if given, fill[0, n) = -1 (the state array of the stage that follows) — the gather launch that used to follow a sort.
+template <typename ROW>
+struct RowIO { const ROW* in; ROW* out; uint32_t* d_alive; uint32_t* n_long; int32_t* fill; };
+template <>
+struct RowIO<void> {};
+template <typename ROW>
 __global__ __launch_bounds__(BK_THREADS) void bk_lds_sort(const uint64_t* __restrict__ key, const uint32_t* __restrict__ val,
                                                            const uint32_t* __restrict__ base, int nbuckets, const uint32_t* __restrict__ d_n,
-                                                           uint64_t* __restrict__ key_out, uint32_t* __restrict__ val_out, uint32_t* __restrict__ err, uint32_t cap) {
+                                                           uint64_t* __restrict__ key_out, uint32_t* __restrict__ val_out, uint32_t* __restrict__ err, uint32_t cap,
+                                                           RowIO<ROW> io) {
+  constexpr bool ROWS = !std::is_same<ROW, void>::value;
   __shared__ uint32_t sk[2][BK_CAP], sv[2][BK_CAP];
   __shared__ uint32_t wcnt[BK_WAVES][1 << BK_DBITS];
   __shared__ uint32_t tot[BK_WAVES];
@@ -291,7 +331,15 @@ __global__ __launch_bounds__(BK_THREADS) void bk_lds_sort(const uint64_t* __rest
     if (dlo > n) dlo = n;
     const uint32_t dm = n - dlo, per = (dm + gridDim.x - 1) / gridDim.x;
     const uint32_t a = dlo + min(dm, (uint32_t)b * per), e = dlo + min(dm, (uint32_t)(b + 1) * per);
-    for (uint32_t i = a + t; i < e; i += BK_THREADS) { key_out[i] = VSV_KEY_DEAD; val_out[i] = val[i]; }
+    for (uint32_t i = a + t; i < e; i += BK_THREADS) { key_out[i] = VSV_KEY_DEAD; if (!ROWS) val_out[i] = val[i]; }
+    if constexpr (ROWS) {
+      if (b == 0 && t == 0) { *io.d_alive = dlo; *io.n_long = 0; }
+      if (io.fill) {
+        const uint32_t fper = (n + gridDim.x - 1) / gridDim.x;
+        const uint32_t fa = min(n, (uint32_t)b * fper), fe = min(n, fa + fper);
+        for (uint32_t i = fa + t; i < fe; i += BK_THREADS) io.fill[i] = -1;
+      }
+    }
   }
   if (b == nbuckets - 1) return;
   uint32_t lo = base[b], hi = base[b + 1];
@@ -327,7 +375,13 @@ __global__ __launch_bounds__(BK_THREADS) void bk_lds_sort(const uint64_t* __rest
   if (width > 0xFFFFFFFFull) { if (t == 0) atomicOr(err, ERRB_SORT_FALLBACK); return; }
   if (m == 1 || width == 0) {                            // one row, or all keys equal: already in order
 #pragma unroll
-    for (int j = 0; j < BK_PER; ++j) { const uint32_t i = (uint32_t)t + (uint32_t)j * BK_THREADS; if (i < m) { key_out[lo + i] = kr[j]; val_out[lo + i] = vr[j]; } }
+    for (int j = 0; j < BK_PER; ++j) {
+      const uint32_t i = (uint32_t)t + (uint32_t)j * BK_THREADS;
+      if (i < m) {
+        key_out[lo + i] = kr[j];
+        if constexpr (ROWS) io.out[lo + i] = io.in[vr[j]]; else val_out[lo + i] = vr[j];
+      }
+    }
     return;
   }
 #pragma unroll
@@ -380,12 +434,15 @@ __global__ __launch_bounds__(BK_THREADS) void bk_lds_sort(const uint64_t* __rest
     __syncthreads();
     src ^= 1;
   }
-  for (uint32_t i = t; i < m; i += BK_THREADS) { key_out[lo + i] = kmin + sk[src][i]; val_out[lo + i] = sv[src][i]; }
+  for (uint32_t i = t; i < m; i += BK_THREADS) {
+    key_out[lo + i] = kmin + sk[src][i];
+    if constexpr (ROWS) io.out[lo + i] = io.in[sv[src][i]]; else val_out[lo + i] = sv[src][i];
+  }
 }
 
-template <int BITS, int ROUNDS>
-SortResult bucket_sort(hipStream_t st, uint64_t* key, uint32_t* val, uint64_t* key_scratch, uint32_t* val_scratch, const uint32_t* d_n,
-                       int64_t max_n, uint64_t kmax, const SortWork& w) {
+template <int BITS, int ROUNDS, typename SRC, typename ROW>
+SortResult bucket_sort(hipStream_t st, SRC src, uint64_t* key, uint32_t* val, uint64_t* key_scratch, uint32_t* val_scratch, const uint32_t* d_n,
+                       int64_t max_n, uint64_t kmax, const SortWork& w, RowIO<ROW> io) {
   int s = 0;
   while ((kmax >> s) > 0xFFFFFFFFull) ++s;
   BucketDigit dg;
@@ -395,14 +452,35 @@ SortResult bucket_sort(hipStream_t st, uint64_t* key, uint32_t* val, uint64_t* k
   ++*w.pass_cursor;
   const int64_t max_tiles = (max_n + rs_tile<ROUNDS>() - 1) / rs_tile<ROUNDS>();
   const int grid = (int)(max_tiles < 1024 ? (max_tiles < 1 ? 1 : max_tiles) : 1024);
-  rs_hist<BITS, ROUNDS, BucketDigit><<<grid, 256, 0, st>>>(key, d_n, dg, w.hist, totals);
+  rs_hist<BITS, ROUNDS, BucketDigit, SRC><<<grid, 256, 0, st>>>(src, d_n, dg, w.hist, totals);
   rs_scan_mb<BITS, ROUNDS, 32, 32><<<(1 << BITS) / 32, 1024, 0, st>>>(w.hist, totals, d_n);
-  rs_scatter<BITS, ROUNDS, BucketDigit><<<grid, 256, 0, st>>>(key, val, d_n, dg, w.hist, key_scratch, val_scratch, totals);
+  rs_scatter<BITS, ROUNDS, BucketDigit, SRC><<<grid, 256, 0, st>>>(src, d_n, dg, w.hist, key_scratch, val_scratch, totals);
   // bucket bases = the scanned histogram row of tile 0 (offset of the first tile's rows of every bucket)
   static const int cap_env = getenv("VSV_BK_CAP") ? atoi(getenv("VSV_BK_CAP")) : BK_CAP;      // tests force the fallback with a tiny capacity
   const uint32_t cap = (uint32_t)(cap_env < 2 ? 2 : cap_env > BK_CAP ? BK_CAP : cap_env);
-  bk_lds_sort<<<1 << BITS, BK_THREADS, 0, st>>>(key_scratch, val_scratch, w.hist, 1 << BITS, d_n, key, val, w.err, cap);
+  bk_lds_sort<ROW><<<1 << BITS, BK_THREADS, 0, st>>>(key_scratch, val_scratch, w.hist, 1 << BITS, d_n, key, val, w.err, cap, io);
   return SortResult{key, val};
+}
+
+// 0: the LSD passes; 8..11: bucket sort with that many bucket bits
+int bucket_bits_for(const SortWork& w, int nbits, uint64_t& kmax) {
+  if (!(w.bucket_bits >= 8 && w.err && w.totals && *w.pass_cursor < w.max_passes && nbits > 12 && nbits - 1 <= 63)) return 0;
+  if (kmax == 0) kmax = 1ull << (nbits - 1);      // unless the caller knows better: the top key bit is the dead flag
+  const int b = w.bucket_bits > 11 ? 11 : w.bucket_bits;
+  return (kmax >> b) < 0xFFFFFFFFull ? b : 0;
+}
+template <typename SRC, typename ROW>
+SortResult bucket_sort_any(hipStream_t st, int b, SRC src, uint64_t* key, uint32_t* val, uint64_t* key_scratch, uint32_t* val_scratch,
+                           const uint32_t* d_n, int64_t max_n, uint64_t kmax, const SortWork& w, RowIO<ROW> io) {
+#define BK_CASE(B)                                                                                                                         \
+  case B: return w.small_tiles ? bucket_sort<B, RS_ROUNDS_SMALL, SRC, ROW>(st, src, key, val, key_scratch, val_scratch, d_n, max_n, kmax, w, io) \
+                               : bucket_sort<B, RS_ROUNDS_BIG, SRC, ROW>(st, src, key, val, key_scratch, val_scratch, d_n, max_n, kmax, w, io);
+  switch (b) {
+    BK_CASE(8) BK_CASE(9) BK_CASE(10)
+    default: return w.small_tiles ? bucket_sort<11, RS_ROUNDS_SMALL, SRC, ROW>(st, src, key, val, key_scratch, val_scratch, d_n, max_n, kmax, w, io)
+                                  : bucket_sort<11, RS_ROUNDS_BIG, SRC, ROW>(st, src, key, val, key_scratch, val_scratch, d_n, max_n, kmax, w, io);
+  }
+#undef BK_CASE
 }
 
 template <int ROUNDS>
@@ -439,24 +517,31 @@ SortResult vsv_radix_sort_pairs(hipStream_t st, uint64_t* key, uint32_t* val, ui
                                 const uint32_t* d_n, int64_t max_n, int nbits, const SortWork& w, uint64_t kmax) {
   // bucket sort when the caller allows it (bucket_bits from the row counts of the handle's previous run), the keys of one bucket
   // can fit 32 bits and a zeroed totals slot is left; anything else takes the LSD passes
-  if (w.bucket_bits >= 8 && w.err && w.totals && *w.pass_cursor < w.max_passes && nbits > 12 && nbits - 1 <= 63) {
-    if (kmax == 0) kmax = 1ull << (nbits - 1);      // unless the caller knows better: the top key bit is the dead flag
-    const int b = w.bucket_bits > 11 ? 11 : w.bucket_bits;
-    if ((kmax >> b) < 0xFFFFFFFFull) {
-      switch (b) {
-        case 8: return w.small_tiles ? bucket_sort<8, RS_ROUNDS_SMALL>(st, key, val, key_scratch, val_scratch, d_n, max_n, kmax, w)
-                                     : bucket_sort<8, RS_ROUNDS_BIG>(st, key, val, key_scratch, val_scratch, d_n, max_n, kmax, w);
-        case 9: return w.small_tiles ? bucket_sort<9, RS_ROUNDS_SMALL>(st, key, val, key_scratch, val_scratch, d_n, max_n, kmax, w)
-                                     : bucket_sort<9, RS_ROUNDS_BIG>(st, key, val, key_scratch, val_scratch, d_n, max_n, kmax, w);
-        case 10: return w.small_tiles ? bucket_sort<10, RS_ROUNDS_SMALL>(st, key, val, key_scratch, val_scratch, d_n, max_n, kmax, w)
-                                      : bucket_sort<10, RS_ROUNDS_BIG>(st, key, val, key_scratch, val_scratch, d_n, max_n, kmax, w);
-        default: return w.small_tiles ? bucket_sort<11, RS_ROUNDS_SMALL>(st, key, val, key_scratch, val_scratch, d_n, max_n, kmax, w)
-                                      : bucket_sort<11, RS_ROUNDS_BIG>(st, key, val, key_scratch, val_scratch, d_n, max_n, kmax, w);
-      }
-    }
-  }
+  const int b = bucket_bits_for(w, nbits, kmax);
+  if (b) return bucket_sort_any<KeyArr, void>(st, b, KeyArr{key, val}, key, val, key_scratch, val_scratch, d_n, max_n, kmax, w, RowIO<void>{});
   return w.small_tiles ? sort_pairs<RS_ROUNDS_SMALL>(st, key, val, key_scratch, val_scratch, d_n, max_n, nbits, w)
                  : sort_pairs<RS_ROUNDS_BIG>(st, key, val, key_scratch, val_scratch, d_n, max_n, nbits, w);
+}
+
+// Sorted copy of a signature table by its stage key / of a call table by (tid, pos), in 4 launches: keys come straight from the rows
+// (hist + scatter), the LDS sort writes the rows. Returns the sorted keys (key_out), or nullptr when the bucket sort does not apply
+// (the caller then builds keys, runs vsv_radix_sort_pairs and gathers).
+const uint64_t* vsv_bucket_sort_sigs(hipStream_t st, const vsv_sig* in, const uint32_t* d_n, int stage, int pb, int tid_lo, int tid_bits, int nbits,
+                                     uint64_t kmax, vsv_sig* sorted, uint64_t* key_out, uint32_t* d_alive, uint32_t* n_long, int32_t* fill,
+                                     const SortWork& w, int64_t max_n) {
+  const int b = bucket_bits_for(w, nbits, kmax);
+  if (!b) return nullptr;
+  bucket_sort_any<SigKey, vsv_sig>(st, b, SigKey{in, stage, pb, tid_lo, tid_bits, w.err}, key_out, nullptr, w.key_alt, w.val_alt, d_n, max_n, kmax, w,
+                                   RowIO<vsv_sig>{in, sorted, d_alive, n_long, fill});
+  return key_out;
+}
+const uint64_t* vsv_bucket_sort_calls(hipStream_t st, const vsv_call* in, const uint32_t* d_n, int pb, int tid_lo, int nbits, uint64_t kmax,
+                                      vsv_call* sorted, uint64_t* key_out, uint32_t* d_alive, uint32_t* n_long, const SortWork& w, int64_t max_n) {
+  const int b = bucket_bits_for(w, nbits, kmax);
+  if (!b) return nullptr;
+  bucket_sort_any<CallKey, vsv_call>(st, b, CallKey{in, pb, tid_lo}, key_out, nullptr, w.key_alt, w.val_alt, d_n, max_n, kmax, w,
+                                     RowIO<vsv_call>{in, sorted, d_alive, n_long, nullptr});
+  return key_out;
 }
 
 int64_t vsv_radix_hist_entries(int64_t max_n) { return 2048 * ((max_n + rs_tile<RS_ROUNDS_SMALL>() - 1) / rs_tile<RS_ROUNDS_SMALL>()); }

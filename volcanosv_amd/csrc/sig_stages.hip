@@ -866,6 +866,9 @@ void vsv_launch_split(hipStream_t st, const RecView& rv, const vsv_params& p, in
 const uint64_t* vsv_launch_sort_stage(hipStream_t st, const vsv_sig* in, const uint32_t* d_n, int stage, int pb, int nbits,
                                       vsv_sig* sorted, uint32_t* d_alive, const StageBufs& b, const SortWork& sw, int64_t cap,
                                       Counters* ctr, int32_t* fill_minus1) {
+  const uint64_t* fast = vsv_bucket_sort_sigs(st, in, d_n, stage, pb, b.tid_lo, b.tid_bits, nbits, stage == 5 ? 0 : b.kmax, sorted, b.key, d_alive,
+                                              &ctr->n_long, fill_minus1, sw, cap);
+  if (fast) return fast;
   build_keys<<<b.grid, 256, 0, st>>>(in, d_n, stage, pb, b.tid_lo, b.tid_bits, b.key, b.idx, ctr);
   const SortResult r = vsv_radix_sort_pairs(st, b.key, b.idx, sw.key_alt, sw.val_alt, d_n, cap, nbits, sw, stage == 5 ? 0 : b.kmax);
   gather_rows<vsv_sig><<<b.grid, 256, 0, st>>>(in, r.val, r.key, d_n, sorted, d_alive, &ctr->n_long, fill_minus1);
@@ -885,6 +888,7 @@ void vsv_launch_pair(hipStream_t st, const vsv_sig* merged, const uint64_t* merg
   const int right = pair_shift < pair_window ? pair_shift : pair_window;
   pair_kernel<<<b.grid, 256, 0, st>>>(merged, merged_key, d_alive3, pair_shift, right, pb, b.cl, calls_tmp);
   pair_finish<<<b.grid, 256, 0, st>>>(merged, d_alive3, b.cl, calls_tmp, pb, b.tid_lo, key2, idx2);
+  if (vsv_bucket_sort_calls(st, calls_tmp, d_alive3, pb, b.tid_lo, nbits, b.kmax, calls, key2, d_ncalls, &ctr->n_long, sw, cap)) return;
   const SortResult r = vsv_radix_sort_pairs(st, key2, idx2, sw.key_alt, sw.val_alt, d_alive3, cap, nbits, sw, b.kmax);
   gather_rows<vsv_call><<<b.grid, 256, 0, st>>>(calls_tmp, r.val, r.key, d_alive3, calls, d_ncalls, &ctr->n_long, nullptr);
 }

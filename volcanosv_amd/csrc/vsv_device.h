@@ -120,6 +120,13 @@ struct SortResult { uint64_t* key; uint32_t* val; };
 SortResult vsv_radix_sort_pairs(hipStream_t st, uint64_t* key, uint32_t* val, uint64_t* key_scratch, uint32_t* val_scratch,
                                 const uint32_t* d_n, int64_t max_n, int nbits, const SortWork& w, uint64_t kmax = 0);
 int64_t vsv_radix_hist_entries(int64_t max_n);
+// rows sorted by their stage key in 4 launches (bucket sort with the keys taken from the rows and the rows gathered by the LDS sort);
+// nullptr = not applicable, use build-keys + vsv_radix_sort_pairs + gather
+const uint64_t* vsv_bucket_sort_sigs(hipStream_t st, const vsv_sig* in, const uint32_t* d_n, int stage, int pb, int tid_lo, int tid_bits, int nbits,
+                                     uint64_t kmax, vsv_sig* sorted, uint64_t* key_out, uint32_t* d_alive, uint32_t* n_long, int32_t* fill,
+                                     const SortWork& w, int64_t max_n);
+const uint64_t* vsv_bucket_sort_calls(hipStream_t st, const vsv_call* in, const uint32_t* d_n, int pb, int tid_lo, int nbits, uint64_t kmax,
+                                      vsv_call* sorted, uint64_t* key_out, uint32_t* d_alive, uint32_t* n_long, const SortWork& w, int64_t max_n);
 
 // cigar_scan.hip
 void vsv_launch_stream_read(hipStream_t st, const void* src, size_t bytes, uint32_t* sink);
