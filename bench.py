@@ -4,7 +4,7 @@
 Headline (BASELINE.json config 2, the configuration the metric is quoted on): one step = one pass of the whole hot path
 (vsv_run_chromosome: cigar scan -> fold -> split pairs -> sort/cluster x2 -> merge -> hap pairing) over one device-resident
 shard of 10 M HiFi-like records of one chromosome. Steps are independent batches, so a rank keeps `--streams` engines (one
-vsv_handle + HIP stream each, default 2) in flight round-robin: the latency-bound signature stages of one batch overlap the
+vsv_handle + HIP stream each, default 3) in flight round-robin: the latency-bound signature stages of one batch overlap the
 bandwidth-bound scan of the next, exactly as a rank that owns several chromosomes runs them (volcanosv_amd/contig_signature.py).
 With N GPUs every rank owns one such chromosome shard (weak scaling, no data-path collective); the per-rank call tables are
 gathered to rank 0 once, inside the timed region. The timed region of `--steps` steps is repeated `--reps` times (each
@@ -15,7 +15,7 @@ The same JSON line carries, under "configs", the other workloads of SURVEY.md §
   config3  50 M ONT-like records, dtype ONT                                                                [N = 1 only]
   contig   row 2c: 200 k contig-like records of ~16 k ops (the literal contig-vs-reference shape)          [N = 1 only]
   config4  22 chromosomes x 20 M records assigned to the ranks by LPT (shard.lpt_assign), FIXED total work (strong scaling:
-           the busiest of 8 ranks holds 3 chromosomes, ideal 7.33x), two engines per rank over its chromosomes, call gather
+           the busiest of 8 ranks holds 3 chromosomes, ideal 7.33x), the rank's engines take turns over its chromosomes, call gather
   config5  Complex_SV: split-contig stream over 22 chromosomes, candidates on the rank that owns the primary alignment,
            cross-rank breakpoint join (shard.exchange_bnd: all-to-all to the owner of the source contig), pairing, gather
 `--config 4` / `--config 5` make one of the last two the headline instead ("scaling": "strong"); `--extras none` skips them all.
@@ -297,7 +297,7 @@ class Bench:
             recs = DeviceRecords(t, nq, c + 1, max_pos=int(index[c, 0]) + 200000, tid_lo=c)
             keep.append(t)
             jobs.append((recs, p))
-        engs = self.engs[:2] if len(self.engs) >= 2 else self.engs     # two engines per rank over its chromosomes (contig_signature.run)
+        engs = self.engs[: max(1, min(len(self.engs), len(jobs)))]     # the rank's engines take turns over its chromosomes (contig_signature.run)
 
         def one_pass(scan_ms):
             """Every chromosome of this rank once; the call tables of all of them are gathered (device rows, one collective)."""
@@ -346,7 +346,7 @@ class Bench:
             load[owner[c]] += 1
         res = {
             "workload": "config4: %d chromosomes x %d HiFi-like records (hg19 lengths), LPT over %d rank(s): %s chromosomes per rank, "
-                        "2 engines per rank, call tables gathered to rank 0 inside the timed region" % (n_chrom, n_per_chrom, self.world, load),
+                        "%d engines per rank, call tables gathered to rank 0 inside the timed region" % (n_chrom, n_per_chrom, self.world, load, len(engs)),
             "scaling": "strong", "records": total_records, "steps": steps, "reps": len(times),
             "ms_per_step": med / steps * 1e3, "ms_per_step_min": ts[0] / steps * 1e3, "ms_per_step_max": ts[-1] / steps * 1e3,
             "records_per_s": total_records * steps / med, "chromosomes_per_rank": load, "ideal_speedup": n_chrom / max(load),
@@ -430,7 +430,7 @@ def main():
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("paths", nargs="*", help=argparse.SUPPRESS)
     ap.add_argument("--max-sigs", type=int, default=0, help="row capacity of an engine (default by workload)")
-    ap.add_argument("--streams", type=int, default=2, help="engines (handle + HIP stream) in flight per rank")
+    ap.add_argument("--streams", type=int, default=3, help="engines (handle + HIP stream) in flight per rank")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one rank per GPU) | gloo (rehearsal: all ranks on cuda:0)")
     args = ap.parse_args()
     if args.cpu_worker:

@@ -37,7 +37,8 @@ typedef enum vsv_status {
   VSV_E_READLEN = -6,      /* reference `assert rl1==rl2` (H:331, RS:172)                           */
   VSV_E_UNSORTED = -7,     /* reference `assert read1.pos<=read2.pos` (H:315) / cigar_off not mono. */
   VSV_E_ZERODIV = -8,      /* CLR gate ZeroDivisionError (C:61, C:70)                               */
-  VSV_E_NO_DEVICE = -9     /* no HIP device / extension built without a GPU present                */
+  VSV_E_NO_DEVICE = -9,    /* no HIP device / extension built without a GPU present                */
+  VSV_E_SEQLEN = -10       /* reference `assert len(read.seq)==offset_contig` (H:397-398, RS:123-124)       */
 } vsv_status;
 
 /* ---- data types (dtype of the extractor) -------------------------------------------------- */
@@ -59,7 +60,10 @@ enum {
   VSV_F_HP2 = 8,       /* 'hp2' in qname                                                          */
   VSV_F_SECONDARY = 16,
   VSV_F_UNMAPPED = 32,
-  VSV_F_SKIP = 64      /* record excluded by the host adaptor (sig_extract: query_length < min_read_len, SE:439; BED) */
+  VSV_F_SKIP = 64,     /* record excluded by the host adaptor (sig_extract: query_length < min_read_len, SE:439; BED) */
+  VSV_F_SEQ_MISMATCH = 128 /* the record stores a SEQ whose length differs from the query length of its CIGAR (M,I,S,=,X). Set by the
+                              BAM readers; a record the extractors walk with this bit raises VSV_E_SEQLEN like the reference's
+                              `if read.seq: assert len(read.seq)==offset_contig` (H:397-398, O:408-409, C:430-431, RS:123-124)   */
 };
 
 /* ---- caller-owned SoA of alignment records (BAM order: tid, pos ascending) ------------------ */

@@ -491,9 +491,11 @@ int orc_run(const vsv_records* r, const vsv_params* p, int literal, orc_out* o) 
       if (dtype == VSV_DTYPE_CLR) { gate = clr_gate(r, i); if (gate < 0) { st = gate; break; } }
       if (r->mapq[i] < p->min_cigar_mapq || !gate) continue;
       st = walk_record(r, i, p, (r->flag[i] >> 2) & 3u, &raw);
+      if (st == 0 && (r->flag[i] & VSV_F_SEQ_MISMATCH)) st = VSV_E_SEQLEN;      /* H:397-398: after the reference_end assert */
     } else if (dtype == VSV_DTYPE_READS) {
       if (r->mapq[i] < p->min_cigar_mapq) continue;            /* RS:120 */
       st = walk_record(r, i, p, 1, &raw);
+      if (st == 0 && (r->flag[i] & VSV_F_SEQ_MISMATCH)) st = VSV_E_SEQLEN;      /* RS:123-124 */
     } else if (dtype == VSV_DTYPE_CUTESV) {
       if ((r->flag[i] & VSV_F_SKIP) || r->mapq[i] < p->min_cigar_mapq) continue;   /* SE:439, 446 */
       st = walk_record(r, i, p, 1, &raw);

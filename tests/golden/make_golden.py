@@ -40,7 +40,7 @@ SCRIPTS = {
 # fake pysam + duck-typed reads
 # ------------------------------------------------------------------------------------------------
 class FakeRead:
-    def __init__(self, chrom, pos, qname, mapq, reverse, cigar):
+    def __init__(self, chrom, pos, qname, mapq, reverse, cigar, seq_len=None):
         self.reference_name = chrom
         self.pos = pos
         self.qname = qname
@@ -49,7 +49,7 @@ class FakeRead:
         self.cigar = [tuple(c) for c in cigar]
         # pysam reference_end: M, D, N, =, X consume the reference
         self.reference_end = pos + sum(l for op, l in self.cigar if op in (0, 2, 3, 7, 8))
-        self.seq = None
+        self.seq = None if seq_len is None else "N" * int(seq_len)      # `if read.seq: assert len(read.seq)==offset_contig` (H:397-398)
 
 
 class FakeAlignmentFile:

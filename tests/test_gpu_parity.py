@@ -410,6 +410,46 @@ def test_error_statuses(eng):
             eng.run(good, default_params(dt))
 
 
+def test_seq_length_assert(eng):
+    """`if read.seq: assert len(read.seq)==offset_contig` (H:397-398, RS:123-124): the BAM readers flag records whose stored SEQ
+    length differs from the CIGAR's query length (VSV_F_SEQ_MISMATCH); a flagged record raises VSV_E_SEQLEN exactly when the
+    reference walks it (haplotype tag + mapq, CLR gate), in both scan layouts, and never when it does not; the status equals the
+    oracle's (which tests/test_reference_live.py pins to the reference)."""
+    from volcanosv_amd import synth
+    from volcanosv_amd.abi import F_SEQ_MISMATCH, SCAN_CONTIGS, SCAN_READS
+    from volcanosv_amd.engine import default_params
+    t, nq, _ = synth.generate(30000, "hifi", seed=91, chrom_len=3_000_000)
+    base = synth.to_soa(t, nq)
+    hp = (base.flag & (F_HP1 | F_HP2)) != 0
+    walked = int(np.flatnonzero(hp & (base.mapq >= 50))[1234])
+    low_q = int(np.flatnonzero(hp & (base.mapq < 50))[7])
+    for dtype in (DTYPE_HIFI, DTYPE_ONT, DTYPE_CLR, DTYPE_READS):
+        for rec, want in ((walked, -10), (low_q, 0)):
+            soa = synth.to_soa(t, nq)
+            soa.flag = soa.flag.copy()                       # to_soa hands out views of the generator's tensors
+            soa.flag[rec] |= F_SEQ_MISMATCH
+            st_o, _ = oracle_run(soa, dtype)
+            assert st_o == want, (dtype, rec, st_o)
+            for layout in (SCAN_READS, SCAN_CONTIGS):
+                p = default_params(dtype)
+                p.scan_layout = layout
+                try:
+                    eng.run(soa, p)
+                    st = 0
+                except VsvError as e:
+                    st = e.status
+                assert st == want, (dtype, rec, layout, st)
+    # CLR: a flagged record the gate rejects is never walked (C:427-431)
+    gated = RecordSoA.from_tuples([(0, 100, "a_hp1", 60, False, [(0, 50), (1, 40), (0, 50), (1, 40), (0, 50)]),
+                                   (0, 900, "b_hp2", 60, False, [(0, 500), (2, 60), (0, 500)])])
+    gated.flag[0] |= F_SEQ_MISMATCH
+    assert oracle_run(gated, DTYPE_CLR)[0] == 0 and oracle_run(gated, DTYPE_HIFI)[0] == -10
+    eng.run(gated, default_params(DTYPE_CLR))
+    with pytest.raises(VsvError) as e:
+        eng.run(gated, default_params(DTYPE_HIFI))
+    assert e.value.status == -10
+
+
 def test_capacity_overflow_reports_required_count():
     from volcanosv_amd import synth
     from volcanosv_amd.engine import Engine, default_params

@@ -291,6 +291,40 @@ def test_error_sites_match_the_reference():
         assert outcome(style, base + [mate1, mate2_ok]) == (0, 0)
         ref, st = outcome(style, base + [mate1, mate2_bad])
         assert ref == -5 and st == -6                                  # an AssertionError there, VSV_E_READLEN here
+    # `if read.seq: assert len(read.seq)==offset_contig` (H:397-398, O:408-409, C:430-431): a stored SEQ of another length than the
+    # CIGAR's query length. The BAM readers mark such records (VSV_F_SEQ_MISMATCH); the assert is only reached by records that are walked.
+    from volcanosv_amd.abi import F_SEQ_MISMATCH
+
+    def outcome_seq(style, recs, seq_lens):
+        """seq_lens[i]: stored SEQ length of record i (None = '*')."""
+        try:
+            mg.run_contig(style, [r + (seq_lens[i],) for i, r in enumerate(recs)], stable=True)
+            ref = 0
+        except AssertionError:
+            ref = -5
+        except ZeroDivisionError:
+            ref = -8
+        soa = _soa(recs, ["chr1"])
+        for i, (r, sl) in enumerate(zip(recs, seq_lens)):
+            qlen = sum(l for op, l in r[5] if op in (0, 1, 4, 7, 8))
+            if sl and sl != qlen:                                     # what volcanosv_amd.bam / the device reader compute
+                soa.flag[i] |= F_SEQ_MISMATCH
+        st, _ = oracle.run(soa, dtype=DTYPE_BY_NAME[style])
+        return ref, st
+
+    walked = ("chr1", 9000, "PS1_hp1_c", 60, False, [(S, 10), (M, 300), (I, 50), (M, 300)])     # query length 660
+    low_q = ("chr1", 9000, "PS1_hp1_c", 20, False, [(S, 10), (M, 300), (I, 50), (M, 300)])
+    untagged = ("chr1", 9000, "PS1_c", 60, False, [(S, 10), (M, 300), (I, 50), (M, 300)])
+    for style in ("Hifi", "ONT", "CLR"):
+        assert outcome_seq(style, base + [walked], [None, None, 660]) == (0, 0)
+        assert outcome_seq(style, base + [walked], [None, None, None]) == (0, 0)                # SEQ '*': nothing to compare
+        ref, st = outcome_seq(style, base + [walked], [None, None, 661])
+        assert ref == -5 and st == -10                                                          # AssertionError there, VSV_E_SEQLEN here
+        assert outcome_seq(style, base + [low_q], [None, None, 661]) == (0, 0)                  # never walked
+        assert outcome_seq(style, base + [untagged], [None, None, 661]) == (0, 0)
+    assert outcome_seq("CLR", base + [eq_gated], [None, None, 5]) == (0, 0)                     # the gate comes first
+    ref, st = outcome_seq("Hifi", base + [eq_ok_gate], [None, None, 5])
+    assert ref == -5 and st == -5                                                               # reference_end assert (H:396) before the SEQ one
 
 
 def test_filter_tra_merge_on_fresh_random_inputs(tmp_path):

@@ -14,7 +14,7 @@ ABI_VERSION = 2
 DTYPE_HIFI, DTYPE_ONT, DTYPE_CLR, DTYPE_READS, DTYPE_SVIM, DTYPE_CUTESV = 0, 1, 2, 3, 4, 5
 DTYPE_BY_NAME = {"Hifi": DTYPE_HIFI, "ONT": DTYPE_ONT, "CLR": DTYPE_CLR, "READS": DTYPE_READS, "SVIM": DTYPE_SVIM, "CUTESV": DTYPE_CUTESV}
 
-F_REVERSE, F_SUPP, F_HP1, F_HP2, F_SECONDARY, F_UNMAPPED, F_SKIP = 1, 2, 4, 8, 16, 32, 64
+F_REVERSE, F_SUPP, F_HP1, F_HP2, F_SECONDARY, F_UNMAPPED, F_SKIP, F_SEQ_MISMATCH = 1, 2, 4, 8, 16, 32, 64, 128
 M_DEL, M_SPLIT, M_HP2, M_DEAD, M_QREV = 1, 2, 4, 8, 16
 
 T_RAW, T_CIGAR, T_SPLIT, T_CLUSTER1, T_MERGED, T_CALLS, T_READS = range(7)
@@ -22,7 +22,7 @@ SCAN_AUTO, SCAN_READS, SCAN_CONTIGS = 0, 1, 2      # vsv_params.scan_layout
 
 STATUS = {
     0: "VSV_OK", -1: "VSV_E_INVALID", -2: "VSV_E_HIP", -3: "VSV_E_CAPACITY", -4: "VSV_E_EMPTY_CIGAR",
-    -5: "VSV_E_REFEND", -6: "VSV_E_READLEN", -7: "VSV_E_UNSORTED", -8: "VSV_E_ZERODIV", -9: "VSV_E_NO_DEVICE",
+    -5: "VSV_E_REFEND", -6: "VSV_E_READLEN", -7: "VSV_E_UNSORTED", -8: "VSV_E_ZERODIV", -9: "VSV_E_NO_DEVICE", -10: "VSV_E_SEQLEN",
 }
 
 E_CAPACITY = -3        # vsv_status values the wrappers act on (the rest only travel inside VsvError)

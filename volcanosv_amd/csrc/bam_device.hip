@@ -180,7 +180,16 @@ __global__ __launch_bounds__(256) void rec_emit(const uint8_t* __restrict__ s, i
     }
     const uint8_t* src = s + cg_src[i];
     const uint32_t nc = n_cig_out[i];
-    for (uint32_t c = lane; c < nc; c += 64) o_cigar[co + c] = ld32(src + 4ull * c);
+    uint64_t ql = 0;                                   // query length of the CIGAR (M,I,S,=,X), summed while the ops are copied
+    for (uint32_t c = lane; c < nc; c += 64) {
+      const uint32_t w = ld32(src + 4ull * c), op = w & 15u;
+      o_cigar[co + c] = w;
+      if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) ql += w >> 4;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) ql += __shfl_xor(ql, d, 64);
+    // a stored SEQ of another length is what the extractors assert on (H:397-398): VSV_F_SEQ_MISMATCH
+    if (lane == 0 && l_seq[i] != 0 && ql != (uint64_t)l_seq[i]) o_flag[k] = flag[i] | (uint8_t)VSV_F_SEQ_MISMATCH;
   }
 }
 

@@ -390,9 +390,17 @@ static int bam_load_impl(vsv_bam* b, int tid, vsv_records* out) {
             if (fl & 0x4) f8 |= VSV_F_UNMAPPED;
             for (uint32_t c = 0; c + 3 <= nlen; ++c)   // 'hp1' in qname / 'hp2' in qname (H:392)
               if (name[c] == 'h' && name[c + 1] == 'p') { if (name[c + 2] == '1') f8 |= VSV_F_HP1; else if (name[c + 2] == '2') f8 |= VSV_F_HP2; }
-            b->pos[i] = pos; b->tid[i] = refID; b->mapq[i] = mq; b->flag[i] = f8; b->l_seq[i] = (uint32_t)l_seq; b->sam_flag[i] = fl;
             if (a.cg_long && n_cig == 2) memcpy(&b->cigar[r.cig_off], a.cg_long, 4u * (size_t)r.n_cig_out);   // real CIGAR lives in CG:B,I
             else if (n_cig) memcpy(&b->cigar[r.cig_off], cg, 4u * (size_t)n_cig);
+            if (l_seq > 0) {   // a stored SEQ must be as long as the CIGAR's query (M,I,S,=,X): what the extractors assert (H:397-398)
+              uint64_t ql = 0;
+              for (uint32_t c = 0; c < r.n_cig_out; ++c) {
+                const uint32_t w = b->cigar[r.cig_off + c], op = w & 15u;
+                if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) ql += w >> 4;
+              }
+              if (ql != (uint64_t)l_seq) f8 |= VSV_F_SEQ_MISMATCH;
+            }
+            b->pos[i] = pos; b->tid[i] = refID; b->mapq[i] = mq; b->flag[i] = f8; b->l_seq[i] = (uint32_t)l_seq; b->sam_flag[i] = fl;
             b->cigar_off[i + 1] = r.cig_off + r.n_cig_out;
             if (b->keep_seq && l_seq > 0) memcpy(&b->seq[r.seq_off], sq, (size_t)((l_seq + 1) / 2));
             aux[k] = a;

@@ -358,6 +358,7 @@ int finish(vsv_handle* h) {
   if (e & ERRB_EMPTY_CIGAR) return fail(h, VSV_E_EMPTY_CIGAR, "record with no CIGAR ops / cigar_off not increasing");
   if (e & ERRB_RANGE) return fail(h, VSV_E_INVALID, "a part spans >= 2^30 CIGAR ops, a position exceeds the max_pos hint, a tid lies outside [tid_lo, n_tids), or a qid is >= n_qids");
   if (e & ERRB_REFEND) return fail(h, VSV_E_REFEND, "N/=/X op in an eligible record on the contig path (offset_ref != reference_end)");
+  if (e & ERRB_SEQLEN) return fail(h, VSV_E_SEQLEN, "a walked record stores a SEQ whose length differs from its CIGAR's query length (VSV_F_SEQ_MISMATCH)");
   if (e & ERRB_ZERODIV) return fail(h, VSV_E_ZERODIV, "CLR gate on a record without M ops");
   if (e & ERRB_UNSORTED) return fail(h, VSV_E_UNSORTED, "split pair with pos1 > pos2");
   if (e & ERRB_READLEN) return fail(h, VSV_E_READLEN, "split pair with unequal read lengths");
@@ -414,6 +415,7 @@ const char* vsv_status_string(int s) {
     case VSV_E_UNSORTED: return "VSV_E_UNSORTED";
     case VSV_E_ZERODIV: return "VSV_E_ZERODIV";
     case VSV_E_NO_DEVICE: return "VSV_E_NO_DEVICE";
+    case VSV_E_SEQLEN: return "VSV_E_SEQLEN";
   }
   return "VSV_E_?";
 }

@@ -195,6 +195,11 @@ __global__ __launch_bounds__(256) void cigar_scan_emit(RecView rv, const uint32_
       if (i < n_tab) {
         const uint32_t nx = off_lo[2 * (size_t)(first + i) + 2] - cb0_lo;
         mono = mono && (int32_t)(nx - v) > 0;   // empty CIGAR => reference IndexError at H:63
+        if (CLS == 0 || CLS == 1) {             // a walked record whose SEQ length differs from its CIGAR's: H:397-398, RS:123-124
+          const uint32_t fl = rv.flag[first + i];
+          if ((fl & VSV_F_SEQ_MISMATCH) && rv.mapq[first + i] >= (uint32_t)min_mapq && (CLS == 1 || (fl & (VSV_F_HP1 | VSV_F_HP2))))
+            atomicOr(&ec.ctr->err, ERRB_SEQLEN);
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -527,6 +532,11 @@ __global__ __launch_bounds__(256) void cigar_scan_long(RecView rv, const uint32_
       const uint64_t o = rv.cigar_off[first + i], nx = rv.cigar_off[(uint64_t)first + i + 1];
       my_off[i] = (uint32_t)o - e0_lo;
       ok = ok && nx > o && o >= e0 && o - e0 < (uint64_t)part_len;      // ascending, inside this part
+      if (CLS == 0 || CLS == 1) {               // a walked record whose SEQ length differs from its CIGAR's: H:397-398, RS:123-124
+        const uint32_t fl = rv.flag[first + i];
+        if ((fl & VSV_F_SEQ_MISMATCH) && rv.mapq[first + i] >= (uint32_t)min_mapq && (CLS == 1 || (fl & (VSV_F_HP1 | VSV_F_HP2))))
+          atomicOr(&ec.ctr->err, ERRB_SEQLEN);
+      }
     }
     __builtin_amdgcn_wave_barrier();
     if (__ballot(!ok)) { if (lane == 0) atomicOr(&ec.ctr->err, ERRB_EMPTY_CIGAR); bad = true; }

@@ -17,6 +17,7 @@ enum : uint32_t {
   ERRB_ZERODIV = 1u << 4,
   ERRB_CAPACITY = 1u << 5,
   ERRB_RANGE = 1u << 6,  // a 64-record batch spans >= 2^31 CIGAR ops
+  ERRB_SEQLEN = 1u << 8,         // a walked record carries VSV_F_SEQ_MISMATCH (H:397-398)
   ERRB_SORT_FALLBACK = 1u << 7,  // a bucket of the bucket sort did not fit in LDS: the run is repeated with the LSD passes
 };
 
