@@ -37,8 +37,8 @@ for hp in (1, 2):
 subprocess.check_call([sys.executable, here + "/svim_asm_bnd.py", "diploid", raw, raw + "assembly_hp1.bam", raw + "assembly_hp2.bam", a.reference, "--query_names"])
 subprocess.check_call([sys.executable, here + "/filter_tra.py", "-vcf", raw + "variants.vcf", "-o", out + "/TRA/", "-bam", str(a.bam_file)])
 code = os.environ.get("VOLCANOSV_COMPLEX_CODE_DIR")
-pipeline.spawn_reference_script(code, "align_ins2ref.py", "-i %s -o %s/DUP -d %s -ref %s -t %d" % (a.indelvcf, out, a.data_type, a.reference, a.n_thread))
-pipeline.spawn_reference_script(code, "filter_inv.py", "-vcf %s/variants.vcf -o %s/INV/ -bam %s" % (raw, out, a.bam_file))
+pipeline.spawn_reference_script(code, "align_ins2ref.py", ["-i", a.indelvcf, "-o", out + "/DUP", "-d", a.data_type, "-ref", a.reference, "-t", a.n_thread])
+pipeline.spawn_reference_script(code, "filter_inv.py", ["-vcf", raw + "/variants.vcf", "-o", out + "/INV/", "-bam", a.bam_file])
 lines = [l for l in open(out + "/TRA/TRA_final.vcf") if l[0] == '#']
 for part in ("DUP/DUP_final.vcf", "TRA/TRA_final.vcf", "INV/INV_final.vcf"):
     if os.path.exists(out + "/" + part):

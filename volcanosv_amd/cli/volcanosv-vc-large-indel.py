@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Drop-in for Large_INDEL/volcanosv-vc-large-indel.py (same flags, plus --gpus). Chromosomes fan out over GPUs (one
-Raw_variant_call.py process per chromosome, LPT over the visible devices) instead of joblib over CPU cores; the signature
-filter and the genotype correction that follow (filter_GT_correction.py) run in this process on the GPU."""
+Raw_variant_call.py process per chromosome, LPT over the visible devices) instead of joblib over CPU cores: at most
+--n_thread of them run at a time (the reference's joblib.Parallel(n_jobs=n_thread), volcanosv-vc-large-indel.py:268), each
+GPU working down its own queue; a chromosome that fails stops the run with its command. The signature filter and the
+genotype correction that follow (filter_GT_correction.py) run in this process on the GPU."""
 import argparse
 import os
 import subprocess
@@ -37,15 +39,35 @@ pipeline.split_reference(a.reference, ref_dir, a.chr_num)
 chroms = [a.chr_num] if a.chr_num is not None else list(range(1, 23))
 fai = {l.split("\t")[0]: int(l.split("\t")[1]) for l in open(a.reference + ".fai")}
 owner = shard.lpt_assign([fai.get("chr%d" % c, 1) for c in chroms], max(1, a.gpus))
-procs = []
-for c, g in zip(chroms, owner):
+import shlex  # noqa: E402
+from concurrent.futures import ThreadPoolExecutor  # noqa: E402
+
+n_gpus = max(1, a.gpus)
+# every process runs minimap2 -t n_thread_align + samtools sort and holds GPU contexts: n_thread bounds how many run at once
+# (spread evenly over the GPUs, at least one per GPU)
+per_gpu = max(1, max(1, a.n_thread) // n_gpus)
+
+
+def run_chromosome(c, g):
     fasta = a.input_dir + "/chr%d/assembly/final_contigs/%s_final_contigs.fa" % (c, a.prefix)
-    sig = "-sigd %s" % a.read_signature_dir if a.read_signature_dir else "-rbam %s" % a.bam_file
-    cmd = "python3 %s/Raw_variant_call.py -contig %s -ref %s %s -o %s -dtype %s -t %d -chr %d -header %s" % (
-        here, fasta, ref_dir + "/chr%d.fa" % c, sig, out + "/chr%d/" % c, a.data_type, a.n_thread_align, c, header_file)
-    procs.append(subprocess.Popen(cmd, shell=True, env=dict(os.environ, HIP_VISIBLE_DEVICES=str(g))))
-for pr in procs:
-    pr.wait()
+    cmd = [sys.executable, os.path.join(here, "Raw_variant_call.py"), "-contig", fasta, "-ref", ref_dir + "/chr%d.fa" % c]
+    cmd += ["-sigd", a.read_signature_dir] if a.read_signature_dir else ["-rbam", a.bam_file]
+    cmd += ["-o", out + "/chr%d/" % c, "-dtype", a.data_type, "-t", str(a.n_thread_align), "-chr", str(c), "-header", header_file]
+    rc = subprocess.call(cmd, env=dict(os.environ, HIP_VISIBLE_DEVICES=str(g)))
+    return c, rc, " ".join(shlex.quote(x) for x in cmd)
+
+
+failed = []
+with ThreadPoolExecutor(max_workers=n_gpus * per_gpu) as pool:
+    # LPT order (largest chromosome first) inside every GPU's queue; the pool size is the concurrency bound
+    order = sorted(zip(chroms, owner), key=lambda t: -fai.get("chr%d" % t[0], 1))
+    for c, rc, cmd in pool.map(lambda t: run_chromosome(*t), order):
+        if rc != 0:
+            failed.append((c, rc, cmd))
+if failed:
+    for c, rc, cmd in failed:
+        print("chr%d: Raw_variant_call.py exited with status %d: %s" % (c, rc, cmd), file=sys.stderr)
+    sys.exit(1)
 body, header = [], open(header_file).readlines()
 for c in chroms:
     path = out + '/chr%d/final_vcf/volcano_variant_no_redundancy.vcf' % c

@@ -31,7 +31,6 @@ struct vsv_handle {
   int64_t last_count = 0;
   // capacities
   int64_t cap_sigs = 0, cap_records = 0, cap_ops = 0;
-  std::vector<DevBuf*> all;
   // record upload buffers (host-pointer callers)
   DevBuf r_pos, r_tid, r_qid, r_off, r_mapq, r_flag, r_cigar;
   DevBuf g_off, g_qs, g_qe, g_rid, g_rs, g_re, g_rev, g_hap, g_len, g_rank;   // segment uploads (BND branch)
@@ -60,7 +59,6 @@ struct vsv_handle {
   std::string names_blob, sa_text;     // name table / SA tag texts of the last device parse (host copies)
   bool want_sa = false;                // vsv_bam_set_want_sa: the device parse also collects the SA:Z texts
   DevBuf o_saoff, o_salen, o_saloc, o_sa;
-  std::string names_blob_unused;   // support join (post-filter)
   int pass_cursor = 0;
   const uint64_t* sorted_key = nullptr;   // sorted keys of the stage just sorted (cluster / pair read them)
   bool small_sort_tiles = true;    // radix tile size, re-decided after every run from its row counts
@@ -1062,6 +1060,8 @@ int vsv_bam_parse_device(vsv_handle* h, const uint8_t* comp, const uint64_t* com
   const int64_t nk = (int64_t)K0;
   out->n_records = nk; out->n_ops = (int64_t)C0; out->n_tids = n_ref;
   if (nk == 0) return 0;
+  // the name table's offsets are 32-bit scans (per window the inflated bytes bound them; over the whole file N0 does)
+  if (N0 > 0xFFFFFFF0ull) return fail(h, VSV_E_CAPACITY, "more than 4 GiB of query names for the device reader: use the host reader");
   if (h->want_sa && S0 > 0) {      // one text per record, '\n' between them (the last separator is dropped)
     h->sa_text.resize((size_t)S0);
     HIPCHK(h, hipMemcpyAsync(&h->sa_text[0], h->o_sa.p, (size_t)S0, hipMemcpyDeviceToHost, st));

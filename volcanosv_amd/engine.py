@@ -276,6 +276,9 @@ class Engine:
             import torch
             ts = [t.contiguous().to(torch.int32) for t in (call_pos, call_len, sig_pos, sig_len)]
             out = torch.empty(len(ts[0]), dtype=torch.int32, device=ts[0].device)
+            # the library reads these on ITS stream: the conversions above (torch's current stream) must have finished; its
+            # own stream is synchronised before the call returns, so `out` is complete for whoever reads it next
+            torch.cuda.current_stream(ts[0].device).synchronize()
             self._check(self.lib.vsv_support_join(self.h, ts[0].data_ptr(), ts[1].data_ptr(), len(ts[0]), ts[2].data_ptr(), ts[3].data_ptr(),
                                                   len(ts[2]), C.byref(p), 1, out.data_ptr()))
             return out
@@ -291,6 +294,7 @@ class Engine:
         if hasattr(arrays[0], "data_ptr"):
             import torch
             ts = [t.contiguous().to(torch.int32) for t in arrays]
+            torch.cuda.current_stream(ts[0].device).synchronize()      # see support_join: the library reads on its own stream
             return [t.data_ptr() for t in ts], ts, 1, ts[0].device
         a = [np.ascontiguousarray(x, dtype=np.int32) for x in arrays]
         return [x.ctypes.data_as(C.c_void_p) for x in a], a, 0, None

@@ -1,8 +1,12 @@
 """Host glue around the hot path: the parts of the reference's L4/L5 drivers that the CLI contract needs
 (Large_INDEL/volcanosv-vc-large-indel.py, Raw_variant_call.py; Complex_SV/volcanosv-vc-complex-sv.py).
-External tools (minimap2, samtools) and the post-filters (FP_filter_v1.py, remove_redundancy.py, filter_GT_correction.py)
-are NOT re-implemented: they are spawned when available, exactly where the reference spawns them."""
+The aligner stays external (minimap2 | samtools sort, spawned where the reference spawns it). The post-filters of the
+Large_INDEL calling stage (FP_filter_v1.py, remove_redundancy.py, calculate_signature_support.py, filter_GT_correction.py)
+run in-process on the GPU (fp_filter.py, remove_redundancy.py, signature_support.py, gt_correction.py); only the
+Complex_SV extras that are out of this build's scope (align_ins2ref.py, filter_inv.py) can still be spawned from a
+reference checkout, and only when VOLCANOSV_CODE_DIR names one (off by default)."""
 import os
+import shlex
 import shutil
 import subprocess
 
@@ -103,20 +107,38 @@ def phase_complex(lines):
 
 def align_contigs(reference, contigs, bam_out, preset, threads, mem="1G"):
     """minimap2 -a -x <preset> --cs -r2k | samtools sort ; samtools index (Raw_variant_call.py:49-58). Uses an existing
-    BAM if the tools are missing."""
+    BAM if the tools are missing. A failing aligner or sort raises (the reference ignores the status and calls variants on
+    whatever the redirection left behind): the pipe runs under pipefail into a temporary file that only a clean run renames."""
     if have("minimap2") and have("samtools"):
-        cmd = "minimap2 -a -x %s --cs -r2k -t %d %s %s | samtools sort -@ %d -m %s > %s && samtools index %s" % (
-            preset, threads, reference, contigs, threads, mem, bam_out, bam_out)
-        subprocess.call(cmd, shell=True)
+        tmp = bam_out + ".tmp.%d" % os.getpid()
+        q = shlex.quote
+        cmd = "set -o pipefail; minimap2 -a -x %s --cs -r2k -t %d %s %s | samtools sort -@ %d -m %s > %s" % (
+            q(preset), threads, q(reference), q(contigs), threads, q(mem), q(tmp))
+        try:
+            rc = subprocess.call(["bash", "-c", cmd])
+            if rc != 0:
+                raise RuntimeError("minimap2 | samtools sort exited with status %d: %s" % (rc, cmd))
+            os.replace(tmp, bam_out)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+        rc = subprocess.call(["samtools", "index", bam_out])
+        if rc != 0:
+            raise RuntimeError("samtools index %s exited with status %d" % (bam_out, rc))
     if not os.path.exists(bam_out):
         raise FileNotFoundError("%s not found and minimap2/samtools are not on PATH (the aligner is external to this build)" % bam_out)
     return bam_out
 
 
 def spawn_reference_script(code_dir, script, args):
-    """Runs one of the reference's own post-filter scripts when a checkout is configured (VOLCANOSV_CODE_DIR)."""
+    """Runs one of the reference's own scripts from a checkout named by VOLCANOSV_CODE_DIR (off unless it is set): only the
+    Complex_SV extras outside this build's scope use it. `args`: list of arguments. Returns False when no checkout is
+    configured; a script that fails raises."""
     path = os.path.join(code_dir or "", script)
     if code_dir and os.path.exists(path):
-        subprocess.call("python3 %s %s" % (path, args), shell=True)
+        argv = ["python3", path] + (shlex.split(args) if isinstance(args, str) else [str(x) for x in args])
+        rc = subprocess.call(argv)
+        if rc != 0:
+            raise RuntimeError("%s exited with status %d" % (" ".join(shlex.quote(x) for x in argv), rc))
         return True
     return False
