@@ -78,8 +78,8 @@ typedef struct vsv_records {
   const uint8_t* flag;         /* [n]   VSV_F_* bits                                               */
   const uint32_t* cigar;       /* [n_ops] BAM packing: len<<4 | op ; 16-byte aligned               */
   int32_t on_device;           /* 0: host pointers (library uploads), 1: device pointers — their contents must be complete
-                                  before the call: the library reads them on the handle's stream and does not know the
-                                  stream that produced them                                          */
+                                  before the call, or ordered before the handle's stream with vsv_wait_for_stream: the
+                                  library reads them on the handle's stream and does not know the stream that produced them */
   int32_t n_qids;              /* max qid + 1 (required when n_records > 0)                            */
   int32_t n_tids;              /* max tid + 1; 0 = unknown (16 key bits are reserved for it)       */
   int32_t max_pos;             /* upper bound of pos (e.g. contig length); 0 = unknown. Only trims sort passes. */
@@ -165,6 +165,11 @@ int64_t vsv_last_count(vsv_handle* h);
 
 /* params with the reference's hard-coded values for `dtype` */
 int vsv_default_params(int dtype, vsv_params* p);
+
+/* Device-resident inputs are read on the HANDLE's stream. If another stream produced them and may still be running, either
+ * synchronise that stream on the host before the call, or call this first: the handle's stream will wait (on the device, no host
+ * synchronisation) for everything enqueued on `producer_hip_stream` (a hipStream_t; NULL = the default stream) so far. */
+int vsv_wait_for_stream(vsv_handle* h, void* producer_hip_stream);
 
 /* capacity (rows) of the signature tables; default 1<<22. Re-allocates the workspace. */
 int vsv_reserve(vsv_handle* h, int64_t max_records, int64_t max_ops, int64_t max_sigs);

@@ -700,3 +700,33 @@ def test_bucket_sort_overflow_falls_back_to_the_lsd_passes():
         assert r.returncode == 0 and "SORT_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
         outs.append(r.stdout.strip().splitlines()[-1])
     assert outs[0] == outs[1] == outs[2]
+
+
+def test_inputs_produced_on_another_stream():
+    """include/volcanosv.h: device-resident inputs are read on the handle's stream. A caller whose arrays are still being produced
+    on another stream orders the two on the device with vsv_wait_for_stream (Engine.wait_for_stream) instead of a host
+    synchronisation: records generated on a side stream behind a long-running kernel, engine on its own stream, no host sync in
+    between — the tables are the oracle's."""
+    import torch
+    from volcanosv_amd import synth
+    from volcanosv_amd.engine import DeviceRecords, Engine, default_params
+    dev = torch.device("cuda", 0)
+    prod, own = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    t_host, nq, nt = synth.generate(300000, "hifi", seed=55, chrom_len=20_000_000)
+    want_soa = synth.to_soa(t_host, nq)
+    st, want = oracle_run(want_soa, DTYPE_HIFI)
+    assert st == 0
+    pinned = {k: v.pin_memory() for k, v in t_host.items()}
+    with Engine(0, stream=own.cuda_stream) as e:
+        for _ in range(3):
+            with torch.cuda.stream(prod):
+                busy = torch.randn(8192, 8192, device=dev)
+                for _k in range(6):
+                    busy = busy @ busy * 1e-4                      # keeps the producer stream busy for a while
+                t = {k: v.to(dev, non_blocking=True) for k, v in pinned.items()}   # the records arrive behind it
+            recs = DeviceRecords(t, nq, nt, sync=False)
+            e.wait_for_stream(prod.cuda_stream)
+            e.run(recs, default_params(DTYPE_HIFI))
+            got = e.tables(DTYPE_HIFI)
+            assert_tables_equal(got, want, list(got.keys()))
+            del t

@@ -483,6 +483,19 @@ void vsv_destroy(vsv_handle* h) {
 const char* vsv_last_error(vsv_handle* h) { return h ? h->err.c_str() : "null handle"; }
 int64_t vsv_last_count(vsv_handle* h) { return h ? h->last_count : 0; }
 
+int vsv_wait_for_stream(vsv_handle* h, void* producer_hip_stream) {
+  if (!h) return VSV_E_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  if ((hipStream_t)producer_hip_stream == h->stream) return 0;          // same stream: already ordered
+  hipEvent_t ev;
+  HIPCHK(h, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  hipError_t e = hipEventRecord(ev, (hipStream_t)producer_hip_stream);
+  if (e == hipSuccess) e = hipStreamWaitEvent(h->stream, ev, 0);
+  (void)hipEventDestroy(ev);                                              // released once the wait has been satisfied
+  if (e != hipSuccess) return fail(h, VSV_E_HIP, std::string("vsv_wait_for_stream: ") + hipGetErrorString(e));
+  return 0;
+}
+
 int vsv_reserve(vsv_handle* h, int64_t max_records, int64_t max_ops, int64_t max_sigs) {
   if (!h) return VSV_E_INVALID;
   if (hipSetDevice(h->device) != hipSuccess) return VSV_E_HIP;

@@ -29,12 +29,14 @@ def default_params(dtype):
 class DeviceRecords:
     """Record SoA already resident in HBM: a dict of torch CUDA tensors (pos,tid,qid,cigar_off,mapq,flag,cigar)."""
 
-    def __init__(self, tensors, n_qids=0, n_tids=0, max_pos=0, tid_lo=0):
-        """max_pos / tid_lo are the sort-key hints of vsv_records: positions <= max_pos, tids in [tid_lo, n_tids)."""
+    def __init__(self, tensors, n_qids=0, n_tids=0, max_pos=0, tid_lo=0, sync=True):
+        """max_pos / tid_lo are the sort-key hints of vsv_records: positions <= max_pos, tids in [tid_lo, n_tids).
+        sync=False: the caller orders the producer before the engine itself (Engine.wait_for_stream)."""
         self.t = tensors
         # the engine reads these arrays on ITS stream: whatever produced them (normally torch's current stream) must be done
-        import torch
-        torch.cuda.current_stream(tensors["pos"].device).synchronize()
+        if sync:
+            import torch
+            torch.cuda.current_stream(tensors["pos"].device).synchronize()
         self.max_pos, self.tid_lo = int(max_pos), int(tid_lo)
         self.n_records = int(tensors["pos"].numel())
         self.n_ops = int(tensors["cigar"].numel())
@@ -85,6 +87,11 @@ class Engine:
     def _check(self, st):
         if st:
             raise VsvError(st, self.lib.vsv_last_error(self.h).decode())
+
+    def wait_for_stream(self, hip_stream):
+        """Device-side ordering: this engine's stream waits for what has been enqueued on `hip_stream` (a raw hipStream_t, e.g.
+        torch.cuda.current_stream().cuda_stream) — for device-resident inputs another stream is still producing."""
+        self._check(self.lib.vsv_wait_for_stream(self.h, C.c_void_p(hip_stream or 0)))
 
     def reserve(self, max_records, max_ops, max_sigs):
         self._check(self.lib.vsv_reserve(self.h, int(max_records), int(max_ops), int(max_sigs)))
