@@ -292,6 +292,10 @@ int vsv_span_count(vsv_handle* h, const vsv_records* recs, const int32_t* q_tid,
 enum { VSV_T_CUTESV_SPLIT = 10 };
 int vsv_cutesv_split(vsv_handle* h, const vsv_segments* segs, const int32_t* read_len, const uint32_t* read_rec,
                      int32_t sv_size, int32_t max_size, int32_t max_split_parts);
+/* has_tra[r] = 1 when read r of the last vsv_cutesv_split yields a translocation candidate (analysis_bnd, SE:100-191, reached with
+ * its two segments at most 100 read bases apart): such a candidate never reaches INS.sigs / DEL.sigs, but it keeps the read's 10 Mb
+ * task from being skipped as empty (SE:533-535), i.e. the task's reads are written to reads.sigs. Host array of n_reads bytes. */
+int vsv_cutesv_split_tra(vsv_handle* h, uint8_t* has_tra, int64_t n_reads);
 
 /* ---- post-filter: read-signature support of the calls (the step right of the path) -------------------
  * Replaces FP_filter_v1.eval_sig + compare_sigs (Large_INDEL/FP_filter_v1.py:87-123), run by Raw_variant_call.py:91-96

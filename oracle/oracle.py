@@ -50,7 +50,7 @@ def lib():
         _LIB.orc_default_redundancy_params.argtypes = [C.POINTER(RedundancyParams)]
         _LIB.orc_redundancy_pairs.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(RedundancyParams), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
         _LIB.orc_free_u32.argtypes = [C.c_void_p]
-        _LIB.orc_cutesv_split.argtypes = [C.POINTER(Segments), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        _LIB.orc_cutesv_split.argtypes = [C.POINTER(Segments), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p]
         _LIB.orc_cov_ins.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
         _LIB.orc_cov_del.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
         _LIB.orc_default_support_params.argtypes = [C.POINTER(SupportParams)]
@@ -160,18 +160,20 @@ def run_cov_del(call_start, call_end, sig_start, sig_end, sig_svlen, flanking=10
     return st, out, has
 
 
-def run_cutesv_split(seg, read_len, read_rec, sv_size=30, max_size=100000, max_split_parts=7):
-    """analysis_split_read INS/DEL candidates on the host: SIG_DTYPE rows in (read, emission) order."""
+def run_cutesv_split(seg, read_len, read_rec, sv_size=30, max_size=100000, max_split_parts=7, tra=False):
+    """analysis_split_read INS/DEL candidates on the host: SIG_DTYPE rows in (read, emission) order. tra=True: also the per-read
+    "yields a translocation candidate" flags (uint8)."""
     s = seg.as_struct()
     rl = np.ascontiguousarray(read_len, dtype=np.int32)
     rr = np.ascontiguousarray(read_rec, dtype=np.uint32)
     a, na = C.c_void_p(), C.c_int64()
+    flags = np.zeros(len(rl), dtype=np.uint8)
     st = lib().orc_cutesv_split(C.byref(s), rl.ctypes.data_as(C.c_void_p), rr.ctypes.data_as(C.c_void_p), int(sv_size), int(max_size),
-                                int(max_split_parts), C.byref(a), C.byref(na))
+                                int(max_split_parts), C.byref(a), C.byref(na), flags.ctypes.data_as(C.c_void_p))
     assert st == 0
     rows = _copy(a.value, na.value, SIG_DTYPE)
     lib().orc_bnd_free(a, None)
-    return rows
+    return (rows, flags) if tra else rows
 
 
 def levenshtein(a, b):

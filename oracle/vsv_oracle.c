@@ -969,11 +969,15 @@ static void orc_pair_rule(orc_cseg e1, orc_cseg e2, const orc_cseg* e3, int64_t 
         if (!e3 || e3->rs >= e2.re) orc_cput(out, 1, e1.re, del, 0, 0, e2.chr, 0, rec);  /* SE:270 */
   }
 }
+/* tra (optional, one byte per read): the read yields a translocation candidate — analysis_bnd (SE:100-191) is reached and its two
+ * segments lie at most 100 read bases apart (SE:109). Those candidates never reach INS.sigs / DEL.sigs, but a task that holds one
+ * is not "empty" (SE:533-535), so its reads go to reads.sigs. */
 int orc_cutesv_split(const vsv_segments* sg, const int32_t* read_len, const uint32_t* read_rec, int32_t sv_size, int32_t max_size,
-                     int32_t max_parts, vsv_sig** rows_out, int64_t* n_rows) {
+                     int32_t max_parts, vsv_sig** rows_out, int64_t* n_rows, uint8_t* tra) {
   sigvec out = {0};
   for (int64_t r = 0; r < sg->n_reads; ++r) {
     int64_t a = (int64_t)sg->seg_off[r], n = (int64_t)sg->seg_off[r + 1] - a;
+    if (tra) tra[r] = 0;
     if (!(n <= max_parts || max_parts == -1)) continue;                                   /* SE:370 */
     orc_cseg* S = (orc_cseg*)malloc(sizeof(orc_cseg) * (size_t)(n + 1));
     for (int64_t k = 0; k < n; ++k) {                                                     /* sorted(key=x[0]), stable (SE:198) */
@@ -991,7 +995,7 @@ int orc_cutesv_split(const vsv_segments* sg, const int32_t* read_len, const uint
           if (e1.rev) { e1 = orc_cflip(S[1], rl); e2 = orc_cflip(S[0], rl); qrev ^= 1; }   /* SE:212-215 */
           orc_pair_rule(e1, e2, NULL, sv, mx, qrev, rec, &out);
         }
-      } else trigger = 1;                                                                 /* SE:237-239 */
+      } else { trigger = 1; if (tra && e2.qs - e1.qe <= 100) tra[r] = 1; }                /* SE:237-239: analysis_bnd */
     } else {
       for (int64_t k = 0; k + 2 < n; ++k) {                                               /* SE:243 */
         orc_cseg e1 = S[k], e2 = S[k + 1], e3 = S[k + 2];
@@ -1003,7 +1007,11 @@ int orc_cutesv_split(const vsv_segments* sg, const int32_t* read_len, const uint
               if (n - 3 == k) orc_pair_rule(e2, e3, NULL, sv, mx, qrev, rec, &out);        /* SE:277-296 */
             }
           }
-        } else trigger = 1;                                                               /* SE:298-299 */
+        } else {                                                                          /* SE:298-302: analysis_bnd */
+          trigger = 1;
+          if (tra && e2.qs - e1.qe <= 100) tra[r] = 1;
+          if (tra && n - 3 == k && e2.chr != e3.chr && e3.qs - e2.qe <= 100) tra[r] = 1;
+        }
       }
       if (n >= 3 && trigger) {                                                            /* SE:305-319 */
         orc_cseg f = S[0], l = S[n - 1];

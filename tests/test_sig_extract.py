@@ -135,11 +135,16 @@ def test_oracle_split_branch_matches_reference(doc):
     from oracle import oracle
     from volcanosv_amd import sig_extract
     reads, soa, seg, names = split_inputs(doc)
-    rows = oracle.run_cutesv_split(seg, seg.read_len, seg.read_rec, 30, 100000, 7)
+    rows, tra = oracle.run_cutesv_split(seg, seg.read_len, seg.read_rec, 30, 100000, 7, tra=True)
     got = sig_extract.split_candidates(soa, rows, lambda rec: reads[rec]["seq"], lambda t: names[t])
     want = split_expected(doc)
     assert got == want
     assert sum(len(v) for v in want.values()) > 50 and any(len(c) == 6 for v in want.values() for c in v)
+    # the translocation candidates of analysis_bnd (7 fields, "TRA"): which reads yield one decides whether a task without any
+    # INS/DEL candidate still writes its reads (SE:533-535)
+    want_tra = {i for i, e in enumerate(doc["cases"]["split"]["expected"]) if any(len(x) == 7 and x[5] == "TRA" for x in e)}
+    got_tra = {int(seg.read_rec[r]) for r in np.flatnonzero(tra)}
+    assert got_tra == want_tra and len(want_tra) > 10
 
 
 @pytest.mark.gpu
@@ -151,7 +156,8 @@ def test_gpu_split_branch_matches_reference_and_oracle(doc):
     with Engine(0) as eng:
         for parts, size in ((7, 100000), (-1, -1), (3, 2000)):
             rows = eng.cutesv_split(seg, seg.read_len, seg.read_rec, 30, size, parts)
-            assert np.array_equal(rows, oracle.run_cutesv_split(seg, seg.read_len, seg.read_rec, 30, size, parts))
+            orows, otra = oracle.run_cutesv_split(seg, seg.read_len, seg.read_rec, 30, size, parts, tra=True)
+            assert np.array_equal(rows, orows) and np.array_equal(eng.cutesv_split_tra(), otra)
         rows = eng.cutesv_split(seg, seg.read_len, seg.read_rec, 30, 100000, 7)
         got = sig_extract.split_candidates(soa, rows, lambda rec: reads[rec]["seq"], lambda t: names[t])
         assert got == split_expected(doc)

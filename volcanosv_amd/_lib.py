@@ -16,7 +16,7 @@ _lib = None
 # every symbol include/volcanosv.h declares
 SYMBOLS = [
     "vsv_abi_version", "vsv_status_string", "vsv_create", "vsv_destroy", "vsv_bam_device_want_sa", "vsv_bam_device_sa_tags", "vsv_stream_ceiling", "vsv_bgzf_set_expected_crc", "vsv_last_error", "vsv_last_count",
-    "vsv_default_params", "vsv_reserve", "vsv_wait_for_stream", "vsv_cigar_scan", "vsv_split_pairs", "vsv_sort_cluster", "vsv_merge_sources",
+    "vsv_default_params", "vsv_reserve", "vsv_wait_for_stream", "vsv_cutesv_split_tra", "vsv_cigar_scan", "vsv_split_pairs", "vsv_sort_cluster", "vsv_merge_sources",
     "vsv_pair_haplotypes", "vsv_run_chromosome", "vsv_run_chromosome_async", "vsv_finish", "vsv_table_count",
     "vsv_table_fill", "vsv_last_scan_ms", "vsv_default_bnd_params", "vsv_bnd_segments", "vsv_bnd_pair", "vsv_bnd_set_candidates",
     "vsv_cutesv_split", "vsv_gt_support", "vsv_span_count", "vsv_bgzf_inflate", "vsv_bam_set_inflate_device", "vsv_bam_parse_device", "vsv_copy_to_host", "vsv_bam_load_device", "vsv_bam_l_seq_device",
@@ -57,6 +57,7 @@ def load():
     lib.vsv_default_params.argtypes = [C.c_int, C.POINTER(Params)]
     lib.vsv_reserve.argtypes = [H, C.c_int64, C.c_int64, C.c_int64]
     lib.vsv_wait_for_stream.argtypes = [H, C.c_void_p]
+    lib.vsv_cutesv_split_tra.argtypes = [H, C.c_void_p, C.c_int64]
     for name in ("vsv_cigar_scan", "vsv_split_pairs", "vsv_run_chromosome", "vsv_run_chromosome_async"):
         getattr(lib, name).argtypes = [H, C.POINTER(Records), C.POINTER(Params)]
     for name in ("vsv_sort_cluster", "vsv_merge_sources", "vsv_pair_haplotypes"):

@@ -52,6 +52,7 @@ struct vsv_handle {
   DevBuf arena;                    // Counters | emit-pool cursors | part-count tile sums | sort digit totals: zeroed by ONE fill per run
   uint32_t* tile_cnt = nullptr;
   DevBuf j_cpos, j_clen, j_spos, j_slen, j_send, j_out, j_err;
+  DevBuf cs_tra; int64_t cs_reads = -1;   // vsv_cutesv_split: per-read translocation flags of the last call
   DevBuf z_comp, z_coff, z_ooff, z_out, z_stat;          // BGZF inflate
   DevBuf p_spec, p_cnt, p_land, p_base, p_recoff, p_pos, p_tid, p_mapq, p_flag, p_lseq, p_sflag, p_ncig, p_cgsrc, p_hash, p_keep, p_kidx,
       p_cigoff, p_sums, p_tot, p_err;                     // device BAM parse: per input record
@@ -472,7 +473,7 @@ void vsv_destroy(vsv_handle* h) {
                     &h->g_re, &h->g_rev, &h->g_hap, &h->g_len, &h->g_rank, &h->j_cpos, &h->j_clen, &h->j_spos, &h->j_slen, &h->j_send, &h->j_out, &h->j_err, &h->z_comp, &h->z_coff, &h->z_ooff, &h->z_out, &h->z_stat, &h->p_spec, &h->p_cnt, &h->p_land, &h->p_base, &h->p_recoff, &h->p_pos, &h->p_tid,
                     &h->p_mapq, &h->p_flag, &h->p_lseq, &h->p_sflag, &h->p_ncig, &h->p_cgsrc, &h->p_hash, &h->p_keep, &h->p_kidx, &h->p_cigoff, &h->p_sums,
                     &h->p_tot, &h->p_err, &h->o_pos, &h->o_tid, &h->o_qid, &h->o_cigoff, &h->o_mapq, &h->o_flag, &h->o_cigar, &h->o_lseq, &h->o_sflag,
-                    &h->o_hash, &h->o_recoff, &h->o_first, &h->o_rank, &h->o_nlen, &h->o_noff, &h->o_blob, &h->o_n, &h->o_names, &h->o_nmoff, &h->o_nmlen, &h->gflag, &h->cmask, &h->o_saoff, &h->o_salen, &h->o_saloc, &h->o_sa};
+                    &h->o_hash, &h->o_recoff, &h->o_first, &h->o_rank, &h->o_nlen, &h->o_noff, &h->o_blob, &h->o_n, &h->o_names, &h->o_nmoff, &h->o_nmlen, &h->gflag, &h->cmask, &h->cs_tra, &h->o_saoff, &h->o_salen, &h->o_saloc, &h->o_sa};
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
   if (h->pinned) hipHostFree(h->pinned);
   if (h->ev0) hipEventDestroy(h->ev0);
@@ -691,13 +692,25 @@ int vsv_cutesv_split(vsv_handle* h, const vsv_segments* sg, const int32_t* read_
   if ((st = ensure(h, h->j_spos, (size_t)sg->n_reads * 4 + 16))) return st;      // rows per read
   if ((st = ensure(h, h->j_slen, (size_t)sg->n_reads * 4 + 16))) return st;      // their exclusive scan
   if ((st = ensure(h, h->j_err, (size_t)(sg->n_reads / 2048 + 4) * 4 + 256))) return st;
+  if ((st = ensure(h, h->cs_tra, (size_t)sg->n_reads + 16))) return st;
+  h->cs_reads = sg->n_reads;
   if (sg->n_reads > 0)
     vsv_launch_cutesv_split(h->stream, d, rl, rr, sv_size, max_size, max_split_parts, (vsv_sig*)h->c2.p, (uint32_t)h->cap_sigs,
-                            (uint32_t*)h->j_spos.p, (uint32_t*)h->j_slen.p, (uint32_t*)h->j_err.p, dctr(h));
+                            (uint32_t*)h->j_spos.p, (uint32_t*)h->j_slen.p, (uint32_t*)h->j_err.p, dctr(h), (uint8_t*)h->cs_tra.p);
   HIPCHK(h, hipGetLastError());
   st = finish(h);
   h->cutesv_rows = sg->n_reads > 0 ? (int64_t)h->host_ctr.n_alive2 : 0;
   return st;
+}
+
+int vsv_cutesv_split_tra(vsv_handle* h, uint8_t* has_tra, int64_t n_reads) {
+  if (!h || n_reads < 0 || (n_reads > 0 && !has_tra)) return VSV_E_INVALID;
+  if (h->cs_reads != n_reads) return fail(h, VSV_E_INVALID, "vsv_cutesv_split_tra: n_reads differs from the last vsv_cutesv_split");
+  if (n_reads == 0) return 0;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpyAsync(has_tra, h->cs_tra.p, (size_t)n_reads, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return 0;
 }
 
 int vsv_bnd_set_candidates(vsv_handle* h, const vsv_bnd* rows, int64_t n, const int32_t* contig_rank, int32_t n_tids, int on_device) {

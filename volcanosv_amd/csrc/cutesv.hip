@@ -49,12 +49,16 @@ constexpr int CS_MAX_SEG = 64;
 template <bool WRITE>
 __global__ __launch_bounds__(64) void cutesv_split(vsv_segments sg, const int32_t* __restrict__ read_len, const uint32_t* __restrict__ read_rec,
                                                    int sv_size, int max_size, int max_parts, vsv_sig* __restrict__ out, uint32_t cap,
-                                                   uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, Counters* ctr) {
+                                                   uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, Counters* ctr,
+                                                   uint8_t* __restrict__ tra) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= sg.n_reads) return;
+  // tra[r]: the read yields a translocation candidate (analysis_bnd reached with the two segments <= 100 read bases apart,
+  // SE:109): not an INS/DEL row, but it makes the read's task non-empty (SE:533-535: its reads go to reads.sigs)
+  uint8_t has_tra = 0;
   const uint64_t a = sg.seg_off[r], b = sg.seg_off[r + 1];
   const uint32_t n = (uint32_t)(b - a);
-  if (!WRITE) cnt[r] = 0;
+  if (!WRITE) { cnt[r] = 0; tra[r] = 0; }
   if (!(n <= (uint32_t)max_parts || max_parts == -1)) return;         // SE:370
   if (n > CS_MAX_SEG) { atomicOr(&ctr->err, ERRB_RANGE); return; }
   const uint64_t base64 = WRITE ? off[r] : 0, slots = WRITE ? cnt[r] : 0xFFFFFFFFull;
@@ -81,7 +85,7 @@ __global__ __launch_bounds__(64) void cutesv_split(vsv_segments sg, const int32_
         if (e1.rev) { const CSeg t1 = cflip(seg(1), rl), t2 = cflip(seg(0), rl); e1 = t1; e2 = t2; qrev ^= 1; }   // SE:212-215
         pair_rule(e1, e2, nullptr, sv, mx, qrev, em);
       }
-    } else trigger = 1;
+    } else { trigger = 1; if (e2.qs - e1.qe <= 100) has_tra = 1; }                                                  // SE:233-235: analysis_bnd
   } else if (n >= 3) {
     for (uint32_t k = 0; k + 2 < n; ++k) {
       CSeg e1 = seg(k), e2 = seg(k + 1), e3 = seg(k + 2);
@@ -91,7 +95,11 @@ __global__ __launch_bounds__(64) void cutesv_split(vsv_segments sg, const int32_
           pair_rule(e1, e2, &e3, sv, mx, qrev, em);
           if (n - 3 == k) pair_rule(e2, e3, nullptr, sv, mx, qrev, em);                                              // SE:277-296
         }
-      } else trigger = 1;                                                                                             // SE:298-299
+      } else {                                                                                                        // SE:298-302: analysis_bnd
+        trigger = 1;
+        if (e2.qs - e1.qe <= 100) has_tra = 1;
+        if (n - 3 == k && e2.chr != e3.chr && e3.qs - e2.qe <= 100) has_tra = 1;
+      }
     }
     if (trigger) {                                                                                                    // SE:305-319
       const CSeg f = seg(0), l = seg(n - 1);
@@ -104,7 +112,7 @@ __global__ __launch_bounds__(64) void cutesv_split(vsv_segments sg, const int32_
       }
     }
   }
-  if (!WRITE) cnt[r] = em.n;
+  if (!WRITE) { cnt[r] = em.n; tra[r] = has_tra; }
 }
 
 }  // namespace
@@ -115,11 +123,11 @@ __global__ void cutesv_set_rows(const uint32_t* __restrict__ cnt, const uint32_t
 
 void vsv_launch_cutesv_split(hipStream_t st, const vsv_segments& sg, const int32_t* read_len, const uint32_t* read_rec, int sv_size,
                              int max_size, int max_parts, vsv_sig* out, uint32_t cap, uint32_t* cnt, uint32_t* off, uint32_t* scan_tmp,
-                             Counters* ctr) {
+                             Counters* ctr, uint8_t* tra) {
   if (sg.n_reads <= 0) return;
   const int grid = (int)((sg.n_reads + 63) / 64);
-  cutesv_split<false><<<grid, 64, 0, st>>>(sg, read_len, read_rec, sv_size, max_size, max_parts, out, cap, cnt, off, ctr);
+  cutesv_split<false><<<grid, 64, 0, st>>>(sg, read_len, read_rec, sv_size, max_size, max_parts, out, cap, cnt, off, ctr, tra);
   vsv_scan_u32_exclusive(st, cnt, (int)sg.n_reads, off, scan_tmp);
-  cutesv_split<true><<<grid, 64, 0, st>>>(sg, read_len, read_rec, sv_size, max_size, max_parts, out, cap, cnt, off, ctr);
+  cutesv_split<true><<<grid, 64, 0, st>>>(sg, read_len, read_rec, sv_size, max_size, max_parts, out, cap, cnt, off, ctr, tra);
   cutesv_set_rows<<<1, 1, 0, st>>>(cnt, off, sg.n_reads, ctr);
 }

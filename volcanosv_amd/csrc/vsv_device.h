@@ -180,7 +180,7 @@ void vsv_launch_cov_del(hipStream_t st, const int32_t* call_start, const int32_t
 // cutesv.hip: sig_extract.py analysis_split_read (INS/DEL branches), lane per read
 void vsv_launch_cutesv_split(hipStream_t st, const vsv_segments& sg, const int32_t* read_len, const uint32_t* read_rec, int sv_size,
                              int max_size, int max_parts, vsv_sig* out, uint32_t cap, uint32_t* cnt, uint32_t* off, uint32_t* scan_tmp,
-                             Counters* ctr);
+                             Counters* ctr, uint8_t* tra);
 
 // redundancy.hip: remove_redundancy.py candidate pairs / DEL predicate, and the edit-distance similarity of INS pairs
 void vsv_launch_rr_pairs(hipStream_t st, bool write, const int32_t* pos, const int32_t* svlen, int64_t n, int is_del, int64_t dist,

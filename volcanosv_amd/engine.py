@@ -190,7 +190,14 @@ class Engine:
         rr = np.ascontiguousarray(read_rec, dtype=np.uint32)
         self._check(self.lib.vsv_cutesv_split(self.h, C.byref(s), rl.ctypes.data_as(C.c_void_p), rr.ctypes.data_as(C.c_void_p), int(sv_size),
                                               int(max_size), int(max_split_parts)))
+        self._cutesv_reads = len(rl)
         return self.table("cutesv_split")
+
+    def cutesv_split_tra(self):
+        """Per-read "yields a translocation candidate" flags (uint8) of the last cutesv_split call (vsv_cutesv_split_tra)."""
+        out = np.zeros(self._cutesv_reads, dtype=np.uint8)
+        self._check(self.lib.vsv_cutesv_split_tra(self.h, out.ctypes.data_as(C.c_void_p), len(out)))
+        return out
 
     def redundancy_params(self, **kw):
         p = RedundancyParams()

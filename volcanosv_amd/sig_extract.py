@@ -228,7 +228,8 @@ def sort_sigs(lines):
 def run(input_bam, reference, work_dir, batches=10000000, max_split_parts=7, min_mapq=20, min_read_len=500, merge_del_threshold=0,
         merge_ins_threshold=100, include_bed=None, min_size=30, max_size=100000, min_siglength=10, device=0, engine=None, log=print):
     """Writes <work_dir>/INS.sigs, DEL.sigs and reads.sigs like sig_extract.py (SE:575-645). The per-task files under
-    signatures/ are not kept; a task without any candidate contributes no reads (single_pipe returns early, SE:533-535)."""
+    signatures/ are not kept; a task without any candidate — INS, DEL or translocation — contributes no reads (single_pipe
+    returns early, SE:533-535)."""
     import os
 
     from .bam import BamFile
@@ -294,6 +295,11 @@ def run(input_bam, reference, work_dir, batches=10000000, max_split_parts=7, min
                     rows = eng.cutesv_split(seg, seg.read_len, seg.read_rec, min_size, max_size, max_split_parts)
                     spl = split_candidates(soa, rows, seq_of, lambda t: names[t])
                 has_cand = np.zeros(len(tix), dtype=bool)
+                if sreads:
+                    # a translocation candidate (analysis_bnd) never reaches INS.sigs / DEL.sigs, but its task is not empty:
+                    # single_pipe writes the task's reads (SE:533-535, 556-560)
+                    tra = eng.cutesv_split_tra()
+                    has_cand[task_of[np.asarray(seg.read_rec)[tra != 0]]] = True
                 for rec in sorted(set(cig) | set(spl)):
                     for c in cig.get(rec, []) + spl.get(rec, []):
                         has_cand[task_of[rec]] = True
