@@ -730,3 +730,41 @@ def test_inputs_produced_on_another_stream():
             got = e.tables(DTYPE_HIFI)
             assert_tables_equal(got, want, list(got.keys()))
             del t
+
+
+def test_pairing_in_rounds_equals_the_sequential_walk():
+    """Dense merged tables (signatures closer than 2 * pair_shift for a whole chromosome) are paired in rounds of reservations
+    instead of one wave walking the list; VSV_PAIR=rounds forces that path from a handle's first run. Every table must equal the
+    oracle's (the literal first-come-first-served loop of pair_sig, H:552-569) on dense and on ordinary inputs, and the dense
+    fuzz family must pass under it."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "from test_gpu_parity import run_both, oracle_run, assert_tables_equal\n"
+            "from helpers import fuzz_cases\n"
+            "from volcanosv_amd import synth\n"
+            "from volcanosv_amd.engine import Engine\n"
+            "from volcanosv_amd.abi import DTYPE_HIFI, DTYPE_ONT\n"
+            "with Engine(0, max_sigs=1 << 23) as e:\n"
+            "    t, nq, _ = synth.generate(4000, 'contig', seed=23, chrom_len=8_000_000)\n"      # ~8000x coverage: one stretch per list
+            "    g = run_both(e, synth.to_soa(t, nq), DTYPE_HIFI)\n"
+            "    n1 = len(g['calls'])\n"
+            "    t, nq, _ = synth.generate(200000, 'ont', seed=24, chrom_len=900_000, events_per_record=0.3, site_step=1500)\n"
+            "    run_both(e, synth.to_soa(t, nq), DTYPE_ONT)\n"
+            "    t, nq, _ = synth.generate(100000, 'hifi', seed=25)\n"
+            "    run_both(e, synth.to_soa(t, nq), DTYPE_HIFI)\n"
+            "    for case, soa, dtype, p in fuzz_cases('dense'):\n"
+            "        st, want = oracle_run(soa, dtype, p)\n"
+            "        e.run(soa, p)\n"
+            "        got = e.tables(dtype)\n"
+            "        assert_tables_equal(got, want, list(got.keys()))\n"
+            "print('PAIR_OK', n1)\n") % (root, os.path.join(root, "tests"))
+    outs = []
+    for env_extra in ({"VSV_PAIR": "rounds"}, {"VSV_PAIR": "walk"}):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env_extra), cwd=root)
+        assert r.returncode == 0 and "PAIR_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1] and int(outs[0].split()[1]) > 50000

@@ -64,6 +64,7 @@ struct vsv_handle {
   const uint64_t* sorted_key = nullptr;   // sorted keys of the stage just sorted (cluster / pair read them)
   bool small_sort_tiles = true;    // radix tile size, re-decided after every run from its row counts
   int lsd_runs = 0;                // > 0: the bucket sort overflowed recently, the next runs use the LSD passes
+  bool dense_pairing = false;      // the last run walked a pairing stretch of thousands of rows with one wave: pair in rounds
   bool in_rerun = false;
   vsv_bnd_params bnd_prm{};
   Counters host_ctr;
@@ -317,7 +318,8 @@ int enq_pair(vsv_handle* h) {
   hipStream_t st = h->stream;
   Counters* c = dctr(h);
   vsv_launch_pair(st, (vsv_sig*)h->merged.p, h->sorted_key, &c->n_alive3, h->prm.pair_shift, h->prm.pair_window, (vsv_call*)h->calls_tmp.p, (vsv_call*)h->calls.p,
-                  &c->n_calls, stage_bufs(h), (uint64_t*)h->key2.p, (uint32_t*)h->idx2.p, sort_work(h), pos_bits(h), key_bits(h), h->cap_sigs, dctr(h));
+                  &c->n_calls, stage_bufs(h), (uint64_t*)h->key2.p, (uint32_t*)h->idx2.p, sort_work(h), pos_bits(h), key_bits(h), h->cap_sigs, dctr(h),
+                  h->dense_pairing);
   HIPCHK(h, hipGetLastError());
   h->stage_done = 5;
   return 0;
@@ -330,6 +332,13 @@ int finish(vsv_handle* h) {
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->host_ctr = *h->pinned;
   h->pending = false;
+  if (h->stage_done >= 5) {   // pairing of the NEXT run: in rounds once a stretch of thousands of rows was met, back to the plain
+                              // kernel when the merged table gets small again (the rounds cost ~20 launches)
+    static const char* force = getenv("VSV_PAIR");          // tests: "rounds" / "walk"
+    if (h->host_ctr.max_stretch > 2048) h->dense_pairing = true;
+    else if (h->host_ctr.n_alive3 < 100000) h->dense_pairing = false;
+    if (force) h->dense_pairing = force[0] == 'r';
+  }
   {  // sort tile size of the NEXT run: small tiles while the largest table stays within ~128 tiles of 4096 rows
     const uint32_t big = h->host_ctr.n_s1 > h->host_ctr.n_cand ? h->host_ctr.n_s1 : h->host_ctr.n_cand;
     h->small_sort_tiles = big <= 128u * 4096u;
@@ -458,6 +467,7 @@ int vsv_create(int device_id, void* hip_stream, vsv_handle** out) {
   hipEventCreate(&h->ev0);
   hipEventCreate(&h->ev1);
   memset(&h->host_ctr, 0, sizeof h->host_ctr);
+  { const char* pm = getenv("VSV_PAIR"); h->dense_pairing = pm && pm[0] == 'r'; }     // tests: the round-based pairing from the first run
   *out = h;
   return 0;
 }

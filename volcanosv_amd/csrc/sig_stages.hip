@@ -686,9 +686,11 @@ __device__ __forceinline__ uint32_t lower_bound_key(const uint64_t* __restrict__
 // scanned 64 hp2 rows at a time and the first match is the lowest set ballot bit. Called by all 64 lanes, (i, jlo) wave-uniform.
 __device__ __forceinline__ void pair_long_stretch(const vsv_sig* __restrict__ m, const uint64_t* __restrict__ key, const uint32_t n,
                                                   int pair_shift, int right, int sh_hap, int32_t* __restrict__ st2,
-                                                  vsv_call* __restrict__ out, const uint32_t i, uint32_t jlo, const int lane) {
+                                                  vsv_call* __restrict__ out, const uint32_t i, uint32_t jlo, const int lane,
+                                                  uint32_t* __restrict__ max_stretch) {
   const uint64_t hp1_prefix = key[i] >> sh_hap, hp2_prefix = hp1_prefix | 1ull;
-  for (uint32_t a = i; a < n; ++a) {
+  uint32_t a = i;
+  for (; a < n; ++a) {
     const vsv_sig s1 = m[a];
     if ((key[a] >> sh_hap) != hp1_prefix) break;
     if (a > i && (int64_t)s1.pos - m[a - 1].pos > 2 * (int64_t)pair_shift) break;
@@ -714,12 +716,111 @@ __device__ __forceinline__ void pair_long_stretch(const vsv_sig* __restrict__ m,
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
+  if (lane == 0) atomicMax(max_stretch, a - i);     // a table with very long stretches is paired in rounds from the next run on
+}
+
+// ---- pairing in rounds: dense tables ------------------------------------------------------------------------------------
+// When signatures lie closer than 2 * pair_shift for whole chromosomes (hundreds of thousands of contigs piled on one
+// reference), a "stretch" is the entire haplotype list and the first-come-first-served walk above is one wave's job. The
+// same result in parallel ("deterministic reservations"): every undecided hp1 row reserves ALL its free candidates with its
+// index as priority (atomicMin; smaller index = earlier in the reference's order), then takes its FIRST free candidate if it
+// holds the reservation there — no earlier undecided row can then ever want that hp2 row, and the rows already decided are
+// final, so this is exactly what the sequential walk would give it; a row without a free candidate is unpaired for good (free
+// candidates only disappear). Rows that lose wait for the next round; what is left after the rounds goes through the
+// sequential rule in chains of neighbouring undecided rows (pair_leftover). Reservations carry the round in their high word,
+// so they need no clearing between rounds.
+__device__ __forceinline__ bool pair_candidate(const vsv_sig& s1, const vsv_sig& s2, int pair_shift) {
+  return ((s1.meta ^ s2.meta) & VSV_M_DEL) == 0 && vsv_match(s1, s2, pair_shift);
+}
+__global__ __launch_bounds__(256) void pair_rounds_prep(const vsv_sig* __restrict__ m, const uint64_t* __restrict__ key, const uint32_t* __restrict__ d_n,
+                                                        int pair_shift, int pb, uint32_t* __restrict__ jlo, uint32_t* __restrict__ done1,
+                                                        uint64_t* __restrict__ res) {
+  const uint32_t n = *d_n;
+  const int sh_hap = pb + 2, sh_tid = pb + 3;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const vsv_sig me = m[i];
+    done1[i] = 0;
+    res[i] = ~0ull;
+    if (me.meta & VSV_M_HP2) { jlo[i] = 0; continue; }
+    const uint64_t tk = key[i] >> sh_tid;
+    jlo[i] = lower_bound_key(key, n, (tk << sh_tid) | (1ull << sh_hap) | vsv_kpos((int32_t)max((int64_t)me.pos - pair_shift, (int64_t)-VSV_POS_BIAS)));
+  }
+}
+template <bool COMMIT>
+__global__ __launch_bounds__(256) void pair_round(const vsv_sig* __restrict__ m, const uint64_t* __restrict__ key, const uint32_t* __restrict__ d_n,
+                                                  int pair_shift, int right, int pb, int32_t* __restrict__ st2, vsv_call* __restrict__ out,
+                                                  const uint32_t* __restrict__ jlo, uint32_t* __restrict__ done1, uint64_t* __restrict__ res,
+                                                  uint32_t round) {
+  const uint32_t n = *d_n;
+  const int sh_hap = pb + 2;
+  const uint64_t stamp = (uint64_t)(~round) << 32;          // newer rounds compare smaller: old reservations lose by themselves
+  for (uint32_t a = blockIdx.x * blockDim.x + threadIdx.x; a < n; a += gridDim.x * blockDim.x) {
+    const vsv_sig s1 = m[a];
+    if ((s1.meta & VSV_M_HP2) || done1[a]) continue;
+    const uint64_t hp2_prefix = (key[a] >> sh_hap) | 1ull;
+    int32_t first = -1;
+    for (uint32_t j = jlo[a]; j < n && (key[j] >> sh_hap) == hp2_prefix; ++j) {
+      const vsv_sig s2 = m[j];
+      if ((int64_t)s2.pos - s1.pos > right) break;
+      if (ld_i32(&st2[j]) != -1 || !pair_candidate(s1, s2, pair_shift)) continue;
+      if (!COMMIT) atomicMin((unsigned long long*)&res[j], (unsigned long long)(stamp | a));
+      else { first = (int32_t)j; break; }
+    }
+    if (!COMMIT) continue;
+    vsv_call c;
+    c.a = (int32_t)a; c.pad = 0;
+    if (first < 0) { c.sig = s1; c.b = -1; c.gt = 1; out[a] = c; done1[a] = 1; }                       // Hifi.py:575-576
+    else if (res[first] == (stamp | a)) {
+      st_i32(&st2[first], (int32_t)a);
+      const vsv_sig s2 = m[first];
+      c.sig = (s1.svlen > s2.svlen) ? s1 : s2; c.b = first; c.gt = 2;                                   // Hifi.py:583-586
+      out[a] = c; done1[a] = 1;
+    }
+  }
+}
+// what the rounds left undecided: chains of undecided hp1 rows whose neighbours lie within 2 * pair_shift (rows further apart
+// share no candidate), one lane per chain, the sequential rule inside
+__global__ __launch_bounds__(256) void pair_leftover(const vsv_sig* __restrict__ m, const uint64_t* __restrict__ key, const uint32_t* __restrict__ d_n,
+                                                     int pair_shift, int right, int pb, int32_t* __restrict__ st2, vsv_call* __restrict__ out,
+                                                     const uint32_t* __restrict__ jlo, const uint32_t* __restrict__ done1) {
+  const uint32_t n = *d_n;
+  const int sh_hap = pb + 2;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const vsv_sig me = m[i];
+    if ((me.meta & VSV_M_HP2) || done1[i]) continue;
+    const uint64_t hp1_prefix = key[i] >> sh_hap, hp2_prefix = hp1_prefix | 1ull;
+    bool head = true;
+    for (uint32_t k = i; k-- > 0;) {                        // an undecided hp1 row of this list within 2 * pair_shift in front?
+      if ((key[k] >> sh_hap) != hp1_prefix || (int64_t)me.pos - m[k].pos > 2 * (int64_t)pair_shift) break;
+      if (!done1[k]) { head = false; break; }
+    }
+    if (!head) continue;
+    int32_t last_pos = me.pos;
+    for (uint32_t a = i; a < n && (key[a] >> sh_hap) == hp1_prefix; ++a) {
+      const vsv_sig s1 = m[a];
+      if ((int64_t)s1.pos - last_pos > 2 * (int64_t)pair_shift) break;      // the next undecided row, if any, leads its own chain
+      if (done1[a]) continue;
+      last_pos = s1.pos;
+      int32_t mate = -1;
+      for (uint32_t j = jlo[a]; j < n && (key[j] >> sh_hap) == hp2_prefix; ++j) {
+        const vsv_sig s2 = m[j];
+        if ((int64_t)s2.pos - s1.pos > right) break;
+        if (ld_i32(&st2[j]) == -1 && pair_candidate(s1, s2, pair_shift)) { mate = (int32_t)j; st_i32(&st2[j], (int32_t)a); break; }
+      }
+      vsv_call c;
+      c.a = (int32_t)a; c.pad = 0;
+      if (mate < 0) { c.sig = s1; c.b = -1; c.gt = 1; }
+      else { const vsv_sig s2 = m[mate]; c.sig = (s1.svlen > s2.svlen) ? s1 : s2; c.b = mate; c.gt = 2; }
+      out[a] = c;                          // (done1 stays as the rounds left it: the other lanes' head tests read it meanwhile)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
 }
 
 // A lane owns the stretch its hp1 row leads; stretches of more than LONG_RUN rows are taken over by the lane's whole wave.
 __global__ __launch_bounds__(256) void pair_kernel(const vsv_sig* __restrict__ m, const uint64_t* __restrict__ key,
                                                    const uint32_t* __restrict__ d_n, int pair_shift, int right, int pb,
-                                                   int32_t* __restrict__ st2, vsv_call* __restrict__ out) {
+                                                   int32_t* __restrict__ st2, vsv_call* __restrict__ out, uint32_t* __restrict__ max_stretch) {
   const uint32_t n = *d_n;
   const int lane = threadIdx.x & 63;
   const int sh_hap = pb + 2, sh_tid = pb + 3;
@@ -766,7 +867,7 @@ __global__ __launch_bounds__(256) void pair_kernel(const vsv_sig* __restrict__ m
     while (lm) {
       const int src = __builtin_ctzll(lm);
       lm &= lm - 1;
-      pair_long_stretch(m, key, n, pair_shift, right, sh_hap, st2, out, (uint32_t)__shfl((int)i, src, 64), (uint32_t)__shfl((int)jlo, src, 64), lane);
+      pair_long_stretch(m, key, n, pair_shift, right, sh_hap, st2, out, (uint32_t)__shfl((int)i, src, 64), (uint32_t)__shfl((int)jlo, src, 64), lane, max_stretch);
     }
   }
 }
@@ -881,12 +982,25 @@ void vsv_launch_cluster(hipStream_t st, const vsv_sig* sorted, const uint64_t* s
   cluster_kernel<<<b.grid, 256, 0, st>>>(sorted, sorted_key, d_alive, max_shift, pb, b.cl, out);
 }
 
+constexpr int PAIR_ROUNDS = 10;
 void vsv_launch_pair(hipStream_t st, const vsv_sig* merged, const uint64_t* merged_key, const uint32_t* d_alive3, int pair_shift, int pair_window,
                      vsv_call* calls_tmp, vsv_call* calls, uint32_t* d_ncalls, const StageBufs& b, uint64_t* key2, uint32_t* idx2,
-                     const SortWork& sw, int pb, int nbits, int64_t cap, Counters* ctr) {
-  // (the stage-3 gather cleared n_long and set the pairing state b.cl to -1)
+                     const SortWork& sw, int pb, int nbits, int64_t cap, Counters* ctr, bool dense) {
+  // (the stage-3 gather set the pairing state b.cl to -1)
   const int right = pair_shift < pair_window ? pair_shift : pair_window;
-  pair_kernel<<<b.grid, 256, 0, st>>>(merged, merged_key, d_alive3, pair_shift, right, pb, b.cl, calls_tmp);
+  if (dense) {
+    // the previous run of this handle walked a stretch of thousands of rows with one wave: pair in rounds instead (scratch: the
+    // call-key arrays, free until pair_finish, and the stage sort's index array)
+    uint32_t* jlo = idx2; uint32_t* done1 = b.idx; uint64_t* res = key2;
+    pair_rounds_prep<<<b.grid, 256, 0, st>>>(merged, merged_key, d_alive3, pair_shift, pb, jlo, done1, res);
+    for (uint32_t r = 0; r < (uint32_t)PAIR_ROUNDS; ++r) {
+      pair_round<false><<<b.grid, 256, 0, st>>>(merged, merged_key, d_alive3, pair_shift, right, pb, b.cl, calls_tmp, jlo, done1, res, r);
+      pair_round<true><<<b.grid, 256, 0, st>>>(merged, merged_key, d_alive3, pair_shift, right, pb, b.cl, calls_tmp, jlo, done1, res, r);
+    }
+    pair_leftover<<<b.grid, 256, 0, st>>>(merged, merged_key, d_alive3, pair_shift, right, pb, b.cl, calls_tmp, jlo, done1);
+  } else {
+    pair_kernel<<<b.grid, 256, 0, st>>>(merged, merged_key, d_alive3, pair_shift, right, pb, b.cl, calls_tmp, &ctr->max_stretch);
+  }
   pair_finish<<<b.grid, 256, 0, st>>>(merged, d_alive3, b.cl, calls_tmp, pb, b.tid_lo, key2, idx2);
   if (vsv_bucket_sort_calls(st, calls_tmp, d_alive3, pb, b.tid_lo, nbits, b.kmax, calls, key2, d_ncalls, &ctr->n_long, sw, cap)) return;
   const SortResult r = vsv_radix_sort_pairs(st, key2, idx2, sw.key_alt, sw.val_alt, d_alive3, cap, nbits, sw, b.kmax);

@@ -34,8 +34,9 @@ struct Counters {
   uint32_t n_calls;
   uint32_t n_reads;
   uint32_t err;
-  uint32_t n_long;     // long runs / stretches queued for the wave-cooperative kernels (reset per stage)
-  uint32_t pad[4];
+  uint32_t n_long;     // (unused: long runs / stretches are taken over by the discovering lane's wave)
+  uint32_t max_stretch; // longest pairing stretch one wave walked in this run: next run's hint for the round-based pairing
+  uint32_t pad[3];
 };
 
 struct RecView {
@@ -161,7 +162,7 @@ void vsv_launch_cluster(hipStream_t st, const vsv_sig* sorted, const uint64_t* s
                         int pb, vsv_sig* out, const StageBufs& b, uint64_t* long_list, Counters* ctr);
 void vsv_launch_pair(hipStream_t st, const vsv_sig* merged, const uint64_t* merged_key, const uint32_t* d_alive3, int pair_shift, int pair_window,
                      vsv_call* calls_tmp, vsv_call* calls, uint32_t* d_ncalls, const StageBufs& b, uint64_t* key2, uint32_t* idx2,
-                     const SortWork& sw, int pb, int nbits, int64_t cap, Counters* ctr);
+                     const SortWork& sw, int pb, int nbits, int64_t cap, Counters* ctr, bool dense);
 
 // bnd.hip
 void vsv_launch_bnd_segments(hipStream_t st, const vsv_segments& s, const vsv_bnd_params& p, vsv_bnd* cand, uint32_t cap, Counters* ctr);
