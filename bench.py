@@ -454,14 +454,16 @@ def main():
         traffic, traffic_source = None, None
         if b.rank == 0:
             ceil_read, ceil_copy = eng.stream_ceiling(t["cigar"], reps=5)
-            pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_cigar_scan_emit_config2.json")
-            if os.path.exists(pmc_path) and shape == "hifi":
+            # HBM bytes per launch from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs, KiB units,
+            # FETCH_SIZE doubled for the wide coalesced stream as MI355X_MICROARCH.md prescribes) of the same kernel on the same
+            # shape, scaled by the op count (which sets the traffic): a profile figure, not an in-run measurement
+            pmc_name = {"hifi": "r02_pmc_cigar_scan_emit_config2.json", "contig": "r02_pmc_cigar_scan_long_contig50k.json"}.get(shape)
+            pmc_path = os.path.join(ROOT, "profiles", pmc_name) if pmc_name else None
+            if pmc_path and os.path.exists(pmc_path):
                 pmc = json.load(open(pmc_path))
-                if abs(recs.n_ops - pmc["n_ops"]) < 0.02 * pmc["n_ops"]:
-                    # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, KiB units) on this
-                    # shape, scaled by the op count (which sets the traffic): a profile figure, not an in-run measurement
+                if shape == "contig" or abs(recs.n_ops - pmc["n_ops"]) < 0.02 * pmc["n_ops"]:
                     traffic = pmc["traffic_bytes_per_launch"] * recs.n_ops / pmc["n_ops"]
-                    traffic_source = "profiles/r01_pmc_cigar_scan_emit_config2.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes), scaled by op count"
+                    traffic_source = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes), scaled by op count" % pmc_name
         label = {2: "config2", 3: "config3", 6: "row 2c (contig-like)"}[args.config]
         line = {
             "metric": METRIC, "value": res["records_per_s"], "unit": "records/s", "n_gpus": b.world, "steps": args.steps, "warmup": args.warmup,
