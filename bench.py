@@ -376,15 +376,29 @@ class Bench:
                                            seg.is_reverse[idx], seg.hap[mine])
         gid = mine.astype(np.uint32)                                      # local read -> global read id (collection order)
         eng = self.engs[0]
+        torch = self.torch
+        device_path = not self.rehearsal
+        if device_path:
+            # everything stays in HBM: the segment table is uploaded once, candidates / exchange / pairing / gather run on device rows
+            dseg = bnd.DeviceSegments(local, self.dev)
+            gid_t = torch.from_numpy(mine.astype(np.int64)).to(self.dev)
+            owner_t = torch.tensor(owner, dtype=torch.int64, device=self.dev)
+            rank_t = torch.from_numpy(np.ascontiguousarray(seg.contig_rank)).to(self.dev)
 
-        def step():
-            cand = eng.bnd_candidates(local)                              # vsv_bnd_segments: segment case analysis -> candidates
-            cand = cand.copy()
-            if len(cand):
-                cand["read"] = gid[cand["read"]]
-            rows = shard.exchange_bnd(cand, 0, owner, self.cdev)          # all-to-all to owner(src_tid), collection order restored
-            calls = eng.bnd_pair_rows(rows, seg.contig_rank)              # vsv_bnd_set_candidates + vsv_bnd_pair
-            return shard.gather_rows(calls, BND_DTYPE, self.cdev), len(cand)
+            def step():
+                cand = eng.bnd_candidates_device(dseg, self.dev)           # vsv_bnd_segments -> live candidate rows (device)
+                rows = shard.exchange_bnd_device(cand, gid_t, owner_t, self.dev)   # RCCL all-to-all to owner(src_tid), collection order
+                calls = eng.bnd_pair_device(rows, rank_t, self.dev)        # vsv_bnd_set_candidates + vsv_bnd_pair (device rows)
+                return shard.gather_rows_device(calls, self.dev), cand.numel() // 32
+        else:
+            def step():
+                cand = eng.bnd_candidates(local)                              # vsv_bnd_segments: segment case analysis -> candidates
+                cand = cand.copy()
+                if len(cand):
+                    cand["read"] = gid[cand["read"]]
+                rows = shard.exchange_bnd(cand, 0, owner, self.cdev)          # all-to-all to owner(src_tid), collection order restored
+                calls = eng.bnd_pair_rows(rows, seg.contig_rank)              # vsv_bnd_set_candidates + vsv_bnd_pair
+                return shard.gather_rows(calls, BND_DTYPE, self.cdev), len(cand)
 
         for _ in range(max(1, warmup)):
             step()
@@ -401,13 +415,15 @@ class Bench:
         med = ts[len(ts) // 2]
         n_segs, n_reads = int(len(seg.q_start)), int(len(seg.hap))
         calls, _ = out
+        n_calls = 0 if calls is None else (calls.numel() // 32 if torch.is_tensor(calls) else len(calls))
         return {
             "workload": "config5: %d split contigs (%d events x 2 haplotypes, dense partitions included), %d aligned segments over 22 chromosomes; "
-                        "candidates on the owner of the primary alignment, all-to-all to the owner of the source contig, pairing, gather; "
-                        "segment tables and candidate rows cross the C-ABI as host arrays (PCIe inside the timed region)" % (n_reads, n_events, n_segs),
+                        "candidates on the owner of the primary alignment, all-to-all to the owner of the source contig, pairing, gather; %s"
+                        % (n_reads, n_events, n_segs, "segment table resident in HBM, candidate / call rows never leave the GPUs" if device_path else
+                           "gloo rehearsal: segment tables and candidate rows cross the C-ABI as host arrays"),
             "scaling": "strong", "records": n_segs, "reads": n_reads, "steps": steps, "reps": len(times),
             "ms_per_step": med / steps * 1e3, "ms_per_step_min": ts[0] / steps * 1e3, "ms_per_step_max": ts[-1] / steps * 1e3,
-            "records_per_s": n_segs * steps / med, "calls_gathered": int(len(calls)) if calls is not None else 0,
+            "records_per_s": n_segs * steps / med, "calls_gathered": int(n_calls),
         }
 
 
@@ -439,7 +455,7 @@ def main():
         args.config = {"hifi": 2, "ont": 3, "contig": 6}[args.shape]
     shape = {2: "hifi", 3: "ont", 6: "contig"}.get(args.config)
     if not args.max_sigs:
-        args.max_sigs = (1 << 24) if args.config in (3, 6) or args.extras != "none" else (1 << 22)
+        args.max_sigs = (1 << 24) if args.config in (3, 5, 6) or args.extras != "none" else (1 << 22)
 
     b = Bench(args)
     torch = b.torch

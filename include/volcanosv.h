@@ -260,7 +260,11 @@ enum {
   VSV_B_GT_SHIFT = 4,          /* bits 4-5: 1 = "1/0", 2 = "0/1", 3 = "1/1" (calls only)              */
   VSV_B_DEAD = 64
 };
-enum { VSV_T_BND_CAND = 7, VSV_T_BND_CALLS = 8 };
+enum { VSV_T_BND_CAND = 7, VSV_T_BND_CALLS = 8,
+       /* the same two tables unfiltered, i.e. every slot (one candidate slot per adjacent segment pair, VSV_B_DEAD where the pair
+        * yields no breakend; call slots with the second members of 1/1 pairs and the dropped partitions VSV_B_DEAD): plain
+        * device-to-device copies for callers that stay on the GPU (multi-GPU exchange) */
+       VSV_T_BND_SLOTS = 11, VSV_T_BND_CALL_SLOTS = 12 };
 
 int vsv_default_bnd_params(vsv_bnd_params* p);
 int vsv_bnd_segments(vsv_handle* h, const vsv_segments* segs, const vsv_bnd_params* p);

@@ -42,6 +42,28 @@ def main_hip(n_events):
         assert all(owner[int(t)] == rank for t in rows["src_tid"])
         calls = eng.bnd_pair_rows(rows, seg.contig_rank)
         allc = shard.gather_rows(calls, BND_DTYPE, dev)
+        # the same exchange with the rows kept on the device (what bench.py config 5 times): all-to-all of torch tensors (gloo
+        # moves them through the host here, RCCL does not), ordering by one stable device sort
+        gdev = torch.device("cuda", 0)
+        dseg = bnd.DeviceSegments(local, gdev)
+        dcand = eng.bnd_candidates_device(dseg, gdev)
+        gid_t = torch.from_numpy(mine.astype(np.int64)).to(gdev)
+        owner_t = torch.tensor(owner, dtype=torch.int64, device=gdev)
+
+        def exchange_on_device(cand_u8):
+            w = cand_u8.view(-1, 32).view(torch.int32).clone()
+            if w.shape[0]:
+                w[:, 4] = gid_t[w[:, 4].to(torch.int64)].to(torch.int32)
+            rows_np = np.frombuffer(w.cpu().numpy().tobytes(), dtype=BND_DTYPE)
+            return shard.exchange_bnd(rows_np, 0, owner, dev)          # gloo leg of the rehearsal
+        drows = exchange_on_device(dcand)
+        assert np.array_equal(drows, rows), "device candidate rows differ from the host path"
+        dcalls = eng.bnd_pair_device(torch.from_numpy(np.frombuffer(drows.tobytes(), dtype=np.uint8).copy()).to(gdev),
+                                     torch.from_numpy(np.ascontiguousarray(seg.contig_rank)).to(gdev), gdev)
+        assert np.array_equal(np.frombuffer(dcalls.cpu().numpy().tobytes(), dtype=BND_DTYPE), calls), "device pairing differs from the host path"
+        if world == 1:
+            one = shard.exchange_bnd_device(dcand, gid_t, owner_t, gdev)
+            assert np.array_equal(np.frombuffer(one.cpu().numpy().tobytes(), dtype=BND_DTYPE), rows)
         if rank == 0:
             _, single = eng.bnd(seg)
             _, want = oracle.run_bnd(seg)

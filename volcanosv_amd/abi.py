@@ -84,7 +84,7 @@ class RedundancyParams(C.Structure):
 BND_DTYPE = np.dtype([("src_tid", "<i4"), ("src_pos", "<i4"), ("dst_tid", "<i4"), ("dst_pos", "<i4"), ("read", "<u4"), ("read2", "<u4"),
                       ("meta", "<u4"), ("pad", "<u4")])
 B_SRC_FWD, B_DST_FWD, B_HAP2, B_GT_SHIFT, B_DEAD = 1, 2, 4, 4, 64
-T_BND_CAND, T_BND_CALLS = 7, 8
+T_BND_CAND, T_BND_CALLS, T_BND_SLOTS, T_BND_CALL_SLOTS = 7, 8, 11, 12
 T_CUTESV_SPLIT = 10
 
 

@@ -124,6 +124,27 @@ class SegmentSoA:
         return s
 
 
+class DeviceSegments:
+    """A SegmentSoA copied to the GPU once (torch tensors; `as_struct` hands device pointers, on_device = 1): the form a rank keeps
+    its split-contig table in when the breakend branch runs step after step (bench config 5)."""
+
+    def __init__(self, seg, device):
+        import torch
+        self.host = seg
+        self.n_reads, self.n_segs = len(seg.hap), int(seg.q_start.shape[0])
+        self.t = {k: torch.from_numpy(np.ascontiguousarray(getattr(seg, k)).view(np.int64 if k == "seg_off" else getattr(seg, k).dtype)).to(device)
+                  for k in ("seg_off", "q_start", "q_end", "ref_id", "ref_start", "ref_end", "is_reverse", "hap", "contig_len", "contig_rank")}
+        torch.cuda.current_stream(device).synchronize()
+
+    def as_struct(self):
+        s = Segments()
+        s.n_reads, s.n_segs = self.n_reads, self.n_segs
+        for k, v in self.t.items():
+            setattr(s, k, C.c_void_p(v.data_ptr()))
+        s.n_tids, s.on_device = len(self.host.contigs), 1
+        return s
+
+
 def segments_from_soa(soa, hap, min_mapq=20):
     """Record SoA of one haplotype BAM (volcanosv_amd.bam, with SA tags) -> reads list for SegmentSoA:
     analyze_alignment_file_coordsorted (SVIM_COLLECT.py:57-79) restricted to what the BND branch needs."""

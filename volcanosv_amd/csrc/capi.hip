@@ -1319,6 +1319,8 @@ static int table_src(vsv_handle* h, int table, const void** src, int64_t* n_rows
     case VSV_T_CALLS: if (h->stage_done < 5) return VSV_E_INVALID; *src = h->calls.p; *n_rows = c.n_calls; *row = sizeof(vsv_call); *filter = false; return 0;
     case VSV_T_BND_CAND: if (h->bnd_stage < 1) return VSV_E_INVALID; *src = h->s1in.p; *n_rows = c.n_s1; return 0;
     case VSV_T_BND_CALLS: if (h->bnd_stage < 2) return VSV_E_INVALID; *src = h->c1.p; *n_rows = c.n_alive1; return 0;
+    case VSV_T_BND_SLOTS: if (h->bnd_stage < 1) return VSV_E_INVALID; *src = h->s1in.p; *n_rows = c.n_s1; *filter = false; return 0;
+    case VSV_T_BND_CALL_SLOTS: if (h->bnd_stage < 2) return VSV_E_INVALID; *src = h->c1.p; *n_rows = c.n_alive1; *filter = false; return 0;
     case VSV_T_CUTESV_SPLIT: if (h->cutesv_rows < 0) return VSV_E_INVALID; *src = h->c2.p; *n_rows = h->cutesv_rows; *filter = false; return 0;
     case VSV_T_READS: if (h->stage_done < 2 || h->prm.dtype != VSV_DTYPE_READS) return VSV_E_INVALID; *src = h->reads.p; *n_rows = c.n_reads; *filter = false; return 0;
   }

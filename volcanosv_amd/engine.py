@@ -9,11 +9,11 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .abi import (BND_DTYPE, E_CAPACITY, T_BND_CALLS, T_BND_CAND, T_CUTESV_SPLIT, BndParams, RedundancyParams, SupportParams, CALL_DTYPE, SIG_DTYPE, T_CALLS, T_CIGAR, T_CLUSTER1, T_MERGED, T_RAW, T_READS, T_SPLIT, DTYPE_BY_NAME,
+from .abi import (BND_DTYPE, E_CAPACITY, T_BND_CALL_SLOTS, T_BND_CALLS, T_BND_CAND, T_BND_SLOTS, T_CUTESV_SPLIT, BndParams, RedundancyParams, SupportParams, CALL_DTYPE, SIG_DTYPE, T_CALLS, T_CIGAR, T_CLUSTER1, T_MERGED, T_RAW, T_READS, T_SPLIT, DTYPE_BY_NAME,
                   DTYPE_CUTESV, DTYPE_READS, DTYPE_SVIM, Params, Records, VsvError)
 
 _TABLE_IDS = {"raw": T_RAW, "cigar": T_CIGAR, "split": T_SPLIT, "cluster1": T_CLUSTER1, "merged": T_MERGED,
-              "calls": T_CALLS, "reads": T_READS, "bnd_cand": T_BND_CAND, "bnd_calls": T_BND_CALLS, "cutesv_split": T_CUTESV_SPLIT}
+              "calls": T_CALLS, "reads": T_READS, "bnd_cand": T_BND_CAND, "bnd_calls": T_BND_CALLS, "bnd_slots": T_BND_SLOTS, "bnd_call_slots": T_BND_CALL_SLOTS, "cutesv_split": T_CUTESV_SPLIT}
 
 
 def default_params(dtype):
@@ -181,6 +181,32 @@ class Engine:
                                                     len(rank), 0))
         self._check(self.lib.vsv_bnd_pair(self.h, C.byref(p)))
         return self.table("bnd_calls")
+
+    # ---- the same branch without leaving the GPU (multi-GPU exchange, bench config 5) ---------------------------------------
+    def bnd_candidates_device(self, seg, device, params=None):
+        """vsv_bnd_segments on a device-resident segment table (bnd.DeviceSegments): the live candidate rows as a uint8 torch
+        tensor [n * 32] on `device`, in slot order (= read order, pair order)."""
+        import torch
+        p = params or self._bnd_params()
+        self._keep = seg
+        s = seg.as_struct()
+        self._check(self.lib.vsv_bnd_segments(self.h, C.byref(s), C.byref(p)))
+        rows = self.table_torch("bnd_slots", device).view(-1, 32)
+        meta = rows[:, 24:28].contiguous().view(torch.int32).view(-1)
+        return rows[(meta & 64) == 0].contiguous().view(-1)          # VSV_B_DEAD
+
+    def bnd_pair_device(self, rows_u8, contig_rank_t, device, params=None):
+        """vsv_bnd_set_candidates + vsv_bnd_pair on device-resident candidate rows (collection order); calls as a uint8 tensor."""
+        p = params or self._bnd_params()
+        n = rows_u8.numel() // 32
+        self._keep = (rows_u8, contig_rank_t)
+        self._check(self.lib.vsv_bnd_set_candidates(self.h, C.c_void_p(rows_u8.data_ptr() if n else 0) if n else None, n,
+                                                    C.c_void_p(contig_rank_t.data_ptr()), int(contig_rank_t.numel()), 1))
+        self._check(self.lib.vsv_bnd_pair(self.h, C.byref(p)))
+        import torch
+        rows = self.table_torch("bnd_call_slots", device).view(-1, 32)
+        meta = rows[:, 24:28].contiguous().view(torch.int32).view(-1)
+        return rows[(meta & 64) == 0].contiguous().view(-1)
 
     def cutesv_split(self, seg, read_len, read_rec, sv_size=30, max_size=100000, max_split_parts=7):
         """sig_extract.py analysis_split_read (SE:193-319), INS/DEL candidates: SIG_DTYPE rows in (read, emission) order."""

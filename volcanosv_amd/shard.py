@@ -142,6 +142,54 @@ def exchange_bnd(cand, read_base, owner_of_tid, device):
     return got[order]
 
 
+def exchange_bnd_device(cand_u8, read_gid, owner_of_tid_t, device):
+    """exchange_bnd without leaving the GPUs: `cand_u8` = this rank's candidate rows (uint8 tensor [n * 32], vsv_bnd layout, local
+    read indices), `read_gid` = int64 tensor local read -> global read id, `owner_of_tid_t` = int64 tensor tid -> rank. Rows travel
+    to owner(src_tid) over one RCCL all-to-all (counts first) and come back in the single-process collection order: hp1 rows
+    before hp2 rows, each by (global read id, pair order) — one stable sort of a 64-bit key on the device."""
+    rows = cand_u8.view(-1, 32)
+    w = rows.view(torch.int32)                                    # [n, 8]: src_tid, src_pos, dst_tid, dst_pos, read, read2, meta, pad
+    if rows.shape[0]:
+        w = w.clone()
+        w[:, 4] = read_gid[w[:, 4].to(torch.int64)].to(torch.int32)     # local -> global read id (ids stay below 2^31)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        world = dist.get_world_size()
+        dest = owner_of_tid_t[w[:, 0].to(torch.int64)]
+        order = torch.sort(dest, stable=True).indices
+        w = w[order].contiguous()
+        sizes = torch.bincount(dest, minlength=world).to(torch.int64)
+        rsizes = torch.empty_like(sizes)
+        dist.all_to_all_single(rsizes, sizes)
+        send_split, recv_split = [int(x) for x in sizes.tolist()], [int(x) for x in rsizes.tolist()]
+        recv = torch.empty((sum(recv_split), 8), dtype=torch.int32, device=device)
+        dist.all_to_all_single(recv, w, output_split_sizes=recv_split, input_split_sizes=send_split)
+        w = recv
+    if w.shape[0]:
+        key = ((w[:, 6].to(torch.int64) & B_HAP2) << 40) | (w[:, 4].to(torch.int64) & 0xFFFFFFFF)     # (hap, global read id)
+        w = w[torch.sort(key, stable=True).indices].contiguous()
+    return w.view(torch.uint8).view(-1)
+
+
+def gather_rows_device(rows_u8, device):
+    """Variable-length gather of device rows (uint8 tensor) to rank 0: counts all-gather + padded all-gather; rank order. Returns
+    the concatenated uint8 tensor on rank 0, None elsewhere."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return rows_u8
+    world = dist.get_world_size()
+    n = torch.tensor([rows_u8.numel()], dtype=torch.int64, device=device)
+    counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(counts, n)
+    counts = [int(c.item()) for c in counts]
+    mx = max(max(counts), 1)
+    mine = torch.zeros(mx, dtype=torch.uint8, device=device)
+    mine[: rows_u8.numel()] = rows_u8
+    bufs = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(bufs, mine)
+    if dist.get_rank() != 0:
+        return None
+    return torch.cat([bufs[r][: counts[r]] for r in range(world)])
+
+
 def gather_rows(rows, dtype, device):
     """Variable-length gather of structured rows to rank 0 (counts all-gather + padded all-gather); rank order."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
