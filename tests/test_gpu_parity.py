@@ -450,6 +450,75 @@ def test_seq_length_assert(eng):
     assert e.value.status == -10
 
 
+def test_clr_gate_edge_cases(eng):
+    """The CLR gate (ins_pct / var_dist, C:53-70, applied at C:422-433) inside the scan: EMPTY M / I ops (the only way to a zero
+    ins_pct denominator with M ops present) send the part to the separate gate pass; records without M ops, with nothing but
+    empty ops, with I ops only; a record longer than the chunks the scan keeps gate words for. Status and tables equal the
+    oracle's in both scan layouts."""
+    from volcanosv_amd import synth
+    from volcanosv_amd.engine import default_params
+    t, nq, _ = synth.generate(6000, "hifi", seed=123, chrom_len=1_500_000, events_per_record=0.5)
+    base = synth.to_soa(t, nq)
+    hp = np.flatnonzero((base.flag & (F_HP1 | F_HP2)) != 0)
+    rng = np.random.default_rng(5)
+
+    def variant(edit):
+        soa = synth.to_soa(t, nq)
+        soa.cigar = soa.cigar.copy()
+        edit(soa)
+        return soa
+
+    def ops_of(soa, r):
+        return soa.cigar[int(soa.cigar_off[r]):int(soa.cigar_off[r + 1])]
+
+    def empty_some_m(soa):                       # an empty M op here and there: results as without the fusion
+        ms = np.flatnonzero((soa.cigar & 15) == 0)
+        soa.cigar[ms[rng.integers(0, len(ms), 40)]] &= np.uint32(15)
+
+    def all_empty(soa):                          # every M and I op of one tagged record empty: m + ins == 0 -> ZeroDivisionError (C:61)
+        seg = ops_of(soa, int(hp[100]))
+        seg[(seg & 15) <= 1] &= np.uint32(15)
+
+    def only_insertions(soa):                    # no M op: var_dist divides by zero (C:70)
+        seg = ops_of(soa, int(hp[200]))
+        seg[(seg & 15) == 0] |= np.uint32(1)
+
+    def untagged_without_m(soa):                 # the gate is never asked for an untagged record
+        r = int(hp[300])
+        soa.flag = soa.flag.copy()
+        soa.flag[r] &= np.uint8(~(F_HP1 | F_HP2) & 255)
+        seg = ops_of(soa, r)
+        seg[(seg & 15) == 0] |= np.uint32(2)
+
+    wants = {"empty_some_m": 0, "all_empty": -8, "only_insertions": -8, "untagged_without_m": 0}
+    for name, edit in (("empty_some_m", empty_some_m), ("all_empty", all_empty), ("only_insertions", only_insertions),
+                       ("untagged_without_m", untagged_without_m)):
+        soa = variant(edit)
+        st_o, want = oracle_run(soa, DTYPE_CLR)
+        assert st_o == wants[name], (name, st_o)
+        for layout in (1, 2):
+            p = default_params(DTYPE_CLR)
+            p.scan_layout = layout
+            try:
+                eng.run(soa, p)
+                st = 0
+            except VsvError as e:
+                st = e.status
+            assert st == st_o, (name, layout, st, st_o)
+            if st == 0:
+                got = eng.tables(DTYPE_CLR)
+                assert_tables_equal(got, want, list(got.keys()))
+    # one record of 30000 ops among reads (more chunks than the scan keeps gate words for): the run repeats with the separate pass
+    long_ops = []
+    for i in range(15000):
+        long_ops += [(0, 37), (2 if i % 50 else 1, 1 if i % 500 else 60)]
+    recs = [(0, 100 + 50 * i, "q%d_hp%d" % (i, 1 + i % 2), 60, False, [(0, 3000), (1, 45), (0, 2000)]) for i in range(300)]
+    recs.insert(150, (0, 5000, "long_hp1", 60, False, long_ops))
+    recs.sort(key=lambda r: r[1])
+    soa = RecordSoA.from_tuples(recs)
+    run_both(eng, soa, DTYPE_CLR)
+
+
 def test_capacity_overflow_reports_required_count():
     from volcanosv_amd import synth
     from volcanosv_amd.engine import Engine, default_params

@@ -64,6 +64,7 @@ struct vsv_handle {
   const uint64_t* sorted_key = nullptr;   // sorted keys of the stage just sorted (cluster / pair read them)
   bool small_sort_tiles = true;    // radix tile size, re-decided after every run from its row counts
   int lsd_runs = 0;                // > 0: the bucket sort overflowed recently, the next runs use the LSD passes
+  bool clr_unfused = false;        // the fused CLR scan met a part too long for its gate state: separate gate pass from now on
   bool dense_pairing = false;      // the last run walked a pairing stretch of thousands of rows with one wave: pair in rounds
   bool in_rerun = false;
   vsv_bnd_params bnd_prm{};
@@ -253,7 +254,12 @@ int enq_scan(vsv_handle* h) {
   h->cutesv_rows = -1;   // the split-candidate table shares a buffer with the merge stage
   const int n_parts = vsv_cigar_parts(h->rv.n_ops, OPS_PER_PART);
   RecView srv = h->rv;
-  if (h->prm.dtype == VSV_DTYPE_CLR && srv.n_records > 0) {   // the scan sees haplotype tags only where the CLR gate passes
+  // CLR: the read-shaped scan carries the gate itself (cigar_scan_emit<0, 4, true>); the long-record scan, and a handle whose fused
+  // scan met a part too long for its gate state, see haplotype tags only where a separate pass over the CIGARs lets the gate pass
+  static const char* clr_mode = getenv("VSV_CLR");          // tests: "separate"
+  const bool clr_fused = h->prm.dtype == VSV_DTYPE_CLR && srv.n_records > 0 && !vsv_scan_is_long(srv, h->prm) && !h->clr_unfused &&
+                         !(clr_mode && clr_mode[0] == 's');
+  if (h->prm.dtype == VSV_DTYPE_CLR && srv.n_records > 0 && !clr_fused) {
     int gs = ensure(h, h->gflag, (size_t)srv.n_records + 16);
     if (gs) return gs;
     vsv_launch_clr_gate(st, h->rv, (uint8_t*)h->gflag.p, dctr(h));
@@ -262,7 +268,7 @@ int enq_scan(vsv_handle* h) {
   vsv_launch_cigar_scan(st, srv, h->prm, (uint32_t*)h->part_rb.p, n_parts, OPS_PER_PART, (vsv_sig*)h->pool.p,
                         (uint64_t*)h->pool_key.p, (uint32_t)h->cap_sigs, (uint32_t*)h->part_count.p, (uint32_t*)h->part_off.p,
                         (uint32_t*)h->scan_tmp.p, (vsv_sig*)h->raw0.p, dctr(h), (uint32_t*)h->shard_cnt.p, h->ev0, h->ev1,
-                        LongScanBufs{h->l_agg.p, (uint32_t*)h->l_carry_r.p, (uint32_t*)h->l_carry_q.p, h->l_tiles.p, h->tile_cnt, 4096, true});
+                        LongScanBufs{h->l_agg.p, (uint32_t*)h->l_carry_r.p, (uint32_t*)h->l_carry_q.p, h->l_tiles.p, h->tile_cnt, 4096, true, clr_fused});
   h->have_scan_ev = n_parts > 0;
   vsv_launch_fold(st, (const vsv_sig*)h->raw0.p, (vsv_sig*)h->s1in.p, h->rv, h->prm, dctr(h), ew_grid(h));
   HIPCHK(h, hipGetLastError());
@@ -345,6 +351,15 @@ int finish(vsv_handle* h) {
   }
   const uint32_t e = h->host_ctr.err;
   h->last_count = h->host_ctr.n_pool;
+  if ((e & ERRB_CLR_FALLBACK) && !h->in_rerun) {
+    // a part of the read-shaped CLR scan held more chunks than its gate state: nothing it decided can be trusted. Same input
+    // again with the gate as a separate pass; this handle keeps that form.
+    h->clr_unfused = true;
+    h->in_rerun = true;
+    const int st = rerun(h);
+    h->in_rerun = false;
+    return st;
+  }
   if ((e & ERRB_SORT_FALLBACK) && !h->in_rerun) {
     // a bucket of the bucket sort did not fit in LDS (tables far from uniform, or much larger than the previous run's): the
     // stages behind it ran on a table that was not written completely, so whatever else they reported means nothing.

@@ -139,12 +139,27 @@ __device__ __forceinline__ const void* align4(const void* p) { return (const voi
 constexpr int K1_RMAX = 320;   // record starts staged per wave (8192-op parts of ~33-op reads hold ~250)
 constexpr int K1_WAVES = 4;
 
-template <int CLS, int DEPTH>
+// GATE (CLR, C:53-70, 422-433): the extractor computes ins_pct / var_dist of EVERY haplotype-tagged record first — a record without
+// M ops divides by zero there whatever its mapq — and walks the CIGAR (signatures, reference_end and SEQ asserts) only where
+// ins_pct <= 0.13 or var_dist >= 200. Instead of a second pass over the CIGARs in front of the scan (clr_gate_records), the scan
+// carries the gate: every chunk leaves four ballots (which lanes hold an M op in op slot 0..3: the compares write them straight
+// into SGPRs) and a running count in LDS; at the end of the part one lane per record counts the M ops between its record's
+// start and end (eight mask reads and popcounts) —
+// a tagged record without M ops raises ZeroDivisionError; and the few records that emit (or carry a forbidden op, or a
+// SEQ-length mismatch) get their exact sums on demand, by the wave, from the L2-hot chunks. A part of more than K1G_CH chunks
+// (a record of thousands of ops in a read-shaped input), or one that holds an EMPTY M / I op (the only way to a zero ins_pct
+// denominator with M ops present), raises ERRB_CLR_FALLBACK: the run is repeated with the separate gate pass.
+constexpr int K1G_CH = 96;      // chunks (24576 ops) of a part whose M-op masks are kept in LDS (32 bytes each)
+
+template <int CLS, int DEPTH, bool GATE = false>
 __global__ __launch_bounds__(256) void cigar_scan_emit(RecView rv, const uint32_t* __restrict__ rb, int n_parts,
                                                         int min_svlen, int min_mapq, EmitCtx ec,
                                                         uint32_t* __restrict__ part_count, int ablate, uint32_t* __restrict__ tile_sum) {
   using T = OpTab<CLS>;
+  static_assert(!GATE || CLS == 0, "the gate belongs to the contig op table");
   __shared__ uint32_t sh_off[K1_WAVES][K1_RMAX + 1];
+  __shared__ uint64_t sh_gm[GATE ? K1_WAVES : 1][GATE ? K1G_CH : 1][4];    // per chunk: which lanes hold an M op in op slot k (lane l: ops 4l..4l+3)
+  __shared__ uint32_t sh_cp[GATE ? K1_WAVES : 1][GATE ? K1G_CH + 1 : 1];   // per chunk: M ops of the part in front of it
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const int part = blockIdx.x * K1_WAVES + wv;
@@ -195,17 +210,46 @@ __global__ __launch_bounds__(256) void cigar_scan_emit(RecView rv, const uint32_
       if (i < n_tab) {
         const uint32_t nx = off_lo[2 * (size_t)(first + i) + 2] - cb0_lo;
         mono = mono && (int32_t)(nx - v) > 0;   // empty CIGAR => reference IndexError at H:63
-        if (CLS == 0 || CLS == 1) {             // a walked record whose SEQ length differs from its CIGAR's: H:397-398, RS:123-124
+        if (!GATE && (CLS == 0 || CLS == 1)) {  // a walked record whose SEQ length differs from its CIGAR's: H:397-398, RS:123-124
           const uint32_t fl = rv.flag[first + i];
           if ((fl & VSV_F_SEQ_MISMATCH) && rv.mapq[first + i] >= (uint32_t)min_mapq && (CLS == 1 || (fl & (VSV_F_HP1 | VSV_F_HP2))))
             atomicOr(&ec.ctr->err, ERRB_SEQLEN);
-        }
+        }                                       // (GATE: whether such a record is walked depends on its gate: end of the part)
       }
     }
     __builtin_amdgcn_wave_barrier();
     if (__ballot(!mono)) { if (lane == 0) atomicOr(&ec.ctr->err, ERRB_EMPTY_CIGAR); bad = true; }
   };
   stage(r0);
+  // ---- CLR gate state (GATE only) ----
+  uint64_t (*my_gm)[4] = sh_gm[GATE ? wv : 0];
+  uint32_t* my_cp = sh_cp[GATE ? wv : 0];
+  uint32_t gate_run_g = 0;
+  bool gate_over = false;
+  if (GATE && lane == 0) my_cp[0] = 0;
+  // exact gate of the record whose ops are [s_r, s_e) (relative): all 64 lanes, the record's chunks come from L2
+  auto gate_of = [&](uint32_t s_r, uint32_t s_e) -> bool {
+    int64_t m = 0, nm = 0, ins = 0;
+    for (uint32_t c = s_r & ~255u; c < s_e; c += 256u) {
+      const uint4 v = load_chunk(c);
+      const uint32_t ww[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t x = c + 4u * (uint32_t)lane + (uint32_t)k;
+        if (x >= s_r && x < s_e) {
+          const uint32_t op = ww[k] & 15u, len = ww[k] >> 4;
+          if (op == 0u) { m += len; ++nm; } else if (op == 1u) ins += len;
+        }
+      }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { m += __shfl_xor(m, d, 64); nm += __shfl_xor(nm, d, 64); ins += __shfl_xor(ins, d, 64); }
+    // (every lane holds the same sums after the butterfly; readfirstlane tells the compiler that the verdict is wave-uniform)
+    const bool zero = m + ins == 0 || nm == 0;                                                            // C:61, C:70
+    const bool pass = !zero && ((100 * ins <= 13 * (m + ins)) || (m >= 200 * nm));                        // C:427 in exact integers
+    if (__builtin_amdgcn_readfirstlane(zero ? 1 : 0)) { if (lane == 0) atomicOr(&ec.ctr->err, ERRB_ZERODIV); }
+    return __builtin_amdgcn_readfirstlane(pass ? 1 : 0) != 0;
+  };
 
   // ---- record lookup (slow path only): 64-record window of the LDS table, one start per lane -------------
   uint32_t wbase = 0;                  // window = table entries [wbase, wbase+64)
@@ -301,6 +345,7 @@ __global__ __launch_bounds__(256) void cigar_scan_emit(RecView rv, const uint32_
   constexpr uint32_t EMIT_R = rev32(EMIT_MASK | (EMIT_MASK << 16));   // bit-reversed, duplicated: sign(EMIT_R << (w & 31)) = bit op
   constexpr uint32_t BAD_R = rev32(T::BAD | (T::BAD << 16));
   uint32_t hd_rec = 0xFFFFFFFFu, hd_fl = 0, hd_mq = 0, hd_tid = 0, hd_first = 0, hd_pos = 0;   // cached record header
+  bool hd_gate = true;                                                                          // ... and its CLR gate (GATE)
 
   // ---- slow path: the chunk holds at least one candidate op (wave-uniform) ------------------------------
   auto slow = [&](const uint4& wcur, const uint32_t cb) {
@@ -355,10 +400,16 @@ __global__ __launch_bounds__(256) void cigar_scan_emit(RecView rv, const uint32_
         if (rec != hd_rec) {             // header of the record (scalar cache); long records emit many times
           sload5(align4(rv.flag + rec), align4(rv.mapq + rec), rv.tid + rec, rv.cigar + cb0 + s_r, rv.pos + rec, hd_fl, hd_mq, hd_tid, hd_first, hd_pos);
           hd_rec = rec;
+          if (GATE) {                    // C:425-427: the gate of a tagged record with enough mapq, once per record
+            const uint32_t gfl = byte_of(hd_fl, rv.flag + rec), gmq = byte_of(hd_mq, rv.mapq + rec);
+            hd_gate = true;
+            if ((gfl & (VSV_F_HP1 | VSV_F_HP2)) && gmq >= (uint32_t)min_mapq)
+              hd_gate = gate_of(s_r, cnt < nwin ? rdlane(s_rel, cnt) : nxt);
+          }
         }
         const uint32_t fl = byte_of(hd_fl, rv.flag + rec), mq = byte_of(hd_mq, rv.mapq + rec);
         uint32_t hapbits;
-        if (CLS == 0) hapbits = (mq >= (uint32_t)min_mapq) ? ((fl >> 2) & 3u) : 0u;               // H:392-394
+        if (CLS == 0) hapbits = (mq >= (uint32_t)min_mapq && (!GATE || hd_gate)) ? ((fl >> 2) & 3u) : 0u;   // H:392-394 (C:427)
         else if (CLS == 1) hapbits = (mq >= (uint32_t)min_mapq) ? 1u : 0u;                        // RS:120
         else if (CLS == 3) hapbits = (!(fl & VSV_F_SKIP) && mq >= (uint32_t)min_mapq) ? 1u : 0u; // SE:439, 446
         else hapbits = (!(fl & (VSV_F_UNMAPPED | VSV_F_SECONDARY)) && mq >= (uint32_t)min_mapq) ? 1u : 0u;
@@ -406,6 +457,30 @@ __global__ __launch_bounds__(256) void cigar_scan_emit(RecView rv, const uint32_
   // of the packed word against min_svlen<<4. The test is a superset of the emit predicate; `slow` is exact.
   auto process_chunk = [&](const uint4& wcur, const uint32_t cb) {
     if (cb >= oe_rel || bad) return;             // ring slots past the end of the part
+    if (GATE) {
+      const uint32_t ci = cb >> 8;
+      if (ci < (uint32_t)K1G_CH) {
+        const uint32_t ww[4] = {wcur.x, wcur.y, wcur.z, wcur.w};
+        uint64_t mk[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mk[k] = __ballot((ww[k] & 15u) == 0u);            // M ops (var_dist's list, C:66-68): one mask per op slot
+        // ins_pct's denominator (C:57-61) is zero although the record has M ops only if every M and I op of it is EMPTY: such ops
+        // (packed words 0 and 1) do not occur in real alignments; a part that holds one takes the separate gate pass instead
+        uint32_t lo4 = min(min(ww[0], ww[1]), min(ww[2], ww[3]));
+        if (cb + 256u > oe_rel || cb < ob_rel) {                                       // ops outside the part read as 0 / belong to the neighbour
+          lo4 = 0xFFFFFFFFu;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { const uint32_t x = cb + 4u * (uint32_t)lane + (uint32_t)k; if (x >= ob_rel && x < oe_rel) lo4 = min(lo4, ww[k]); }
+        }
+        if (__ballot(lo4 < 2u)) gate_over = true;
+        gate_run_g += (uint32_t)(__popcll(mk[0]) + __popcll(mk[1]) + __popcll(mk[2]) + __popcll(mk[3]));
+        if (lane == 0) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) my_gm[ci][k] = mk[k];
+          my_cp[ci + 1] = gate_run_g;
+        }
+      } else gate_over = true;
+    }
     bool cand = ((int32_t)(EMIT_R << (wcur.x & 31u)) < 0 && wcur.x >= thr16) |
                 ((int32_t)(EMIT_R << (wcur.y & 31u)) < 0 && wcur.y >= thr16) |
                 ((int32_t)(EMIT_R << (wcur.z & 31u)) < 0 && wcur.z >= thr16) |
@@ -442,6 +517,49 @@ __global__ __launch_bounds__(256) void cigar_scan_emit(RecView rv, const uint32_
   }
   // every record start of the part goes through stage() once: an empty CIGAR must raise (H:63 IndexError)
   while (!bad && tbase + n_tab < r1) stage(tbase + n_tab);
+  if (GATE && !bad) {
+    if (gate_over) { if (lane == 0) atomicOr(&ec.ctr->err, ERRB_CLR_FALLBACK); }
+    else {
+      __builtin_amdgcn_wave_barrier();
+      const uint32_t n_ch = (oe_rel + 255u) >> 8;
+      auto m_ops_before = [&](uint32_t x) -> uint32_t {                 // M ops of the part in front of op x
+        const uint32_t ci = x >> 8;
+        if (ci >= n_ch) return my_cp[n_ch];
+        const uint32_t l = (x & 255u) >> 2, kk = x & 3u;
+        uint32_t c = my_cp[ci];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+          const uint32_t nl = l + (k < kk ? 1u : 0u);                   // lanes of slot k in front of x
+          c += (uint32_t)__popcll(my_gm[ci][k] & (nl >= 64u ? ~0ull : (1ull << nl) - 1ull));
+        }
+        return c;
+      };
+      for (uint32_t first = r0; first < r1; first += (uint32_t)K1_RMAX) {
+        const uint32_t nrec = min((uint32_t)K1_RMAX, r1 - first);
+        for (uint32_t i0 = 0; i0 < nrec; i0 += 64) {                     // whole waves: the on-demand gates below are wave-cooperative
+          const uint32_t i = i0 + (uint32_t)lane;
+          const bool live = i < nrec;
+          uint32_t s_r = 0, s_e = 0, fl = 0, mq = 0;
+          if (live) {
+            s_r = off_lo[2 * (size_t)(first + i)] - cb0_lo;
+            s_e = off_lo[2 * (size_t)(first + i) + 2] - cb0_lo;
+            fl = rv.flag[first + i]; mq = rv.mapq[first + i];
+          }
+          const bool tagged = live && (fl & (VSV_F_HP1 | VSV_F_HP2));
+          // no M op at all: var_dist (and ins_pct, unless the record has I ops: then var_dist) divides by zero — C:61 / C:70,
+          // whatever the record's mapq
+          if (tagged && m_ops_before(s_e) == m_ops_before(s_r)) atomicOr(&ec.ctr->err, ERRB_ZERODIV);
+          // a tagged record with enough mapq and a SEQ of another length: asserted only if its gate lets it be walked (C:427-431)
+          uint64_t need = __ballot(tagged && (fl & VSV_F_SEQ_MISMATCH) && mq >= (uint32_t)min_mapq);
+          while (need) {
+            const int src = __builtin_ctzll(need);
+            need &= need - 1;
+            if (gate_of(rdlane(s_r, (uint32_t)src), rdlane(s_e, (uint32_t)src)) && lane == 0) atomicOr(&ec.ctr->err, ERRB_SEQLEN);
+          }
+        }
+      }
+    }
+  }
   release_left();
   // (per-tile sums of these counts through atomics were tried: the parts of a tile finish together, so ~2000 adds queue up on
   // one word at a time and the scan took 540 instead of 250 us)
@@ -1028,6 +1146,7 @@ void vsv_launch_cigar_scan(hipStream_t st, const RecView& rv, const vsv_params& 
 #define K1_LAUNCH(CLS)                                                                                                          \
   do {                                                                                                                          \
     if (long_mode) cigar_scan_long<CLS><<<grid, 256, 0, st>>>(rv, part_rb, n_parts, p.min_svlen, p.min_cigar_mapq, ec, part_count, (PartAgg*)lb.agg, ablate); \
+    else if (CLS == 0 && lb.clr_fused) cigar_scan_emit<0, 4, true><<<grid, 256, 0, st>>>(rv, part_rb, n_parts, p.min_svlen, p.min_cigar_mapq, ec, part_count, ablate, tsum); \
     else if (depth == 4) cigar_scan_emit<CLS, 4><<<grid, 256, 0, st>>>(rv, part_rb, n_parts, p.min_svlen, p.min_cigar_mapq, ec, part_count, ablate, tsum); \
     else cigar_scan_emit<CLS, 3><<<grid, 256, 0, st>>>(rv, part_rb, n_parts, p.min_svlen, p.min_cigar_mapq, ec, part_count, ablate, tsum);            \
   } while (0)

@@ -18,6 +18,7 @@ enum : uint32_t {
   ERRB_CAPACITY = 1u << 5,
   ERRB_RANGE = 1u << 6,  // a 64-record batch spans >= 2^31 CIGAR ops
   ERRB_SEQLEN = 1u << 8,         // a walked record carries VSV_F_SEQ_MISMATCH (H:397-398)
+  ERRB_CLR_FALLBACK = 1u << 9,   // a part too long for the gate state of the fused CLR scan: the run is repeated with the separate gate pass
   ERRB_SORT_FALLBACK = 1u << 7,  // a bucket of the bucket sort did not fit in LDS: the run is repeated with the LSD passes
 };
 
@@ -139,6 +140,7 @@ struct LongScanBufs {   // scratch of the scan launcher beyond the part tables
   void* agg; uint32_t* carry_r; uint32_t* carry_q; void* tile_sum;   // long-record scan (cigar_scan_long): aggregates, carries, tile sums
   uint32_t* tile_cnt; int tile_cnt_cap;    // read-shaped scan: zeroed per run, the waves add their part counts per 2048-part tile
   bool arena_zeroed;                       // the caller zeroed shard_cnt together with the counters
+  bool clr_fused;                          // CLR, read-shaped scan: the gate is computed inside the scan (flags arrive ungated)
 };
 bool vsv_scan_is_long(const RecView& rv, const vsv_params& p);
 size_t vsv_long_scan_bytes(int64_t n_ops, int which);
