@@ -241,6 +241,7 @@ class Bench:
         p = default_params(dtype)
         table = "reads" if dtype_name == "READS" else "calls"
         engs = self.engs[: max(1, min(len(self.engs), steps))]
+        p.split_overlap = 1 if len(engs) >= 3 else 0      # VSV_OVERLAP_OFF: three engines in flight fill the GPU by themselves
         weng = self.run_steps([(recs, p)], max(warmup, len(engs)), [], engs)
         self.gather(weng, table)            # warm-up of the gather path too (first collective of a shape sets up its channels)
         times, scan_ms, gathered = [], [], None
@@ -298,6 +299,7 @@ class Bench:
             keep.append(t)
             jobs.append((recs, p))
         engs = self.engs[: max(1, min(len(self.engs), len(jobs)))]     # the rank's engines take turns over its chromosomes (contig_signature.run)
+        p.split_overlap = 1 if len(engs) >= 3 else 0
 
         def one_pass(scan_ms):
             """Every chromosome of this rank once; the call tables of all of them are gathered (device rows, one collective)."""

@@ -102,8 +102,14 @@ typedef struct vsv_params {
   int32_t merge_ins_threshold; /* CUTESV only: 100 (SE -mi): INS signals of one read at most this far apart are merged */
   int32_t merge_del_threshold; /* CUTESV only: 0   (SE -md)                                           */
   int32_t scan_layout;      /* VSV_SCAN_*: work mapping of the CIGAR scan; results are identical, only the speed differs  */
-  int32_t reserved[4];
+  int32_t split_overlap;    /* VSV_OVERLAP_*: where vsv_run_chromosome builds the split candidates; results are identical        */
+  int32_t reserved[3];
 } vsv_params;
+enum {
+  VSV_OVERLAP_AUTO = 0, /* on a second stream of the handle, next to the CIGAR scan: shortest latency of one handle             */
+  VSV_OVERLAP_OFF = 1   /* on the handle's stream: callers that keep three or more handles busy on one GPU (the engines'
+                           kernels overlap each other already; the extra stream only adds events)                              */
+};
 enum {
   VSV_SCAN_AUTO = 0,    /* by the mean CIGAR length of the call's records                                             */
   VSV_SCAN_READS = 1,   /* record-aligned parts, lazily evaluated offsets: reads, tens to hundreds of ops per record  */

@@ -87,6 +87,12 @@ def cmd_trace(a):
         f.write("%s: %d launches, %.1f us busy, %.1f us span\n" % (a.title, len(step), busy, span))
         for k, (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             f.write("%-44s n=%3d us=%9.1f\n" % (k, n, us))
+        if a.timeline:
+            f.write("\nin launch order: start (us since the step began), duration, idle time in front of the launch\n")
+            t0, prev = step[0][0], step[0][0]
+            for s, e, n in step:
+                f.write("%9.1f %8.1f %7.1f  %s\n" % ((s - t0) / 1e3, (e - s) / 1e3, max(0, s - prev) / 1e3, short(n)))
+                prev = max(prev, e)
     print(open(a.out_txt).read())
 
 
@@ -99,6 +105,7 @@ p.add_argument("--records", type=int, required=True); p.add_argument("--ops", ty
 p.add_argument("--skip", type=int, default=0); p.add_argument("--out", required=True)
 p = sub.add_parser("trace")
 p.add_argument("--dir", required=True); p.add_argument("--out-csv", required=True); p.add_argument("--out-txt", required=True)
+p.add_argument("--timeline", action="store_true", help="append the launches of the step in order with their gaps")
 p.add_argument("--title", default="one step of bench.py config 2 (10 M records), kernels in launch-aggregated form")
 a = ap.parse_args()
 {"pmc": cmd_pmc, "trace": cmd_trace}[a.cmd](a)

@@ -19,6 +19,7 @@ M_DEL, M_SPLIT, M_HP2, M_DEAD, M_QREV = 1, 2, 4, 8, 16
 
 T_RAW, T_CIGAR, T_SPLIT, T_CLUSTER1, T_MERGED, T_CALLS, T_READS = range(7)
 SCAN_AUTO, SCAN_READS, SCAN_CONTIGS = 0, 1, 2      # vsv_params.scan_layout
+OVERLAP_AUTO, OVERLAP_OFF = 0, 1                     # vsv_params.split_overlap
 
 STATUS = {
     0: "VSV_OK", -1: "VSV_E_INVALID", -2: "VSV_E_HIP", -3: "VSV_E_CAPACITY", -4: "VSV_E_EMPTY_CIGAR",
@@ -50,7 +51,7 @@ class Params(C.Structure):
         ("dtype", C.c_int32), ("min_svlen", C.c_int32), ("min_cigar_mapq", C.c_int32),
         ("min_split_mapq", C.c_int32), ("max_split_svlen", C.c_int32), ("cluster_shift", C.c_int32),
         ("pair_shift", C.c_int32), ("pair_window", C.c_int32), ("enable_split", C.c_int32),
-        ("merge_ins_threshold", C.c_int32), ("merge_del_threshold", C.c_int32), ("scan_layout", C.c_int32), ("reserved", C.c_int32 * 4),
+        ("merge_ins_threshold", C.c_int32), ("merge_del_threshold", C.c_int32), ("scan_layout", C.c_int32), ("split_overlap", C.c_int32), ("reserved", C.c_int32 * 3),
     ]
 
 

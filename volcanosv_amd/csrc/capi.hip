@@ -61,9 +61,12 @@ struct vsv_handle {
   bool want_sa = false;                // vsv_bam_set_want_sa: the device parse also collects the SA:Z texts
   DevBuf o_saoff, o_salen, o_saloc, o_sa;
   int pass_cursor = 0;
+  int group_cursor = 0;
+  uint32_t* groups = nullptr;      // view into `arena`
   const uint64_t* sorted_key = nullptr;   // sorted keys of the stage just sorted (cluster / pair read them)
   bool small_sort_tiles = true;    // radix tile size, re-decided after every run from its row counts
   int lsd_runs = 0;                // > 0: the bucket sort overflowed recently, the next runs use the LSD passes
+  uint64_t sort_hint_rows = 0;     // the row count the bucket sort of the run in flight was sized for
   bool clr_unfused = false;        // the fused CLR scan met a part too long for its gate state: separate gate pass from now on
   bool dense_pairing = false;      // the last run walked a pairing stretch of thousands of rows with one wave: pair in rounds
   bool in_rerun = false;
@@ -72,6 +75,14 @@ struct vsv_handle {
   Counters* pinned = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool have_scan_ev = false;
+  // the fused run builds the split candidates (record arrays only) on `aux` while the scan streams the CIGARs on `stream`
+  hipStream_t aux = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool fork_split = false;         // this run is the fused one: enq_scan may start the candidates early
+  bool split_cands_done = false;   // the candidates of this run are enqueued (enq_split only evaluates the pairs)
+  bool aux_pending = false;        // work on `aux` that `stream` has not been made to wait for yet
+  SplitSorted split_sorted{nullptr, nullptr, nullptr, nullptr};
+  DevBuf scan_tmp2;                // block sums of the candidate-count scan (scan_tmp belongs to the CIGAR scan)
   // state
   RecView rv{};
   int n_tids = 0;
@@ -145,6 +156,7 @@ int reserve(vsv_handle* h, int64_t max_records, int64_t max_ops, int64_t max_sig
     if ((st = ensure(h, h->cmask, nblk * 512 + 1024))) return st;      // SC_ROUNDS (2) x 256 bytes per block of 2048 records
     const size_t m = n_parts > nblk ? n_parts : nblk;
     if ((st = ensure(h, h->scan_tmp, (m / 2048 + 2) * 4))) return st;
+    if ((st = ensure(h, h->scan_tmp2, (nblk / 2048 + 2) * 4))) return st;
     h->cap_ops = ops;
     h->cap_records = recs;
   }
@@ -198,6 +210,7 @@ int bind_records(vsv_handle* h, const vsv_records* r) {
 }
 
 constexpr int MAX_SORT_PASSES = 64;
+constexpr int MAX_GROUP_SLOTS = 8;      // bucket sorts of one run that may skip their scan launch (a contig run has 6-7)
 SortWork sort_work(vsv_handle* h) {
   SortWork w;
   w.key_alt = (uint64_t*)h->key_alt.p; w.val_alt = (uint32_t*)h->val_alt.p; w.hist = (uint32_t*)h->hist.p; w.max_items = h->cap_sigs;
@@ -210,18 +223,32 @@ SortWork sort_work(vsv_handle* h) {
   static const char* mode = getenv("VSV_SORT");
   const Counters& c = h->host_ctr;
   const uint64_t rows = c.n_s1 > c.n_cand ? c.n_s1 : c.n_cand;
+  static const int per_bucket = getenv("VSV_BK_ROWS") ? atoi(getenv("VSV_BK_ROWS")) : 640;     // timing experiments
   int bb = 8;
-  while (bb < 11 && (rows >> bb) > 640) ++bb;
-  w.bucket_bits = (h->lsd_runs > 0 || (mode && mode[0] == 'l') || (rows >> 11) > 640) ? 0 : bb;
+  while (bb < 11 && (rows >> bb) > (uint64_t)per_bucket) ++bb;
+  // (a handle's first run knows no row count: LSD passes rather than a guess that overflows and repeats the run)
+  w.bucket_bits = (h->lsd_runs > 0 || rows == 0 || (mode && mode[0] == 'l') || (rows >> 11) > 640) ? 0 : bb;
+  h->sort_hint_rows = rows;
+  w.hint_rows = rows;
+  w.groups = h->groups; w.group_cursor = &h->group_cursor; w.max_group_slots = MAX_GROUP_SLOTS;
   w.err = h->ctr.p ? &((Counters*)h->ctr.p)->err : nullptr;
   return w;
 }
 // zero the device counters and the per-pass sort totals: start of every run
 constexpr size_t ARENA_CTR = 256, ARENA_SHARD = 256 * 16 * sizeof(uint32_t), ARENA_TILES = 4096 * sizeof(uint32_t),
-                 ARENA_TOTALS = (size_t)MAX_SORT_PASSES * 2048 * sizeof(uint32_t), ARENA_BYTES = ARENA_CTR + ARENA_SHARD + ARENA_TILES + ARENA_TOTALS;
+                 ARENA_TOTALS = (size_t)MAX_SORT_PASSES * 2048 * sizeof(uint32_t),
+                 ARENA_GROUPS = (size_t)MAX_GROUP_SLOTS * VSV_RS_MAX_GROUPS * 2048 * sizeof(uint32_t),     // 4 MB: ~1 us more of the fill
+                 ARENA_BYTES = ARENA_CTR + ARENA_SHARD + ARENA_TILES + ARENA_TOTALS + ARENA_GROUPS;
+int join_aux(vsv_handle* h) {
+  if (h->aux_pending) { HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0)); h->aux_pending = false; }
+  return 0;
+}
 int reset_run_state(vsv_handle* h) {
+  { int js = join_aux(h); if (js) return js; }    // an abandoned run's candidates may still be counting into the arena
+  h->split_cands_done = false;
   HIPCHK(h, hipMemsetAsync(h->arena.p, 0, ARENA_BYTES, h->stream));
   h->pass_cursor = 0;
+  h->group_cursor = 0;
   return 0;
 }
 int tid_bits(vsv_handle* h);
@@ -247,6 +274,15 @@ int key_bits(vsv_handle* h) { return pos_bits(h) + 3 + tid_bits(h) + 1; }   // +
 bool is_contig(int dtype) { return dtype == VSV_DTYPE_HIFI || dtype == VSV_DTYPE_ONT || dtype == VSV_DTYPE_CLR; }
 
 // ---- stage enqueue functions ------------------------------------------------------------------------
+int enq_split_candidates(vsv_handle* h, hipStream_t st) {
+  h->split_sorted = vsv_launch_split_candidates(st, h->rv, h->prm, h->n_tids, (uint32_t*)h->tab.p, h->tab_size, (uint32_t*)h->blk_cnt.p,
+                                                (uint32_t*)h->blk_off.p, (uint32_t*)h->scan_tmp2.p, (uint64_t*)h->ckey.p, (uint32_t*)h->crec.p,
+                                                (uint64_t*)h->okey.p, (uint32_t*)h->oval.p, (uint64_t*)h->key2.p, (uint32_t*)h->idx2.p, sort_work(h),
+                                                (uint32_t)h->cap_sigs, dctr(h), (uint8_t*)h->cmask.p, ew_grid(h));
+  HIPCHK(h, hipGetLastError());
+  h->split_cands_done = true;
+  return 0;
+}
 int enq_scan(vsv_handle* h) {
   hipStream_t st = h->stream;
   { int rs = reset_run_state(h); if (rs) return rs; }
@@ -265,6 +301,12 @@ int enq_scan(vsv_handle* h) {
     vsv_launch_clr_gate(st, h->rv, (uint8_t*)h->gflag.p, dctr(h));
     srv.flag = (const uint8_t*)h->gflag.p;
   }
+  // fused run: the split candidates need the record arrays only — they go to the auxiliary stream, enqueued BEHIND the scan (the
+  // host spends ~50 us enqueuing them: the scan is already streaming by then) but ordered after this run's reset only
+  static const char* where = getenv("VSV_SPLIT_STREAM");   // timing experiments: "main" keeps everything on the handle's stream
+  const bool early_cands = h->fork_split && h->prm.enable_split && h->prm.dtype != VSV_DTYPE_SVIM && h->prm.dtype != VSV_DTYPE_CUTESV && h->rv.n_records > 0;
+  const bool fork = early_cands && h->aux && h->prm.split_overlap != VSV_OVERLAP_OFF && !(where && where[0] == 'm');
+  if (fork) HIPCHK(h, hipEventRecord(h->ev_fork, st));
   vsv_launch_cigar_scan(st, srv, h->prm, (uint32_t*)h->part_rb.p, n_parts, OPS_PER_PART, (vsv_sig*)h->pool.p,
                         (uint64_t*)h->pool_key.p, (uint32_t)h->cap_sigs, (uint32_t*)h->part_count.p, (uint32_t*)h->part_off.p,
                         (uint32_t*)h->scan_tmp.p, (vsv_sig*)h->raw0.p, dctr(h), (uint32_t*)h->shard_cnt.p, h->ev0, h->ev1,
@@ -272,6 +314,12 @@ int enq_scan(vsv_handle* h) {
   h->have_scan_ev = n_parts > 0;
   vsv_launch_fold(st, (const vsv_sig*)h->raw0.p, (vsv_sig*)h->s1in.p, h->rv, h->prm, dctr(h), ew_grid(h));
   HIPCHK(h, hipGetLastError());
+  if (early_cands) {
+    if (fork) HIPCHK(h, hipStreamWaitEvent(h->aux, h->ev_fork, 0));
+    int cs = enq_split_candidates(h, fork ? h->aux : st);
+    if (cs) return cs;
+    if (fork) { HIPCHK(h, hipEventRecord(h->ev_join, h->aux)); h->aux_pending = true; }
+  }
   h->stage_done = 1;
   return 0;
 }
@@ -281,10 +329,10 @@ int enq_split(vsv_handle* h) {
   vsv_params p = h->prm;
   RecView rv = h->rv;
   if (!p.enable_split || p.dtype == VSV_DTYPE_SVIM) rv.n_records = 0;  // n_s1 = n_raw
-  vsv_launch_split(st, rv, p, h->n_tids, (uint32_t*)h->tab.p, h->tab_size, (uint32_t*)h->blk_cnt.p, (uint32_t*)h->blk_off.p,
-                   (uint32_t*)h->scan_tmp.p, (uint64_t*)h->ckey.p, (uint32_t*)h->crec.p, (uint64_t*)h->okey.p,
-                   (uint32_t*)h->oval.p, (uint64_t*)h->key2.p, (uint32_t*)h->idx2.p, sort_work(h), (vsv_sig*)h->s1in.p,
-                   (uint32_t)h->cap_sigs, dctr(h), (uint8_t*)h->cmask.p, ew_grid(h));
+  if (rv.n_records > 0 && !h->split_cands_done) { int cs = enq_split_candidates(h, st); if (cs) return cs; }
+  { int js = join_aux(h); if (js) return js; }
+  vsv_launch_split_eval(st, rv, p, h->n_tids, rv.n_records > 0 ? h->split_sorted : SplitSorted{nullptr, nullptr, nullptr, nullptr},
+                        (vsv_sig*)h->s1in.p, (uint32_t)h->cap_sigs, dctr(h), ew_grid(h));
   if (p.dtype == VSV_DTYPE_READS) {
     // reads.py:281-286 merge_all: one stable sort of [del_cigar, ins_cigar, del_split, ins_split] by pos
     const int nbits = pos_bits(h) + 2 + tid_bits(h) + 1;
@@ -334,6 +382,7 @@ int enq_pair(vsv_handle* h) {
 int rerun(vsv_handle* h);
 int finish(vsv_handle* h) {
   HIPCHK(h, hipSetDevice(h->device));   // the current device is per host thread
+  { int js = join_aux(h); if (js) return js; }
   HIPCHK(h, hipMemcpyAsync(h->pinned, h->ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->host_ctr = *h->pinned;
@@ -351,6 +400,12 @@ int finish(vsv_handle* h) {
   }
   const uint32_t e = h->host_ctr.err;
   h->last_count = h->host_ctr.n_pool;
+  static const char* trace = getenv("VSV_TRACE_COUNTERS");
+  if (trace) {
+    const Counters& c = h->host_ctr;
+    fprintf(stderr, "[vsv] n_pool %u n_raw %u n_cand %u n_s1 %u alive %u %u %u calls %u max_stretch %u err %#x\n", c.n_pool, c.n_raw, c.n_cand, c.n_s1,
+            c.n_alive1, c.n_alive2, c.n_alive3, c.n_calls, c.max_stretch, c.err);
+  }
   if ((e & ERRB_CLR_FALLBACK) && !h->in_rerun) {
     // a part of the read-shaped CLR scan held more chunks than its gate state: nothing it decided can be trusted. Same input
     // again with the gate as a separate pass; this handle keeps that form.
@@ -364,10 +419,14 @@ int finish(vsv_handle* h) {
     // a bucket of the bucket sort did not fit in LDS (tables far from uniform, or much larger than the previous run's): the
     // stages behind it ran on a table that was not written completely, so whatever else they reported means nothing.
     // Same input again through the LSD passes (real errors show up there); this handle keeps them for a while.
+    // A table that simply outgrew the previous run's (the size hint was stale) goes back to buckets of the right size at once.
+    const uint64_t rows_now = h->host_ctr.n_s1 > h->host_ctr.n_cand ? h->host_ctr.n_s1 : h->host_ctr.n_cand;
+    const bool stale_hint = rows_now > h->sort_hint_rows + h->sort_hint_rows / 2;
     h->lsd_runs = 16;
     h->in_rerun = true;
     const int st = rerun(h);
     h->in_rerun = false;
+    if (stale_hint) h->lsd_runs = 0;
     return st;
   }
   if (e & ERRB_CAPACITY) {
@@ -395,6 +454,7 @@ int rerun(vsv_handle* h) {
     HIPCHK(h, hipMemsetAsync(&dctr(h)->err, 0, sizeof(uint32_t), h->stream));     // the other counters describe the candidates
     if (h->totals.p) HIPCHK(h, hipMemsetAsync(h->totals.p, 0, (size_t)MAX_SORT_PASSES * 2048 * sizeof(uint32_t), h->stream));
     h->pass_cursor = 0;
+    h->group_cursor = MAX_GROUP_SLOTS;      // (the group sums are not zeroed here: these sorts keep their scan launch)
     vsv_launch_bnd_pair(h->stream, (const vsv_bnd*)h->s1in.p, h->segs.contig_rank, bits_for((uint64_t)h->segs.n_tids + 1), h->bnd_prm,
                         (vsv_bnd*)h->s1s.p, (vsv_bnd*)h->c1.p, dctr(h), stage_bufs(h), sort_work(h), h->cap_sigs);
     HIPCHK(h, hipGetLastError());
@@ -402,7 +462,10 @@ int rerun(vsv_handle* h) {
   }
   const int upto = h->stage_done;
   if (upto < 1) return fail(h, VSV_E_HIP, "bucket sort overflow outside a signature run");
-  if ((st = enq_scan(h))) return st;
+  h->fork_split = upto >= 2;
+  st = enq_scan(h);
+  h->fork_split = false;
+  if (st) return st;
   if (upto >= 2 && (st = enq_split(h))) return st;
   if (upto >= 3 && (st = enq_stage1(h))) return st;
   if (upto >= 4 && (st = enq_merge(h))) return st;
@@ -478,9 +541,13 @@ int vsv_create(int device_id, void* hip_stream, vsv_handle** out) {
   h->shard_cnt.p = ar + ARENA_CTR; h->shard_cnt.bytes = ARENA_SHARD;
   h->tile_cnt = (uint32_t*)(ar + ARENA_CTR + ARENA_SHARD);
   h->totals.p = ar + ARENA_CTR + ARENA_SHARD + ARENA_TILES; h->totals.bytes = ARENA_TOTALS;
+  h->groups = (uint32_t*)(ar + ARENA_CTR + ARENA_SHARD + ARENA_TILES + ARENA_TOTALS);
   if (hipHostMalloc((void**)&h->pinned, sizeof(Counters)) != hipSuccess) { hipFree(h->arena.p); delete h; return VSV_E_HIP; }
   hipEventCreate(&h->ev0);
   hipEventCreate(&h->ev1);
+  if (hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking) != hipSuccess) h->aux = nullptr;   // without it everything stays on `stream`
+  hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
+  hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
   memset(&h->host_ctr, 0, sizeof h->host_ctr);
   { const char* pm = getenv("VSV_PAIR"); h->dense_pairing = pm && pm[0] == 'r'; }     // tests: the round-based pairing from the first run
   *out = h;
@@ -491,7 +558,10 @@ void vsv_destroy(vsv_handle* h) {
   if (!h) return;
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
-  DevBuf* bufs[] = {&h->r_pos, &h->r_tid, &h->r_qid, &h->r_off, &h->r_mapq, &h->r_flag, &h->r_cigar, &h->part_rb, &h->part_count,
+  if (h->aux) { hipStreamSynchronize(h->aux); hipStreamDestroy(h->aux); }
+  if (h->ev_fork) hipEventDestroy(h->ev_fork);
+  if (h->ev_join) hipEventDestroy(h->ev_join);
+  DevBuf* bufs[] = {&h->scan_tmp2, &h->r_pos, &h->r_tid, &h->r_qid, &h->r_off, &h->r_mapq, &h->r_flag, &h->r_cigar, &h->part_rb, &h->part_count,
                     &h->part_off, &h->scan_tmp, &h->l_agg, &h->l_carry_r, &h->l_carry_q, &h->l_tiles, &h->z_crctab, &h->z_crc, &h->pool, &h->pool_key, &h->raw0, &h->s1in, &h->s1s, &h->c1, &h->s2s, &h->c2,
                     &h->merged, &h->calls_tmp, &h->calls, &h->reads, &h->tab, &h->blk_cnt, &h->blk_off, &h->ckey, &h->crec,
                     &h->okey, &h->oval, &h->key, &h->idx, &h->cl, &h->key2, &h->idx2, &h->key_alt, &h->val_alt, &h->hist, &h->arena, &h->g_off, &h->g_qs, &h->g_qe, &h->g_rid, &h->g_rs,
@@ -545,6 +615,7 @@ int vsv_split_pairs(vsv_handle* h, const vsv_records* recs, const vsv_params* p)
   if (!h || h->stage_done < 1) return fail(h, VSV_E_INVALID, "vsv_cigar_scan must run first");
   (void)recs;
   if (p) { h->prm.enable_split = p->enable_split; h->prm.min_split_mapq = p->min_split_mapq; h->prm.max_split_svlen = p->max_split_svlen; }
+  h->split_cands_done = false;          // the candidates depend on min_split_mapq
   int st = enq_split(h);
   if (st) return st;
   return finish(h);
@@ -578,7 +649,10 @@ int vsv_pair_haplotypes(vsv_handle* h, const vsv_params* p) {
 int vsv_run_chromosome_async(vsv_handle* h, const vsv_records* recs, const vsv_params* p) {
   int st = start(h, recs, p);
   if (st) return st;
-  if ((st = enq_scan(h))) return st;
+  h->fork_split = true;
+  st = enq_scan(h);
+  h->fork_split = false;
+  if (st) return st;
   if (p->dtype != VSV_DTYPE_SVIM && p->dtype != VSV_DTYPE_CUTESV) { if ((st = enq_split(h))) return st; }
   if (is_contig(p->dtype)) {
     if ((st = enq_stage1(h))) return st;
@@ -750,6 +824,7 @@ int vsv_bnd_set_candidates(vsv_handle* h, const vsv_bnd* rows, int64_t n, const 
   HIPCHK(h, hipMemcpyAsync(h->g_rank.p, contig_rank, (size_t)n_tids * 4, kind, h->stream));
   if (h->totals.p) HIPCHK(h, hipMemsetAsync(h->totals.p, 0, (size_t)MAX_SORT_PASSES * 2048 * sizeof(uint32_t), h->stream));
   h->pass_cursor = 0;
+  h->group_cursor = MAX_GROUP_SLOTS;        // (the group sums are not zeroed here: these sorts keep their scan launch)
   Counters c; memset(&c, 0, sizeof c);
   c.n_s1 = (uint32_t)n;
   *h->pinned = c;

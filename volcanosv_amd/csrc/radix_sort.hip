@@ -22,6 +22,7 @@ namespace {
 constexpr int RS_WAVES = 4;
 constexpr int RS_ROUNDS_BIG = 16, RS_ROUNDS_SMALL = 4;
 template <int ROUNDS> constexpr uint32_t rs_tile() { return RS_WAVES * ROUNDS * 64; }
+constexpr uint32_t RS_GROUP = 16;       // tiles per group of the self-scanning bucket pass (rs_scatter<..., SELF>)
 
 template <int BITS>
 __device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid) {
@@ -85,7 +86,7 @@ struct CallKey {     // (tid, pos) key of a call row: the final order of pair_si
 
 template <int BITS, int ROUNDS, typename DIGIT, typename SRC>
 __global__ __launch_bounds__(256) void rs_hist(SRC src, const uint32_t* __restrict__ d_n, DIGIT dg,
-                                               uint32_t* __restrict__ hist, uint32_t* __restrict__ totals) {
+                                               uint32_t* __restrict__ hist, uint32_t* __restrict__ totals, uint32_t* __restrict__ groups = nullptr) {
   constexpr int BINS = 1 << BITS;
   __shared__ uint32_t cnt[BINS];
   const uint32_t n = *d_n, ntiles = n_tiles_of<ROUNDS>(n);
@@ -102,6 +103,8 @@ __global__ __launch_bounds__(256) void rs_hist(SRC src, const uint32_t* __restri
       const uint32_t c = cnt[d];
       hist[(size_t)tile * BINS + d] = c;
       if (totals && c) atomicAdd(&totals[d], c);   // per-digit totals of the whole input (zeroed at run start)
+      // ... and of every group of RS_GROUP tiles (a table with more groups than the slot holds is refused by bk_lds_sort)
+      if (groups && c && tile / RS_GROUP < (uint32_t)VSV_RS_MAX_GROUPS) atomicAdd(&groups[(size_t)(tile / RS_GROUP) * BINS + d], c);
     }
     __syncthreads();
   }
@@ -218,18 +221,41 @@ __global__ __launch_bounds__(1024) void rs_scan_mb(uint32_t* __restrict__ hist, 
   }
 }
 
-template <int BITS, int RS_ROUNDS, typename DIGIT, typename SRC>
+// SELF: `hist` still holds the raw per-tile counts (no scan launch ran): the block derives its tile's offsets itself — digit bases
+// from an in-block exclusive scan of the per-digit totals, plus the counts in front of its tile: the sums of the whole groups of
+// RS_GROUP tiles (accumulated by rs_hist) and the tiles of its own group — at most VSV_RS_MAX_GROUPS + RS_GROUP - 1 L2-hot rows of
+// BINS entries, whatever the table's size (a walk over every earlier tile is bound by the CU's 64 B/clk L2 port: 4 us at 270 tiles).
+template <int BITS, int RS_ROUNDS, typename DIGIT, typename SRC, bool SELF = false>
 __global__ __launch_bounds__(256) void rs_scatter(SRC src,
                                                   const uint32_t* __restrict__ d_n, DIGIT dg,
                                                   const uint32_t* __restrict__ hist, uint64_t* __restrict__ key_out,
-                                                  uint32_t* __restrict__ val_out, const uint32_t* __restrict__ totals) {
+                                                  uint32_t* __restrict__ val_out, const uint32_t* __restrict__ totals,
+                                                  const uint32_t* __restrict__ groups = nullptr) {
   constexpr int BINS = 1 << BITS;
+  constexpr int DPT = BINS / 256;             // digits per thread in the self-scan (BINS >= 256)
   __shared__ uint32_t wcnt[RS_WAVES][BINS];   // per-wave running digit counters, then (wave, digit) bases
-  (void)totals;
+  __shared__ uint32_t dbase[SELF ? BINS : 1];
+  __shared__ uint32_t wsum[RS_WAVES];
   constexpr uint32_t RS_TILE = rs_tile<RS_ROUNDS>();
   const uint32_t n = *d_n, ntiles = n_tiles_of<RS_ROUNDS>(n);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint64_t lt = (1ull << lane) - 1ull;
+  if (SELF && ntiles > (uint32_t)VSV_RS_MAX_GROUPS * RS_GROUP) return;   // more groups than the slot of group sums holds: see bk_lds_sort
+  if (SELF) {                                  // exclusive scan of the digit totals: thread t owns digits [t * DPT, (t + 1) * DPT)
+    uint32_t tt[DPT], mine = 0;
+#pragma unroll
+    for (int k = 0; k < DPT; ++k) { tt[k] = totals[threadIdx.x * DPT + k]; mine += tt[k]; }
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += o; }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    uint32_t run = incl - mine;
+    for (int w = 0; w < wv; ++w) run += wsum[w];
+#pragma unroll
+    for (int k = 0; k < DPT; ++k) { dbase[threadIdx.x * DPT + k] = run; run += tt[k]; }
+    __syncthreads();
+  }
   for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     for (int d = threadIdx.x; d < BINS; d += 256)
 #pragma unroll
@@ -255,10 +281,53 @@ __global__ __launch_bounds__(256) void rs_scatter(SRC src,
       rk[r] = ok ? old + (uint32_t)__popcll(m & lt) : 0xFFFFFFFFu;
     }
     __syncthreads();
-    for (int d = threadIdx.x; d < BINS; d += 256) {  // exclusive prefix of the digit's count over the waves + global base
-      uint32_t run = hist[(size_t)tile * BINS + d];
+    if (SELF) {
+      uint32_t col[DPT];
 #pragma unroll
-      for (int w = 0; w < RS_WAVES; ++w) { const uint32_t c = wcnt[w][d]; wcnt[w][d] = run; run += c; }
+      for (int k = 0; k < DPT; ++k) col[k] = dbase[threadIdx.x * DPT + k];
+      const uint32_t g_me = tile / RS_GROUP;
+      const uint32_t* gp = groups + threadIdx.x * DPT;
+      const uint32_t* hp = hist + (size_t)g_me * RS_GROUP * BINS + threadIdx.x * DPT;
+      {                                            // the tiles of the own group in front of this one: at most RS_GROUP - 1 rows, all in flight
+        const uint32_t in_group = tile - g_me * RS_GROUP;
+        uint32_t c[RS_GROUP - 1][DPT];
+#pragma unroll
+        for (uint32_t u = 0; u < RS_GROUP - 1; ++u)
+#pragma unroll
+          for (int k = 0; k < DPT; ++k) c[u][k] = u < in_group ? hp[(size_t)u * BINS + k] : 0u;
+#pragma unroll
+        for (uint32_t u = 0; u < RS_GROUP - 1; ++u)
+#pragma unroll
+          for (int k = 0; k < DPT; ++k) col[k] += c[u][k];
+      }
+      uint32_t gb = 0;
+      for (; gb + 8 <= g_me; gb += 8) {            // whole groups in front: eight rows in flight
+        uint32_t c[8][DPT];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int k = 0; k < DPT; ++k) c[u][k] = gp[(size_t)(gb + u) * BINS + k];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int k = 0; k < DPT; ++k) col[k] += c[u][k];
+      }
+      for (; gb < g_me; ++gb)
+#pragma unroll
+        for (int k = 0; k < DPT; ++k) col[k] += gp[(size_t)gb * BINS + k];
+#pragma unroll
+      for (int k = 0; k < DPT; ++k) {
+        const int d = threadIdx.x * DPT + k;
+        uint32_t run = col[k];
+#pragma unroll
+        for (int w = 0; w < RS_WAVES; ++w) { const uint32_t c = wcnt[w][d]; wcnt[w][d] = run; run += c; }
+      }
+    } else {
+      for (int d = threadIdx.x; d < BINS; d += 256) {  // exclusive prefix of the digit's count over the waves + global base
+        uint32_t run = hist[(size_t)tile * BINS + d];
+#pragma unroll
+        for (int w = 0; w < RS_WAVES; ++w) { const uint32_t c = wcnt[w][d]; wcnt[w][d] = run; run += c; }
+      }
     }
     __syncthreads();
 #pragma unroll
@@ -283,7 +352,7 @@ void one_pass(hipStream_t st, int64_t max_n, const uint64_t* kin, const uint32_t
   rs_hist<BITS, ROUNDS, LsdDigit, KeyArr><<<grid, 256, 0, st>>>(KeyArr{kin, vin}, d_n, dg, hist, totals);
   if (totals) rs_scan_mb<BITS, ROUNDS, 128, 8><<<(1 << BITS) / 128, 1024, 0, st>>>(hist, totals, d_n);
   else rs_scan<BITS, ROUNDS><<<1, 1024, 0, st>>>(hist, d_n);
-  rs_scatter<BITS, ROUNDS, LsdDigit, KeyArr><<<grid, 256, 0, st>>>(KeyArr{kin, vin}, d_n, dg, hist, kout, vout, totals);
+  rs_scatter<BITS, ROUNDS, LsdDigit, KeyArr, false><<<grid, 256, 0, st>>>(KeyArr{kin, vin}, d_n, dg, hist, kout, vout, totals);
 }
 
 // ---- bucket sort: ONE counting pass into <= 2048 key-range buckets, then one workgroup sorts each bucket in LDS -----------
@@ -315,19 +384,36 @@ template <>
 struct RowIO<void> {};
 template <typename ROW>
 __global__ __launch_bounds__(BK_THREADS) void bk_lds_sort(const uint64_t* __restrict__ key, const uint32_t* __restrict__ val,
-                                                           const uint32_t* __restrict__ base, int nbuckets, const uint32_t* __restrict__ d_n,
+                                                           const uint32_t* __restrict__ base, const uint32_t* __restrict__ totals, int nbuckets,
+                                                           const uint32_t* __restrict__ d_n,
                                                            uint64_t* __restrict__ key_out, uint32_t* __restrict__ val_out, uint32_t* __restrict__ err, uint32_t cap,
-                                                           RowIO<ROW> io) {
+                                                           uint32_t max_tile_rows, RowIO<ROW> io) {
   constexpr bool ROWS = !std::is_same<ROW, void>::value;
   __shared__ uint32_t sk[2][BK_CAP], sv[2][BK_CAP];
   __shared__ uint32_t wcnt[BK_WAVES][1 << BK_DBITS];
   __shared__ uint32_t tot[BK_WAVES];
   __shared__ unsigned long long s_min, s_max;
+  __shared__ uint32_t s_lo;
   const uint32_t n = *d_n;
   const int b = blockIdx.x;
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  if (totals && (n + max_tile_rows - 1) / max_tile_rows > (uint32_t)VSV_RS_MAX_GROUPS * RS_GROUP) {
+    // the table outgrew the group sums of the self-scanning pass (sized from the previous run): nothing was scattered
+    if (t == 0) atomicOr(err, ERRB_SORT_FALLBACK);
+    return;
+  }
+  if (totals) {          // no scan launch ran (self-scanning scatter): the bucket's first row = the totals of the buckets in front of it
+    uint32_t part = 0;
+    for (int d = t; d < b; d += BK_THREADS) part += totals[d];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) part += (uint32_t)__shfl_xor((int)part, d, 64);
+    if (t == 0) s_lo = 0;
+    __syncthreads();
+    if (lane == 0 && part) atomicAdd(&s_lo, part);
+    __syncthreads();
+  }
   {  // the last bucket holds the dead rows (all keys equal, nothing to sort): every workgroup moves a slice of it
-    uint32_t dlo = base[nbuckets - 1];
+    uint32_t dlo = totals ? n - min(n, totals[nbuckets - 1]) : base[nbuckets - 1];
     if (dlo > n) dlo = n;
     const uint32_t dm = n - dlo, per = (dm + gridDim.x - 1) / gridDim.x;
     const uint32_t a = dlo + min(dm, (uint32_t)b * per), e = dlo + min(dm, (uint32_t)(b + 1) * per);
@@ -342,7 +428,7 @@ __global__ __launch_bounds__(BK_THREADS) void bk_lds_sort(const uint64_t* __rest
     }
   }
   if (b == nbuckets - 1) return;
-  uint32_t lo = base[b], hi = base[b + 1];
+  uint32_t lo = totals ? s_lo : base[b], hi = totals ? lo + totals[b] : base[b + 1];
   if (lo > n) lo = n;
   if (hi > n) hi = n;
   if (hi <= lo) return;
@@ -386,6 +472,7 @@ __global__ __launch_bounds__(BK_THREADS) void bk_lds_sort(const uint64_t* __rest
   }
 #pragma unroll
   for (int j = 0; j < BK_PER; ++j) { const uint32_t i = (uint32_t)t + (uint32_t)j * BK_THREADS; if (i < m) { sk[0][i] = (uint32_t)(kr[j] - kmin); sv[0][i] = vr[j]; } }
+  int src = 0;
   // stable LSD passes over the bits that differ inside the bucket, digits as equal as possible and at most BK_DBITS wide
   const int wbits = 64 - __builtin_clzll(width);
   const int passes = (wbits + BK_DBITS - 1) / BK_DBITS;
@@ -395,7 +482,6 @@ __global__ __launch_bounds__(BK_THREADS) void bk_lds_sort(const uint64_t* __rest
   const uint32_t per = ((m + BK_WAVES - 1) / BK_WAVES + 63u) & ~63u;
   const uint32_t c0 = min(m, (uint32_t)wv * per), c1 = min(m, c0 + per);
   const uint64_t lt = (1ull << lane) - 1ull;
-  int src = 0;
   for (int pass = 0, shift = 0; pass < passes; ++pass, shift += db) {
     for (uint32_t d = t; d < BK_WAVES * nbins; d += BK_THREADS) wcnt[d / nbins][d % nbins] = 0;
     __syncthreads();
@@ -452,13 +538,26 @@ SortResult bucket_sort(hipStream_t st, SRC src, uint64_t* key, uint32_t* val, ui
   ++*w.pass_cursor;
   const int64_t max_tiles = (max_n + rs_tile<ROUNDS>() - 1) / rs_tile<ROUNDS>();
   const int grid = (int)(max_tiles < 1024 ? (max_tiles < 1 ? 1 : max_tiles) : 1024);
-  rs_hist<BITS, ROUNDS, BucketDigit, SRC><<<grid, 256, 0, st>>>(src, d_n, dg, w.hist, totals);
-  rs_scan_mb<BITS, ROUNDS, 32, 32><<<(1 << BITS) / 32, 1024, 0, st>>>(w.hist, totals, d_n);
-  rs_scatter<BITS, ROUNDS, BucketDigit, SRC><<<grid, 256, 0, st>>>(src, d_n, dg, w.hist, key_scratch, val_scratch, totals);
-  // bucket bases = the scanned histogram row of tile 0 (offset of the first tile's rows of every bucket)
+  // the self-scanning form needs a zeroed slot of group sums and a table of at most VSV_RS_MAX_GROUPS groups of tiles (the row
+  // count of the handle's previous run; a table that grew past it is caught below: the sort falls back like an overflowing bucket)
+  static const char* scan_env = getenv("VSV_BK_SCAN");      // timing experiments / tests: "self" | "launch"
+  uint32_t* groups = nullptr;
+  if (w.groups && *w.group_cursor < w.max_group_slots && w.hint_rows > 0 &&
+      w.hint_rows + w.hint_rows / 2 <= (uint64_t)VSV_RS_MAX_GROUPS * RS_GROUP * rs_tile<ROUNDS>() && !(scan_env && scan_env[0] == 'l')) {
+    groups = w.groups + (size_t)(*w.group_cursor) * VSV_RS_MAX_GROUPS * 2048;
+    ++*w.group_cursor;
+  }
+  const bool self = groups != nullptr;
+  rs_hist<BITS, ROUNDS, BucketDigit, SRC><<<grid, 256, 0, st>>>(src, d_n, dg, w.hist, totals, groups);
+  if (self) rs_scatter<BITS, ROUNDS, BucketDigit, SRC, true><<<grid, 256, 0, st>>>(src, d_n, dg, w.hist, key_scratch, val_scratch, totals, groups);
+  else {
+    rs_scan_mb<BITS, ROUNDS, 32, 32><<<(1 << BITS) / 32, 1024, 0, st>>>(w.hist, totals, d_n);
+    rs_scatter<BITS, ROUNDS, BucketDigit, SRC, false><<<grid, 256, 0, st>>>(src, d_n, dg, w.hist, key_scratch, val_scratch, totals);
+  }
+  // bucket bases = the scanned histogram row of tile 0 (offset of the first tile's rows of every bucket), or the totals in front
   static const int cap_env = getenv("VSV_BK_CAP") ? atoi(getenv("VSV_BK_CAP")) : BK_CAP;      // tests force the fallback with a tiny capacity
   const uint32_t cap = (uint32_t)(cap_env < 2 ? 2 : cap_env > BK_CAP ? BK_CAP : cap_env);
-  bk_lds_sort<ROW><<<1 << BITS, BK_THREADS, 0, st>>>(key_scratch, val_scratch, w.hist, 1 << BITS, d_n, key, val, w.err, cap, io);
+  bk_lds_sort<ROW><<<1 << BITS, BK_THREADS, 0, st>>>(key_scratch, val_scratch, w.hist, self ? totals : nullptr, 1 << BITS, d_n, key, val, w.err, cap, rs_tile<ROUNDS>(), io);
   return SortResult{key, val};
 }
 

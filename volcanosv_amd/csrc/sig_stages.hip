@@ -184,8 +184,15 @@ __device__ __forceinline__ void load_qid8(const uint32_t* __restrict__ qid, int6
     for (int k = 0; k < 8; ++k) q[k] = (base + k < n) ? qid[base + k] + 1u : 0u;
   }
 }
-__global__ __launch_bounds__(256) void qid_tile_max(const uint32_t* __restrict__ qid, int64_t n, uint32_t* __restrict__ tile_max, bool vec) {
+// (+ every block clears its slice of the name table's bits for qid_mark_dups: no fill launch)
+__global__ __launch_bounds__(256) void qid_tile_max(const uint32_t* __restrict__ qid, int64_t n, uint32_t* __restrict__ tile_max, bool vec,
+                                                    uint32_t* __restrict__ tab, uint32_t tab_words) {
   __shared__ uint32_t sh[4];
+  {
+    const uint32_t per = (tab_words + gridDim.x - 1) / gridDim.x;
+    const uint32_t a = min(tab_words, blockIdx.x * per), e = min(tab_words, a + per);
+    for (uint32_t i = a + threadIdx.x; i < e; i += 256) tab[i] = 0;
+  }
   uint32_t q[8];
   load_qid8(qid, (int64_t)blockIdx.x * QM_TILE + threadIdx.x * 8, n, vec, q);
   uint32_t m = 0;
@@ -314,14 +321,11 @@ __global__ __launch_bounds__(256) void split_cand(RecView rv, SplitCfg c, const 
     return;
   }
   uint32_t off = blk[blockIdx.x];  // exclusive block offset
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {   // the last block knows the total: publish the candidate and row counts
-    uint32_t t = off;
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {   // the last block knows the total: publish the candidate count
+    uint32_t t = off;                                       // (n_s1 = n_raw + n_cand is split_eval's: this kernel may run next to the scan)
     for (int k = 0; k < SC_ROUNDS; ++k) for (int w = 0; w < 4; ++w) t += cnt[k][w];
-    const uint32_t nc = t < cap ? t : cap;
-    ctr->n_cand = nc;
+    ctr->n_cand = t < cap ? t : cap;
     if (t > cap) atomicOr(&ctr->err, ERRB_CAPACITY);
-    const uint32_t s1 = ctr->n_raw + nc;
-    ctr->n_s1 = s1 < cap ? s1 : cap;
   }
 #pragma unroll
   for (int k = 0; k < SC_ROUNDS; ++k) {
@@ -404,6 +408,7 @@ __global__ __launch_bounds__(256) void split_eval(RecView rv, const uint64_t* __
                                                   SplitCfg c, int dtype, int max_svlen, vsv_sig* __restrict__ s1in,
                                                   uint32_t cap, Counters* ctr) {
   const uint32_t n = ctr->n_cand, n_raw = ctr->n_raw;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { const uint32_t s1 = n_raw + n; ctr->n_s1 = s1 < cap ? s1 : cap; }
   const int lane = threadIdx.x & (SE_GROUP - 1), wlane = threadIdx.x & 63;
   const uint32_t ngroups = gridDim.x * (blockDim.x / SE_GROUP);
   const bool reads = dtype == VSV_DTYPE_READS;
@@ -924,43 +929,55 @@ void vsv_launch_fold(hipStream_t st, const vsv_sig* raw, vsv_sig* s1in, const Re
 
 static int bits_for(uint64_t n) { int b = 1; while ((1ull << b) < n && b < 63) ++b; return b; }
 
-void vsv_launch_split(hipStream_t st, const RecView& rv, const vsv_params& p, int n_tids, uint32_t* tab, uint32_t tab_size,
-                      uint32_t* blk_cnt, uint32_t* blk_off, uint32_t* scan_tmp, uint64_t* ckey, uint32_t* crec,
-                      uint64_t* okey, uint32_t* oval, uint64_t* key2, uint32_t* idx2, const SortWork& sw, vsv_sig* s1in,
-                      uint32_t cap, Counters* ctr, uint8_t* cmask, int grid) {
+static SplitCfg split_cfg(const RecView& rv, const vsv_params& p, int n_tids) {
   SplitCfg c;
   c.contig = p.dtype != VSV_DTYPE_READS;
   c.min_mapq = p.min_split_mapq;
   c.qid_bits = bits_for((uint64_t)(rv.n_qids > 0 ? rv.n_qids : rv.n_records) + 1);
   c.tid_shift = c.qid_bits + 1;
   c.tid_lo = rv.tid_lo;
-  const int tid_bits = bits_for((uint64_t)(n_tids > 0 ? n_tids - rv.tid_lo : 65536) + 1);
-  c.tid_bits = tid_bits;
+  c.tid_bits = bits_for((uint64_t)(n_tids > 0 ? n_tids - rv.tid_lo : 65536) + 1);
+  return c;
+}
+
+// The split stage in two halves. The first — which query names occur more than once, the candidate records, their two orderings
+// (by name, then by record) — reads nothing but the record arrays: the fused run enqueues it on the handle's auxiliary stream,
+// next to the CIGAR scan (capi.hip enq_scan). The second, split_eval, appends its rows behind the scan's (n_raw) and joins.
+SplitSorted vsv_launch_split_candidates(hipStream_t st, const RecView& rv, const vsv_params& p, int n_tids, uint32_t* tab, uint32_t tab_size,
+                                        uint32_t* blk_cnt, uint32_t* blk_off, uint32_t* scan_tmp, uint64_t* ckey, uint32_t* crec,
+                                        uint64_t* okey, uint32_t* oval, uint64_t* key2, uint32_t* idx2, const SortWork& sw,
+                                        uint32_t cap, Counters* ctr, uint8_t* cmask, int grid) {
+  SplitSorted out{nullptr, nullptr, nullptr, nullptr};
+  if (rv.n_records <= 0) return out;
+  const SplitCfg c = split_cfg(rv, p, n_tids);
   const int rec_bits = bits_for((uint64_t)rv.n_records + 1);
-  if (rv.n_records > 0) {
-    const uint64_t nq = rv.n_qids > 0 ? (uint64_t)rv.n_qids : (uint64_t)tab_size * 32;
-    (void)hipMemsetAsync(tab, 0, (size_t)((nq + 31) / 32 + 1) * sizeof(uint32_t), st);
-    const int qtiles = (int)((rv.n_records + QM_TILE - 1) / QM_TILE);
-    // wide loads need 16-byte (qid) / 4-byte (flag, mapq) aligned arrays; anything else takes the element-wise path
-    const bool vec = ((uintptr_t)rv.qid & 15u) == 0 && ((uintptr_t)rv.flag & 3u) == 0 && ((uintptr_t)rv.mapq & 3u) == 0;
-    qid_tile_max<<<qtiles, 256, 0, st>>>(rv.qid, rv.n_records, blk_cnt, vec);
-    qid_scan_max<<<1, 1024, 0, st>>>(blk_cnt, qtiles);
-    qid_mark_dups<<<qtiles, 256, 0, st>>>(rv.qid, rv.n_records, blk_cnt, tab, vec, (uint32_t)nq, &ctr->err);
-    const int nblk = (int)(((uint64_t)rv.n_records + SC_TILE_REC - 1) / SC_TILE_REC);
-    split_cand<false><<<nblk, 256, 0, st>>>(rv, c, tab, blk_cnt, ckey, crec, cap, vec, ctr, cmask);
-    vsv_scan_u32_exclusive(st, blk_cnt, nblk, blk_off, scan_tmp);
-    split_cand<true><<<nblk, 256, 0, st>>>(rv, c, tab, blk_off, ckey, crec, cap, vec, ctr, cmask);
-    // the first result may live in the shared scratch pair, so the second sort gets a scratch pair of its own
-    const SortResult r1 = vsv_radix_sort_pairs(st, ckey, crec, sw.key_alt, sw.val_alt, &ctr->n_cand, cap, c.tid_shift + tid_bits, sw,
-                                               1ull << (c.tid_shift + tid_bits));     // no dead keys in this table: the whole range is alive
-    split_mark_pairs<<<grid, 256, 0, st>>>(r1.key, r1.val, c, rec_bits, okey, oval, ctr);
-    const SortResult r2 = vsv_radix_sort_pairs(st, okey, oval, key2, idx2, &ctr->n_cand, cap, rec_bits + 1 + tid_bits + 1, sw);
-    const int eg = grid * 8 < 1024 ? 1024 : (grid * 8 > 8192 ? 8192 : grid * 8);
-    if (vsv_scan_is_long(rv, p)) split_eval<64><<<eg, 256, 0, st>>>(rv, r2.key, r2.val, r1.key, r1.val, c, p.dtype, p.max_split_svlen, s1in, cap, ctr);
-    else split_eval<8><<<eg, 256, 0, st>>>(rv, r2.key, r2.val, r1.key, r1.val, c, p.dtype, p.max_split_svlen, s1in, cap, ctr);
-  } else {
-    set_n_s1<<<1, 1, 0, st>>>(ctr, cap);
-  }
+  const uint64_t nq = rv.n_qids > 0 ? (uint64_t)rv.n_qids : (uint64_t)tab_size * 32;
+  const int qtiles = (int)((rv.n_records + QM_TILE - 1) / QM_TILE);
+  // wide loads need 16-byte (qid) / 4-byte (flag, mapq) aligned arrays; anything else takes the element-wise path
+  const bool vec = ((uintptr_t)rv.qid & 15u) == 0 && ((uintptr_t)rv.flag & 3u) == 0 && ((uintptr_t)rv.mapq & 3u) == 0;
+  qid_tile_max<<<qtiles, 256, 0, st>>>(rv.qid, rv.n_records, blk_cnt, vec, tab, (uint32_t)((nq + 31) / 32 + 1));
+  qid_scan_max<<<1, 1024, 0, st>>>(blk_cnt, qtiles);
+  qid_mark_dups<<<qtiles, 256, 0, st>>>(rv.qid, rv.n_records, blk_cnt, tab, vec, (uint32_t)nq, &ctr->err);
+  const int nblk = (int)(((uint64_t)rv.n_records + SC_TILE_REC - 1) / SC_TILE_REC);
+  split_cand<false><<<nblk, 256, 0, st>>>(rv, c, tab, blk_cnt, ckey, crec, cap, vec, ctr, cmask);
+  vsv_scan_u32_exclusive(st, blk_cnt, nblk, blk_off, scan_tmp);
+  split_cand<true><<<nblk, 256, 0, st>>>(rv, c, tab, blk_off, ckey, crec, cap, vec, ctr, cmask);
+  // the first result may live in the shared scratch pair, so the second sort gets a scratch pair of its own
+  const SortResult r1 = vsv_radix_sort_pairs(st, ckey, crec, sw.key_alt, sw.val_alt, &ctr->n_cand, cap, c.tid_shift + c.tid_bits, sw,
+                                             1ull << (c.tid_shift + c.tid_bits));     // no dead keys in this table: the whole range is alive
+  split_mark_pairs<<<grid, 256, 0, st>>>(r1.key, r1.val, c, rec_bits, okey, oval, ctr);
+  const SortResult r2 = vsv_radix_sort_pairs(st, okey, oval, key2, idx2, &ctr->n_cand, cap, rec_bits + 1 + c.tid_bits + 1, sw);
+  out.ckey = r1.key; out.crec = r1.val; out.okey = r2.key; out.oval = r2.val;
+  return out;
+}
+
+void vsv_launch_split_eval(hipStream_t st, const RecView& rv, const vsv_params& p, int n_tids, const SplitSorted& so, vsv_sig* s1in,
+                           uint32_t cap, Counters* ctr, int grid) {
+  if (rv.n_records <= 0 || !so.okey) { set_n_s1<<<1, 1, 0, st>>>(ctr, cap); return; }
+  const SplitCfg c = split_cfg(rv, p, n_tids);
+  const int eg = grid * 8 < 1024 ? 1024 : (grid * 8 > 8192 ? 8192 : grid * 8);
+  if (vsv_scan_is_long(rv, p)) split_eval<64><<<eg, 256, 0, st>>>(rv, so.okey, so.oval, so.ckey, so.crec, c, p.dtype, p.max_split_svlen, s1in, cap, ctr);
+  else split_eval<8><<<eg, 256, 0, st>>>(rv, so.okey, so.oval, so.ckey, so.crec, c, p.dtype, p.max_split_svlen, s1in, cap, ctr);
 }
 
 // sort rows `in[0,n)` by the stage key into `sorted`, publish the alive count

@@ -107,7 +107,13 @@ struct SortWork {       // scratch for vsv_radix_sort_pairs
   bool small_tiles;     // 1024-row instead of 4096-row tiles; chosen by the caller from the row count of the previous run (both exact)
   int bucket_bits;      // 8..11: bucket sort (one counting pass + LDS sort per bucket) with 2^bits buckets; 0: LSD passes only
   uint32_t* err;        // device error word (ERRB_SORT_FALLBACK)
+  uint64_t hint_rows;   // rows of the largest table of the handle's previous run (0 = unknown): speed decisions only
+  // bucket sorts without a scan launch: zeroed slots of [VSV_RS_MAX_GROUPS][2048] sums over groups of tiles, one per sort
+  uint32_t* groups;
+  int* group_cursor;
+  int max_group_slots;
 };
+constexpr int VSV_RS_MAX_GROUPS = 64;
 struct StageBufs {
   uint64_t* key;        // sort keys of the current stage (kept sorted for cluster / pair kernels)
   uint32_t* idx;
@@ -152,10 +158,13 @@ void vsv_launch_cigar_scan(hipStream_t st, const RecView& rv, const vsv_params& 
 // sig_stages.hip
 void vsv_launch_clr_gate(hipStream_t st, const RecView& rv, uint8_t* gflag, Counters* ctr);   // CLR: gated flag bytes for the scan
 void vsv_launch_fold(hipStream_t st, const vsv_sig* raw, vsv_sig* s1in, const RecView& rv, const vsv_params& p, Counters* ctr, int grid);
-void vsv_launch_split(hipStream_t st, const RecView& rv, const vsv_params& p, int n_tids, uint32_t* tab, uint32_t tab_size,
-                      uint32_t* blk_cnt, uint32_t* blk_off, uint32_t* scan_tmp, uint64_t* ckey, uint32_t* crec,
-                      uint64_t* okey, uint32_t* oval, uint64_t* key2, uint32_t* idx2, const SortWork& sw, vsv_sig* s1in,
-                      uint32_t cap, Counters* ctr, uint8_t* cmask, int grid);
+struct SplitSorted { const uint64_t* ckey; const uint32_t* crec; const uint64_t* okey; const uint32_t* oval; };   // candidates by name / pairs by record
+SplitSorted vsv_launch_split_candidates(hipStream_t st, const RecView& rv, const vsv_params& p, int n_tids, uint32_t* tab, uint32_t tab_size,
+                                        uint32_t* blk_cnt, uint32_t* blk_off, uint32_t* scan_tmp, uint64_t* ckey, uint32_t* crec,
+                                        uint64_t* okey, uint32_t* oval, uint64_t* key2, uint32_t* idx2, const SortWork& sw,
+                                        uint32_t cap, Counters* ctr, uint8_t* cmask, int grid);
+void vsv_launch_split_eval(hipStream_t st, const RecView& rv, const vsv_params& p, int n_tids, const SplitSorted& so, vsv_sig* s1in,
+                           uint32_t cap, Counters* ctr, int grid);
 // returns the sorted key array (kept for the cluster / pair kernel that follows)
 const uint64_t* vsv_launch_sort_stage(hipStream_t st, const vsv_sig* in, const uint32_t* d_n, int stage, int pb, int nbits,
                                       vsv_sig* sorted, uint32_t* d_alive, const StageBufs& b, const SortWork& sw, int64_t cap,
