@@ -76,7 +76,7 @@ struct vsv_handle {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool have_scan_ev = false;
   // the fused run builds the split candidates (record arrays only) on `aux` while the scan streams the CIGARs on `stream`
-  hipStream_t aux = nullptr;
+  hipStream_t aux = nullptr, aux2 = nullptr;   // aux2: second lane of the sliced BGZF inflate
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool fork_split = false;         // this run is the fused one: enq_scan may start the candidates early
   bool split_cands_done = false;   // the candidates of this run are enqueued (enq_split only evaluates the pairs)
@@ -546,6 +546,7 @@ int vsv_create(int device_id, void* hip_stream, vsv_handle** out) {
   hipEventCreate(&h->ev0);
   hipEventCreate(&h->ev1);
   if (hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking) != hipSuccess) h->aux = nullptr;   // without it everything stays on `stream`
+  if (hipStreamCreateWithFlags(&h->aux2, hipStreamNonBlocking) != hipSuccess) h->aux2 = nullptr;
   hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
   hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
   memset(&h->host_ctr, 0, sizeof h->host_ctr);
@@ -559,6 +560,7 @@ void vsv_destroy(vsv_handle* h) {
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
   if (h->aux) { hipStreamSynchronize(h->aux); hipStreamDestroy(h->aux); }
+  if (h->aux2) { hipStreamSynchronize(h->aux2); hipStreamDestroy(h->aux2); }
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
   if (h->ev_join) hipEventDestroy(h->ev_join);
   DevBuf* bufs[] = {&h->scan_tmp2, &h->r_pos, &h->r_tid, &h->r_qid, &h->r_off, &h->r_mapq, &h->r_flag, &h->r_cigar, &h->part_rb, &h->part_count,
@@ -953,13 +955,7 @@ static int inflate_to_device(vsv_handle* h, const uint8_t* comp, const uint64_t*
   if ((st = upload(h, h->z_ooff, ooff.data(), (size_t)(n + 1) * 8))) return st;
   if ((st = ensure(h, h->z_out, obytes + 64))) return st;
   if ((st = ensure(h, h->z_stat, (size_t)n * 4))) return st;
-  if ((st = upload(h, h->z_comp, comp + comp_off[0], cbytes))) return st;
-  // one launch for all members: a member is milliseconds of serial decode, so the launch is as long as its slowest member and
-  // batches (to overlap the upload with the decode) only add such latencies up — tried, 39 -> 71 ms on a 9 k-member file
-  vsv_launch_bgzf_inflate(h->stream, (const uint8_t*)h->z_comp.p, (const uint64_t*)h->z_coff.p, (const uint64_t*)h->z_ooff.p, n,
-                          (uint8_t*)h->z_out.p, (int32_t*)h->z_stat.p);
-  HIPCHK(h, hipGetLastError());
-  std::vector<uint32_t> crc;
+  if ((st = ensure(h, h->z_comp, cbytes + 16))) return st;
   if (expect_crc) {        // the gzip trailer's CRC-32 of every member, computed where the bytes are
     if (!h->z_crctab.p) {
       std::vector<uint32_t> t(256 + 17 * 32);
@@ -967,13 +963,63 @@ static int inflate_to_device(vsv_handle* h, const uint8_t* comp, const uint64_t*
       if ((st = upload(h, h->z_crctab, t.data(), t.size() * 4))) return st;
     }
     if ((st = ensure(h, h->z_crc, (size_t)n * 4))) return st;
-    vsv_launch_bgzf_crc32(h->stream, (const uint8_t*)h->z_out.p, (const uint64_t*)h->z_ooff.p, n, (const uint32_t*)h->z_crctab.p, (uint32_t*)h->z_crc.p);
+  }
+  // The members go up in a few slices and every slice is decoded as soon as it has arrived, on the handle's auxiliary streams:
+  // the copy of slice k + 1 (pageable memory: the host thread is inside the copy) runs under the decode of slice k. A slice's
+  // launch lasts as long as its slowest member (milliseconds of serial decode): on ONE stream those latencies add up (39 -> 71 ms
+  // on a 9 k-member file), on two streams they overlap. What is left is the decode itself: 28.7 ms of kernel time for 9 124
+  // members whatever the slicing.
+  static const int slices_env = getenv("VSV_INFLATE_SLICES") ? atoi(getenv("VSV_INFLATE_SLICES")) : 0;      // timing experiments
+  int n_slices = slices_env > 0 ? slices_env : (int)(n / 2048);       // 9 k members: 1 slice 38.6 ms, 2: 33.7, 4: 31.3, 8: 34.5
+  if (n_slices < 1 || !h->aux || !h->aux2) n_slices = 1;
+  if (n_slices > (slices_env > 0 ? 8 : 4)) n_slices = slices_env > 0 ? 8 : 4;
+  std::vector<hipEvent_t> evs;
+  auto drop_events = [&]() { for (hipEvent_t e : evs) (void)hipEventDestroy(e); evs.clear(); };
+  hipStream_t lanes[2] = {n_slices > 1 ? h->aux : h->stream, n_slices > 1 ? h->aux2 : h->stream};
+  hipError_t herr = hipSuccess;
+  for (int c = 0; c < n_slices && herr == hipSuccess; ++c) {
+    const int64_t m0 = n * c / n_slices, m1 = n * (c + 1) / n_slices;
+    if (m1 <= m0) continue;
+    const size_t b0 = (size_t)coff[m0], b1 = (size_t)coff[m1];
+    if (b1 > b0) herr = hipMemcpyAsync((uint8_t*)h->z_comp.p + b0, comp + comp_off[0] + b0, b1 - b0, hipMemcpyHostToDevice, h->stream);
+    hipStream_t ls = lanes[c & 1];
+    if (herr == hipSuccess && ls != h->stream) {
+      hipEvent_t e;
+      herr = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+      if (herr == hipSuccess) { evs.push_back(e); herr = hipEventRecord(e, h->stream); }
+      if (herr == hipSuccess) herr = hipStreamWaitEvent(ls, e, 0);
+    }
+    if (herr != hipSuccess) break;
+    vsv_launch_bgzf_inflate(ls, (const uint8_t*)h->z_comp.p, (const uint64_t*)h->z_coff.p + m0, (const uint64_t*)h->z_ooff.p + m0, m1 - m0,
+                            (uint8_t*)h->z_out.p, (int32_t*)h->z_stat.p + m0);
+    if (expect_crc)
+      vsv_launch_bgzf_crc32(ls, (const uint8_t*)h->z_out.p, (const uint64_t*)h->z_ooff.p + m0, m1 - m0, (const uint32_t*)h->z_crctab.p, (uint32_t*)h->z_crc.p + m0);
+    herr = hipGetLastError();
+  }
+  for (int k = 0; k < 2 && herr == hipSuccess && n_slices > 1; ++k) {       // the handle's stream continues when both lanes are done
+    hipEvent_t e;
+    herr = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    if (herr == hipSuccess) { evs.push_back(e); herr = hipEventRecord(e, lanes[k]); }
+    if (herr == hipSuccess) herr = hipStreamWaitEvent(h->stream, e, 0);
+  }
+  if (herr != hipSuccess) {
+    (void)hipDeviceSynchronize();
+    drop_events();
+    return fail(h, VSV_E_HIP, std::string("bgzf inflate: ") + hipGetErrorString(herr));
+  }
+  std::vector<uint32_t> crc;
+  if (expect_crc) {
     crc.resize((size_t)n);
-    HIPCHK(h, hipMemcpyAsync(crc.data(), h->z_crc.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    hipError_t ce = hipMemcpyAsync(crc.data(), h->z_crc.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream);
+    if (ce != hipSuccess) { (void)hipDeviceSynchronize(); drop_events(); return fail(h, VSV_E_HIP, std::string("crc copy: ") + hipGetErrorString(ce)); }
   }
   std::vector<int32_t> stat((size_t)n);
-  HIPCHK(h, hipMemcpyAsync(stat.data(), h->z_stat.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  {
+    hipError_t se = hipMemcpyAsync(stat.data(), h->z_stat.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream);
+    if (se == hipSuccess) se = hipStreamSynchronize(h->stream);
+    drop_events();
+    if (se != hipSuccess) return fail(h, VSV_E_HIP, std::string("bgzf inflate: ") + hipGetErrorString(se));
+  }
   for (int64_t i = 0; i < n; ++i)
     if (stat[i]) { h->last_count = i; char m[96]; snprintf(m, sizeof m, "BGZF member %lld is not a valid deflate stream (code %d)", (long long)i, stat[i]); return fail(h, VSV_E_INVALID, m); }
   if (expect_crc)

@@ -16,13 +16,15 @@ namespace {
 
 constexpr int MAXBITS = 15, MAXLCODES = 286, MAXDCODES = 30, FIXLCODES = 288;
 
-constexpr int LFAST = 9, DFAST = 8;    // bits resolved by one table lookup; longer codes fall back to the bit-serial decode
+constexpr int LFAST = 10, DFAST = 9;   // bits resolved by one table lookup; longer codes fall back to the bit-serial decode
 struct Tables {
   uint16_t lcount[MAXBITS + 1], lsymbol[FIXLCODES];
   uint16_t dcount[MAXBITS + 1], dsymbol[MAXDCODES];
   uint8_t lengths[MAXLCODES + MAXDCODES + 2];
-  uint16_t lfast[1 << LFAST];          // [next LFAST stream bits] -> symbol << 4 | code length, 0 = longer code
-  uint16_t dfast[1 << DFAST];
+  // [next LFAST / DFAST stream bits] -> everything the body of a block needs from the symbol in one dword (lit_entry / dist_entry
+  // below) | code length in bits 0-3; 0 in those bits = a longer code (bit-serial decode)
+  uint32_t lfast[1 << LFAST];
+  uint32_t dfast[1 << DFAST];
 };
 
 // one dword of the compressed stream through the scalar cache (lgkmcnt): it does not queue behind the output stores
@@ -36,14 +38,20 @@ __device__ __forceinline__ uint32_t sload_dword(const uint32_t* p) {
 }
 
 struct Bits {                       // all members wave-uniform
-  const uint32_t* w; uint32_t nwords; uint32_t wi; uint64_t buf; int cnt; int skip; bool over;
+  const uint32_t* p; const uint32_t* end; uint64_t buf; int cnt; int skip; bool over;
   // the stream is read as aligned dwords; `skip` leading bytes of the first dword belong to the previous member
   __device__ __forceinline__ void refill() {
-    if (cnt <= 32 && wi < nwords) {
-      uint64_t v = sload_dword(w + wi); ++wi;
+    if (cnt <= 32 && p != end) {
+      uint64_t v = sload_dword(p); ++p;
       int nb = 32;
       if (skip) { v >>= 8 * skip; nb -= 8 * skip; skip = 0; }
       buf |= v << cnt; cnt += nb;
+    }
+  }
+  // the same once the first dword is in (skip == 0): the block bodies
+  __device__ __forceinline__ void refill_body() {
+    if (cnt <= 32) {
+      if (p != end) { const uint64_t v = sload_dword(p); ++p; buf |= v << cnt; cnt += 32; }
     }
   }
   __device__ __forceinline__ uint32_t get(int n) {          // n <= 16
@@ -118,8 +126,8 @@ __device__ __forceinline__ int construct_by_lane0(uint16_t* count, uint16_t* sym
 // Fast table of a code whose count[] / symbol[] are built: entry [v] for every LFAST-bit value v of the stream whose low bits
 // are a complete code of length <= BITS (stream bits arrive LSB first, code bits MSB first, hence the bit reversal).
 // The 64 lanes share the work: lane handles the sorted symbols lane, lane + 64, ...
-template <int BITS>
-__device__ __forceinline__ void build_fast(const uint16_t* count, const uint16_t* symbol, uint16_t* fast, int lane) {
+template <int BITS, typename ENTRY>
+__device__ __forceinline__ void build_fast(const uint16_t* count, const uint16_t* symbol, uint32_t* fast, int lane, ENTRY entry) {
   for (int i = lane; i < (1 << BITS); i += 64) fast[i] = 0;
   __builtin_amdgcn_wave_barrier();
   int code = 0, index = 0;                           // canonical first code / first sorted index of the current length
@@ -127,7 +135,7 @@ __device__ __forceinline__ void build_fast(const uint16_t* count, const uint16_t
     const int c = __builtin_amdgcn_readfirstlane((int)count[len]);
     for (int r = lane; r < c; r += 64) {
       const uint32_t rev = __builtin_bitreverse32((uint32_t)(code + r)) >> (32 - len);
-      const uint16_t e = (uint16_t)((symbol[index + r] << 4) | len);
+      const uint32_t e = entry((int)symbol[index + r]) | (uint32_t)len;
       for (uint32_t hi = 0; hi < (1u << (BITS - len)); ++hi) fast[rev | (hi << len)] = e;
     }
     code = (code + c) << 1;
@@ -136,73 +144,205 @@ __device__ __forceinline__ void build_fast(const uint16_t* count, const uint16_t
   __builtin_amdgcn_wave_barrier();
 }
 
-template <int BITS>
-__device__ __forceinline__ int decode_fast(Bits& b, const uint16_t* fast, const Counts& k, const uint16_t* symbol) {
-  if (b.cnt < MAXBITS) { b.refill(); if (b.cnt < MAXBITS) b.refill(); }
-  const int e = __builtin_amdgcn_readfirstlane((int)fast[(uint32_t)b.buf & ((1u << BITS) - 1u)]);
-  const int len = e & 15;
-  if (e != 0 && len <= b.cnt) { b.buf >>= len; b.cnt -= len; return e >> 4; }
-  return decode_reg(b, k, symbol);                   // code longer than BITS bits, or the stream is about to end
+// base value and extra bits of the length symbols 257..285 (sym = symbol - 257) and the distance symbols 0..29 (RFC 1951 3.2.5),
+// computed: a table in constant memory is a vector load and a round trip to the cache per lookup, twice per match
+__device__ __forceinline__ void length_code(int sym, uint32_t& base, int& ext) {
+  if (sym < 8) { base = 3u + (uint32_t)sym; ext = 0; }
+  else if (sym == 28) { base = 258u; ext = 0; }
+  else { ext = (sym - 4) >> 2; base = 3u + ((4u + ((uint32_t)sym & 3u)) << ext); }
 }
-
-__constant__ uint16_t LBASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-__constant__ uint8_t LEXT[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-__constant__ uint16_t DBASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-__constant__ uint8_t DEXT[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+__device__ __forceinline__ void dist_code(int ds, uint32_t& base, int& ext) {
+  if (ds < 4) { base = 1u + (uint32_t)ds; ext = 0; }
+  else { ext = (ds - 2) >> 1; base = 1u + ((2u + ((uint32_t)ds & 1u)) << ext); }
+}
 __constant__ uint8_t CLORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
-// Output side of one member: literals wait one per lane and are stored 64 at a time.
+// Output side of one member: literals wait one per lane and are stored 64 at a time. Every byte also goes to a ring of the last
+// RING bytes in LDS: an LZ77 match that starts inside the ring (the usual case: the previous records of a BAM block) copies from
+// LDS at LDS latency — a store to global memory followed by a load of the same bytes is a round trip to L2 of a microsecond, and a
+// member holds thousands of matches (10 ms per member, whatever the occupancy, when every match took that trip). Matches from
+// further back read global memory as before, after a wait for the stores.
+constexpr uint32_t RING = 8192;
 struct Out {
-  uint8_t* dst; uint32_t o, cap; uint32_t npend; uint32_t lit; int lane;      // o counts flushed bytes; lit = this lane's pending byte
+  uint8_t* dst; uint32_t o, cap; uint32_t npend; uint32_t lit; int lane; uint8_t* ring;   // o counts flushed bytes; lit = this lane's pending byte
+  bool full;                        // more output than the member's ISIZE: nothing is written any more, the block body ends with -3
+  // the pending literals leave — unless they do not fit the member's ISIZE
   __device__ __forceinline__ void flush() {
-    if ((uint32_t)lane < npend) dst[o + lane] = (uint8_t)lit;
+    // (one lane predicate, no early exit: a uniform branch around the masked stores makes the compiler treat the whole bit
+    // reader as divergent, i.e. moves it from the scalar to the vector unit)
+    const bool fits = o + npend <= cap;
+    if (!fits) full = true;
+    if ((uint32_t)lane < (fits ? npend : 0u)) { dst[o + lane] = (uint8_t)lit; ring[(o + lane) & (RING - 1u)] = (uint8_t)lit; }
     o += npend; npend = 0;
   }
-  __device__ __forceinline__ bool literal(uint32_t sym) {
-    if (o + npend >= cap) return false;
+  __device__ __forceinline__ void literal(uint32_t sym) {   // (the ISIZE test waits for the flush: at most 64 pending bytes)
     if ((uint32_t)lane == npend) lit = sym;
     if (++npend == 64) flush();
-    return true;
   }
   // copy len bytes from distance dist behind the write position; sources may overlap the destination (dist < len)
   __device__ __forceinline__ bool match(uint32_t len, uint32_t dist) {
     flush();
-    if (dist > o || o + len > cap) return false;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the bytes just stored are the bytes about to be read
-    const uint32_t step = dist < 64u ? dist : 64u;
+    if (full || dist > o || o + len > cap) return false;
+    __builtin_amdgcn_wave_barrier();
+    if (dist + 64u <= RING) {
+      // every source byte is in the ring (the ring holds the last RING bytes; a step writes at most 64 ahead). An overlapping match
+      // (dist < len) repeats its first dist bytes: all lanes read from that period, no step waits for the one before.
+      if (dist >= len) {
+        for (uint32_t base = 0; base < len; base += 64u) {
+          const uint32_t i = base + (uint32_t)lane;
+          if (i < len) { const uint8_t v = ring[(o - dist + i) & (RING - 1u)]; dst[o + i] = v; ring[(o + i) & (RING - 1u)] = v; }
+        }
+      } else {
+        uint32_t src = (uint32_t)lane % dist;                 // position of byte `i` in the period; advances by 64 mod dist per step
+        const uint32_t adv = 64u % dist;
+        for (uint32_t base = 0; base < len; base += 64u) {
+          const uint32_t i = base + (uint32_t)lane;
+          if (i < len) dst[o + i] = ring[(o - dist + src) & (RING - 1u)];
+          src += adv; if (src >= dist) src -= dist;
+        }
+        __builtin_amdgcn_wave_barrier();                      // the ring receives the run after all reads of its period are done
+        src = (uint32_t)lane % dist;
+        for (uint32_t base = 0; base < len; base += 64u) {
+          const uint32_t i = base + (uint32_t)lane;
+          if (i < len) ring[(o + i) & (RING - 1u)] = ring[(o - dist + src) & (RING - 1u)];
+          src += adv; if (src >= dist) src -= dist;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      o += len;
+      return true;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the bytes stored so far are the bytes about to be read
+    const uint32_t step = dist < 64u ? dist : 64u;                      // (dist > RING - 64 here: one step per 64 bytes)
     for (uint32_t base = 0; base < len; base += step) {
       const uint32_t nb = (len - base) < step ? (len - base) : step;
-      if ((uint32_t)lane < nb) dst[o + base + lane] = dst[o + base + lane - dist];
-      if (base + step < len && dist < len) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next step reads what this one wrote
+      if ((uint32_t)lane < nb) { const uint8_t v = dst[o + base + lane - dist]; dst[o + base + lane] = v; ring[(o + base + lane) & (RING - 1u)] = v; }
     }
     o += len;
     return true;
   }
 };
 
+// What the block body needs from a literal/length symbol, in one dword (bits 0-3 are the code length, added by build_fast):
+//   bits 4-5  kind: 0 literal, 1 end of block, 2 length, 3 not a symbol of the alphabet (286, 287)
+//   literal:  bits 8-15 the byte          length: bits 8-16 base length, bits 20-23 number of extra bits
+// and from a distance symbol: bits 4-7 number of extra bits, bits 8-23 base distance, bit 24 not a distance (30, 31)
+enum { K_LIT = 0, K_END = 1, K_LEN = 2, K_BAD = 3 };
+__device__ __forceinline__ uint32_t lit_entry(int sym) {
+  if (sym < 256) return ((uint32_t)sym << 8) | (K_LIT << 4);
+  if (sym == 256) return K_END << 4;
+  if (sym - 257 >= 29) return K_BAD << 4;
+  uint32_t base; int ext;
+  length_code(sym - 257, base, ext);
+  return (base << 8) | ((uint32_t)ext << 20) | (K_LEN << 4);
+}
+__device__ __forceinline__ uint32_t dist_entry(int ds) {
+  if (ds >= 30) return 1u << 24;
+  uint32_t base; int ext;
+  dist_code(ds, base, ext);
+  return (base << 8) | ((uint32_t)ext << 4);
+}
+
+// The body of a block. The scalar unit issues one instruction per cycle for the whole CU and every wave here is one serial
+// decoder, so the kernel's speed is the number of scalar instructions per symbol (rocprofv3 SQ_INSTS_SALU: ~100 per symbol, 0.63
+// per CU cycle, before this form). fast_run handles only what nearly every symbol is — a literal, or a match whose source lies in
+// the LDS ring and does not overlap its destination, both with a code the fast tables resolve — in a loop without any other way
+// through it: everything else leaves the loop BEFORE the symbol is consumed and codes() decodes that one symbol the general way.
+enum { FR_SLOW = 1 };
+__device__ __forceinline__ int fast_run(Bits& b, const Tables& T, Out& out) {
+  uint64_t buf = b.buf; int cnt = b.cnt; const uint32_t* p = b.p; const uint32_t* const end = b.end;
+  uint32_t o = out.o, npend = out.npend, lit = out.lit;
+  bool full = out.full;
+  const uint32_t cap = out.cap; const int lane = out.lane;
+  uint8_t* const dst = out.dst; uint8_t* const ring = out.ring;
+  for (;;) {
+    if (cnt <= 32) { if (p != end) { const uint64_t v = sload_dword(p); ++p; buf |= v << cnt; cnt += 32; } }
+    const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)T.lfast[(uint32_t)buf & ((1u << LFAST) - 1u)]);
+    const uint32_t len = e & 15u;
+    if (len - 1u >= (uint32_t)cnt) break;
+    if ((e & 0x30u) == 0u) {                                    // literal
+      buf >>= len; cnt -= (int)len;
+      if ((uint32_t)lane == npend) lit = (e >> 8) & 255u;
+      if (++npend == 64u) {                                     // (as Out::flush: one lane predicate, no branch around the stores)
+        const bool fits = o + 64u <= cap;
+        if ((uint32_t)lane < (fits ? 64u : 0u)) { dst[o + lane] = (uint8_t)lit; ring[(o + lane) & (RING - 1u)] = (uint8_t)lit; }
+        if (!fits) full = true;
+        o += 64u; npend = 0u;
+      }
+      continue;
+    }
+    if ((e & 0x30u) != (K_LEN << 4)) break;                     // end of block / not a symbol
+    // a match: decode it completely on copies, commit only if it is one of the common kind
+    uint64_t buf2 = buf >> len; int cnt2 = cnt - (int)len;
+    const uint32_t lext = (e >> 20) & 15u;
+    if ((int)lext > cnt2) break;
+    const uint32_t mlen = ((e >> 8) & 0x1FFu) + ((uint32_t)buf2 & ((1u << lext) - 1u));
+    buf2 >>= lext; cnt2 -= (int)lext;
+    const uint32_t* p2 = p;
+    if (cnt2 <= 32) { if (p2 != end) { const uint64_t v = sload_dword(p2); ++p2; buf2 |= v << cnt2; cnt2 += 32; } }
+    const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)T.dfast[(uint32_t)buf2 & ((1u << DFAST) - 1u)]);
+    const uint32_t dl = d & 15u;
+    if (dl - 1u >= (uint32_t)cnt2 || (d >> 24)) break;
+    buf2 >>= dl; cnt2 -= (int)dl;
+    const uint32_t dext = (d >> 4) & 15u;
+    if ((int)dext > cnt2) break;
+    const uint32_t dist = ((d >> 8) & 0xFFFFu) + ((uint32_t)buf2 & ((1u << dext) - 1u));
+    buf2 >>= dext; cnt2 -= (int)dext;
+    const uint32_t at = o + npend;                               // where the match starts
+    if (dist < mlen || dist + 64u > RING || dist > at || at + mlen > cap) break;
+    buf = buf2; cnt = cnt2; p = p2;
+    if ((uint32_t)lane < npend) { dst[o + lane] = (uint8_t)lit; ring[(o + lane) & (RING - 1u)] = (uint8_t)lit; }
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t base = 0; base < mlen; base += 64u) {
+      const uint32_t i = base + (uint32_t)lane;
+      if (i < mlen) { const uint8_t v = ring[(at - dist + i) & (RING - 1u)]; dst[at + i] = v; ring[(at + i) & (RING - 1u)] = v; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    o = at + mlen; npend = 0u;
+  }
+  b.buf = buf; b.cnt = cnt; b.p = p;
+  out.o = o; out.npend = npend; out.lit = lit; out.full = full;
+  return FR_SLOW;
+}
+
 __device__ __forceinline__ int codes(Bits& b, Tables& T, Out& out) {
-  build_fast<LFAST>(T.lcount, T.lsymbol, T.lfast, out.lane);
-  build_fast<DFAST>(T.dcount, T.dsymbol, T.dfast, out.lane);
+  build_fast<LFAST>(T.lcount, T.lsymbol, T.lfast, out.lane, [](int s_) { return lit_entry(s_); });
+  build_fast<DFAST>(T.dcount, T.dsymbol, T.dfast, out.lane, [](int s_) { return dist_entry(s_); });
   const Counts kl = load_counts(T.lcount), kd = load_counts(T.dcount);
   for (;;) {
-    int sym = decode_fast<LFAST>(b, T.lfast, kl, T.lsymbol);
-    if (sym < 0) return sym;
-    if (sym < 256) {
-      if (!out.literal((uint32_t)sym)) return -3;
-    } else if (sym == 256) {
-      return 0;
-    } else {
-      sym -= 257;
-      if (sym >= 29) return -4;
-      const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)LBASE[sym]) + b.get(__builtin_amdgcn_readfirstlane((int)LEXT[sym]));
-      const int ds = decode_fast<DFAST>(b, T.dfast, kd, T.dsymbol);
+    fast_run(b, T, out);
+    // one symbol the general way: long codes, the end of the stream or of the block, far or overlapping matches, errors
+    b.refill();
+    uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)T.lfast[(uint32_t)b.buf & ((1u << LFAST) - 1u)]);
+    const uint32_t len = e & 15u;
+    if (len - 1u >= (uint32_t)b.cnt) {                         // len == 0: a code longer than LFAST bits; len > cnt: the stream is about to end
+      const int sym = decode_reg(b, kl, T.lsymbol);
+      if (sym < 0) return sym;
+      e = lit_entry(sym);
+    } else { b.buf >>= len; b.cnt -= (int)len; }
+    const uint32_t kind = (e >> 4) & 3u;
+    if (kind == K_LIT) { out.literal((e >> 8) & 255u); continue; }
+    if (kind == K_END) { out.flush(); return out.full ? -3 : 0; }
+    if (kind == K_BAD) return -4;
+    const int lext = (int)((e >> 20) & 15u);
+    if (lext > b.cnt) { b.over = true; return -1; }
+    const uint32_t mlen = ((e >> 8) & 0x1FFu) + ((uint32_t)b.buf & ((1u << lext) - 1u));
+    b.buf >>= lext; b.cnt -= lext;
+    b.refill();
+    uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)T.dfast[(uint32_t)b.buf & ((1u << DFAST) - 1u)]);
+    const uint32_t dl = d & 15u;
+    if (dl - 1u >= (uint32_t)b.cnt) {
+      const int ds = decode_reg(b, kd, T.dsymbol);
       if (ds < 0) return ds;
-      if (ds >= 30) return -5;
-      const uint32_t dist = (uint32_t)__builtin_amdgcn_readfirstlane((int)DBASE[ds]) + b.get(__builtin_amdgcn_readfirstlane((int)DEXT[ds]));
-      if (b.over) return -1;
-      if (dist > out.o + out.npend) return -6;
-      if (!out.match(len, dist)) return -3;
-    }
+      d = dist_entry(ds);
+    } else { b.buf >>= dl; b.cnt -= (int)dl; }
+    if (d >> 24) return -5;
+    const int dext = (int)((d >> 4) & 15u);
+    if (dext > b.cnt) { b.over = true; return -1; }
+    const uint32_t dist = ((d >> 8) & 0xFFFFu) + ((uint32_t)b.buf & ((1u << dext) - 1u));
+    b.buf >>= dext; b.cnt -= dext;
+    if (dist > out.o + out.npend) return -6;
+    if (!out.match(mlen, dist)) return -3;
   }
 }
 
@@ -210,14 +350,16 @@ __global__ __launch_bounds__(64) void bgzf_inflate(const uint8_t* __restrict__ c
                                                    const uint64_t* __restrict__ out_off, int64_t n, uint8_t* __restrict__ outp,
                                                    int32_t* __restrict__ status) {
   __shared__ Tables T;
+  __shared__ uint8_t ring[RING];
   const int lane = threadIdx.x;
   const int64_t m = blockIdx.x;                                 // one wave = one block = one member: everything below is uniform
   if (m >= n) return;
   const uint64_t c0 = comp_off[m], c1 = comp_off[m + 1];
   const uint64_t a0 = c0 & ~3ull;                               // comp is 256-byte aligned (hipMalloc), so this is a dword boundary
-  Bits b{reinterpret_cast<const uint32_t*>(comp + a0), (uint32_t)((c1 - a0 + 3) / 4), 0u, 0ull, 0, (int)(c0 - a0), false};
+  const uint32_t* w0 = reinterpret_cast<const uint32_t*>(comp + a0);
+  Bits b{w0, w0 + (uint32_t)((c1 - a0 + 3) / 4), 0ull, 0, (int)(c0 - a0), false};
   // bits beyond the member's last byte (the tail of its last dword) are never consumed by a valid stream: it ends first
-  Out out{outp + out_off[m], 0u, (uint32_t)(out_off[m + 1] - out_off[m]), 0u, 0u, lane};
+  Out out{outp + out_off[m], 0u, (uint32_t)(out_off[m + 1] - out_off[m]), 0u, 0u, lane, ring, false};
   int err = 0;
   for (int guard = 0; guard < 70000 && !err; ++guard) {        // a member holds at most 64 KiB: far fewer blocks than this
     const uint32_t last = b.get(1), type = b.get(2);
@@ -227,7 +369,7 @@ __global__ __launch_bounds__(64) void bgzf_inflate(const uint8_t* __restrict__ c
       const uint32_t len = b.get(16), nlen = b.get(16);
       if (b.over || (len ^ 0xFFFFu) != nlen) { err = -7; break; }
       if (out.o + out.npend + len > out.cap) { err = -3; break; }
-      for (uint32_t k = 0; k < len; ++k) { const uint32_t v = b.get(8); if (b.over) { err = -1; break; } out.literal(v); }
+      for (uint32_t k = 0; k < len; ++k) { const uint32_t v = b.get(8); if (b.over) { err = -1; break; } out.literal(v); if (out.full) { err = -3; break; } }
     } else if (type == 1) {                                     // fixed codes
       if (lane == 0) {
         int s = 0;
@@ -282,6 +424,7 @@ __global__ __launch_bounds__(64) void bgzf_inflate(const uint8_t* __restrict__ c
     if (last) break;
   }
   out.flush();
+  if (out.full && !err) err = -3;
   if (!err && out.o != out.cap) err = -16;                      // ISIZE of the member must be met exactly
   if (lane == 0) status[m] = err;
 }
