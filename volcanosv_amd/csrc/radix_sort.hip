@@ -345,12 +345,17 @@ __global__ __launch_bounds__(256) void rs_scatter(SRC src,
 
 template <int BITS, int ROUNDS>
 void one_pass(hipStream_t st, int64_t max_n, const uint64_t* kin, const uint32_t* vin, const uint32_t* d_n, int shift, uint32_t* hist,
-              uint64_t* kout, uint32_t* vout, uint32_t* totals) {
+              uint64_t* kout, uint32_t* vout, uint32_t* totals, uint64_t hint_rows) {
   const int64_t max_tiles = (max_n + rs_tile<ROUNDS>() - 1) / rs_tile<ROUNDS>();
   const int grid = (int)(max_tiles < 1024 ? (max_tiles < 1 ? 1 : max_tiles) : 1024);
   const LsdDigit dg{shift};
   rs_hist<BITS, ROUNDS, LsdDigit, KeyArr><<<grid, 256, 0, st>>>(KeyArr{kin, vin}, d_n, dg, hist, totals);
-  if (totals) rs_scan_mb<BITS, ROUNDS, 128, 8><<<(1 << BITS) / 128, 1024, 0, st>>>(hist, totals, d_n);
+  // tables of hundreds of tiles and more (10^6-10^7 rows: config 3's candidates, the contig shape's raw signatures): 16 digits x 64
+  // tile groups per block instead of 128 x 8 — eight times the blocks and an eighth of the sequential tile walk per thread (the
+  // 128 x 8 form ran on 4-8 CUs for 0.5-0.9 ms per pass there)
+  const bool wide = hint_rows >= 256ull * rs_tile<ROUNDS>();
+  if (totals && wide) rs_scan_mb<BITS, ROUNDS, 16, 64><<<(1 << BITS) / 16, 1024, 0, st>>>(hist, totals, d_n);
+  else if (totals) rs_scan_mb<BITS, ROUNDS, 128, 8><<<(1 << BITS) / 128, 1024, 0, st>>>(hist, totals, d_n);
   else rs_scan<BITS, ROUNDS><<<1, 1024, 0, st>>>(hist, d_n);
   rs_scatter<BITS, ROUNDS, LsdDigit, KeyArr, false><<<grid, 256, 0, st>>>(KeyArr{kin, vin}, d_n, dg, hist, kout, vout, totals);
 }
@@ -597,10 +602,10 @@ SortResult sort_pairs(hipStream_t st, uint64_t* key, uint32_t* val, uint64_t* ke
     uint32_t* totals = nullptr;
     if (w.totals && *w.pass_cursor < w.max_passes) { totals = w.totals + (size_t)(*w.pass_cursor) * 2048; ++*w.pass_cursor; }
     switch (bits <= 8 ? 8 : bits) {
-      case 8: one_pass<8, ROUNDS>(st, max_n, kin, vin, d_n, shift, w.hist, kout, vout, totals); shift += 8; break;
-      case 9: one_pass<9, ROUNDS>(st, max_n, kin, vin, d_n, shift, w.hist, kout, vout, totals); shift += 9; break;
-      case 10: one_pass<10, ROUNDS>(st, max_n, kin, vin, d_n, shift, w.hist, kout, vout, totals); shift += 10; break;
-      default: one_pass<11, ROUNDS>(st, max_n, kin, vin, d_n, shift, w.hist, kout, vout, totals); shift += 11; break;
+      case 8: one_pass<8, ROUNDS>(st, max_n, kin, vin, d_n, shift, w.hist, kout, vout, totals, w.hint_rows); shift += 8; break;
+      case 9: one_pass<9, ROUNDS>(st, max_n, kin, vin, d_n, shift, w.hist, kout, vout, totals, w.hint_rows); shift += 9; break;
+      case 10: one_pass<10, ROUNDS>(st, max_n, kin, vin, d_n, shift, w.hist, kout, vout, totals, w.hint_rows); shift += 10; break;
+      default: one_pass<11, ROUNDS>(st, max_n, kin, vin, d_n, shift, w.hist, kout, vout, totals, w.hint_rows); shift += 11; break;
     }
     uint64_t* tk = kin; kin = kout; kout = tk;
     uint32_t* tv = vin; vin = vout; vout = tv;
