@@ -230,8 +230,10 @@ __global__ __launch_bounds__(1024) void qid_scan_max(uint32_t* __restrict__ tile
     __syncthreads();
   }
 }
+// raw_tiles: tile_excl still holds the tiles' own maxima (no qid_scan_max launch ran)
 __global__ __launch_bounds__(256) void qid_mark_dups(const uint32_t* __restrict__ qid, int64_t n, const uint32_t* __restrict__ tile_excl,
-                                                     uint32_t* __restrict__ dupbits, bool vec, uint32_t n_qids, uint32_t* __restrict__ err) {
+                                                     uint32_t* __restrict__ dupbits, bool vec, uint32_t n_qids, uint32_t* __restrict__ err,
+                                                     bool raw_tiles) {
   __shared__ uint32_t sh[4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   uint32_t q[8], m = 0;
@@ -245,7 +247,18 @@ __global__ __launch_bounds__(256) void qid_mark_dups(const uint32_t* __restrict_
   uint32_t excl = (uint32_t)__shfl_up((int)incl, 1, 64);
   if (lane == 0) excl = 0;
   __syncthreads();
-  uint32_t run = max(tile_excl[blockIdx.x], excl);
+  // the largest id of the tiles in front of this one: every block reduces the raw tile maxima itself (a few thousand L2-hot words)
+  // instead of waiting for a single-block prefix-max launch
+  __shared__ uint32_t sh_before[4];
+  uint32_t before = 0;
+  if (raw_tiles) {
+    for (int j = threadIdx.x; j < (int)blockIdx.x; j += 256) before = max(before, tile_excl[j]);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) before = max(before, (uint32_t)__shfl_xor((int)before, d, 64));
+  } else before = tile_excl[blockIdx.x];
+  if (lane == 0) sh_before[wv] = before;
+  __syncthreads();
+  uint32_t run = max(max(max(sh_before[0], sh_before[1]), max(sh_before[2], sh_before[3])), excl);
   for (int w = 0; w < wv; ++w) run = max(run, sh[w]);
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
@@ -259,11 +272,12 @@ __global__ __launch_bounds__(256) void qid_mark_dups(const uint32_t* __restrict_
 // dword each, qid as one 16-byte load when the arrays are aligned), i.e. 8 items in (record, hap) order as an 8-bit mask.
 constexpr int SC_ROUNDS = 2;
 constexpr int SC_TILE_REC = 256 * 4 * SC_ROUNDS;    // records per block
+// WRITE with raw_counts: blk still holds the blocks' own counts (no scan launch ran)
 template <bool WRITE>
 __global__ __launch_bounds__(256) void split_cand(RecView rv, SplitCfg c, const uint32_t* __restrict__ tab,
                                                   uint32_t* __restrict__ blk, uint64_t* __restrict__ ckey,
                                                   uint32_t* __restrict__ crec, uint32_t cap, bool vec, Counters* __restrict__ ctr,
-                                                  uint8_t* __restrict__ masks) {
+                                                  uint8_t* __restrict__ masks, bool raw_counts = false) {
   // masks[block][round][thread]: the 8-bit item mask of a thread's 4 records. The count pass writes it, the write pass reads it
   // back instead of streaming qid / flag / mapq and probing the name table a second time.
   __shared__ uint32_t cnt[SC_ROUNDS][4];
@@ -320,7 +334,17 @@ __global__ __launch_bounds__(256) void split_cand(RecView rv, SplitCfg c, const 
     }
     return;
   }
-  uint32_t off = blk[blockIdx.x];  // exclusive block offset
+  // exclusive block offset = the counts of the blocks in front of this one, summed here (no scan launch in between)
+  __shared__ uint32_t sh_off[4];
+  uint32_t off = 0;
+  if (raw_counts) {
+    for (int j = threadIdx.x; j < (int)blockIdx.x; j += 256) off += blk[j];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) off += (uint32_t)__shfl_xor((int)off, d, 64);
+  } else if (threadIdx.x == 0) off = blk[blockIdx.x];
+  if ((threadIdx.x & 63) == 0) sh_off[threadIdx.x >> 6] = off;
+  __syncthreads();
+  off = sh_off[0] + sh_off[1] + sh_off[2] + sh_off[3];
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {   // the last block knows the total: publish the candidate count
     uint32_t t = off;                                       // (n_s1 = n_raw + n_cand is split_eval's: this kernel may run next to the scan)
     for (int k = 0; k < SC_ROUNDS; ++k) for (int w = 0; w < 4; ++w) t += cnt[k][w];
@@ -956,12 +980,18 @@ SplitSorted vsv_launch_split_candidates(hipStream_t st, const RecView& rv, const
   // wide loads need 16-byte (qid) / 4-byte (flag, mapq) aligned arrays; anything else takes the element-wise path
   const bool vec = ((uintptr_t)rv.qid & 15u) == 0 && ((uintptr_t)rv.flag & 3u) == 0 && ((uintptr_t)rv.mapq & 3u) == 0;
   qid_tile_max<<<qtiles, 256, 0, st>>>(rv.qid, rv.n_records, blk_cnt, vec, tab, (uint32_t)((nq + 31) / 32 + 1));
-  qid_scan_max<<<1, 1024, 0, st>>>(blk_cnt, qtiles);
-  qid_mark_dups<<<qtiles, 256, 0, st>>>(rv.qid, rv.n_records, blk_cnt, tab, vec, (uint32_t)nq, &ctr->err);
+  // up to 8192 tiles / blocks (16 M records) the consumers reduce the per-tile values in front of them themselves: two 5-10 us
+  // launches less; beyond that the reductions (quadratic in the tile count) cost more than the scan launches
+  const bool self_scan = qtiles <= 8192;
+  if (!self_scan) qid_scan_max<<<1, 1024, 0, st>>>(blk_cnt, qtiles);
+  qid_mark_dups<<<qtiles, 256, 0, st>>>(rv.qid, rv.n_records, blk_cnt, tab, vec, (uint32_t)nq, &ctr->err, self_scan);
   const int nblk = (int)(((uint64_t)rv.n_records + SC_TILE_REC - 1) / SC_TILE_REC);
   split_cand<false><<<nblk, 256, 0, st>>>(rv, c, tab, blk_cnt, ckey, crec, cap, vec, ctr, cmask);
-  vsv_scan_u32_exclusive(st, blk_cnt, nblk, blk_off, scan_tmp);
-  split_cand<true><<<nblk, 256, 0, st>>>(rv, c, tab, blk_off, ckey, crec, cap, vec, ctr, cmask);
+  if (self_scan) split_cand<true><<<nblk, 256, 0, st>>>(rv, c, tab, blk_cnt, ckey, crec, cap, vec, ctr, cmask, true);
+  else {
+    vsv_scan_u32_exclusive(st, blk_cnt, nblk, blk_off, scan_tmp);
+    split_cand<true><<<nblk, 256, 0, st>>>(rv, c, tab, blk_off, ckey, crec, cap, vec, ctr, cmask, false);
+  }
   // the first result may live in the shared scratch pair, so the second sort gets a scratch pair of its own
   const SortResult r1 = vsv_radix_sort_pairs(st, ckey, crec, sw.key_alt, sw.val_alt, &ctr->n_cand, cap, c.tid_shift + c.tid_bits, sw,
                                              1ull << (c.tid_shift + c.tid_bits));     // no dead keys in this table: the whole range is alive
