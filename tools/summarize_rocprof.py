@@ -69,8 +69,8 @@ def cmd_trace(a):
     shutil.copy(stats[-1], a.out_csv)
     rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(trace[-1]))]
     rows.sort()
-    # the timed steps are the last K occurrences of the scan kernel; one step = [scan_i's partition_kernel, next one)
-    starts = [i for i, r in enumerate(rows) if "partition_kernel" in r[2]]
+    # one step = [partition_search of step i, partition_search of step i + 1)
+    starts = [i for i, r in enumerate(rows) if "partition_search" in r[2] or "partition_kernel" in r[2]]
     if len(starts) < 2:
         sys.exit("fewer than two steps in the trace")
     lo, hi = starts[-2], starts[-1]

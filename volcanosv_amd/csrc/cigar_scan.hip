@@ -73,15 +73,10 @@ __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t lane) {
 
 // ---- K0: part boundaries -----------------------------------------------------------------------
 // rb[p] = first record whose start offset >= p*ops_per_part; rb[n_parts] = n_records.
-__global__ void partition_kernel(const uint64_t* __restrict__ cigar_off, int64_t n_records, uint32_t* __restrict__ rb,
-                                 int n_parts, int ops_per_part, int64_t n_ops) {
-  int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p > n_parts) return;
-  if (p == n_parts) { rb[p] = (uint32_t)n_records; return; }
-  const uint64_t target = (uint64_t)p * (uint64_t)ops_per_part;
-  // first r in [0, n] with cigar_off[r] >= target. Interpolated guess (records are about equally long), a galloping bracket around
-  // it, then the bisection: ~12 dependent loads instead of log2(n) = 23 on a 10 M-record shard. Invariant: cigar_off[lo] < target
-  // (or lo = -1) and cigar_off[hi] >= target (or hi = n); whatever the offsets are, the result lies in [0, n].
+// first r in [0, n] with cigar_off[r] >= target. Interpolated guess (records are about equally long), a galloping bracket around
+// it, then the bisection: ~12 dependent loads instead of log2(n) = 23 on a 10 M-record shard. Invariant: cigar_off[lo] < target
+// (or lo = -1) and cigar_off[hi] >= target (or hi = n); whatever the offsets are, the result lies in [0, n].
+__device__ __forceinline__ int64_t first_record_at(const uint64_t* __restrict__ cigar_off, int64_t n_records, uint64_t target, int64_t n_ops) {
   int64_t g = n_ops > 0 ? (int64_t)((double)target / (double)n_ops * (double)n_records) : 0;
   g = g < 0 ? 0 : g > n_records ? n_records : g;
   int64_t lo, hi;
@@ -96,7 +91,49 @@ __global__ void partition_kernel(const uint64_t* __restrict__ cigar_off, int64_t
     const int64_t mid = lo + ((hi - lo) >> 1);
     if (cigar_off[mid] >= target) hi = mid; else lo = mid;
   }
-  rb[p] = (uint32_t)hi;
+  return hi;
+}
+// a search per part: fine up to a few hundred thousand parts (config 2: 80 k parts, 13 us)
+__global__ void partition_search(const uint64_t* __restrict__ cigar_off, int64_t n_records, uint32_t* __restrict__ rb,
+                                 int n_parts, int ops_per_part, int64_t n_ops, int stride) {
+  const int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * stride;
+  if (p > n_parts) return;
+  rb[p] = p == n_parts ? (uint32_t)n_records : (uint32_t)first_record_at(cigar_off, n_records, (uint64_t)p * (uint64_t)ops_per_part, n_ops);
+}
+// Millions of parts (config 3: 2.2 M): a search per part touches a different cache line per lane and step — 1.7 GB of traffic,
+// 0.52 ms. Instead partition_search finds every 64th boundary, and here one wave per 64 consecutive parts reads the offsets between
+// its two known boundaries once (64 parts x ~22 records on read-shaped input), coalesced, into LDS, where every lane bisects. A range
+// that does not fit (records of a few ops) is searched the old way.
+constexpr int PK_RANGE = 1024;
+__global__ __launch_bounds__(64) void partition_fill(const uint64_t* __restrict__ cigar_off, int64_t n_records, uint32_t* __restrict__ rb,
+                                                     int n_parts, int ops_per_part, int64_t n_ops) {
+  __shared__ uint64_t sh[PK_RANGE];
+  const int lane = threadIdx.x;
+  const int64_t p0 = (int64_t)blockIdx.x * 64, p = p0 + lane;
+  const int64_t ra = rb[p0], rb_end = p0 + 64 >= n_parts ? n_records : (int64_t)rb[p0 + 64];
+  const int64_t cnt = rb_end - ra + 1;                       // offsets [ra, rb_end]: every answer of the wave lies there
+  const bool ranged = cnt >= 1 && cnt <= 64 * (int64_t)PK_RANGE;   // (wave-uniform; cnt < 1 only if the offsets are not monotone)
+  const bool mine = lane != 0 && p < n_parts;                 // (every 64th boundary is partition_search's)
+  const uint64_t target = (uint64_t)p * (uint64_t)ops_per_part;
+  int64_t res = -1;
+  if (ranged) {
+    for (int64_t base = 0; base < cnt; base += PK_RANGE) {   // the range in LDS-sized pieces; a lane's answer lies in the first piece
+      const int64_t m = cnt - base < PK_RANGE ? cnt - base : PK_RANGE;     // whose last offset reaches its target
+      for (int64_t i = lane; i < m; i += 64) sh[i] = cigar_off[ra + base + i];
+      __builtin_amdgcn_wave_barrier();
+      if (mine && res < 0 && sh[m - 1] >= target) {
+        int64_t lo = -1, hi = m - 1;                          // sh[lo] < target <= sh[hi] with sh[-1] = -inf
+        while (hi - lo > 1) { const int64_t mid = lo + ((hi - lo) >> 1); if (sh[mid] >= target) hi = mid; else lo = mid; }
+        res = ra + base + hi;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if (p == n_parts && lane != 0) { rb[p] = (uint32_t)n_records; return; }
+  if (!mine) return;
+  if (res < 0) res = first_record_at(cigar_off, n_records, target, n_ops);   // offsets that are not monotone, or a huge range
+  if (res > n_records) res = n_records;
+  rb[p] = (uint32_t)res;
 }
 
 // Emit pool = K1_SHARDS independent sub-pools (cursor s on its own 64-byte line). A single cursor word saturates at
@@ -1134,7 +1171,12 @@ void vsv_launch_cigar_scan(hipStream_t st, const RecView& rv, const vsv_params& 
   const bool long_mode = vsv_scan_is_long(rv, p);
   if (long_mode) { n_parts = vsv_cigar_parts_long(rv.n_ops); ops_per_part = K1L_PART; }
   if (!lb.arena_zeroed) (void)hipMemsetAsync(shard_cnt, 0, K1_SHARDS * 16 * sizeof(uint32_t), st);
-  partition_kernel<<<(n_parts + 1 + 255) / 256, 256, 0, st>>>(rv.cigar_off, rv.n_records, part_rb, n_parts, ops_per_part, rv.n_ops);
+  if (n_parts < (1 << 20)) partition_search<<<(n_parts + 1 + 255) / 256, 256, 0, st>>>(rv.cigar_off, rv.n_records, part_rb, n_parts, ops_per_part, rv.n_ops, 1);
+  else {
+    const int coarse = n_parts / 64 + 1;
+    partition_search<<<(coarse + 255) / 256, 256, 0, st>>>(rv.cigar_off, rv.n_records, part_rb, n_parts, ops_per_part, rv.n_ops, 64);
+    partition_fill<<<(n_parts + 1 + 63) / 64, 64, 0, st>>>(rv.cigar_off, rv.n_records, part_rb, n_parts, ops_per_part, rv.n_ops);
+  }
   EmitCtx ec{pool, pool_key, shard_cnt, cap / K1_SHARDS, ctr};
   const int waves_per_block = 4;
   const int grid = (n_parts + waves_per_block - 1) / waves_per_block;
