@@ -422,6 +422,78 @@ __device__ __forceinline__ void op_sums(const uint32_t* __restrict__ cigar, uint
   for (; k < b; k += width) op_add(cigar[k], reads, rf, rl);
 }
 
+// the pair rules of one candidate pair (`need` = it reached the length test): Hifi.py:331-371, ONT.py:348-373, CLR.py:369-377, reads.py:179-196
+__device__ __forceinline__ vsv_sig split_rules(const RecView& rv, bool need, uint32_t i1, uint32_t i2, uint32_t hap, uint32_t last1, uint32_t first2,
+                                               int64_t rf1, int64_t rl1, int64_t rl2, int dtype, int max_svlen, Counters* ctr) {
+  vsv_sig out = dead_sig();
+  if (need) {
+    if (rl1 != rl2) atomicOr(&ctr->err, ERRB_READLEN);                                          // Hifi.py:331
+    else {
+      const int64_t Ref1e = (int64_t)rv.pos[i1] + rf1, Ref2s = rv.pos[i2];
+      const int64_t Read1e = rl1 - (int64_t)(last1 >> 4), Read2s = first2 >> 4;
+      const int64_t Diffdis = (Ref2s - Ref1e) - (Read2s - Read1e);
+      const int64_t absd = Diffdis < 0 ? -Diffdis : Diffdis;
+      if (absd <= max_svlen) {                                                                 // Hifi.py:354
+        vsv_sig s = dead_sig();
+        s.rec = i1; s.rec2 = i2; s.tid = rv.tid[i1];
+        uint32_t meta = VSV_M_SPLIT | (hap ? VSV_M_HP2 : 0u);
+        bool emit = false;
+        if (dtype == VSV_DTYPE_HIFI) {
+          if (Diffdis >= 30) {
+            const int64_t Diffolp = Read1e - Read2s, ao = Diffolp < 0 ? -Diffolp : Diffolp;
+            if (ao <= 3000) {                                                                 // Hifi.py:357
+              const int64_t h = Diffolp / 2;                                                  // int(Diffolp/2)
+              s.pos = (int32_t)(Ref1e - h); s.svlen = (int32_t)Diffdis;
+              s.q_start = (int32_t)(Read1e - h); s.q_end = s.q_start + 1; meta |= VSV_M_DEL; emit = true;
+            }
+          } else if (Diffdis <= -30) {
+            const int64_t Diffolp = Ref1e - Ref2s, ao = Diffolp < 0 ? -Diffolp : Diffolp;
+            if (Diffolp < 3000) {                                                             // Hifi.py:362
+              int64_t sv = Read2s - Read1e + Diffolp; if (sv < 0) sv = -sv;
+              s.pos = (int32_t)(ao > 400 ? (Ref1e + Ref2s) / 2 : Ref2s);
+              s.svlen = (int32_t)sv; s.q_start = (int32_t)(Read1e - Diffolp); s.q_end = (int32_t)Read2s; emit = true;
+            }
+          }
+        } else if (dtype == VSV_DTYPE_ONT || dtype == VSV_DTYPE_CLR) {
+          // fp64 products exactly as CPython evaluates them (ONT.py:348-373, CLR.py:369-377); this
+          // file is compiled with -ffp-contract=off.
+          const double r_ = dtype == VSV_DTYPE_ONT ? 0.5 : 0.3;
+          const double lo_f = dtype == VSV_DTYPE_ONT ? 0.8 : 0.3;
+          if (Diffdis >= 30) {
+            const int64_t Diffolp = Read1e - Read2s;
+            const double dr = (double)Diffdis * r_;
+            if (-dr <= (double)Diffolp && (double)Diffolp <= dr) {
+              s.pos = (int32_t)Ref1e; s.svlen = (int32_t)Diffdis; s.q_start = (int32_t)Read1e; s.q_end = (int32_t)Read2s;
+              meta |= VSV_M_DEL; emit = true;
+            }
+          } else {
+            const int64_t Diffolp = Ref1e - Ref2s, ao = Diffolp < 0 ? -Diffolp : Diffolp;
+            const double lo = (double)Diffdis * lo_f, hi = (double)absd * r_;
+            if (lo <= (double)Diffolp && (double)Diffolp <= hi && Diffdis <= -30) {
+              int64_t sv = Read2s - Read1e + Diffolp; if (sv < 0) sv = -sv;
+              s.pos = (int32_t)(ao > 400 ? (Ref1e + Ref2s) / 2 : Ref2s);
+              s.svlen = (int32_t)sv; s.q_start = (int32_t)(Read1e - Diffolp); s.q_end = (int32_t)Read2s; emit = true;
+            }
+          }
+        } else {  // READS: reads.py:179-196
+          const int64_t Diffolp = Ref1e - Ref2s;
+          if (Diffolp < 30 && Diffdis >= 30) {
+            s.pos = (int32_t)Ref1e; s.svlen = (int32_t)Diffdis; s.q_start = (int32_t)Read1e; s.q_end = (int32_t)Read2s;
+            meta |= VSV_M_DEL; emit = true;
+          } else if (Diffolp < 30 && Diffdis <= -30) {
+            s.pos = (int32_t)((Ref1e + Ref2s) / 2); s.svlen = (int32_t)absd;
+            s.q_start = (int32_t)Read1e; s.q_end = (int32_t)Read2s; emit = true;
+          }
+        }
+        if (emit) { s.meta = meta; out = s; }
+      }
+    }
+  }
+  return out;
+}
+
+// (One lane per slot for the chain of scattered loads that finds a pair — 64 chains per wave instead of 8 — and the CIGAR sums in
+// eight rounds of 8-lane groups was tried: config 3's 1.24 ms became 1.04, config 2's 31 us became 53; not kept.)
 // SE_GROUP lanes per pair slot (in okey order); writes one signature row (possibly dead) per slot. Control flow is uniform
 // per group up to the sums (the group shuffles need every lane of the group). SE_GROUP = 8 for reads (tens to hundreds of ops per
 // CIGAR; a stray pair of long records is summed by all 64 lanes of the wave, one such pair after the other), SE_GROUP = 64 for
@@ -481,70 +553,7 @@ __global__ __launch_bounds__(256) void split_eval(RecView rv, const uint64_t* __
     }
     // ---- phase 3: the pair rules, one lane per slot -------------------------------------------------------------------
     if (lane != 0 || !live || !room) continue;
-    vsv_sig out = dead_sig();
-    if (need) {
-      if (rl1 != rl2) atomicOr(&ctr->err, ERRB_READLEN);                                          // Hifi.py:331
-      else {
-        const int64_t Ref1e = (int64_t)rv.pos[i1] + rf1, Ref2s = rv.pos[i2];
-        const int64_t Read1e = rl1 - (int64_t)(last1 >> 4), Read2s = first2 >> 4;
-        const int64_t Diffdis = (Ref2s - Ref1e) - (Read2s - Read1e);
-        const int64_t absd = Diffdis < 0 ? -Diffdis : Diffdis;
-        if (absd <= max_svlen) {                                                                 // Hifi.py:354
-          vsv_sig s = dead_sig();
-          s.rec = i1; s.rec2 = i2; s.tid = rv.tid[i1];
-          uint32_t meta = VSV_M_SPLIT | (hap ? VSV_M_HP2 : 0u);
-          bool emit = false;
-          if (dtype == VSV_DTYPE_HIFI) {
-            if (Diffdis >= 30) {
-              const int64_t Diffolp = Read1e - Read2s, ao = Diffolp < 0 ? -Diffolp : Diffolp;
-              if (ao <= 3000) {                                                                 // Hifi.py:357
-                const int64_t h = Diffolp / 2;                                                  // int(Diffolp/2)
-                s.pos = (int32_t)(Ref1e - h); s.svlen = (int32_t)Diffdis;
-                s.q_start = (int32_t)(Read1e - h); s.q_end = s.q_start + 1; meta |= VSV_M_DEL; emit = true;
-              }
-            } else if (Diffdis <= -30) {
-              const int64_t Diffolp = Ref1e - Ref2s, ao = Diffolp < 0 ? -Diffolp : Diffolp;
-              if (Diffolp < 3000) {                                                             // Hifi.py:362
-                int64_t sv = Read2s - Read1e + Diffolp; if (sv < 0) sv = -sv;
-                s.pos = (int32_t)(ao > 400 ? (Ref1e + Ref2s) / 2 : Ref2s);
-                s.svlen = (int32_t)sv; s.q_start = (int32_t)(Read1e - Diffolp); s.q_end = (int32_t)Read2s; emit = true;
-              }
-            }
-          } else if (dtype == VSV_DTYPE_ONT || dtype == VSV_DTYPE_CLR) {
-            // fp64 products exactly as CPython evaluates them (ONT.py:348-373, CLR.py:369-377); this
-            // file is compiled with -ffp-contract=off.
-            const double r_ = dtype == VSV_DTYPE_ONT ? 0.5 : 0.3;
-            const double lo_f = dtype == VSV_DTYPE_ONT ? 0.8 : 0.3;
-            if (Diffdis >= 30) {
-              const int64_t Diffolp = Read1e - Read2s;
-              const double dr = (double)Diffdis * r_;
-              if (-dr <= (double)Diffolp && (double)Diffolp <= dr) {
-                s.pos = (int32_t)Ref1e; s.svlen = (int32_t)Diffdis; s.q_start = (int32_t)Read1e; s.q_end = (int32_t)Read2s;
-                meta |= VSV_M_DEL; emit = true;
-              }
-            } else {
-              const int64_t Diffolp = Ref1e - Ref2s, ao = Diffolp < 0 ? -Diffolp : Diffolp;
-              const double lo = (double)Diffdis * lo_f, hi = (double)absd * r_;
-              if (lo <= (double)Diffolp && (double)Diffolp <= hi && Diffdis <= -30) {
-                int64_t sv = Read2s - Read1e + Diffolp; if (sv < 0) sv = -sv;
-                s.pos = (int32_t)(ao > 400 ? (Ref1e + Ref2s) / 2 : Ref2s);
-                s.svlen = (int32_t)sv; s.q_start = (int32_t)(Read1e - Diffolp); s.q_end = (int32_t)Read2s; emit = true;
-              }
-            }
-          } else {  // READS: reads.py:179-196
-            const int64_t Diffolp = Ref1e - Ref2s;
-            if (Diffolp < 30 && Diffdis >= 30) {
-              s.pos = (int32_t)Ref1e; s.svlen = (int32_t)Diffdis; s.q_start = (int32_t)Read1e; s.q_end = (int32_t)Read2s;
-              meta |= VSV_M_DEL; emit = true;
-            } else if (Diffolp < 30 && Diffdis <= -30) {
-              s.pos = (int32_t)((Ref1e + Ref2s) / 2); s.svlen = (int32_t)absd;
-              s.q_start = (int32_t)Read1e; s.q_end = (int32_t)Read2s; emit = true;
-            }
-          }
-          if (emit) { s.meta = meta; out = s; }
-        }
-      }
-    }
+    const vsv_sig out = split_rules(rv, need, i1, i2, hap, last1, first2, rf1, rl1, rl2, dtype, max_svlen, ctr);
     s1in[n_raw + q] = out;
   }
 }
