@@ -373,6 +373,13 @@ int vsv_redundancy_pairs(vsv_handle* h, int is_del, const int32_t* pos, const in
  * sig_extract's split-read branch read, SVIM_COLLECT.py:12, SE:479): '\n'-joined in record order, empty for records without the
  * tag; valid until the handle's next device parse. */
 int vsv_bam_device_want_sa(vsv_handle* h, int want);
+/* The device reader also keeps the packed SEQ fields (4 bits per base, device-resident, in record order): pysam's query_sequence
+ * of sig_extract.py (SE:468-469 slices it per INS piece, SE:215 reads the reversed read). vsv_bam_device_seq_slices decodes n slices
+ * to ASCII: slice i = bases [start[i], start[i] + len[i]) of record rec[i] (of the REVERSED read where rev[i] != 0), written to
+ * out + out_off[i]. Host arrays in, host bytes out; a slice outside its record or outside out_bytes is VSV_E_INVALID. */
+int vsv_bam_device_want_seq(vsv_handle* h, int want);
+int vsv_bam_device_seq_slices(vsv_handle* h, const uint32_t* rec, const uint32_t* start, const uint32_t* len, const uint8_t* rev, int64_t n,
+                              const uint64_t* out_off, uint8_t* out, int64_t out_bytes);
 const char* vsv_bam_device_sa_tags(vsv_handle* h, int64_t* len);
 /* CRC-32 values of the members' gzip trailers (host array of n_members words, caller-owned, NULL / 0 clears): the next
  * vsv_bgzf_inflate / vsv_bam_parse_device over exactly n_members members computes each member's CRC-32 on the GPU and fails

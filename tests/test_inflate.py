@@ -410,3 +410,58 @@ def test_device_reader_on_the_reference_held_bam_fixtures():
                     assert len(bnd.parse_sa(view.sa_tags[0], tid_of)) == 2               # test_satag.py:36-45
                     neg = bnd.parse_sa(view.sa_tags[1], tid_of)
                     assert len(neg) == 1 and neg[0][4] == 0                              # test_satag.py:46-54
+
+
+@pytest.mark.gpu
+def test_sequences_kept_on_the_device_and_sliced_there(tmp_path):
+    """fetch_device(seq=True): the packed SEQ fields stay on the GPU and DeviceRecordView.seq_slices decodes Python-style slices of
+    them (negative and overlong bounds, the reversed read of sig_extract's split INS, SE:215): equal to the slices of the host
+    reader's query sequences, for whole files and for one chromosome of a file, odd and even lengths, reads without SEQ."""
+    from volcanosv_amd import bam
+    from volcanosv_amd.abi import VsvError
+    from volcanosv_amd.engine import Engine
+    rng = np.random.default_rng(4242)
+    bases = np.frombuffer(b"=ACMGRSVTWYHKDBN", dtype=np.uint8)
+    refs = [("chr1", 3_000_000), ("chr2", 2_000_000)]
+    recs = []
+    for tid in range(2):
+        for p in np.sort(rng.integers(0, 1_500_000, 700)):
+            l = int(rng.choice([0, 1, 2, 3, 63, 64, 65, int(rng.integers(100, 9000))]))
+            seq = bases[rng.integers(0, 16, l)].tobytes().decode() if l else None
+            recs.append(dict(tid=tid, pos=int(p), qname="r%d_hp%d" % (len(recs), 1 + len(recs) % 2), mapq=60, flag=0,
+                             cigar=[(0, max(1, l))] if l else [(0, 10)], seq=seq))
+    path = str(tmp_path / "seq.bam")
+    bam.write_bam(path, refs, recs)
+    with Engine(0) as eng, bam.BamFile(path) as bf:
+        for chrom in (None, "chr2"):
+            host = bf.fetch_soa(chrom, keep_seq=True)
+            view = bf.fetch_device(eng, chrom, seq=True)
+            assert isinstance(view, bam.DeviceRecordView) and view.n_records == host.n_records
+            reqs, want = [], []
+            for _ in range(3000):
+                r = int(rng.integers(0, host.n_records))
+                l = int(host.l_seq[r])
+                a, b = int(rng.integers(-l - 5, l + 6)), int(rng.integers(-l - 5, l + 6))
+                rv = bool(rng.random() < 0.3)
+                reqs.append((r, a, b, rv))
+                q = host.seq[r]
+                want.append((q[::-1] if rv else q)[a:b])
+            for r in range(0, host.n_records, 97):                          # whole reads
+                reqs.append((r, 0, int(host.l_seq[r]), False))
+                want.append(host.seq[r])
+            assert view.seq_slices(reqs) == want
+            assert view.seq_slices([]) == []
+        plain = bf.fetch_device(eng, "chr1")                                # without seq=True nothing is kept
+        with pytest.raises(ValueError):
+            plain.seq_slices([(0, 0, 1, False)])
+        # the C-ABI refuses slices outside their record / of records that were not loaded
+        view = bf.fetch_device(eng, "chr1", seq=True)
+        import ctypes as C
+        one = lambda v, dt: np.array([v], dtype=dt)
+        out, off = np.zeros(64, np.uint8), np.zeros(1, np.uint64)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        l0 = int(view.l_seq_host()[0])
+        for rec, start, ln in ((0, l0, 1), (view.n_records, 0, 0), (0, 0, l0 + 1)):
+            st = eng.lib.vsv_bam_device_seq_slices(eng.h, vp(one(rec, np.uint32)), vp(one(start, np.uint32)), vp(one(ln, np.uint32)), vp(one(0, np.uint8)), 1,
+                                                   vp(off), vp(out), 64)
+            assert st != 0

@@ -144,7 +144,37 @@ class DeviceRecordView:
         r.n_records, r.n_ops, r.on_device, r.n_qids, r.n_tids = hi - lo, self._rec.n_ops, 1, self._rec.n_qids, self._rec.n_tids
         v = DeviceRecordView(r, self.qnames, self.tid_names, int(self._l_seq_ptr or 0) + 4 * lo, int(self._sam_flags_ptr or 0) + 4 * lo, self._engine)
         v._parent = self
+        v.has_seq, v._first_record = getattr(self, "has_seq", False), getattr(self, "_first_record", 0) + lo
         return v
+
+    def seq_slices(self, requests):
+        """requests: [(record, start, stop, reversed)] in Python slice terms (record's query_sequence[start:stop], of the reversed
+        read if `reversed`; start / stop may be negative or run past the end exactly like a Python slice). Returns the strings. The
+        sequences stay on the GPU (fetch_device(seq=True)); one call decodes all slices."""
+        if not getattr(self, "has_seq", False):
+            raise ValueError("fetch_device(seq=True) keeps the sequences on the device")
+        n = len(requests)
+        if n == 0:
+            return []
+        l_seq = self.l_seq_host()
+        first = getattr(self, "_first_record", 0)
+        rec = np.zeros(n, np.uint32); start = np.zeros(n, np.uint32); ln = np.zeros(n, np.uint32); rev = np.zeros(n, np.uint8)
+        for i, (r, a, b, rv) in enumerate(requests):
+            lo, hi, _ = slice(a, b).indices(int(l_seq[r]))
+            rec[i], start[i], ln[i], rev[i] = first + r, lo, max(0, hi - lo), 1 if rv else 0
+        off = np.zeros(n + 1, np.uint64)
+        np.cumsum(ln, out=off[1:])
+        out = np.zeros(int(off[n]) + 1, np.uint8)
+        eng = self._engine
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        eng._check(eng.lib.vsv_bam_device_seq_slices(eng.h, vp(rec), vp(start), vp(ln), vp(rev), n, vp(off), vp(out), int(off[n])))
+        text = out[:int(off[n])].tobytes().decode()
+        return [text[int(off[i]):int(off[i + 1])] for i in range(n)]
+
+    def l_seq_host(self):
+        if getattr(self, "_l_seq_host", None) is None:
+            self._l_seq_host = self._pull(self._l_seq_ptr, self.n_records, np.uint32)
+        return self._l_seq_host
 
     def to_host(self):
         """RecordSoA copy (plus l_seq / sam_flags) of the device arrays."""
@@ -190,22 +220,24 @@ class BamFile:
     def get_tid(self, name):
         return self.references.index(name) if name in self.references else -1
 
-    def fetch_device(self, engine, chrom=None, sa=False):
+    def fetch_device(self, engine, chrom=None, sa=False, seq=False):
         """All records of `chrom` (or of every reference) inflated and parsed on the GPU: returns a DeviceRecordView whose arrays
         live in `engine`'s handle (valid until its next fetch_device). Query names come back to the host (lazily split); with
-        sa=True the SA:Z tag texts too (`view.sa_tags`, '' where absent). Sequences are not extracted by this path."""
+        sa=True the SA:Z tag texts too (`view.sa_tags`, '' where absent); with seq=True the packed SEQ fields stay on the device and
+        `view.seq_slices` decodes slices of them."""
         tid = -1 if chrom is None else self.get_tid(chrom)
         if chrom is not None and tid < 0:
             raise KeyError("reference %r not in BAM header" % chrom)
         r = Records()
         self.lib.vsv_bam_device_want_sa(engine.h, 1 if sa else 0)
+        self.lib.vsv_bam_device_want_seq(engine.h, 1 if seq else 0)
         st = self.lib.vsv_bam_load_device(self.h, engine.h, tid, C.byref(r))
         if st:
             msg = self.lib.vsv_bam_error(self.h).decode()
             if "use the host reader" in msg:          # hash collision / speculation that does not settle: correct, just not on the GPU
                 import warnings
                 warnings.warn("device BAM reader gave up (%s); falling back to the host reader" % msg)
-                return self.fetch_soa(chrom)
+                return self.fetch_soa(chrom, keep_seq=seq)
             raise VsvError(st, msg)
         ln = C.c_int64()
         p = self.lib.vsv_bam_qnames(self.h, C.byref(ln))
@@ -214,6 +246,7 @@ class BamFile:
         if sa:
             p = self.lib.vsv_bam_device_sa_tags(engine.h, C.byref(ln))
             view.sa_tags = LazyLines(C.string_at(p, ln.value), int(r.n_records))
+        view.has_seq = bool(seq)
         return view
 
     def use_gpu_inflate(self, engine):

@@ -320,6 +320,51 @@ __global__ __launch_bounds__(256) void win_sa_store(const uint8_t* __restrict__ 
     d[l] = '\n';
   }
 }
+// Packed SEQ of every kept record of the window (two bases per byte, BAM nibble alphabet): one lane per record reports the field's
+// stream offset and byte count, seq_store copies the bytes into the compact store (one wave per record: reads are kilobases long) and
+// records where every record's SEQ starts. The inserted sequences of sig_extract (SE:468-469) are slices of it (seq_slices below).
+__global__ __launch_bounds__(256) void win_seq_find(const uint8_t* __restrict__ s, const uint64_t* __restrict__ w_rec_off, int64_t nk,
+                                                    uint64_t* __restrict__ seq_off, uint32_t* __restrict__ seq_len) {
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nk; k += (int64_t)gridDim.x * blockDim.x) {
+    const uint8_t* r = s + w_rec_off[k];
+    const uint32_t l_name = r[12], nc = ld16(r + 16);
+    const int32_t ls = (int32_t)ld32(r + 20);
+    seq_off[k] = w_rec_off[k] + 36ull + l_name + 4ull * nc;             // (rec_fields has checked that the field ends inside the record)
+    seq_len[k] = ls > 0 ? (uint32_t)((ls + 1) / 2) : 0u;
+  }
+}
+__global__ __launch_bounds__(256) void win_seq_store(const uint8_t* __restrict__ s, const uint64_t* __restrict__ seq_off, const uint32_t* __restrict__ seq_len,
+                                                     const uint32_t* __restrict__ loff, int64_t nk, uint64_t k0, uint64_t q0, uint8_t* __restrict__ blob,
+                                                     uint64_t* __restrict__ rec_seq_off) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t k = wave; k < nk; k += nwaves) {
+    const uint8_t* p = s + seq_off[k];
+    uint8_t* d = blob + q0 + loff[k];
+    const uint32_t l = seq_len[k];
+    for (uint32_t c = (uint32_t)lane; c < l; c += 64u) d[c] = p[c];
+    if (lane == 0) rec_seq_off[k0 + (uint64_t)k] = q0 + loff[k];
+  }
+}
+// ASCII slices of the stored sequences: slice i = bases [start, start + len) of record rec[i], read from the REVERSED read when
+// rev[i] (sig_extract's split INS, SE:215: reversed, not complemented). One wave per slice; the caller guarantees start + len <= l_seq.
+__global__ __launch_bounds__(256) void seq_slices(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ rec_seq_off, const uint32_t* __restrict__ l_seq,
+                                                  const uint32_t* __restrict__ rec, const uint32_t* __restrict__ start, const uint32_t* __restrict__ len,
+                                                  const uint8_t* __restrict__ rev, int64_t n, const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t i = wave; i < n; i += nwaves) {
+    const uint32_t r = rec[i], a = start[i], l = len[i], ls = l_seq[r];
+    const uint8_t* p = blob + rec_seq_off[r];
+    uint8_t* d = out + out_off[i];
+    const bool rv = rev[i] != 0;
+    for (uint32_t c = (uint32_t)lane; c < l; c += 64u) {
+      const uint32_t idx = rv ? ls - 1u - (a + c) : a + c;
+      const uint32_t b = p[idx >> 1];
+      d[c] = (uint8_t)"=ACMGRSVTWYHKDBN"[(idx & 1u) ? (b & 15u) : (b >> 4)];
+    }
+  }
+}
 // name table for the host: the first occurrences in id order, '\n'-separated (the stored NUL becomes the separator)
 __global__ __launch_bounds__(256) void name_lens(const uint32_t* __restrict__ nm_len, const uint32_t* __restrict__ is_first, int64_t n, uint32_t* __restrict__ len) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) len[i] = is_first[i] ? nm_len[i] : 0u;
@@ -396,6 +441,17 @@ void vsv_bamdev_name_copy(hipStream_t st, const uint8_t* names, const uint64_t* 
   if (n > 0) name_copy<<<1024, 256, 0, st>>>(names, nm_off, nm_len, is_first, noff, n, blob);
 }
 
+void vsv_bamdev_win_seq_find(hipStream_t st, const uint8_t* s, const uint64_t* w_rec_off, int64_t nk, uint64_t* seq_off, uint32_t* seq_len) {
+  if (nk > 0) win_seq_find<<<1024, 256, 0, st>>>(s, w_rec_off, nk, seq_off, seq_len);
+}
+void vsv_bamdev_win_seq_store(hipStream_t st, const uint8_t* s, const uint64_t* seq_off, const uint32_t* seq_len, const uint32_t* loff, int64_t nk,
+                              uint64_t k0, uint64_t q0, uint8_t* blob, uint64_t* rec_seq_off) {
+  if (nk > 0) win_seq_store<<<2048, 256, 0, st>>>(s, seq_off, seq_len, loff, nk, k0, q0, blob, rec_seq_off);
+}
+void vsv_bamdev_seq_slices(hipStream_t st, const uint8_t* blob, const uint64_t* rec_seq_off, const uint32_t* l_seq, const uint32_t* rec,
+                           const uint32_t* start, const uint32_t* len, const uint8_t* rev, int64_t n, const uint64_t* out_off, uint8_t* out) {
+  if (n > 0) seq_slices<<<(int)((n + 3) / 4 < 2048 ? (n + 3) / 4 : 2048), 256, 0, st>>>(blob, rec_seq_off, l_seq, rec, start, len, rev, n, out_off, out);
+}
 void vsv_bamdev_win_sa_find(hipStream_t st, const uint8_t* s, const uint64_t* w_rec_off, int64_t nk, uint64_t* sa_off, uint32_t* sa_len) {
   if (nk > 0) win_sa_find<<<1024, 256, 0, st>>>(s, w_rec_off, nk, sa_off, sa_len);
 }

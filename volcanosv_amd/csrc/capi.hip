@@ -60,6 +60,9 @@ struct vsv_handle {
   std::string names_blob, sa_text;     // name table / SA tag texts of the last device parse (host copies)
   bool want_sa = false;                // vsv_bam_set_want_sa: the device parse also collects the SA:Z texts
   DevBuf o_saoff, o_salen, o_saloc, o_sa;
+  bool want_seq = false;               // vsv_bam_device_want_seq: the device parse also keeps the packed SEQ fields (device-resident)
+  DevBuf o_sqoff, o_sqlen, o_sqloc, o_seq, o_recseq, q_rec, q_start, q_len, q_rev, q_ooff, q_out;
+  int64_t seq_records = -1;            // records whose SEQ the store holds (-1: none)
   int pass_cursor = 0;
   int group_cursor = 0;
   uint32_t* groups = nullptr;      // view into `arena`
@@ -577,7 +580,8 @@ void vsv_destroy(vsv_handle* h) {
                     &h->g_re, &h->g_rev, &h->g_hap, &h->g_len, &h->g_rank, &h->j_cpos, &h->j_clen, &h->j_spos, &h->j_slen, &h->j_send, &h->j_out, &h->j_err, &h->z_comp, &h->z_coff, &h->z_ooff, &h->z_out, &h->z_stat, &h->p_spec, &h->p_cnt, &h->p_land, &h->p_base, &h->p_recoff, &h->p_pos, &h->p_tid,
                     &h->p_mapq, &h->p_flag, &h->p_lseq, &h->p_sflag, &h->p_ncig, &h->p_cgsrc, &h->p_hash, &h->p_keep, &h->p_kidx, &h->p_cigoff, &h->p_sums,
                     &h->p_tot, &h->p_err, &h->o_pos, &h->o_tid, &h->o_qid, &h->o_cigoff, &h->o_mapq, &h->o_flag, &h->o_cigar, &h->o_lseq, &h->o_sflag,
-                    &h->o_hash, &h->o_recoff, &h->o_first, &h->o_rank, &h->o_nlen, &h->o_noff, &h->o_blob, &h->o_n, &h->o_names, &h->o_nmoff, &h->o_nmlen, &h->gflag, &h->cmask, &h->cs_tra, &h->o_saoff, &h->o_salen, &h->o_saloc, &h->o_sa};
+                    &h->o_hash, &h->o_recoff, &h->o_first, &h->o_rank, &h->o_nlen, &h->o_noff, &h->o_blob, &h->o_n, &h->o_names, &h->o_nmoff, &h->o_nmlen, &h->gflag, &h->cmask, &h->cs_tra, &h->o_saoff, &h->o_salen, &h->o_saloc, &h->o_sa,
+                    &h->o_sqoff, &h->o_sqlen, &h->o_sqloc, &h->o_seq, &h->o_recseq, &h->q_rec, &h->q_start, &h->q_len, &h->q_rev, &h->q_ooff, &h->q_out};
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
   if (h->pinned) hipHostFree(h->pinned);
   if (h->ev0) hipEventDestroy(h->ev0);
@@ -1035,6 +1039,41 @@ static int inflate_to_device(vsv_handle* h, const uint8_t* comp, const uint64_t*
   return 0;
 }
 
+int vsv_bam_device_want_seq(vsv_handle* h, int want) {
+  if (!h) return VSV_E_INVALID;
+  h->want_seq = want != 0;
+  return 0;
+}
+int vsv_bam_device_seq_slices(vsv_handle* h, const uint32_t* rec, const uint32_t* start, const uint32_t* len, const uint8_t* rev, int64_t n,
+                              const uint64_t* out_off, uint8_t* out, int64_t out_bytes) {
+  if (!h || n < 0 || out_bytes < 0 || (n > 0 && (!rec || !start || !len || !rev || !out_off || !out))) return VSV_E_INVALID;
+  if (h->seq_records < 0) return fail(h, VSV_E_INVALID, "no sequences on the device: vsv_bam_device_want_seq before the load");
+  if (n == 0) return 0;
+  HIPCHK(h, hipSetDevice(h->device));
+  // the slices must lie inside their records and inside the output: checked here, on the host copies of the (small) request arrays
+  std::vector<uint32_t> lseq((size_t)h->seq_records);
+  HIPCHK(h, hipMemcpyAsync(lseq.data(), h->o_lseq.p, lseq.size() * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  for (int64_t i = 0; i < n; ++i) {
+    if ((int64_t)rec[i] >= h->seq_records) return fail(h, VSV_E_INVALID, "sequence slice of a record that was not loaded");
+    if ((uint64_t)start[i] + len[i] > lseq[rec[i]]) return fail(h, VSV_E_INVALID, "sequence slice outside its record");
+    if (out_off[i] + len[i] > (uint64_t)out_bytes) return fail(h, VSV_E_INVALID, "sequence slice outside the output buffer");
+  }
+  int st;
+  if ((st = upload(h, h->q_rec, rec, (size_t)n * 4))) return st;
+  if ((st = upload(h, h->q_start, start, (size_t)n * 4))) return st;
+  if ((st = upload(h, h->q_len, len, (size_t)n * 4))) return st;
+  if ((st = upload(h, h->q_rev, rev, (size_t)n))) return st;
+  if ((st = upload(h, h->q_ooff, out_off, (size_t)n * 8))) return st;
+  if ((st = ensure(h, h->q_out, (size_t)out_bytes + 16))) return st;
+  vsv_bamdev_seq_slices(h->stream, (const uint8_t*)h->o_seq.p, (const uint64_t*)h->o_recseq.p, (const uint32_t*)h->o_lseq.p, (const uint32_t*)h->q_rec.p,
+                        (const uint32_t*)h->q_start.p, (const uint32_t*)h->q_len.p, (const uint8_t*)h->q_rev.p, n, (const uint64_t*)h->q_ooff.p,
+                        (uint8_t*)h->q_out.p);
+  HIPCHK(h, hipGetLastError());
+  if (out_bytes) HIPCHK(h, hipMemcpyAsync(out, h->q_out.p, (size_t)out_bytes, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
 int vsv_bam_device_want_sa(vsv_handle* h, int want) {
   if (!h) return VSV_E_INVALID;
   h->want_sa = want != 0;
@@ -1104,8 +1143,9 @@ int vsv_bam_parse_device(vsv_handle* h, const uint8_t* comp, const uint64_t* com
 #define DEVMEM(expr) do { if ((rc = (expr))) return rc == VSV_E_HIP ? fail(h, VSV_E_CAPACITY, "device memory exhausted in the device reader: use the host reader") : rc; } while (0)
   DEVMEM(ensure(h, h->p_err, 256)); DEVMEM(ensure(h, h->p_tot, 256)); DEVMEM(ensure(h, h->o_n, 256));
   HIPCHK(h, hipMemsetAsync(h->p_err.p, 0, 4, st));
-  uint64_t carry = first_record, K0 = 0, C0 = 0, N0 = 0, S0 = 0;
+  uint64_t carry = first_record, K0 = 0, C0 = 0, N0 = 0, S0 = 0, Q0 = 0;
   h->sa_text.clear();
+  h->seq_records = -1;
   const bool timing = getenv("VSV_BAM_TIMING") != nullptr;
   double t_inf = 0, t_chain = 0, t_rec = 0, t_names = 0, t_qid = 0;
   int n_windows = 0, n_rounds = 0;
@@ -1229,6 +1269,22 @@ int vsv_bam_parse_device(vsv_handle* h, const uint8_t* comp, const uint64_t* com
           HIPCHK(h, hipStreamSynchronize(st));
           S0 += sb_w;
         }
+        if (h->want_seq) {  // packed SEQ of the kept records, appended in record order; stays on the device
+          DEVMEM(ensure(h, h->o_sqoff, (size_t)nk * 8)); DEVMEM(ensure(h, h->o_sqlen, (size_t)nk * 4 + 16)); DEVMEM(ensure(h, h->o_sqloc, (size_t)nk * 4 + 16));
+          DEVMEM(ensure_keep(h, h->o_recseq, K * 8, (size_t)K0 * 8));
+          vsv_bamdev_win_seq_find(st, s, (const uint64_t*)h->o_recoff.p, (int64_t)nk, (uint64_t*)h->o_sqoff.p, (uint32_t*)h->o_sqlen.p);
+          vsv_scan_u32_exclusive(st, (const uint32_t*)h->o_sqlen.p, (int)nk, (uint32_t*)h->o_sqloc.p, (uint32_t*)h->p_sums.p);
+          uint32_t qo_ = 0, ql_ = 0;
+          HIPCHK(h, hipMemcpyAsync(&qo_, (uint32_t*)h->o_sqloc.p + (nk - 1), 4, hipMemcpyDeviceToHost, st));
+          HIPCHK(h, hipMemcpyAsync(&ql_, (uint32_t*)h->o_sqlen.p + (nk - 1), 4, hipMemcpyDeviceToHost, st));
+          HIPCHK(h, hipStreamSynchronize(st));
+          const uint64_t qb_w = (uint64_t)qo_ + ql_;
+          DEVMEM(ensure_keep(h, h->o_seq, (size_t)(Q0 + qb_w) + 16, (size_t)Q0));
+          vsv_bamdev_win_seq_store(st, s, (const uint64_t*)h->o_sqoff.p, (const uint32_t*)h->o_sqlen.p, (const uint32_t*)h->o_sqloc.p, (int64_t)nk, K0, Q0,
+                                   (uint8_t*)h->o_seq.p, (uint64_t*)h->o_recseq.p);
+          HIPCHK(h, hipStreamSynchronize(st));
+          Q0 += qb_w;
+        }
         K0 += nk; C0 += ops_w; N0 += nb_w;
         lap(t_names);
       }
@@ -1238,6 +1294,7 @@ int vsv_bam_parse_device(vsv_handle* h, const uint8_t* comp, const uint64_t* com
   }
   const int64_t nk = (int64_t)K0;
   out->n_records = nk; out->n_ops = (int64_t)C0; out->n_tids = n_ref;
+  if (h->want_seq) h->seq_records = nk;
   if (nk == 0) return 0;
   // the name table's offsets are 32-bit scans (per window the inflated bytes bound them; over the whole file N0 does)
   if (N0 > 0xFFFFFFF0ull) return fail(h, VSV_E_CAPACITY, "more than 4 GiB of query names for the device reader: use the host reader");

@@ -225,6 +225,11 @@ void vsv_bamdev_assign(hipStream_t st, const uint64_t* skey, const uint32_t* sva
 void vsv_bamdev_win_name_lens(hipStream_t st, const uint8_t* s, const uint64_t* w_rec_off, int64_t nk, uint32_t* len);
 void vsv_bamdev_win_name_store(hipStream_t st, const uint8_t* s, const uint64_t* w_rec_off, const uint32_t* loff, int64_t nk, uint64_t k0, uint64_t n0,
                                uint8_t* names, uint64_t* nm_off, uint32_t* nm_len);
+void vsv_bamdev_win_seq_find(hipStream_t st, const uint8_t* s, const uint64_t* w_rec_off, int64_t nk, uint64_t* seq_off, uint32_t* seq_len);
+void vsv_bamdev_win_seq_store(hipStream_t st, const uint8_t* s, const uint64_t* seq_off, const uint32_t* seq_len, const uint32_t* loff, int64_t nk,
+                              uint64_t k0, uint64_t q0, uint8_t* blob, uint64_t* rec_seq_off);
+void vsv_bamdev_seq_slices(hipStream_t st, const uint8_t* blob, const uint64_t* rec_seq_off, const uint32_t* l_seq, const uint32_t* rec,
+                           const uint32_t* start, const uint32_t* len, const uint8_t* rev, int64_t n, const uint64_t* out_off, uint8_t* out);
 void vsv_bamdev_win_sa_find(hipStream_t st, const uint8_t* s, const uint64_t* w_rec_off, int64_t nk, uint64_t* sa_off, uint32_t* sa_len);
 void vsv_bamdev_win_sa_store(hipStream_t st, const uint8_t* s, const uint64_t* sa_off, const uint32_t* sa_len, const uint32_t* loff, int64_t nk,
                              uint64_t s0, uint8_t* blob);

@@ -43,10 +43,52 @@ def leading_hardclip(soa, rec):
     return (w >> 4) if (w & 15) == 5 else 0
 
 
-def cigar_candidates(soa, raw, combined, seq_of, chr_name):
+class DeferredSeq:
+    """Slices of the reads' sequences, asked for while the candidates are built and fetched together afterwards: with the device
+    reader the sequences stay on the GPU and one call decodes every slice (DeviceRecordView.seq_slices); with the host reader
+    they come out of the packed host copy. ask() returns a token, text(tokens) the concatenated slices after resolve()."""
+
+    def __init__(self, fetch):
+        self.fetch, self.req, self.out = fetch, [], None
+
+    def ask(self, rec, start, stop, reverse=False):
+        self.req.append((int(rec), int(start), int(stop), bool(reverse)))
+        return len(self.req) - 1
+
+    def resolve(self):
+        self.out = self.fetch(self.req)
+
+    def text(self, tokens):
+        return "".join(self.out[t] for t in tokens)
+
+
+def host_seq_fetch(seq_of):
+    """fetch function of DeferredSeq over sequences on the host: seq_of(rec) -> the read's query_sequence (or an indexable of them,
+    e.g. the PackedSeq of BamFile.fetch_soa(keep_seq=True))."""
+    get = seq_of if callable(seq_of) else seq_of.__getitem__
+
+    def fetch(reqs):
+        cache, out = {}, []
+        for rec, a, b, rv in reqs:
+            if rec not in cache:
+                cache[rec] = get(rec)
+            q = cache[rec]
+            out.append(str((q[::-1] if rv else q)[a:b]))
+        return out
+    return fetch
+
+
+def _own_seqs(seqs):
+    """(DeferredSeq, created here?) — the candidate builders also take a plain seq_of(rec) callable and then resolve at once."""
+    return (seqs, False) if isinstance(seqs, DeferredSeq) else (DeferredSeq(host_seq_fetch(seqs)), True)
+
+
+def cigar_candidates(soa, raw, combined, seqs, chr_name):
     """Per-record candidate lists in the reference's layout and order (SE:476-477: the read's INS signals, then its DEL
     signals): INS [pos, len, read_name, seq, 'INS', chr], DEL [pos, len, read_name, 'DEL', chr].
-    `seq_of(rec)` returns the read's stored sequence (query_sequence)."""
+    `seqs` = DeferredSeq over the reads' stored sequences (query_sequence); the INS entries carry slice tokens until
+    resolve_sequences()."""
+    seqs, own = _own_seqs(seqs)
     out = {}
     for row in combined:
         rec = int(row["rec"])
@@ -55,17 +97,20 @@ def cigar_candidates(soa, raw, combined, seq_of, chr_name):
         if int(row["meta"]) & M_DEL:
             dele.append([int(row["pos"]), int(row["svlen"]), name, "DEL", chr_name])
         else:
-            seq, hc, left, k = seq_of(rec), leading_hardclip(soa, rec), int(row["q_end"]), int(row["rec2"])
+            hc, left, k = leading_hardclip(soa, rec), int(row["q_end"]), int(row["rec2"])
             parts = []
             while left:                                     # pieces = the next `q_end` INS rows of this record in raw order
                 r = raw[k]
                 if int(r["rec"]) == rec and not (int(r["meta"]) & M_DEL):
                     a = int(r["q_start"]) - hc              # SE:468-469: [shift_ins_read - len - hardclip_left : shift_ins_read - hardclip_left]
-                    parts.append(seq[a:a + int(r["svlen"])])       # same Python slice as the reference, same numbers
+                    parts.append(seqs.ask(rec, a, a + int(r["svlen"])))       # same Python slice as the reference, same numbers
                     left -= 1
                 k += 1
-            ins.append([int(row["pos"]), int(row["svlen"]), name, "".join(parts), "INS", chr_name])
-    return {rec: a + b for rec, (a, b) in out.items()}
+            ins.append([int(row["pos"]), int(row["svlen"]), name, parts, "INS", chr_name])
+    res = {rec: a + b for rec, (a, b) in out.items()}
+    if own:
+        resolve_sequences(seqs, res)
+    return res
 
 
 # ---- split-read branch (organize_split_signal SE:341-371 on the host, analysis_split_read SE:193-319 on the GPU) ---------
@@ -148,9 +193,20 @@ def split_reads(soa, sam_flags, query_lengths, sa_tags, chrom_id, min_mapq=20):
     return reads
 
 
-def split_candidates(soa, rows, seq_of, chrom_name):
+def resolve_sequences(seqs, *candidate_maps):
+    """Fetches every slice asked for and replaces the token lists of the INS candidates by their text."""
+    seqs.resolve()
+    for cands in candidate_maps:
+        for lst in cands.values():
+            for c in lst:
+                if len(c) == 6 and isinstance(c[3], list):
+                    c[3] = seqs.text(c[3])
+
+
+def split_candidates(soa, rows, seqs, chrom_name):
     """Rows of vsv_cutesv_split -> {record: [candidates]} in the reference's layout: INS [int(pos), len, name, seq, 'INS', chr],
-    DEL [pos, len, name, 'DEL', chr]. chrom_name: id -> name."""
+    DEL [pos, len, name, 'DEL', chr]. chrom_name: id -> name. `seqs`: DeferredSeq (tokens until resolve_sequences) or seq_of(rec)."""
+    seqs, own = _own_seqs(seqs)
     out = {}
     for row in rows:
         rec = int(row["rec"])
@@ -158,11 +214,11 @@ def split_candidates(soa, rows, seq_of, chrom_name):
         if int(row["meta"]) & M_DEL:
             c = [int(row["pos"]), int(row["svlen"]), name, "DEL", chrom_name(int(row["tid"]))]
         else:
-            q = seq_of(rec)
-            if int(row["meta"]) & M_QREV:
-                q = q[::-1]
-            c = [int(row["pos"]), int(row["svlen"]), name, str(q[int(row["q_start"]):int(row["q_end"])]), "INS", chrom_name(int(row["tid"]))]
+            tok = seqs.ask(rec, int(row["q_start"]), int(row["q_end"]), bool(int(row["meta"]) & M_QREV))
+            c = [int(row["pos"]), int(row["svlen"]), name, [tok], "INS", chrom_name(int(row["tid"]))]
         out.setdefault(rec, []).append(c)
+    if own:
+        resolve_sequences(seqs, out)
     return out
 
 
@@ -226,13 +282,14 @@ def sort_sigs(lines):
 
 
 def run(input_bam, reference, work_dir, batches=10000000, max_split_parts=7, min_mapq=20, min_read_len=500, merge_del_threshold=0,
-        merge_ins_threshold=100, include_bed=None, min_size=30, max_size=100000, min_siglength=10, device=0, engine=None, log=print):
+        merge_ins_threshold=100, include_bed=None, min_size=30, max_size=100000, min_siglength=10, device=0, engine=None, log=print,
+        device_ingest=True):
     """Writes <work_dir>/INS.sigs, DEL.sigs and reads.sigs like sig_extract.py (SE:575-645). The per-task files under
     signatures/ are not kept; a task without any candidate — INS, DEL or translocation — contributes no reads (single_pipe
     returns early, SE:533-535)."""
     import os
 
-    from .bam import BamFile
+    from .bam import BamFile, DeviceRecordView
     from .engine import Engine
     if not os.path.isfile(reference):
         raise FileNotFoundError("[Errno 2] No such file: '%s'" % reference)
@@ -256,7 +313,18 @@ def run(input_bam, reference, work_dir, batches=10000000, max_split_parts=7, min
                 return ids[n]
 
             for chrom, ln in contigs:
-                soa = bam.fetch_soa(chrom, keep_seq=True)
+                # BGZF inflate + record parse on the GPU, the packed sequences stay there (the host reader only if the device
+                # reader gives up on the file)
+                view = bam.fetch_device(eng, chrom, sa=True, seq=True) if device_ingest else bam.fetch_soa(chrom, keep_seq=True)
+                if view.n_records == 0:
+                    continue
+                if isinstance(view, DeviceRecordView):
+                    soa = view.to_host()
+                    soa.sa_tags = view.sa_tags
+                    seqs = DeferredSeq(view.seq_slices)
+                else:
+                    soa = view
+                    seqs = DeferredSeq(host_seq_fetch(soa.seq))
                 n = soa.n_records
                 if n == 0:
                     continue
@@ -284,8 +352,7 @@ def run(input_bam, reference, work_dir, batches=10000000, max_split_parts=7, min
                     _pad_empty_cigars(soa, n_ops)
                 eng.run(soa, p)
                 raw, comb = eng.table("raw"), eng.table("cigar")
-                seq_of = lambda rec: soa.seq[rec]
-                cig = cigar_candidates(soa, raw, comb, seq_of, chrom)
+                cig = cigar_candidates(soa, raw, comb, seqs, chrom)
                 ok = live & (soa.l_seq.astype(np.int64) >= min_read_len)
                 sflags = np.where(ok, soa.sam_flags, 0xFFFF)                       # skipped reads never reach the split branch
                 sreads = split_reads(soa, sflags, soa.l_seq, soa.sa_tags, chrom_id, min_mapq)
@@ -293,7 +360,8 @@ def run(input_bam, reference, work_dir, batches=10000000, max_split_parts=7, min
                 if sreads:
                     seg = SplitSegments(sreads)
                     rows = eng.cutesv_split(seg, seg.read_len, seg.read_rec, min_size, max_size, max_split_parts)
-                    spl = split_candidates(soa, rows, seq_of, lambda t: names[t])
+                    spl = split_candidates(soa, rows, seqs, lambda t: names[t])
+                resolve_sequences(seqs, cig, spl)
                 has_cand = np.zeros(len(tix), dtype=bool)
                 if sreads:
                     # a translocation candidate (analysis_bnd) never reaches INS.sigs / DEL.sigs, but its task is not empty:
