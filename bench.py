@@ -495,6 +495,10 @@ def main():
                          "frac": res["scan"]["frac"], "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": res["algorithmic_bytes_per_step"], "avg_launch_ms": res["scan"]["avg_launch_ms"],
                          "alone_launch_ms": res["scan"]["alone_launch_ms"], "alone_frac": res["scan"]["alone_frac"],
+                         "note": "achieved / frac / avg_launch_ms: HIP events around the kernel on its launch stream, averaged over the timed region, "
+                                 "where %d engines are in flight and the launch shares the GPU with the other engines' kernels; alone_*: the same launch "
+                                 "on the same input with nothing else in flight (what rocprofv3 --kernel-trace reports too: under the profiler the "
+                                 "engines' kernels overlap far less, see profiles/)" % res["streams"],
                          # the library's own read-stream / copy kernels over the same CIGAR array, after the timed region
                          "measured_read_stream": ceil_read, "measured_copy_stream": ceil_copy,
                          "frac_of_measured_read_stream": res["scan"]["GBs"] / ceil_read if ceil_read else None},
