@@ -39,6 +39,7 @@ __device__ __forceinline__ uint32_t sload_dword(const uint32_t* p) {
 
 struct Bits {                       // all members wave-uniform
   const uint32_t* p; const uint32_t* end; uint64_t buf; int cnt; int skip; bool over;
+  const uint32_t* w0; uint32_t end_bit;   // the member's first (aligned) dword and its end, in bits from there
   // the stream is read as aligned dwords; `skip` leading bytes of the first dword belong to the previous member
   __device__ __forceinline__ void refill() {
     if (cnt <= 32 && p != end) {
@@ -243,66 +244,133 @@ __device__ __forceinline__ uint32_t dist_entry(int ds) {
   return (base << 8) | ((uint32_t)ext << 4);
 }
 
-// The body of a block. The scalar unit issues one instruction per cycle for the whole CU and every wave here is one serial
-// decoder, so the kernel's speed is the number of scalar instructions per symbol (rocprofv3 SQ_INSTS_SALU: ~100 per symbol, 0.63
-// per CU cycle, before this form). fast_run handles only what nearly every symbol is — a literal, or a match whose source lies in
-// the LDS ring and does not overlap its destination, both with a code the fast tables resolve — in a loop without any other way
-// through it: everything else leaves the loop BEFORE the symbol is consumed and codes() decodes that one symbol the general way.
-enum { FR_SLOW = 1 };
-__device__ __forceinline__ int fast_run(Bits& b, const Tables& T, Out& out) {
-  uint64_t buf = b.buf; int cnt = b.cnt; const uint32_t* p = b.p; const uint32_t* const end = b.end;
-  uint32_t o = out.o, npend = out.npend, lit = out.lit;
-  bool full = out.full;
-  const uint32_t cap = out.cap; const int lane = out.lane;
+// The body of a block. A wave that decodes symbol after symbol on the scalar unit needs ~100 scalar instructions per symbol, and a
+// CU issues one scalar instruction per cycle for all its waves: that, not memory, bounded this kernel (rocprofv3: 1.2e10 scalar
+// instructions for 9 124 members, 0.63 per CU cycle, the vector unit idle). fast_windows decodes a WINDOW of 64 bit positions at
+// once on the vector unit: lane i assumes that a literal/length symbol starts at bit pos + i and decodes it completely — table
+// lookup, extra bits, and for a length symbol the distance code behind it — which gives every lane the symbol's kind, payload and
+// total length in bits, i.e. where the next symbol would start. The window's first bit IS a symbol start, so a short scalar walk
+// (lane -> next lane, ~6 instructions per symbol) marks the lanes that really are symbols; one prefix sum over their output lengths
+// places them, the literals are stored by their lanes at once and the matches are copied in order, 64 bytes per step, from the LDS
+// ring or (sources further back than the ring) from global memory. A window ends in front of anything the tables do not resolve
+// in one lookup, an end-of-block, a match that overlaps its own output, or the end of the stream: codes() decodes that one
+// symbol the general way and comes back.
+__device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)v, d, 64); if (lane >= d) v += o; }
+  return v;
+}
+__device__ __forceinline__ void sload_5(const uint32_t* p, uint32_t& w0, uint32_t& w1, uint32_t& w2, uint32_t& w3, uint32_t& w4) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const uint64_t a = (uint64_t)(uintptr_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+  const uint32_t* q = (const uint32_t*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+  u32x4 v; uint32_t t;
+  asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dword %1, %2, 0x10\n\ts_waitcnt lgkmcnt(0)" : "=&s"(v), "=&s"(t) : "s"(q) : "memory");
+  w0 = v.x; w1 = v.y; w2 = v.z; w3 = v.w; w4 = t;
+}
+enum { C_LIT = 0, C_END = 1, C_MATCH = 2, C_STOP = 3 };
+__device__ __forceinline__ void fast_windows(Bits& b, const Tables& T, Out& out) {
+  out.flush();
+  if (out.full || b.skip) return;
+  const int lane = out.lane;
   uint8_t* const dst = out.dst; uint8_t* const ring = out.ring;
-  for (;;) {
-    if (cnt <= 32) { if (p != end) { const uint64_t v = sload_dword(p); ++p; buf |= v << cnt; cnt += 32; } }
-    const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)T.lfast[(uint32_t)buf & ((1u << LFAST) - 1u)]);
-    const uint32_t len = e & 15u;
-    if (len - 1u >= (uint32_t)cnt) break;
-    if ((e & 0x30u) == 0u) {                                    // literal
-      buf >>= len; cnt -= (int)len;
-      if ((uint32_t)lane == npend) lit = (e >> 8) & 255u;
-      if (++npend == 64u) {                                     // (as Out::flush: one lane predicate, no branch around the stores)
-        const bool fits = o + 64u <= cap;
-        if ((uint32_t)lane < (fits ? 64u : 0u)) { dst[o + lane] = (uint8_t)lit; ring[(o + lane) & (RING - 1u)] = (uint8_t)lit; }
-        if (!fits) full = true;
-        o += 64u; npend = 0u;
+  const uint32_t cap = out.cap;
+  uint32_t o = out.o;
+  const uint32_t nwords = (uint32_t)(b.end - b.w0);
+  uint32_t bp = (uint32_t)(b.p - b.w0) * 32u - (uint32_t)b.cnt;      // bits of the stream consumed so far
+  for (int guard = 0; guard < 70000; ++guard) {
+    const uint32_t wi = bp >> 5, r = bp & 31u;
+    if (wi + 5u > nwords || bp + 160u > b.end_bit) break;               // the last few dozen bytes of a member: the general path
+    uint32_t W0, W1, W2, W3, W4;
+    sload_5(b.w0 + wi, W0, W1, W2, W3, W4);
+    // 64 stream bits from bit position bp + lane
+    const uint32_t t = r + (uint32_t)lane, d = t >> 5, sh = t & 31u;
+    const uint32_t xl = d == 0u ? W0 : d == 1u ? W1 : W2, xm = d == 0u ? W1 : d == 1u ? W2 : W3, xh = d == 0u ? W2 : d == 1u ? W3 : W4;
+    uint64_t x = (((uint64_t)xm << 32) | xl) >> sh;
+    if (sh) x |= (uint64_t)xh << (64u - sh);
+    // the symbol that would start here
+    const uint32_t e = T.lfast[(uint32_t)x & ((1u << LFAST) - 1u)];
+    const uint32_t len = e & 15u, kind = (e >> 4) & 3u;
+    uint32_t cls = len == 0u ? (uint32_t)C_STOP : kind == K_LIT ? (uint32_t)C_LIT : kind == K_END ? (uint32_t)C_END : kind == K_LEN ? (uint32_t)C_MATCH : (uint32_t)C_STOP;
+    uint32_t tb = len, mlen = 1u, dist = 0u;
+    const uint32_t byte = (e >> 8) & 255u;
+    if (cls == C_MATCH) {
+      const uint32_t lext = (e >> 20) & 15u;
+      const uint64_t x1 = x >> len;
+      mlen = ((e >> 8) & 0x1FFu) + ((uint32_t)x1 & ((1u << lext) - 1u));
+      const uint64_t x2 = x1 >> lext;
+      const uint32_t de = T.dfast[(uint32_t)x2 & ((1u << DFAST) - 1u)];
+      const uint32_t dl = de & 15u, dext = (de >> 4) & 15u;
+      dist = ((de >> 8) & 0xFFFFu) + ((uint32_t)(x2 >> dl) & ((1u << dext) - 1u));
+      tb = len + lext + dl + dext;                                       // <= 15 + 5 + 15 + 13 = 48 of the 64 bits at hand
+      if (dl == 0u || (de >> 24)) cls = C_STOP;
+    }
+    // ---- which lanes are symbols: the walk from lane 0 -------------------------------------------------------------
+    const uint32_t next = (uint32_t)lane + tb;
+    uint64_t valid = 0;
+    uint32_t i = 0;
+    bool stop = false;
+    while (i < 64u) {
+      const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cls, (int)i);
+      if (c == C_STOP || c == C_END) { stop = true; break; }
+      valid |= 1ull << i;
+      i = (uint32_t)__builtin_amdgcn_readlane((int)next, (int)i);
+    }
+    uint32_t consumed = i;                                               // bits (the stopping symbol itself is not consumed)
+    const bool mine = (valid >> lane) & 1ull;
+    // ---- where the symbols' bytes go ----------------------------------------------------------------------------------
+    const uint32_t outlen = mine ? mlen : 0u;                            // (literals: mlen = 1)
+    const uint32_t incl = wave_incl_sum(outlen, lane);
+    const uint32_t at = o + (incl - outlen);
+    // a symbol that cannot be committed here: output beyond ISIZE, a match that reaches in front of the member's output or into its
+    // own (dist < mlen: the general path's repeating copy). The window ends in front of the first one.
+    const bool bad = mine && (at + outlen > cap || (cls == C_MATCH && (dist > at || dist < mlen)));
+    const uint64_t bm = __ballot(bad);
+    uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    if (bm) {
+      const int j = __builtin_ctzll(bm);
+      valid &= (1ull << j) - 1ull;
+      consumed = (uint32_t)j;
+      total = (uint32_t)__builtin_amdgcn_readlane((int)(incl - outlen), j);
+      stop = true;
+    }
+    const bool on = (valid >> lane) & 1ull;
+    // ---- literals: every lane its own byte; matches: in stream order, the whole wave on each ----------------------------
+    if (on && cls == C_LIT) { dst[at] = (uint8_t)byte; ring[at & (RING - 1u)] = (uint8_t)byte; }
+    __builtin_amdgcn_wave_barrier();
+    uint64_t mm = __ballot(on && cls == C_MATCH);
+    while (mm) {
+      const int l = __builtin_ctzll(mm);
+      mm &= mm - 1ull;
+      const uint32_t ml = (uint32_t)__builtin_amdgcn_readlane((int)mlen, l), di = (uint32_t)__builtin_amdgcn_readlane((int)dist, l);
+      const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)at, l);
+      // the ring already holds this window's literals, up to o + total: a source is read from it only if none of them (nor the
+      // 64 bytes a step writes ahead) can have overwritten it
+      if (di + (o + total - a) + 64u <= RING) {
+        for (uint32_t base = 0; base < ml; base += 64u) {
+          const uint32_t k = base + (uint32_t)lane;
+          if (k < ml) { const uint8_t v = ring[(a - di + k) & (RING - 1u)]; dst[a + k] = v; ring[(a + k) & (RING - 1u)] = v; }
+        }
+      } else {                                                           // the source left the ring: global memory, once the stores have landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (uint32_t base = 0; base < ml; base += 64u) {
+          const uint32_t k = base + (uint32_t)lane;
+          if (k < ml) { const uint8_t v = dst[a - di + k]; dst[a + k] = v; ring[(a + k) & (RING - 1u)] = v; }
+        }
       }
-      continue;
+      __builtin_amdgcn_wave_barrier();
     }
-    if ((e & 0x30u) != (K_LEN << 4)) break;                     // end of block / not a symbol
-    // a match: decode it completely on copies, commit only if it is one of the common kind
-    uint64_t buf2 = buf >> len; int cnt2 = cnt - (int)len;
-    const uint32_t lext = (e >> 20) & 15u;
-    if ((int)lext > cnt2) break;
-    const uint32_t mlen = ((e >> 8) & 0x1FFu) + ((uint32_t)buf2 & ((1u << lext) - 1u));
-    buf2 >>= lext; cnt2 -= (int)lext;
-    const uint32_t* p2 = p;
-    if (cnt2 <= 32) { if (p2 != end) { const uint64_t v = sload_dword(p2); ++p2; buf2 |= v << cnt2; cnt2 += 32; } }
-    const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)T.dfast[(uint32_t)buf2 & ((1u << DFAST) - 1u)]);
-    const uint32_t dl = d & 15u;
-    if (dl - 1u >= (uint32_t)cnt2 || (d >> 24)) break;
-    buf2 >>= dl; cnt2 -= (int)dl;
-    const uint32_t dext = (d >> 4) & 15u;
-    if ((int)dext > cnt2) break;
-    const uint32_t dist = ((d >> 8) & 0xFFFFu) + ((uint32_t)buf2 & ((1u << dext) - 1u));
-    buf2 >>= dext; cnt2 -= (int)dext;
-    const uint32_t at = o + npend;                               // where the match starts
-    if (dist < mlen || dist + 64u > RING || dist > at || at + mlen > cap) break;
-    buf = buf2; cnt = cnt2; p = p2;
-    if ((uint32_t)lane < npend) { dst[o + lane] = (uint8_t)lit; ring[(o + lane) & (RING - 1u)] = (uint8_t)lit; }
-    __builtin_amdgcn_wave_barrier();
-    for (uint32_t base = 0; base < mlen; base += 64u) {
-      const uint32_t i = base + (uint32_t)lane;
-      if (i < mlen) { const uint8_t v = ring[(at - dist + i) & (RING - 1u)]; dst[at + i] = v; ring[(at + i) & (RING - 1u)] = v; }
-    }
-    __builtin_amdgcn_wave_barrier();
-    o = at + mlen; npend = 0u;
+    o += total; bp += consumed;
+    if (stop || consumed == 0u) break;
   }
-  b.buf = buf; b.cnt = cnt; b.p = p;
-  out.o = o; out.npend = npend; out.lit = lit; out.full = full;
-  return FR_SLOW;
+  // back to the scalar reader at bit position bp
+  out.o = o;
+  const uint32_t wi = bp >> 5, r = bp & 31u;
+  if (wi < nwords) {
+    const uint64_t v = sload_dword(b.w0 + wi);
+    b.buf = v >> r; b.cnt = 32 - (int)r; b.p = b.w0 + wi + 1;
+  } else { b.buf = 0; b.cnt = 0; b.p = b.end; }
 }
 
 __device__ __forceinline__ int codes(Bits& b, Tables& T, Out& out) {
@@ -310,7 +378,7 @@ __device__ __forceinline__ int codes(Bits& b, Tables& T, Out& out) {
   build_fast<DFAST>(T.dcount, T.dsymbol, T.dfast, out.lane, [](int s_) { return dist_entry(s_); });
   const Counts kl = load_counts(T.lcount), kd = load_counts(T.dcount);
   for (;;) {
-    fast_run(b, T, out);
+    fast_windows(b, T, out);
     // one symbol the general way: long codes, the end of the stream or of the block, far or overlapping matches, errors
     b.refill();
     uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)T.lfast[(uint32_t)b.buf & ((1u << LFAST) - 1u)]);
@@ -357,7 +425,7 @@ __global__ __launch_bounds__(64) void bgzf_inflate(const uint8_t* __restrict__ c
   const uint64_t c0 = comp_off[m], c1 = comp_off[m + 1];
   const uint64_t a0 = c0 & ~3ull;                               // comp is 256-byte aligned (hipMalloc), so this is a dword boundary
   const uint32_t* w0 = reinterpret_cast<const uint32_t*>(comp + a0);
-  Bits b{w0, w0 + (uint32_t)((c1 - a0 + 3) / 4), 0ull, 0, (int)(c0 - a0), false};
+  Bits b{w0, w0 + (uint32_t)((c1 - a0 + 3) / 4), 0ull, 0, (int)(c0 - a0), false, w0, (uint32_t)((c1 - a0) * 8)};
   // bits beyond the member's last byte (the tail of its last dword) are never consumed by a valid stream: it ends first
   Out out{outp + out_off[m], 0u, (uint32_t)(out_off[m + 1] - out_off[m]), 0u, 0u, lane, ring, false};
   int err = 0;
