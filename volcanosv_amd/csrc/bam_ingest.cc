@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <atomic>
@@ -196,6 +197,8 @@ bool read_header(vsv_bam* b) {
 }
 
 }  // namespace
+
+extern "C" void* vsv_internal_pinned(vsv_handle* h, uint64_t bytes);   // capi.hip
 
 extern "C" {
 
@@ -494,6 +497,36 @@ static int bam_load_device_impl(vsv_bam* b, vsv_handle* h, int tid, vsv_records*
   if (map.p == MAP_FAILED) { b->err = "cannot map the BAM file"; return VSV_E_INVALID; }
   (void)madvise(map.p, map.n, MADV_SEQUENTIAL);
   const uint8_t* comp = (const uint8_t*)map.p;
+  // Files of up to 1 GiB are first read into a page-locked buffer of the handle by a few threads (the page cache delivers ~10 GB/s
+  // per thread): the member table then reads hot memory instead of faulting one mapped page per member, and the device reader's
+  // uploads are asynchronous DMAs at PCIe speed that run under the decode of the previous slice. Larger files stream from the
+  // mapping, window by window.
+  static const char* pin_env = getenv("VSV_BAM_PINNED");      // timing experiments: "0" keeps the mapped file
+  if ((size_t)fsize <= (1ull << 30) && !(pin_env && pin_env[0] == '0')) {
+    uint8_t* pin = (uint8_t*)vsv_internal_pinned(h, (uint64_t)fsize + 64);
+    if (pin) {
+      const int fd = fileno(b->f);
+      unsigned nt = std::thread::hardware_concurrency();
+      nt = nt == 0 ? 4 : nt > 8 ? 8 : nt;
+      if ((size_t)fsize < (8u << 20)) nt = 1;
+      std::vector<std::thread> pool;
+      std::vector<int> ok(nt, 1);
+      const size_t per = ((size_t)fsize / nt + 4095) & ~(size_t)4095;
+      for (unsigned t = 0; t < nt; ++t)
+        pool.emplace_back([&, t]() {
+          size_t o = (size_t)t * per, e = o + per < (size_t)fsize ? o + per : (size_t)fsize;
+          while (o < e) {
+            const ssize_t g = pread(fd, pin + o, e - o, (off_t)o);
+            if (g <= 0) { ok[t] = 0; return; }
+            o += (size_t)g;
+          }
+        });
+      for (auto& th : pool) th.join();
+      bool all = true;
+      for (int v : ok) all = all && v;
+      if (all) { memset(pin + fsize, 0, 64); comp = pin; }
+    }
+  }
   const double t1 = now();
   std::vector<uint64_t> coff;
   std::vector<uint32_t> isz, crcs;

@@ -63,6 +63,7 @@ struct vsv_handle {
   bool want_seq = false;               // vsv_bam_device_want_seq: the device parse also keeps the packed SEQ fields (device-resident)
   DevBuf o_sqoff, o_sqlen, o_sqloc, o_seq, o_recseq, q_rec, q_start, q_len, q_rev, q_ooff, q_out;
   int64_t seq_records = -1;            // records whose SEQ the store holds (-1: none)
+  void* pin_buf = nullptr; size_t pin_bytes = 0;   // page-locked staging of a BAM file's compressed bytes (vsv_internal_pinned)
   int pass_cursor = 0;
   int group_cursor = 0;
   uint32_t* groups = nullptr;      // view into `arena`
@@ -584,6 +585,7 @@ void vsv_destroy(vsv_handle* h) {
                     &h->o_sqoff, &h->o_sqlen, &h->o_sqloc, &h->o_seq, &h->o_recseq, &h->q_rec, &h->q_start, &h->q_len, &h->q_rev, &h->q_ooff, &h->q_out};
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
   if (h->pinned) hipHostFree(h->pinned);
+  if (h->pin_buf) hipHostFree(h->pin_buf);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
   delete h;
@@ -1039,6 +1041,19 @@ static int inflate_to_device(vsv_handle* h, const uint8_t* comp, const uint64_t*
   return 0;
 }
 
+// Page-locked host buffer of at least `bytes` (kept by the handle, grown geometrically): the device reader stages a file's compressed
+// bytes there, so that their upload is an asynchronous DMA at PCIe speed instead of a copy through the runtime's own staging.
+// nullptr if it cannot be had (the caller then hands over pageable memory).
+void* vsv_internal_pinned(vsv_handle* h, uint64_t bytes) {
+  if (!h || bytes == 0) return nullptr;
+  if (h->pin_bytes >= bytes) return h->pin_buf;
+  if (hipSetDevice(h->device) != hipSuccess) return nullptr;
+  if (h->pin_buf) { (void)hipHostFree(h->pin_buf); h->pin_buf = nullptr; h->pin_bytes = 0; }
+  size_t nb = (size_t)bytes + (size_t)bytes / 4 + 4096;
+  if (hipHostMalloc(&h->pin_buf, nb) != hipSuccess) { (void)hipGetLastError(); h->pin_buf = nullptr; return nullptr; }
+  h->pin_bytes = nb;
+  return h->pin_buf;
+}
 int vsv_bam_device_want_seq(vsv_handle* h, int want) {
   if (!h) return VSV_E_INVALID;
   h->want_seq = want != 0;

@@ -255,10 +255,14 @@ __device__ __forceinline__ uint32_t dist_entry(int ds) {
 // ring or (sources further back than the ring) from global memory. A window ends in front of anything the tables do not resolve
 // in one lookup, an end-of-block, a match that overlaps its own output, or the end of the stream: codes() decodes that one
 // symbol the general way and comes back.
-__device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)v, d, 64); if (lane >= d) v += o; }
-  return v;
+// inclusive prefix sum over the 64 lanes in six DPP steps (row_shr 1, 2, 4, 8, row_bcast 15 / 31): shuffles through ds_bpermute cost
+// an LDS round trip each, and this sum sits on the critical path of every window
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
+__device__ __forceinline__ uint32_t dpp0(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, BANK_MASK, false); }
+__device__ __forceinline__ uint32_t wave_incl_sum(uint32_t x, int) {
+  x += dpp0<0x111>(x); x += dpp0<0x112>(x); x += dpp0<0x114>(x); x += dpp0<0x118>(x);
+  x += dpp0<0x142, 0xA>(x); x += dpp0<0x143, 0xC>(x);
+  return x;
 }
 __device__ __forceinline__ void sload_5(const uint32_t* p, uint32_t& w0, uint32_t& w1, uint32_t& w2, uint32_t& w3, uint32_t& w4) {
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
