@@ -16,15 +16,15 @@ namespace {
 
 constexpr int MAXBITS = 15, MAXLCODES = 286, MAXDCODES = 30, FIXLCODES = 288;
 
-constexpr int LFAST = 10, DFAST = 9;   // bits resolved by one table lookup; longer codes fall back to the bit-serial decode
+constexpr int LFAST = 11, DFAST = 10;  // bits resolved by one table lookup; longer codes fall back to the bit-serial decode
 struct Tables {
   uint16_t lcount[MAXBITS + 1], lsymbol[FIXLCODES];
   uint16_t dcount[MAXBITS + 1], dsymbol[MAXDCODES];
   uint8_t lengths[MAXLCODES + MAXDCODES + 2];
   // [next LFAST / DFAST stream bits] -> everything the body of a block needs from the symbol in one dword (lit_entry / dist_entry
   // below) | code length in bits 0-3; 0 in those bits = a longer code (bit-serial decode)
-  uint32_t lfast[1 << LFAST];
-  uint32_t dfast[1 << DFAST];
+  uint16_t lfast[1 << LFAST];
+  uint16_t dfast[1 << DFAST];
 };
 
 // one dword of the compressed stream through the scalar cache (lgkmcnt): it does not queue behind the output stores
@@ -128,7 +128,7 @@ __device__ __forceinline__ int construct_by_lane0(uint16_t* count, uint16_t* sym
 // are a complete code of length <= BITS (stream bits arrive LSB first, code bits MSB first, hence the bit reversal).
 // The 64 lanes share the work: lane handles the sorted symbols lane, lane + 64, ...
 template <int BITS, typename ENTRY>
-__device__ __forceinline__ void build_fast(const uint16_t* count, const uint16_t* symbol, uint32_t* fast, int lane, ENTRY entry) {
+__device__ __forceinline__ void build_fast(const uint16_t* count, const uint16_t* symbol, uint16_t* fast, int lane, ENTRY entry) {
   for (int i = lane; i < (1 << BITS); i += 64) fast[i] = 0;
   __builtin_amdgcn_wave_barrier();
   int code = 0, index = 0;                           // canonical first code / first sorted index of the current length
@@ -136,7 +136,7 @@ __device__ __forceinline__ void build_fast(const uint16_t* count, const uint16_t
     const int c = __builtin_amdgcn_readfirstlane((int)count[len]);
     for (int r = lane; r < c; r += 64) {
       const uint32_t rev = __builtin_bitreverse32((uint32_t)(code + r)) >> (32 - len);
-      const uint32_t e = entry((int)symbol[index + r]) | (uint32_t)len;
+      const uint16_t e = (uint16_t)(entry((int)symbol[index + r]) | (uint32_t)len);
       for (uint32_t hi = 0; hi < (1u << (BITS - len)); ++hi) fast[rev | (hi << len)] = e;
     }
     code = (code + c) << 1;
@@ -244,6 +244,18 @@ __device__ __forceinline__ uint32_t dist_entry(int ds) {
   return (base << 8) | ((uint32_t)ext << 4);
 }
 
+// The fast tables hold 16-bit entries (2048 + 1024 of them: 6 KB): bits 0-3 the code length (0 = longer than the table resolves),
+// bits 4-5 the kind, bits 6-13 the literal byte or the index of the length symbol (0..28) / bits 4-8 the index of the distance symbol
+// (30, 31: not a distance, bit 9). Base value and extra bits follow from the index by arithmetic (length_code / dist_code) in the
+// lanes that need them.
+__device__ __forceinline__ uint32_t lit16(int sym) {
+  if (sym < 256) return ((uint32_t)sym << 6) | (K_LIT << 4);
+  if (sym == 256) return K_END << 4;
+  if (sym - 257 >= 29) return K_BAD << 4;
+  return ((uint32_t)(sym - 257) << 6) | (K_LEN << 4);
+}
+__device__ __forceinline__ uint32_t dist16(int ds) { return ds >= 30 ? (1u << 9) : ((uint32_t)ds << 4); }
+
 // The body of a block. A wave that decodes symbol after symbol on the scalar unit needs ~100 scalar instructions per symbol, and a
 // CU issues one scalar instruction per cycle for all its waves: that, not memory, bounded this kernel (rocprofv3: 1.2e10 scalar
 // instructions for 9 124 members, 0.63 per CU cycle, the vector unit idle). fast_windows decodes a WINDOW of 64 bit positions at
@@ -298,17 +310,19 @@ __device__ __forceinline__ void fast_windows(Bits& b, const Tables& T, Out& out)
     const uint32_t len = e & 15u, kind = (e >> 4) & 3u;
     uint32_t cls = len == 0u ? (uint32_t)C_STOP : kind == K_LIT ? (uint32_t)C_LIT : kind == K_END ? (uint32_t)C_END : kind == K_LEN ? (uint32_t)C_MATCH : (uint32_t)C_STOP;
     uint32_t tb = len, mlen = 1u, dist = 0u;
-    const uint32_t byte = (e >> 8) & 255u;
+    const uint32_t byte = (e >> 6) & 255u;
     if (cls == C_MATCH) {
-      const uint32_t lext = (e >> 20) & 15u;
+      uint32_t lbase, dbase; int lext, dext;
+      length_code((int)byte, lbase, lext);                              // (byte = the length symbol's index here)
       const uint64_t x1 = x >> len;
-      mlen = ((e >> 8) & 0x1FFu) + ((uint32_t)x1 & ((1u << lext) - 1u));
+      mlen = lbase + ((uint32_t)x1 & ((1u << lext) - 1u));
       const uint64_t x2 = x1 >> lext;
       const uint32_t de = T.dfast[(uint32_t)x2 & ((1u << DFAST) - 1u)];
-      const uint32_t dl = de & 15u, dext = (de >> 4) & 15u;
-      dist = ((de >> 8) & 0xFFFFu) + ((uint32_t)(x2 >> dl) & ((1u << dext) - 1u));
-      tb = len + lext + dl + dext;                                       // <= 15 + 5 + 15 + 13 = 48 of the 64 bits at hand
-      if (dl == 0u || (de >> 24)) cls = C_STOP;
+      const uint32_t dl = de & 15u;
+      dist_code((int)((de >> 4) & 31u), dbase, dext);
+      dist = dbase + ((uint32_t)(x2 >> dl) & ((1u << dext) - 1u));
+      tb = len + (uint32_t)lext + dl + (uint32_t)dext;                   // <= 15 + 5 + 15 + 13 = 48 of the 64 bits at hand
+      if (dl == 0u || (de >> 9)) cls = C_STOP;
     }
     // ---- which lanes are symbols: the walk from lane 0 -------------------------------------------------------------
     const uint32_t next = (uint32_t)lane + tb;
@@ -378,38 +392,36 @@ __device__ __forceinline__ void fast_windows(Bits& b, const Tables& T, Out& out)
 }
 
 __device__ __forceinline__ int codes(Bits& b, Tables& T, Out& out) {
-  build_fast<LFAST>(T.lcount, T.lsymbol, T.lfast, out.lane, [](int s_) { return lit_entry(s_); });
-  build_fast<DFAST>(T.dcount, T.dsymbol, T.dfast, out.lane, [](int s_) { return dist_entry(s_); });
+  build_fast<LFAST>(T.lcount, T.lsymbol, T.lfast, out.lane, [](int s_) { return lit16(s_); });
+  build_fast<DFAST>(T.dcount, T.dsymbol, T.dfast, out.lane, [](int s_) { return dist16(s_); });
   const Counts kl = load_counts(T.lcount), kd = load_counts(T.dcount);
   for (;;) {
     fast_windows(b, T, out);
     // one symbol the general way: long codes, the end of the stream or of the block, far or overlapping matches, errors
-    b.refill();
-    uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)T.lfast[(uint32_t)b.buf & ((1u << LFAST) - 1u)]);
-    const uint32_t len = e & 15u;
-    if (len - 1u >= (uint32_t)b.cnt) {                         // len == 0: a code longer than LFAST bits; len > cnt: the stream is about to end
-      const int sym = decode_reg(b, kl, T.lsymbol);
+    uint32_t e;
+    {
+      const int sym = decode_reg(b, kl, T.lsymbol);              // (bit-serial canonical decode: a few percent of the symbols come here)
       if (sym < 0) return sym;
       e = lit_entry(sym);
-    } else { b.buf >>= len; b.cnt -= (int)len; }
+    }
     const uint32_t kind = (e >> 4) & 3u;
     if (kind == K_LIT) { out.literal((e >> 8) & 255u); continue; }
     if (kind == K_END) { out.flush(); return out.full ? -3 : 0; }
     if (kind == K_BAD) return -4;
     const int lext = (int)((e >> 20) & 15u);
+    b.refill();
     if (lext > b.cnt) { b.over = true; return -1; }
     const uint32_t mlen = ((e >> 8) & 0x1FFu) + ((uint32_t)b.buf & ((1u << lext) - 1u));
     b.buf >>= lext; b.cnt -= lext;
-    b.refill();
-    uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)T.dfast[(uint32_t)b.buf & ((1u << DFAST) - 1u)]);
-    const uint32_t dl = d & 15u;
-    if (dl - 1u >= (uint32_t)b.cnt) {
+    uint32_t d;
+    {
       const int ds = decode_reg(b, kd, T.dsymbol);
       if (ds < 0) return ds;
       d = dist_entry(ds);
-    } else { b.buf >>= dl; b.cnt -= (int)dl; }
+    }
     if (d >> 24) return -5;
     const int dext = (int)((d >> 4) & 15u);
+    b.refill();
     if (dext > b.cnt) { b.over = true; return -1; }
     const uint32_t dist = ((d >> 8) & 0xFFFFu) + ((uint32_t)b.buf & ((1u << dext) - 1u));
     b.buf >>= dext; b.cnt -= dext;
