@@ -502,6 +502,9 @@ static int bam_load_device_impl(vsv_bam* b, vsv_handle* h, int tid, vsv_records*
   // uploads are asynchronous DMAs at PCIe speed that run under the decode of the previous slice. Larger files stream from the
   // mapping, window by window.
   static const char* pin_env = getenv("VSV_BAM_PINNED");      // timing experiments: "0" keeps the mapped file
+  std::vector<std::thread> pool;
+  std::vector<std::atomic<int>> ready;                        // per reader thread: 0 reading, 1 done, -1 failed
+  size_t per = 0;
   if ((size_t)fsize <= (1ull << 30) && !(pin_env && pin_env[0] == '0')) {
     uint8_t* pin = (uint8_t*)vsv_internal_pinned(h, (uint64_t)fsize + 64);
     if (pin) {
@@ -509,32 +512,46 @@ static int bam_load_device_impl(vsv_bam* b, vsv_handle* h, int tid, vsv_records*
       unsigned nt = std::thread::hardware_concurrency();
       nt = nt == 0 ? 4 : nt > 8 ? 8 : nt;
       if ((size_t)fsize < (8u << 20)) nt = 1;
-      std::vector<std::thread> pool;
-      std::vector<int> ok(nt, 1);
-      const size_t per = ((size_t)fsize / nt + 4095) & ~(size_t)4095;
+      ready = std::vector<std::atomic<int>>(nt);
+      for (auto& r : ready) r.store(0);
+      per = ((size_t)fsize / nt + 4095) & ~(size_t)4095;
       for (unsigned t = 0; t < nt; ++t)
-        pool.emplace_back([&, t]() {
+        pool.emplace_back([&ready, pin, fd, fsize, per, t]() {
           size_t o = (size_t)t * per, e = o + per < (size_t)fsize ? o + per : (size_t)fsize;
           while (o < e) {
             const ssize_t g = pread(fd, pin + o, e - o, (off_t)o);
-            if (g <= 0) { ok[t] = 0; return; }
+            if (g <= 0) { ready[t].store(-1, std::memory_order_release); return; }
             o += (size_t)g;
           }
+          ready[t].store(1, std::memory_order_release);
         });
-      for (auto& th : pool) th.join();
-      bool all = true;
-      for (int v : ok) all = all && v;
-      if (all) { memset(pin + fsize, 0, 64); comp = pin; }
+      memset(pin + fsize, 0, 64);
+      comp = pin;
     }
   }
+  struct Joiner { std::vector<std::thread>& p; ~Joiner() { for (auto& th : p) if (th.joinable()) th.join(); } } joiner{pool};
+  // bytes [0, end) of the staged file are in place? (the member table below walks the file while the readers are still at work)
+  bool stage_failed = false;
+  auto wait_for = [&](size_t end) {
+    if (pool.empty()) return;
+    const size_t last = (end == 0 ? 0 : end - 1) / per;
+    for (size_t t = 0; t <= last && t < ready.size(); ++t) {
+      int v;
+      while ((v = ready[t].load(std::memory_order_acquire)) == 0) std::this_thread::yield();
+      if (v < 0) stage_failed = true;
+    }
+  };
   const double t1 = now();
   std::vector<uint64_t> coff;
   std::vector<uint32_t> isz, crcs;
   for (size_t o = 0; o < (size_t)fsize;) {
+    wait_for(o + 18 < (size_t)fsize ? o + 18 : (size_t)fsize);
+    if (stage_failed) { b->err = "cannot read the BAM file"; return VSV_E_INVALID; }
     const uint8_t* hdr = comp + o;
     if (o + 18 > (size_t)fsize || hdr[0] != 31 || hdr[1] != 139 || hdr[2] != 8 || !(hdr[3] & 4)) { b->err = "not a BGZF block"; return VSV_E_INVALID; }
     const uint16_t xlen = hdr[10] | (hdr[11] << 8);
     if (o + 12 + (size_t)xlen + 8 > (size_t)fsize) { b->err = "truncated BGZF block"; return VSV_E_INVALID; }
+    wait_for(o + 12 + (size_t)xlen);
     int bsize = -1;
     for (size_t e = 0; e + 4 <= xlen;) {
       const uint8_t* x = hdr + 12 + e;
@@ -544,12 +561,16 @@ static int bam_load_device_impl(vsv_bam* b, vsv_handle* h, int tid, vsv_records*
       e += 4 + slen;
     }
     if (bsize < 0 || o + (size_t)bsize + 1 > (size_t)fsize || (size_t)bsize + 1 < 12u + xlen + 8u) { b->err = "truncated or malformed BGZF block"; return VSV_E_INVALID; }
+    wait_for(o + (size_t)bsize + 1);
+    if (stage_failed) { b->err = "cannot read the BAM file"; return VSV_E_INVALID; }
     const uint8_t* tr = hdr + bsize + 1 - 8;
     crcs.push_back((uint32_t)tr[0] | ((uint32_t)tr[1] << 8) | ((uint32_t)tr[2] << 16) | ((uint32_t)tr[3] << 24));
     coff.push_back(o + 12 + xlen);
     isz.push_back((uint32_t)tr[4] | ((uint32_t)tr[5] << 8) | ((uint32_t)tr[6] << 16) | ((uint32_t)tr[7] << 24));
     o += (size_t)bsize + 1;
   }
+  wait_for((size_t)fsize);
+  if (stage_failed) { b->err = "cannot read the BAM file"; return VSV_E_INVALID; }
   coff.push_back((uint64_t)fsize);
   const double t2 = now();
   const char* names = nullptr; int64_t names_len = 0;

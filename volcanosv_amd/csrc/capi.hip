@@ -57,7 +57,9 @@ struct vsv_handle {
   DevBuf p_spec, p_cnt, p_land, p_base, p_recoff, p_pos, p_tid, p_mapq, p_flag, p_lseq, p_sflag, p_ncig, p_cgsrc, p_hash, p_keep, p_kidx,
       p_cigoff, p_sums, p_tot, p_err;                     // device BAM parse: per input record
   DevBuf o_pos, o_tid, o_qid, o_cigoff, o_mapq, o_flag, o_cigar, o_lseq, o_sflag, o_hash, o_recoff, o_first, o_rank, o_nlen, o_noff, o_blob, o_n, o_names, o_nmoff, o_nmlen;
-  std::string names_blob, sa_text;     // name table / SA tag texts of the last device parse (host copies)
+  std::string sa_text;                 // SA tag texts of the last device parse (host copy)
+  char* names_pin = nullptr; size_t names_cap = 0, names_len = 0;   // name table of the last device parse: page-locked host copy (a
+                                       // std::string would be zero-filled by resize and filled through the runtime's staging: 46 MB = 5 ms)
   bool want_sa = false;                // vsv_bam_set_want_sa: the device parse also collects the SA:Z texts
   DevBuf o_saoff, o_salen, o_saloc, o_sa;
   bool want_seq = false;               // vsv_bam_device_want_seq: the device parse also keeps the packed SEQ fields (device-resident)
@@ -586,6 +588,7 @@ void vsv_destroy(vsv_handle* h) {
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
   if (h->pinned) hipHostFree(h->pinned);
   if (h->pin_buf) hipHostFree(h->pin_buf);
+  if (h->names_pin) hipHostFree(h->names_pin);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
   delete h;
@@ -1151,8 +1154,8 @@ int vsv_bam_parse_device(vsv_handle* h, const uint8_t* comp, const uint64_t* com
   if (first_record > stream_total) return fail(h, VSV_E_INVALID, "header longer than the stream");
   memset(out, 0, sizeof *out);
   out->on_device = 1;
-  h->names_blob.clear();
-  if (names) *names = h->names_blob.c_str();
+  h->names_len = 0;
+  if (names) *names = "";
   if (names_len) *names_len = 0;
   int rc;
 #define DEVMEM(expr) do { if ((rc = (expr))) return rc == VSV_E_HIP ? fail(h, VSV_E_CAPACITY, "device memory exhausted in the device reader: use the host reader") : rc; } while (0)
@@ -1355,10 +1358,16 @@ int vsv_bam_parse_device(vsv_handle* h, const uint8_t* comp, const uint64_t* com
   DEVMEM(ensure(h, h->o_blob, blob_bytes + 16));
   vsv_bamdev_name_copy(st, (const uint8_t*)h->o_names.p, (const uint64_t*)h->o_nmoff.p, (const uint32_t*)h->o_nmlen.p, (const uint32_t*)h->o_first.p,
                        (const uint32_t*)h->o_noff.p, nk, (uint8_t*)h->o_blob.p);
-  h->names_blob.resize(blob_bytes);
-  if (blob_bytes) HIPCHK(h, hipMemcpyAsync(&h->names_blob[0], h->o_blob.p, blob_bytes, hipMemcpyDeviceToHost, st));
+  if (h->names_cap < blob_bytes + 1) {
+    if (h->names_pin) { (void)hipHostFree(h->names_pin); h->names_pin = nullptr; h->names_cap = 0; }
+    const size_t nb = blob_bytes + blob_bytes / 4 + 4096;
+    HIPCHK(h, hipHostMalloc((void**)&h->names_pin, nb));
+    h->names_cap = nb;
+  }
+  if (blob_bytes) HIPCHK(h, hipMemcpyAsync(h->names_pin, h->o_blob.p, blob_bytes, hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipStreamSynchronize(st));
-  if (blob_bytes) h->names_blob.pop_back();                          // the separator after the last name
+  h->names_len = blob_bytes ? blob_bytes - 1 : 0;                     // the separator after the last name is dropped
+  h->names_pin[h->names_len] = 0;
   lap(t_qid);
   if (timing)
     fprintf(stderr, "[vsv_bam_parse_device] %d windows: upload+inflate %.1f ms, record chain %.1f ms (%d rounds), fields+emit %.1f ms, names %.1f ms, query ids + name table %.1f ms\n",
@@ -1368,8 +1377,8 @@ int vsv_bam_parse_device(vsv_handle* h, const uint8_t* comp, const uint64_t* com
   out->cigar_off = (const uint64_t*)h->o_cigoff.p; out->mapq = (const uint8_t*)h->o_mapq.p; out->flag = (const uint8_t*)h->o_flag.p;
   out->cigar = (const uint32_t*)h->o_cigar.p;
   out->n_qids = (int32_t)(lr + lf);
-  if (names) *names = h->names_blob.c_str();
-  if (names_len) *names_len = (int64_t)h->names_blob.size();
+  if (names) *names = h->names_pin;
+  if (names_len) *names_len = (int64_t)h->names_len;
   if (l_seq_dev) *l_seq_dev = (const uint32_t*)h->o_lseq.p;
   if (sam_flags_dev) *sam_flags_dev = (const uint32_t*)h->o_sflag.p;
   h->stage_done = 0;
