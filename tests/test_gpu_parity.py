@@ -302,6 +302,37 @@ def test_staged_api_equals_fused(eng):
     staged = eng.tables(DTYPE_HIFI)
     assert np.array_equal(raw, fused["raw"]) and np.array_equal(c1, fused["cluster1"])
     assert_tables_equal(staged, fused, list(fused.keys()))
+    # split_min_mapq changed between the stages: the candidates are rebuilt with it (they depend on it), like a fused run with it
+    p2 = default_params(DTYPE_HIFI)
+    p2.min_split_mapq = 60
+    eng.run(soa, p2)
+    fused2 = eng.tables(DTYPE_HIFI)
+    eng.cigar_scan(soa, p)
+    eng.split_pairs(p2)
+    eng.sort_cluster(p2)
+    eng.merge_sources(p2)
+    eng.pair_haplotypes(p2)
+    assert_tables_equal(eng.tables(DTYPE_HIFI), fused2, list(fused2.keys()))
+
+
+def test_split_overlap_modes_give_the_same_tables(eng):
+    """vsv_params.split_overlap: the fused run builds the split candidates on the handle's auxiliary stream beside the scan (AUTO) or
+    on the handle's stream (OFF); a timing choice only. Alternating runs on one handle, read-shaped and contig-shaped input, all
+    data types that have a split stage."""
+    from volcanosv_amd import synth
+    from volcanosv_amd.abi import OVERLAP_AUTO, OVERLAP_OFF
+    from volcanosv_amd.engine import default_params
+    for shape, n, kw in (("hifi", 60000, dict(chrom_len=2_000_000, events_per_record=0.3, site_step=1000)), ("contig", 40, dict(chrom_len=20_000_000))):
+        t, nq, _ = synth.generate(n, shape, seed=77, **kw)
+        soa = synth.to_soa(t, nq)
+        for dtype in (DTYPE_HIFI, DTYPE_ONT, DTYPE_CLR, DTYPE_READS):
+            _, want = oracle_run(soa, dtype)
+            for mode in (OVERLAP_AUTO, OVERLAP_OFF, OVERLAP_AUTO):
+                p = default_params(dtype)
+                p.split_overlap = mode
+                eng.run(soa, p)
+                got = eng.tables(dtype)
+                assert_tables_equal(got, want, list(got.keys()))
 
 
 def test_edge_cases(eng):
