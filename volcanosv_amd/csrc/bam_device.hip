@@ -157,7 +157,9 @@ __global__ __launch_bounds__(256) void rec_fields(const uint8_t* __restrict__ s,
   keep[i] = (ref >= 0 && (want_tid < 0 || ref == want_tid)) ? 1u : 0u;
 }
 
-// compaction of the kept records + CIGAR copy: one wave per input record
+// compaction of the kept records + CIGAR copy: G lanes per input record — a whole wave for contig alignments (10^3-10^6 ops), eight
+// lanes for reads (tens of ops: a wave per record left most lanes idle and took 1.5 ms for 3 M records, 0.5 TB/s)
+template <int G>
 __global__ __launch_bounds__(256) void rec_emit(const uint8_t* __restrict__ s, int64_t n, const uint32_t* __restrict__ keep, const uint32_t* __restrict__ kidx,
                                                 const int32_t* __restrict__ pos, const int32_t* __restrict__ tid, const uint8_t* __restrict__ mapq,
                                                 const uint8_t* __restrict__ flag, const uint32_t* __restrict__ l_seq, const uint32_t* __restrict__ sam_flag,
@@ -167,29 +169,31 @@ __global__ __launch_bounds__(256) void rec_emit(const uint8_t* __restrict__ s, i
                                                 uint8_t* __restrict__ o_flag, uint32_t* __restrict__ o_l_seq, uint32_t* __restrict__ o_sam_flag,
                                                 uint64_t* __restrict__ o_cig_off, uint32_t* __restrict__ o_cigar, uint64_t* __restrict__ o_hash,
                                                 uint64_t* __restrict__ o_rec_off, uint64_t k0, uint64_t c0) {
-  const int lane = threadIdx.x & 63;
-  const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
-  for (int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < n; i += nw) {
-    if (!keep[i]) continue;
+  const int lane = threadIdx.x & (G - 1);
+  const int64_t ng = (int64_t)gridDim.x * (blockDim.x / G);
+  const int64_t n_pad = (n + (64 / G) - 1) / (64 / G) * (64 / G);          // whole waves iterate together: the group sums shuffle
+  for (int64_t i0 = (int64_t)blockIdx.x * (blockDim.x / G) + (threadIdx.x / G); i0 < n_pad; i0 += ng) {
+    const bool live = i0 < n && keep[i0];
+    const int64_t i = i0 < n ? i0 : n - 1;
     const uint32_t kl = kidx[i];                     // index among the kept records of this window
     const uint64_t k = k0 + kl;                       // ... and of the whole file
     const uint64_t co = c0 + cig_off_in[i];
-    if (lane == 0) {
+    if (live && lane == 0) {
       o_pos[k] = pos[i]; o_tid[k] = tid[i]; o_mapq[k] = mapq[i]; o_flag[k] = flag[i]; o_l_seq[k] = l_seq[i]; o_sam_flag[k] = sam_flag[i];
       o_cig_off[k] = co; o_hash[k] = hash[i]; o_rec_off[kl] = rec_off[i];
     }
     const uint8_t* src = s + cg_src[i];
-    const uint32_t nc = n_cig_out[i];
+    const uint32_t nc = live ? n_cig_out[i] : 0u;
     uint64_t ql = 0;                                   // query length of the CIGAR (M,I,S,=,X), summed while the ops are copied
-    for (uint32_t c = lane; c < nc; c += 64) {
+    for (uint32_t c = lane; c < nc; c += G) {
       const uint32_t w = ld32(src + 4ull * c), op = w & 15u;
       o_cigar[co + c] = w;
       if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) ql += w >> 4;
     }
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) ql += __shfl_xor(ql, d, 64);
+    for (int d = G / 2; d > 0; d >>= 1) ql += __shfl_xor(ql, d, 64);
     // a stored SEQ of another length is what the extractors assert on (H:397-398): VSV_F_SEQ_MISMATCH
-    if (lane == 0 && l_seq[i] != 0 && ql != (uint64_t)l_seq[i]) o_flag[k] = flag[i] | (uint8_t)VSV_F_SEQ_MISMATCH;
+    if (live && lane == 0 && l_seq[i] != 0 && ql != (uint64_t)l_seq[i]) o_flag[k] = flag[i] | (uint8_t)VSV_F_SEQ_MISMATCH;
   }
 }
 
@@ -413,10 +417,14 @@ void vsv_bamdev_emit(hipStream_t st, const uint8_t* s, int64_t n, const uint32_t
                      const uint8_t* mapq, const uint8_t* flag, const uint32_t* l_seq, const uint32_t* sam_flag, const uint32_t* n_cig_out,
                      const uint64_t* cg_src, const uint64_t* hash, const uint64_t* cig_off_in, const uint64_t* rec_off, int32_t* o_pos, int32_t* o_tid,
                      uint8_t* o_mapq, uint8_t* o_flag, uint32_t* o_l_seq, uint32_t* o_sam_flag, uint64_t* o_cig_off, uint32_t* o_cigar, uint64_t* o_hash,
-                     uint64_t* w_rec_off, uint64_t k0, uint64_t c0) {
+                     uint64_t* w_rec_off, uint64_t k0, uint64_t c0, uint64_t ops_hint) {
   if (n <= 0) return;
-  rec_emit<<<2048, 256, 0, st>>>(s, n, keep, kidx, pos, tid, mapq, flag, l_seq, sam_flag, n_cig_out, cg_src, hash, cig_off_in, rec_off, o_pos, o_tid,
-                                 o_mapq, o_flag, o_l_seq, o_sam_flag, o_cig_off, o_cigar, o_hash, w_rec_off, k0, c0);
+  if (ops_hint / (uint64_t)n >= 256)
+    rec_emit<64><<<2048, 256, 0, st>>>(s, n, keep, kidx, pos, tid, mapq, flag, l_seq, sam_flag, n_cig_out, cg_src, hash, cig_off_in, rec_off, o_pos, o_tid,
+                                       o_mapq, o_flag, o_l_seq, o_sam_flag, o_cig_off, o_cigar, o_hash, w_rec_off, k0, c0);
+  else
+    rec_emit<8><<<4096, 256, 0, st>>>(s, n, keep, kidx, pos, tid, mapq, flag, l_seq, sam_flag, n_cig_out, cg_src, hash, cig_off_in, rec_off, o_pos, o_tid,
+                                      o_mapq, o_flag, o_l_seq, o_sam_flag, o_cig_off, o_cigar, o_hash, w_rec_off, k0, c0);
 }
 void vsv_bamdev_iota(hipStream_t st, uint32_t* p, int64_t n) { if (n > 0) iota_u32<<<1024, 256, 0, st>>>(p, n); }
 void vsv_bamdev_mark_first(hipStream_t st, const uint64_t* skey, const uint32_t* sval, int64_t n, uint32_t* is_first) {

@@ -1258,7 +1258,7 @@ int vsv_bam_parse_device(vsv_handle* h, const uint8_t* comp, const uint64_t* com
                         (const uint32_t*)h->p_ncig.p, (const uint64_t*)h->p_cgsrc.p, (const uint64_t*)h->p_hash.p, (const uint64_t*)h->p_cigoff.p,
                         (const uint64_t*)h->p_recoff.p, (int32_t*)h->o_pos.p, (int32_t*)h->o_tid.p, (uint8_t*)h->o_mapq.p, (uint8_t*)h->o_flag.p,
                         (uint32_t*)h->o_lseq.p, (uint32_t*)h->o_sflag.p, (uint64_t*)h->o_cigoff.p, (uint32_t*)h->o_cigar.p, (uint64_t*)h->o_hash.p,
-                        (uint64_t*)h->o_recoff.p, K0, C0);
+                        (uint64_t*)h->o_recoff.p, K0, C0, ops_w);
         lap(t_rec);
         // names of the kept records into the compact store (the inflated window is gone when the query ids are assigned)
         vsv_bamdev_win_name_lens(st, s, (const uint64_t*)h->o_recoff.p, (int64_t)nk, (uint32_t*)h->o_nlen.p);

@@ -217,7 +217,7 @@ void vsv_bamdev_emit(hipStream_t st, const uint8_t* s, int64_t n, const uint32_t
                      const uint8_t* mapq, const uint8_t* flag, const uint32_t* l_seq, const uint32_t* sam_flag, const uint32_t* n_cig_out,
                      const uint64_t* cg_src, const uint64_t* hash, const uint64_t* cig_off_in, const uint64_t* rec_off, int32_t* o_pos, int32_t* o_tid,
                      uint8_t* o_mapq, uint8_t* o_flag, uint32_t* o_l_seq, uint32_t* o_sam_flag, uint64_t* o_cig_off, uint32_t* o_cigar, uint64_t* o_hash,
-                     uint64_t* w_rec_off, uint64_t k0, uint64_t c0);
+                     uint64_t* w_rec_off, uint64_t k0, uint64_t c0, uint64_t ops_hint);
 void vsv_bamdev_iota(hipStream_t st, uint32_t* p, int64_t n);
 void vsv_bamdev_mark_first(hipStream_t st, const uint64_t* skey, const uint32_t* sval, int64_t n, uint32_t* is_first);
 void vsv_bamdev_assign(hipStream_t st, const uint64_t* skey, const uint32_t* sval, int64_t n, const uint32_t* first_rank, const uint8_t* names,
