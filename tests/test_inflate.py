@@ -29,11 +29,29 @@ def make_members(seed=3):
         idx = rng.integers(0, n, n // 20 + 1)
         reps[idx] = rng.integers(0, 256, len(idx))
         blobs.append(reps.tobytes())
+    # what the window decoder treats specially: matches from 8-32 KiB back (source outside the LDS ring), codes longer than the
+    # fast tables resolve (a geometric byte distribution gives 12-15-bit literal codes), overlapping matches of short periods
+    # (distance 1-5), literal / match alternation at every position, and their mixtures
+    far = rng.integers(0, 256, 21000, dtype=np.uint8).tobytes()
+    blobs.append((far * 4)[:65280])
+    blobs.append((rng.integers(0, 256, 9000, dtype=np.uint8).tobytes() * 8)[:65280])
+    geo = np.minimum(rng.geometric(0.06, 65280) - 1, 255).astype(np.uint8)
+    blobs.append(geo.tobytes())
+    blobs.append(b"".join(bytes([int(rng.integers(0, 256))] * int(rng.integers(1, 6))) * int(rng.integers(1, 40)) for _ in range(3000))[:65280])
+    alt = bytearray()
+    while len(alt) < 65000:
+        alt += rng.integers(0, 256, int(rng.integers(1, 4)), dtype=np.uint8).tobytes()
+        if len(alt) > 40:
+            a = int(rng.integers(0, len(alt) - 12))
+            alt += alt[a:a + int(rng.integers(3, 12))]
+    blobs.append(bytes(alt[:65280]))
+    mix = bytearray(geo[:30000].tobytes()) + bytearray(far[:15000]) + bytearray(geo[:5000].tobytes()) + bytearray(far[:15000])
+    blobs.append(bytes(mix[:65280]))
     members = []
     for i, d in enumerate(blobs):
         for level, strat in ((0, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY),
                              (6, zlib.Z_FIXED), (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_RLE)):
-            if (i + level) % 2 == 0 or i < 8:
+            if (i + level) % 2 == 0 or i < 8 or i >= len(blobs) - 6:
                 members.append((raw_deflate(d, level, strat), d))
     return members
 
