@@ -510,7 +510,7 @@ static int bam_load_device_impl(vsv_bam* b, vsv_handle* h, int tid, vsv_records*
     if (pin) {
       const int fd = fileno(b->f);
       unsigned nt = std::thread::hardware_concurrency();
-      nt = nt == 0 ? 4 : nt > 8 ? 8 : nt;
+      nt = nt == 0 ? 4 : nt > 16 ? 16 : nt;
       if ((size_t)fsize < (8u << 20)) nt = 1;
       ready = std::vector<std::atomic<int>>(nt);
       for (auto& r : ready) r.store(0);
