@@ -78,9 +78,18 @@ struct SigKey {      // stage key of a signature row (vsv_key_stage; stage 5 = t
   }
   __device__ __forceinline__ uint32_t val_at(uint32_t i) const { return i; }
 };
-struct CallKey {     // (tid, pos) key of a call row: the final order of pair_sig's output (H:594)
-  const vsv_call* rows; int pb, tid_lo;
-  __device__ __forceinline__ uint64_t key_at(uint32_t i, bool) const { return vsv_key_stage(rows[i].sig, 4, pb, tid_lo); }
+// (tid, pos) key of a call row: the final order of pair_sig's output (H:594). The hp1 rows' calls were written by the pairing
+// kernels; an hp2 row's call is derived here from the merged table and the pairing state — unpaired -> a 0/1 call of its own
+// (H:588-592), paired -> dead — so the pass that used to write those rows and all keys (pair_finish) is not launched.
+struct CallKey {
+  const vsv_call* rows; int pb, tid_lo; const vsv_sig* m; const int32_t* st2;
+  __device__ __forceinline__ uint64_t key_at(uint32_t i, bool) const {
+    if (m) {
+      const vsv_sig me = m[i];
+      if (me.meta & VSV_M_HP2) return st2[i] == -1 ? vsv_key_stage(me, 4, pb, tid_lo) : VSV_KEY_DEAD;
+    }
+    return vsv_key_stage(rows[i].sig, 4, pb, tid_lo);
+  }
   __device__ __forceinline__ uint32_t val_at(uint32_t i) const { return i; }
 };
 
@@ -384,9 +393,23 @@ __device__ __forceinline__ uint64_t match_digit_rt(uint32_t d, bool valid, int b
 // are the result (plus their keys): rows_out[i] = rows_in[value_i] for the alive rows, *d_alive = their count, *n_long = 0 and,
 // if given, fill[0, n) = -1 (the state array of the stage that follows) — the gather launch that used to follow a sort.
 template <typename ROW>
-struct RowIO { const ROW* in; ROW* out; uint32_t* d_alive; uint32_t* n_long; int32_t* fill; };
+struct RowIO {
+  const ROW* in; ROW* out; uint32_t* d_alive; uint32_t* n_long; int32_t* fill;
+  __device__ __forceinline__ ROW fetch(uint32_t v) const { return in[v]; }
+};
 template <>
 struct RowIO<void> {};
+template <>
+struct RowIO<vsv_call> {                     // m != nullptr: the calls of hp2 rows are built on the fly (CallKey)
+  const vsv_call* in; vsv_call* out; uint32_t* d_alive; uint32_t* n_long; int32_t* fill; const vsv_sig* m;
+  __device__ __forceinline__ vsv_call fetch(uint32_t v) const {
+    if (m) {
+      const vsv_sig me = m[v];
+      if (me.meta & VSV_M_HP2) { vsv_call c; c.sig = me; c.a = -1; c.b = (int32_t)v; c.gt = 1; c.pad = 0; return c; }   // (alive rows only: unpaired)
+    }
+    return in[v];
+  }
+};
 template <typename ROW>
 __global__ __launch_bounds__(BK_THREADS) void bk_lds_sort(const uint64_t* __restrict__ key, const uint32_t* __restrict__ val,
                                                            const uint32_t* __restrict__ base, const uint32_t* __restrict__ totals, int nbuckets,
@@ -470,7 +493,7 @@ __global__ __launch_bounds__(BK_THREADS) void bk_lds_sort(const uint64_t* __rest
       const uint32_t i = (uint32_t)t + (uint32_t)j * BK_THREADS;
       if (i < m) {
         key_out[lo + i] = kr[j];
-        if constexpr (ROWS) io.out[lo + i] = io.in[vr[j]]; else val_out[lo + i] = vr[j];
+        if constexpr (ROWS) io.out[lo + i] = io.fetch(vr[j]); else val_out[lo + i] = vr[j];
       }
     }
     return;
@@ -527,7 +550,7 @@ __global__ __launch_bounds__(BK_THREADS) void bk_lds_sort(const uint64_t* __rest
   }
   for (uint32_t i = t; i < m; i += BK_THREADS) {
     key_out[lo + i] = kmin + sk[src][i];
-    if constexpr (ROWS) io.out[lo + i] = io.in[sv[src][i]]; else val_out[lo + i] = sv[src][i];
+    if constexpr (ROWS) io.out[lo + i] = io.fetch(sv[src][i]); else val_out[lo + i] = sv[src][i];
   }
 }
 
@@ -640,11 +663,12 @@ const uint64_t* vsv_bucket_sort_sigs(hipStream_t st, const vsv_sig* in, const ui
   return key_out;
 }
 const uint64_t* vsv_bucket_sort_calls(hipStream_t st, const vsv_call* in, const uint32_t* d_n, int pb, int tid_lo, int nbits, uint64_t kmax,
-                                      vsv_call* sorted, uint64_t* key_out, uint32_t* d_alive, uint32_t* n_long, const SortWork& w, int64_t max_n) {
+                                      vsv_call* sorted, uint64_t* key_out, uint32_t* d_alive, uint32_t* n_long, const SortWork& w, int64_t max_n,
+                                      const vsv_sig* merged, const int32_t* st2) {
   const int b = bucket_bits_for(w, nbits, kmax);
   if (!b) return nullptr;
-  bucket_sort_any<CallKey, vsv_call>(st, b, CallKey{in, pb, tid_lo}, key_out, nullptr, w.key_alt, w.val_alt, d_n, max_n, kmax, w,
-                                     RowIO<vsv_call>{in, sorted, d_alive, n_long, nullptr});
+  bucket_sort_any<CallKey, vsv_call>(st, b, CallKey{in, pb, tid_lo, merged, st2}, key_out, nullptr, w.key_alt, w.val_alt, d_n, max_n, kmax, w,
+                                     RowIO<vsv_call>{in, sorted, d_alive, n_long, nullptr, merged});
   return key_out;
 }
 

@@ -1057,8 +1057,9 @@ void vsv_launch_pair(hipStream_t st, const vsv_sig* merged, const uint64_t* merg
   } else {
     pair_kernel<<<b.grid, 256, 0, st>>>(merged, merged_key, d_alive3, pair_shift, right, pb, b.cl, calls_tmp, &ctr->max_stretch);
   }
+  // bucket sort: the hp2 rows' calls and every key are derived inside the sort's kernels (CallKey / RowIO<vsv_call>::fetch)
+  if (vsv_bucket_sort_calls(st, calls_tmp, d_alive3, pb, b.tid_lo, nbits, b.kmax, calls, key2, d_ncalls, &ctr->n_long, sw, cap, merged, b.cl)) return;
   pair_finish<<<b.grid, 256, 0, st>>>(merged, d_alive3, b.cl, calls_tmp, pb, b.tid_lo, key2, idx2);
-  if (vsv_bucket_sort_calls(st, calls_tmp, d_alive3, pb, b.tid_lo, nbits, b.kmax, calls, key2, d_ncalls, &ctr->n_long, sw, cap)) return;
   const SortResult r = vsv_radix_sort_pairs(st, key2, idx2, sw.key_alt, sw.val_alt, d_alive3, cap, nbits, sw, b.kmax);
   gather_rows<vsv_call><<<b.grid, 256, 0, st>>>(calls_tmp, r.val, r.key, d_alive3, calls, d_ncalls, &ctr->n_long, nullptr);
 }

@@ -135,7 +135,8 @@ const uint64_t* vsv_bucket_sort_sigs(hipStream_t st, const vsv_sig* in, const ui
                                      uint64_t kmax, vsv_sig* sorted, uint64_t* key_out, uint32_t* d_alive, uint32_t* n_long, int32_t* fill,
                                      const SortWork& w, int64_t max_n);
 const uint64_t* vsv_bucket_sort_calls(hipStream_t st, const vsv_call* in, const uint32_t* d_n, int pb, int tid_lo, int nbits, uint64_t kmax,
-                                      vsv_call* sorted, uint64_t* key_out, uint32_t* d_alive, uint32_t* n_long, const SortWork& w, int64_t max_n);
+                                      vsv_call* sorted, uint64_t* key_out, uint32_t* d_alive, uint32_t* n_long, const SortWork& w, int64_t max_n,
+                                      const vsv_sig* merged = nullptr, const int32_t* st2 = nullptr);
 
 // cigar_scan.hip
 void vsv_launch_stream_read(hipStream_t st, const void* src, size_t bytes, uint32_t* sink);
