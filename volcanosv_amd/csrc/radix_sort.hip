@@ -93,6 +93,24 @@ struct CallKey {
   __device__ __forceinline__ uint32_t val_at(uint32_t i) const { return i; }
 };
 
+// key of a split-pair slot, straight from the candidates sorted by (tid, hap, name): candidate j followed by another one of the same
+// name heads a pair slot keyed (tid, hap, record of the name's first candidate); every other slot is dead (H:421-457). What the
+// separate split_mark_pairs pass computed in front of the sort.
+struct PairKey {
+  const uint64_t* ckey; const uint32_t* crec; int qid_bits, rec_bits; const uint32_t* d_n;
+  __device__ __forceinline__ uint64_t key_at(uint32_t j, bool) const {
+    const uint32_t n = *d_n;
+    const uint64_t k = ckey[j];
+    if (j + 1 < n && ckey[j + 1] == k) {
+      uint32_t g = j;
+      while (g > 0 && ckey[g - 1] == k) --g;
+      return ((k >> qid_bits) << rec_bits) | crec[g];
+    }
+    return VSV_KEY_DEAD;
+  }
+  __device__ __forceinline__ uint32_t val_at(uint32_t j) const { return j; }
+};
+
 template <int BITS, int ROUNDS, typename DIGIT, typename SRC>
 __global__ __launch_bounds__(256) void rs_hist(SRC src, const uint32_t* __restrict__ d_n, DIGIT dg,
                                                uint32_t* __restrict__ hist, uint32_t* __restrict__ totals, uint32_t* __restrict__ groups = nullptr) {
@@ -670,6 +688,16 @@ const uint64_t* vsv_bucket_sort_calls(hipStream_t st, const vsv_call* in, const 
   bucket_sort_any<CallKey, vsv_call>(st, b, CallKey{in, pb, tid_lo, merged, st2}, key_out, nullptr, w.key_alt, w.val_alt, d_n, max_n, kmax, w,
                                      RowIO<vsv_call>{in, sorted, d_alive, n_long, nullptr, merged});
   return key_out;
+}
+
+// pair slots sorted by (tid, hap, record) without materialising their keys first; {nullptr, nullptr} = not applicable (the caller runs
+// split_mark_pairs + vsv_radix_sort_pairs)
+SortResult vsv_bucket_sort_pair_slots(hipStream_t st, const uint64_t* ckey, const uint32_t* crec, int qid_bits, int rec_bits, const uint32_t* d_n,
+                                      uint64_t* okey, uint32_t* oval, uint64_t* key_scratch, uint32_t* val_scratch, int64_t max_n, int nbits, const SortWork& w) {
+  uint64_t kmax = 0;
+  const int b = bucket_bits_for(w, nbits, kmax);
+  if (!b) return SortResult{nullptr, nullptr};
+  return bucket_sort_any<PairKey, void>(st, b, PairKey{ckey, crec, qid_bits, rec_bits, d_n}, okey, oval, key_scratch, val_scratch, d_n, max_n, kmax, w, RowIO<void>{});
 }
 
 int64_t vsv_radix_hist_entries(int64_t max_n) { return 2048 * ((max_n + rs_tile<RS_ROUNDS_SMALL>() - 1) / rs_tile<RS_ROUNDS_SMALL>()); }

@@ -1004,8 +1004,12 @@ SplitSorted vsv_launch_split_candidates(hipStream_t st, const RecView& rv, const
   // the first result may live in the shared scratch pair, so the second sort gets a scratch pair of its own
   const SortResult r1 = vsv_radix_sort_pairs(st, ckey, crec, sw.key_alt, sw.val_alt, &ctr->n_cand, cap, c.tid_shift + c.tid_bits, sw,
                                              1ull << (c.tid_shift + c.tid_bits));     // no dead keys in this table: the whole range is alive
-  split_mark_pairs<<<grid, 256, 0, st>>>(r1.key, r1.val, c, rec_bits, okey, oval, ctr);
-  const SortResult r2 = vsv_radix_sort_pairs(st, okey, oval, key2, idx2, &ctr->n_cand, cap, rec_bits + 1 + c.tid_bits + 1, sw);
+  // pair slots by record: the bucket sort takes their keys straight from the sorted candidates; the LSD passes want them written out
+  SortResult r2 = vsv_bucket_sort_pair_slots(st, r1.key, r1.val, c.qid_bits, rec_bits, &ctr->n_cand, okey, oval, key2, idx2, cap, rec_bits + 1 + c.tid_bits + 1, sw);
+  if (!r2.key) {
+    split_mark_pairs<<<grid, 256, 0, st>>>(r1.key, r1.val, c, rec_bits, okey, oval, ctr);
+    r2 = vsv_radix_sort_pairs(st, okey, oval, key2, idx2, &ctr->n_cand, cap, rec_bits + 1 + c.tid_bits + 1, sw);
+  }
   out.ckey = r1.key; out.crec = r1.val; out.okey = r2.key; out.oval = r2.val;
   return out;
 }

@@ -129,6 +129,8 @@ struct SortResult { uint64_t* key; uint32_t* val; };
 SortResult vsv_radix_sort_pairs(hipStream_t st, uint64_t* key, uint32_t* val, uint64_t* key_scratch, uint32_t* val_scratch,
                                 const uint32_t* d_n, int64_t max_n, int nbits, const SortWork& w, uint64_t kmax = 0);
 int64_t vsv_radix_hist_entries(int64_t max_n);
+SortResult vsv_bucket_sort_pair_slots(hipStream_t st, const uint64_t* ckey, const uint32_t* crec, int qid_bits, int rec_bits, const uint32_t* d_n,
+                                      uint64_t* okey, uint32_t* oval, uint64_t* key_scratch, uint32_t* val_scratch, int64_t max_n, int nbits, const SortWork& w);
 // rows sorted by their stage key in 4 launches (bucket sort with the keys taken from the rows and the rows gathered by the LDS sort);
 // nullptr = not applicable, use build-keys + vsv_radix_sort_pairs + gather
 const uint64_t* vsv_bucket_sort_sigs(hipStream_t st, const vsv_sig* in, const uint32_t* d_n, int stage, int pb, int tid_lo, int tid_bits, int nbits,
