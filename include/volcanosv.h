@@ -108,7 +108,8 @@ typedef struct vsv_params {
 enum {
   VSV_OVERLAP_AUTO = 0, /* on a second stream of the handle, next to the CIGAR scan: shortest latency of one handle             */
   VSV_OVERLAP_OFF = 1   /* on the handle's stream: callers that keep three or more handles busy on one GPU (the engines'
-                           kernels overlap each other already; the extra stream only adds events)                              */
+                           kernels overlap each other already; the extra stream only adds events). The sorts then also run
+                           in workgroups of one wave per SIMD, which find room beside another handle's scan                     */
 };
 enum {
   VSV_SCAN_AUTO = 0,    /* by the mean CIGAR length of the call's records                                             */

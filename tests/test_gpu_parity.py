@@ -38,16 +38,20 @@ def assert_tables_equal(got, want, names):
 
 def run_both(eng, soa, dtype, params=None):
     """HIP path vs oracle, once per work mapping of the CIGAR scan (vsv_params.scan_layout: record-aligned parts for reads,
-    fixed-size parts with carried offsets for contigs): whatever the records look like, both are exact."""
-    from volcanosv_amd.abi import SCAN_CONTIGS, SCAN_READS
+    fixed-size parts with carried offsets for contigs): whatever the records look like, both are exact. The second run also takes the
+    other execution mode of the stages behind the scan (vsv_params.split_overlap = OFF: split candidates on the handle's stream,
+    sorts in 256-thread workgroups)."""
+    from volcanosv_amd.abi import OVERLAP_OFF, SCAN_CONTIGS, SCAN_READS
     from volcanosv_amd.engine import default_params
     p = params if params is not None else default_params(dtype)
     st, want = oracle_run(soa, dtype, p)
     assert st == 0
-    keep = p.scan_layout
+    keep, keep_ov = p.scan_layout, p.split_overlap
     try:
         for layout in (SCAN_CONTIGS, SCAN_READS):
             p.scan_layout = layout
+            if layout == SCAN_READS:
+                p.split_overlap = OVERLAP_OFF
             eng.run(soa, p)
             got = eng.tables(dtype)
             try:
@@ -55,7 +59,7 @@ def run_both(eng, soa, dtype, params=None):
             except AssertionError as e:
                 raise AssertionError("scan_layout %d: %s" % (layout, e))
     finally:
-        p.scan_layout = keep
+        p.scan_layout, p.split_overlap = keep, keep_ov
     return got
 
 

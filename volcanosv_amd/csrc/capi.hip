@@ -236,6 +236,7 @@ SortWork sort_work(vsv_handle* h) {
   w.bucket_bits = (h->lsd_runs > 0 || rows == 0 || (mode && mode[0] == 'l') || (rows >> 11) > 640) ? 0 : bb;
   h->sort_hint_rows = rows;
   w.hint_rows = rows;
+  w.shared_gpu = h->prm.split_overlap == VSV_OVERLAP_OFF;
   w.groups = h->groups; w.group_cursor = &h->group_cursor; w.max_group_slots = MAX_GROUP_SLOTS;
   w.err = h->ctr.p ? &((Counters*)h->ctr.p)->err : nullptr;
   return w;

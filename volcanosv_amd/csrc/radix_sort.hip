@@ -395,10 +395,12 @@ void one_pass(hipStream_t st, int64_t max_n, const uint64_t* kin, const uint32_t
 // wave ballots as in rs_scatter. 4 launches instead of 9-12. A range that does not fit (more than BK_CAP rows, or keys more than
 // 2^32 apart) raises ERRB_SORT_FALLBACK: the caller runs the table again through the LSD passes (same result, the usual speed).
 constexpr int BK_CAP = 4096;        // rows a workgroup sorts in LDS
-constexpr int BK_THREADS = 512;
-constexpr int BK_WAVES = BK_THREADS / 64;
-constexpr int BK_PER = BK_CAP / BK_THREADS;   // rows a thread holds while the bucket is loaded
-constexpr int BK_DBITS = 9;         // widest digit of the in-LDS passes
+// Workgroup of the LDS sort: 512 threads (two waves per SIMD, 9-bit digits) when the handle has the GPU to itself; 256 threads
+// (one wave per SIMD like the CIGAR scan's workgroups, 8-bit digits, no register-resident copy of the bucket) when several
+// handles share it (vsv_params.split_overlap = VSV_OVERLAP_OFF): a workgroup of 8 waves x 64 VGPRs finds no room on a CU whose
+// SIMDs another engine's scan keeps refilling one wave at a time and waits for that scan's tail (86 us instead of 12 for the
+// candidate sort). Same box, config 2: one engine 0.61-0.65 ms per step with 512 threads against 0.66-0.68 with 256; three
+// engines 0.46-0.47 against 0.45.
 __device__ __forceinline__ uint64_t match_digit_rt(uint32_t d, bool valid, int bits) {
   uint64_t m = __ballot(valid);
   for (int b = 0; b < bits; ++b) {
@@ -428,13 +430,15 @@ struct RowIO<vsv_call> {                     // m != nullptr: the calls of hp2 r
     return in[v];
   }
 };
-template <typename ROW>
+template <typename ROW, int BK_THREADS>
 __global__ __launch_bounds__(BK_THREADS) void bk_lds_sort(const uint64_t* __restrict__ key, const uint32_t* __restrict__ val,
                                                            const uint32_t* __restrict__ base, const uint32_t* __restrict__ totals, int nbuckets,
                                                            const uint32_t* __restrict__ d_n,
                                                            uint64_t* __restrict__ key_out, uint32_t* __restrict__ val_out, uint32_t* __restrict__ err, uint32_t cap,
                                                            uint32_t max_tile_rows, RowIO<ROW> io) {
   constexpr bool ROWS = !std::is_same<ROW, void>::value;
+  constexpr int BK_WAVES = BK_THREADS / 64, BK_DBITS = BK_THREADS >= 512 ? 9 : 8, BK_PER = BK_THREADS >= 512 ? BK_CAP / BK_THREADS : 1;
+  constexpr bool IN_REGS = BK_THREADS >= 512;     // the bucket waits in registers between the min / max reduction and the LDS fill
   __shared__ uint32_t sk[2][BK_CAP], sv[2][BK_CAP];
   __shared__ uint32_t wcnt[BK_WAVES][1 << BK_DBITS];
   __shared__ uint32_t tot[BK_WAVES];
@@ -485,15 +489,19 @@ __global__ __launch_bounds__(BK_THREADS) void bk_lds_sort(const uint64_t* __rest
   uint64_t kr[BK_PER];
   uint32_t vr[BK_PER];
   uint64_t kmin = ~0ull, kmax = 0;
+  if constexpr (IN_REGS) {
 #pragma unroll
-  for (int j = 0; j < BK_PER; ++j) {
-    const uint32_t i = (uint32_t)t + (uint32_t)j * BK_THREADS;
-    kr[j] = i < m ? key[lo + i] : 0ull;
-    vr[j] = i < m ? val[lo + i] : 0u;
-  }
+    for (int j = 0; j < BK_PER; ++j) {
+      const uint32_t i = (uint32_t)t + (uint32_t)j * BK_THREADS;
+      kr[j] = i < m ? key[lo + i] : 0ull;
+      vr[j] = i < m ? val[lo + i] : 0u;
+    }
 #pragma unroll
-  for (int j = 0; j < BK_PER; ++j) {
-    if ((uint32_t)t + (uint32_t)j * BK_THREADS < m) { kmin = kr[j] < kmin ? kr[j] : kmin; kmax = kr[j] > kmax ? kr[j] : kmax; }
+    for (int j = 0; j < BK_PER; ++j) {
+      if ((uint32_t)t + (uint32_t)j * BK_THREADS < m) { kmin = kr[j] < kmin ? kr[j] : kmin; kmax = kr[j] > kmax ? kr[j] : kmax; }
+    }
+  } else {
+    for (uint32_t i = (uint32_t)t; i < m; i += BK_THREADS) { const uint64_t k = key[lo + i]; kmin = k < kmin ? k : kmin; kmax = k > kmax ? k : kmax; }
   }
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) {
@@ -506,18 +514,18 @@ __global__ __launch_bounds__(BK_THREADS) void bk_lds_sort(const uint64_t* __rest
   const uint64_t width = kmax - kmin;
   if (width > 0xFFFFFFFFull) { if (t == 0) atomicOr(err, ERRB_SORT_FALLBACK); return; }
   if (m == 1 || width == 0) {                            // one row, or all keys equal: already in order
-#pragma unroll
-    for (int j = 0; j < BK_PER; ++j) {
-      const uint32_t i = (uint32_t)t + (uint32_t)j * BK_THREADS;
-      if (i < m) {
-        key_out[lo + i] = kr[j];
-        if constexpr (ROWS) io.out[lo + i] = io.fetch(vr[j]); else val_out[lo + i] = vr[j];
-      }
+    for (uint32_t i = (uint32_t)t; i < m; i += BK_THREADS) {
+      key_out[lo + i] = key[lo + i];
+      if constexpr (ROWS) io.out[lo + i] = io.fetch(val[lo + i]); else val_out[lo + i] = val[lo + i];
     }
     return;
   }
+  if constexpr (IN_REGS) {
 #pragma unroll
-  for (int j = 0; j < BK_PER; ++j) { const uint32_t i = (uint32_t)t + (uint32_t)j * BK_THREADS; if (i < m) { sk[0][i] = (uint32_t)(kr[j] - kmin); sv[0][i] = vr[j]; } }
+    for (int j = 0; j < BK_PER; ++j) { const uint32_t i = (uint32_t)t + (uint32_t)j * BK_THREADS; if (i < m) { sk[0][i] = (uint32_t)(kr[j] - kmin); sv[0][i] = vr[j]; } }
+  } else {
+    for (uint32_t i = (uint32_t)t; i < m; i += BK_THREADS) { sk[0][i] = (uint32_t)(key[lo + i] - kmin); sv[0][i] = val[lo + i]; }
+  }
   int src = 0;
   // stable LSD passes over the bits that differ inside the bucket, digits as equal as possible and at most BK_DBITS wide
   const int wbits = 64 - __builtin_clzll(width);
@@ -603,7 +611,8 @@ SortResult bucket_sort(hipStream_t st, SRC src, uint64_t* key, uint32_t* val, ui
   // bucket bases = the scanned histogram row of tile 0 (offset of the first tile's rows of every bucket), or the totals in front
   static const int cap_env = getenv("VSV_BK_CAP") ? atoi(getenv("VSV_BK_CAP")) : BK_CAP;      // tests force the fallback with a tiny capacity
   const uint32_t cap = (uint32_t)(cap_env < 2 ? 2 : cap_env > BK_CAP ? BK_CAP : cap_env);
-  bk_lds_sort<ROW><<<1 << BITS, BK_THREADS, 0, st>>>(key_scratch, val_scratch, w.hist, self ? totals : nullptr, 1 << BITS, d_n, key, val, w.err, cap, rs_tile<ROUNDS>(), io);
+  if (w.shared_gpu) bk_lds_sort<ROW, 256><<<1 << BITS, 256, 0, st>>>(key_scratch, val_scratch, w.hist, self ? totals : nullptr, 1 << BITS, d_n, key, val, w.err, cap, rs_tile<ROUNDS>(), io);
+  else bk_lds_sort<ROW, 512><<<1 << BITS, 512, 0, st>>>(key_scratch, val_scratch, w.hist, self ? totals : nullptr, 1 << BITS, d_n, key, val, w.err, cap, rs_tile<ROUNDS>(), io);
   return SortResult{key, val};
 }
 

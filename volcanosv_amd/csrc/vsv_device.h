@@ -107,6 +107,7 @@ struct SortWork {       // scratch for vsv_radix_sort_pairs
   bool small_tiles;     // 1024-row instead of 4096-row tiles; chosen by the caller from the row count of the previous run (both exact)
   int bucket_bits;      // 8..11: bucket sort (one counting pass + LDS sort per bucket) with 2^bits buckets; 0: LSD passes only
   uint32_t* err;        // device error word (ERRB_SORT_FALLBACK)
+  bool shared_gpu;      // several handles keep the GPU busy (vsv_params.split_overlap = OFF): LDS sort in 256-thread workgroups
   uint64_t hint_rows;   // rows of the largest table of the handle's previous run (0 = unknown): speed decisions only
   // bucket sorts without a scan launch: zeroed slots of [VSV_RS_MAX_GROUPS][2048] sums over groups of tiles, one per sort
   uint32_t* groups;
