@@ -431,7 +431,7 @@ def test_device_reader_on_the_reference_held_bam_fixtures():
 
 
 @pytest.mark.gpu
-def test_sequences_kept_on_the_device_and_sliced_there(tmp_path):
+def test_sequences_kept_on_the_device_and_sliced_there(tmp_path, monkeypatch):
     """fetch_device(seq=True): the packed SEQ fields stay on the GPU and DeviceRecordView.seq_slices decodes Python-style slices of
     them (negative and overlong bounds, the reversed read of sig_extract's split INS, SE:215): equal to the slices of the host
     reader's query sequences, for whole files and for one chromosome of a file, odd and even lengths, reads without SEQ."""
@@ -451,9 +451,12 @@ def test_sequences_kept_on_the_device_and_sliced_there(tmp_path):
     path = str(tmp_path / "seq.bam")
     bam.write_bam(path, refs, recs)
     with Engine(0) as eng, bam.BamFile(path) as bf:
-        for chrom in (None, "chr2"):
+        for chrom, window in ((None, None), ("chr2", None), (None, 40), ("chr2", 17)):      # one reader window, and many small ones
+            if window:
+                monkeypatch.setenv("VSV_BAM_WINDOW", str(window))
             host = bf.fetch_soa(chrom, keep_seq=True)
             view = bf.fetch_device(eng, chrom, seq=True)
+            monkeypatch.delenv("VSV_BAM_WINDOW", raising=False)
             assert isinstance(view, bam.DeviceRecordView) and view.n_records == host.n_records
             reqs, want = [], []
             for _ in range(3000):
