@@ -6,8 +6,11 @@ Headline (BASELINE.json config 2, the configuration the metric is quoted on): on
 shard of 10 M HiFi-like records of one chromosome. Steps are independent batches, so a rank keeps `--streams` engines (one
 vsv_handle + HIP stream each, default 3) in flight round-robin: the latency-bound signature stages of one batch overlap the
 bandwidth-bound scan of the next, exactly as a rank that owns several chromosomes runs them (volcanosv_amd/contig_signature.py).
-With N GPUs every rank owns one such chromosome shard (weak scaling, no data-path collective); the per-rank call tables are
-gathered to rank 0 once, inside the timed region. The timed region of `--steps` steps is repeated `--reps` times (each
+With N GPUs every rank owns one such chromosome shard (weak scaling, no data-path collective); EVERY step's call table is copied out of
+its engine and collected on rank 0 (counts all-gather + exact-size send/recv to rank 0 only, shard.gather_bytes_start) inside the
+timed region, the transfer running under the next steps' compute. `python bench.py --gpus N` without a torchrun environment starts
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child process (before anything touches the GPU) and relays
+its line. The timed region of `--steps` steps is repeated `--reps` times (each
 bracketed by barrier + synchronize, MAX over ranks) and the MEDIAN repetition is the headline; min / max are reported.
 
 The same JSON line carries, under "configs", the other workloads of SURVEY.md §8d measured in the same run:
@@ -131,6 +134,31 @@ def cpu_baseline(t, nq, dtype, n_sample, reps, procs):
     return out
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` outside a torchrun environment: N ranks (one per GPU) through torch.distributed.run, started as a
+    CHILD process before this process has imported torch or touched the GPU (never an exec). Rank 0's JSON line is relayed on
+    stdout, everything else on stderr; the exit code is the child's."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    for ln in r.stdout.splitlines():
+        if not ln.startswith('{"metric"'):
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1])
+    sys.stdout.flush()
+    sys.exit(r.returncode if r.returncode else (0 if lines else 1))
+
+
 class Bench:
     def __init__(self, args):
         import torch
@@ -140,7 +168,7 @@ class Bench:
         self.rank = int(os.environ.get("RANK", "0"))
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         if args.gpus != self.world and self.rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE is %d (launch with torch.distributed.run); measuring %d rank(s)" % (args.gpus, self.world, self.world),
+            print("bench.py: --gpus %d but WORLD_SIZE is %d; measuring %d rank(s) and reporting n_gpus = %d" % (args.gpus, self.world, self.world, self.world),
                   file=sys.stderr)
         if not torch.cuda.is_available():
             sys.exit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
@@ -156,6 +184,7 @@ class Bench:
                 dist.init_process_group("gloo")
             else:
                 dist.init_process_group("nccl", device_id=self.dev)
+        self.n_ranks_seen = dist.get_world_size() if self.world > 1 else 1        # what the process group says, not what was asked for
         from volcanosv_amd.engine import Engine
         n_streams = max(1, args.streams)
         self.streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=self.dev) for _ in range(n_streams - 1)]
@@ -187,44 +216,51 @@ class Bench:
             dt = float(tmax.item())
         return dt, out
 
-    def run_steps(self, jobs, k, scan_ms, engs=None):
+    def run_steps(self, jobs, k, scan_ms, engs=None, table=None):
         """k steps; step i runs jobs[i % len(jobs)] = (records, params) on engine i % n. A step's counters (status + table sizes)
-        are read back, once, before its engine is reused. Returns the engine of the last step."""
+        are read back, once, before its engine is reused. With `table` every finished step pays for its collect: the step's table
+        is copied out of the engine (the engine's buffers are overwritten by its next run) and its gather to rank 0 is started
+        (asynchronous: the transfer runs under the next steps); at most n gathers are in flight, all are complete on return.
+        Returns (engine of the last step, what the last step gathered)."""
         engs = engs or self.engs
         n = len(engs)
+        pend, last = [], None
+
+        def done(e):
+            nonlocal last
+            e.finish()
+            scan_ms.append(e.scan_ms())
+            if table is not None:
+                pend.append(self.gather_start(e, table))
+                if len(pend) > n:
+                    last = pend.pop(0).wait()
         for i in range(k):
             e = engs[i % n]
             if i >= n:
-                e.finish()
-                scan_ms.append(e.scan_ms())
+                done(e)
             recs, p = jobs[i % len(jobs)]
             e.run_async(recs, p)
         for i in range(max(0, k - n), k):
-            e = engs[i % n]
-            e.finish()
-            scan_ms.append(e.scan_ms())
-        return engs[(k - 1) % n]
+            done(engs[i % n])
+        for h in pend:
+            last = h.wait()
+        return engs[(k - 1) % n], last
 
-    def gather(self, eng, table):
-        """Final gather of the per-rank tables to rank 0 (device-to-device copy out of the library, RCCL all-gather over xGMI);
-        the host copy happens after the timed region."""
+    def gather_start(self, eng, table):
+        """One step's collect: the table leaves the engine (device-to-device copy by the library) and its gather to rank 0 starts
+        (shard.gather_bytes_start: counts all-gather + exact-size RCCL send/recv to rank 0 only, over xGMI). Returns the handle;
+        `.wait()` gives (per-rank uint8 tensors, byte counts) on rank 0. The host copy happens after the timed region."""
         from volcanosv_amd import shard
-        if table == "reads":
-            return eng.table_torch("reads", self.dev)
+        rows = eng.table_torch(table, self.dev)
         if self.rehearsal:
-            return shard.gather_calls(eng.table("calls"), self.cdev)
-        return shard.gather_calls(eng.table_torch("calls", self.dev), self.dev, to_host=False)
+            rows = rows.cpu()                       # gloo rehearsal: collectives on host tensors
+        return shard.gather_bytes_start(rows, self.cdev)
 
     def n_gathered(self, g, table):
-        from volcanosv_amd import shard
         from volcanosv_amd.abi import SIG_DTYPE
-        if g is None:
+        if g is None or g[0] is None:
             return 0
-        if isinstance(g, tuple):
-            return len(shard.finish_gather(g))
-        if self.torch.is_tensor(g):
-            return g.numel() // SIG_DTYPE.itemsize if table == "reads" else g.numel() // 48
-        return len(g)
+        return sum(g[1]) // (SIG_DTYPE.itemsize if table == "reads" else 48)
 
     # ---- one chromosome-shard workload (configs 2, 3, 2c, reads flavour) -----------------------------------------------------
     def shard_workload(self, shape, n_records, dtype_name, config_idx, steps, warmup, reps, keep=False):
@@ -242,15 +278,16 @@ class Bench:
         table = "reads" if dtype_name == "READS" else "calls"
         engs = self.engs[: max(1, min(len(self.engs), steps))]
         p.split_overlap = 1 if len(engs) >= 3 else 0      # VSV_OVERLAP_OFF: three engines in flight fill the GPU by themselves
-        weng = self.run_steps([(recs, p)], max(warmup, len(engs)), [], engs)
-        self.gather(weng, table)            # warm-up of the gather path too (first collective of a shape sets up its channels)
+        self.run_steps([(recs, p)], max(warmup, len(engs)), [], engs, table)     # (warm-up of the gather path too: the first transfer between two ranks sets up its channels)
+        reruns0 = sum(e.rerun_count() for e in engs)
         times, scan_ms, gathered = [], [], None
         for _ in range(max(1, reps)):
-            def region():
-                eng = self.run_steps([(recs, p)], steps, scan_ms, engs)
-                return self.gather(eng, table), eng
-            dt, (gathered, eng) = self.timed(region)
+            dt, (eng, gathered) = self.timed(lambda: self.run_steps([(recs, p)], steps, scan_ms, engs, table))
             times.append(dt)
+        reruns = sum(e.rerun_count() for e in engs) - reruns0
+        # the same steps on ONE engine, one after the other (the latency of a chromosome, no overlap between steps)
+        k1 = max(3, min(steps, 10))
+        dt1, _ = self.timed(lambda: self.run_steps([(recs, p)], k1, [], engs[:1], table))
         n_raw = len(eng.table("raw"))
         alg_bytes = 24 * recs.n_records + 4 * recs.n_ops + 32 * n_raw      # SURVEY.md §8d, per launch
         scan_s = sum(scan_ms) / len(scan_ms) / 1e3
@@ -266,6 +303,8 @@ class Bench:
             "shape": shape, "dtype": dtype_name, "records": recs.n_records, "ops": recs.n_ops, "raw_signatures": n_raw,
             "rows_gathered": self.n_gathered(gathered, table), "steps": steps, "reps": len(times), "streams": len(engs),
             "ms_per_step": med / steps * 1e3, "ms_per_step_min": ts[0] / steps * 1e3, "ms_per_step_max": ts[-1] / steps * 1e3,
+            "single_engine_ms_per_step": dt1 / k1 * 1e3,
+            "reruns": reruns,          # whole-run repetitions inside the timed regions (bucket-sort overflow / fused CLR gate fallbacks, vsv_rerun_count)
             "records_per_s": recs.n_records * self.world * steps / med, "ops_per_s": recs.n_ops * self.world * steps / med,
             "scan": {"kernel": "cigar_scan_long" if recs.n_ops >= 512 * recs.n_records else "cigar_scan_emit", "avg_launch_ms": scan_s * 1e3,
                      "GBs": alg_bytes / scan_s / 1e9, "frac": alg_bytes / scan_s / 1e9 / HBM_PEAK_GBS,
@@ -320,20 +359,26 @@ class Bench:
             return parts
 
         def region(k, scan_ms):
-            last = []
+            """k whole-genome jobs; every job pays for its collect (the reference's parent collects once per job,
+            volcanosv-vc-large-indel.py:271-278): the rank's call tables go to rank 0 as one transfer that runs under the next job."""
+            pend, g = [], None
             for _ in range(k):
-                last = one_pass(scan_ms)
-            rows = torch.cat(last) if last else torch.zeros(0, dtype=torch.uint8, device=self.dev)
-            if self.rehearsal:
-                from volcanosv_amd.abi import CALL_DTYPE
-                return shard.gather_calls(rows.cpu().numpy().view(CALL_DTYPE), self.cdev)
-            return shard.gather_calls(rows, self.dev, to_host=False)
+                parts = one_pass(scan_ms)
+                rows = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.uint8, device=self.dev)
+                pend.append(shard.gather_bytes_start(rows.cpu() if self.rehearsal else rows, self.cdev))
+                if len(pend) > 2:
+                    g = pend.pop(0).wait()
+            for h in pend:
+                g = h.wait()
+            return g
 
         region(max(1, warmup), [])
+        reruns0 = sum(e.rerun_count() for e in engs)
         times, scan_ms, g = [], [], None
         for _ in range(max(1, reps)):
             dt, g = self.timed(lambda: region(steps, scan_ms))
             times.append(dt)
+        reruns = sum(e.rerun_count() for e in engs) - reruns0
         ts = sorted(times)
         med = ts[len(ts) // 2]
         total_records = int(index[:, 1].sum().item())
@@ -354,7 +399,7 @@ class Bench:
             "records_per_s": total_records * steps / med, "chromosomes_per_rank": load, "ideal_speedup": n_chrom / max(load),
             "scan_avg_launch_ms": (sum(scan_ms) / len(scan_ms)) if scan_ms else None,
             "whole_path_frac_of_aggregate_hbm": float(tot.item()) * steps / med / 1e9 / (HBM_PEAK_GBS * self.world),
-            "calls_gathered": self.n_gathered(g, "calls"),
+            "calls_gathered": self.n_gathered(g, "calls"), "reruns": reruns, "n_ranks_seen": self.world,
         }
         del keep, jobs
         torch.cuda.empty_cache()
@@ -431,7 +476,8 @@ class Bench:
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1, help="informational: the world size comes from WORLD_SIZE (torch.distributed.run)")
+    ap.add_argument("--gpus", type=int, default=1, help="ranks (one per GPU). Under torch.distributed.run the world size comes from WORLD_SIZE; "
+                    "without it, --gpus N > 1 starts torch.distributed.run with N ranks as a child process")
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed --steps region; the median is reported")
@@ -453,6 +499,8 @@ def main():
     args = ap.parse_args()
     if args.cpu_worker:
         return cpu_worker(args.paths, args.cpu_reps)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus)
     if args.shape:
         args.config = {"hifi": 2, "ont": 3, "contig": 6}[args.shape]
     shape = {2: "hifi", 3: "ont", 6: "contig"}.get(args.config)
@@ -487,25 +535,28 @@ def main():
             "metric": METRIC, "value": res["records_per_s"], "unit": "records/s", "n_gpus": b.world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "reps": res["reps"], "ms_per_step_min": res["ms_per_step_min"], "ms_per_step_max": res["ms_per_step_max"],
-            "config": {"workload": "%s: %d %s-like records/GPU, 1 chromosome per GPU, dtype %s, %d CIGAR ops, %d raw signatures, %d rows gathered"
+            "n_ranks_seen": b.n_ranks_seen, "single_engine_ms_per_step": res["single_engine_ms_per_step"], "reruns": res["reruns"],
+            "config": {"workload": "%s: %d %s-like records/GPU, 1 chromosome per GPU, dtype %s, %d CIGAR ops, %d raw signatures, %d rows gathered per step"
                                    % (label, recs.n_records, shape, dtype_name, recs.n_ops, res["raw_signatures"], res["rows_gathered"]),
+                       "headline": "batch throughput: %d engines per GPU in flight round-robin over the same device-resident shard (the stages of one step "
+                                   "overlap the scan of the next; nothing is cached between steps); one chromosome's latency = single_engine_ms_per_step; "
+                                   "every step's call table is copied out of its engine and collected on rank 0 inside the timed region" % res["streams"],
                        "records_per_gpu": recs.n_records, "parallelism": "chromosome-sharded x%d" % b.world, "streams_per_gpu": res["streams"],
                        "ops_per_s": res["ops_per_s"], "whole_path_frac_of_hbm_peak": res["whole_path_frac"]},
-            "roofline": {"bound": "hbm", "kernel": res["scan"]["kernel"], "achieved": res["scan"]["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": res["scan"]["frac"], "traffic": traffic, "traffic_source": traffic_source,
-                         "algorithmic_bytes_per_launch": res["algorithmic_bytes_per_step"], "avg_launch_ms": res["scan"]["avg_launch_ms"],
-                         "alone_launch_ms": res["scan"]["alone_launch_ms"], "alone_frac": res["scan"]["alone_frac"],
-                         "note": "achieved / frac / avg_launch_ms: HIP events around the kernel on its launch stream, averaged over the timed region, "
-                                 "where %d engines are in flight and the launch shares the GPU with the other engines' kernels; alone_*: the same launch "
-                                 "on the same input with nothing else in flight (what rocprofv3 --kernel-trace reports too: under the profiler the "
-                                 "engines' kernels overlap far less, see profiles/)" % res["streams"],
+            "roofline": {"bound": "hbm", "kernel": res["scan"]["kernel"], "achieved": res["scan"]["alone_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": res["scan"]["alone_frac"], "traffic": traffic, "traffic_source": traffic_source,
+                         "algorithmic_bytes_per_launch": res["algorithmic_bytes_per_step"], "avg_launch_ms": res["scan"]["alone_launch_ms"],
+                         "overlapped_launch_ms": res["scan"]["avg_launch_ms"], "overlapped_achieved": res["scan"]["GBs"], "overlapped_frac": res["scan"]["frac"],
+                         "note": "achieved / frac / avg_launch_ms: the scan launch by itself (HIP events around the kernel on its launch stream, same input, "
+                                 "nothing else in flight) - what rocprofv3 --kernel-trace reports too, see profiles/; overlapped_*: the same events averaged "
+                                 "over the timed region, where %d engines are in flight and the launch shares the GPU with the other engines' kernels" % res["streams"],
                          # the library's own read-stream / copy kernels over the same CIGAR array, after the timed region
                          "measured_read_stream": ceil_read, "measured_copy_stream": ceil_copy,
-                         "frac_of_measured_read_stream": res["scan"]["GBs"] / ceil_read if ceil_read else None},
+                         "frac_of_measured_read_stream": res["scan"]["alone_GBs"] / ceil_read if ceil_read else None},
         }
     elif args.config == 4:
         res = b.config4(args.records or 20_000_000, args.steps if args.steps != 50 else 10, args.warmup, args.reps)
-        line = {"metric": METRIC, "value": res["records_per_s"], "unit": "records/s", "n_gpus": b.world, "steps": res["steps"], "warmup": args.warmup,
+        line = {"metric": METRIC, "value": res["records_per_s"], "unit": "records/s", "n_gpus": b.world, "n_ranks_seen": b.n_ranks_seen, "steps": res["steps"], "warmup": args.warmup,
                 "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
                 "reps": res["reps"], "ms_per_step_min": res["ms_per_step_min"], "ms_per_step_max": res["ms_per_step_max"],
                 "config": {"workload": res["workload"], "parallelism": "22 chromosomes LPT-sharded x%d" % b.world, "detail": res},
@@ -513,7 +564,7 @@ def main():
                              "avg_launch_ms": res["scan_avg_launch_ms"], "whole_path_frac_of_aggregate_hbm": res["whole_path_frac_of_aggregate_hbm"]}}
     else:
         res = b.config5(args.records or 1_000_000, args.steps if args.steps != 50 else 5, args.warmup, args.reps)
-        line = {"metric": METRIC, "value": res["records_per_s"], "unit": "records/s", "n_gpus": b.world, "steps": res["steps"], "warmup": args.warmup,
+        line = {"metric": METRIC, "value": res["records_per_s"], "unit": "records/s", "n_gpus": b.world, "n_ranks_seen": b.n_ranks_seen, "steps": res["steps"], "warmup": args.warmup,
                 "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "i32", "data": "synthetic",
                 "reps": res["reps"], "ms_per_step_min": res["ms_per_step_min"], "ms_per_step_max": res["ms_per_step_max"],
                 "config": {"workload": res["workload"], "parallelism": "primary-alignment owner x%d + all-to-all" % b.world, "detail": res},

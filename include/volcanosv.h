@@ -206,6 +206,11 @@ int vsv_run_chromosome_async(vsv_handle* h, const vsv_records* recs, const vsv_p
  * buffer of the caller (>= 1 MiB), in GB/s; the copy figure counts bytes read + bytes written. */
 int vsv_stream_ceiling(vsv_handle* h, const void* dev_buf, int64_t bytes, int32_t reps, double* read_gbs, double* copy_gbs);
 int vsv_finish(vsv_handle* h);
+/* Measurement aid: how many times vsv_finish() had to repeat a whole run on this handle so far — a bucket of the bucket sort that
+ * did not fit in LDS (the run is repeated through the LSD radix passes) or a part too long for the gate state of the fused CLR
+ * scan (repeated with the separate gate pass). Results are identical either way; a bench line reports the count so that a hidden
+ * repetition inside a timed region is visible. */
+int64_t vsv_rerun_count(vsv_handle* h);
 
 /* two-phase readback: count, then fill a caller buffer (host or device) */
 int vsv_table_count(vsv_handle* h, int table, int64_t* n_rows);

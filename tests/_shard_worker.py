@@ -56,6 +56,21 @@ def main():
         print("SHARD_OK %d calls from %d ranks, owners %s" % (len(allc), world, owner))
     else:
         assert allc is None
+    # the gather primitive itself: exact-size transfers to rank 0 only, asynchronous handles, empty senders, several in flight
+    mk = lambda r, k: torch.arange(0 if (r + k) % 3 == 0 else 1000 * (r + 1) + k, dtype=torch.int64).to(torch.uint8)
+    pend = [shard.gather_bytes_start(mk(rank, k), dev) for k in range(4)]
+    for k, h in enumerate(pend):
+        bufs, counts = h.wait()
+        assert counts == [int(mk(r, k).numel()) for r in range(world)]
+        if rank == 0:
+            assert all(torch.equal(bufs[r], mk(r, k)) for r in range(world))
+        else:
+            assert bufs is None                       # nobody but rank 0 receives anything
+    rows = shard.gather_rows_device(mk(rank, 1), dev)
+    assert (rows is None) == (rank != 0)
+    if rank == 0:
+        assert torch.equal(rows, torch.cat([mk(r, 1) for r in range(world)]))
+        print("GATHER_OK")
     dist.barrier()
     dist.destroy_process_group()
 

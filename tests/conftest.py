@@ -4,6 +4,8 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the library honours its test hooks (VSV_SORT, VSV_PAIR, VSV_BK_CAP, VSV_BAM_WINDOW, ...) only under VSV_DEBUG=1 (csrc/vsv_env.h)
+os.environ.setdefault("VSV_DEBUG", "1")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

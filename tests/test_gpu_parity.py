@@ -806,6 +806,45 @@ def test_bucket_sort_overflow_falls_back_to_the_lsd_passes():
     assert outs[0] == outs[1] == outs[2]
 
 
+def test_clr_fallback_followed_by_a_bucket_overflow():
+    """Both whole-run fallbacks in one call: a CLR part longer than the fused gate's state (the run is repeated with the separate
+    gate pass) whose repetition then overflows a bucket of the bucket sort (VSV_BK_CAP=2: repeated again through the LSD passes).
+    finish() resolves them one after the other; neither flag may reach the success path with half-written tables."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "from test_gpu_parity import oracle_run, assert_tables_equal\n"
+            "from volcanosv_amd.soa import RecordSoA\n"
+            "from volcanosv_amd.engine import Engine, default_params\n"
+            "from volcanosv_amd.abi import DTYPE_CLR\n"
+            "long_ops = []\n"
+            "for i in range(15000):\n"
+            "    long_ops += [(0, 37), (2 if i %% 50 else 1, 1 if i %% 500 else 60)]\n"
+            "recs = [(0, 100 + 50 * i, 'q%%d_hp%%d' %% (i, 1 + i %% 2), 60, False, [(0, 3000), (1, 45 + i %% 7), (0, 2000)]) for i in range(300)]\n"
+            "recs.insert(150, (0, 5000, 'long_hp1', 60, False, long_ops))\n"
+            "recs.sort(key=lambda r: r[1])\n"
+            "soa = RecordSoA.from_tuples(recs)\n"
+            "p = default_params(DTYPE_CLR)\n"
+            "p.scan_layout = 1\n"                                    # record-aligned parts: the long record is one part of > 96 chunks
+            "st, want = oracle_run(soa, DTYPE_CLR, p)\n"
+            "assert st == 0\n"
+            "with Engine(0) as e:\n"
+            "    e.run(soa, p)\n"
+            "    got = e.tables(DTYPE_CLR)\n"
+            "    assert_tables_equal(got, want, list(got.keys()))\n"
+            "    n = e.rerun_count()\n"
+            "    e.run(soa, p)\n"                                    # the handle keeps the separate gate and the LSD passes: no repetition
+            "    assert_tables_equal(e.tables(DTYPE_CLR), want, list(got.keys()))\n"
+            "    print('FALLBACKS_OK', n, e.rerun_count())\n") % (root, os.path.join(root, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, VSV_DEBUG="1", VSV_BK_CAP="2"), cwd=root)
+    assert r.returncode == 0 and "FALLBACKS_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+    n_first, n_second = [int(x) for x in r.stdout.strip().splitlines()[-1].split()[1:]]
+    assert n_first == 2 and n_second == 2
+
+
 def test_inputs_produced_on_another_stream():
     """include/volcanosv.h: device-resident inputs are read on the handle's stream. A caller whose arrays are still being produced
     on another stream orders the two on the device with vsv_wait_for_stream (Engine.wait_for_stream) instead of a host
@@ -834,6 +873,36 @@ def test_inputs_produced_on_another_stream():
             got = e.tables(DTYPE_HIFI)
             assert_tables_equal(got, want, list(got.keys()))
             del t
+
+
+def test_bnd_device_rows_produced_on_torchs_stream_for_an_engine_with_its_own():
+    """Engine.bnd_pair_device copies candidate rows on the HANDLE's stream; in the multi-GPU exchange they have just been produced
+    on torch's current stream (index, sort, all-to-all). An engine on a stream of its own (bench engs[1..]) must order the two on
+    the device: rows that arrive behind a long-running kernel on torch's stream, no host synchronisation in between."""
+    import torch
+    from oracle import oracle
+    from volcanosv_amd import synth
+    from volcanosv_amd.abi import BND_DTYPE
+    from volcanosv_amd.engine import Engine
+    dev = torch.device("cuda", 0)
+    seg, _ = synth.generate_bnd(4000, seed=78)
+    cand, _ = oracle.run_bnd(seg)
+    hap2 = (cand["meta"] & 4) != 0
+    rows = cand[np.lexsort((np.arange(len(cand)), cand["read"], hap2))]       # collection order
+    want = oracle.run_bnd_pair(rows, seg.contig_rank)
+    pinned = torch.from_numpy(np.frombuffer(rows.tobytes(), dtype=np.uint8).copy()).pin_memory()
+    rank_t = torch.from_numpy(np.ascontiguousarray(seg.contig_rank)).to(dev)
+    torch.cuda.synchronize()
+    own = torch.cuda.Stream(device=dev)
+    with Engine(0, stream=own.cuda_stream) as e:
+        for _ in range(3):
+            busy = torch.randn(8192, 8192, device=dev)
+            for _k in range(6):
+                busy = busy @ busy * 1e-4                                        # torch's current stream stays busy for a while
+            rows_t = pinned.to(dev, non_blocking=True)                           # ... and the rows arrive behind it
+            got = e.bnd_pair_device(rows_t, rank_t, dev)
+            assert np.array_equal(np.frombuffer(got.cpu().numpy().tobytes(), dtype=BND_DTYPE), want)
+            del rows_t
 
 
 def test_pairing_in_rounds_equals_the_sequential_walk():
@@ -872,3 +941,141 @@ def test_pairing_in_rounds_equals_the_sequential_walk():
         assert r.returncode == 0 and "PAIR_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
         outs.append(r.stdout.strip().splitlines()[-1])
     assert outs[0] == outs[1] and int(outs[0].split()[1]) > 50000
+
+
+def test_full_size_config4_call_tables():
+    """BASELINE.json config 4 at N = 1 and FULL size: 22 chromosomes (hg19 lengths) x 20 M HiFi-like records, generated with
+    bench.py's seeds and run exactly as bench.py config4 runs them (three engines taking turns, tid_lo / n_tids / max_pos key hints,
+    split_overlap off) — every chromosome's call table and raw table equal the CPU oracle's on all 20 M records (the oracle runs of
+    several chromosomes overlap on the host cores, ctypes releases the GIL)."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from volcanosv_amd import shard, synth
+    from volcanosv_amd.engine import DeviceRecords, Engine, default_params
+    dev = torch.device("cuda", 0)
+    n_chrom, n_per = 22, 20_000_000
+    owner = shard.lpt_assign([n_per] * n_chrom, 1)
+    assert set(owner) == {0}
+    p = default_params(DTYPE_HIFI)
+    p.split_overlap = 1
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(2)]
+    engs = [Engine(0, stream=s.cuda_stream, max_sigs=1 << 22) for s in streams]
+    pool = ThreadPoolExecutor(max_workers=8)
+    pending, total_calls = [], 0
+
+    def check(c, got, fut):
+        st, want = fut.result()
+        assert st == 0, c
+        try:
+            assert_tables_equal(got, want, ["raw", "calls"])
+        except AssertionError as e:
+            raise AssertionError("chromosome %d: %s" % (c, e))
+        return len(want["calls"])
+    try:
+        busy = {}
+        for c in range(n_chrom + len(engs)):
+            e = engs[c % len(engs)]
+            if c % len(engs) in busy:                               # the engine's previous chromosome: collect before it is reused
+                pc, t, nq = busy.pop(c % len(engs))
+                e.finish()
+                got = {k: e.table(k) for k in ("raw", "calls")}
+                soa = synth.to_soa(t, nq)                           # host copy of the same 20 M records for the oracle
+                del t
+                pending.append((pc, got, pool.submit(oracle_run, soa, DTYPE_HIFI, p)))
+                while len(pending) > 6:
+                    total_calls += check(*pending.pop(0))
+            if c < n_chrom:
+                t, nq, _ = synth.generate(n_per, "hifi", seed=20250328 + 4 + 1000 * c, tid=c, chrom_len=synth.HG19_LEN[c], device=dev)
+                recs = DeviceRecords(t, nq, c + 1, max_pos=synth.HG19_LEN[c] + 200000, tid_lo=c)
+                e.run_async(recs, p)
+                busy[c % len(engs)] = (c, t, nq)
+        for item in pending:
+            total_calls += check(*item)
+        assert total_calls > 22 * 50_000
+    finally:
+        pool.shutdown(wait=True)
+        for e in engs:
+            e.close()
+        torch.cuda.empty_cache()
+
+
+def test_full_size_config5_breakends():
+    """BASELINE.json config 5 at full size (1 M events x 2 haplotypes, bench.py's seed, ~6.7 M aligned segments): candidates,
+    collection-order exchange and pairing on device rows as bench.py config5 runs them at N = 1, against oracle.run_bnd."""
+    import torch
+    from oracle import oracle
+    from volcanosv_amd import bnd, shard, synth
+    from volcanosv_amd.abi import BND_DTYPE
+    from volcanosv_amd.engine import Engine
+    dev = torch.device("cuda", 0)
+    eng = Engine(0, max_sigs=1 << 24)                                # bench.py's row capacity for this workload
+    seg, primary_tid = synth.generate_bnd(1_000_000, seed=20250328 + 5)
+    assert len(seg.q_start) > 6_000_000
+    dseg = bnd.DeviceSegments(seg, dev)
+    gid_t = torch.arange(len(seg.hap), dtype=torch.int64, device=dev)
+    owner_t = torch.zeros(len(synth.HG19_LEN), dtype=torch.int64, device=dev)
+    rank_t = torch.from_numpy(np.ascontiguousarray(seg.contig_rank)).to(dev)
+    got = []
+    for _ in range(2):                                               # twice: deterministic
+        cand = eng.bnd_candidates_device(dseg, dev)
+        rows = shard.exchange_bnd_device(cand, gid_t, owner_t, dev)
+        calls = eng.bnd_pair_device(rows, rank_t, dev)
+        got.append((np.frombuffer(cand.cpu().numpy().tobytes(), dtype=BND_DTYPE), np.frombuffer(calls.cpu().numpy().tobytes(), dtype=BND_DTYPE)))
+    assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
+    ocand, ocalls = oracle.run_bnd(seg)
+    assert len(ocalls) > 1_000_000
+    assert np.array_equal(got[0][0], ocand)
+    fields = ("src_tid", "src_pos", "dst_tid", "dst_pos", "read", "read2", "meta")
+    canon = lambda c: c[np.lexsort(tuple(c[f] for f in reversed(fields)))]
+    a, b = canon(got[0][1]), canon(ocalls)
+    assert len(a) == len(b)
+    for f in fields:
+        assert np.array_equal(a[f], b[f]), f                         # the same calls (slot order vs key order)
+    eng.close()
+    del dseg
+    torch.cuda.empty_cache()
+
+
+def test_full_size_row2c_contigs():
+    """SURVEY §8d row 2c at full size (200 k contig-like records of ~16 k ops, 3.2 G CIGAR ops, bench.py's seed): determinism,
+    sortedness and internal consistency of the tables of the whole input, and bit-exact tables against the CPU oracle for the
+    20 k-record prefix (the part of the pile the oracle finishes in seconds: the same densities as the whole)."""
+    import torch
+    from volcanosv_amd import synth
+    from volcanosv_amd.engine import DeviceRecords, Engine, default_params
+    t, nq, nt = synth.generate(200_000, "contig", seed=20250328 + 6, tid=0, chrom_len=synth.CHR10_LEN, device="cuda")
+    assert t["cigar"].numel() > 3_000_000_000
+    p = default_params(DTYPE_HIFI)
+    with Engine(0, max_sigs=1 << 24) as e:
+        dr = DeviceRecords(t, nq, 1, max_pos=synth.CHR10_LEN + 200000, tid_lo=0)
+        runs = []
+        for _ in range(3):                                           # (the handle's first run sorts with other kernels than the later ones)
+            e.run(dr, p)
+            runs.append({k: e.table(k) for k in ("raw", "merged", "calls")})
+        for other in runs[1:]:
+            assert_tables_equal(other, runs[0], ["raw", "merged", "calls"])
+        a = runs[0]
+        assert len(a["raw"]) > 6_000_000 and len(a["calls"]) > 2_000_000
+        key = a["calls"]["sig"]["pos"].astype(np.int64)
+        assert np.all(np.diff(key) >= 0)                             # one chromosome: sorted by pos
+        mk = ((a["merged"]["meta"].astype(np.int64) & 4) << 40) | (a["merged"]["pos"].astype(np.int64) + 65536)
+        assert np.all(np.diff(mk) >= 0)                              # merged: (hap, pos)
+        c = a["calls"]
+        paired = c["gt"] == 2
+        assert paired.sum() > 100_000
+        m = a["merged"]
+        assert np.all((m["meta"][c["a"][paired]] & 4) == 0) and np.all((m["meta"][c["b"][paired]] & 4) != 0)
+        assert len(np.unique(c["b"][paired])) == paired.sum()        # an hp2 row pairs at most once
+        # every merged row is in exactly one call: hp1 rows through a, hp2 rows through b
+        assert len(c) == len(m) - paired.sum()
+        k = 20_000
+        n_ops = int(t["cigar_off"][k])
+        sl = {name: (v[: k + 1] if name == "cigar_off" else v[:n_ops] if name == "cigar" else v[:k]) for name, v in t.items()}
+        nq_k = int(sl["qid"].max()) + 1
+        e.run(DeviceRecords(sl, nq_k, 1, max_pos=synth.CHR10_LEN + 200000), p)
+        got = e.tables(DTYPE_HIFI)
+        st, want = oracle_run(synth.to_soa({n: v.cpu() for n, v in sl.items()}, nq_k), DTYPE_HIFI, p)
+        assert st == 0 and len(want["calls"]) > 150_000
+        assert_tables_equal(got, want, list(got.keys()))
+    del t, sl
+    torch.cuda.empty_cache()

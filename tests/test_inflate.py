@@ -486,3 +486,49 @@ def test_sequences_kept_on_the_device_and_sliced_there(tmp_path, monkeypatch):
             st = eng.lib.vsv_bam_device_seq_slices(eng.h, vp(one(rec, np.uint32)), vp(one(start, np.uint32)), vp(one(ln, np.uint32)), vp(one(0, np.uint8)), 1,
                                                    vp(off), vp(out), 64)
             assert st != 0
+
+
+@pytest.mark.gpu
+def test_staged_file_whose_size_is_not_slice_aligned(tmp_path):
+    """The device reader stages a file of 8 MiB and more into a page-locked buffer of the handle with up to 16 reader threads, one
+    slice each. A file of 16 * 4096 * k + r bytes (r = 1..15) used to leave its last r bytes to no reader (slice size rounded from
+    floor(size / threads)), i.e. to whatever an earlier, larger file had left in the reused buffer: the trailer of the last
+    member then failed its checks. Same handle, larger file first; every array equals the host reader's."""
+    import struct
+    from volcanosv_amd import bam
+    from volcanosv_amd.engine import Engine
+
+    def recs(n):
+        return [dict(tid=0, pos=1000 + 50 * i, qname="PS%d_hp%d" % (i, 1 + i % 2), mapq=60, flag=0, cigar=[(0, 500), (1, 40 + i % 9), (0, 300)],
+                     seq_len=30000) for i in range(n)]
+
+    def padded_empty_member(total):
+        """An empty BGZF member of exactly `total` bytes: the BC subfield plus a second extra subfield as ballast."""
+        ballast = total - 28 - 4
+        assert 0 <= ballast < 60000
+        xlen = 6 + 4 + ballast
+        return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff" + struct.pack("<H", xlen) + b"BC\x02\x00" + struct.pack("<H", total - 1) +
+                b"XX" + struct.pack("<H", ballast) + b"\x00" * ballast + b"\x03\x00" + struct.pack("<II", 0, 0))
+
+    big, small = str(tmp_path / "big.bam"), str(tmp_path / "small.bam")
+    bam.write_bam(big, [("chr1", 50_000_000)], recs(330), level=0)
+    bam.write_bam(small, [("chr1", 50_000_000)], recs(200), level=0)
+    assert os.path.getsize(big) > os.path.getsize(small) + (1 << 20) and os.path.getsize(small) > (8 << 20)
+    with Engine(0) as eng:
+        for r in (1, 7, 15):
+            body = open(small, "rb").read()[:-28]                       # without the EOF marker
+            want = -(-(len(body) + 32 + 28) // 65536) * 65536 + r       # 16 * 4096 * k + r
+            path = str(tmp_path / ("small_%d.bam" % r))
+            with open(path, "wb") as f:
+                f.write(body + padded_empty_member(want - len(body) - 28) + bam._bgzf_block(b""))
+            assert os.path.getsize(path) % 65536 == r
+            with bam.BamFile(big) as bf:
+                assert isinstance(bf.fetch_device(eng, "chr1"), bam.DeviceRecordView)
+            with bam.BamFile(path) as bf:
+                host = bf.fetch_soa("chr1")
+                view = bf.fetch_device(eng, "chr1")
+                assert isinstance(view, bam.DeviceRecordView)
+                dev = view.to_host()
+                for name in ("pos", "tid", "qid", "cigar_off", "mapq", "flag", "cigar", "l_seq"):
+                    assert np.array_equal(getattr(host, name), getattr(dev, name)), (r, name)
+                assert host.n_records == 200

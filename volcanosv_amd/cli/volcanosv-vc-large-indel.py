@@ -58,12 +58,28 @@ def run_chromosome(c, g):
 
 
 failed = []
+# one queue per GPU (its chromosomes by shard.lpt_assign, largest first) worked down by per_gpu threads: at most per_gpu processes
+# (each with its aligner and its GPU buffers) share a device, and no GPU idles while another one holds several jobs
+queues = [sorted([c for c, o in zip(chroms, owner) if o == g], key=lambda c: -fai.get("chr%d" % c, 1)) for g in range(n_gpus)]
 with ThreadPoolExecutor(max_workers=n_gpus * per_gpu) as pool:
-    # LPT order (largest chromosome first) inside every GPU's queue; the pool size is the concurrency bound
-    order = sorted(zip(chroms, owner), key=lambda t: -fai.get("chr%d" % t[0], 1))
-    for c, rc, cmd in pool.map(lambda t: run_chromosome(*t), order):
-        if rc != 0:
-            failed.append((c, rc, cmd))
+    futs = []
+    for g, q in enumerate(queues):
+        it = iter(q)
+        lock = __import__("threading").Lock()
+
+        def worker(g=g, it=it, lock=lock):
+            res = []
+            while True:
+                with lock:
+                    c = next(it, None)
+                if c is None:
+                    return res
+                res.append(run_chromosome(c, g))
+        futs += [pool.submit(worker) for _ in range(min(per_gpu, max(1, len(q))))]
+    for f in futs:
+        for c, rc, cmd in f.result():
+            if rc != 0:
+                failed.append((c, rc, cmd))
 if failed:
     for c, rc, cmd in failed:
         print("chr%d: Raw_variant_call.py exited with status %d: %s" % (c, rc, cmd), file=sys.stderr)

@@ -13,6 +13,8 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include "vsv_env.h"
+
 #include <atomic>
 #include <exception>
 #include <string>
@@ -306,7 +308,7 @@ static int bam_load_impl(vsv_bam* b, int tid, vsv_records* out) {
   std::vector<RecRef> refs;
   std::vector<RecAux> aux;
   bool first_rec = true;
-  static const bool timing = getenv("VSV_BAM_TIMING") != nullptr;
+  static const bool timing = vsv_dbg_env("VSV_BAM_TIMING") != nullptr;
   double t_fill = 0, t_hop = 0, t_par = 0, t_seq = 0;
   auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   for (;;) {
@@ -477,7 +479,7 @@ static int bam_load_device_impl(vsv_bam* b, vsv_handle* h, int tid, vsv_records*
   const bool hdr_ok = read_header(b);
   b->n_threads = user_threads; b->gpu = user_gpu;
   if (!hdr_ok) return VSV_E_INVALID;
-  const bool timing = getenv("VSV_BAM_TIMING") != nullptr;
+  const bool timing = vsv_dbg_env("VSV_BAM_TIMING") != nullptr;
   auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t0 = now();
   const uint64_t first_record = b->inflated_total - (b->buf.size() - b->rd);
@@ -501,7 +503,7 @@ static int bam_load_device_impl(vsv_bam* b, vsv_handle* h, int tid, vsv_records*
   // per thread): the member table then reads hot memory instead of faulting one mapped page per member, and the device reader's
   // uploads are asynchronous DMAs at PCIe speed that run under the decode of the previous slice. Larger files stream from the
   // mapping, window by window.
-  static const char* pin_env = getenv("VSV_BAM_PINNED");      // timing experiments: "0" keeps the mapped file
+  static const char* pin_env = vsv_dbg_env("VSV_BAM_PINNED");      // timing experiments: "0" keeps the mapped file
   std::vector<std::thread> pool;
   std::vector<std::atomic<int>> ready;                        // per reader thread: 0 reading, 1 done, -1 failed
   size_t per = 0;
@@ -514,7 +516,7 @@ static int bam_load_device_impl(vsv_bam* b, vsv_handle* h, int tid, vsv_records*
       if ((size_t)fsize < (8u << 20)) nt = 1;
       ready = std::vector<std::atomic<int>>(nt);
       for (auto& r : ready) r.store(0);
-      per = ((size_t)fsize / nt + 4095) & ~(size_t)4095;
+      per = (((size_t)fsize + nt - 1) / nt + 4095) & ~(size_t)4095;     // nt * per >= fsize: every byte has a reader
       for (unsigned t = 0; t < nt; ++t)
         pool.emplace_back([&ready, pin, fd, fsize, per, t]() {
           size_t o = (size_t)t * per, e = o + per < (size_t)fsize ? o + per : (size_t)fsize;

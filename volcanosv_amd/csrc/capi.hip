@@ -15,7 +15,7 @@
 namespace {
 
 // ops per K1 part (one wave each); VSV_OPS_PER_PART overrides it for timing experiments
-static const int OPS_PER_PART = getenv("VSV_OPS_PER_PART") && atoi(getenv("VSV_OPS_PER_PART")) >= 1024 ? atoi(getenv("VSV_OPS_PER_PART")) : 4096;
+static const int OPS_PER_PART = vsv_dbg_env("VSV_OPS_PER_PART") && atoi(vsv_dbg_env("VSV_OPS_PER_PART")) >= 1024 ? atoi(vsv_dbg_env("VSV_OPS_PER_PART")) : 4096;
 
 struct DevBuf {
   void* p = nullptr;
@@ -76,6 +76,7 @@ struct vsv_handle {
   bool clr_unfused = false;        // the fused CLR scan met a part too long for its gate state: separate gate pass from now on
   bool dense_pairing = false;      // the last run walked a pairing stretch of thousands of rows with one wave: pair in rounds
   bool in_rerun = false;
+  int64_t reruns = 0;             // whole-run repetitions taken by finish() so far (vsv_rerun_count)
   vsv_bnd_params bnd_prm{};
   Counters host_ctr;
   Counters* pinned = nullptr;
@@ -221,15 +222,15 @@ SortWork sort_work(vsv_handle* h) {
   SortWork w;
   w.key_alt = (uint64_t*)h->key_alt.p; w.val_alt = (uint32_t*)h->val_alt.p; w.hist = (uint32_t*)h->hist.p; w.max_items = h->cap_sigs;
   w.totals = (uint32_t*)h->totals.p; w.pass_cursor = &h->pass_cursor; w.max_passes = MAX_SORT_PASSES; w.small_tiles = h->small_sort_tiles;
-  static const char* force = getenv("VSV_SORT_TILE");   // timing experiments: "big" / "small"
+  static const char* force = vsv_dbg_env("VSV_SORT_TILE");   // timing experiments: "big" / "small"
   if (force) w.small_tiles = force[0] == 's';
   // bucket sort: the fewest buckets (256..2048) that keep the largest table of the previous run at <= 640 rows per bucket, i.e.
   // ~1300 per occupied one with half of the key range populated (a workgroup sorts up to 4096); tables beyond ~1.3 M rows, a
   // handle whose last bucket sort overflowed, and VSV_SORT=lsd take the LSD passes
-  static const char* mode = getenv("VSV_SORT");
+  static const char* mode = vsv_dbg_env("VSV_SORT");
   const Counters& c = h->host_ctr;
   const uint64_t rows = c.n_s1 > c.n_cand ? c.n_s1 : c.n_cand;
-  static const int per_bucket = getenv("VSV_BK_ROWS") ? atoi(getenv("VSV_BK_ROWS")) : 640;     // timing experiments
+  static const int per_bucket = vsv_dbg_env("VSV_BK_ROWS") ? atoi(vsv_dbg_env("VSV_BK_ROWS")) : 640;     // timing experiments
   int bb = 8;
   while (bb < 11 && (rows >> bb) > (uint64_t)per_bucket) ++bb;
   // (a handle's first run knows no row count: LSD passes rather than a guess that overflows and repeats the run)
@@ -305,7 +306,7 @@ int enq_scan(vsv_handle* h) {
   RecView srv = h->rv;
   // CLR: the read-shaped scan carries the gate itself (cigar_scan_emit<0, 4, true>); the long-record scan, and a handle whose fused
   // scan met a part too long for its gate state, see haplotype tags only where a separate pass over the CIGARs lets the gate pass
-  static const char* clr_mode = getenv("VSV_CLR");          // tests: "separate"
+  static const char* clr_mode = vsv_dbg_env("VSV_CLR");          // tests: "separate"
   const bool clr_fused = h->prm.dtype == VSV_DTYPE_CLR && srv.n_records > 0 && !vsv_scan_is_long(srv, h->prm) && !h->clr_unfused &&
                          !(clr_mode && clr_mode[0] == 's');
   if (h->prm.dtype == VSV_DTYPE_CLR && srv.n_records > 0 && !clr_fused) {
@@ -316,7 +317,7 @@ int enq_scan(vsv_handle* h) {
   }
   // fused run: the split candidates need the record arrays only — they go to the auxiliary stream, enqueued BEHIND the scan (the
   // host spends ~50 us enqueuing them: the scan is already streaming by then) but ordered after this run's reset only
-  static const char* where = getenv("VSV_SPLIT_STREAM");   // timing experiments: "main" keeps everything on the handle's stream
+  static const char* where = vsv_dbg_env("VSV_SPLIT_STREAM");   // timing experiments: "main" keeps everything on the handle's stream
   const bool early_cands = h->fork_split && h->prm.enable_split && h->prm.dtype != VSV_DTYPE_SVIM && h->prm.dtype != VSV_DTYPE_CUTESV && h->rv.n_records > 0;
   const bool fork = early_cands && h->prm.split_overlap != VSV_OVERLAP_OFF && !(where && where[0] == 'm') && have_aux(h, false);
   if (fork) HIPCHK(h, hipEventRecord(h->ev_fork, st));
@@ -402,7 +403,7 @@ int finish(vsv_handle* h) {
   h->pending = false;
   if (h->stage_done >= 5) {   // pairing of the NEXT run: in rounds once a stretch of thousands of rows was met, back to the plain
                               // kernel when the merged table gets small again (the rounds cost ~20 launches)
-    static const char* force = getenv("VSV_PAIR");          // tests: "rounds" / "walk"
+    static const char* force = vsv_dbg_env("VSV_PAIR");          // tests: "rounds" / "walk"
     if (h->host_ctr.max_stretch > 2048) h->dense_pairing = true;
     else if (h->host_ctr.n_alive3 < 100000) h->dense_pairing = false;
     if (force) h->dense_pairing = force[0] == 'r';
@@ -413,32 +414,37 @@ int finish(vsv_handle* h) {
   }
   const uint32_t e = h->host_ctr.err;
   h->last_count = h->host_ctr.n_pool;
-  static const char* trace = getenv("VSV_TRACE_COUNTERS");
+  static const char* trace = vsv_dbg_env("VSV_TRACE_COUNTERS");
   if (trace) {
     const Counters& c = h->host_ctr;
     fprintf(stderr, "[vsv] n_pool %u n_raw %u n_cand %u n_s1 %u alive %u %u %u calls %u max_stretch %u err %#x\n", c.n_pool, c.n_raw, c.n_cand, c.n_s1,
             c.n_alive1, c.n_alive2, c.n_alive3, c.n_calls, c.max_stretch, c.err);
   }
-  if ((e & ERRB_CLR_FALLBACK) && !h->in_rerun) {
-    // a part of the read-shaped CLR scan held more chunks than its gate state: nothing it decided can be trusted. Same input
-    // again with the gate as a separate pass; this handle keeps that form.
-    h->clr_unfused = true;
+  if (e & (ERRB_CLR_FALLBACK | ERRB_SORT_FALLBACK)) {
+    // ERRB_CLR_FALLBACK: a part of the read-shaped CLR scan held more chunks than its gate state — nothing that run decided can be
+    // trusted; same input again with the gate as a separate pass (this handle keeps that form). ERRB_SORT_FALLBACK: a bucket of
+    // the bucket sort did not fit in LDS (tables far from uniform, or much larger than the previous run's) — the stages behind it
+    // ran on a table that was not written completely; same input again through the LSD passes (real errors show up there; the
+    // handle keeps them for a while, or goes back to buckets of the right size at once when the size hint was simply stale).
+    // The fallbacks are resolved in a loop, one at a time — the rerun of a CLR fallback may still overflow a bucket — and neither
+    // bit ever reaches the success path.
+    if (h->in_rerun) return 1;                 // the outermost finish() decides (1 = "again", never leaves this file)
     h->in_rerun = true;
-    const int st = rerun(h);
+    int st = 1;
+    bool stale_hint = false;
+    for (int attempt = 0; attempt < 3 && st == 1; ++attempt) {
+      const uint32_t ee = h->host_ctr.err;
+      if (ee & ERRB_CLR_FALLBACK) h->clr_unfused = true;
+      else {
+        const uint64_t rows_now = h->host_ctr.n_s1 > h->host_ctr.n_cand ? h->host_ctr.n_s1 : h->host_ctr.n_cand;
+        stale_hint = rows_now > h->sort_hint_rows + h->sort_hint_rows / 2;
+        h->lsd_runs = 16;
+      }
+      ++h->reruns;
+      st = rerun(h);
+    }
     h->in_rerun = false;
-    return st;
-  }
-  if ((e & ERRB_SORT_FALLBACK) && !h->in_rerun) {
-    // a bucket of the bucket sort did not fit in LDS (tables far from uniform, or much larger than the previous run's): the
-    // stages behind it ran on a table that was not written completely, so whatever else they reported means nothing.
-    // Same input again through the LSD passes (real errors show up there); this handle keeps them for a while.
-    // A table that simply outgrew the previous run's (the size hint was stale) goes back to buckets of the right size at once.
-    const uint64_t rows_now = h->host_ctr.n_s1 > h->host_ctr.n_cand ? h->host_ctr.n_s1 : h->host_ctr.n_cand;
-    const bool stale_hint = rows_now > h->sort_hint_rows + h->sort_hint_rows / 2;
-    h->lsd_runs = 16;
-    h->in_rerun = true;
-    const int st = rerun(h);
-    h->in_rerun = false;
+    if (st == 1) return fail(h, VSV_E_HIP, "bucket-sort / fused-CLR-gate fallback did not converge");
     if (stale_hint) h->lsd_runs = 0;
     return st;
   }
@@ -564,7 +570,7 @@ int vsv_create(int device_id, void* hip_stream, vsv_handle** out) {
   hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
   hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
   memset(&h->host_ctr, 0, sizeof h->host_ctr);
-  { const char* pm = getenv("VSV_PAIR"); h->dense_pairing = pm && pm[0] == 'r'; }     // tests: the round-based pairing from the first run
+  { const char* pm = vsv_dbg_env("VSV_PAIR"); h->dense_pairing = pm && pm[0] == 'r'; }     // tests: the round-based pairing from the first run
   *out = h;
   return 0;
 }
@@ -597,6 +603,7 @@ void vsv_destroy(vsv_handle* h) {
 
 const char* vsv_last_error(vsv_handle* h) { return h ? h->err.c_str() : "null handle"; }
 int64_t vsv_last_count(vsv_handle* h) { return h ? h->last_count : 0; }
+int64_t vsv_rerun_count(vsv_handle* h) { return h ? h->reruns : 0; }
 
 int vsv_wait_for_stream(vsv_handle* h, void* producer_hip_stream) {
   if (!h) return VSV_E_INVALID;
@@ -986,7 +993,7 @@ static int inflate_to_device(vsv_handle* h, const uint8_t* comp, const uint64_t*
   // launch lasts as long as its slowest member (milliseconds of serial decode): on ONE stream those latencies add up (39 -> 71 ms
   // on a 9 k-member file), on two streams they overlap. What is left is the decode itself: 28.7 ms of kernel time for 9 124
   // members whatever the slicing.
-  static const int slices_env = getenv("VSV_INFLATE_SLICES") ? atoi(getenv("VSV_INFLATE_SLICES")) : 0;      // timing experiments
+  static const int slices_env = vsv_dbg_env("VSV_INFLATE_SLICES") ? atoi(vsv_dbg_env("VSV_INFLATE_SLICES")) : 0;      // timing experiments
   int n_slices = slices_env > 0 ? slices_env : (int)(n / 2048);       // 9 k members: 1 slice 38.6 ms, 2: 33.7, 4: 31.3, 8: 34.5
   if (n_slices < 1 || (n_slices > 1 && !have_aux(h, true))) n_slices = 1;
   if (n_slices > (slices_env > 0 ? 8 : 4)) n_slices = slices_env > 0 ? 8 : 4;
@@ -1148,7 +1155,7 @@ int vsv_bam_parse_device(vsv_handle* h, const uint8_t* comp, const uint64_t* com
   // The file is processed in windows of members (the whole file when it is small): a window is inflated, its records are
   // chained / parsed / appended to the output arrays, and the next window starts at the member that holds the first record
   // the previous one could not complete. VSV_BAM_WINDOW overrides the window size (tests use tiny windows).
-  const int64_t window_members = getenv("VSV_BAM_WINDOW") && atoll(getenv("VSV_BAM_WINDOW")) > 0 ? atoll(getenv("VSV_BAM_WINDOW")) : 32768;
+  const int64_t window_members = vsv_dbg_env("VSV_BAM_WINDOW") && atoll(vsv_dbg_env("VSV_BAM_WINDOW")) > 0 ? atoll(vsv_dbg_env("VSV_BAM_WINDOW")) : 32768;
   std::vector<uint64_t> ginf((size_t)n_members + 1, 0);
   for (int64_t i = 0; i < n_members; ++i) ginf[i + 1] = ginf[i] + isize[i];
   const uint64_t stream_total = ginf[n_members];
@@ -1165,7 +1172,7 @@ int vsv_bam_parse_device(vsv_handle* h, const uint8_t* comp, const uint64_t* com
   uint64_t carry = first_record, K0 = 0, C0 = 0, N0 = 0, S0 = 0, Q0 = 0;
   h->sa_text.clear();
   h->seq_records = -1;
-  const bool timing = getenv("VSV_BAM_TIMING") != nullptr;
+  const bool timing = vsv_dbg_env("VSV_BAM_TIMING") != nullptr;
   double t_inf = 0, t_chain = 0, t_rec = 0, t_names = 0, t_qid = 0;
   int n_windows = 0, n_rounds = 0;
   auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };

@@ -1155,7 +1155,7 @@ void vsv_scan_u32_exclusive(hipStream_t st, const uint32_t* in, int n, uint32_t*
 int vsv_cigar_parts(int64_t n_ops, int ops_per_part) { return (int)((n_ops + ops_per_part - 1) / ops_per_part); }
 
 bool vsv_scan_is_long(const RecView& rv, const vsv_params& p) {
-  static const char* force = getenv("VSV_K1_MODE");              // timing experiments: "long" / "short"
+  static const char* force = vsv_dbg_env("VSV_K1_MODE");              // timing experiments: "long" / "short"
   if (force) return force[0] == 'l';
   if (p.scan_layout == VSV_SCAN_READS) return false;
   if (p.scan_layout == VSV_SCAN_CONTIGS) return true;
@@ -1181,8 +1181,8 @@ void vsv_launch_cigar_scan(hipStream_t st, const RecView& rv, const vsv_params& 
   const int waves_per_block = 4;
   const int grid = (n_parts + waves_per_block - 1) / waves_per_block;
   if (ev0) (void)hipEventRecord(ev0, st);
-  static const int ablate = getenv("VSV_K1_ABLATE") ? atoi(getenv("VSV_K1_ABLATE")) : 0;  // timing experiments only
-  static const int depth = getenv("VSV_K1_DEPTH") ? atoi(getenv("VSV_K1_DEPTH")) : 4;     // chunks in flight per wave (3 or 4)
+  static const int ablate = vsv_dbg_env("VSV_K1_ABLATE") ? atoi(vsv_dbg_env("VSV_K1_ABLATE")) : 0;  // timing experiments only
+  static const int depth = vsv_dbg_env("VSV_K1_DEPTH") ? atoi(vsv_dbg_env("VSV_K1_DEPTH")) : 4;     // chunks in flight per wave (3 or 4)
   const int n_tiles = (n_parts + SCAN_TILE - 1) / SCAN_TILE;
   uint32_t* tsum = nullptr;
 #define K1_LAUNCH(CLS)                                                                                                          \

@@ -594,7 +594,7 @@ SortResult bucket_sort(hipStream_t st, SRC src, uint64_t* key, uint32_t* val, ui
   const int grid = (int)(max_tiles < 1024 ? (max_tiles < 1 ? 1 : max_tiles) : 1024);
   // the self-scanning form needs a zeroed slot of group sums and a table of at most VSV_RS_MAX_GROUPS groups of tiles (the row
   // count of the handle's previous run; a table that grew past it is caught below: the sort falls back like an overflowing bucket)
-  static const char* scan_env = getenv("VSV_BK_SCAN");      // timing experiments / tests: "self" | "launch"
+  static const char* scan_env = vsv_dbg_env("VSV_BK_SCAN");      // timing experiments / tests: "self" | "launch"
   uint32_t* groups = nullptr;
   if (w.groups && *w.group_cursor < w.max_group_slots && w.hint_rows > 0 &&
       w.hint_rows + w.hint_rows / 2 <= (uint64_t)VSV_RS_MAX_GROUPS * RS_GROUP * rs_tile<ROUNDS>() && !(scan_env && scan_env[0] == 'l')) {
@@ -609,7 +609,7 @@ SortResult bucket_sort(hipStream_t st, SRC src, uint64_t* key, uint32_t* val, ui
     rs_scatter<BITS, ROUNDS, BucketDigit, SRC, false><<<grid, 256, 0, st>>>(src, d_n, dg, w.hist, key_scratch, val_scratch, totals);
   }
   // bucket bases = the scanned histogram row of tile 0 (offset of the first tile's rows of every bucket), or the totals in front
-  static const int cap_env = getenv("VSV_BK_CAP") ? atoi(getenv("VSV_BK_CAP")) : BK_CAP;      // tests force the fallback with a tiny capacity
+  static const int cap_env = vsv_dbg_env("VSV_BK_CAP") ? atoi(vsv_dbg_env("VSV_BK_CAP")) : BK_CAP;      // tests force the fallback with a tiny capacity
   const uint32_t cap = (uint32_t)(cap_env < 2 ? 2 : cap_env > BK_CAP ? BK_CAP : cap_env);
   if (w.shared_gpu) bk_lds_sort<ROW, 256><<<1 << BITS, 256, 0, st>>>(key_scratch, val_scratch, w.hist, self ? totals : nullptr, 1 << BITS, d_n, key, val, w.err, cap, rs_tile<ROUNDS>(), io);
   else bk_lds_sort<ROW, 512><<<1 << BITS, 512, 0, st>>>(key_scratch, val_scratch, w.hist, self ? totals : nullptr, 1 << BITS, d_n, key, val, w.err, cap, rs_tile<ROUNDS>(), io);

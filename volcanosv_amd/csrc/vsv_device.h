@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "../../include/volcanosv.h"
+#include "vsv_env.h"
 
 #define VSV_WAVE 64
 

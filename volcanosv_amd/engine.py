@@ -99,6 +99,10 @@ class Engine:
     def last_count(self):
         return int(self.lib.vsv_last_count(self.h))
 
+    def rerun_count(self):
+        """Whole-run repetitions vsv_finish() took on this engine so far (bucket-sort overflow / fused-CLR-gate fallbacks)."""
+        return int(self.lib.vsv_rerun_count(self.h))
+
     # ---- stage entry points --------------------------------------------------------------------------
     def _recs(self, soa):
         self._keep = soa  # keep host arrays / tensors alive while the GPU reads them
@@ -197,13 +201,16 @@ class Engine:
 
     def bnd_pair_device(self, rows_u8, contig_rank_t, device, params=None):
         """vsv_bnd_set_candidates + vsv_bnd_pair on device-resident candidate rows (collection order); calls as a uint8 tensor."""
+        import torch
         p = params or self._bnd_params()
         n = rows_u8.numel() // 32
         self._keep = (rows_u8, contig_rank_t)
+        # the rows were just produced on torch's current stream (exchange_bnd_device: index, sort, all-to-all); the library copies
+        # them on the HANDLE's stream: order the two on the device
+        self.wait_for_stream(torch.cuda.current_stream(device).cuda_stream)
         self._check(self.lib.vsv_bnd_set_candidates(self.h, C.c_void_p(rows_u8.data_ptr() if n else 0) if n else None, n,
                                                     C.c_void_p(contig_rank_t.data_ptr()), int(contig_rank_t.numel()), 1))
         self._check(self.lib.vsv_bnd_pair(self.h, C.byref(p)))
-        import torch
         rows = self.table_torch("bnd_call_slots", device).view(-1, 32)
         meta = rows[:, 24:28].contiguous().view(torch.int32).view(-1)
         return rows[(meta & 64) == 0].contiguous().view(-1)

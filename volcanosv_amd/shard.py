@@ -38,14 +38,68 @@ def broadcast_index(index, device):
     return buf
 
 
+class _RootGather:
+    """Handle of a variable-length gather to rank 0 in flight (gather_bytes_start): `wait()` completes it and returns, on rank 0,
+    (list of per-rank uint8 tensors in rank order, list of byte counts); (None, counts) on the other ranks."""
+
+    def __init__(self, works, bufs, counts, keep):
+        self.works, self.bufs, self.counts, self.keep = works, bufs, counts, keep
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        self.works, self.keep = [], None
+        return self.bufs, self.counts
+
+
+def gather_bytes_start(t_u8, device):
+    """Variable-length gather of a uint8 tensor to RANK 0 ONLY (the reference collects once, on the parent:
+    volcanosv-vc-large-indel.py:271-278): one all-gather of the byte counts (8 bytes per rank), then grouped point-to-point
+    transfers — every rank r > 0 sends exactly its bytes to rank 0, rank 0 posts one exact-size receive per sender; nobody else
+    receives anything (a padded all-gather would deliver every rank's table to every rank: 8x the xGMI traffic at N = 8, on links
+    that are point-to-point). The transfers are asynchronous: the caller goes on enqueuing its next chromosome and calls
+    `.wait()` on the returned handle when it needs the rows (t_u8 is kept alive until then)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return _RootGather([], [t_u8], [int(t_u8.numel())], None)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    n = torch.tensor([int(t_u8.numel())], dtype=torch.int64, device=device)
+    counts_t = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(counts_t, n)
+    counts = [int(c.item()) for c in counts_t]
+    ops, bufs = [], None
+    src = t_u8.to(device).contiguous()
+    if rank == 0:
+        bufs = [src] + [torch.empty(counts[r], dtype=torch.uint8, device=device) for r in range(1, world)]
+        ops = [dist.P2POp(dist.irecv, bufs[r], r) for r in range(1, world) if counts[r]]
+    elif counts[rank]:
+        ops = [dist.P2POp(dist.isend, src, 0)]
+    works = dist.batch_isend_irecv(ops) if ops else []
+    return _RootGather(works, bufs, counts, src)
+
+
+def gather_bytes(t_u8, device):
+    return gather_bytes_start(t_u8, device).wait()
+
+
+def _calls_as_u8(calls, device):
+    if torch.is_tensor(calls):
+        return calls
+    return torch.from_numpy(np.frombuffer(calls.tobytes(), dtype=np.uint8).copy()) if len(calls) else torch.zeros(0, dtype=torch.uint8)
+
+
+def gather_calls_start(calls, device):
+    """gather_calls in two halves: enqueue now (returns a handle), `finish_gather(handle.wait())` / `.wait()` later, so that a
+    rank's transfer runs under its next chromosome's compute."""
+    return gather_bytes_start(_calls_as_u8(calls, device).to(device), device)
+
+
 def gather_calls(calls, device, to_host=True):
     """calls: this rank's call table — a numpy CALL_DTYPE array (host path, gloo tests) or a uint8 torch tensor holding the
-    rows on `device` (GPU path: the bytes go GPU -> RCCL all-gather -> rank 0 with no host hop on the senders).
+    rows on `device` (GPU path: the bytes go GPU -> RCCL send/recv -> rank 0 with no host hop on the senders).
     Returns on rank 0 the concatenation over ranks in (tid, pos) order as a numpy array, None elsewhere. Every rank's
     table is already sorted by (tid, pos) and tids are disjoint across ranks, so the merge is a concatenation of the
     per-rank tables ordered by their tids (a stable sort only if two ranks interleave tids).
-    Counts go through one all_gather, rows through one padded all_gather (tables are KB-MB: latency-bound, so a single
-    collective beats per-peer send/recv rings on point-to-point xGMI)."""
+    Counts go through one all-gather, rows through exact-size point-to-point transfers to rank 0 only (gather_bytes_start)."""
     row = CALL_DTYPE.itemsize
     as_tensor = torch.is_tensor(calls)
     if not dist.is_initialized() or dist.get_world_size() == 1:
@@ -53,24 +107,11 @@ def gather_calls(calls, device, to_host=True):
             return calls
         single = ([calls], [calls.numel() // row])
         return single if not to_host else finish_gather(single)
-    world = dist.get_world_size()
-    n_rows = (calls.numel() // row) if as_tensor else len(calls)
-    n = torch.tensor([n_rows], dtype=torch.int64, device=device)
-    counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(counts, n)
-    counts = [int(c.item()) for c in counts]
-    mx = max(max(counts), 1)
-    mine = torch.zeros(mx * row, dtype=torch.uint8, device=device)
-    if n_rows:
-        src = calls if as_tensor else torch.from_numpy(np.frombuffer(calls.tobytes(), dtype=np.uint8).copy())
-        mine[: n_rows * row] = src.to(device)
-    bufs = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(bufs, mine)
+    bufs, counts = gather_bytes(_calls_as_u8(calls, device).to(device), device)
     if dist.get_rank() != 0:
         return None
-    if not to_host:       # rows are on rank 0's device; `finish_gather` turns them into the merged numpy table later
-        return (bufs, counts)
-    return finish_gather((bufs, counts))
+    g = (bufs, [c // row for c in counts])
+    return g if not to_host else finish_gather(g)     # to_host=False: rows stay on rank 0's device until finish_gather
 
 
 def finish_gather(gathered):
@@ -171,41 +212,23 @@ def exchange_bnd_device(cand_u8, read_gid, owner_of_tid_t, device):
 
 
 def gather_rows_device(rows_u8, device):
-    """Variable-length gather of device rows (uint8 tensor) to rank 0: counts all-gather + padded all-gather; rank order. Returns
-    the concatenated uint8 tensor on rank 0, None elsewhere."""
+    """Variable-length gather of device rows (uint8 tensor) to rank 0 only (gather_bytes_start: counts all-gather + exact-size
+    send/recv); rank order. Returns the concatenated uint8 tensor on rank 0, None elsewhere."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return rows_u8
-    world = dist.get_world_size()
-    n = torch.tensor([rows_u8.numel()], dtype=torch.int64, device=device)
-    counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(counts, n)
-    counts = [int(c.item()) for c in counts]
-    mx = max(max(counts), 1)
-    mine = torch.zeros(mx, dtype=torch.uint8, device=device)
-    mine[: rows_u8.numel()] = rows_u8
-    bufs = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(bufs, mine)
+    bufs, counts = gather_bytes(rows_u8, device)
     if dist.get_rank() != 0:
         return None
-    return torch.cat([bufs[r][: counts[r]] for r in range(world)])
+    return torch.cat([b for b, c in zip(bufs, counts) if c]) if any(counts) else torch.zeros(0, dtype=torch.uint8, device=device)
 
 
 def gather_rows(rows, dtype, device):
-    """Variable-length gather of structured rows to rank 0 (counts all-gather + padded all-gather); rank order."""
+    """Variable-length gather of structured numpy rows to rank 0 only (host path, gloo tests); rank order."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return rows
-    world = dist.get_world_size()
-    n = torch.tensor([len(rows)], dtype=torch.int64, device=device)
-    counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(counts, n)
-    counts = [int(c.item()) for c in counts]
-    row = dtype.itemsize
-    mx = max(max(counts), 1)
-    mine = torch.zeros(mx * row, dtype=torch.uint8, device=device)
-    if len(rows):
-        mine[: len(rows) * row] = torch.from_numpy(np.frombuffer(rows.tobytes(), dtype=np.uint8).copy()).to(device)
-    bufs = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(bufs, mine)
+    src = torch.from_numpy(np.frombuffer(rows.tobytes(), dtype=np.uint8).copy()) if len(rows) else torch.zeros(0, dtype=torch.uint8)
+    bufs, counts = gather_bytes(src.to(device), device)
     if dist.get_rank() != 0:
         return None
-    return np.concatenate([np.frombuffer(bufs[r][: counts[r] * row].cpu().numpy().tobytes(), dtype=dtype) for r in range(world)])
+    parts = [np.frombuffer(b.cpu().numpy().tobytes(), dtype=dtype) for b, c in zip(bufs, counts) if c]
+    return np.concatenate(parts) if parts else np.zeros(0, dtype)
