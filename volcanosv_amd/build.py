@@ -10,7 +10,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["cigar_scan.hip", "radix_sort.hip", "sig_stages.hip", "bnd.hip", "support.hip", "cutesv.hip", "redundancy.hip", "inflate.hip", "bam_device.hip", "capi.hip", "bam_ingest.cc"]
+SOURCES = ["cigar_scan.hip", "radix_sort.hip", "sig_stages.hip", "slim_path.hip", "bnd.hip", "support.hip", "cutesv.hip", "redundancy.hip", "inflate.hip", "bam_device.hip", "capi.hip", "bam_ingest.cc"]
 LIB = os.path.join(HERE, "libvolcanosv_hip.so")
 # -ffp-contract=off: the ONT/CLR split rule compares fp64 products exactly as CPython does
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-Wno-unused-value"]

@@ -77,6 +77,14 @@ struct vsv_handle {
   bool dense_pairing = false;      // the last run walked a pairing stretch of thousands of rows with one wave: pair in rounds
   bool in_rerun = false;
   int64_t reruns = 0;             // whole-run repetitions taken by finish() so far (vsv_rerun_count)
+  // large tables (slim_path.hip): element buffers, pairing scratch, what the run in flight left where
+  DevBuf sl[6], sl_hj, sl_done, sl_state;
+  uint64_t sl_epoch = 0;
+  bool big_run = false;            // the stages of this run work on 16-byte elements; rows are gathered on request
+  bool sl_prebuilt = false;        // ... and fold / split_eval have written the stage-1 elements next to their rows
+  void* sl_e2 = nullptr;           // stage-1 cluster output (n_alive1 slots)
+  void* sl_m = nullptr;            // merged elements (n_alive3)
+  bool c1_stale = false, merged_stale = false;      // VSV_T_CLUSTER1 / VSV_T_MERGED rows not gathered yet
   vsv_bnd_params bnd_prm{};
   Counters host_ctr;
   Counters* pinned = nullptr;
@@ -266,6 +274,9 @@ int reset_run_state(vsv_handle* h) {
   return 0;
 }
 int tid_bits(vsv_handle* h);
+bool want_big(vsv_handle* h);
+int slim_work(vsv_handle* h, SlimWork& w);
+int sort_bits(vsv_handle* h);
 // blocks of the row-parallel kernels: one row per thread for the largest table of the handle's previous run (+25 %), between 128
 // and 4096 blocks; a first run sizes for the row capacity. Every such kernel grid-strides, so this is speed only.
 int ew_grid(vsv_handle* h) {
@@ -326,7 +337,18 @@ int enq_scan(vsv_handle* h) {
                         (uint32_t*)h->scan_tmp.p, (vsv_sig*)h->raw0.p, dctr(h), (uint32_t*)h->shard_cnt.p, h->ev0, h->ev1,
                         LongScanBufs{h->l_agg.p, (uint32_t*)h->l_carry_r.p, (uint32_t*)h->l_carry_q.p, h->l_tiles.p, h->tile_cnt, 4096, true, clr_fused});
   h->have_scan_ev = n_parts > 0;
-  vsv_launch_fold(st, (const vsv_sig*)h->raw0.p, (vsv_sig*)h->s1in.p, h->rv, h->prm, dctr(h), ew_grid(h));
+  // the path of the stages behind the split stage is decided here, so that the fold (and split_eval) can write the elements of a
+  // large-table run next to their rows
+  h->big_run = want_big(h) && 4 * vsv_slim_sort_passes(sort_bits(h)) + 16 <= MAX_SORT_PASSES;
+  h->sl_prebuilt = false;
+  SlimOut so{nullptr, 0, 0, 0, nullptr};
+  if (h->big_run) {
+    SlimWork w;
+    { int ws = slim_work(h, w); if (ws) return ws; }
+    so = SlimOut{w.buf[0], pos_bits(h), h->rv.tid_lo, tid_bits(h), &dctr(h)->err};
+    h->sl_prebuilt = true;
+  }
+  vsv_launch_fold(st, (const vsv_sig*)h->raw0.p, (vsv_sig*)h->s1in.p, h->rv, h->prm, dctr(h), ew_grid(h), so);
   HIPCHK(h, hipGetLastError());
   if (early_cands) {
     if (fork) HIPCHK(h, hipStreamWaitEvent(h->aux, h->ev_fork, 0));
@@ -345,8 +367,10 @@ int enq_split(vsv_handle* h) {
   if (!p.enable_split || p.dtype == VSV_DTYPE_SVIM) rv.n_records = 0;  // n_s1 = n_raw
   if (rv.n_records > 0 && !h->split_cands_done) { int cs = enq_split_candidates(h, st); if (cs) return cs; }
   { int js = join_aux(h); if (js) return js; }
+  SlimOut so{nullptr, 0, 0, 0, nullptr};
+  if (h->big_run && h->sl_prebuilt) so = SlimOut{h->sl[0].p, pos_bits(h), h->rv.tid_lo, tid_bits(h), &dctr(h)->err};
   vsv_launch_split_eval(st, rv, p, h->n_tids, rv.n_records > 0 ? h->split_sorted : SplitSorted{nullptr, nullptr, nullptr, nullptr},
-                        (vsv_sig*)h->s1in.p, (uint32_t)h->cap_sigs, dctr(h), ew_grid(h));
+                        (vsv_sig*)h->s1in.p, (uint32_t)h->cap_sigs, dctr(h), ew_grid(h), so);
   if (p.dtype == VSV_DTYPE_READS) {
     // reads.py:281-286 merge_all: one stable sort of [del_cigar, ins_cigar, del_split, ins_split] by pos
     const int nbits = pos_bits(h) + 2 + tid_bits(h) + 1;
@@ -358,9 +382,51 @@ int enq_split(vsv_handle* h) {
   return 0;
 }
 
+// Tables beyond what the bucket sort takes (~1.3 M rows: the contig pile of SURVEY row 2c, config 3's ONT tables) run their sort /
+// cluster / merge / pair stages on 16-byte elements (slim_path.hip). Decided per run from the row counts of the handle's previous
+// run; VSV_BIG=1 / 0 (under VSV_DEBUG) forces either path for the tests. Results are identical.
+bool want_big(vsv_handle* h) {
+  if (!is_contig(h->prm.dtype)) return false;
+  static const char* force = vsv_dbg_env("VSV_BIG");
+  if (force) return force[0] == '1';
+  const Counters& c = h->host_ctr;
+  const uint64_t rows = c.n_s1 > c.n_cand ? c.n_s1 : c.n_cand;
+  return (rows >> 11) > 640;
+}
+int slim_work(vsv_handle* h, SlimWork& w) {
+  const size_t n = (size_t)h->cap_sigs;
+  for (int k = 0; k < 6; ++k) { int st = ensure(h, h->sl[k], n * 16 + 64); if (st) return st; w.buf[k] = h->sl[k].p; }
+  int st;
+  if ((st = ensure(h, h->sl_hj, n * 4 + 64))) return st;
+  if ((st = ensure(h, h->sl_done, n * 4 + 64))) return st;
+  {  // look-back words of the chained-scan passes: zeroed once (epochs start at 1)
+    const size_t bytes = ((n + 4095) / 4096 + 1) * 512 * sizeof(uint64_t);
+    if (h->sl_state.bytes < bytes) {
+      if ((st = ensure(h, h->sl_state, bytes))) return st;
+      HIPCHK(h, hipMemsetAsync(h->sl_state.p, 0, h->sl_state.bytes, h->stream));
+    }
+  }
+  w.state = (uint64_t*)h->sl_state.p; w.epoch = &h->sl_epoch;
+  w.cap = h->cap_sigs; w.hist = (uint32_t*)h->hist.p; w.totals = (uint32_t*)h->totals.p; w.pass_cursor = &h->pass_cursor;
+  w.grid = ew_grid(h); w.cl = (int32_t*)h->cl.p; w.hj = (uint32_t*)h->sl_hj.p; w.done1 = (uint32_t*)h->sl_done.p;
+  return 0;
+}
+int sort_bits(vsv_handle* h) { return pos_bits(h) + 3 + tid_bits(h); }
+
 int enq_stage1(vsv_handle* h) {
   hipStream_t st = h->stream;
   Counters* c = dctr(h);
+  h->big_run = h->big_run && h->pass_cursor + 4 * vsv_slim_sort_passes(sort_bits(h)) <= MAX_SORT_PASSES;     // (decided in enq_scan)
+  h->c1_stale = h->merged_stale = false;
+  if (h->big_run) {
+    SlimWork w;
+    { int ws = slim_work(h, w); if (ws) return ws; }
+    h->sl_e2 = vsv_slim_stage1(st, (const vsv_sig*)h->s1in.p, &c->n_s1, &c->n_alive1, pos_bits(h), h->rv.tid_lo, tid_bits(h), h->prm.cluster_shift, w, c, h->sl_prebuilt);
+    h->c1_stale = true;
+    HIPCHK(h, hipGetLastError());
+    h->stage_done = 3;
+    return 0;
+  }
   h->sorted_key = vsv_launch_sort_stage(st, (vsv_sig*)h->s1in.p, &c->n_s1, 1, pos_bits(h), key_bits(h), (vsv_sig*)h->s1s.p, &c->n_alive1, stage_bufs(h),
                         sort_work(h), h->cap_sigs, dctr(h));
   vsv_launch_cluster(st, (vsv_sig*)h->s1s.p, h->sorted_key, &c->n_alive1, h->prm.cluster_shift, pos_bits(h), (vsv_sig*)h->c1.p, stage_bufs(h), (uint64_t*)h->key2.p, dctr(h));
@@ -372,6 +438,15 @@ int enq_stage1(vsv_handle* h) {
 int enq_merge(vsv_handle* h) {
   hipStream_t st = h->stream;
   Counters* c = dctr(h);
+  if (h->big_run) {
+    SlimWork w;
+    { int ws = slim_work(h, w); if (ws) return ws; }
+    h->sl_m = vsv_slim_merge(st, h->sl_e2, &c->n_alive1, &c->n_alive2, &c->n_alive3, pos_bits(h), tid_bits(h), h->prm.cluster_shift, w);
+    h->merged_stale = true;
+    HIPCHK(h, hipGetLastError());
+    h->stage_done = 4;
+    return 0;
+  }
   h->sorted_key = vsv_launch_sort_stage(st, (vsv_sig*)h->c1.p, &c->n_alive1, 2, pos_bits(h), key_bits(h), (vsv_sig*)h->s2s.p, &c->n_alive2, stage_bufs(h),
                         sort_work(h), h->cap_sigs, dctr(h));
   vsv_launch_cluster(st, (vsv_sig*)h->s2s.p, h->sorted_key, &c->n_alive2, h->prm.cluster_shift, pos_bits(h), (vsv_sig*)h->c2.p, stage_bufs(h), (uint64_t*)h->key2.p, dctr(h));
@@ -385,6 +460,15 @@ int enq_merge(vsv_handle* h) {
 int enq_pair(vsv_handle* h) {
   hipStream_t st = h->stream;
   Counters* c = dctr(h);
+  if (h->big_run) {
+    SlimWork w;
+    { int ws = slim_work(h, w); if (ws) return ws; }
+    vsv_slim_pair(st, h->sl_m, &c->n_alive3, &c->n_calls, pos_bits(h), tid_bits(h), h->prm.pair_shift, h->prm.pair_window, (const vsv_sig*)h->s1in.p,
+                  (vsv_call*)h->calls.p, h->dense_pairing, w, c);
+    HIPCHK(h, hipGetLastError());
+    h->stage_done = 5;
+    return 0;
+  }
   vsv_launch_pair(st, (vsv_sig*)h->merged.p, h->sorted_key, &c->n_alive3, h->prm.pair_shift, h->prm.pair_window, (vsv_call*)h->calls_tmp.p, (vsv_call*)h->calls.p,
                   &c->n_calls, stage_bufs(h), (uint64_t*)h->key2.p, (uint32_t*)h->idx2.p, sort_work(h), pos_bits(h), key_bits(h), h->cap_sigs, dctr(h),
                   h->dense_pairing);
@@ -405,7 +489,7 @@ int finish(vsv_handle* h) {
                               // kernel when the merged table gets small again (the rounds cost ~20 launches)
     static const char* force = vsv_dbg_env("VSV_PAIR");          // tests: "rounds" / "walk"
     if (h->host_ctr.max_stretch > 2048) h->dense_pairing = true;
-    else if (h->host_ctr.n_alive3 < 100000) h->dense_pairing = false;
+    else if (h->host_ctr.n_alive3 < 100000 || h->big_run) h->dense_pairing = false;     // (a run on elements measures its stretches whichever way it pairs)
     if (force) h->dense_pairing = force[0] == 'r';
   }
   {  // sort tile size of the NEXT run: small tiles while the largest table stays within ~128 tiles of 4096 rows
@@ -417,8 +501,8 @@ int finish(vsv_handle* h) {
   static const char* trace = vsv_dbg_env("VSV_TRACE_COUNTERS");
   if (trace) {
     const Counters& c = h->host_ctr;
-    fprintf(stderr, "[vsv] n_pool %u n_raw %u n_cand %u n_s1 %u alive %u %u %u calls %u max_stretch %u err %#x\n", c.n_pool, c.n_raw, c.n_cand, c.n_s1,
-            c.n_alive1, c.n_alive2, c.n_alive3, c.n_calls, c.max_stretch, c.err);
+    fprintf(stderr, "[vsv] n_pool %u n_raw %u n_cand %u n_s1 %u alive %u %u %u calls %u max_stretch %u err %#x pad %u %u %u\n", c.n_pool, c.n_raw, c.n_cand, c.n_s1,
+            c.n_alive1, c.n_alive2, c.n_alive3, c.n_calls, c.max_stretch, c.err, c.pad[0], c.pad[1], c.pad[2]);
   }
   if (e & (ERRB_CLR_FALLBACK | ERRB_SORT_FALLBACK)) {
     // ERRB_CLR_FALLBACK: a part of the read-shaped CLR scan held more chunks than its gate state — nothing that run decided can be
@@ -593,6 +677,10 @@ void vsv_destroy(vsv_handle* h) {
                     &h->o_hash, &h->o_recoff, &h->o_first, &h->o_rank, &h->o_nlen, &h->o_noff, &h->o_blob, &h->o_n, &h->o_names, &h->o_nmoff, &h->o_nmlen, &h->gflag, &h->cmask, &h->cs_tra, &h->o_saoff, &h->o_salen, &h->o_saloc, &h->o_sa,
                     &h->o_sqoff, &h->o_sqlen, &h->o_sqloc, &h->o_seq, &h->o_recseq, &h->q_rec, &h->q_start, &h->q_len, &h->q_rev, &h->q_ooff, &h->q_out};
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
+  for (DevBuf& b : h->sl) if (b.p) hipFree(b.p);
+  if (h->sl_hj.p) hipFree(h->sl_hj.p);
+  if (h->sl_done.p) hipFree(h->sl_done.p);
+  if (h->sl_state.p) hipFree(h->sl_state.p);
   if (h->pinned) hipHostFree(h->pinned);
   if (h->pin_buf) hipHostFree(h->pin_buf);
   if (h->names_pin) hipHostFree(h->names_pin);
@@ -1540,6 +1628,13 @@ int vsv_last_scan_ms(vsv_handle* h, float* ms) {
 
 static int table_src(vsv_handle* h, int table, const void** src, int64_t* n_rows, size_t* row, bool* filter) {
   const Counters& c = h->host_ctr;
+  // a run on elements (slim_path.hip) gathers the rows of these two tables when somebody asks for them
+  if (h->big_run && ((table == VSV_T_CLUSTER1 && h->stage_done >= 3 && h->c1_stale) || (table == VSV_T_MERGED && h->stage_done >= 4 && h->merged_stale))) {
+    if (hipSetDevice(h->device) != hipSuccess) return VSV_E_HIP;
+    if (table == VSV_T_CLUSTER1) { vsv_slim_rows(h->stream, h->sl_e2, c.n_alive1, (const vsv_sig*)h->s1in.p, (vsv_sig*)h->c1.p); h->c1_stale = false; }
+    else { vsv_slim_rows(h->stream, h->sl_m, c.n_alive3, (const vsv_sig*)h->s1in.p, (vsv_sig*)h->merged.p); h->merged_stale = false; }
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return VSV_E_HIP;
+  }
   *filter = true;
   *row = sizeof(vsv_sig);
   switch (table) {

@@ -36,11 +36,13 @@ __device__ __forceinline__ int64_t wave_sum64(int64_t v) {
 // thousands of signatures; one thread per RECORD made this the slowest kernel of the contig-like shape). Out of place: every
 // row is written once, by the thread that owns its chain.
 __device__ __forceinline__ int fold_slot(uint32_t meta) { return ((meta & VSV_M_HP2) ? 2 : 0) + ((meta & VSV_M_DEL) ? 1 : 0); }
-__global__ __launch_bounds__(256) void fold_kernel(const vsv_sig* __restrict__ in, vsv_sig* __restrict__ out, const Counters* ctr) {
+__global__ __launch_bounds__(256) void fold_kernel(const vsv_sig* __restrict__ in, vsv_sig* __restrict__ out_rows, const Counters* ctr, SlimOut so) {
   const uint32_t n = ctr->n_raw;
+  // every row is written once (+ its element, when the run works on elements)
+#define FOLD_PUT(IDX, ROW) do { const vsv_sig r_ = (ROW); const uint32_t x_ = (IDX); out_rows[x_] = r_; vsv_slim_emit(so, x_, r_); } while (0)
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const vsv_sig me = in[i];
-    if (me.meta & VSV_M_DEAD) { out[i] = me; continue; }
+    if (me.meta & VSV_M_DEAD) { FOLD_PUT(i, me); continue; }
     const int slot = fold_slot(me.meta);
     const int64_t T = (me.meta & VSV_M_DEL) ? 150 : 380;
     bool head = true;
@@ -74,10 +76,11 @@ __global__ __launch_bounds__(256) void fold_kernel(const vsv_sig* __restrict__ i
           merged = true;
         }
       }
-      if (merged) { vsv_sig dd = s2; dd.meta |= VSV_M_DEAD; out[k] = dd; }
-      else { out[last] = s1; last = k; s1 = s2; }
+      if (merged) { vsv_sig dd = s2; dd.meta |= VSV_M_DEAD; FOLD_PUT(k, dd); }
+      else { FOLD_PUT(last, s1); last = k; s1 = s2; }
     }
-    out[last] = s1;
+    FOLD_PUT(last, s1);
+#undef FOLD_PUT
   }
 }
 
@@ -502,7 +505,7 @@ template <int SE_GROUP>
 __global__ __launch_bounds__(256) void split_eval(RecView rv, const uint64_t* __restrict__ okey, const uint32_t* __restrict__ oval,
                                                   const uint64_t* __restrict__ ckey, const uint32_t* __restrict__ crec,
                                                   SplitCfg c, int dtype, int max_svlen, vsv_sig* __restrict__ s1in,
-                                                  uint32_t cap, Counters* ctr) {
+                                                  uint32_t cap, Counters* ctr, SlimOut sl) {
   const uint32_t n = ctr->n_cand, n_raw = ctr->n_raw;
   if (blockIdx.x == 0 && threadIdx.x == 0) { const uint32_t s1 = n_raw + n; ctr->n_s1 = s1 < cap ? s1 : cap; }
   const int lane = threadIdx.x & (SE_GROUP - 1), wlane = threadIdx.x & 63;
@@ -555,6 +558,7 @@ __global__ __launch_bounds__(256) void split_eval(RecView rv, const uint64_t* __
     if (lane != 0 || !live || !room) continue;
     const vsv_sig out = split_rules(rv, need, i1, i2, hap, last1, first2, rf1, rl1, rl2, dtype, max_svlen, ctr);
     s1in[n_raw + q] = out;
+    vsv_slim_emit(sl, n_raw + q, out);
   }
 }
 
@@ -953,9 +957,9 @@ void vsv_launch_clr_gate(hipStream_t st, const RecView& rv, uint8_t* gflag, Coun
 }
 
 // raw (T_RAW, written by place_raw) -> s1in: folded on the contig path, combined for sig_extract, a plain copy otherwise
-void vsv_launch_fold(hipStream_t st, const vsv_sig* raw, vsv_sig* s1in, const RecView& rv, const vsv_params& p, Counters* ctr, int grid) {
+void vsv_launch_fold(hipStream_t st, const vsv_sig* raw, vsv_sig* s1in, const RecView& rv, const vsv_params& p, Counters* ctr, int grid, const SlimOut& so) {
   const int dtype = p.dtype;
-  if (dtype == VSV_DTYPE_HIFI || dtype == VSV_DTYPE_ONT || dtype == VSV_DTYPE_CLR) { fold_kernel<<<grid, 256, 0, st>>>(raw, s1in, ctr); return; }
+  if (dtype == VSV_DTYPE_HIFI || dtype == VSV_DTYPE_ONT || dtype == VSV_DTYPE_CLR) { fold_kernel<<<grid, 256, 0, st>>>(raw, s1in, ctr, so); return; }
   copy_rows<vsv_sig><<<grid, 256, 0, st>>>(raw, &ctr->n_raw, s1in);
   if (dtype == VSV_DTYPE_CUTESV) combine_kernel<<<EW_GRID, 256, 0, st>>>(s1in, ctr, p.merge_ins_threshold, p.merge_del_threshold);
 }
@@ -1015,12 +1019,12 @@ SplitSorted vsv_launch_split_candidates(hipStream_t st, const RecView& rv, const
 }
 
 void vsv_launch_split_eval(hipStream_t st, const RecView& rv, const vsv_params& p, int n_tids, const SplitSorted& so, vsv_sig* s1in,
-                           uint32_t cap, Counters* ctr, int grid) {
+                           uint32_t cap, Counters* ctr, int grid, const SlimOut& sl) {
   if (rv.n_records <= 0 || !so.okey) { set_n_s1<<<1, 1, 0, st>>>(ctr, cap); return; }
   const SplitCfg c = split_cfg(rv, p, n_tids);
   const int eg = grid * 8 < 1024 ? 1024 : (grid * 8 > 8192 ? 8192 : grid * 8);
-  if (vsv_scan_is_long(rv, p)) split_eval<64><<<eg, 256, 0, st>>>(rv, so.okey, so.oval, so.ckey, so.crec, c, p.dtype, p.max_split_svlen, s1in, cap, ctr);
-  else split_eval<8><<<eg, 256, 0, st>>>(rv, so.okey, so.oval, so.ckey, so.crec, c, p.dtype, p.max_split_svlen, s1in, cap, ctr);
+  if (vsv_scan_is_long(rv, p)) split_eval<64><<<eg, 256, 0, st>>>(rv, so.okey, so.oval, so.ckey, so.crec, c, p.dtype, p.max_split_svlen, s1in, cap, ctr, sl);
+  else split_eval<8><<<eg, 256, 0, st>>>(rv, so.okey, so.oval, so.ckey, so.crec, c, p.dtype, p.max_split_svlen, s1in, cap, ctr, sl);
 }
 
 // sort rows `in[0,n)` by the stage key into `sorted`, publish the alive count

@@ -1,0 +1,1145 @@
+// slim_path.hip — the stages behind the scan for LARGE signature tables (10^6-10^7 rows: contig alignments piled on one
+// chromosome; config 3's ONT tables):
+//   sort_sig                   H:170-179     -> sl_hist / sl_scan / sl_scatter (stable LSD passes over 16-byte elements)
+//   cluster_del / cluster_ins  H:196-288     -> sl_cluster
+//   merge_all                  H:478-499     -> the same two kernels on the stage-2 / stage-3 keys
+//   pair_sig                   H:548-603     -> sl_pair_prep + sl_pair_walk (or sl_pair_round* on dense piles) + the call sort
+// (paths relative to bin/VolcanoSV-vc/Large_INDEL/extract_contig_signature_Hifi.py in the reference).
+//
+// Everything a stage decides depends on (list, pos, svlen, type) only, and every row a stage passes on is a verbatim copy of a
+// row of the stage-1 input table (the fold's output + the split rows): cluster representatives, merged rows and the kept
+// signature of a call are all rows of that table. So the stages run on SLIM elements — {stage key, svlen, row index | type} =
+// 16 bytes instead of 32-byte rows + 8-byte keys + 4-byte indices — and the 32-byte rows are gathered exactly once, for the call
+// table (and for VSV_T_CLUSTER1 / VSV_T_MERGED when a caller asks for them). A stage that drops a row writes a dead element; the
+// next sort's first pass skips dead elements, so its output is compact and its element count is the live count. Sorting is
+// stable LSD with 8-9 bit digits over 4096-element tiles: 16 elements of a digit per tile = 256 contiguous bytes per (tile,
+// digit), where the 11-bit digits of radix_sort.hip (tuned for the launch-bound small tables) write 2 elements = partial lines.
+#include "vsv_device.h"
+
+namespace {
+
+struct __align__(16) Slim {
+  uint64_t key;     // stage key (vsv_key_stage layout), VSV_KEY_DEAD = dropped
+  int32_t svlen;    // (call elements: index of the hp2 mate in the merged table, -1 = none)
+  uint32_t idx;     // row of the stage-1 input table | SL_DEL  (call elements: slot in the merged table)
+};
+constexpr uint32_t SL_DEL = 0x80000000u;
+constexpr uint32_t SL_ROW = 0x7FFFFFFFu;
+
+__device__ __forceinline__ Slim ld_slim(const Slim* p) {
+  const uint4 v = *reinterpret_cast<const uint4*>(p);
+  Slim s;
+  s.key = (uint64_t)v.x | ((uint64_t)v.y << 32); s.svlen = (int32_t)v.z; s.idx = v.w;
+  return s;
+}
+__device__ __forceinline__ void st_slim(Slim* p, const Slim& s) {
+  *reinterpret_cast<uint4*>(p) = make_uint4((uint32_t)s.key, (uint32_t)(s.key >> 32), (uint32_t)s.svlen, s.idx);
+}
+__device__ __forceinline__ Slim dead_slim() { Slim s; s.key = VSV_KEY_DEAD; s.svlen = 0; s.idx = 0; return s; }
+
+struct KeyFmt {      // bit layout of the run's keys
+  int pb;            // position bits; hap at pb + 2, type at pb + 1, source at pb, tid above pb + 3
+  __device__ __forceinline__ int32_t pos(uint64_t k) const {
+    const uint32_t kp = pb >= 32 ? (uint32_t)k : (uint32_t)k & ((1u << pb) - 1u);
+    return (int32_t)(kp - (uint32_t)VSV_POS_BIAS);
+  }
+};
+
+// exact integer form of the reference's ratio predicates, as vsv_match (vsv_device.h) on (pos, svlen, type)
+__device__ __forceinline__ bool sl_match(int32_t p1, int32_t v1, int32_t p2, int32_t v2, bool del, int max_shift) {
+  int64_t shift = (int64_t)p1 - p2;
+  if (shift < 0) shift = -shift;
+  if (shift > max_shift) return false;
+  const int64_t l1 = v1, l2 = v2, mn = l1 < l2 ? l1 : l2, mx = l1 < l2 ? l2 : l1;
+  if (2 * mn < mx) return false;
+  if (del) {
+    const int64_t s1 = p1, e1 = s1 + l1, s2 = p2, e2 = s2 + l2;
+    const int64_t ov = (e1 < e2 ? e1 : e2) - (s1 > s2 ? s1 : s2);
+    if (2 * ov < mn) return false;
+  }
+  return true;
+}
+
+// ---- rows -> slim elements (stage-1 keys) ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sl_from_rows(const vsv_sig* __restrict__ rows, const uint32_t* __restrict__ d_n, int pb, int tid_lo, int tid_bits,
+                                                    Slim* __restrict__ out, uint32_t* __restrict__ err) {
+  const uint32_t n = *d_n;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const vsv_sig v = rows[i];
+    Slim s;
+    s.key = vsv_key_stage(v, 1, pb, tid_lo);
+    s.svlen = v.svlen;
+    s.idx = i | ((v.meta & VSV_M_DEL) ? SL_DEL : 0u);
+    if (!(v.meta & VSV_M_DEAD) && ((pb < 32 && (vsv_kpos(v.pos) >> pb) != 0) || ((uint32_t)(v.tid - tid_lo) >> tid_bits) != 0))
+      atomicOr(err, ERRB_RANGE);            // max_pos hint too small / tid outside [tid_lo, n_tids)
+    st_slim(out + i, s);
+  }
+}
+
+// ---- stable LSD radix sort of slim elements ----------------------------------------------------------------------------------
+constexpr int SL_WAVES = 4, SL_ROUNDS = 16;
+constexpr uint32_t SL_TILE = SL_WAVES * SL_ROUNDS * 64;      // 4096 elements
+
+// where the elements of a sort's first pass come from: an array, or the pairing state (the call elements are never materialised)
+struct SrcSlim {
+  const Slim* p;
+  __device__ __forceinline__ Slim at(uint32_t i) const { return ld_slim(p + i); }
+};
+// Call element of merged slot i (pair_sig's output rows, H:571-592): an hp1 row is a call whatever happened — alone (0/1) or with
+// its mate (1/1: the longer of the two signatures is kept, the hp1 one on ties, H:583-586); an hp2 row is a call iff nobody took
+// it. Key = (tid, pos) of the kept signature; svlen field = the mate's slot; idx = the slot itself.
+struct SrcCalls {
+  const Slim* m; const int32_t* st; int hap_bit;
+  __device__ __forceinline__ Slim at(uint32_t i) const {
+    const Slim me = ld_slim(m + i);
+    const uint64_t hb = 1ull << hap_bit;
+    Slim c;
+    c.idx = i;
+    const int32_t s = st[i];
+    if (me.key & hb) {
+      c.svlen = -1;
+      c.key = s == -1 ? (me.key & ~hb) : VSV_KEY_DEAD;
+    } else {
+      c.svlen = s;
+      uint64_t k = me.key;
+      if (s >= 0) { const Slim mate = ld_slim(m + s); if (!(me.svlen > mate.svlen)) k = mate.key & ~hb; }
+      c.key = k;
+    }
+    return c;
+  }
+};
+
+template <int BITS>
+__device__ __forceinline__ uint64_t sl_match_digit(uint32_t d, bool valid) {
+  uint64_t m = __ballot(valid);
+#pragma unroll
+  for (int b = 0; b < BITS; ++b) {
+    const uint64_t bal = __ballot((d >> b) & 1u);
+    m &= ((d >> b) & 1u) ? bal : ~bal;
+  }
+  return m;
+}
+__device__ __forceinline__ uint32_t sl_tiles(uint32_t n) { return (n + SL_TILE - 1) / SL_TILE; }
+
+// hist[tile][d] = elements of the tile with digit d (dead elements of a first pass do not count); totals[d] += the same
+template <int BITS, typename SRC, bool SKIP_DEAD>
+__global__ __launch_bounds__(256) void sl_hist(SRC src, const uint32_t* __restrict__ d_n, int shift, uint32_t* __restrict__ hist, uint32_t* __restrict__ totals) {
+  constexpr int BINS = 1 << BITS;
+  __shared__ uint32_t cnt[BINS];
+  const uint32_t n = *d_n, ntiles = sl_tiles(n);
+  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int d = threadIdx.x; d < BINS; d += 256) cnt[d] = 0;
+    __syncthreads();
+    const uint32_t base = tile * SL_TILE;
+#pragma unroll 4
+    for (int k = 0; k < (int)SL_TILE / 256; ++k) {
+      const uint32_t i = base + k * 256 + threadIdx.x;
+      if (i < n) {
+        const uint64_t key = src.at(i).key;
+        if (!SKIP_DEAD || key != VSV_KEY_DEAD) atomicAdd(&cnt[(uint32_t)(key >> shift) & (BINS - 1)], 1u);
+      }
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < BINS; d += 256) {
+      const uint32_t c = cnt[d];
+      hist[(size_t)tile * BINS + d] = c;
+      if (c) atomicAdd(&totals[d], c);
+    }
+    __syncthreads();
+  }
+}
+
+// hist[tile][d] -> exclusive offsets in (digit, tile) order. A block owns 16 digits x 64 groups of tiles (1024 threads); digit bases
+// from the totals. Block 0 also publishes the pass's element count (= live elements, for a first pass) where asked.
+template <int BITS>
+__global__ __launch_bounds__(1024) void sl_scan(uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals, const uint32_t* __restrict__ d_n,
+                                                uint32_t* __restrict__ d_total) {
+  constexpr int BINS = 1 << BITS, DG = 16, TG = 64;
+  __shared__ uint32_t red[1024];
+  __shared__ uint32_t dig[DG];
+  __shared__ uint32_t part[TG][DG];
+  const uint32_t ntiles = sl_tiles(*d_n);
+  const int t = threadIdx.x, dl = t & (DG - 1), g = t / DG;
+  const int d0 = blockIdx.x * DG, d = d0 + dl;
+  auto block_sum = [&](uint32_t v) -> uint32_t {
+    __syncthreads();
+    red[t] = v;
+    __syncthreads();
+    for (int k = 512; k > 0; k >>= 1) { if (t < k) red[t] += red[t + k]; __syncthreads(); }
+    return red[0];
+  };
+  uint32_t before = 0;
+  for (int i = t; i < d0; i += 1024) before += totals[i];
+  const uint32_t prev = block_sum(before);          // elements with a digit in front of this block's
+  if (blockIdx.x == 0 && d_total) {                  // (uniform per block)
+    uint32_t all = 0;
+    for (int i = t; i < BINS; i += 1024) all += totals[i];
+    all = block_sum(all);
+    if (t == 0) *d_total = all;
+  }
+  const uint32_t mine = t < DG ? totals[d] : 0;
+  if (t < DG) dig[t] = mine;
+  __syncthreads();
+  for (int k = 1; k < DG; k <<= 1) {
+    const uint32_t v = (t < DG && t >= k) ? dig[t - k] : 0;
+    __syncthreads();
+    if (t < DG) dig[t] += v;
+    __syncthreads();
+  }
+  if (t < DG) dig[t] = prev + dig[t] - mine;        // exclusive digit base
+  const uint32_t per = (ntiles + TG - 1) / TG;
+  const uint32_t t0 = min(ntiles, (uint32_t)g * per), t1 = min(ntiles, t0 + per);
+  uint32_t sum = 0;
+  for (uint32_t tb = t0; tb < t1; tb += 16) {
+    uint32_t c[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) c[k] = (tb + k < t1) ? hist[(size_t)(tb + k) * BINS + d] : 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sum += c[k];
+  }
+  part[g][dl] = sum;
+  __syncthreads();
+  uint32_t run = dig[dl];
+  for (int gg = 0; gg < g; ++gg) run += part[gg][dl];
+  for (uint32_t tb = t0; tb < t1; tb += 16) {
+    uint32_t c[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) c[k] = (tb + k < t1) ? hist[(size_t)(tb + k) * BINS + d] : 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      if (tb + k < t1) hist[(size_t)(tb + k) * BINS + d] = run;
+      run += c[k];
+    }
+  }
+}
+
+// stable scatter of one pass: ranks inside a wave from ballot matches, per-wave running counters in LDS (as rs_scatter)
+template <int BITS, typename SRC, bool SKIP_DEAD>
+__global__ __launch_bounds__(256) void sl_scatter(SRC src, const uint32_t* __restrict__ d_n, int shift, const uint32_t* __restrict__ hist, Slim* __restrict__ out) {
+  constexpr int BINS = 1 << BITS;
+  __shared__ uint32_t wcnt[SL_WAVES][BINS];
+  const uint32_t n = *d_n, ntiles = sl_tiles(n);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint64_t lt = (1ull << lane) - 1ull;
+  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int d = threadIdx.x; d < BINS; d += 256)
+#pragma unroll
+      for (int w = 0; w < SL_WAVES; ++w) wcnt[w][d] = 0;
+    __syncthreads();
+    const uint32_t wbase = tile * SL_TILE + wv * (SL_ROUNDS * 64);
+    Slim e_[SL_ROUNDS];
+    uint32_t rk[SL_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < SL_ROUNDS; ++r) {
+      const uint32_t i = wbase + r * 64 + lane;
+      bool ok = i < n;
+      if (ok) e_[r] = src.at(i); else e_[r] = dead_slim();
+      if (SKIP_DEAD) ok = ok && e_[r].key != VSV_KEY_DEAD;
+      const uint32_t d = (uint32_t)(e_[r].key >> shift) & (BINS - 1);
+      const uint64_t m = sl_match_digit<BITS>(d, ok);
+      const uint32_t old = ok ? wcnt[wv][d] : 0;
+      __builtin_amdgcn_wave_barrier();
+      if (ok && (m & lt) == 0) wcnt[wv][d] = old + (uint32_t)__popcll(m);
+      __builtin_amdgcn_wave_barrier();
+      rk[r] = ok ? old + (uint32_t)__popcll(m & lt) : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < BINS; d += 256) {  // exclusive prefix of the digit's count over the waves + global base
+      uint32_t run = hist[(size_t)tile * BINS + d];
+#pragma unroll
+      for (int w = 0; w < SL_WAVES; ++w) { const uint32_t c = wcnt[w][d]; wcnt[w][d] = run; run += c; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SL_ROUNDS; ++r) {
+      if (rk[r] != 0xFFFFFFFFu) {
+        const uint32_t d = (uint32_t)(e_[r].key >> shift) & (BINS - 1);
+        st_slim(out + wcnt[wv][d] + rk[r], e_[r]);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---- the same passes in ONE kernel each (chained scan, "onesweep") -----------------------------------------------------------------
+// sl_hist + sl_scan + sl_scatter read every element twice per pass and keep a [tile][digit] matrix in between. Here one kernel
+// (sl_digit_totals) reads the sort's input once for the digit totals of ALL its passes — the multiset of live keys is the same in
+// every pass — and a pass is a single kernel: a block takes the next tile in order (a ticket), ranks its elements in registers,
+// publishes its per-digit counts and gets the counts of the tiles in front of it by looking BACK at what they have published
+// (aggregate first, inclusive prefix once known; thread d follows digit d). Tickets are taken in launch order, so every tile a
+// block waits for belongs to a block that is already running. State words carry an epoch (one per pass launch), so the state
+// buffer is never cleared. One read and one write of the elements per pass.
+constexpr uint64_t OS_AGG = 1ull << 32, OS_PFX = 2ull << 32;
+constexpr int OS_EPOCH_SHIFT = 34;
+constexpr int OS_MAX_PASSES = 8;
+
+template <typename SRC, bool SKIP_DEAD>
+__global__ __launch_bounds__(256) void sl_digit_totals(SRC src, const uint32_t* __restrict__ d_n, int passes, int bits, uint32_t* __restrict__ totals /* [passes][2048] */) {
+  __shared__ uint32_t cnt[OS_MAX_PASSES][512];
+  const uint32_t n = *d_n, ntiles = sl_tiles(n), bins = 1u << bits;
+  for (uint32_t k = threadIdx.x; k < (uint32_t)passes * 512u; k += 256) cnt[k >> 9][k & 511u] = 0;
+  __syncthreads();
+  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const uint32_t base = tile * SL_TILE;
+#pragma unroll 4
+    for (int k = 0; k < (int)SL_TILE / 256; ++k) {
+      const uint32_t i = base + k * 256 + threadIdx.x;
+      if (i < n) {
+        const uint64_t key = src.at(i).key;
+        if (!SKIP_DEAD || key != VSV_KEY_DEAD)
+          for (int p = 0; p < passes; ++p) atomicAdd(&cnt[p][(uint32_t)(key >> (p * bits)) & (bins - 1u)], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < (uint32_t)passes * bins; k += 256) {
+    const uint32_t p = k / bins, d = k % bins, c = cnt[p][d];
+    if (c) atomicAdd(&totals[(size_t)p * 2048 + d], c);
+  }
+}
+
+template <int BITS, typename SRC, bool FIRST>
+__global__ __launch_bounds__(256) void sl_onesweep(SRC src, const uint32_t* __restrict__ d_slots, int shift, uint32_t* __restrict__ totals /* this pass: digit totals, [2047] = ticket */,
+                                                   uint64_t* __restrict__ state, uint64_t epoch, Slim* __restrict__ out, uint32_t* __restrict__ d_live) {
+  constexpr int BINS = 1 << BITS, DPT = BINS / 256;
+  __shared__ uint32_t wcnt[SL_WAVES][BINS];
+  __shared__ uint32_t dbase[BINS];
+  __shared__ uint32_t wsum[SL_WAVES];
+  __shared__ uint32_t s_tile;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint64_t lt = (1ull << lane) - 1ull;
+  // digit bases = exclusive scan of the totals (thread t owns digits [t * DPT, (t + 1) * DPT)); their sum = the live elements
+  uint32_t tt[DPT], mine = 0;
+#pragma unroll
+  for (int k = 0; k < DPT; ++k) { tt[k] = totals[threadIdx.x * DPT + k]; mine += tt[k]; }
+  uint32_t incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += o; }
+  if (lane == 63) wsum[wv] = incl;
+  __syncthreads();
+  uint32_t run0 = incl - mine;
+  for (int w = 0; w < wv; ++w) run0 += wsum[w];
+#pragma unroll
+  for (int k = 0; k < DPT; ++k) { dbase[threadIdx.x * DPT + k] = run0; run0 += tt[k]; }
+  const uint32_t live = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  // a first pass walks the input SLOTS (dead ones included) and publishes the live count; the others walk the live elements
+  const uint32_t n = FIRST ? *d_slots : live, ntiles = sl_tiles(n);
+  if (FIRST && d_live && blockIdx.x == 0 && threadIdx.x == 0) *d_live = live;
+  const uint64_t ep = epoch << OS_EPOCH_SHIFT;
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) s_tile = atomicAdd(&totals[2047], 1u);
+    for (int d = threadIdx.x; d < BINS; d += 256)
+#pragma unroll
+      for (int w = 0; w < SL_WAVES; ++w) wcnt[w][d] = 0;
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    if (tile >= ntiles) break;
+    const uint32_t wbase = tile * SL_TILE + wv * (SL_ROUNDS * 64);
+    Slim e_[SL_ROUNDS];
+    uint32_t rk[SL_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < SL_ROUNDS; ++r) {
+      const uint32_t i = wbase + r * 64 + lane;
+      bool ok = i < n;
+      if (ok) e_[r] = src.at(i); else e_[r] = dead_slim();
+      if (FIRST) ok = ok && e_[r].key != VSV_KEY_DEAD;
+      const uint32_t d = (uint32_t)(e_[r].key >> shift) & (BINS - 1);
+      const uint64_t m = sl_match_digit<BITS>(d, ok);
+      const uint32_t old = ok ? wcnt[wv][d] : 0;
+      __builtin_amdgcn_wave_barrier();
+      if (ok && (m & lt) == 0) wcnt[wv][d] = old + (uint32_t)__popcll(m);
+      __builtin_amdgcn_wave_barrier();
+      rk[r] = ok ? old + (uint32_t)__popcll(m & lt) : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < DPT; ++k) {
+      const int d = threadIdx.x * DPT + k;
+      uint32_t c[SL_WAVES], cnt = 0;
+#pragma unroll
+      for (int w = 0; w < SL_WAVES; ++w) { c[w] = wcnt[w][d]; cnt += c[w]; }
+      uint64_t* my = state + (size_t)tile * BINS + d;
+      uint32_t excl = 0;
+      if (tile == 0) __hip_atomic_store(my, ep | OS_PFX | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else {
+        __hip_atomic_store(my, ep | OS_AGG | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (uint32_t t = tile - 1;; --t) {                   // look back: aggregates until a tile that knows its inclusive prefix
+          uint64_t v;
+          for (;;) {
+            v = __hip_atomic_load(state + (size_t)t * BINS + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((v >> OS_EPOCH_SHIFT) == epoch && (v & (OS_AGG | OS_PFX))) break;
+            __builtin_amdgcn_s_sleep(1);
+          }
+          excl += (uint32_t)v;
+          if ((v & OS_PFX) || t == 0) break;
+        }
+        __hip_atomic_store(my, ep | OS_PFX | (uint64_t)(excl + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      uint32_t run = dbase[d] + excl;
+#pragma unroll
+      for (int w = 0; w < SL_WAVES; ++w) { wcnt[w][d] = run; run += c[w]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SL_ROUNDS; ++r) {
+      if (rk[r] != 0xFFFFFFFFu) {
+        const uint32_t d = (uint32_t)(e_[r].key >> shift) & (BINS - 1);
+        st_slim(out + wcnt[wv][d] + rk[r], e_[r]);
+      }
+    }
+  }
+}
+
+// ---- seeded greedy clustering on the sorted elements (H:196-288) ------------------------------------------------------------
+// A run = maximal stretch of one list whose consecutive positions differ by <= max_shift; no match crosses a run boundary, so
+// runs are independent and the reference's full scans reduce to a scan inside the run. The lane that holds a run's first element
+// performs the sequential greedy exactly (seed = first unassigned element, members = unassigned elements that match the SEED,
+// representative = first longest member, H:236-247); runs of more than SL_LONG_RUN elements are taken over by the lane's whole
+// wave. Slot i of the output = the representative (with the next stage's key: `drop` cleared) if element i is a seed, dead
+// otherwise — seed order. A block stages its 1024 slots (+ a halo) in LDS: run heads, run ends and the greedy's inner loop read
+// there instead of chasing dependent global loads.
+constexpr uint32_t SL_LONG_RUN = 48;
+constexpr int CL_TILE = 1024, CL_HALO = 127;       // LDS holds slots [t0 - 1, t0 + CL_TILE + CL_HALO)
+
+__device__ __forceinline__ int32_t ld_i32(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_i32(int32_t* p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// One wave on a long run [i, e): seeds stay sequential, the scan of a seed's window and the search for the next seed are 64-wide.
+// cl[] (one word per slot) is accessed with agent-scope relaxed atomics. Called by ALL 64 lanes with wave-uniform (i, e).
+__device__ __forceinline__ void sl_cluster_long(const Slim* __restrict__ s, int max_shift, KeyFmt kf, uint64_t drop, int32_t* __restrict__ cl,
+                                                Slim* __restrict__ out, const uint32_t i, const uint32_t e, const int lane) {
+  for (uint32_t k = i + lane; k < e; k += 64) st_i32(&cl[k], -1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  uint32_t a = i;
+  while (a < e) {
+    const Slim s1 = ld_slim(s + a);
+    const int32_t p1 = kf.pos(s1.key);
+    const bool del = (s1.idx & SL_DEL) != 0;
+    if (lane == 0) st_i32(&cl[a], (int32_t)a);
+    uint64_t best = ((uint64_t)(uint32_t)s1.svlen << 32) | (0xFFFFFFFFu - a);   // max length, then lowest index
+    for (uint32_t b0 = a + 1; b0 < e; b0 += 64) {
+      const uint32_t b = b0 + lane;
+      const bool valid = b < e;
+      Slim s2 = s1;
+      if (valid) s2 = ld_slim(s + b);
+      const int32_t p2 = kf.pos(s2.key);
+      const bool inwin = valid && (int64_t)p2 - p1 <= max_shift;
+      if (__ballot(inwin) == 0) break;          // positions ascend: the whole tile is beyond the window
+      if (inwin && ld_i32(&cl[b]) == -1 && sl_match(p1, s1.svlen, p2, s2.svlen, del, max_shift)) {
+        st_i32(&cl[b], (int32_t)a);
+        const uint64_t c = ((uint64_t)(uint32_t)s2.svlen << 32) | (0xFFFFFFFFu - b);
+        if (c > best) best = c;
+      }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { const uint64_t o = __shfl_xor(best, d, 64); if (o > best) best = o; }
+    if (lane == 0) { Slim rep = ld_slim(s + (0xFFFFFFFFu - (uint32_t)best)); rep.key &= ~drop; st_slim(out + a, rep); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    uint32_t nxt = e;                            // next seed: first unassigned element after a
+    for (uint32_t b0 = a + 1; b0 < e; b0 += 64) {
+      const uint32_t b = b0 + lane;
+      const uint64_t free_m = __ballot(b < e && ld_i32(&cl[b]) == -1);
+      if (free_m) { nxt = b0 + (uint32_t)__builtin_ctzll(free_m); break; }
+    }
+    a = nxt;
+  }
+  for (uint32_t k = i + lane; k < e; k += 64) if (ld_i32(&cl[k]) != (int32_t)k) st_slim(out + k, dead_slim());
+}
+
+__global__ __launch_bounds__(256) void sl_cluster(const Slim* __restrict__ s, const uint32_t* __restrict__ d_n, int max_shift, KeyFmt kf, int drop_bit,
+                                                  Slim* __restrict__ out, int32_t* __restrict__ cl) {
+  constexpr int LDS_N = CL_TILE + CL_HALO + 1;
+  __shared__ uint4 sh[LDS_N];
+  const uint32_t n = *d_n;
+  const int lane = threadIdx.x & 63;
+  const uint64_t drop = 1ull << drop_bit;
+  const uint32_t ntiles = (n + CL_TILE - 1) / CL_TILE;
+  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const uint32_t t0 = tile * CL_TILE;
+    __syncthreads();
+    for (int k = threadIdx.x; k < LDS_N; k += 256) {
+      const int64_t slot = (int64_t)t0 - 1 + k;
+      if (slot >= 0 && slot < (int64_t)n) sh[k] = *reinterpret_cast<const uint4*>(s + slot);
+    }
+    __syncthreads();
+    auto get = [&](uint32_t k) -> Slim {            // element k: from LDS when the block staged it
+      const uint32_t rel = k + 1u - t0;
+      uint4 v;
+      if (rel < (uint32_t)LDS_N) v = sh[rel]; else v = *reinterpret_cast<const uint4*>(s + k);
+      Slim x;
+      x.key = (uint64_t)v.x | ((uint64_t)v.y << 32); x.svlen = (int32_t)v.z; x.idx = v.w;
+      return x;
+    };
+#pragma unroll 1
+    for (int r = 0; r < CL_TILE / 256; ++r) {
+      const uint32_t i = t0 + (uint32_t)r * 256u + threadIdx.x;
+      bool is_long = false;
+      uint32_t e = 0;
+      if (i < n) {
+        const Slim me = get(i);
+        const uint64_t lk = me.key >> kf.pb;
+        bool head = true;
+        if (i > 0) { const Slim pv = get(i - 1); head = !((pv.key >> kf.pb) == lk && (int64_t)kf.pos(me.key) - kf.pos(pv.key) <= max_shift); }
+        if (head) {
+          e = i + 1;
+          int32_t last = kf.pos(me.key);
+          while (e < n && e - i <= SL_LONG_RUN) {
+            const Slim x = get(e);
+            const int32_t px = kf.pos(x.key);
+            if ((x.key >> kf.pb) != lk || (int64_t)px - last > max_shift) break;
+            last = px; ++e;
+          }
+          if (e - i > SL_LONG_RUN) {
+            is_long = true;
+            while (e < n) {
+              const Slim x = get(e);
+              const int32_t px = kf.pos(x.key);
+              if ((x.key >> kf.pb) != lk || (int64_t)px - last > max_shift) break;
+              last = px; ++e;
+            }
+          } else {
+            const uint32_t len = e - i;
+            const bool del = (me.idx & SL_DEL) != 0;
+            uint64_t assigned = 0;
+            for (uint32_t a = 0; a < len; ++a) {
+              if ((assigned >> a) & 1ull) { st_slim(out + i + a, dead_slim()); continue; }
+              const Slim s1 = get(i + a);
+              const int32_t p1 = kf.pos(s1.key);
+              uint32_t best = a;
+              int32_t best_len = s1.svlen;
+              for (uint32_t b = a + 1; b < len; ++b) {
+                const Slim s2 = get(i + b);
+                const int32_t p2 = kf.pos(s2.key);
+                if ((int64_t)p2 - p1 > max_shift) break;
+                if ((assigned >> b) & 1ull) continue;
+                if (sl_match(p1, s1.svlen, p2, s2.svlen, del, max_shift)) {
+                  assigned |= 1ull << b;
+                  if (s2.svlen > best_len) { best = b; best_len = s2.svlen; }
+                }
+              }
+              Slim rep = best == a ? s1 : get(i + best);
+              rep.key &= ~drop;
+              st_slim(out + i + a, rep);
+            }
+          }
+        }
+      }
+      uint64_t lm = __ballot(is_long);
+      while (lm) {
+        const int src = __builtin_ctzll(lm);
+        lm &= lm - 1;
+        sl_cluster_long(s, max_shift, kf, drop, cl, out, (uint32_t)__shfl((int)i, src, 64), (uint32_t)__shfl((int)e, src, 64), lane);
+      }
+    }
+  }
+}
+
+// ---- haplotype pairing (pair_sig, H:548-592) on the merged elements --------------------------------------------------------------
+// Merged table m sorted by (tid, hap, pos). The reference walks the hp1 rows in order and gives each the first free hp2 row of its
+// type within pair_shift that matches — first come, first served. Only rows of one type compete for an hp2 row, so the walk
+// decomposes by type, and inside a type it can be cut between two consecutive hp1 rows a < b wherever no hp2 row of the type lies
+// in [pos_b - shift, pos_a + right]: whatever the rows up to a can reach (pos <= pos_a + right) lies in front of whatever the rows
+// from b on can reach (pos >= pos_b - shift). sl_pair_prep finds every hp1 row's first candidate (jlo) and marks the rows that
+// start such a stretch; sl_pair_walk runs the sequential rule per stretch (a lane, or the lane's whole wave beyond SL_LONG_RUN
+// rows). st[]: hp1 slot -> its mate's slot or -1; hp2 slot -> the hp1 slot that took it or -1.
+__device__ __forceinline__ uint32_t sl_lower_bound(const Slim* __restrict__ m, uint32_t n, uint64_t target) {
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (m[mid].key >= target) hi = mid; else lo = mid + 1; }
+  return lo;
+}
+constexpr uint32_t PJ_HEAD = 0x80000000u;
+
+// The kernel also looks for GIANT stretches (a pile of contigs so dense that a type's rows go on for thousands of rows without a
+// cut): a window of 2048 consecutive slots that holds >= 512 hp1 rows of a type and no stretch start among them reports
+// max_stretch = 4096, which makes the handle pair its NEXT run in rounds (and a window with starts everywhere lets it go back).
+constexpr uint32_t PJ_WINDOW = 2048;
+__global__ __launch_bounds__(256) void sl_pair_prep(const Slim* __restrict__ m, const uint32_t* __restrict__ d_n, KeyFmt kf, int pair_shift, int right,
+                                                    uint32_t* __restrict__ hj, int32_t* __restrict__ st, uint32_t* __restrict__ max_stretch) {
+  __shared__ uint32_t rows_t[2], heads_t[2];
+  const uint32_t n = *d_n;
+  const int sh_hap = kf.pb + 2, sh_tid = kf.pb + 3;
+  for (uint32_t base = blockIdx.x * PJ_WINDOW; base < n; base += gridDim.x * PJ_WINDOW) {
+    if (threadIdx.x < 2) { rows_t[threadIdx.x] = 0; heads_t[threadIdx.x] = 0; }
+    __syncthreads();
+    for (uint32_t k8 = 0; k8 < PJ_WINDOW / 256; ++k8) {
+      const uint32_t i = base + k8 * 256u + threadIdx.x;
+      if (i >= n) continue;
+      const Slim me = ld_slim(m + i);
+      st[i] = -1;
+      if ((me.key >> sh_hap) & 1ull) { hj[i] = 0; continue; }
+      const int32_t pb_ = kf.pos(me.key);
+      const uint64_t tk = me.key >> sh_tid;
+      const uint32_t jlo = sl_lower_bound(m, n, (tk << sh_tid) | (1ull << sh_hap) | vsv_kpos((int32_t)max((int64_t)pb_ - pair_shift, (int64_t)-VSV_POS_BIAS)));
+      bool head = true;
+      const uint32_t t = me.idx & SL_DEL;
+      const uint64_t hp1_prefix = me.key >> sh_hap, hp2_prefix = hp1_prefix | 1ull;
+      for (uint32_t k = i; k-- > 0;) {
+        const Slim x = ld_slim(m + k);
+        if ((x.key >> sh_hap) != hp1_prefix) break;
+        const int32_t pa = kf.pos(x.key);
+        if ((int64_t)pb_ - pa > (int64_t)pair_shift + right) break;      // nothing earlier shares a candidate with this row
+        if ((x.idx & SL_DEL) != t) continue;
+        // the previous row of this type: the walk can be cut here iff no hp2 row of the type lies in [pos_b - shift, pos_a + right]
+        for (uint32_t j = jlo; j < n; ++j) {
+          const Slim y = ld_slim(m + j);
+          if ((y.key >> sh_hap) != hp2_prefix || (int64_t)kf.pos(y.key) - pa > right) break;
+          if ((y.idx & SL_DEL) == t) { head = false; break; }
+        }
+        break;
+      }
+      hj[i] = jlo | (head ? PJ_HEAD : 0u);
+      atomicAdd(&rows_t[t ? 1 : 0], 1u);
+      if (head) atomicAdd(&heads_t[t ? 1 : 0], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 && rows_t[threadIdx.x] >= 512u && heads_t[threadIdx.x] == 0u) atomicMax(max_stretch, 4096u);
+    __syncthreads();
+  }
+}
+
+// One wave on a long stretch of type t that starts at hp1 row i: rows stay sequential, a row's candidate window is scanned 64 hp2
+// rows at a time and the first match is the lowest set ballot bit. Called by all 64 lanes, (i, jlo) wave-uniform.
+__device__ __forceinline__ void sl_pair_long(const Slim* __restrict__ m, const uint32_t n, KeyFmt kf, int pair_shift, int right,
+                                             const uint32_t* __restrict__ hj, int32_t* __restrict__ st, const uint32_t i, uint32_t jlo, const int lane,
+                                             uint32_t* __restrict__ max_stretch) {
+  const int sh_hap = kf.pb + 2;
+  const Slim first = ld_slim(m + i);
+  const uint64_t hp1_prefix = first.key >> sh_hap, hp2_prefix = hp1_prefix | 1ull;
+  const uint32_t t = first.idx & SL_DEL;
+  uint32_t count = 0;
+  for (uint32_t a = i; a < n; ++a) {
+    const Slim s1 = ld_slim(m + a);
+    if ((s1.key >> sh_hap) != hp1_prefix) break;
+    if ((s1.idx & SL_DEL) != t) continue;
+    if (a != i && (hj[a] & PJ_HEAD)) break;
+    ++count;
+    const int32_t p1 = kf.pos(s1.key);
+    for (;;) {                                     // first hp2 row at or after pos - shift (wave-uniform walk)
+      if (jlo >= n) break;
+      const Slim y = ld_slim(m + jlo);
+      if ((y.key >> sh_hap) != hp2_prefix || (int64_t)p1 - kf.pos(y.key) <= pair_shift) break;
+      ++jlo;
+    }
+    int32_t mate = -1;
+    for (uint32_t j0 = jlo; j0 < n; j0 += 64) {
+      const uint32_t j = j0 + lane;
+      bool valid = j < n;
+      Slim s2 = s1;
+      if (valid) s2 = ld_slim(m + j);
+      valid = valid && (s2.key >> sh_hap) == hp2_prefix;
+      const int32_t p2 = kf.pos(s2.key);
+      const bool inwin = valid && (int64_t)p2 - p1 <= right;
+      if (__ballot(inwin) == 0) break;
+      const bool ok = inwin && (s2.idx & SL_DEL) == t && ld_i32(&st[j]) == -1 && sl_match(p1, s1.svlen, p2, s2.svlen, t != 0, pair_shift);
+      const uint64_t bal = __ballot(ok);
+      if (bal) { mate = (int32_t)(j0 + (uint32_t)__builtin_ctzll(bal)); break; }
+    }
+    if (lane == 0) { st_i32(&st[a], mate); if (mate >= 0) st_i32(&st[mate], (int32_t)a); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  if (lane == 0) atomicMax(max_stretch, count);    // a table with very long stretches is paired in rounds from the next run on
+}
+
+__global__ __launch_bounds__(256) void sl_pair_walk(const Slim* __restrict__ m, const uint32_t* __restrict__ d_n, KeyFmt kf, int pair_shift, int right,
+                                                    const uint32_t* __restrict__ hj, int32_t* __restrict__ st, uint32_t* __restrict__ max_stretch) {
+  const uint32_t n = *d_n;
+  const int lane = threadIdx.x & 63;
+  const int sh_hap = kf.pb + 2;
+  for (uint32_t i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += gridDim.x * blockDim.x) {   // wave-uniform trip count
+    const uint32_t i = i0 + (uint32_t)lane;
+    bool is_long = false;
+    uint32_t jlo = 0;
+    if (i < n) {
+      const Slim me = ld_slim(m + i);
+      const uint32_t w = hj[i];
+      if (!((me.key >> sh_hap) & 1ull) && (w & PJ_HEAD)) {
+        jlo = w & ~PJ_HEAD;
+        const uint64_t hp1_prefix = me.key >> sh_hap, hp2_prefix = hp1_prefix | 1ull;
+        const uint32_t t = me.idx & SL_DEL;
+        // rows of the stretch: this type's rows up to the next head
+        uint32_t cnt = 1, e = i + 1;
+        for (; e < n && cnt <= SL_LONG_RUN; ++e) {
+          const Slim x = ld_slim(m + e);
+          if ((x.key >> sh_hap) != hp1_prefix) break;
+          if ((x.idx & SL_DEL) != t) continue;
+          if (hj[e] & PJ_HEAD) break;
+          ++cnt;
+        }
+        if (cnt > SL_LONG_RUN) is_long = true;
+        else {
+          uint32_t jl = jlo;
+          for (uint32_t a = i; a < e; ++a) {
+            const Slim s1 = a == i ? me : ld_slim(m + a);
+            if ((s1.idx & SL_DEL) != t) continue;
+            const int32_t p1 = kf.pos(s1.key);
+            for (; jl < n; ++jl) {
+              const Slim y = ld_slim(m + jl);
+              if ((y.key >> sh_hap) != hp2_prefix || (int64_t)p1 - kf.pos(y.key) <= pair_shift) break;
+            }
+            int32_t mate = -1;
+            for (uint32_t j = jl; j < n; ++j) {
+              const Slim s2 = ld_slim(m + j);
+              if ((s2.key >> sh_hap) != hp2_prefix) break;
+              const int32_t p2 = kf.pos(s2.key);
+              if ((int64_t)p2 - p1 > right) break;
+              if ((s2.idx & SL_DEL) == t && st[j] == -1 && sl_match(p1, s1.svlen, p2, s2.svlen, t != 0, pair_shift)) {
+                mate = (int32_t)j; st[j] = (int32_t)a; break;                 // H:560-569
+              }
+            }
+            st[a] = mate;
+          }
+        }
+      }
+    }
+    uint64_t lm = __ballot(is_long);
+    while (lm) {
+      const int src = __builtin_ctzll(lm);
+      lm &= lm - 1;
+      sl_pair_long(m, n, kf, pair_shift, right, hj, st, (uint32_t)__shfl((int)i, src, 64), (uint32_t)__shfl((int)jlo, src, 64), lane, max_stretch);
+    }
+  }
+}
+
+// ---- the same walk with the tables staged in LDS -------------------------------------------------------------------------------
+// sl_pair_prep + sl_pair_walk chase dependent global loads (a row's first candidate by bisection, its window, the stretch's next
+// row): ~10 loads of ~1 us per hp1 row on one lane. Here a block stages a window of the hp1 rows (+ halo) and the hp2 rows they can
+// reach in LDS and does everything there: first candidates by bisection in LDS, stretch starts (compacted into a list so that the
+// walks run on dense lanes), the walks themselves — a walk evaluates the cut in front of every row itself, so no flag array is
+// needed; whatever lies outside the staged windows is read from global memory by the same accessors. st[] must be -1 everywhere
+// before the launch.
+constexpr int PW = 512, PW_BACK = 64, PW_FWD = 64, PW_A = PW_BACK + PW + PW_FWD, PW_B = 1024;
+
+__global__ __launch_bounds__(256) void sl_fill_i32(int32_t* __restrict__ p, int32_t v, const uint32_t* __restrict__ d_n) {
+  const uint32_t n = *d_n;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v;
+}
+
+// first index in [0, n) whose key is >= target, by the 64 lanes of a wave: 65-ary steps (4 dependent loads for 10^7 rows)
+__device__ __forceinline__ uint32_t sl_wave_lower_bound(const Slim* __restrict__ m, uint32_t n, uint64_t target, int lane) {
+  uint32_t lo = 0, hi = n;                        // the answer lies in [lo, hi]; keys in front of lo are < target, keys from hi on >= target
+  while (hi - lo > 64u) {
+    const uint64_t span = (uint64_t)(hi - lo);
+    const uint32_t probe = lo + (uint32_t)(span * (uint32_t)(lane + 1) / 65u);      // lo <= probe < hi, ascending with the lane
+    const bool ge = m[probe].key >= target;
+    const uint64_t bal = __ballot(ge);
+    // lanes below the first set bit hold keys < target, the first set lane a key >= target
+    const int f = bal ? __builtin_ctzll(bal) : 64;
+    const uint32_t nlo = f == 0 ? lo : (lo + (uint32_t)(span * (uint32_t)f / 65u)) + 1u;
+    const uint32_t nhi = f == 64 ? hi : lo + (uint32_t)(span * (uint32_t)(f + 1) / 65u);
+    lo = nlo; hi = nhi;
+  }
+  const uint32_t i = lo + (uint32_t)lane;
+  const bool ge = i < hi && m[i].key >= target;
+  const uint64_t bal = __ballot(ge);
+  return bal ? lo + (uint32_t)__builtin_ctzll(bal) : hi;
+}
+
+__global__ __launch_bounds__(256) void sl_pair_fused(const Slim* __restrict__ m, const uint32_t* __restrict__ d_n, KeyFmt kf, int pair_shift, int right,
+                                                     int32_t* __restrict__ st, uint32_t* __restrict__ max_stretch, int ablate) {
+  __shared__ uint4 shA[PW_A], shB[PW_B];
+  __shared__ uint2 heads[PW];
+  __shared__ int32_t takenB[PW_B];            // pairing state of the staged hp2 rows (every hp2 row of a type belongs to ONE stretch, i.e. one lane)
+  __shared__ uint32_t n_heads, rows_t[2], heads_t[2], s_j[2];
+  const uint32_t n = *d_n;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int sh_hap = kf.pb + 2;
+  auto unpack = [](const uint4 v) -> Slim { Slim x; x.key = (uint64_t)v.x | ((uint64_t)v.y << 32); x.svlen = (int32_t)v.z; x.idx = v.w; return x; };
+  for (uint32_t base = blockIdx.x * PW; base < n; base += gridDim.x * PW) {
+    const uint32_t a_lo = base >= (uint32_t)PW_BACK ? base - PW_BACK : 0u, a_hi = min(n, base + PW + PW_FWD), w_hi = min(n, base + PW);
+    __syncthreads();
+    if (threadIdx.x < 2) { rows_t[threadIdx.x] = 0; heads_t[threadIdx.x] = 0; }
+    if (threadIdx.x == 0) n_heads = 0;
+    for (uint32_t k = threadIdx.x; k < a_hi - a_lo; k += 256) shA[k] = *reinterpret_cast<const uint4*>(m + a_lo + k);
+    // the hp2 rows this window can reach: [first candidate of its first row, first row beyond the reach of its last row)
+    if (wv < 2) {
+      const Slim e = ld_slim(m + (wv == 0 ? a_lo : a_hi - 1));
+      uint32_t r = 0;
+      if (!((e.key >> sh_hap) & 1ull)) {
+        const int64_t p = wv == 0 ? (int64_t)kf.pos(e.key) - pair_shift : (int64_t)kf.pos(e.key) + right + 1;
+        const uint64_t target = (((e.key >> sh_hap) | 1ull) << sh_hap) | vsv_kpos((int32_t)max(p, (int64_t)-VSV_POS_BIAS));
+        r = sl_wave_lower_bound(m, n, target, lane);
+      }
+      if (lane == 0) s_j[wv] = r;
+    }
+    __syncthreads();
+    const uint32_t j0 = s_j[0], j1 = s_j[1] > s_j[0] ? min(s_j[1], s_j[0] + (uint32_t)PW_B) : s_j[0];
+    for (uint32_t k = threadIdx.x; k < j1 - j0; k += 256) { shB[k] = *reinterpret_cast<const uint4*>(m + j0 + k); takenB[k] = -1; }
+    __syncthreads();
+    auto getA = [&](uint32_t k) -> Slim { const uint32_t rel = k - a_lo; return rel < a_hi - a_lo ? unpack(shA[rel]) : ld_slim(m + k); };
+    auto getB = [&](uint32_t j) -> Slim { const uint32_t rel = j - j0; return rel < j1 - j0 ? unpack(shB[rel]) : ld_slim(m + j); };
+    // ---- phase 1: first candidates and stretch starts of the window's hp1 rows ----
+    for (uint32_t i = base + threadIdx.x; i < w_hi && !(ablate & 2); i += 256) {
+      const Slim me = getA(i);
+      if ((me.key >> sh_hap) & 1ull) continue;
+      const uint32_t t = me.idx & SL_DEL;
+      const int32_t pb_ = kf.pos(me.key);
+      const uint64_t hp1_prefix = me.key >> sh_hap, hp2_prefix = hp1_prefix | 1ull;
+      const uint64_t target = (hp2_prefix << sh_hap) | vsv_kpos((int32_t)max((int64_t)pb_ - pair_shift, (int64_t)-VSV_POS_BIAS));
+      uint32_t jlo;
+      if (j1 > j0 && unpack(shB[0]).key < target && unpack(shB[j1 - j0 - 1]).key >= target) {     // the answer lies inside the staged rows
+        uint32_t lo = 0, hi = j1 - j0 - 1;                     // key[lo] < target <= key[hi]
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (unpack(shB[mid]).key >= target) hi = mid; else lo = mid; }
+        jlo = j0 + hi;
+      } else jlo = sl_lower_bound(m, n, target);
+      bool head = true;
+      for (uint32_t k = i; k-- > 0;) {
+        const Slim x = getA(k);
+        if ((x.key >> sh_hap) != hp1_prefix) break;
+        const int32_t pa = kf.pos(x.key);
+        if ((int64_t)pb_ - pa > (int64_t)pair_shift + right) break;      // nothing earlier shares a candidate with this row
+        if ((x.idx & SL_DEL) != t) continue;
+        for (uint32_t j = jlo; j < n; ++j) {                             // an hp2 row of the type in [pos_b - shift, pos_a + right]?
+          const Slim y = getB(j);
+          if ((y.key >> sh_hap) != hp2_prefix || (int64_t)kf.pos(y.key) - pa > right) break;
+          if ((y.idx & SL_DEL) == t) { head = false; break; }
+        }
+        break;
+      }
+      atomicAdd(&rows_t[t ? 1 : 0], 1u);
+      if (head) { atomicAdd(&heads_t[t ? 1 : 0], 1u); heads[atomicAdd(&n_heads, 1u)] = make_uint2(i, jlo); }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 && rows_t[threadIdx.x] >= 384u && heads_t[threadIdx.x] == 0u) atomicMax(max_stretch, 4096u);   // a giant stretch passes through
+    // ---- phase 2: eight lanes per stretch ----
+    // A lane per stretch leaves the wave waiting for its longest lane, every step of which is a dependent LDS read. Here a group
+    // of 8 lanes owns a stretch: the rows stay sequential, but the pointer advance, the candidate window (with the cut test in
+    // front of the row folded into the same sweep: the cut holds iff no hp2 row of the type turns up before the first row beyond
+    // prev + right) and the search for the stretch's next row each look at 8 elements per step; group ballots decide.
+    const uint32_t nh = (ablate & 1) ? 0u : n_heads;
+    const int grp = threadIdx.x >> 3, sub = threadIdx.x & 7, gsh = lane & ~7;
+    auto gballot = [&](bool p) -> uint32_t { return (uint32_t)(__ballot(p) >> gsh) & 0xFFu; };
+    for (uint32_t h0 = 0; h0 < nh; h0 += 32) {
+      const uint32_t h = h0 + (uint32_t)grp;
+      bool active = h < nh;
+      uint32_t a = 0, jl = 0, cnt = 0, t = 0;
+      int32_t prev_pos = 0;
+      uint64_t hp1_prefix = 0, hp2_prefix = 1;
+      Slim s1 = dead_slim();
+      if (active) {
+        a = heads[h].x; jl = heads[h].y;
+        s1 = getA(a);
+        t = s1.idx & SL_DEL;
+        hp1_prefix = s1.key >> sh_hap; hp2_prefix = hp1_prefix | 1ull;
+      }
+      while (__ballot(active)) {
+        const int32_t p1 = kf.pos(s1.key);
+        // 1. first hp2 row at or after pos - shift
+        bool adv = active;
+        while (__ballot(adv)) {
+          const uint32_t j = jl + (uint32_t)sub;
+          bool passed = false;
+          if (adv && j < n) { const Slim y = getB(j); passed = (y.key >> sh_hap) == hp2_prefix && (int64_t)p1 - kf.pos(y.key) > pair_shift; }
+          const uint32_t k = (uint32_t)__builtin_ctz(~gballot(passed) | 0x100u);      // rows in front of the first one that stays
+          if (adv) { jl += k; if (k < 8u) adv = false; }
+        }
+        // 2. the candidate window, 8 rows per step
+        bool scanning = active, cut = false, seen_t = cnt == 0;
+        int32_t mate = -1;
+        uint32_t jc = jl;
+        while (__ballot(scanning)) {
+          const uint32_t j = jc + (uint32_t)sub;
+          bool valid = scanning && j < n;
+          Slim y = s1;
+          if (valid) y = getB(j);
+          valid = valid && (y.key >> sh_hap) == hp2_prefix;
+          const int32_t p2 = kf.pos(y.key);
+          const bool beyond = !valid || (int64_t)p2 - p1 > right;
+          const bool is_t = !beyond && (y.idx & SL_DEL) == t;
+          const bool past = !beyond && (int64_t)p2 - prev_pos > right;             // beyond the reach of the stretch's previous row
+          bool ok = false;
+          if (is_t) {
+            const uint32_t rel = j - j0;
+            const bool fr = rel < j1 - j0 ? takenB[rel] == -1 : ld_i32(&st[j]) == -1;
+            ok = fr && sl_match(p1, s1.svlen, p2, y.svlen, t != 0, pair_shift);
+          }
+          const uint32_t b_e = gballot(beyond), b_t = gballot(is_t), b_p = gballot(past), b_ok = gballot(ok);
+          if (scanning) {
+            const uint32_t e = (uint32_t)__builtin_ctz(b_e | 0x100u), mk = (1u << e) - 1u;
+            const uint32_t ft = (uint32_t)__builtin_ctz((b_t & mk) | 0x100u), fp = (uint32_t)__builtin_ctz((b_p & mk) | 0x100u);
+            if (!seen_t) {
+              if (fp < 8u && fp <= ft) cut = true;           // no row of the type in [pos - shift, prev + right]
+              else if (ft < 8u) seen_t = true;
+              else if (e < 8u) cut = true;                   // (the window ended without one)
+            }
+            if (cut) scanning = false;
+            else {
+              const uint32_t fo = (uint32_t)__builtin_ctz((b_ok & mk) | 0x100u);
+              if (fo < 8u) { mate = (int32_t)(jc + fo); scanning = false; }                          // H:560-569
+              else if (e < 8u) scanning = false;
+              else jc += 8u;
+            }
+          }
+        }
+        // 3. the row's result
+        if (active) {
+          if (cut) active = false;                           // the row starts a stretch of its own (another group walks it)
+          else {
+            if (sub == 0) {
+              st[a] = mate;
+              if (mate >= 0) {
+                const uint32_t rel = (uint32_t)mate - j0;
+                if (rel < j1 - j0) takenB[rel] = (int32_t)a;
+                st_i32(&st[mate], (int32_t)a);
+              }
+            }
+            ++cnt; prev_pos = p1;
+          }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the group's next row sees the state (LDS, or L2 for unstaged rows)
+        // 4. the list's next row of this type
+        bool seek = active;
+        uint32_t kb = a + 1u;
+        while (__ballot(seek)) {
+          const uint32_t k = kb + (uint32_t)sub;
+          const bool inb = seek && k < n;
+          Slim x = s1;
+          if (inb) x = getA(k);
+          const bool stop = seek && (!inb || (x.key >> sh_hap) != hp1_prefix);
+          const bool is_t = inb && !stop && (x.idx & SL_DEL) == t;
+          const uint32_t fs = (uint32_t)__builtin_ctz(gballot(stop) | 0x100u), ft = (uint32_t)__builtin_ctz(gballot(is_t) | 0x100u);
+          const int srcl = gsh + (int)(ft < 8u ? ft : 0u);
+          Slim nx;
+          nx.key = __shfl(x.key, srcl, 64); nx.svlen = __shfl(x.svlen, srcl, 64); nx.idx = (uint32_t)__shfl((int)x.idx, srcl, 64);
+          if (seek) {
+            if (ft < fs) { a = kb + ft; s1 = nx; seek = false; }
+            else if (fs < 8u) { active = false; seek = false; }
+            else kb += 8u;
+          }
+        }
+      }
+      if (sub == 0 && cnt > 1024u) atomicMax(max_stretch, cnt);
+    }
+  }
+}
+
+// ---- pairing in rounds: dense piles (deterministic reservations; see sig_stages.hip "Pairing in rounds") -------------------------
+// Every undecided hp1 row reserves ALL its free candidates with its index as priority (atomicMin; the round in the high word so
+// nothing needs clearing), then takes its FIRST free candidate if it holds the reservation there: no earlier undecided row can then
+// ever want that hp2 row and the decided rows are final, so this is exactly what the sequential walk gives it; a row without a free
+// candidate is unpaired for good. What the rounds leave goes through the sequential rule in chains (sl_pair_leftover).
+__device__ __forceinline__ bool sl_candidate(const Slim& s1, int32_t p1, const Slim& s2, int32_t p2, int pair_shift) {
+  return ((s1.idx ^ s2.idx) & SL_DEL) == 0 && sl_match(p1, s1.svlen, p2, s2.svlen, (s1.idx & SL_DEL) != 0, pair_shift);
+}
+template <bool COMMIT>
+__global__ __launch_bounds__(256) void sl_pair_round(const Slim* __restrict__ m, const uint32_t* __restrict__ d_n, KeyFmt kf, int pair_shift, int right,
+                                                     int32_t* __restrict__ st, const uint32_t* __restrict__ hj, uint32_t* __restrict__ done1,
+                                                     uint64_t* __restrict__ res, uint32_t round) {
+  const uint32_t n = *d_n;
+  const int sh_hap = kf.pb + 2;
+  const uint64_t stamp = (uint64_t)(~round) << 32;          // newer rounds compare smaller: old reservations lose by themselves
+  for (uint32_t a = blockIdx.x * blockDim.x + threadIdx.x; a < n; a += gridDim.x * blockDim.x) {
+    const Slim s1 = ld_slim(m + a);
+    if (((s1.key >> sh_hap) & 1ull) || done1[a]) continue;
+    const uint64_t hp2_prefix = (s1.key >> sh_hap) | 1ull;
+    const int32_t p1 = kf.pos(s1.key);
+    int32_t first = -1;
+    for (uint32_t j = hj[a] & ~PJ_HEAD; j < n; ++j) {
+      const Slim s2 = ld_slim(m + j);
+      if ((s2.key >> sh_hap) != hp2_prefix) break;
+      const int32_t p2 = kf.pos(s2.key);
+      if ((int64_t)p2 - p1 > right) break;
+      if (ld_i32(&st[j]) != -1 || !sl_candidate(s1, p1, s2, p2, pair_shift)) continue;
+      if (!COMMIT) atomicMin((unsigned long long*)&res[j], (unsigned long long)(stamp | a));
+      else { first = (int32_t)j; break; }
+    }
+    if (!COMMIT) continue;
+    if (first < 0) { done1[a] = 1; }                                                  // H:575-576 (st[a] stays -1)
+    else if (res[first] == (stamp | a)) { st_i32(&st[first], (int32_t)a); st_i32(&st[a], first); done1[a] = 1; }
+  }
+}
+// (rounds count from 1: the reservation words start at all ones, which no round's stamp exceeds)
+__global__ __launch_bounds__(256) void sl_pair_rounds_init(const uint32_t* __restrict__ d_n, uint32_t* __restrict__ done1, uint64_t* __restrict__ res) {
+  const uint32_t n = *d_n;
+  for (uint32_t a = blockIdx.x * blockDim.x + threadIdx.x; a < n; a += gridDim.x * blockDim.x) { done1[a] = 0; res[a] = ~0ull; }
+}
+__global__ __launch_bounds__(256) void sl_pair_leftover(const Slim* __restrict__ m, const uint32_t* __restrict__ d_n, KeyFmt kf, int pair_shift, int right,
+                                                        int32_t* __restrict__ st, const uint32_t* __restrict__ hj, const uint32_t* __restrict__ done1) {
+  const uint32_t n = *d_n;
+  const int sh_hap = kf.pb + 2;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const Slim me = ld_slim(m + i);
+    if (((me.key >> sh_hap) & 1ull) || done1[i]) continue;
+    const uint64_t hp1_prefix = me.key >> sh_hap, hp2_prefix = hp1_prefix | 1ull;
+    const int32_t pme = kf.pos(me.key);
+    bool head = true;
+    for (uint32_t k = i; k-- > 0;) {                        // an undecided hp1 row of this list within 2 * pair_shift in front?
+      const Slim x = ld_slim(m + k);
+      if ((x.key >> sh_hap) != hp1_prefix || (int64_t)pme - kf.pos(x.key) > 2 * (int64_t)pair_shift) break;
+      if (!done1[k]) { head = false; break; }
+    }
+    if (!head) continue;
+    int32_t last_pos = pme;
+    for (uint32_t a = i; a < n; ++a) {
+      const Slim s1 = ld_slim(m + a);
+      if ((s1.key >> sh_hap) != hp1_prefix) break;
+      const int32_t p1 = kf.pos(s1.key);
+      if ((int64_t)p1 - last_pos > 2 * (int64_t)pair_shift) break;      // the next undecided row, if any, leads its own chain
+      if (done1[a]) continue;
+      last_pos = p1;
+      int32_t mate = -1;
+      for (uint32_t j = hj[a] & ~PJ_HEAD; j < n; ++j) {
+        const Slim s2 = ld_slim(m + j);
+        if ((s2.key >> sh_hap) != hp2_prefix) break;
+        const int32_t p2 = kf.pos(s2.key);
+        if ((int64_t)p2 - p1 > right) break;
+        if (ld_i32(&st[j]) == -1 && sl_candidate(s1, p1, s2, p2, pair_shift)) { mate = (int32_t)j; st_i32(&st[j], (int32_t)a); break; }
+      }
+      st_i32(&st[a], mate);                  // (done1 stays as the rounds left it: the other lanes' head tests read it meanwhile)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+}
+
+// ---- rows out ------------------------------------------------------------------------------------------------------------------
+// sorted call elements -> vsv_call rows (H:571-592): the kept signature's row comes from the stage-1 input table
+__global__ __launch_bounds__(256) void sl_calls_out(const Slim* __restrict__ cs, const uint32_t* __restrict__ d_n, const Slim* __restrict__ m, int hap_bit,
+                                                    const vsv_sig* __restrict__ rows, vsv_call* __restrict__ out) {
+  const uint32_t n = *d_n;
+  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+    const Slim c = ld_slim(cs + k);
+    const Slim me = ld_slim(m + c.idx);
+    vsv_call o;
+    o.pad = 0;
+    uint32_t row = me.idx & SL_ROW;
+    if ((me.key >> hap_bit) & 1ull) { o.a = -1; o.b = (int32_t)c.idx; o.gt = 1; }                  // H:588-592
+    else {
+      o.a = (int32_t)c.idx; o.b = c.svlen;
+      if (c.svlen < 0) o.gt = 1;                                                                   // H:575-576
+      else { o.gt = 2; const Slim mate = ld_slim(m + c.svlen); if (!(me.svlen > mate.svlen)) row = mate.idx & SL_ROW; }   // H:583-586
+    }
+    o.sig = rows[row];
+    out[k] = o;
+  }
+}
+// slim table -> signature rows (VSV_T_CLUSTER1 / VSV_T_MERGED on request): a dead element gives a dead row
+__global__ __launch_bounds__(256) void sl_rows_out(const Slim* __restrict__ e, uint32_t n, const vsv_sig* __restrict__ rows, vsv_sig* __restrict__ out) {
+  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+    const Slim x = ld_slim(e + k);
+    vsv_sig r;
+    if (x.key == VSV_KEY_DEAD) { r.pos = 0; r.svlen = 0; r.q_start = 0; r.q_end = 0; r.rec = 0; r.rec2 = 0; r.meta = VSV_M_DEAD; r.tid = 0; }
+    else r = rows[x.idx & SL_ROW];
+    out[k] = r;
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------------------
+template <int BITS, typename SRC, bool SKIP>
+void sl_pass(hipStream_t st, SRC src, const uint32_t* d_n, int shift, Slim* out, uint32_t* hist, uint32_t* totals, uint32_t* d_total, int grid) {
+  sl_hist<BITS, SRC, SKIP><<<grid, 256, 0, st>>>(src, d_n, shift, hist, totals);
+  sl_scan<BITS><<<(1 << BITS) / 16, 1024, 0, st>>>(hist, totals, d_n, d_total);
+  sl_scatter<BITS, SRC, SKIP><<<grid, 256, 0, st>>>(src, d_n, shift, hist, out);
+}
+
+// Stable sort of the live elements of `src` (n slots, *d_slots) by key bits [0, nbits): the first pass skips dead elements and
+// publishes the live count (*d_live), the later passes run on that count. Ping-pong between a and b; returns the buffer that holds
+// the result (nothing is copied back).
+template <typename SRC>
+Slim* sl_sort(hipStream_t st, SRC src, const uint32_t* d_slots, uint32_t* d_live, int nbits, Slim* a, Slim* b, const SlimWork& w) {
+  if (nbits < 1) nbits = 1;
+  int passes = (nbits + 8) / 9;
+  const int bits = (nbits + passes - 1) / passes <= 8 ? 8 : 9;
+  passes = (nbits + bits - 1) / bits;
+  const int64_t max_tiles = (w.cap + SL_TILE - 1) / SL_TILE;
+  const int grid = (int)(max_tiles < 2048 ? (max_tiles < 1 ? 1 : max_tiles) : 2048);
+  Slim* dst = a;
+  Slim* other = b;
+  // the chained-scan passes measure the same as histogram + scan + scatter (row 2c: 4.72 ms per step either way: with ~770 blocks
+  // resident and ~1500 tiles, half of the tiles look back over hundreds of aggregates); they stay behind VSV_SLIM_SORT=chain
+  static const char* mode = vsv_dbg_env("VSV_SLIM_SORT");
+  const bool chained = mode && mode[0] == 'c' && passes <= OS_MAX_PASSES && w.state != nullptr;
+  uint32_t* totals0 = w.totals + (size_t)(*w.pass_cursor) * 2048;
+  if (chained) sl_digit_totals<SRC, true><<<grid < 1024 ? grid : 1024, 256, 0, st>>>(src, d_slots, passes, bits, totals0);
+  for (int p = 0; p < passes; ++p) {
+    uint32_t* totals = w.totals + (size_t)(*w.pass_cursor) * 2048;
+    ++*w.pass_cursor;
+    const int shift = p * bits;
+    const uint64_t epoch = ++*w.epoch & ((1ull << 30) - 1ull);
+    if (p == 0) {
+      if (chained) {
+        if (bits == 8) sl_onesweep<8, SRC, true><<<grid, 256, 0, st>>>(src, d_slots, shift, totals, w.state, epoch, dst, d_live);
+        else sl_onesweep<9, SRC, true><<<grid, 256, 0, st>>>(src, d_slots, shift, totals, w.state, epoch, dst, d_live);
+      } else if (bits == 8) sl_pass<8, SRC, true>(st, src, d_slots, shift, dst, w.hist, totals, d_live, grid);
+      else sl_pass<9, SRC, true>(st, src, d_slots, shift, dst, w.hist, totals, d_live, grid);
+    } else {
+      const SrcSlim in{other};
+      if (chained) {
+        if (bits == 8) sl_onesweep<8, SrcSlim, false><<<grid, 256, 0, st>>>(in, d_live, shift, totals, w.state, epoch, dst, nullptr);
+        else sl_onesweep<9, SrcSlim, false><<<grid, 256, 0, st>>>(in, d_live, shift, totals, w.state, epoch, dst, nullptr);
+      } else if (bits == 8) sl_pass<8, SrcSlim, false>(st, in, d_live, shift, dst, w.hist, totals, nullptr, grid);
+      else sl_pass<9, SrcSlim, false>(st, in, d_live, shift, dst, w.hist, totals, nullptr, grid);
+    }
+    Slim* t = dst; dst = other; other = t;
+  }
+  return other;        // the buffer the last pass wrote
+}
+
+}  // namespace
+
+// ================================================== entry points (capi.hip) ==================================================
+int vsv_slim_sort_passes(int nbits) {
+  if (nbits < 1) nbits = 1;
+  int passes = (nbits + 8) / 9;
+  const int bits = (nbits + passes - 1) / passes <= 8 ? 8 : 9;
+  return (nbits + bits - 1) / bits;
+}
+
+// stage 1: rows -> elements, sort by (tid, hap, type, source, pos), cluster per list. Returns the cluster output (slots = *d_alive1).
+void* vsv_slim_stage1(hipStream_t st, const vsv_sig* s1in, const uint32_t* d_n_s1, uint32_t* d_alive1, int pb, int tid_lo, int tid_bits, int cluster_shift,
+                      const SlimWork& w, Counters* ctr, bool prebuilt) {
+  Slim* b0 = (Slim*)w.buf[0]; Slim* b1 = (Slim*)w.buf[1]; Slim* e2 = (Slim*)w.buf[2];
+  // (a fused run has the elements already: fold_kernel / split_eval wrote them next to the rows, vsv_slim_emit)
+  if (!prebuilt) sl_from_rows<<<w.grid, 256, 0, st>>>(s1in, d_n_s1, pb, tid_lo, tid_bits, b0, &ctr->err);
+  Slim* sorted = sl_sort(st, SrcSlim{b0}, d_n_s1, d_alive1, pb + 3 + tid_bits, b1, b0, w);
+  const int64_t tiles = (w.cap + CL_TILE - 1) / CL_TILE;
+  sl_cluster<<<(int)(tiles < 4096 ? (tiles < 1 ? 1 : tiles) : 4096), 256, 0, st>>>(sorted, d_alive1, cluster_shift, KeyFmt{pb}, pb, e2, w.cl);
+  return e2;
+}
+
+// merge_all: sort the stage-1 representatives by (tid, hap, type, pos), cluster, sort by (tid, hap, pos). Returns the merged elements.
+void* vsv_slim_merge(hipStream_t st, const void* e2, const uint32_t* d_alive1, uint32_t* d_alive2, uint32_t* d_alive3, int pb, int tid_bits,
+                     int cluster_shift, const SlimWork& w) {
+  Slim* b0 = (Slim*)w.buf[0]; Slim* b1 = (Slim*)w.buf[1]; Slim* e3 = (Slim*)w.buf[3]; Slim* m0 = (Slim*)w.buf[4]; Slim* m1 = (Slim*)w.buf[5];
+  Slim* s2 = sl_sort(st, SrcSlim{(const Slim*)e2}, d_alive1, d_alive2, pb + 3 + tid_bits, b0, b1, w);
+  const int64_t tiles = (w.cap + CL_TILE - 1) / CL_TILE;
+  sl_cluster<<<(int)(tiles < 4096 ? (tiles < 1 ? 1 : tiles) : 4096), 256, 0, st>>>(s2, d_alive2, cluster_shift, KeyFmt{pb}, pb + 1, e3, w.cl);
+  // the result must outlive the pairing stage and the readback: it lands in one of the two buffers reserved for it
+  return sl_sort(st, SrcSlim{e3}, d_alive2, d_alive3, pb + 3 + tid_bits, m0, m1, w);
+}
+
+// pair_sig + the final order: pairing state in w.cl, call elements sorted by (tid, pos), call rows gathered from s1in
+void vsv_slim_pair(hipStream_t st, const void* merged, const uint32_t* d_alive3, uint32_t* d_ncalls, int pb, int tid_bits, int pair_shift, int pair_window,
+                   const vsv_sig* s1in, vsv_call* calls, bool dense, const SlimWork& w, Counters* ctr) {
+  const Slim* m = (const Slim*)merged;
+  const KeyFmt kf{pb};
+  const int right = pair_shift < pair_window ? pair_shift : pair_window;
+  // scratch: buffers 0 / 1 hold nothing that is still needed (buffer 2 = the stage-1 clusters, 4 / 5 = the merged elements)
+  Slim* b0 = (Slim*)w.buf[0]; Slim* b1 = (Slim*)w.buf[1];
+  static const char* unfused = vsv_dbg_env("VSV_PAIR_KERNELS");                  // tests / timing: "global" = sl_pair_prep + sl_pair_walk
+  if (dense) {
+    sl_pair_prep<<<w.grid, 256, 0, st>>>(m, d_alive3, kf, pair_shift, right, w.hj, w.cl, &ctr->max_stretch);
+    uint32_t* done1 = w.done1; uint64_t* res = (uint64_t*)w.buf[3];         // (the stage-2 clusters are consumed)
+    sl_pair_rounds_init<<<w.grid, 256, 0, st>>>(d_alive3, done1, res);
+    for (uint32_t r = 0; r < 10; ++r) {
+      sl_pair_round<false><<<w.grid, 256, 0, st>>>(m, d_alive3, kf, pair_shift, right, w.cl, w.hj, done1, res, r + 1);
+      sl_pair_round<true><<<w.grid, 256, 0, st>>>(m, d_alive3, kf, pair_shift, right, w.cl, w.hj, done1, res, r + 1);
+    }
+    sl_pair_leftover<<<w.grid, 256, 0, st>>>(m, d_alive3, kf, pair_shift, right, w.cl, w.hj, done1);
+  } else if (unfused && unfused[0] == 'g') {
+    sl_pair_prep<<<w.grid, 256, 0, st>>>(m, d_alive3, kf, pair_shift, right, w.hj, w.cl, &ctr->max_stretch);
+    sl_pair_walk<<<w.grid, 256, 0, st>>>(m, d_alive3, kf, pair_shift, right, w.hj, w.cl, &ctr->max_stretch);
+  } else {
+    sl_fill_i32<<<w.grid, 256, 0, st>>>(w.cl, -1, d_alive3);
+    const int64_t wins = (w.cap + PW - 1) / PW;
+    static const int ablate = vsv_dbg_env("VSV_PAIR_ABLATE") ? atoi(vsv_dbg_env("VSV_PAIR_ABLATE")) : 0;     // timing experiments only
+    sl_pair_fused<<<(int)(wins < 8192 ? (wins < 1 ? 1 : wins) : 8192), 256, 0, st>>>(m, d_alive3, kf, pair_shift, right, w.cl, &ctr->max_stretch, ablate);
+  }
+  Slim* cs = sl_sort(st, SrcCalls{m, w.cl, pb + 2}, d_alive3, d_ncalls, pb + 3 + tid_bits, b0, b1, w);
+  sl_calls_out<<<w.grid, 256, 0, st>>>(cs, d_ncalls, m, pb + 2, s1in, calls);
+}
+
+void vsv_slim_rows(hipStream_t st, const void* elems, uint32_t n, const vsv_sig* s1in, vsv_sig* out) {
+  if (n == 0) return;
+  const uint32_t g = (n + 255) / 256;
+  sl_rows_out<<<g < 4096 ? g : 4096, 256, 0, st>>>((const Slim*)elems, n, s1in, out);
+}

@@ -95,6 +95,18 @@ __host__ __device__ inline bool vsv_match(const vsv_sig& a, const vsv_sig& b, in
   return true;
 }
 
+// 16-byte element of the large-table path (slim_path.hip): {stage-1 key, svlen, row | type}. The kernels that write the stage-1
+// input rows (fold, split_eval) emit it next to the row when the run works on elements, so no pass re-reads the rows for it.
+struct SlimOut { void* base; int pb, tid_lo, tid_bits; uint32_t* err; };     // base == nullptr: the run does not use elements
+#define VSV_SL_DEL 0x80000000u
+__device__ __forceinline__ void vsv_slim_emit(const SlimOut& so, uint32_t i, const vsv_sig& v) {
+  if (!so.base) return;
+  const uint64_t k = vsv_key_stage(v, 1, so.pb, so.tid_lo);
+  if (!(v.meta & VSV_M_DEAD) && ((so.pb < 32 && (vsv_kpos(v.pos) >> so.pb) != 0) || ((uint32_t)(v.tid - so.tid_lo) >> so.tid_bits) != 0))
+    atomicOr(so.err, ERRB_RANGE);            // max_pos hint too small / tid outside [tid_lo, n_tids)
+  reinterpret_cast<uint4*>(so.base)[i] = make_uint4((uint32_t)k, (uint32_t)(k >> 32), (uint32_t)v.svlen, i | ((v.meta & VSV_M_DEL) ? VSV_SL_DEL : 0u));
+}
+
 // ---- launch wrappers implemented in the .hip files ------------------------------------------------
 struct SortWork {       // scratch for vsv_radix_sort_pairs
   uint64_t* key_alt;
@@ -162,14 +174,15 @@ void vsv_launch_cigar_scan(hipStream_t st, const RecView& rv, const vsv_params& 
 
 // sig_stages.hip
 void vsv_launch_clr_gate(hipStream_t st, const RecView& rv, uint8_t* gflag, Counters* ctr);   // CLR: gated flag bytes for the scan
-void vsv_launch_fold(hipStream_t st, const vsv_sig* raw, vsv_sig* s1in, const RecView& rv, const vsv_params& p, Counters* ctr, int grid);
+void vsv_launch_fold(hipStream_t st, const vsv_sig* raw, vsv_sig* s1in, const RecView& rv, const vsv_params& p, Counters* ctr, int grid,
+                     const SlimOut& so = SlimOut{nullptr, 0, 0, 0, nullptr});
 struct SplitSorted { const uint64_t* ckey; const uint32_t* crec; const uint64_t* okey; const uint32_t* oval; };   // candidates by name / pairs by record
 SplitSorted vsv_launch_split_candidates(hipStream_t st, const RecView& rv, const vsv_params& p, int n_tids, uint32_t* tab, uint32_t tab_size,
                                         uint32_t* blk_cnt, uint32_t* blk_off, uint32_t* scan_tmp, uint64_t* ckey, uint32_t* crec,
                                         uint64_t* okey, uint32_t* oval, uint64_t* key2, uint32_t* idx2, const SortWork& sw,
                                         uint32_t cap, Counters* ctr, uint8_t* cmask, int grid);
 void vsv_launch_split_eval(hipStream_t st, const RecView& rv, const vsv_params& p, int n_tids, const SplitSorted& so, vsv_sig* s1in,
-                           uint32_t cap, Counters* ctr, int grid);
+                           uint32_t cap, Counters* ctr, int grid, const SlimOut& sl = SlimOut{nullptr, 0, 0, 0, nullptr});
 // returns the sorted key array (kept for the cluster / pair kernel that follows)
 const uint64_t* vsv_launch_sort_stage(hipStream_t st, const vsv_sig* in, const uint32_t* d_n, int stage, int pb, int nbits,
                                       vsv_sig* sorted, uint32_t* d_alive, const StageBufs& b, const SortWork& sw, int64_t cap,
@@ -179,6 +192,30 @@ void vsv_launch_cluster(hipStream_t st, const vsv_sig* sorted, const uint64_t* s
 void vsv_launch_pair(hipStream_t st, const vsv_sig* merged, const uint64_t* merged_key, const uint32_t* d_alive3, int pair_shift, int pair_window,
                      vsv_call* calls_tmp, vsv_call* calls, uint32_t* d_ncalls, const StageBufs& b, uint64_t* key2, uint32_t* idx2,
                      const SortWork& sw, int pb, int nbits, int64_t cap, Counters* ctr, bool dense);
+
+// slim_path.hip: the stages behind the scan on 16-byte elements, for tables of 10^6-10^7 rows (capi.hip picks the path per run)
+struct SlimWork {
+  void* buf[6];         // element buffers, cap x 16 bytes each: 0 / 1 scratch of the sorts, 2 stage-1 clusters (kept for VSV_T_CLUSTER1),
+                        // 3 stage-2 clusters / pairing reservations, 4 / 5 merged elements (kept for VSV_T_MERGED and the calls)
+  int64_t cap;          // elements per buffer (= row capacity of the handle)
+  uint32_t* hist;       // [512 * tiles of 4096]
+  uint32_t* totals;     // zeroed per-pass digit totals, 2048 entries per slot (SortWork::totals)
+  int* pass_cursor;
+  int grid;             // blocks of the row-parallel kernels
+  int32_t* cl;          // one word per slot: long-run cluster state, then the pairing state
+  uint32_t* hj;         // pairing: first candidate of every hp1 row | stretch-start flag
+  uint32_t* done1;      // pairing in rounds: decided flags
+  uint64_t* state;      // chained-scan passes: [512 * tiles of 4096] look-back words (epoch-stamped, never cleared)
+  uint64_t* epoch;      // host-side pass counter of the handle
+};
+int vsv_slim_sort_passes(int nbits);
+void* vsv_slim_stage1(hipStream_t st, const vsv_sig* s1in, const uint32_t* d_n_s1, uint32_t* d_alive1, int pb, int tid_lo, int tid_bits, int cluster_shift,
+                      const SlimWork& w, Counters* ctr, bool prebuilt);
+void* vsv_slim_merge(hipStream_t st, const void* e2, const uint32_t* d_alive1, uint32_t* d_alive2, uint32_t* d_alive3, int pb, int tid_bits, int cluster_shift,
+                     const SlimWork& w);
+void vsv_slim_pair(hipStream_t st, const void* merged, const uint32_t* d_alive3, uint32_t* d_ncalls, int pb, int tid_bits, int pair_shift, int pair_window,
+                   const vsv_sig* s1in, vsv_call* calls, bool dense, const SlimWork& w, Counters* ctr);
+void vsv_slim_rows(hipStream_t st, const void* elems, uint32_t n, const vsv_sig* s1in, vsv_sig* out);
 
 // bnd.hip
 void vsv_launch_bnd_segments(hipStream_t st, const vsv_segments& s, const vsv_bnd_params& p, vsv_bnd* cand, uint32_t cap, Counters* ctr);
