@@ -78,8 +78,7 @@ struct vsv_handle {
   bool in_rerun = false;
   int64_t reruns = 0;             // whole-run repetitions taken by finish() so far (vsv_rerun_count)
   // large tables (slim_path.hip): element buffers, pairing scratch, what the run in flight left where
-  DevBuf sl[6], sl_hj, sl_done, sl_state;
-  uint64_t sl_epoch = 0;
+  DevBuf sl[6], sl_hj, sl_done;
   bool big_run = false;            // the stages of this run work on 16-byte elements; rows are gathered on request
   bool sl_prebuilt = false;        // ... and fold / split_eval have written the stage-1 elements next to their rows
   void* sl_e2 = nullptr;           // stage-1 cluster output (n_alive1 slots)
@@ -300,10 +299,13 @@ bool is_contig(int dtype) { return dtype == VSV_DTYPE_HIFI || dtype == VSV_DTYPE
 
 // ---- stage enqueue functions ------------------------------------------------------------------------
 int enq_split_candidates(vsv_handle* h, hipStream_t st) {
+  SlimWork w;
+  const bool slim = h->big_run && is_contig(h->prm.dtype);     // (a large-table run: the candidate tables are large too)
+  if (slim) { int ws = slim_work(h, w); if (ws) return ws; }
   h->split_sorted = vsv_launch_split_candidates(st, h->rv, h->prm, h->n_tids, (uint32_t*)h->tab.p, h->tab_size, (uint32_t*)h->blk_cnt.p,
                                                 (uint32_t*)h->blk_off.p, (uint32_t*)h->scan_tmp2.p, (uint64_t*)h->ckey.p, (uint32_t*)h->crec.p,
                                                 (uint64_t*)h->okey.p, (uint32_t*)h->oval.p, (uint64_t*)h->key2.p, (uint32_t*)h->idx2.p, sort_work(h),
-                                                (uint32_t)h->cap_sigs, dctr(h), (uint8_t*)h->cmask.p, ew_grid(h));
+                                                (uint32_t)h->cap_sigs, dctr(h), (uint8_t*)h->cmask.p, ew_grid(h), slim ? &w : nullptr);
   HIPCHK(h, hipGetLastError());
   h->split_cands_done = true;
   return 0;
@@ -399,19 +401,13 @@ int slim_work(vsv_handle* h, SlimWork& w) {
   int st;
   if ((st = ensure(h, h->sl_hj, n * 4 + 64))) return st;
   if ((st = ensure(h, h->sl_done, n * 4 + 64))) return st;
-  {  // look-back words of the chained-scan passes: zeroed once (epochs start at 1)
-    const size_t bytes = ((n + 4095) / 4096 + 1) * 512 * sizeof(uint64_t);
-    if (h->sl_state.bytes < bytes) {
-      if ((st = ensure(h, h->sl_state, bytes))) return st;
-      HIPCHK(h, hipMemsetAsync(h->sl_state.p, 0, h->sl_state.bytes, h->stream));
-    }
-  }
-  w.state = (uint64_t*)h->sl_state.p; w.epoch = &h->sl_epoch;
   w.cap = h->cap_sigs; w.hist = (uint32_t*)h->hist.p; w.totals = (uint32_t*)h->totals.p; w.pass_cursor = &h->pass_cursor;
   w.grid = ew_grid(h); w.cl = (int32_t*)h->cl.p; w.hj = (uint32_t*)h->sl_hj.p; w.done1 = (uint32_t*)h->sl_done.p;
   return 0;
 }
 int sort_bits(vsv_handle* h) { return pos_bits(h) + 3 + tid_bits(h); }
+// (tid - tid_lo) takes bits_for(n_tids - tid_lo) bits: none for a single-chromosome shard (tid_bits() keeps one more for the range check)
+int slim_tid_bits(vsv_handle* h) { return h->n_tids > h->rv.tid_lo ? bits_for((uint64_t)(h->n_tids - h->rv.tid_lo)) - (h->n_tids - h->rv.tid_lo == 1 ? 1 : 0) : tid_bits(h); }
 
 int enq_stage1(vsv_handle* h) {
   hipStream_t st = h->stream;
@@ -421,7 +417,7 @@ int enq_stage1(vsv_handle* h) {
   if (h->big_run) {
     SlimWork w;
     { int ws = slim_work(h, w); if (ws) return ws; }
-    h->sl_e2 = vsv_slim_stage1(st, (const vsv_sig*)h->s1in.p, &c->n_s1, &c->n_alive1, pos_bits(h), h->rv.tid_lo, tid_bits(h), h->prm.cluster_shift, w, c, h->sl_prebuilt);
+    h->sl_e2 = vsv_slim_stage1(st, (const vsv_sig*)h->s1in.p, &c->n_s1, &c->n_alive1, pos_bits(h), h->rv.tid_lo, slim_tid_bits(h), h->prm.cluster_shift, w, c, h->sl_prebuilt);
     h->c1_stale = true;
     HIPCHK(h, hipGetLastError());
     h->stage_done = 3;
@@ -441,7 +437,7 @@ int enq_merge(vsv_handle* h) {
   if (h->big_run) {
     SlimWork w;
     { int ws = slim_work(h, w); if (ws) return ws; }
-    h->sl_m = vsv_slim_merge(st, h->sl_e2, &c->n_alive1, &c->n_alive2, &c->n_alive3, pos_bits(h), tid_bits(h), h->prm.cluster_shift, w);
+    h->sl_m = vsv_slim_merge(st, h->sl_e2, &c->n_alive1, &c->n_alive2, &c->n_alive3, pos_bits(h), slim_tid_bits(h), h->prm.cluster_shift, w);
     h->merged_stale = true;
     HIPCHK(h, hipGetLastError());
     h->stage_done = 4;
@@ -463,7 +459,7 @@ int enq_pair(vsv_handle* h) {
   if (h->big_run) {
     SlimWork w;
     { int ws = slim_work(h, w); if (ws) return ws; }
-    vsv_slim_pair(st, h->sl_m, &c->n_alive3, &c->n_calls, pos_bits(h), tid_bits(h), h->prm.pair_shift, h->prm.pair_window, (const vsv_sig*)h->s1in.p,
+    vsv_slim_pair(st, h->sl_m, &c->n_alive3, &c->n_calls, pos_bits(h), slim_tid_bits(h), h->prm.pair_shift, h->prm.pair_window, (const vsv_sig*)h->s1in.p,
                   (vsv_call*)h->calls.p, h->dense_pairing, w, c);
     HIPCHK(h, hipGetLastError());
     h->stage_done = 5;
@@ -680,7 +676,6 @@ void vsv_destroy(vsv_handle* h) {
   for (DevBuf& b : h->sl) if (b.p) hipFree(b.p);
   if (h->sl_hj.p) hipFree(h->sl_hj.p);
   if (h->sl_done.p) hipFree(h->sl_done.p);
-  if (h->sl_state.p) hipFree(h->sl_state.p);
   if (h->pinned) hipHostFree(h->pinned);
   if (h->pin_buf) hipHostFree(h->pin_buf);
   if (h->names_pin) hipHostFree(h->names_pin);

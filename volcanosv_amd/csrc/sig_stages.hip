@@ -983,7 +983,7 @@ static SplitCfg split_cfg(const RecView& rv, const vsv_params& p, int n_tids) {
 SplitSorted vsv_launch_split_candidates(hipStream_t st, const RecView& rv, const vsv_params& p, int n_tids, uint32_t* tab, uint32_t tab_size,
                                         uint32_t* blk_cnt, uint32_t* blk_off, uint32_t* scan_tmp, uint64_t* ckey, uint32_t* crec,
                                         uint64_t* okey, uint32_t* oval, uint64_t* key2, uint32_t* idx2, const SortWork& sw,
-                                        uint32_t cap, Counters* ctr, uint8_t* cmask, int grid) {
+                                        uint32_t cap, Counters* ctr, uint8_t* cmask, int grid, const SlimWork* slim) {
   SplitSorted out{nullptr, nullptr, nullptr, nullptr};
   if (rv.n_records <= 0) return out;
   const SplitCfg c = split_cfg(rv, p, n_tids);
@@ -1004,6 +1004,15 @@ SplitSorted vsv_launch_split_candidates(hipStream_t st, const RecView& rv, const
   else {
     vsv_scan_u32_exclusive(st, blk_cnt, nblk, blk_off, scan_tmp);
     split_cand<true><<<nblk, 256, 0, st>>>(rv, c, tab, blk_off, ckey, crec, cap, vec, ctr, cmask, false);
+  }
+  if (slim) {
+    // large inputs (config 3: ~10^7 candidates): both sorts through the 8-bit passes over 16-byte elements (slim_path.hip; the
+    // 9-11 bit passes over separate key / value arrays write 16- and 8-byte pieces: 0.3-0.4 ms per pass there). Dead pair slots
+    // are dropped by the second sort's first pass: the live ones come first, as before.
+    const SortResult r1 = vsv_slim_sort_pairs(st, ckey, crec, &ctr->n_cand, c.tid_shift + c.tid_bits, sw.key_alt, sw.val_alt, &ctr->n_pairs, *slim);
+    const SortResult r2 = vsv_slim_sort_pair_slots(st, r1.key, r1.val, c.qid_bits, rec_bits, &ctr->n_cand, rec_bits + 1 + c.tid_bits, okey, oval, &ctr->n_pairs, *slim);
+    out.ckey = r1.key; out.crec = r1.val; out.okey = r2.key; out.oval = r2.val;
+    return out;
   }
   // the first result may live in the shared scratch pair, so the second sort gets a scratch pair of its own
   const SortResult r1 = vsv_radix_sort_pairs(st, ckey, crec, sw.key_alt, sw.val_alt, &ctr->n_cand, cap, c.tid_shift + c.tid_bits, sw,

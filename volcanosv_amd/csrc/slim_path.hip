@@ -109,6 +109,16 @@ struct SrcCalls {
   }
 };
 
+// The keys of the later stages carry list bits that are zero for every element (source after the first clustering, type after the
+// second, haplotype in the call keys): the passes sort on the key with those bits squeezed out, which saves a pass (30 bits = three
+// 10-bit passes for a single-chromosome shard).
+struct KeyCmp {
+  int zlo, zbits;      // `zbits` zero bits at bit `zlo` are not sorted on (zbits = 0: the key as it is)
+  __device__ __forceinline__ uint64_t operator()(uint64_t k) const {
+    return zbits ? ((k & ((1ull << zlo) - 1ull)) | ((k >> (zlo + zbits)) << zlo)) : k;
+  }
+};
+
 template <int BITS>
 __device__ __forceinline__ uint64_t sl_match_digit(uint32_t d, bool valid) {
   uint64_t m = __ballot(valid);
@@ -123,7 +133,7 @@ __device__ __forceinline__ uint32_t sl_tiles(uint32_t n) { return (n + SL_TILE -
 
 // hist[tile][d] = elements of the tile with digit d (dead elements of a first pass do not count); totals[d] += the same
 template <int BITS, typename SRC, bool SKIP_DEAD>
-__global__ __launch_bounds__(256) void sl_hist(SRC src, const uint32_t* __restrict__ d_n, int shift, uint32_t* __restrict__ hist, uint32_t* __restrict__ totals) {
+__global__ __launch_bounds__(256) void sl_hist(SRC src, const uint32_t* __restrict__ d_n, int shift, KeyCmp kc, uint32_t* __restrict__ hist, uint32_t* __restrict__ totals) {
   constexpr int BINS = 1 << BITS;
   __shared__ uint32_t cnt[BINS];
   const uint32_t n = *d_n, ntiles = sl_tiles(n);
@@ -136,7 +146,7 @@ __global__ __launch_bounds__(256) void sl_hist(SRC src, const uint32_t* __restri
       const uint32_t i = base + k * 256 + threadIdx.x;
       if (i < n) {
         const uint64_t key = src.at(i).key;
-        if (!SKIP_DEAD || key != VSV_KEY_DEAD) atomicAdd(&cnt[(uint32_t)(key >> shift) & (BINS - 1)], 1u);
+        if (!SKIP_DEAD || key != VSV_KEY_DEAD) atomicAdd(&cnt[(uint32_t)(kc(key) >> shift) & (BINS - 1)], 1u);
       }
     }
     __syncthreads();
@@ -215,7 +225,7 @@ __global__ __launch_bounds__(1024) void sl_scan(uint32_t* __restrict__ hist, con
 
 // stable scatter of one pass: ranks inside a wave from ballot matches, per-wave running counters in LDS (as rs_scatter)
 template <int BITS, typename SRC, bool SKIP_DEAD>
-__global__ __launch_bounds__(256) void sl_scatter(SRC src, const uint32_t* __restrict__ d_n, int shift, const uint32_t* __restrict__ hist, Slim* __restrict__ out) {
+__global__ __launch_bounds__(256) void sl_scatter(SRC src, const uint32_t* __restrict__ d_n, int shift, KeyCmp kc, const uint32_t* __restrict__ hist, Slim* __restrict__ out) {
   constexpr int BINS = 1 << BITS;
   __shared__ uint32_t wcnt[SL_WAVES][BINS];
   const uint32_t n = *d_n, ntiles = sl_tiles(n);
@@ -235,7 +245,7 @@ __global__ __launch_bounds__(256) void sl_scatter(SRC src, const uint32_t* __res
       bool ok = i < n;
       if (ok) e_[r] = src.at(i); else e_[r] = dead_slim();
       if (SKIP_DEAD) ok = ok && e_[r].key != VSV_KEY_DEAD;
-      const uint32_t d = (uint32_t)(e_[r].key >> shift) & (BINS - 1);
+      const uint32_t d = (uint32_t)(kc(e_[r].key) >> shift) & (BINS - 1);
       const uint64_t m = sl_match_digit<BITS>(d, ok);
       const uint32_t old = ok ? wcnt[wv][d] : 0;
       __builtin_amdgcn_wave_barrier();
@@ -253,141 +263,11 @@ __global__ __launch_bounds__(256) void sl_scatter(SRC src, const uint32_t* __res
 #pragma unroll
     for (int r = 0; r < SL_ROUNDS; ++r) {
       if (rk[r] != 0xFFFFFFFFu) {
-        const uint32_t d = (uint32_t)(e_[r].key >> shift) & (BINS - 1);
+        const uint32_t d = (uint32_t)(kc(e_[r].key) >> shift) & (BINS - 1);
         st_slim(out + wcnt[wv][d] + rk[r], e_[r]);
       }
     }
     __syncthreads();
-  }
-}
-
-// ---- the same passes in ONE kernel each (chained scan, "onesweep") -----------------------------------------------------------------
-// sl_hist + sl_scan + sl_scatter read every element twice per pass and keep a [tile][digit] matrix in between. Here one kernel
-// (sl_digit_totals) reads the sort's input once for the digit totals of ALL its passes — the multiset of live keys is the same in
-// every pass — and a pass is a single kernel: a block takes the next tile in order (a ticket), ranks its elements in registers,
-// publishes its per-digit counts and gets the counts of the tiles in front of it by looking BACK at what they have published
-// (aggregate first, inclusive prefix once known; thread d follows digit d). Tickets are taken in launch order, so every tile a
-// block waits for belongs to a block that is already running. State words carry an epoch (one per pass launch), so the state
-// buffer is never cleared. One read and one write of the elements per pass.
-constexpr uint64_t OS_AGG = 1ull << 32, OS_PFX = 2ull << 32;
-constexpr int OS_EPOCH_SHIFT = 34;
-constexpr int OS_MAX_PASSES = 8;
-
-template <typename SRC, bool SKIP_DEAD>
-__global__ __launch_bounds__(256) void sl_digit_totals(SRC src, const uint32_t* __restrict__ d_n, int passes, int bits, uint32_t* __restrict__ totals /* [passes][2048] */) {
-  __shared__ uint32_t cnt[OS_MAX_PASSES][512];
-  const uint32_t n = *d_n, ntiles = sl_tiles(n), bins = 1u << bits;
-  for (uint32_t k = threadIdx.x; k < (uint32_t)passes * 512u; k += 256) cnt[k >> 9][k & 511u] = 0;
-  __syncthreads();
-  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const uint32_t base = tile * SL_TILE;
-#pragma unroll 4
-    for (int k = 0; k < (int)SL_TILE / 256; ++k) {
-      const uint32_t i = base + k * 256 + threadIdx.x;
-      if (i < n) {
-        const uint64_t key = src.at(i).key;
-        if (!SKIP_DEAD || key != VSV_KEY_DEAD)
-          for (int p = 0; p < passes; ++p) atomicAdd(&cnt[p][(uint32_t)(key >> (p * bits)) & (bins - 1u)], 1u);
-      }
-    }
-  }
-  __syncthreads();
-  for (uint32_t k = threadIdx.x; k < (uint32_t)passes * bins; k += 256) {
-    const uint32_t p = k / bins, d = k % bins, c = cnt[p][d];
-    if (c) atomicAdd(&totals[(size_t)p * 2048 + d], c);
-  }
-}
-
-template <int BITS, typename SRC, bool FIRST>
-__global__ __launch_bounds__(256) void sl_onesweep(SRC src, const uint32_t* __restrict__ d_slots, int shift, uint32_t* __restrict__ totals /* this pass: digit totals, [2047] = ticket */,
-                                                   uint64_t* __restrict__ state, uint64_t epoch, Slim* __restrict__ out, uint32_t* __restrict__ d_live) {
-  constexpr int BINS = 1 << BITS, DPT = BINS / 256;
-  __shared__ uint32_t wcnt[SL_WAVES][BINS];
-  __shared__ uint32_t dbase[BINS];
-  __shared__ uint32_t wsum[SL_WAVES];
-  __shared__ uint32_t s_tile;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const uint64_t lt = (1ull << lane) - 1ull;
-  // digit bases = exclusive scan of the totals (thread t owns digits [t * DPT, (t + 1) * DPT)); their sum = the live elements
-  uint32_t tt[DPT], mine = 0;
-#pragma unroll
-  for (int k = 0; k < DPT; ++k) { tt[k] = totals[threadIdx.x * DPT + k]; mine += tt[k]; }
-  uint32_t incl = mine;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += o; }
-  if (lane == 63) wsum[wv] = incl;
-  __syncthreads();
-  uint32_t run0 = incl - mine;
-  for (int w = 0; w < wv; ++w) run0 += wsum[w];
-#pragma unroll
-  for (int k = 0; k < DPT; ++k) { dbase[threadIdx.x * DPT + k] = run0; run0 += tt[k]; }
-  const uint32_t live = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-  // a first pass walks the input SLOTS (dead ones included) and publishes the live count; the others walk the live elements
-  const uint32_t n = FIRST ? *d_slots : live, ntiles = sl_tiles(n);
-  if (FIRST && d_live && blockIdx.x == 0 && threadIdx.x == 0) *d_live = live;
-  const uint64_t ep = epoch << OS_EPOCH_SHIFT;
-  for (;;) {
-    __syncthreads();
-    if (threadIdx.x == 0) s_tile = atomicAdd(&totals[2047], 1u);
-    for (int d = threadIdx.x; d < BINS; d += 256)
-#pragma unroll
-      for (int w = 0; w < SL_WAVES; ++w) wcnt[w][d] = 0;
-    __syncthreads();
-    const uint32_t tile = s_tile;
-    if (tile >= ntiles) break;
-    const uint32_t wbase = tile * SL_TILE + wv * (SL_ROUNDS * 64);
-    Slim e_[SL_ROUNDS];
-    uint32_t rk[SL_ROUNDS];
-#pragma unroll
-    for (int r = 0; r < SL_ROUNDS; ++r) {
-      const uint32_t i = wbase + r * 64 + lane;
-      bool ok = i < n;
-      if (ok) e_[r] = src.at(i); else e_[r] = dead_slim();
-      if (FIRST) ok = ok && e_[r].key != VSV_KEY_DEAD;
-      const uint32_t d = (uint32_t)(e_[r].key >> shift) & (BINS - 1);
-      const uint64_t m = sl_match_digit<BITS>(d, ok);
-      const uint32_t old = ok ? wcnt[wv][d] : 0;
-      __builtin_amdgcn_wave_barrier();
-      if (ok && (m & lt) == 0) wcnt[wv][d] = old + (uint32_t)__popcll(m);
-      __builtin_amdgcn_wave_barrier();
-      rk[r] = ok ? old + (uint32_t)__popcll(m & lt) : 0xFFFFFFFFu;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < DPT; ++k) {
-      const int d = threadIdx.x * DPT + k;
-      uint32_t c[SL_WAVES], cnt = 0;
-#pragma unroll
-      for (int w = 0; w < SL_WAVES; ++w) { c[w] = wcnt[w][d]; cnt += c[w]; }
-      uint64_t* my = state + (size_t)tile * BINS + d;
-      uint32_t excl = 0;
-      if (tile == 0) __hip_atomic_store(my, ep | OS_PFX | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else {
-        __hip_atomic_store(my, ep | OS_AGG | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (uint32_t t = tile - 1;; --t) {                   // look back: aggregates until a tile that knows its inclusive prefix
-          uint64_t v;
-          for (;;) {
-            v = __hip_atomic_load(state + (size_t)t * BINS + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((v >> OS_EPOCH_SHIFT) == epoch && (v & (OS_AGG | OS_PFX))) break;
-            __builtin_amdgcn_s_sleep(1);
-          }
-          excl += (uint32_t)v;
-          if ((v & OS_PFX) || t == 0) break;
-        }
-        __hip_atomic_store(my, ep | OS_PFX | (uint64_t)(excl + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      uint32_t run = dbase[d] + excl;
-#pragma unroll
-      for (int w = 0; w < SL_WAVES; ++w) { wcnt[w][d] = run; run += c[w]; }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < SL_ROUNDS; ++r) {
-      if (rk[r] != 0xFFFFFFFFu) {
-        const uint32_t d = (uint32_t)(e_[r].key >> shift) & (BINS - 1);
-        st_slim(out + wcnt[wv][d] + rk[r], e_[r]);
-      }
-    }
   }
 }
 
@@ -598,122 +478,21 @@ __global__ __launch_bounds__(256) void sl_pair_prep(const Slim* __restrict__ m, 
   }
 }
 
-// One wave on a long stretch of type t that starts at hp1 row i: rows stay sequential, a row's candidate window is scanned 64 hp2
-// rows at a time and the first match is the lowest set ballot bit. Called by all 64 lanes, (i, jlo) wave-uniform.
-__device__ __forceinline__ void sl_pair_long(const Slim* __restrict__ m, const uint32_t n, KeyFmt kf, int pair_shift, int right,
-                                             const uint32_t* __restrict__ hj, int32_t* __restrict__ st, const uint32_t i, uint32_t jlo, const int lane,
-                                             uint32_t* __restrict__ max_stretch) {
-  const int sh_hap = kf.pb + 2;
-  const Slim first = ld_slim(m + i);
-  const uint64_t hp1_prefix = first.key >> sh_hap, hp2_prefix = hp1_prefix | 1ull;
-  const uint32_t t = first.idx & SL_DEL;
-  uint32_t count = 0;
-  for (uint32_t a = i; a < n; ++a) {
-    const Slim s1 = ld_slim(m + a);
-    if ((s1.key >> sh_hap) != hp1_prefix) break;
-    if ((s1.idx & SL_DEL) != t) continue;
-    if (a != i && (hj[a] & PJ_HEAD)) break;
-    ++count;
-    const int32_t p1 = kf.pos(s1.key);
-    for (;;) {                                     // first hp2 row at or after pos - shift (wave-uniform walk)
-      if (jlo >= n) break;
-      const Slim y = ld_slim(m + jlo);
-      if ((y.key >> sh_hap) != hp2_prefix || (int64_t)p1 - kf.pos(y.key) <= pair_shift) break;
-      ++jlo;
-    }
-    int32_t mate = -1;
-    for (uint32_t j0 = jlo; j0 < n; j0 += 64) {
-      const uint32_t j = j0 + lane;
-      bool valid = j < n;
-      Slim s2 = s1;
-      if (valid) s2 = ld_slim(m + j);
-      valid = valid && (s2.key >> sh_hap) == hp2_prefix;
-      const int32_t p2 = kf.pos(s2.key);
-      const bool inwin = valid && (int64_t)p2 - p1 <= right;
-      if (__ballot(inwin) == 0) break;
-      const bool ok = inwin && (s2.idx & SL_DEL) == t && ld_i32(&st[j]) == -1 && sl_match(p1, s1.svlen, p2, s2.svlen, t != 0, pair_shift);
-      const uint64_t bal = __ballot(ok);
-      if (bal) { mate = (int32_t)(j0 + (uint32_t)__builtin_ctzll(bal)); break; }
-    }
-    if (lane == 0) { st_i32(&st[a], mate); if (mate >= 0) st_i32(&st[mate], (int32_t)a); }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  if (lane == 0) atomicMax(max_stretch, count);    // a table with very long stretches is paired in rounds from the next run on
-}
-
-__global__ __launch_bounds__(256) void sl_pair_walk(const Slim* __restrict__ m, const uint32_t* __restrict__ d_n, KeyFmt kf, int pair_shift, int right,
-                                                    const uint32_t* __restrict__ hj, int32_t* __restrict__ st, uint32_t* __restrict__ max_stretch) {
-  const uint32_t n = *d_n;
-  const int lane = threadIdx.x & 63;
-  const int sh_hap = kf.pb + 2;
-  for (uint32_t i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += gridDim.x * blockDim.x) {   // wave-uniform trip count
-    const uint32_t i = i0 + (uint32_t)lane;
-    bool is_long = false;
-    uint32_t jlo = 0;
-    if (i < n) {
-      const Slim me = ld_slim(m + i);
-      const uint32_t w = hj[i];
-      if (!((me.key >> sh_hap) & 1ull) && (w & PJ_HEAD)) {
-        jlo = w & ~PJ_HEAD;
-        const uint64_t hp1_prefix = me.key >> sh_hap, hp2_prefix = hp1_prefix | 1ull;
-        const uint32_t t = me.idx & SL_DEL;
-        // rows of the stretch: this type's rows up to the next head
-        uint32_t cnt = 1, e = i + 1;
-        for (; e < n && cnt <= SL_LONG_RUN; ++e) {
-          const Slim x = ld_slim(m + e);
-          if ((x.key >> sh_hap) != hp1_prefix) break;
-          if ((x.idx & SL_DEL) != t) continue;
-          if (hj[e] & PJ_HEAD) break;
-          ++cnt;
-        }
-        if (cnt > SL_LONG_RUN) is_long = true;
-        else {
-          uint32_t jl = jlo;
-          for (uint32_t a = i; a < e; ++a) {
-            const Slim s1 = a == i ? me : ld_slim(m + a);
-            if ((s1.idx & SL_DEL) != t) continue;
-            const int32_t p1 = kf.pos(s1.key);
-            for (; jl < n; ++jl) {
-              const Slim y = ld_slim(m + jl);
-              if ((y.key >> sh_hap) != hp2_prefix || (int64_t)p1 - kf.pos(y.key) <= pair_shift) break;
-            }
-            int32_t mate = -1;
-            for (uint32_t j = jl; j < n; ++j) {
-              const Slim s2 = ld_slim(m + j);
-              if ((s2.key >> sh_hap) != hp2_prefix) break;
-              const int32_t p2 = kf.pos(s2.key);
-              if ((int64_t)p2 - p1 > right) break;
-              if ((s2.idx & SL_DEL) == t && st[j] == -1 && sl_match(p1, s1.svlen, p2, s2.svlen, t != 0, pair_shift)) {
-                mate = (int32_t)j; st[j] = (int32_t)a; break;                 // H:560-569
-              }
-            }
-            st[a] = mate;
-          }
-        }
-      }
-    }
-    uint64_t lm = __ballot(is_long);
-    while (lm) {
-      const int src = __builtin_ctzll(lm);
-      lm &= lm - 1;
-      sl_pair_long(m, n, kf, pair_shift, right, hj, st, (uint32_t)__shfl((int)i, src, 64), (uint32_t)__shfl((int)jlo, src, 64), lane, max_stretch);
-    }
-  }
-}
-
-// ---- the same walk with the tables staged in LDS -------------------------------------------------------------------------------
-// sl_pair_prep + sl_pair_walk chase dependent global loads (a row's first candidate by bisection, its window, the stretch's next
-// row): ~10 loads of ~1 us per hp1 row on one lane. Here a block stages a window of the hp1 rows (+ halo) and the hp2 rows they can
-// reach in LDS and does everything there: first candidates by bisection in LDS, stretch starts (compacted into a list so that the
-// walks run on dense lanes), the walks themselves — a walk evaluates the cut in front of every row itself, so no flag array is
-// needed; whatever lies outside the staged windows is read from global memory by the same accessors. st[] must be -1 everywhere
-// before the launch.
-constexpr int PW = 512, PW_BACK = 64, PW_FWD = 64, PW_A = PW_BACK + PW + PW_FWD, PW_B = 1024;
-
 __global__ __launch_bounds__(256) void sl_fill_i32(int32_t* __restrict__ p, int32_t v, const uint32_t* __restrict__ d_n) {
   const uint32_t n = *d_n;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v;
 }
+
+// ---- the walk from LDS -----------------------------------------------------------------------------------------------------
+// The walks are bound by instructions issued, not by bytes: a lane per stretch makes its wave wait for the longest stretch, a group of
+// lanes per stretch spends ~500 wave instructions per row. sl_pair_lds gives ONE wave a window of 256 slots: the window's hp1
+// rows (+ halo) and the hp2 rows they can reach are staged in LDS as (pos, svlen | type) pairs — 8 bytes per row, list membership
+// resolved at staging time — then (1) every hp1 row gets its first candidate by bisection in LDS and its stretch-start test, the
+// starts go to a list; (2) the lanes take stretches from the list until it is empty (a lane that finishes a short stretch takes the
+// next one: the wave is not held up by its longest stretch) and walk them a row per step: one sweep over the row's window advances
+// the candidate pointer, decides the cut in front of the row (no hp2 row of the type at or in front of prev + right) and finds the
+// mate. Rows outside the staged windows are read from global memory by the same accessors. st[] must be -1 before the launch.
+constexpr int QW = 256, QW_BACK = 64, QW_FWD = 64, QA = QW_BACK + QW + QW_FWD, QB = 512;
 
 // first index in [0, n) whose key is >= target, by the 64 lanes of a wave: 65-ary steps (4 dependent loads for 10^7 rows)
 __device__ __forceinline__ uint32_t sl_wave_lower_bound(const Slim* __restrict__ m, uint32_t n, uint64_t target, int lane) {
@@ -721,194 +500,274 @@ __device__ __forceinline__ uint32_t sl_wave_lower_bound(const Slim* __restrict__
   while (hi - lo > 64u) {
     const uint64_t span = (uint64_t)(hi - lo);
     const uint32_t probe = lo + (uint32_t)(span * (uint32_t)(lane + 1) / 65u);      // lo <= probe < hi, ascending with the lane
-    const bool ge = m[probe].key >= target;
-    const uint64_t bal = __ballot(ge);
-    // lanes below the first set bit hold keys < target, the first set lane a key >= target
-    const int f = bal ? __builtin_ctzll(bal) : 64;
+    const uint64_t bal = __ballot(m[probe].key >= target);
+    const int f = bal ? __builtin_ctzll(bal) : 64;        // lanes below f hold keys < target, lane f a key >= target
     const uint32_t nlo = f == 0 ? lo : (lo + (uint32_t)(span * (uint32_t)f / 65u)) + 1u;
     const uint32_t nhi = f == 64 ? hi : lo + (uint32_t)(span * (uint32_t)(f + 1) / 65u);
     lo = nlo; hi = nhi;
   }
   const uint32_t i = lo + (uint32_t)lane;
-  const bool ge = i < hi && m[i].key >= target;
-  const uint64_t bal = __ballot(ge);
+  const uint64_t bal = __ballot(i < hi && m[i].key >= target);
   return bal ? lo + (uint32_t)__builtin_ctzll(bal) : hi;
 }
 
-__global__ __launch_bounds__(256) void sl_pair_fused(const Slim* __restrict__ m, const uint32_t* __restrict__ d_n, KeyFmt kf, int pair_shift, int right,
-                                                     int32_t* __restrict__ st, uint32_t* __restrict__ max_stretch, int ablate) {
-  __shared__ uint4 shA[PW_A], shB[PW_B];
-  __shared__ uint2 heads[PW];
-  __shared__ int32_t takenB[PW_B];            // pairing state of the staged hp2 rows (every hp2 row of a type belongs to ONE stretch, i.e. one lane)
-  __shared__ uint32_t n_heads, rows_t[2], heads_t[2], s_j[2];
+__global__ __launch_bounds__(64) void sl_pair_lds(const Slim* __restrict__ m, const uint32_t* __restrict__ d_n, KeyFmt kf, int pair_shift, int right,
+                                                  int32_t* __restrict__ st, const uint32_t* __restrict__ widx, uint32_t* __restrict__ max_stretch) {
+  __shared__ int32_t a_pos[QA], b_pos[QB + 8];
+  __shared__ uint32_t a_lt[QA], b_lt[QB + 8];        // svlen | type << 31
+  __shared__ uint32_t a_pre[QA];                     // list of the slot: key >> hap bit (tid, hap)
+  __shared__ uint8_t b_taken[QB + 8];
+  __shared__ uint32_t h_a[QW], h_j[QW];
+  __shared__ uint32_t n_heads, next_head, rows_t[2], heads_t[2];
   const uint32_t n = *d_n;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x;
   const int sh_hap = kf.pb + 2;
-  auto unpack = [](const uint4 v) -> Slim { Slim x; x.key = (uint64_t)v.x | ((uint64_t)v.y << 32); x.svlen = (int32_t)v.z; x.idx = v.w; return x; };
-  for (uint32_t base = blockIdx.x * PW; base < n; base += gridDim.x * PW) {
-    const uint32_t a_lo = base >= (uint32_t)PW_BACK ? base - PW_BACK : 0u, a_hi = min(n, base + PW + PW_FWD), w_hi = min(n, base + PW);
+  const int64_t reach = (int64_t)pair_shift + right;
+  for (uint32_t base = blockIdx.x * QW; base < n; base += gridDim.x * QW) {
+    const uint32_t w_hi = min(n, base + QW);
+    // ---- stage the window's slots (+ halo): one round trip, everything else about them is decided from LDS ----
+    const uint32_t a_lo = base >= (uint32_t)QW_BACK ? base - QW_BACK : 0u, a_hi = min(n, w_hi + QW_FWD), a_cnt = a_hi - a_lo;
     __syncthreads();
-    if (threadIdx.x < 2) { rows_t[threadIdx.x] = 0; heads_t[threadIdx.x] = 0; }
-    if (threadIdx.x == 0) n_heads = 0;
-    for (uint32_t k = threadIdx.x; k < a_hi - a_lo; k += 256) shA[k] = *reinterpret_cast<const uint4*>(m + a_lo + k);
-    // the hp2 rows this window can reach: [first candidate of its first row, first row beyond the reach of its last row)
-    if (wv < 2) {
-      const Slim e = ld_slim(m + (wv == 0 ? a_lo : a_hi - 1));
-      uint32_t r = 0;
-      if (!((e.key >> sh_hap) & 1ull)) {
-        const int64_t p = wv == 0 ? (int64_t)kf.pos(e.key) - pair_shift : (int64_t)kf.pos(e.key) + right + 1;
-        const uint64_t target = (((e.key >> sh_hap) | 1ull) << sh_hap) | vsv_kpos((int32_t)max(p, (int64_t)-VSV_POS_BIAS));
-        r = sl_wave_lower_bound(m, n, target, lane);
-      }
-      if (lane == 0) s_j[wv] = r;
+    for (uint32_t r = lane; r < a_cnt; r += 64) {
+      const Slim x = ld_slim(m + a_lo + r);
+      a_pos[r] = kf.pos(x.key);
+      a_lt[r] = ((uint32_t)x.svlen & 0x7FFFFFFFu) | (x.idx & SL_DEL);
+      a_pre[r] = (uint32_t)(x.key >> sh_hap);
     }
     __syncthreads();
-    const uint32_t j0 = s_j[0], j1 = s_j[1] > s_j[0] ? min(s_j[1], s_j[0] + (uint32_t)PW_B) : s_j[0];
-    for (uint32_t k = threadIdx.x; k < j1 - j0; k += 256) { shB[k] = *reinterpret_cast<const uint4*>(m + j0 + k); takenB[k] = -1; }
-    __syncthreads();
-    auto getA = [&](uint32_t k) -> Slim { const uint32_t rel = k - a_lo; return rel < a_hi - a_lo ? unpack(shA[rel]) : ld_slim(m + k); };
-    auto getB = [&](uint32_t j) -> Slim { const uint32_t rel = j - j0; return rel < j1 - j0 ? unpack(shB[rel]) : ld_slim(m + j); };
-    // ---- phase 1: first candidates and stretch starts of the window's hp1 rows ----
-    for (uint32_t i = base + threadIdx.x; i < w_hi && !(ablate & 2); i += 256) {
-      const Slim me = getA(i);
-      if ((me.key >> sh_hap) & 1ull) continue;
-      const uint32_t t = me.idx & SL_DEL;
-      const int32_t pb_ = kf.pos(me.key);
-      const uint64_t hp1_prefix = me.key >> sh_hap, hp2_prefix = hp1_prefix | 1ull;
-      const uint64_t target = (hp2_prefix << sh_hap) | vsv_kpos((int32_t)max((int64_t)pb_ - pair_shift, (int64_t)-VSV_POS_BIAS));
-      uint32_t jlo;
-      if (j1 > j0 && unpack(shB[0]).key < target && unpack(shB[j1 - j0 - 1]).key >= target) {     // the answer lies inside the staged rows
-        uint32_t lo = 0, hi = j1 - j0 - 1;                     // key[lo] < target <= key[hi]
-        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (unpack(shB[mid]).key >= target) hi = mid; else lo = mid; }
-        jlo = j0 + hi;
-      } else jlo = sl_lower_bound(m, n, target);
-      bool head = true;
-      for (uint32_t k = i; k-- > 0;) {
-        const Slim x = getA(k);
-        if ((x.key >> sh_hap) != hp1_prefix) break;
-        const int32_t pa = kf.pos(x.key);
-        if ((int64_t)pb_ - pa > (int64_t)pair_shift + right) break;      // nothing earlier shares a candidate with this row
-        if ((x.idx & SL_DEL) != t) continue;
-        for (uint32_t j = jlo; j < n; ++j) {                             // an hp2 row of the type in [pos_b - shift, pos_a + right]?
-          const Slim y = getB(j);
-          if ((y.key >> sh_hap) != hp2_prefix || (int64_t)kf.pos(y.key) - pa > right) break;
-          if ((y.idx & SL_DEL) == t) { head = false; break; }
-        }
-        break;
+    uint32_t sub = base;
+    while (sub < w_hi) {
+      // ---- the next run of hp1 rows of one list inside the window: [s_lo, s_hi) ----
+      uint32_t s_lo = w_hi, s_hi = w_hi;
+      for (uint32_t q = sub; q < w_hi && s_lo == w_hi; q += 64) {
+        const uint32_t k = q + lane;
+        const uint64_t bal = __ballot(k < w_hi && !(a_pre[k - a_lo] & 1u));
+        if (bal) s_lo = q + (uint32_t)__builtin_ctzll(bal);
       }
-      atomicAdd(&rows_t[t ? 1 : 0], 1u);
-      if (head) { atomicAdd(&heads_t[t ? 1 : 0], 1u); heads[atomicAdd(&n_heads, 1u)] = make_uint2(i, jlo); }
-    }
-    __syncthreads();
-    if (threadIdx.x < 2 && rows_t[threadIdx.x] >= 384u && heads_t[threadIdx.x] == 0u) atomicMax(max_stretch, 4096u);   // a giant stretch passes through
-    // ---- phase 2: eight lanes per stretch ----
-    // A lane per stretch leaves the wave waiting for its longest lane, every step of which is a dependent LDS read. Here a group
-    // of 8 lanes owns a stretch: the rows stay sequential, but the pointer advance, the candidate window (with the cut test in
-    // front of the row folded into the same sweep: the cut holds iff no hp2 row of the type turns up before the first row beyond
-    // prev + right) and the search for the stretch's next row each look at 8 elements per step; group ballots decide.
-    const uint32_t nh = (ablate & 1) ? 0u : n_heads;
-    const int grp = threadIdx.x >> 3, sub = threadIdx.x & 7, gsh = lane & ~7;
-    auto gballot = [&](bool p) -> uint32_t { return (uint32_t)(__ballot(p) >> gsh) & 0xFFu; };
-    for (uint32_t h0 = 0; h0 < nh; h0 += 32) {
-      const uint32_t h = h0 + (uint32_t)grp;
-      bool active = h < nh;
-      uint32_t a = 0, jl = 0, cnt = 0, t = 0;
-      int32_t prev_pos = 0;
-      uint64_t hp1_prefix = 0, hp2_prefix = 1;
-      Slim s1 = dead_slim();
-      if (active) {
-        a = heads[h].x; jl = heads[h].y;
-        s1 = getA(a);
-        t = s1.idx & SL_DEL;
-        hp1_prefix = s1.key >> sh_hap; hp2_prefix = hp1_prefix | 1ull;
+      if (s_lo >= w_hi) break;
+      const uint32_t P1 = a_pre[s_lo - a_lo], P2 = P1 | 1u;
+      for (uint32_t q = s_lo; q < w_hi && s_hi == w_hi; q += 64) {
+        const uint32_t k = q + lane;
+        const uint64_t bal = __ballot(k < w_hi && a_pre[k - a_lo] != P1);
+        if (bal) s_hi = q + (uint32_t)__builtin_ctzll(bal);
       }
-      while (__ballot(active)) {
-        const int32_t p1 = kf.pos(s1.key);
-        // 1. first hp2 row at or after pos - shift
-        bool adv = active;
-        while (__ballot(adv)) {
-          const uint32_t j = jl + (uint32_t)sub;
-          bool passed = false;
-          if (adv && j < n) { const Slim y = getB(j); passed = (y.key >> sh_hap) == hp2_prefix && (int64_t)p1 - kf.pos(y.key) > pair_shift; }
-          const uint32_t k = (uint32_t)__builtin_ctz(~gballot(passed) | 0x100u);      // rows in front of the first one that stays
-          if (adv) { jl += k; if (k < 8u) adv = false; }
+      sub = s_hi;
+      // rows of list P1 among the staged slots: [a_vlo, a_vhi) (the list is contiguous)
+      uint32_t a_vlo = s_lo, a_vhi = s_hi;
+      for (uint32_t q = 0; q < a_cnt; q += 64) {
+        const uint32_t r = q + lane;
+        const uint64_t bal = __ballot(r < a_cnt && a_pre[r] == P1);
+        if (bal) {
+          const uint32_t first = a_lo + q + (uint32_t)__builtin_ctzll(bal), last = a_lo + q + 63u - (uint32_t)__builtin_clzll(bal);
+          if (first < a_vlo) a_vlo = first;
+          if (last + 1 > a_vhi) a_vhi = last + 1;
         }
-        // 2. the candidate window, 8 rows per step
-        bool scanning = active, cut = false, seen_t = cnt == 0;
+      }
+      // ---- the hp2 rows the staged rows can reach start at j0 (precomputed for the window's first staged slot); QB rows from there ----
+      uint32_t j0;
+      if (a_vlo == a_lo && widx) j0 = widx[base / QW];
+      else {
+        const int64_t p_first = (int64_t)a_pos[a_vlo - a_lo] - pair_shift;
+        j0 = sl_wave_lower_bound(m, n, ((uint64_t)P2 << sh_hap) | vsv_kpos((int32_t)max(p_first, (int64_t)-VSV_POS_BIAS)), lane);
+      }
+      __syncthreads();
+      if (lane < 2) { rows_t[lane] = 0; heads_t[lane] = 0; }
+      if (lane == 0) { n_heads = 0; next_head = 0; }
+      uint32_t b_cnt = QB;                           // leading staged rows that belong to list P2
+      for (uint32_t q = 0; q < (uint32_t)QB; q += 64) {
+        const uint32_t r = q + lane, j = j0 + r;
+        bool ok = j < n;
+        if (ok) {
+          const Slim y = ld_slim(m + j);
+          ok = (uint32_t)(y.key >> sh_hap) == P2;
+          b_pos[r] = kf.pos(y.key);
+          b_lt[r] = ((uint32_t)y.svlen & 0x7FFFFFFFu) | (y.idx & SL_DEL);
+          b_taken[r] = 0;
+        }
+        const uint64_t bad = ~__ballot(ok);
+        if (bad && b_cnt == (uint32_t)QB) b_cnt = q + (uint32_t)__builtin_ctzll(bad);
+      }
+      const bool clipped = b_cnt == (uint32_t)QB;    // the list may go on behind the staged rows (else it ends there)
+      // a list that ends inside the staged rows is followed by eight rows "beyond every window": the batched sweep may read past its end
+      if (!clipped && lane < 8) { b_pos[b_cnt + lane] = 0x7FFFFFFF; b_lt[b_cnt + lane] = 0; b_taken[b_cnt + lane] = 1; }
+      const uint32_t b_pad = clipped ? b_cnt : b_cnt + 8u;
+      __syncthreads();
+      auto getA = [&](uint32_t k, int32_t& p, uint32_t& lt) -> bool {          // row k of list P1?
+        const uint32_t rel = k - a_lo;
+        if (rel < a_cnt) { p = a_pos[rel]; lt = a_lt[rel]; return k >= a_vlo && k < a_vhi; }
+        if (k >= n) return false;
+        const Slim x = ld_slim(m + k);
+        p = kf.pos(x.key); lt = ((uint32_t)x.svlen & 0x7FFFFFFFu) | (x.idx & SL_DEL);
+        return (uint32_t)(x.key >> sh_hap) == P1;
+      };
+      auto getB = [&](uint32_t j, int32_t& p, uint32_t& lt) -> bool {          // hp2 row j of list P2?
+        const uint32_t rel = j - j0;
+        if (rel < b_cnt) { p = b_pos[rel]; lt = b_lt[rel]; return true; }
+        if (!clipped || j >= n) return false;
+        const Slim y = ld_slim(m + j);
+        p = kf.pos(y.key); lt = ((uint32_t)y.svlen & 0x7FFFFFFFu) | (y.idx & SL_DEL);
+        return (uint32_t)(y.key >> sh_hap) == P2;
+      };
+      // ---- phase 1: first candidate and stretch-start test of the window's rows ----
+      for (uint32_t i = s_lo + lane; i < s_hi; i += 64) {
+        const int32_t pb_ = a_pos[i - a_lo];
+        const uint32_t t = a_lt[i - a_lo] & SL_DEL;
+        const int32_t tp = (int32_t)max((int64_t)pb_ - pair_shift, (int64_t)-VSV_POS_BIAS);
+        uint32_t jlo;
+        if (b_cnt == 0) jlo = j0;
+        else if (b_pos[0] >= tp) jlo = j0;                                           // (j0 is the answer for the smallest target among the staged rows)
+        else if (b_pos[b_cnt - 1] >= tp) {
+          uint32_t lo = 0, hi = b_cnt - 1;                                           // pos[lo] < tp <= pos[hi]
+          while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (b_pos[mid] >= tp) hi = mid; else lo = mid; }
+          jlo = j0 + hi;
+        } else if (!clipped) jlo = j0 + b_cnt;                                       // behind the list's last row
+        else jlo = sl_lower_bound(m, n, ((uint64_t)P2 << sh_hap) | vsv_kpos(tp));
+        bool head = true;
+        for (uint32_t k = i; k-- > 0;) {
+          int32_t pa; uint32_t lt;
+          if (!getA(k, pa, lt)) break;
+          if ((int64_t)pb_ - pa > reach) break;                          // nothing earlier shares a candidate with this row
+          if ((lt & SL_DEL) != t) continue;
+          for (uint32_t j = jlo;; ++j) {                                 // an hp2 row of the type in [pos_b - shift, pos_a + right]?
+            int32_t py; uint32_t ly;
+            if (!getB(j, py, ly) || (int64_t)py - pa > right) break;
+            if ((ly & SL_DEL) == t) { head = false; break; }
+          }
+          break;
+        }
+        atomicAdd(&rows_t[t ? 1 : 0], 1u);
+        if (head) { atomicAdd(&heads_t[t ? 1 : 0], 1u); const uint32_t s = atomicAdd(&n_heads, 1u); h_a[s] = i; h_j[s] = jlo; }
+      }
+      __syncthreads();
+      if (lane < 2 && rows_t[lane] >= 96u && heads_t[lane] == 0u) atomicMax(max_stretch, 4096u);        // a giant stretch passes through
+      // ---- phase 2: lanes take stretches until the list is empty; a row per step ----
+      const uint32_t nh = n_heads;
+      bool active = false;
+      uint32_t a = 0, jl = 0, cnt = 0, t = 0, l1 = 0;
+      int32_t p1 = 0, prev = 0;
+      for (;;) {
+        if (!active) {
+          const uint32_t h = atomicAdd(&next_head, 1u);
+          if (h < nh) {
+            a = h_a[h]; jl = h_j[h]; cnt = 0;
+            p1 = a_pos[a - a_lo]; l1 = a_lt[a - a_lo]; t = l1 & SL_DEL;
+            active = true;
+          }
+        }
+        if (!__ballot(active)) break;
+        if (!active) continue;
+        // One sweep over the row's window: rows in front of pos - shift are passed for good, then the cut test, then the mate.
+        // The kernel is bound by instructions ISSUED (divergent loops cost scalar mask bookkeeping per trip), so the sweep takes the
+        // staged candidates eight at a time in straight-line code: five predicate masks, first-set-bit arithmetic, no branch per
+        // candidate. (Positions ascend: "passed" is a prefix of the batch, "beyond" and "past" are suffixes.)
+        bool seen_t = cnt == 0, cut = false, done = false;
         int32_t mate = -1;
-        uint32_t jc = jl;
-        while (__ballot(scanning)) {
-          const uint32_t j = jc + (uint32_t)sub;
-          bool valid = scanning && j < n;
-          Slim y = s1;
-          if (valid) y = getB(j);
-          valid = valid && (y.key >> sh_hap) == hp2_prefix;
-          const int32_t p2 = kf.pos(y.key);
-          const bool beyond = !valid || (int64_t)p2 - p1 > right;
-          const bool is_t = !beyond && (y.idx & SL_DEL) == t;
-          const bool past = !beyond && (int64_t)p2 - prev_pos > right;             // beyond the reach of the stretch's previous row
-          bool ok = false;
-          if (is_t) {
+        const int32_t v1 = (int32_t)(l1 & 0x7FFFFFFFu);
+        while (!done && jl - j0 + 8u <= b_pad) {
+          const uint32_t jb = jl, r0 = jb - j0;
+          uint32_t m_passed = 0, m_beyond = 0, m_past = 0, m_t = 0, m_ok = 0;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int32_t p2 = b_pos[r0 + u];
+            const uint32_t l2 = b_lt[r0 + u];
+            const bool ist = (l2 & SL_DEL) == t;
+            m_passed |= ((int64_t)p1 - p2 > pair_shift ? 1u : 0u) << u;
+            m_beyond |= ((int64_t)p2 - p1 > right ? 1u : 0u) << u;
+            m_past |= ((int64_t)p2 - prev > right ? 1u : 0u) << u;
+            m_t |= (ist ? 1u : 0u) << u;
+            m_ok |= (ist && b_taken[r0 + u] == 0 && sl_match(p1, v1, p2, (int32_t)(l2 & 0x7FFFFFFFu), t != 0, pair_shift) ? 1u : 0u) << u;
+          }
+          const uint32_t np = (uint32_t)__builtin_ctz(~m_passed | 0x100u);           // rows in front of pos - shift: passed for good
+          if (np == 8u) { jl = jb + 8u; continue; }
+          jl = jb + np;
+          const uint32_t e = (uint32_t)__builtin_ctz(m_beyond | 0x100u);
+          const uint32_t live = ((1u << e) - 1u) & ~((1u << np) - 1u);              // the row's candidates in this batch
+          const uint32_t ft = (uint32_t)__builtin_ctz((m_t & live) | 0x100u), fp = (uint32_t)__builtin_ctz((m_past & live) | 0x100u);
+          const uint32_t fo = (uint32_t)__builtin_ctz((m_ok & live) | 0x100u);
+          if (!seen_t) {
+            if (fp < 8u && fp <= ft) cut = true;                  // no row of the type at or in front of prev + right
+            else if (ft < 8u) seen_t = true;
+          }
+          done = true;
+          if (cut) break;
+          if (fo < 8u) { mate = (int32_t)(jb + fo); break; }                                // H:560-569
+          if (e < 8u) break;                                      // the window ended inside the batch
+          for (uint32_t j = jb + 8u;; ++j) {                     // it goes on behind the batch: the rest of it, a row at a time
+            int32_t p2; uint32_t l2;
+            if (!getB(j, p2, l2)) break;
+            if (!seen_t && (int64_t)p2 - prev > right) { cut = true; break; }
+            if ((int64_t)p2 - p1 > right) break;
+            if ((l2 & SL_DEL) != t) continue;
+            seen_t = true;
             const uint32_t rel = j - j0;
-            const bool fr = rel < j1 - j0 ? takenB[rel] == -1 : ld_i32(&st[j]) == -1;
-            ok = fr && sl_match(p1, s1.svlen, p2, y.svlen, t != 0, pair_shift);
-          }
-          const uint32_t b_e = gballot(beyond), b_t = gballot(is_t), b_p = gballot(past), b_ok = gballot(ok);
-          if (scanning) {
-            const uint32_t e = (uint32_t)__builtin_ctz(b_e | 0x100u), mk = (1u << e) - 1u;
-            const uint32_t ft = (uint32_t)__builtin_ctz((b_t & mk) | 0x100u), fp = (uint32_t)__builtin_ctz((b_p & mk) | 0x100u);
-            if (!seen_t) {
-              if (fp < 8u && fp <= ft) cut = true;           // no row of the type in [pos - shift, prev + right]
-              else if (ft < 8u) seen_t = true;
-              else if (e < 8u) cut = true;                   // (the window ended without one)
-            }
-            if (cut) scanning = false;
-            else {
-              const uint32_t fo = (uint32_t)__builtin_ctz((b_ok & mk) | 0x100u);
-              if (fo < 8u) { mate = (int32_t)(jc + fo); scanning = false; }                          // H:560-569
-              else if (e < 8u) scanning = false;
-              else jc += 8u;
-            }
+            if ((rel < b_cnt ? b_taken[rel] == 0 : st[j] == -1) && sl_match(p1, v1, p2, (int32_t)(l2 & 0x7FFFFFFFu), t != 0, pair_shift)) { mate = (int32_t)j; break; }
           }
         }
-        // 3. the row's result
-        if (active) {
-          if (cut) active = false;                           // the row starts a stretch of its own (another group walks it)
-          else {
-            if (sub == 0) {
-              st[a] = mate;
-              if (mate >= 0) {
-                const uint32_t rel = (uint32_t)mate - j0;
-                if (rel < j1 - j0) takenB[rel] = (int32_t)a;
-                st_i32(&st[mate], (int32_t)a);
-              }
-            }
-            ++cnt; prev_pos = p1;
+        if (!done) {                                              // candidates outside the staged rows: the same sweep, a row at a time
+          for (uint32_t j = jl;; ++j) {
+            int32_t p2; uint32_t l2;
+            if (!getB(j, p2, l2)) break;
+            if ((int64_t)p1 - p2 > pair_shift) { jl = j + 1; continue; }
+            if (!seen_t && (int64_t)p2 - prev > right) { cut = true; break; }
+            if ((int64_t)p2 - p1 > right) break;
+            if ((l2 & SL_DEL) != t) continue;
+            seen_t = true;
+            const uint32_t rel = j - j0;
+            if ((rel < b_cnt ? b_taken[rel] == 0 : st[j] == -1) && sl_match(p1, v1, p2, (int32_t)(l2 & 0x7FFFFFFFu), t != 0, pair_shift)) { mate = (int32_t)j; break; }
           }
         }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the group's next row sees the state (LDS, or L2 for unstaged rows)
-        // 4. the list's next row of this type
-        bool seek = active;
-        uint32_t kb = a + 1u;
-        while (__ballot(seek)) {
-          const uint32_t k = kb + (uint32_t)sub;
-          const bool inb = seek && k < n;
-          Slim x = s1;
-          if (inb) x = getA(k);
-          const bool stop = seek && (!inb || (x.key >> sh_hap) != hp1_prefix);
-          const bool is_t = inb && !stop && (x.idx & SL_DEL) == t;
-          const uint32_t fs = (uint32_t)__builtin_ctz(gballot(stop) | 0x100u), ft = (uint32_t)__builtin_ctz(gballot(is_t) | 0x100u);
-          const int srcl = gsh + (int)(ft < 8u ? ft : 0u);
-          Slim nx;
-          nx.key = __shfl(x.key, srcl, 64); nx.svlen = __shfl(x.svlen, srcl, 64); nx.idx = (uint32_t)__shfl((int)x.idx, srcl, 64);
-          if (seek) {
-            if (ft < fs) { a = kb + ft; s1 = nx; seek = false; }
-            else if (fs < 8u) { active = false; seek = false; }
-            else kb += 8u;
+        if (cut || !seen_t) {                         // no hp2 row of the type in [pos - shift, prev + right]: the row starts its own stretch
+          if (cnt > 1024u) atomicMax(max_stretch, cnt);
+          active = false;
+          continue;
+        }
+        st[a] = mate;
+        if (mate >= 0) { st[mate] = (int32_t)a; const uint32_t rel = (uint32_t)mate - j0; if (rel < b_cnt) b_taken[rel] = 1; }
+        ++cnt; prev = p1;
+        bool more = false, ended = false;             // the list's next row of this type: four staged slots at a time
+        uint32_t k = a + 1;
+        while (k - a_lo + 4u <= a_cnt) {
+          const uint32_t r0 = k - a_lo;
+          uint32_t m_stop = 0, m_t = 0;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            m_stop |= (a_pre[r0 + u] != P1 ? 1u : 0u) << u;
+            m_t |= ((a_lt[r0 + u] & SL_DEL) == t ? 1u : 0u) << u;
+          }
+          const uint32_t fs = (uint32_t)__builtin_ctz(m_stop | 0x10u), ft = (uint32_t)__builtin_ctz(m_t | 0x10u);
+          if (ft < fs) { a = k + ft; p1 = a_pos[r0 + ft]; l1 = a_lt[r0 + ft]; more = true; break; }
+          if (fs < 4u) { ended = true; break; }
+          k += 4u;
+        }
+        if (!more && !ended) {
+          for (;; ++k) {
+            int32_t pk; uint32_t lk;
+            if (!getA(k, pk, lk)) break;
+            if ((lk & SL_DEL) == t) { a = k; p1 = pk; l1 = lk; more = true; break; }
           }
         }
+        if (!more) { if (cnt > 1024u) atomicMax(max_stretch, cnt); active = false; }
       }
-      if (sub == 0 && cnt > 1024u) atomicMax(max_stretch, cnt);
+    }
+  }
+}
+
+// st[] = -1 for the pairing, and for every window of sl_pair_lds the first hp2 row its first staged slot can reach (one bisection per
+// window here, in parallel, instead of a chain of dependent loads at the start of every window's wave)
+__global__ __launch_bounds__(256) void sl_pair_index(const Slim* __restrict__ m, const uint32_t* __restrict__ d_n, KeyFmt kf, int pair_shift,
+                                                     int32_t* __restrict__ st, uint32_t* __restrict__ widx) {
+  const uint32_t n = *d_n;
+  const int sh_hap = kf.pb + 2;
+  const uint32_t nwin = (n + QW - 1) / QW;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    st[i] = -1;
+    if (i < nwin) {
+      const uint32_t base = i * QW, s = base >= (uint32_t)QW_BACK ? base - QW_BACK : 0u;
+      const Slim x = ld_slim(m + s);
+      uint32_t r = 0;
+      if (!((x.key >> sh_hap) & 1ull))
+        r = sl_lower_bound(m, n, (((x.key >> sh_hap) | 1ull) << sh_hap) | vsv_kpos((int32_t)max((int64_t)kf.pos(x.key) - pair_shift, (int64_t)-VSV_POS_BIAS)));
+      widx[i] = r;
     }
   }
 }
@@ -1025,49 +884,45 @@ __global__ __launch_bounds__(256) void sl_rows_out(const Slim* __restrict__ e, u
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------------
 template <int BITS, typename SRC, bool SKIP>
-void sl_pass(hipStream_t st, SRC src, const uint32_t* d_n, int shift, Slim* out, uint32_t* hist, uint32_t* totals, uint32_t* d_total, int grid) {
-  sl_hist<BITS, SRC, SKIP><<<grid, 256, 0, st>>>(src, d_n, shift, hist, totals);
+void sl_pass(hipStream_t st, SRC src, const uint32_t* d_n, int shift, KeyCmp kc, Slim* out, uint32_t* hist, uint32_t* totals, uint32_t* d_total, int grid) {
+  sl_hist<BITS, SRC, SKIP><<<grid, 256, 0, st>>>(src, d_n, shift, kc, hist, totals);
   sl_scan<BITS><<<(1 << BITS) / 16, 1024, 0, st>>>(hist, totals, d_n, d_total);
-  sl_scatter<BITS, SRC, SKIP><<<grid, 256, 0, st>>>(src, d_n, shift, hist, out);
+  sl_scatter<BITS, SRC, SKIP><<<grid, 256, 0, st>>>(src, d_n, shift, kc, hist, out);
 }
 
 // Stable sort of the live elements of `src` (n slots, *d_slots) by key bits [0, nbits): the first pass skips dead elements and
 // publishes the live count (*d_live), the later passes run on that count. Ping-pong between a and b; returns the buffer that holds
 // the result (nothing is copied back).
-template <typename SRC>
-Slim* sl_sort(hipStream_t st, SRC src, const uint32_t* d_slots, uint32_t* d_live, int nbits, Slim* a, Slim* b, const SlimWork& w) {
+// digit plan of a sort on `nbits` significant bits: 8-bit passes, or 10-bit ones when that saves a pass (a 10-bit pass costs ~10 % more
+// than an 8-bit one: 64-byte instead of 256-byte pieces per tile and digit, a four times larger histogram)
+struct DigitPlan { int bits, passes; };
+DigitPlan sl_plan(int nbits) {
   if (nbits < 1) nbits = 1;
-  int passes = (nbits + 8) / 9;
-  const int bits = (nbits + passes - 1) / passes <= 8 ? 8 : 9;
-  passes = (nbits + bits - 1) / bits;
+  const int p8 = (nbits + 7) / 8, p10 = (nbits + 9) / 10;
+  static const int force_bits = vsv_dbg_env("VSV_SLIM_BITS") ? atoi(vsv_dbg_env("VSV_SLIM_BITS")) : 0;     // timing experiments
+  if (force_bits == 8) return DigitPlan{8, p8};
+  if (force_bits == 10) return DigitPlan{10, p10};
+  return p10 < p8 ? DigitPlan{10, p10} : DigitPlan{8, p8};
+}
+template <typename SRC>
+Slim* sl_sort(hipStream_t st, SRC src, const uint32_t* d_slots, uint32_t* d_live, int nbits, KeyCmp kc, Slim* a, Slim* b, const SlimWork& w) {
+  const DigitPlan dp = sl_plan(nbits - kc.zbits);
+  const int bits = dp.bits, passes = dp.passes;
   const int64_t max_tiles = (w.cap + SL_TILE - 1) / SL_TILE;
   const int grid = (int)(max_tiles < 2048 ? (max_tiles < 1 ? 1 : max_tiles) : 2048);
   Slim* dst = a;
   Slim* other = b;
-  // the chained-scan passes measure the same as histogram + scan + scatter (row 2c: 4.72 ms per step either way: with ~770 blocks
-  // resident and ~1500 tiles, half of the tiles look back over hundreds of aggregates); they stay behind VSV_SLIM_SORT=chain
-  static const char* mode = vsv_dbg_env("VSV_SLIM_SORT");
-  const bool chained = mode && mode[0] == 'c' && passes <= OS_MAX_PASSES && w.state != nullptr;
-  uint32_t* totals0 = w.totals + (size_t)(*w.pass_cursor) * 2048;
-  if (chained) sl_digit_totals<SRC, true><<<grid < 1024 ? grid : 1024, 256, 0, st>>>(src, d_slots, passes, bits, totals0);
   for (int p = 0; p < passes; ++p) {
     uint32_t* totals = w.totals + (size_t)(*w.pass_cursor) * 2048;
     ++*w.pass_cursor;
     const int shift = p * bits;
-    const uint64_t epoch = ++*w.epoch & ((1ull << 30) - 1ull);
     if (p == 0) {
-      if (chained) {
-        if (bits == 8) sl_onesweep<8, SRC, true><<<grid, 256, 0, st>>>(src, d_slots, shift, totals, w.state, epoch, dst, d_live);
-        else sl_onesweep<9, SRC, true><<<grid, 256, 0, st>>>(src, d_slots, shift, totals, w.state, epoch, dst, d_live);
-      } else if (bits == 8) sl_pass<8, SRC, true>(st, src, d_slots, shift, dst, w.hist, totals, d_live, grid);
-      else sl_pass<9, SRC, true>(st, src, d_slots, shift, dst, w.hist, totals, d_live, grid);
+      if (bits == 8) sl_pass<8, SRC, true>(st, src, d_slots, shift, kc, dst, w.hist, totals, d_live, grid);
+      else sl_pass<10, SRC, true>(st, src, d_slots, shift, kc, dst, w.hist, totals, d_live, grid);
     } else {
       const SrcSlim in{other};
-      if (chained) {
-        if (bits == 8) sl_onesweep<8, SrcSlim, false><<<grid, 256, 0, st>>>(in, d_live, shift, totals, w.state, epoch, dst, nullptr);
-        else sl_onesweep<9, SrcSlim, false><<<grid, 256, 0, st>>>(in, d_live, shift, totals, w.state, epoch, dst, nullptr);
-      } else if (bits == 8) sl_pass<8, SrcSlim, false>(st, in, d_live, shift, dst, w.hist, totals, nullptr, grid);
-      else sl_pass<9, SrcSlim, false>(st, in, d_live, shift, dst, w.hist, totals, nullptr, grid);
+      if (bits == 8) sl_pass<8, SrcSlim, false>(st, in, d_live, shift, kc, dst, w.hist, totals, nullptr, grid);
+      else sl_pass<10, SrcSlim, false>(st, in, d_live, shift, kc, dst, w.hist, totals, nullptr, grid);
     }
     Slim* t = dst; dst = other; other = t;
   }
@@ -1077,12 +932,7 @@ Slim* sl_sort(hipStream_t st, SRC src, const uint32_t* d_slots, uint32_t* d_live
 }  // namespace
 
 // ================================================== entry points (capi.hip) ==================================================
-int vsv_slim_sort_passes(int nbits) {
-  if (nbits < 1) nbits = 1;
-  int passes = (nbits + 8) / 9;
-  const int bits = (nbits + passes - 1) / passes <= 8 ? 8 : 9;
-  return (nbits + bits - 1) / bits;
-}
+int vsv_slim_sort_passes(int nbits) { return (nbits + 7) / 8; }     // (upper bound: a 10-bit plan never takes more passes)
 
 // stage 1: rows -> elements, sort by (tid, hap, type, source, pos), cluster per list. Returns the cluster output (slots = *d_alive1).
 void* vsv_slim_stage1(hipStream_t st, const vsv_sig* s1in, const uint32_t* d_n_s1, uint32_t* d_alive1, int pb, int tid_lo, int tid_bits, int cluster_shift,
@@ -1090,7 +940,7 @@ void* vsv_slim_stage1(hipStream_t st, const vsv_sig* s1in, const uint32_t* d_n_s
   Slim* b0 = (Slim*)w.buf[0]; Slim* b1 = (Slim*)w.buf[1]; Slim* e2 = (Slim*)w.buf[2];
   // (a fused run has the elements already: fold_kernel / split_eval wrote them next to the rows, vsv_slim_emit)
   if (!prebuilt) sl_from_rows<<<w.grid, 256, 0, st>>>(s1in, d_n_s1, pb, tid_lo, tid_bits, b0, &ctr->err);
-  Slim* sorted = sl_sort(st, SrcSlim{b0}, d_n_s1, d_alive1, pb + 3 + tid_bits, b1, b0, w);
+  Slim* sorted = sl_sort(st, SrcSlim{b0}, d_n_s1, d_alive1, pb + 3 + tid_bits, KeyCmp{0, 0}, b1, b0, w);
   const int64_t tiles = (w.cap + CL_TILE - 1) / CL_TILE;
   sl_cluster<<<(int)(tiles < 4096 ? (tiles < 1 ? 1 : tiles) : 4096), 256, 0, st>>>(sorted, d_alive1, cluster_shift, KeyFmt{pb}, pb, e2, w.cl);
   return e2;
@@ -1100,11 +950,11 @@ void* vsv_slim_stage1(hipStream_t st, const vsv_sig* s1in, const uint32_t* d_n_s
 void* vsv_slim_merge(hipStream_t st, const void* e2, const uint32_t* d_alive1, uint32_t* d_alive2, uint32_t* d_alive3, int pb, int tid_bits,
                      int cluster_shift, const SlimWork& w) {
   Slim* b0 = (Slim*)w.buf[0]; Slim* b1 = (Slim*)w.buf[1]; Slim* e3 = (Slim*)w.buf[3]; Slim* m0 = (Slim*)w.buf[4]; Slim* m1 = (Slim*)w.buf[5];
-  Slim* s2 = sl_sort(st, SrcSlim{(const Slim*)e2}, d_alive1, d_alive2, pb + 3 + tid_bits, b0, b1, w);
+  Slim* s2 = sl_sort(st, SrcSlim{(const Slim*)e2}, d_alive1, d_alive2, pb + 3 + tid_bits, KeyCmp{pb, 1}, b0, b1, w);
   const int64_t tiles = (w.cap + CL_TILE - 1) / CL_TILE;
   sl_cluster<<<(int)(tiles < 4096 ? (tiles < 1 ? 1 : tiles) : 4096), 256, 0, st>>>(s2, d_alive2, cluster_shift, KeyFmt{pb}, pb + 1, e3, w.cl);
   // the result must outlive the pairing stage and the readback: it lands in one of the two buffers reserved for it
-  return sl_sort(st, SrcSlim{e3}, d_alive2, d_alive3, pb + 3 + tid_bits, m0, m1, w);
+  return sl_sort(st, SrcSlim{e3}, d_alive2, d_alive3, pb + 3 + tid_bits, KeyCmp{pb, 2}, m0, m1, w);
 }
 
 // pair_sig + the final order: pairing state in w.cl, call elements sorted by (tid, pos), call rows gathered from s1in
@@ -1115,7 +965,6 @@ void vsv_slim_pair(hipStream_t st, const void* merged, const uint32_t* d_alive3,
   const int right = pair_shift < pair_window ? pair_shift : pair_window;
   // scratch: buffers 0 / 1 hold nothing that is still needed (buffer 2 = the stage-1 clusters, 4 / 5 = the merged elements)
   Slim* b0 = (Slim*)w.buf[0]; Slim* b1 = (Slim*)w.buf[1];
-  static const char* unfused = vsv_dbg_env("VSV_PAIR_KERNELS");                  // tests / timing: "global" = sl_pair_prep + sl_pair_walk
   if (dense) {
     sl_pair_prep<<<w.grid, 256, 0, st>>>(m, d_alive3, kf, pair_shift, right, w.hj, w.cl, &ctr->max_stretch);
     uint32_t* done1 = w.done1; uint64_t* res = (uint64_t*)w.buf[3];         // (the stage-2 clusters are consumed)
@@ -1125,17 +974,59 @@ void vsv_slim_pair(hipStream_t st, const void* merged, const uint32_t* d_alive3,
       sl_pair_round<true><<<w.grid, 256, 0, st>>>(m, d_alive3, kf, pair_shift, right, w.cl, w.hj, done1, res, r + 1);
     }
     sl_pair_leftover<<<w.grid, 256, 0, st>>>(m, d_alive3, kf, pair_shift, right, w.cl, w.hj, done1);
-  } else if (unfused && unfused[0] == 'g') {
-    sl_pair_prep<<<w.grid, 256, 0, st>>>(m, d_alive3, kf, pair_shift, right, w.hj, w.cl, &ctr->max_stretch);
-    sl_pair_walk<<<w.grid, 256, 0, st>>>(m, d_alive3, kf, pair_shift, right, w.hj, w.cl, &ctr->max_stretch);
   } else {
-    sl_fill_i32<<<w.grid, 256, 0, st>>>(w.cl, -1, d_alive3);
-    const int64_t wins = (w.cap + PW - 1) / PW;
-    static const int ablate = vsv_dbg_env("VSV_PAIR_ABLATE") ? atoi(vsv_dbg_env("VSV_PAIR_ABLATE")) : 0;     // timing experiments only
-    sl_pair_fused<<<(int)(wins < 8192 ? (wins < 1 ? 1 : wins) : 8192), 256, 0, st>>>(m, d_alive3, kf, pair_shift, right, w.cl, &ctr->max_stretch, ablate);
+    sl_pair_index<<<w.grid, 256, 0, st>>>(m, d_alive3, kf, pair_shift, w.cl, w.hj);       // (w.hj: one word per window)
+    const int64_t wins = (w.cap + QW - 1) / QW;
+    sl_pair_lds<<<(int)(wins < 32768 ? (wins < 1 ? 1 : wins) : 32768), 64, 0, st>>>(m, d_alive3, kf, pair_shift, right, w.cl, w.hj, &ctr->max_stretch);
   }
-  Slim* cs = sl_sort(st, SrcCalls{m, w.cl, pb + 2}, d_alive3, d_ncalls, pb + 3 + tid_bits, b0, b1, w);
+  Slim* cs = sl_sort(st, SrcCalls{m, w.cl, pb + 2}, d_alive3, d_ncalls, pb + 3 + tid_bits, KeyCmp{pb, 3}, b0, b1, w);
   sl_calls_out<<<w.grid, 256, 0, st>>>(cs, d_ncalls, m, pb + 2, s1in, calls);
+}
+
+// ---- (key, value) pair arrays through the same passes: the split stage's candidate sorts on large inputs ---------------------------
+namespace {
+struct SrcPairs {
+  const uint64_t* key; const uint32_t* val;
+  __device__ __forceinline__ Slim at(uint32_t i) const { Slim s; s.key = key[i]; s.svlen = 0; s.idx = val[i]; return s; }
+};
+// key of a split-pair slot, straight from the candidates sorted by (tid, hap, name) (as PairKey of radix_sort.hip): candidate j followed
+// by another one of the same name heads a pair slot keyed (tid, hap, record of the name's first candidate); every other slot is dead
+struct SrcPairSlots {
+  const uint64_t* ckey; const uint32_t* crec; int qid_bits, rec_bits; const uint32_t* d_n;
+  __device__ __forceinline__ Slim at(uint32_t j) const {
+    const uint32_t n = *d_n;
+    const uint64_t k = ckey[j];
+    Slim s; s.svlen = 0; s.idx = j; s.key = VSV_KEY_DEAD;
+    if (j + 1 < n && ckey[j + 1] == k) {
+      uint32_t g = j;
+      while (g > 0 && ckey[g - 1] == k) --g;
+      s.key = ((k >> qid_bits) << rec_bits) | crec[g];
+    }
+    return s;
+  }
+};
+// sorted elements -> (key, value) arrays of n slots: the live ones in order, dead keys behind them
+__global__ __launch_bounds__(256) void sl_unpack_pairs(const Slim* __restrict__ e, const uint32_t* __restrict__ d_live, const uint32_t* __restrict__ d_n,
+                                                       uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
+  const uint32_t n = *d_n, live = *d_live;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    if (i < live) { const Slim x = ld_slim(e + i); key[i] = x.key; val[i] = x.idx; }
+    else { key[i] = VSV_KEY_DEAD; val[i] = 0; }
+  }
+}
+}  // namespace
+
+SortResult vsv_slim_sort_pairs(hipStream_t st, const uint64_t* key, const uint32_t* val, const uint32_t* d_n, int nbits, uint64_t* out_key, uint32_t* out_val,
+                               uint32_t* d_live, const SlimWork& w) {
+  Slim* r = sl_sort(st, SrcPairs{key, val}, d_n, d_live, nbits, KeyCmp{0, 0}, (Slim*)w.buf[3], (Slim*)w.buf[4], w);
+  sl_unpack_pairs<<<w.grid, 256, 0, st>>>(r, d_live, d_n, out_key, out_val);
+  return SortResult{out_key, out_val};
+}
+SortResult vsv_slim_sort_pair_slots(hipStream_t st, const uint64_t* ckey, const uint32_t* crec, int qid_bits, int rec_bits, const uint32_t* d_n, int nbits,
+                                    uint64_t* out_key, uint32_t* out_val, uint32_t* d_live, const SlimWork& w) {
+  Slim* r = sl_sort(st, SrcPairSlots{ckey, crec, qid_bits, rec_bits, d_n}, d_n, d_live, nbits, KeyCmp{0, 0}, (Slim*)w.buf[3], (Slim*)w.buf[4], w);
+  sl_unpack_pairs<<<w.grid, 256, 0, st>>>(r, d_live, d_n, out_key, out_val);
+  return SortResult{out_key, out_val};
 }
 
 void vsv_slim_rows(hipStream_t st, const void* elems, uint32_t n, const vsv_sig* s1in, vsv_sig* out) {

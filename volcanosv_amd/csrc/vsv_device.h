@@ -172,6 +172,7 @@ void vsv_launch_cigar_scan(hipStream_t st, const RecView& rv, const vsv_params& 
                            uint32_t* part_off, uint32_t* scan_tmp, vsv_sig* raw, Counters* ctr, uint32_t* shard_cnt,
                            hipEvent_t ev0, hipEvent_t ev1, const LongScanBufs& lb);
 
+struct SlimWork;
 // sig_stages.hip
 void vsv_launch_clr_gate(hipStream_t st, const RecView& rv, uint8_t* gflag, Counters* ctr);   // CLR: gated flag bytes for the scan
 void vsv_launch_fold(hipStream_t st, const vsv_sig* raw, vsv_sig* s1in, const RecView& rv, const vsv_params& p, Counters* ctr, int grid,
@@ -180,7 +181,7 @@ struct SplitSorted { const uint64_t* ckey; const uint32_t* crec; const uint64_t*
 SplitSorted vsv_launch_split_candidates(hipStream_t st, const RecView& rv, const vsv_params& p, int n_tids, uint32_t* tab, uint32_t tab_size,
                                         uint32_t* blk_cnt, uint32_t* blk_off, uint32_t* scan_tmp, uint64_t* ckey, uint32_t* crec,
                                         uint64_t* okey, uint32_t* oval, uint64_t* key2, uint32_t* idx2, const SortWork& sw,
-                                        uint32_t cap, Counters* ctr, uint8_t* cmask, int grid);
+                                        uint32_t cap, Counters* ctr, uint8_t* cmask, int grid, const struct SlimWork* slim = nullptr);
 void vsv_launch_split_eval(hipStream_t st, const RecView& rv, const vsv_params& p, int n_tids, const SplitSorted& so, vsv_sig* s1in,
                            uint32_t cap, Counters* ctr, int grid, const SlimOut& sl = SlimOut{nullptr, 0, 0, 0, nullptr});
 // returns the sorted key array (kept for the cluster / pair kernel that follows)
@@ -198,15 +199,13 @@ struct SlimWork {
   void* buf[6];         // element buffers, cap x 16 bytes each: 0 / 1 scratch of the sorts, 2 stage-1 clusters (kept for VSV_T_CLUSTER1),
                         // 3 stage-2 clusters / pairing reservations, 4 / 5 merged elements (kept for VSV_T_MERGED and the calls)
   int64_t cap;          // elements per buffer (= row capacity of the handle)
-  uint32_t* hist;       // [512 * tiles of 4096]
+  uint32_t* hist;       // [1024 * tiles of 4096]
   uint32_t* totals;     // zeroed per-pass digit totals, 2048 entries per slot (SortWork::totals)
   int* pass_cursor;
   int grid;             // blocks of the row-parallel kernels
   int32_t* cl;          // one word per slot: long-run cluster state, then the pairing state
   uint32_t* hj;         // pairing: first candidate of every hp1 row | stretch-start flag
   uint32_t* done1;      // pairing in rounds: decided flags
-  uint64_t* state;      // chained-scan passes: [512 * tiles of 4096] look-back words (epoch-stamped, never cleared)
-  uint64_t* epoch;      // host-side pass counter of the handle
 };
 int vsv_slim_sort_passes(int nbits);
 void* vsv_slim_stage1(hipStream_t st, const vsv_sig* s1in, const uint32_t* d_n_s1, uint32_t* d_alive1, int pb, int tid_lo, int tid_bits, int cluster_shift,
@@ -216,6 +215,12 @@ void* vsv_slim_merge(hipStream_t st, const void* e2, const uint32_t* d_alive1, u
 void vsv_slim_pair(hipStream_t st, const void* merged, const uint32_t* d_alive3, uint32_t* d_ncalls, int pb, int tid_bits, int pair_shift, int pair_window,
                    const vsv_sig* s1in, vsv_call* calls, bool dense, const SlimWork& w, Counters* ctr);
 void vsv_slim_rows(hipStream_t st, const void* elems, uint32_t n, const vsv_sig* s1in, vsv_sig* out);
+// (key, value) arrays through the element passes (element buffers 3 / 4 as scratch): the split stage's candidate sorts on large inputs.
+// Dead keys are dropped by the first pass and written back behind the live ones; *d_live = the live count.
+SortResult vsv_slim_sort_pairs(hipStream_t st, const uint64_t* key, const uint32_t* val, const uint32_t* d_n, int nbits, uint64_t* out_key, uint32_t* out_val,
+                               uint32_t* d_live, const SlimWork& w);
+SortResult vsv_slim_sort_pair_slots(hipStream_t st, const uint64_t* ckey, const uint32_t* crec, int qid_bits, int rec_bits, const uint32_t* d_n, int nbits,
+                                    uint64_t* out_key, uint32_t* out_val, uint32_t* d_live, const SlimWork& w);
 
 // bnd.hip
 void vsv_launch_bnd_segments(hipStream_t st, const vsv_segments& s, const vsv_bnd_params& p, vsv_bnd* cand, uint32_t cap, Counters* ctr);
