@@ -327,10 +327,51 @@ __device__ __forceinline__ void sl_cluster_long(const Slim* __restrict__ s, int 
   for (uint32_t k = i + lane; k < e; k += 64) if (ld_i32(&cl[k]) != (int32_t)k) st_slim(out + k, dead_slim());
 }
 
+// The kernel is bound by the instructions it issues (a lane per run with data-dependent loops keeps a wave busy for its longest run
+// and pays scalar mask bookkeeping per trip), so the tile is staged pre-digested — position, list, svlen, index as four LDS arrays —
+// and the work is split by run length: every lane looks eight elements ahead of a run's first element in straight-line code and
+// files the run under "at most 4", "at most 8" or "longer"; the first two classes (95 % of the runs of a pile, all of them in
+// sparse data) are then clustered by fully unrolled code on registers, dense lanes first; only the rest takes the loops.
+template <int N>
+__device__ __forceinline__ void sl_cluster_small(const int32_t* __restrict__ l_pos, const int32_t* __restrict__ l_len, const uint32_t* __restrict__ l_lid,
+                                                 const uint32_t* __restrict__ l_idx, uint32_t rel0, uint32_t len, uint32_t i, int max_shift, KeyFmt kf, uint64_t drop,
+                                                 Slim* __restrict__ out) {
+  int32_t p[N], v[N];
+#pragma unroll
+  for (int u = 0; u < N; ++u) { p[u] = l_pos[rel0 + u]; v[u] = l_len[rel0 + u]; }
+  const bool del = (l_idx[rel0] & SL_DEL) != 0;
+  const uint32_t lid = l_lid[rel0];
+  uint32_t assigned = ~((1u << len) - 1u);          // elements behind the run never join
+#pragma unroll
+  for (int a = 0; a < N; ++a) {
+    const bool seed = !((assigned >> a) & 1u);
+    int best = a;
+    int32_t best_len = v[a];
+#pragma unroll
+    for (int b = a + 1; b < N; ++b) {
+      const bool m = seed && !((assigned >> b) & 1u) && sl_match(p[a], v[a], p[b], v[b], del, max_shift);     // (shift > max_shift fails the match)
+      assigned |= (m ? 1u : 0u) << b;
+      if (m && v[b] > best_len) { best = b; best_len = v[b]; }
+    }
+    if ((uint32_t)a < len) {
+      Slim r = dead_slim();
+      if (seed) {
+        r.key = ((((uint64_t)lid) << kf.pb) | vsv_kpos(l_pos[rel0 + best])) & ~drop;
+        r.svlen = best_len;
+        r.idx = l_idx[rel0 + best];
+      }
+      st_slim(out + i + a, r);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void sl_cluster(const Slim* __restrict__ s, const uint32_t* __restrict__ d_n, int max_shift, KeyFmt kf, int drop_bit,
                                                   Slim* __restrict__ out, int32_t* __restrict__ cl) {
   constexpr int LDS_N = CL_TILE + CL_HALO + 1;
-  __shared__ uint4 sh[LDS_N];
+  __shared__ int32_t l_pos[LDS_N], l_len[LDS_N];
+  __shared__ uint32_t l_lid[LDS_N], l_idx[LDS_N];
+  __shared__ uint16_t h4[CL_TILE], h8[CL_TILE], hx[CL_TILE];      // run heads (tile-relative slot) by class
+  __shared__ uint32_t n4, n8, nx;
   const uint32_t n = *d_n;
   const int lane = threadIdx.x & 63;
   const uint64_t drop = 1ull << drop_bit;
@@ -338,70 +379,100 @@ __global__ __launch_bounds__(256) void sl_cluster(const Slim* __restrict__ s, co
   for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const uint32_t t0 = tile * CL_TILE;
     __syncthreads();
-    for (int k = threadIdx.x; k < LDS_N; k += 256) {
+    if (threadIdx.x == 0) { n4 = 0; n8 = 0; nx = 0; }
+    for (int k = threadIdx.x; k < LDS_N; k += 256) {          // LDS index k = slot t0 - 1 + k
       const int64_t slot = (int64_t)t0 - 1 + k;
-      if (slot >= 0 && slot < (int64_t)n) sh[k] = *reinterpret_cast<const uint4*>(s + slot);
+      if (slot >= 0 && slot < (int64_t)n) {
+        const Slim x = ld_slim(s + slot);
+        l_pos[k] = kf.pos(x.key); l_len[k] = x.svlen; l_lid[k] = (uint32_t)(x.key >> kf.pb); l_idx[k] = x.idx;
+      } else { l_pos[k] = 0; l_len[k] = 0; l_lid[k] = 0xFFFFFFFFu; l_idx[k] = 0; }     // (no list has this id: it ends every run)
     }
     __syncthreads();
-    auto get = [&](uint32_t k) -> Slim {            // element k: from LDS when the block staged it
-      const uint32_t rel = k + 1u - t0;
-      uint4 v;
-      if (rel < (uint32_t)LDS_N) v = sh[rel]; else v = *reinterpret_cast<const uint4*>(s + k);
-      Slim x;
-      x.key = (uint64_t)v.x | ((uint64_t)v.y << 32); x.svlen = (int32_t)v.z; x.idx = v.w;
-      return x;
-    };
+    // ---- run heads, and how far their runs go (eight elements of look-ahead, straight-line) ----
 #pragma unroll 1
     for (int r = 0; r < CL_TILE / 256; ++r) {
-      const uint32_t i = t0 + (uint32_t)r * 256u + threadIdx.x;
+      const uint32_t rel = (uint32_t)r * 256u + threadIdx.x + 1u, i = t0 + rel - 1u;
+      if (i >= n) continue;
+      const uint32_t lid = l_lid[rel];
+      const bool head = !(l_lid[rel - 1] == lid && (int64_t)l_pos[rel] - l_pos[rel - 1] <= max_shift) || i == 0;
+      if (!head) continue;
+      uint32_t cont = 0;
+#pragma unroll
+      for (int u = 1; u <= 8; ++u)
+        cont |= (l_lid[rel + u] == lid && (int64_t)l_pos[rel + u] - l_pos[rel + u - 1] <= max_shift ? 1u : 0u) << (u - 1);
+      const uint32_t len = 1u + (uint32_t)__builtin_ctz(~cont | 0x100u);          // 1..9 (9: the run goes on)
+      if (len <= 4u) h4[atomicAdd(&n4, 1u)] = (uint16_t)((rel - 1u) | ((len - 1u) << 12));
+      else if (len <= 8u) h8[atomicAdd(&n8, 1u)] = (uint16_t)((rel - 1u) | ((len - 5u) << 12));
+      else hx[atomicAdd(&nx, 1u)] = (uint16_t)(rel - 1u);
+    }
+    __syncthreads();
+    // ---- runs of at most 4 and at most 8 elements: unrolled greedy on registers ----
+    for (uint32_t h = threadIdx.x; h < n4; h += 256) {
+      const uint32_t w = h4[h], r0 = w & 0xFFFu, len = (w >> 12) + 1u;
+      sl_cluster_small<4>(l_pos, l_len, l_lid, l_idx, r0 + 1u, len, t0 + r0, max_shift, kf, drop, out);
+    }
+    for (uint32_t h = threadIdx.x; h < n8; h += 256) {
+      const uint32_t w = h8[h], r0 = w & 0xFFFu, len = (w >> 12) + 5u;
+      sl_cluster_small<8>(l_pos, l_len, l_lid, l_idx, r0 + 1u, len, t0 + r0, max_shift, kf, drop, out);
+    }
+    // ---- longer runs: the sequential greedy with loops; beyond SL_LONG_RUN elements the lane's whole wave ----
+    auto get = [&](uint32_t k) -> Slim {            // element k: from LDS when the block staged it
+      const uint32_t rel = k + 1u - t0;
+      if (rel < (uint32_t)LDS_N && l_lid[rel] != 0xFFFFFFFFu) {
+        Slim x;
+        x.key = ((uint64_t)l_lid[rel] << kf.pb) | vsv_kpos(l_pos[rel]); x.svlen = l_len[rel]; x.idx = l_idx[rel];
+        return x;
+      }
+      return ld_slim(s + k);
+    };
+    const uint32_t nxx = nx;
+    for (uint32_t h0 = 0; h0 < nxx; h0 += 256) {               // (block-uniform trip count: the wave take-over below needs whole waves)
+      const uint32_t h = h0 + threadIdx.x;
       bool is_long = false;
-      uint32_t e = 0;
-      if (i < n) {
+      uint32_t i = 0, e = 0;
+      if (h < nxx) {
+        i = t0 + hx[h];
         const Slim me = get(i);
         const uint64_t lk = me.key >> kf.pb;
-        bool head = true;
-        if (i > 0) { const Slim pv = get(i - 1); head = !((pv.key >> kf.pb) == lk && (int64_t)kf.pos(me.key) - kf.pos(pv.key) <= max_shift); }
-        if (head) {
-          e = i + 1;
-          int32_t last = kf.pos(me.key);
-          while (e < n && e - i <= SL_LONG_RUN) {
+        e = i + 1;
+        int32_t last = kf.pos(me.key);
+        while (e < n && e - i <= SL_LONG_RUN) {
+          const Slim x = get(e);
+          const int32_t px = kf.pos(x.key);
+          if ((x.key >> kf.pb) != lk || (int64_t)px - last > max_shift) break;
+          last = px; ++e;
+        }
+        if (e - i > SL_LONG_RUN) {
+          is_long = true;
+          while (e < n) {
             const Slim x = get(e);
             const int32_t px = kf.pos(x.key);
             if ((x.key >> kf.pb) != lk || (int64_t)px - last > max_shift) break;
             last = px; ++e;
           }
-          if (e - i > SL_LONG_RUN) {
-            is_long = true;
-            while (e < n) {
-              const Slim x = get(e);
-              const int32_t px = kf.pos(x.key);
-              if ((x.key >> kf.pb) != lk || (int64_t)px - last > max_shift) break;
-              last = px; ++e;
-            }
-          } else {
-            const uint32_t len = e - i;
-            const bool del = (me.idx & SL_DEL) != 0;
-            uint64_t assigned = 0;
-            for (uint32_t a = 0; a < len; ++a) {
-              if ((assigned >> a) & 1ull) { st_slim(out + i + a, dead_slim()); continue; }
-              const Slim s1 = get(i + a);
-              const int32_t p1 = kf.pos(s1.key);
-              uint32_t best = a;
-              int32_t best_len = s1.svlen;
-              for (uint32_t b = a + 1; b < len; ++b) {
-                const Slim s2 = get(i + b);
-                const int32_t p2 = kf.pos(s2.key);
-                if ((int64_t)p2 - p1 > max_shift) break;
-                if ((assigned >> b) & 1ull) continue;
-                if (sl_match(p1, s1.svlen, p2, s2.svlen, del, max_shift)) {
-                  assigned |= 1ull << b;
-                  if (s2.svlen > best_len) { best = b; best_len = s2.svlen; }
-                }
+        } else {
+          const uint32_t len = e - i;
+          const bool del = (me.idx & SL_DEL) != 0;
+          uint64_t assigned = 0;
+          for (uint32_t a = 0; a < len; ++a) {
+            if ((assigned >> a) & 1ull) { st_slim(out + i + a, dead_slim()); continue; }
+            const Slim s1 = get(i + a);
+            const int32_t p1 = kf.pos(s1.key);
+            uint32_t best = a;
+            int32_t best_len = s1.svlen;
+            for (uint32_t b = a + 1; b < len; ++b) {
+              const Slim s2 = get(i + b);
+              const int32_t p2 = kf.pos(s2.key);
+              if ((int64_t)p2 - p1 > max_shift) break;
+              if ((assigned >> b) & 1ull) continue;
+              if (sl_match(p1, s1.svlen, p2, s2.svlen, del, max_shift)) {
+                assigned |= 1ull << b;
+                if (s2.svlen > best_len) { best = b; best_len = s2.svlen; }
               }
-              Slim rep = best == a ? s1 : get(i + best);
-              rep.key &= ~drop;
-              st_slim(out + i + a, rep);
             }
+            Slim rep = best == a ? s1 : get(i + best);
+            rep.key &= ~drop;
+            st_slim(out + i + a, rep);
           }
         }
       }
