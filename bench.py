@@ -525,7 +525,7 @@ def main():
             # HBM bytes per launch from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs, KiB units,
             # FETCH_SIZE doubled for the wide coalesced stream as MI355X_MICROARCH.md prescribes) of the same kernel on the same
             # shape, scaled by the op count (which sets the traffic): a profile figure, not an in-run measurement
-            pmc_name = {"hifi": "r02_pmc_cigar_scan_emit_config2.json", "contig": "r02_pmc_cigar_scan_long_contig50k.json"}.get(shape)
+            pmc_name = {"hifi": "r02_pmc_cigar_scan_emit_config2.json", "contig": "r03_pmc_cigar_scan_long_contig200k.json"}.get(shape)
             pmc_path = os.path.join(ROOT, "profiles", pmc_name) if pmc_name else None
             if pmc_path and os.path.exists(pmc_path):
                 pmc = json.load(open(pmc_path))

@@ -3,7 +3,7 @@
 //   sort_sig                   H:170-179     -> sl_hist / sl_scan / sl_scatter (stable LSD passes over 16-byte elements)
 //   cluster_del / cluster_ins  H:196-288     -> sl_cluster
 //   merge_all                  H:478-499     -> the same two kernels on the stage-2 / stage-3 keys
-//   pair_sig                   H:548-603     -> sl_pair_prep + sl_pair_walk (or sl_pair_round* on dense piles) + the call sort
+//   pair_sig                   H:548-603     -> sl_pair_index + sl_pair_lds (or sl_pair_prep + sl_pair_round* on dense piles) + the call sort
 // (paths relative to bin/VolcanoSV-vc/Large_INDEL/extract_contig_signature_Hifi.py in the reference).
 //
 // Everything a stage decides depends on (list, pos, svlen, type) only, and every row a stage passes on is a verbatim copy of a
@@ -491,9 +491,9 @@ __global__ __launch_bounds__(256) void sl_cluster(const Slim* __restrict__ s, co
 // type within pair_shift that matches — first come, first served. Only rows of one type compete for an hp2 row, so the walk
 // decomposes by type, and inside a type it can be cut between two consecutive hp1 rows a < b wherever no hp2 row of the type lies
 // in [pos_b - shift, pos_a + right]: whatever the rows up to a can reach (pos <= pos_a + right) lies in front of whatever the rows
-// from b on can reach (pos >= pos_b - shift). sl_pair_prep finds every hp1 row's first candidate (jlo) and marks the rows that
-// start such a stretch; sl_pair_walk runs the sequential rule per stretch (a lane, or the lane's whole wave beyond SL_LONG_RUN
-// rows). st[]: hp1 slot -> its mate's slot or -1; hp2 slot -> the hp1 slot that took it or -1.
+// from b on can reach (pos >= pos_b - shift). Such a stretch is walked by one lane with the sequential rule (sl_pair_lds, below).
+// sl_pair_prep finds every hp1 row's first candidate (jlo) for the round-based pairing of dense piles and looks for giant stretches.
+// st[]: hp1 slot -> its mate's slot or -1; hp2 slot -> the hp1 slot that took it or -1.
 __device__ __forceinline__ uint32_t sl_lower_bound(const Slim* __restrict__ m, uint32_t n, uint64_t target) {
   uint32_t lo = 0, hi = n;
   while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (m[mid].key >= target) hi = mid; else lo = mid + 1; }
