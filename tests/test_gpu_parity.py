@@ -1081,6 +1081,42 @@ def test_full_size_row2c_contigs():
     torch.cuda.empty_cache()
 
 
+def test_element_path_falls_back_to_rows_beyond_its_32_bit_limits():
+    """The element kernels compute positions and lengths in 32 bits; a length outside [0, 2^30) (here: five insertions of 2^28 - 1
+    bases folded into one signature of 1.3e9, H:91-97) raises a device flag where the elements are built and the same input runs
+    again on rows, with the 64-bit predicates. Tables equal the oracle's; one repetition, then the handle stays on rows."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "from test_gpu_parity import oracle_run, assert_tables_equal\n"
+            "from volcanosv_amd.soa import RecordSoA\n"
+            "from volcanosv_amd.engine import Engine, default_params\n"
+            "from volcanosv_amd.abi import DTYPE_HIFI\n"
+            "big = (1 << 28) - 1\n"
+            "recs = [(0, 100 + 50 * i, 'q%%d_hp%%d' %% (i, 1 + i %% 2), 60, False, [(0, 3000), (1, 45 + i %% 7), (0, 2000)]) for i in range(200)]\n"
+            "recs.insert(100, (0, 5000, 'huge_hp1', 60, False, [(0, 100)] + [(1, big), (0, 10)] * 5 + [(0, 50)]))\n"
+            "recs.sort(key=lambda r: r[1])\n"
+            "soa = RecordSoA.from_tuples(recs)\n"
+            "soa.max_pos = 1 << 20\n"
+            "p = default_params(DTYPE_HIFI)\n"
+            "st, want = oracle_run(soa, DTYPE_HIFI, p)\n"
+            "assert st == 0 and int(want['cigar']['svlen'].max()) > (1 << 30)\n"
+            "with Engine(0) as e:\n"
+            "    e.run(soa, p)\n"
+            "    got = e.tables(DTYPE_HIFI)\n"
+            "    assert_tables_equal(got, want, list(got.keys()))\n"
+            "    n = e.rerun_count()\n"
+            "    e.run(soa, p)\n"
+            "    assert_tables_equal(e.tables(DTYPE_HIFI), want, list(got.keys()))\n"
+            "    print('LIMITS_OK', n, e.rerun_count())\n") % (root, os.path.join(root, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, VSV_DEBUG="1", VSV_BIG="1"), cwd=root)
+    assert r.returncode == 0 and "LIMITS_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+    assert r.stdout.strip().splitlines()[-1].split()[1:] == ["1", "1"]
+
+
 def test_element_path_on_the_parity_cases():
     """Tables of more than ~1.3 M rows run their sort / cluster / merge / pair stages on 16-byte elements (csrc/slim_path.hip); the
     handle picks the path from the row counts of its previous run, so the small parity cases above never reach it. VSV_BIG=1 forces it

@@ -76,6 +76,7 @@ struct vsv_handle {
   bool clr_unfused = false;        // the fused CLR scan met a part too long for its gate state: separate gate pass from now on
   bool dense_pairing = false;      // the last run walked a pairing stretch of thousands of rows with one wave: pair in rounds
   bool in_rerun = false;
+  int row_runs = 0;                // > 0: an input met the 32-bit limits of the element path recently: the next runs stay on rows
   int64_t reruns = 0;             // whole-run repetitions taken by finish() so far (vsv_rerun_count)
   // large tables (slim_path.hip): element buffers, pairing scratch, what the run in flight left where
   DevBuf sl[6], sl_hj, sl_done;
@@ -274,6 +275,7 @@ int reset_run_state(vsv_handle* h) {
 }
 int tid_bits(vsv_handle* h);
 bool want_big(vsv_handle* h);
+bool big_allowed(vsv_handle* h);
 int slim_work(vsv_handle* h, SlimWork& w);
 int sort_bits(vsv_handle* h);
 // blocks of the row-parallel kernels: one row per thread for the largest table of the handle's previous run (+25 %), between 128
@@ -314,6 +316,7 @@ int enq_scan(vsv_handle* h) {
   hipStream_t st = h->stream;
   { int rs = reset_run_state(h); if (rs) return rs; }
   if (h->lsd_runs > 0 && !h->in_rerun) --h->lsd_runs;
+  if (h->row_runs > 0 && !h->in_rerun) --h->row_runs;
   h->cutesv_rows = -1;   // the split-candidate table shares a buffer with the merge stage
   const int n_parts = vsv_cigar_parts(h->rv.n_ops, OPS_PER_PART);
   RecView srv = h->rv;
@@ -341,7 +344,7 @@ int enq_scan(vsv_handle* h) {
   h->have_scan_ev = n_parts > 0;
   // the path of the stages behind the split stage is decided here, so that the fold (and split_eval) can write the elements of a
   // large-table run next to their rows
-  h->big_run = want_big(h) && 4 * vsv_slim_sort_passes(sort_bits(h)) + 16 <= MAX_SORT_PASSES;
+  h->big_run = want_big(h) && big_allowed(h) && 4 * vsv_slim_sort_passes(sort_bits(h)) + 16 <= MAX_SORT_PASSES;
   h->sl_prebuilt = false;
   SlimOut so{nullptr, 0, 0, 0, nullptr};
   if (h->big_run) {
@@ -395,6 +398,9 @@ bool want_big(vsv_handle* h) {
   const uint64_t rows = c.n_s1 > c.n_cand ? c.n_s1 : c.n_cand;
   return (rows >> 11) > 640;
 }
+// (the element kernels compute positions and lengths in 32 bits: an input that does not fit raises ERRB_SLIM_FALLBACK and the handle stays
+// on rows for a while; element indices carry two flag bits)
+bool big_allowed(vsv_handle* h) { return h->row_runs == 0 && h->cap_sigs < (1ll << 30); }
 int slim_work(vsv_handle* h, SlimWork& w) {
   const size_t n = (size_t)h->cap_sigs;
   for (int k = 0; k < 6; ++k) { int st = ensure(h, h->sl[k], n * 16 + 64); if (st) return st; w.buf[k] = h->sl[k].p; }
@@ -500,7 +506,7 @@ int finish(vsv_handle* h) {
     fprintf(stderr, "[vsv] n_pool %u n_raw %u n_cand %u n_s1 %u alive %u %u %u calls %u max_stretch %u err %#x pad %u %u %u\n", c.n_pool, c.n_raw, c.n_cand, c.n_s1,
             c.n_alive1, c.n_alive2, c.n_alive3, c.n_calls, c.max_stretch, c.err, c.pad[0], c.pad[1], c.pad[2]);
   }
-  if (e & (ERRB_CLR_FALLBACK | ERRB_SORT_FALLBACK)) {
+  if (e & (ERRB_CLR_FALLBACK | ERRB_SORT_FALLBACK | ERRB_SLIM_FALLBACK)) {
     // ERRB_CLR_FALLBACK: a part of the read-shaped CLR scan held more chunks than its gate state — nothing that run decided can be
     // trusted; same input again with the gate as a separate pass (this handle keeps that form). ERRB_SORT_FALLBACK: a bucket of
     // the bucket sort did not fit in LDS (tables far from uniform, or much larger than the previous run's) — the stages behind it
@@ -512,9 +518,10 @@ int finish(vsv_handle* h) {
     h->in_rerun = true;
     int st = 1;
     bool stale_hint = false;
-    for (int attempt = 0; attempt < 3 && st == 1; ++attempt) {
+    for (int attempt = 0; attempt < 4 && st == 1; ++attempt) {
       const uint32_t ee = h->host_ctr.err;
       if (ee & ERRB_CLR_FALLBACK) h->clr_unfused = true;
+      else if (ee & ERRB_SLIM_FALLBACK) h->row_runs = 16;       // a length outside [0, 2^30): the same input on rows (64-bit predicates)
       else {
         const uint64_t rows_now = h->host_ctr.n_s1 > h->host_ctr.n_cand ? h->host_ctr.n_s1 : h->host_ctr.n_cand;
         stale_hint = rows_now > h->sort_hint_rows + h->sort_hint_rows / 2;

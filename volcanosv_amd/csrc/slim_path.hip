@@ -45,16 +45,18 @@ struct KeyFmt {      // bit layout of the run's keys
   }
 };
 
-// exact integer form of the reference's ratio predicates, as vsv_match (vsv_device.h) on (pos, svlen, type)
+// exact integer form of the reference's ratio predicates, as vsv_match (vsv_device.h) on (pos, svlen, type) — in 32 bits: the element
+// path keeps only inputs whose positions (+ bias) fit 30 bits and whose lengths lie in [0, 2^30) (checked where the elements are
+// built: ERRB_SLIM_FALLBACK sends anything else back to the row path), so no sum or difference below leaves int32.
+// The cluster and pairing kernels are bound by instructions issued; the 64-bit form of this predicate was a third of them.
 __device__ __forceinline__ bool sl_match(int32_t p1, int32_t v1, int32_t p2, int32_t v2, bool del, int max_shift) {
-  int64_t shift = (int64_t)p1 - p2;
-  if (shift < 0) shift = -shift;
-  if (shift > max_shift) return false;
-  const int64_t l1 = v1, l2 = v2, mn = l1 < l2 ? l1 : l2, mx = l1 < l2 ? l2 : l1;
+  const int32_t d = p1 - p2;
+  if ((d < 0 ? -d : d) > max_shift) return false;
+  const int32_t mn = v1 < v2 ? v1 : v2, mx = v1 < v2 ? v2 : v1;
   if (2 * mn < mx) return false;
   if (del) {
-    const int64_t s1 = p1, e1 = s1 + l1, s2 = p2, e2 = s2 + l2;
-    const int64_t ov = (e1 < e2 ? e1 : e2) - (s1 > s2 ? s1 : s2);
+    const int32_t e1 = p1 + v1, e2 = p2 + v2;
+    const int32_t ov = (e1 < e2 ? e1 : e2) - (p1 > p2 ? p1 : p2);
     if (2 * ov < mn) return false;
   }
   return true;
@@ -72,6 +74,7 @@ __global__ __launch_bounds__(256) void sl_from_rows(const vsv_sig* __restrict__ 
     s.idx = i | ((v.meta & VSV_M_DEL) ? SL_DEL : 0u);
     if (!(v.meta & VSV_M_DEAD) && ((pb < 32 && (vsv_kpos(v.pos) >> pb) != 0) || ((uint32_t)(v.tid - tid_lo) >> tid_bits) != 0))
       atomicOr(err, ERRB_RANGE);            // max_pos hint too small / tid outside [tid_lo, n_tids)
+    if (!(v.meta & VSV_M_DEAD) && ((uint32_t)v.svlen >= (1u << 30) || (vsv_kpos(v.pos) >> 30) != 0)) atomicOr(err, ERRB_SLIM_FALLBACK);
     st_slim(out + i, s);
   }
 }
@@ -394,12 +397,12 @@ __global__ __launch_bounds__(256) void sl_cluster(const Slim* __restrict__ s, co
       const uint32_t rel = (uint32_t)r * 256u + threadIdx.x + 1u, i = t0 + rel - 1u;
       if (i >= n) continue;
       const uint32_t lid = l_lid[rel];
-      const bool head = !(l_lid[rel - 1] == lid && (int64_t)l_pos[rel] - l_pos[rel - 1] <= max_shift) || i == 0;
+      const bool head = !(l_lid[rel - 1] == lid && l_pos[rel] - l_pos[rel - 1] <= max_shift) || i == 0;
       if (!head) continue;
       uint32_t cont = 0;
 #pragma unroll
       for (int u = 1; u <= 8; ++u)
-        cont |= (l_lid[rel + u] == lid && (int64_t)l_pos[rel + u] - l_pos[rel + u - 1] <= max_shift ? 1u : 0u) << (u - 1);
+        cont |= (l_lid[rel + u] == lid && l_pos[rel + u] - l_pos[rel + u - 1] <= max_shift ? 1u : 0u) << (u - 1);
       const uint32_t len = 1u + (uint32_t)__builtin_ctz(~cont | 0x100u);          // 1..9 (9: the run goes on)
       if (len <= 4u) h4[atomicAdd(&n4, 1u)] = (uint16_t)((rel - 1u) | ((len - 1u) << 12));
       else if (len <= 8u) h8[atomicAdd(&n8, 1u)] = (uint16_t)((rel - 1u) | ((len - 5u) << 12));
@@ -701,7 +704,7 @@ __global__ __launch_bounds__(64) void sl_pair_lds(const Slim* __restrict__ m, co
           if ((lt & SL_DEL) != t) continue;
           for (uint32_t j = jlo;; ++j) {                                 // an hp2 row of the type in [pos_b - shift, pos_a + right]?
             int32_t py; uint32_t ly;
-            if (!getB(j, py, ly) || (int64_t)py - pa > right) break;
+            if (!getB(j, py, ly) || py - pa > right) break;
             if ((ly & SL_DEL) == t) { head = false; break; }
           }
           break;
@@ -742,9 +745,9 @@ __global__ __launch_bounds__(64) void sl_pair_lds(const Slim* __restrict__ m, co
             const int32_t p2 = b_pos[r0 + u];
             const uint32_t l2 = b_lt[r0 + u];
             const bool ist = (l2 & SL_DEL) == t;
-            m_passed |= ((int64_t)p1 - p2 > pair_shift ? 1u : 0u) << u;
-            m_beyond |= ((int64_t)p2 - p1 > right ? 1u : 0u) << u;
-            m_past |= ((int64_t)p2 - prev > right ? 1u : 0u) << u;
+            m_passed |= (p1 - p2 > pair_shift ? 1u : 0u) << u;
+            m_beyond |= (p2 - p1 > right ? 1u : 0u) << u;
+            m_past |= (p2 - prev > right ? 1u : 0u) << u;
             m_t |= (ist ? 1u : 0u) << u;
             m_ok |= (ist && b_taken[r0 + u] == 0 && sl_match(p1, v1, p2, (int32_t)(l2 & 0x7FFFFFFFu), t != 0, pair_shift) ? 1u : 0u) << u;
           }
@@ -766,8 +769,8 @@ __global__ __launch_bounds__(64) void sl_pair_lds(const Slim* __restrict__ m, co
           for (uint32_t j = jb + 8u;; ++j) {                     // it goes on behind the batch: the rest of it, a row at a time
             int32_t p2; uint32_t l2;
             if (!getB(j, p2, l2)) break;
-            if (!seen_t && (int64_t)p2 - prev > right) { cut = true; break; }
-            if ((int64_t)p2 - p1 > right) break;
+            if (!seen_t && p2 - prev > right) { cut = true; break; }
+            if (p2 - p1 > right) break;
             if ((l2 & SL_DEL) != t) continue;
             seen_t = true;
             const uint32_t rel = j - j0;
@@ -778,9 +781,9 @@ __global__ __launch_bounds__(64) void sl_pair_lds(const Slim* __restrict__ m, co
           for (uint32_t j = jl;; ++j) {
             int32_t p2; uint32_t l2;
             if (!getB(j, p2, l2)) break;
-            if ((int64_t)p1 - p2 > pair_shift) { jl = j + 1; continue; }
-            if (!seen_t && (int64_t)p2 - prev > right) { cut = true; break; }
-            if ((int64_t)p2 - p1 > right) break;
+            if (p1 - p2 > pair_shift) { jl = j + 1; continue; }
+            if (!seen_t && p2 - prev > right) { cut = true; break; }
+            if (p2 - p1 > right) break;
             if ((l2 & SL_DEL) != t) continue;
             seen_t = true;
             const uint32_t rel = j - j0;

@@ -21,6 +21,7 @@ enum : uint32_t {
   ERRB_SEQLEN = 1u << 8,         // a walked record carries VSV_F_SEQ_MISMATCH (H:397-398)
   ERRB_CLR_FALLBACK = 1u << 9,   // a part too long for the gate state of the fused CLR scan: the run is repeated with the separate gate pass
   ERRB_SORT_FALLBACK = 1u << 7,  // a bucket of the bucket sort did not fit in LDS: the run is repeated with the LSD passes
+  ERRB_SLIM_FALLBACK = 1u << 10, // an svlen outside [0, 2^30) or a position of 2^30 and more met the element path (32-bit predicates): the run is repeated on rows
 };
 
 // One cache line of device counters, zeroed at the start of every run.
@@ -104,6 +105,7 @@ __device__ __forceinline__ void vsv_slim_emit(const SlimOut& so, uint32_t i, con
   const uint64_t k = vsv_key_stage(v, 1, so.pb, so.tid_lo);
   if (!(v.meta & VSV_M_DEAD) && ((so.pb < 32 && (vsv_kpos(v.pos) >> so.pb) != 0) || ((uint32_t)(v.tid - so.tid_lo) >> so.tid_bits) != 0))
     atomicOr(so.err, ERRB_RANGE);            // max_pos hint too small / tid outside [tid_lo, n_tids)
+  if (!(v.meta & VSV_M_DEAD) && ((uint32_t)v.svlen >= (1u << 30) || (vsv_kpos(v.pos) >> 30) != 0)) atomicOr(so.err, ERRB_SLIM_FALLBACK);      // the element kernels compute in 32 bits
   reinterpret_cast<uint4*>(so.base)[i] = make_uint4((uint32_t)k, (uint32_t)(k >> 32), (uint32_t)v.svlen, i | ((v.meta & VSV_M_DEL) ? VSV_SL_DEL : 0u));
 }
 
