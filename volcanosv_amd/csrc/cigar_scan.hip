@@ -741,9 +741,11 @@ __global__ __launch_bounds__(256) void cigar_scan_long(RecView rv, const uint32_
   constexpr uint32_t BAD_R = rev32(T::BAD | (T::BAD << 16));
   constexpr uint32_t REF2 = dup16(T::REF), QRY2 = dup16(T::QRY);   // bit (w & 31) of these = bit (op) of the table
   uint32_t hd_rec = 0xFFFFFFFFu, hd_fl = 0, hd_mq = 0, hd_tid = 0, hd_first = 0, hd_pos = 0;   // cached record header (SGPRs)
+  uint32_t hd_hap = 0, hd_hc = 0;                                                               // ... and what the emissions derive from it
 
   // ---- the chunk handed from the streaming blocks to the (single) emission block -----------------------------------------
   uint32_t pw[4] = {0, 0, 0, 0}, p_pr0 = 0, p_pq0 = 0;          // its ops and each lane's exclusive in-chunk prefix
+  bool pe0 = false, pe1 = false, pe2 = false, pe3 = false;      // ... and which of them are candidates (lane masks: they stay in scalar registers)
   bool p_badany = false;
   uint32_t p_cb = 0, p_tot_r = 0, p_tot_q = 0;
   bool pending = false;
@@ -771,6 +773,7 @@ __global__ __launch_bounds__(256) void cigar_scan_long(RecView rv, const uint32_
     const bool any_cand = __ballot(e0 | e1 | e2 | e3 | bd) != 0ull && !(ablate & 1);
     if (!any_cand && !(nxt < cb + 256u)) { run_r += tot_r; run_q += tot_q; return; }
     pw[0] = w[0]; pw[1] = w[1]; pw[2] = w[2]; pw[3] = w[3];
+    pe0 = e0 && !(ablate & 1); pe1 = e1 && !(ablate & 1); pe2 = e2 && !(ablate & 1); pe3 = e3 && !(ablate & 1);
     p_pr0 = incl_r - sum_r; p_pq0 = incl_q - sum_q;
     p_badany = any_cand && __ballot(bd) != 0ull;
     p_cb = cb; p_tot_r = tot_r; p_tot_q = tot_q;
@@ -789,9 +792,7 @@ __global__ __launch_bounds__(256) void cigar_scan_long(RecView rv, const uint32_
       if (hi_cap < hi) hi = hi_cap;
       // ---- segment [lo, hi) of record cur_rec ----
       if (hi > lo && cur_rec != 0xFFFFFFFFu) {
-        bool e[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) e[k] = (int32_t)(EMIT_R << (pw[k] & 31u)) < 0 && pw[k] >= thr16 && !(ablate & 1);
+        bool e[4] = {pe0, pe1, pe2, pe3};                        // (the streaming block's tests: not evaluated again)
         const bool whole = lo == cb && hi == cb + 256u;
         if (!whole) {
 #pragma unroll
@@ -819,20 +820,23 @@ __global__ __launch_bounds__(256) void cigar_scan_long(RecView rv, const uint32_
             if (fo >= (uint64_t)rv.n_ops) fo = 0;                // garbage offsets are reported by the part that stages them
             sload5(align4(rv.flag + rec), align4(rv.mapq + rec), rv.tid + rec, rv.cigar + fo, rv.pos + rec, hd_fl, hd_mq, hd_tid, hd_first, hd_pos);
             hd_rec = rec;
+            // ... and what every emission of the record derives from it (the kernel is bound by scalar instructions on dense input:
+            // a Mb contig emits thousands of times per header)
+            const uint32_t fl = byte_of(hd_fl, rv.flag + rec), mq = byte_of(hd_mq, rv.mapq + rec);
+            if (CLS == 0) hd_hap = (mq >= (uint32_t)min_mapq) ? ((fl >> 2) & 3u) : 0u;               // H:392-394
+            else if (CLS == 1) hd_hap = (mq >= (uint32_t)min_mapq) ? 1u : 0u;                        // RS:120
+            else if (CLS == 3) hd_hap = (!(fl & VSV_F_SKIP) && mq >= (uint32_t)min_mapq) ? 1u : 0u; // SE:439, 446
+            else hd_hap = (!(fl & (VSV_F_UNMAPPED | VSV_F_SECONDARY)) && mq >= (uint32_t)min_mapq) ? 1u : 0u;
+            hd_hc = (T::HC && (hd_first & 15u) == 5u) ? (hd_first >> 4) : 0u;                       // H:63-65
           }
-          const uint32_t fl = byte_of(hd_fl, rv.flag + rec), mq = byte_of(hd_mq, rv.mapq + rec);
-          uint32_t hapbits;
-          if (CLS == 0) hapbits = (mq >= (uint32_t)min_mapq) ? ((fl >> 2) & 3u) : 0u;               // H:392-394
-          else if (CLS == 1) hapbits = (mq >= (uint32_t)min_mapq) ? 1u : 0u;                        // RS:120
-          else if (CLS == 3) hapbits = (!(fl & VSV_F_SKIP) && mq >= (uint32_t)min_mapq) ? 1u : 0u; // SE:439, 446
-          else hapbits = (!(fl & (VSV_F_UNMAPPED | VSV_F_SECONDARY)) && mq >= (uint32_t)min_mapq) ? 1u : 0u;
+          const uint32_t hapbits = hd_hap;
           if (hapbits && any_b && lane == 0) atomicOr(&ec.ctr->err, ERRB_REFEND);   // N/=/X on the contig table: H:396 assert
           if (hapbits && n != 0) {
             const uint32_t sh = (hapbits == 3u) ? 1u : 0u;       // two rows per signature when the name carries both tags
             const uint32_t nrows = n << sh;
             if (nrows > (uint32_t)K1L_STAGE) { hi_cap = lo + (uint32_t)K1L_STAGE / 2u; continue; }   // 32 ops hold at most 64 rows: cut the segment
             if (n_staged + nrows > (uint32_t)K1L_STAGE) flush();
-            const uint32_t hc = (T::HC && (hd_first & 15u) == 5u) ? (hd_first >> 4) : 0u;           // H:63-65
+            const uint32_t hc = hd_hc;
             const uint32_t rec2 = in_head ? 0xFFFFFFFEu : 0xFFFFFFFFu;   // staged rows: rec2 carries the "misses the part's carry" flag
             const uint32_t pos0 = hd_pos + base_r, q0 = base_q + hc;
             const uint32_t hapmeta = (CLS == 0 && hapbits == 2u) ? VSV_M_HP2 : 0u;
