@@ -11,6 +11,8 @@ from .abi import ABI_VERSION, BndParams, Params, Records, RedundancyParams, Segm
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvolcanosv_hip.so")
+if os.environ.get("VSV_DEBUG") == "1" and os.environ.get("VSV_LIB"):      # A/B timing of two builds on the same box (tools/ab.sh)
+    LIB_PATH = os.environ["VSV_LIB"]
 _lib = None
 
 # every symbol include/volcanosv.h declares
