@@ -1121,12 +1121,14 @@ def test_element_path_on_the_parity_cases():
     """Tables of more than ~1.3 M rows run their sort / cluster / merge / pair stages on 16-byte elements (csrc/slim_path.hip); the
     handle picks the path from the row counts of its previous run, so the small parity cases above never reach it. VSV_BIG=1 forces it
     for every size: the golden fixtures, the synthetic shapes, multi-chromosome inputs, the key hints, the three fuzz families and the
-    dense piles go through it in ONE child process (the same assertions against the oracle and the reference's outputs)."""
+    dense piles go through it in ONE child process (the same assertions against the oracle and the reference's outputs). On that path
+    the split stage of read-shaped input works per candidate (cand_info / split_eval_info, csrc/sig_stages.hip) instead of per pair."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sel = "golden_contig or synthetic_vs_oracle or multi_tid or tid_hint or random_small or dense_runs or config4_shape or clr_gate or split_overlap"
+    sel = ("golden_contig or golden_reads or synthetic_vs_oracle or multi_tid or tid_hint or random_small or dense_runs or config4_shape or clr_gate or "
+           "split_overlap or edge_cases or unaligned_device_views")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu", "-k", sel,
                         "-p", "no:cacheprovider"], capture_output=True, text=True, timeout=800, env=dict(os.environ, VSV_DEBUG="1", VSV_BIG="1"), cwd=root)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1500:]

@@ -47,6 +47,7 @@ struct vsv_handle {
   DevBuf gflag;           // CLR: flag bytes with the haplotype bits cleared where the gate fails (input of the scan)
   DevBuf pool, pool_key, raw0, s1in, s1s, c1, s2s, c2, merged, calls_tmp, calls, reads;
   DevBuf tab, blk_cnt, blk_off, ckey, crec, okey, oval;
+  DevBuf cinfo, cord, oc1;             // large read-shaped inputs: per-candidate record info, candidate ordinals by name, a slot's first candidate
   DevBuf key, idx, cl, key2, idx2, key_alt, val_alt, hist;
   DevBuf ctr, shard_cnt, totals;   // views into `arena`
   DevBuf arena;                    // Counters | emit-pool cursors | part-count tile sums | sort digit totals: zeroed by ONE fill per run
@@ -303,11 +304,19 @@ bool is_contig(int dtype) { return dtype == VSV_DTYPE_HIFI || dtype == VSV_DTYPE
 int enq_split_candidates(vsv_handle* h, hipStream_t st) {
   SlimWork w;
   const bool slim = h->big_run && is_contig(h->prm.dtype);     // (a large-table run: the candidate tables are large too)
-  if (slim) { int ws = slim_work(h, w); if (ws) return ws; }
+  CandBufs cb{nullptr, nullptr, nullptr};
+  if (slim) {
+    int ws = slim_work(h, w); if (ws) return ws;
+    if (!vsv_scan_is_long(h->rv, h->prm)) {           // per-candidate record info for split_eval_info (sig_stages.hip)
+      const size_t n = (size_t)h->cap_sigs;
+      if ((ws = ensure(h, h->cinfo, n * 32 + 64)) || (ws = ensure(h, h->cord, n * 4 + 64)) || (ws = ensure(h, h->oc1, n * 4 + 64))) return ws;
+      cb = CandBufs{h->cinfo.p, (uint32_t*)h->cord.p, (uint32_t*)h->oc1.p};
+    }
+  }
   h->split_sorted = vsv_launch_split_candidates(st, h->rv, h->prm, h->n_tids, (uint32_t*)h->tab.p, h->tab_size, (uint32_t*)h->blk_cnt.p,
                                                 (uint32_t*)h->blk_off.p, (uint32_t*)h->scan_tmp2.p, (uint64_t*)h->ckey.p, (uint32_t*)h->crec.p,
                                                 (uint64_t*)h->okey.p, (uint32_t*)h->oval.p, (uint64_t*)h->key2.p, (uint32_t*)h->idx2.p, sort_work(h),
-                                                (uint32_t)h->cap_sigs, dctr(h), (uint8_t*)h->cmask.p, ew_grid(h), slim ? &w : nullptr);
+                                                (uint32_t)h->cap_sigs, dctr(h), (uint8_t*)h->cmask.p, ew_grid(h), slim ? &w : nullptr, cb);
   HIPCHK(h, hipGetLastError());
   h->split_cands_done = true;
   return 0;
@@ -407,6 +416,7 @@ int slim_work(vsv_handle* h, SlimWork& w) {
   int st;
   if ((st = ensure(h, h->sl_hj, n * 4 + 64))) return st;
   if ((st = ensure(h, h->sl_done, n * 4 + 64))) return st;
+  { const Counters& c = h->host_ctr; const uint64_t r = c.n_s1 > c.n_cand ? c.n_s1 : c.n_cand; w.rows_hint = r ? (int64_t)(r + r / 4) : h->cap_sigs; }
   w.cap = h->cap_sigs; w.hist = (uint32_t*)h->hist.p; w.totals = (uint32_t*)h->totals.p; w.pass_cursor = &h->pass_cursor;
   w.grid = ew_grid(h); w.cl = (int32_t*)h->cl.p; w.hj = (uint32_t*)h->sl_hj.p; w.done1 = (uint32_t*)h->sl_done.p;
   return 0;
@@ -682,6 +692,7 @@ void vsv_destroy(vsv_handle* h) {
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
   for (DevBuf& b : h->sl) if (b.p) hipFree(b.p);
   if (h->sl_hj.p) hipFree(h->sl_hj.p);
+  for (DevBuf* b : {&h->cinfo, &h->cord, &h->oc1}) if (b->p) hipFree(b->p);
   if (h->sl_done.p) hipFree(h->sl_done.p);
   if (h->pinned) hipHostFree(h->pinned);
   if (h->pin_buf) hipHostFree(h->pin_buf);

@@ -12,6 +12,7 @@
 // fall to the end of the next stable radix sort; `count_alive` then publishes the live row count on
 // the device. Nothing here synchronises with the host.
 #include "vsv_device.h"
+#include "vsv_env.h"
 
 namespace {
 
@@ -405,40 +406,62 @@ __device__ __forceinline__ int64_t group_sum64(int64_t v) {
   for (int d = SE_GROUP / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
   return v;
 }
-// reference span (pysam reference_end - pos) and read length (get_readlen, Hifi.py:290-305 / reads.py) of the ops [a, b):
-// lane `l` of `width` lanes takes every width-th op; the caller reduces.
-__device__ __forceinline__ void op_add(uint32_t w, bool reads, int64_t& rf, int64_t& rl) {
-  const uint32_t op = w & 15u, len = w >> 4;
-  if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rf += len;           // pysam reference_end
-  if (op == 0 || op == 1 || op == 4 || op == 5 || (reads && (op == 7 || op == 8))) rl += len;  // get_readlen
-}
-__device__ __forceinline__ void op_sums(const uint32_t* __restrict__ cigar, uint64_t a, uint64_t b, bool reads, uint32_t l, uint32_t width,
+// reference span (pysam reference_end - pos) and read length (get_readlen, Hifi.py:290-305 / reads.py) of the ops [a, b): lane `l` of
+// `width` lanes takes every width-th group of four ops (one 16-byte load); the caller reduces. The kernel is bound by the instructions
+// it issues, not by the CIGAR bytes (PMC, config 3: 317 M vector + 351 M scalar wave instructions per launch in the compare-and-select
+// form — every `op == x || ...` is a compare plus a scalar OR): an op costs a bit-field extract of its bit in the op set (sign-extended
+// to a mask), an AND and an add per sum, in 32 bits; eight ops (< 2^31: a length has 28 bits) go to the 64-bit sums at a time.
+constexpr uint32_t SE_REF_OPS = 0x18D;                  // M D N = X consume the reference (pysam reference_end)
+constexpr uint32_t SE_LEN_OPS = 0x033;                  // M I S H count for get_readlen (Hifi.py:290-305) ...
+constexpr uint32_t SE_LEN_OPS_READS = 0x1B3;            // ... and = X too in reads.py
+__device__ __forceinline__ uint32_t se_mask(uint32_t table, uint32_t op) { return (uint32_t)__builtin_amdgcn_sbfe(table, op, 1); }
+template <bool WANT_REF>
+__device__ __forceinline__ void op_sums(const uint32_t* __restrict__ cigar, uint64_t a, uint64_t b, uint32_t len_ops, uint32_t l, uint32_t width,
                                         int64_t& rf, int64_t& rl) {
-  uint64_t k = a + l;
-  for (; k + 7ull * width < b; k += 8ull * width) {       // eight loads in flight: a Mb contig's CIGAR is 10^4-10^6 ops
-    uint32_t w[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) w[u] = cigar[k + (uint64_t)u * width];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) op_add(w[u], reads, rf, rl);
+  if (b <= a) return;
+  uint32_t sr = 0, sq = 0;
+  auto add = [&](uint32_t w) {
+    const uint32_t op = w & 15u, len = w >> 4;
+    if (WANT_REF) sr += len & se_mask(SE_REF_OPS, op);
+    sq += len & se_mask(len_ops, op);
+  };
+  // 16-byte groups of the ARRAY (whatever the pointer's own alignment): [a4, b4); up to three ops in front and behind, one lane each
+  const uint64_t mis = ((uintptr_t)cigar >> 2) & 3u;
+  const uint64_t a4 = ((a + mis + 3ull) & ~3ull) - mis, b4 = ((b + mis) & ~3ull) - mis;
+  const uint64_t he = a4 < b ? a4 : b;                  // head = [a, he)
+  if (a + l < he) add(cigar[a + l]);
+  if (b4 >= a4 && b4 + l < b) add(cigar[b4 + l]);       // tail = [b4, b) (b4 < a4: the head was everything)
+  const uint64_t nq = b4 > a4 ? (b4 - a4) >> 2 : 0;
+  const uint4* __restrict__ qp = reinterpret_cast<const uint4*>(cigar + a4);
+  uint64_t q = l;
+  for (; q + width < nq; q += 2ull * width) {
+    const uint4 v0 = qp[q], v1 = qp[q + width];
+    add(v0.x); add(v0.y); add(v0.z); add(v0.w);
+    if (WANT_REF) { rf += sr; sr = 0; }
+    rl += sq; sq = 0;
+    add(v1.x); add(v1.y); add(v1.z); add(v1.w);
+    if (WANT_REF) { rf += sr; sr = 0; }
+    rl += sq; sq = 0;
   }
-  for (; k < b; k += width) op_add(cigar[k], reads, rf, rl);
+  if (q < nq) { const uint4 v0 = qp[q]; add(v0.x); add(v0.y); add(v0.z); add(v0.w); }
+  if (WANT_REF) rf += sr;
+  rl += sq;
 }
 
 // the pair rules of one candidate pair (`need` = it reached the length test): Hifi.py:331-371, ONT.py:348-373, CLR.py:369-377, reads.py:179-196
-__device__ __forceinline__ vsv_sig split_rules(const RecView& rv, bool need, uint32_t i1, uint32_t i2, uint32_t hap, uint32_t last1, uint32_t first2,
-                                               int64_t rf1, int64_t rl1, int64_t rl2, int dtype, int max_svlen, Counters* ctr) {
+__device__ __forceinline__ vsv_sig split_rules(bool need, uint32_t i1, uint32_t i2, int32_t pos1, int32_t pos2, int32_t tid1, uint32_t hap, uint32_t last1,
+                                               uint32_t first2, int64_t rf1, int64_t rl1, int64_t rl2, int dtype, int max_svlen, Counters* ctr) {
   vsv_sig out = dead_sig();
   if (need) {
     if (rl1 != rl2) atomicOr(&ctr->err, ERRB_READLEN);                                          // Hifi.py:331
     else {
-      const int64_t Ref1e = (int64_t)rv.pos[i1] + rf1, Ref2s = rv.pos[i2];
+      const int64_t Ref1e = (int64_t)pos1 + rf1, Ref2s = pos2;
       const int64_t Read1e = rl1 - (int64_t)(last1 >> 4), Read2s = first2 >> 4;
       const int64_t Diffdis = (Ref2s - Ref1e) - (Read2s - Read1e);
       const int64_t absd = Diffdis < 0 ? -Diffdis : Diffdis;
       if (absd <= max_svlen) {                                                                 // Hifi.py:354
         vsv_sig s = dead_sig();
-        s.rec = i1; s.rec2 = i2; s.tid = rv.tid[i1];
+        s.rec = i1; s.rec2 = i2; s.tid = tid1;
         uint32_t meta = VSV_M_SPLIT | (hap ? VSV_M_HP2 : 0u);
         bool emit = false;
         if (dtype == VSV_DTYPE_HIFI) {
@@ -495,8 +518,6 @@ __device__ __forceinline__ vsv_sig split_rules(const RecView& rv, bool need, uin
   return out;
 }
 
-// (One lane per slot for the chain of scattered loads that finds a pair — 64 chains per wave instead of 8 — and the CIGAR sums in
-// eight rounds of 8-lane groups was tried: config 3's 1.24 ms became 1.04, config 2's 31 us became 53; not kept.)
 // SE_GROUP lanes per pair slot (in okey order); writes one signature row (possibly dead) per slot. Control flow is uniform
 // per group up to the sums (the group shuffles need every lane of the group). SE_GROUP = 8 for reads (tens to hundreds of ops per
 // CIGAR; a stray pair of long records is summed by all 64 lanes of the wave, one such pair after the other), SE_GROUP = 64 for
@@ -505,12 +526,12 @@ template <int SE_GROUP>
 __global__ __launch_bounds__(256) void split_eval(RecView rv, const uint64_t* __restrict__ okey, const uint32_t* __restrict__ oval,
                                                   const uint64_t* __restrict__ ckey, const uint32_t* __restrict__ crec,
                                                   SplitCfg c, int dtype, int max_svlen, vsv_sig* __restrict__ s1in,
-                                                  uint32_t cap, Counters* ctr, SlimOut sl) {
-  const uint32_t n = ctr->n_cand, n_raw = ctr->n_raw;
+                                                  uint32_t cap, Counters* ctr, SlimOut sl, bool live_only) {
+  const uint32_t n = live_only ? ctr->n_pairs : ctr->n_cand, n_raw = ctr->n_raw;     // (live_only: the dead slots were dropped by the sort)
   if (blockIdx.x == 0 && threadIdx.x == 0) { const uint32_t s1 = n_raw + n; ctr->n_s1 = s1 < cap ? s1 : cap; }
   const int lane = threadIdx.x & (SE_GROUP - 1), wlane = threadIdx.x & 63;
   const uint32_t ngroups = gridDim.x * (blockDim.x / SE_GROUP);
-  const bool reads = dtype == VSV_DTYPE_READS;
+  const uint32_t len_ops = dtype == VSV_DTYPE_READS ? SE_LEN_OPS_READS : SE_LEN_OPS;
   // whole waves iterate together (uniform trip count) so that every shuffle sees all its lanes active
   const uint32_t n_pad = (n + (64 / SE_GROUP) - 1) / (64 / SE_GROUP) * (64 / SE_GROUP);
   for (uint32_t q0 = blockIdx.x * (blockDim.x / SE_GROUP) + (threadIdx.x / SE_GROUP); q0 < n_pad; q0 += ngroups) {
@@ -541,7 +562,7 @@ __global__ __launch_bounds__(256) void split_eval(RecView rv, const uint64_t* __
     // ---- phase 2: reference span of record 1, read lengths of both --------------------------------------------------
     const bool is_long = SE_GROUP < 64 && need && (b1 - a1) + (b2 - a2) > SE_LONG_OPS;
     int64_t rf1 = 0, rl1 = 0, rf2 = 0, rl2 = 0;
-    if (need && !is_long) { op_sums(rv.cigar, a1, b1, reads, lane, SE_GROUP, rf1, rl1); op_sums(rv.cigar, a2, b2, reads, lane, SE_GROUP, rf2, rl2); }
+    if (need && !is_long) { op_sums<true>(rv.cigar, a1, b1, len_ops, lane, SE_GROUP, rf1, rl1); op_sums<false>(rv.cigar, a2, b2, len_ops, lane, SE_GROUP, rf2, rl2); }
     rf1 = group_sum64<SE_GROUP>(rf1); rl1 = group_sum64<SE_GROUP>(rl1); rl2 = group_sum64<SE_GROUP>(rl2);
     uint64_t lm = __ballot(is_long && lane == 0);
     while (lm) {                                       // wave-uniform: one long pair at a time, 64 lanes on its two CIGARs
@@ -549,14 +570,158 @@ __global__ __launch_bounds__(256) void split_eval(RecView rv, const uint64_t* __
       lm &= lm - 1;
       const uint64_t xa1 = __shfl(a1, src, 64), xb1 = __shfl(b1, src, 64), xa2 = __shfl(a2, src, 64), xb2 = __shfl(b2, src, 64);
       int64_t f1 = 0, l1 = 0, f2 = 0, l2 = 0;
-      op_sums(rv.cigar, xa1, xb1, reads, (uint32_t)wlane, 64, f1, l1);
-      op_sums(rv.cigar, xa2, xb2, reads, (uint32_t)wlane, 64, f2, l2);
+      op_sums<true>(rv.cigar, xa1, xb1, len_ops, (uint32_t)wlane, 64, f1, l1);
+      op_sums<false>(rv.cigar, xa2, xb2, len_ops, (uint32_t)wlane, 64, f2, l2);
       f1 = wave_sum64(f1); l1 = wave_sum64(l1); l2 = wave_sum64(l2);
       if ((wlane & ~(SE_GROUP - 1)) == src) { rf1 = f1; rl1 = l1; rl2 = l2; }
     }
     // ---- phase 3: the pair rules, one lane per slot -------------------------------------------------------------------
     if (lane != 0 || !live || !room) continue;
-    const vsv_sig out = split_rules(rv, need, i1, i2, hap, last1, first2, rf1, rl1, rl2, dtype, max_svlen, ctr);
+    int32_t pos1 = 0, pos2 = 0, tid1 = 0;
+    if (need) { pos1 = rv.pos[i1]; pos2 = rv.pos[i2]; tid1 = rv.tid[i1]; }
+    const vsv_sig out = split_rules(need, i1, i2, pos1, pos2, tid1, hap, last1, first2, rf1, rl1, rl2, dtype, max_svlen, ctr);
+    s1in[n_raw + q] = out;
+    vsv_slim_emit(sl, n_raw + q, out);
+  }
+}
+
+// ---- large candidate tables of read-shaped input (config 3: 7.2 M candidates, 1.5 M live pair slots of ~180-op ONT reads) ------------
+// split_eval<8> above spends its time on scattered loads: a slot follows five dependent levels of them (slot -> candidate -> record
+// fields of both records -> CIGAR edges -> the CIGAR sums), some twelve sectors per pair in front of the sums, a wave holds 8 slots and
+// only lane 0 of a group evaluates the rules (ablation on config 3: 0.28 ms slot skeleton, 0.30 chain, 0.53 sums, 0.20 rules of 1.29 ms).
+// Here the record fields a pair needs are collected once per CANDIDATE, in record order (cand_info: coalesced candidates, ascending
+// gathers, 32 bytes out) as part of the candidate half of the stage, which a fused run enqueues next to the CIGAR scan; the sorts carry
+// the candidates' ordinals (slim_path.hip SrcPairs / SrcPairSlots); and split_eval_info takes 64 live slots per wave: ONE lane per
+// slot for the key, the two ordinals, the two entries, the rules and the row store, and the CIGAR sums (the bulk: 2.4 GB on config 3,
+// 0.4 ms at HBM speed) in eight rounds of 8-lane groups — round r sums the slots of lanes 8r..8r+7 with every load of both CIGARs of a
+// round, the two edge ops included, in flight before the first add.
+struct __align__(16) CandInfo {
+  uint32_t rec; int32_t pos; uint32_t fm, nops;        // record, POS, flag | mapq << 8, CIGAR ops
+  uint64_t a; int32_t tid; uint32_t pad;               // first op of the CIGAR, tid
+};
+static_assert(sizeof(CandInfo) == 32, "CandInfo layout");
+__global__ __launch_bounds__(256) void cand_info(RecView rv, const uint64_t* __restrict__ ckey, const uint32_t* __restrict__ crec, SplitCfg c,
+                                                 CandInfo* __restrict__ out, const Counters* __restrict__ ctr) {
+  const uint32_t n = ctr->n_cand;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    CandInfo ci;
+    uint64_t a, b;
+    ci.rec = crec[i];
+    ci.tid = (int32_t)(ckey[i] >> c.tid_shift) + c.tid_lo;
+    vsv_op_range(rv, ci.rec, a, b);
+    ci.a = a; ci.nops = (uint32_t)(b - a < 0xFFFFFFFFull ? b - a : 0xFFFFFFFFull);      // (a CIGAR holds < 2^32 ops: cigar_off spans are checked by the scan)
+    ci.pos = rv.pos[ci.rec];
+    ci.fm = (uint32_t)rv.flag[ci.rec] | ((uint32_t)rv.mapq[ci.rec] << 8);
+    ci.pad = 0;
+    out[i] = ci;
+  }
+}
+constexpr int SEW_DEPTH = 8;
+// (same sums as op_sums<WANT_REF>(..., l, 8, ...); up to 8 x 16 bytes per lane in flight: 256 ops per trip; b > a is the caller's)
+template <bool WANT_REF>
+__device__ __forceinline__ void op_sums_burst(const uint32_t* __restrict__ cigar, uint64_t a, uint64_t b, uint32_t len_ops, uint32_t l, int64_t& rf, int64_t& rl) {
+  uint32_t sr = 0, sq = 0;
+  auto add = [&](uint32_t w) {
+    const uint32_t op = w & 15u, len = w >> 4;
+    if (WANT_REF) sr += len & se_mask(SE_REF_OPS, op);
+    sq += len & se_mask(len_ops, op);
+  };
+  const uint64_t mis = ((uintptr_t)cigar >> 2) & 3u;
+  const uint64_t a4 = ((a + mis + 3ull) & ~3ull) - mis, b4 = ((b + mis) & ~3ull) - mis;
+  const uint64_t he = a4 < b ? a4 : b;
+  uint32_t wh = 0, wt = 0;                               // (a packed word 0 = an empty M op: adds nothing)
+  if (a + l < he) wh = cigar[a + l];
+  if (b4 >= a4 && b4 + l < b) wt = cigar[b4 + l];
+  const uint64_t nq = b4 > a4 ? (b4 - a4) >> 2 : 0;
+  const uint4* __restrict__ qp = reinterpret_cast<const uint4*>(cigar + a4);
+  for (uint64_t q0 = 0; q0 < nq; q0 += 8ull * SEW_DEPTH) {
+    uint4 v[SEW_DEPTH];
+#pragma unroll
+    for (int u = 0; u < SEW_DEPTH; ++u) {
+      const uint64_t q = q0 + (uint64_t)u * 8u + l;
+      v[u] = q < nq ? qp[q] : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < SEW_DEPTH; ++u) {
+      add(v[u].x); add(v[u].y); add(v[u].z); add(v[u].w);
+      if (u & 1) { if (WANT_REF) { rf += sr; sr = 0; } rl += sq; sq = 0; }     // (eight ops per flush: < 2^31)
+    }
+  }
+  add(wh); add(wt);
+  if (WANT_REF) rf += sr;
+  rl += sq;
+}
+__device__ __forceinline__ bool is_clip(uint32_t w) { const uint32_t op = w & 15u; return op == 4u || op == 5u; }
+__global__ __launch_bounds__(256) void split_eval_info(const uint32_t* __restrict__ cigar, const uint64_t* __restrict__ okey, const uint32_t* __restrict__ oc1,
+                                                       const uint32_t* __restrict__ oc2, const CandInfo* __restrict__ cinfo, int min_mapq, int rec_bits,
+                                                       int dtype, int max_svlen, vsv_sig* __restrict__ s1in, uint32_t cap, Counters* ctr, SlimOut sl) {
+  const uint32_t n = ctr->n_pairs, n_raw = ctr->n_raw;           // (the live slots: the sort dropped the others)
+  if (blockIdx.x == 0 && threadIdx.x == 0) { const uint32_t s1 = n_raw + n; ctr->n_s1 = s1 < cap ? s1 : cap; }
+  const uint32_t lane = threadIdx.x & 63u, g = lane >> 3, gl = lane & 7u;
+  const uint32_t nwaves = gridDim.x * (blockDim.x / 64), wave = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+  const uint32_t len_ops = dtype == VSV_DTYPE_READS ? SE_LEN_OPS_READS : SE_LEN_OPS;
+  for (uint64_t q64 = (uint64_t)wave * 64u; q64 < n; q64 += (uint64_t)nwaves * 64u) {     // wave-uniform trip count
+    const uint32_t q = (uint32_t)q64 + lane;
+    const bool room = q < n && n_raw + q < cap;
+    if (q < n && !room) atomicOr(&ctr->err, ERRB_CAPACITY);
+    // ---- the pair, and what of the length test (Hifi.py:315-324) does not need the CIGARs ----
+    bool pre = false;
+    uint32_t i1 = 0, i2 = 0, hap = 0, n1 = 0, n2 = 0;
+    int32_t pos1 = 0, pos2 = 0, tid1 = 0;
+    uint64_t a1 = 0, a2 = 0;
+    if (room) {
+      const uint64_t ok = okey[q];
+      if (ok != VSV_KEY_DEAD) {
+        const CandInfo A = cinfo[oc1[q]], B = cinfo[oc2[q]];
+        i1 = A.rec; i2 = B.rec; pos1 = A.pos; pos2 = B.pos; tid1 = A.tid; a1 = A.a; n1 = A.nops; a2 = B.a; n2 = B.nops;
+        hap = (uint32_t)(ok >> rec_bits) & 1u;
+        if (pos1 > pos2) atomicOr(&ctr->err, ERRB_UNSORTED);                                   // Hifi.py:315
+        else pre = (((A.fm ^ B.fm) & VSV_F_REVERSE) == 0) && (int)(A.fm >> 8) >= min_mapq && (int)(B.fm >> 8) >= min_mapq && n1 > 0 && n2 > 0;
+      }
+    }
+    // ---- reference span of record 1, read lengths of both, the last op of record 1 and the first of record 2 ----
+    const bool is_long = pre && (uint64_t)n1 + n2 > SE_LONG_OPS;
+    int64_t rf1 = 0, rl1 = 0, rl2 = 0;
+    uint32_t last1 = 0, first2 = 0;
+    const uint64_t todo = __ballot(pre && !is_long);
+#pragma unroll 1
+    for (uint32_t r = 0; r < 8; ++r) {
+      if (((todo >> (8u * r)) & 0xFFull) == 0) continue;                                     // (wave-uniform)
+      const int src = (int)(8u * r + g);
+      const bool on = (todo >> src) & 1ull;
+      const uint64_t xa1 = __shfl(a1, src, 64), xa2 = __shfl(a2, src, 64);
+      const uint32_t xn1 = (uint32_t)__shfl((int)n1, src, 64), xn2 = (uint32_t)__shfl((int)n2, src, 64);
+      int64_t f1 = 0, l1 = 0, f2 = 0, l2 = 0;
+      uint32_t e = 0;
+      if (on) {
+        if (gl == 0) e = cigar[xa1 + xn1 - 1u];                                              // (the lines of the sums: no extra traffic)
+        if (gl == 1) e = cigar[xa2];
+        op_sums_burst<true>(cigar, xa1, xa1 + xn1, len_ops, gl, f1, l1);
+        op_sums_burst<false>(cigar, xa2, xa2 + xn2, len_ops, gl, f2, l2);
+      }
+      f1 = group_sum64<8>(f1); l1 = group_sum64<8>(l1); l2 = group_sum64<8>(l2);
+      // the owner of slot 8r + k is lane 8r + k; its sums sit in (every lane of) group k, its edge ops in lanes 0 and 1 of that group
+      const int from = (int)((lane & 7u) * 8u);
+      const int64_t of1 = __shfl(f1, from, 64), ol1 = __shfl(l1, from, 64), ol2 = __shfl(l2, from, 64);
+      const uint32_t oe1 = (uint32_t)__shfl((int)e, from, 64), oe2 = (uint32_t)__shfl((int)e, from + 1, 64);
+      if (g == r) { rf1 = of1; rl1 = ol1; rl2 = ol2; last1 = oe1; first2 = oe2; }
+    }
+    uint64_t lm = __ballot(is_long);
+    while (lm) {                                       // wave-uniform: one long pair at a time, 64 lanes on its two CIGARs
+      const int src = __builtin_ctzll(lm);
+      lm &= lm - 1;
+      const uint64_t xa1 = __shfl(a1, src, 64), xa2 = __shfl(a2, src, 64);
+      const uint32_t xn1 = (uint32_t)__shfl((int)n1, src, 64), xn2 = (uint32_t)__shfl((int)n2, src, 64);
+      int64_t f1 = 0, l1 = 0, f2 = 0, l2 = 0;
+      op_sums<true>(cigar, xa1, xa1 + xn1, len_ops, lane, 64, f1, l1);
+      op_sums<false>(cigar, xa2, xa2 + xn2, len_ops, lane, 64, f2, l2);
+      f1 = wave_sum64(f1); l1 = wave_sum64(l1); l2 = wave_sum64(l2);
+      if ((int)lane == src) { rf1 = f1; rl1 = l1; rl2 = l2; last1 = cigar[xa1 + xn1 - 1u]; first2 = cigar[xa2]; }
+    }
+    // ---- the rest of the length test, the pair rules and the row, one lane per slot ----
+    if (!room) continue;
+    const bool need = pre && is_clip(last1) && is_clip(first2);                                // Hifi.py:323-324
+    const vsv_sig out = split_rules(need, i1, i2, pos1, pos2, tid1, hap, last1, first2, rf1, rl1, rl2, dtype, max_svlen, ctr);
     s1in[n_raw + q] = out;
     vsv_slim_emit(sl, n_raw + q, out);
   }
@@ -983,7 +1148,7 @@ static SplitCfg split_cfg(const RecView& rv, const vsv_params& p, int n_tids) {
 SplitSorted vsv_launch_split_candidates(hipStream_t st, const RecView& rv, const vsv_params& p, int n_tids, uint32_t* tab, uint32_t tab_size,
                                         uint32_t* blk_cnt, uint32_t* blk_off, uint32_t* scan_tmp, uint64_t* ckey, uint32_t* crec,
                                         uint64_t* okey, uint32_t* oval, uint64_t* key2, uint32_t* idx2, const SortWork& sw,
-                                        uint32_t cap, Counters* ctr, uint8_t* cmask, int grid, const SlimWork* slim) {
+                                        uint32_t cap, Counters* ctr, uint8_t* cmask, int grid, const SlimWork* slim, const CandBufs& cb) {
   SplitSorted out{nullptr, nullptr, nullptr, nullptr};
   if (rv.n_records <= 0) return out;
   const SplitCfg c = split_cfg(rv, p, n_tids);
@@ -1009,9 +1174,20 @@ SplitSorted vsv_launch_split_candidates(hipStream_t st, const RecView& rv, const
     // large inputs (config 3: ~10^7 candidates): both sorts through the 8-bit passes over 16-byte elements (slim_path.hip; the
     // 9-11 bit passes over separate key / value arrays write 16- and 8-byte pieces: 0.3-0.4 ms per pass there). Dead pair slots
     // are dropped by the second sort's first pass: the live ones come first, as before.
-    const SortResult r1 = vsv_slim_sort_pairs(st, ckey, crec, &ctr->n_cand, c.tid_shift + c.tid_bits, sw.key_alt, sw.val_alt, &ctr->n_pairs, *slim);
-    const SortResult r2 = vsv_slim_sort_pair_slots(st, r1.key, r1.val, c.qid_bits, rec_bits, &ctr->n_cand, rec_bits + 1 + c.tid_bits, okey, oval, &ctr->n_pairs, *slim);
+    // read-shaped input: what a pair needs of its two records is computed per candidate, here (cand_info), and the sorts carry the
+    // candidates' ordinals; contig alignments (10^4-10^6 ops per CIGAR, few candidates) keep the per-pair sums of split_eval<64>
+    static const char* info_mode = vsv_dbg_env("VSV_SPLIT_INFO");          // timing experiments: "0" = per-pair gathers (split_eval<8>)
+    const bool info = cb.cinfo && !vsv_scan_is_long(rv, p) && !(info_mode && info_mode[0] == '0');
+    if (info) {
+      cand_info<<<grid, 256, 0, st>>>(rv, ckey, crec, c, (CandInfo*)cb.cinfo, ctr);
+    }
+    const SortResult r1 = vsv_slim_sort_pairs(st, ckey, crec, &ctr->n_cand, c.tid_shift + c.tid_bits, sw.key_alt, sw.val_alt, &ctr->n_pairs, *slim,
+                                              info ? cb.cord : nullptr);
+    const SortResult r2 = vsv_slim_sort_pair_slots(st, r1.key, r1.val, c.qid_bits, rec_bits, &ctr->n_cand, rec_bits + 1 + c.tid_bits, okey, oval, &ctr->n_pairs, *slim,
+                                                   info ? cb.cord : nullptr, info ? cb.oc1 : nullptr);
     out.ckey = r1.key; out.crec = r1.val; out.okey = r2.key; out.oval = r2.val;
+    out.live_only = true;                              // ctr->n_pairs = the live slots, in front
+    if (info) { out.oc1 = cb.oc1; out.cinfo = cb.cinfo; }
     return out;
   }
   // the first result may live in the shared scratch pair, so the second sort gets a scratch pair of its own
@@ -1032,8 +1208,11 @@ void vsv_launch_split_eval(hipStream_t st, const RecView& rv, const vsv_params& 
   if (rv.n_records <= 0 || !so.okey) { set_n_s1<<<1, 1, 0, st>>>(ctr, cap); return; }
   const SplitCfg c = split_cfg(rv, p, n_tids);
   const int eg = grid * 8 < 1024 ? 1024 : (grid * 8 > 8192 ? 8192 : grid * 8);
-  if (vsv_scan_is_long(rv, p)) split_eval<64><<<eg, 256, 0, st>>>(rv, so.okey, so.oval, so.ckey, so.crec, c, p.dtype, p.max_split_svlen, s1in, cap, ctr, sl);
-  else split_eval<8><<<eg, 256, 0, st>>>(rv, so.okey, so.oval, so.ckey, so.crec, c, p.dtype, p.max_split_svlen, s1in, cap, ctr, sl);
+  if (so.cinfo) {
+    const int rec_bits = bits_for((uint64_t)rv.n_records + 1);
+    split_eval_info<<<eg, 256, 0, st>>>(rv.cigar, so.okey, so.oc1, so.oval, (const CandInfo*)so.cinfo, c.min_mapq, rec_bits, p.dtype, p.max_split_svlen, s1in, cap, ctr, sl);
+  } else if (vsv_scan_is_long(rv, p)) split_eval<64><<<eg, 256, 0, st>>>(rv, so.okey, so.oval, so.ckey, so.crec, c, p.dtype, p.max_split_svlen, s1in, cap, ctr, sl, so.live_only);
+  else split_eval<8><<<eg, 256, 0, st>>>(rv, so.okey, so.oval, so.ckey, so.crec, c, p.dtype, p.max_split_svlen, s1in, cap, ctr, sl, so.live_only);
 }
 
 // sort rows `in[0,n)` by the stage key into `sorted`, publish the alive count

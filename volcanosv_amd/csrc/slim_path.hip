@@ -80,8 +80,9 @@ __global__ __launch_bounds__(256) void sl_from_rows(const vsv_sig* __restrict__ 
 }
 
 // ---- stable LSD radix sort of slim elements ----------------------------------------------------------------------------------
-constexpr int SL_WAVES = 4, SL_ROUNDS = 16;
-constexpr uint32_t SL_TILE = SL_WAVES * SL_ROUNDS * 64;      // 4096 elements
+// A tile = 4096 elements, worked by a block of WAVES waves (4 or 16: a table of a few million elements has only some hundred tiles,
+// and 4 waves per tile leave the chip at two waves per SIMD with nothing to hide the dependent LDS / ballot chains behind).
+constexpr uint32_t SL_TILE = 4096;
 
 // where the elements of a sort's first pass come from: an array, or the pairing state (the call elements are never materialised)
 struct SrcSlim {
@@ -135,25 +136,25 @@ __device__ __forceinline__ uint64_t sl_match_digit(uint32_t d, bool valid) {
 __device__ __forceinline__ uint32_t sl_tiles(uint32_t n) { return (n + SL_TILE - 1) / SL_TILE; }
 
 // hist[tile][d] = elements of the tile with digit d (dead elements of a first pass do not count); totals[d] += the same
-template <int BITS, typename SRC, bool SKIP_DEAD>
-__global__ __launch_bounds__(256) void sl_hist(SRC src, const uint32_t* __restrict__ d_n, int shift, KeyCmp kc, uint32_t* __restrict__ hist, uint32_t* __restrict__ totals) {
-  constexpr int BINS = 1 << BITS;
+template <int BITS, typename SRC, bool SKIP_DEAD, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void sl_hist(SRC src, const uint32_t* __restrict__ d_n, int shift, KeyCmp kc, uint32_t* __restrict__ hist, uint32_t* __restrict__ totals) {
+  constexpr int BINS = 1 << BITS, T = WAVES * 64;
   __shared__ uint32_t cnt[BINS];
   const uint32_t n = *d_n, ntiles = sl_tiles(n);
   for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    for (int d = threadIdx.x; d < BINS; d += 256) cnt[d] = 0;
+    for (int d = threadIdx.x; d < BINS; d += T) cnt[d] = 0;
     __syncthreads();
     const uint32_t base = tile * SL_TILE;
 #pragma unroll 4
-    for (int k = 0; k < (int)SL_TILE / 256; ++k) {
-      const uint32_t i = base + k * 256 + threadIdx.x;
+    for (int k = 0; k < (int)SL_TILE / T; ++k) {
+      const uint32_t i = base + k * T + threadIdx.x;
       if (i < n) {
         const uint64_t key = src.at(i).key;
         if (!SKIP_DEAD || key != VSV_KEY_DEAD) atomicAdd(&cnt[(uint32_t)(kc(key) >> shift) & (BINS - 1)], 1u);
       }
     }
     __syncthreads();
-    for (int d = threadIdx.x; d < BINS; d += 256) {
+    for (int d = threadIdx.x; d < BINS; d += T) {
       const uint32_t c = cnt[d];
       hist[(size_t)tile * BINS + d] = c;
       if (c) atomicAdd(&totals[d], c);
@@ -227,23 +228,23 @@ __global__ __launch_bounds__(1024) void sl_scan(uint32_t* __restrict__ hist, con
 }
 
 // stable scatter of one pass: ranks inside a wave from ballot matches, per-wave running counters in LDS (as rs_scatter)
-template <int BITS, typename SRC, bool SKIP_DEAD>
-__global__ __launch_bounds__(256) void sl_scatter(SRC src, const uint32_t* __restrict__ d_n, int shift, KeyCmp kc, const uint32_t* __restrict__ hist, Slim* __restrict__ out) {
-  constexpr int BINS = 1 << BITS;
-  __shared__ uint32_t wcnt[SL_WAVES][BINS];
+template <int BITS, typename SRC, bool SKIP_DEAD, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void sl_scatter(SRC src, const uint32_t* __restrict__ d_n, int shift, KeyCmp kc, const uint32_t* __restrict__ hist, Slim* __restrict__ out) {
+  constexpr int BINS = 1 << BITS, T = WAVES * 64, ROUNDS = (int)SL_TILE / T;
+  __shared__ uint32_t wcnt[WAVES][BINS];
   const uint32_t n = *d_n, ntiles = sl_tiles(n);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint64_t lt = (1ull << lane) - 1ull;
   for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    for (int d = threadIdx.x; d < BINS; d += 256)
+    for (int d = threadIdx.x; d < BINS; d += T)
 #pragma unroll
-      for (int w = 0; w < SL_WAVES; ++w) wcnt[w][d] = 0;
+      for (int w = 0; w < WAVES; ++w) wcnt[w][d] = 0;
     __syncthreads();
-    const uint32_t wbase = tile * SL_TILE + wv * (SL_ROUNDS * 64);
-    Slim e_[SL_ROUNDS];
-    uint32_t rk[SL_ROUNDS];
+    const uint32_t wbase = tile * SL_TILE + wv * (ROUNDS * 64);
+    Slim e_[ROUNDS];
+    uint32_t rk[ROUNDS];
 #pragma unroll
-    for (int r = 0; r < SL_ROUNDS; ++r) {
+    for (int r = 0; r < ROUNDS; ++r) {
       const uint32_t i = wbase + r * 64 + lane;
       bool ok = i < n;
       if (ok) e_[r] = src.at(i); else e_[r] = dead_slim();
@@ -257,14 +258,14 @@ __global__ __launch_bounds__(256) void sl_scatter(SRC src, const uint32_t* __res
       rk[r] = ok ? old + (uint32_t)__popcll(m & lt) : 0xFFFFFFFFu;
     }
     __syncthreads();
-    for (int d = threadIdx.x; d < BINS; d += 256) {  // exclusive prefix of the digit's count over the waves + global base
+    for (int d = threadIdx.x; d < BINS; d += T) {  // exclusive prefix of the digit's count over the waves + global base
       uint32_t run = hist[(size_t)tile * BINS + d];
 #pragma unroll
-      for (int w = 0; w < SL_WAVES; ++w) { const uint32_t c = wcnt[w][d]; wcnt[w][d] = run; run += c; }
+      for (int w = 0; w < WAVES; ++w) { const uint32_t c = wcnt[w][d]; wcnt[w][d] = run; run += c; }
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < SL_ROUNDS; ++r) {
+    for (int r = 0; r < ROUNDS; ++r) {
       if (rk[r] != 0xFFFFFFFFu) {
         const uint32_t d = (uint32_t)(kc(e_[r].key) >> shift) & (BINS - 1);
         st_slim(out + wcnt[wv][d] + rk[r], e_[r]);
@@ -958,10 +959,12 @@ __global__ __launch_bounds__(256) void sl_rows_out(const Slim* __restrict__ e, u
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------------
 template <int BITS, typename SRC, bool SKIP>
-void sl_pass(hipStream_t st, SRC src, const uint32_t* d_n, int shift, KeyCmp kc, Slim* out, uint32_t* hist, uint32_t* totals, uint32_t* d_total, int grid) {
-  sl_hist<BITS, SRC, SKIP><<<grid, 256, 0, st>>>(src, d_n, shift, kc, hist, totals);
+void sl_pass(hipStream_t st, SRC src, const uint32_t* d_n, int shift, KeyCmp kc, Slim* out, uint32_t* hist, uint32_t* totals, uint32_t* d_total, int grid, bool wide) {
+  if (wide) sl_hist<BITS, SRC, SKIP, 16><<<grid, 1024, 0, st>>>(src, d_n, shift, kc, hist, totals);
+  else sl_hist<BITS, SRC, SKIP, 4><<<grid, 256, 0, st>>>(src, d_n, shift, kc, hist, totals);
   sl_scan<BITS><<<(1 << BITS) / 16, 1024, 0, st>>>(hist, totals, d_n, d_total);
-  sl_scatter<BITS, SRC, SKIP><<<grid, 256, 0, st>>>(src, d_n, shift, kc, hist, out);
+  if (wide) sl_scatter<BITS, SRC, SKIP, 16><<<grid, 1024, 0, st>>>(src, d_n, shift, kc, hist, out);
+  else sl_scatter<BITS, SRC, SKIP, 4><<<grid, 256, 0, st>>>(src, d_n, shift, kc, hist, out);
 }
 
 // Stable sort of the live elements of `src` (n slots, *d_slots) by key bits [0, nbits): the first pass skips dead elements and
@@ -984,6 +987,9 @@ Slim* sl_sort(hipStream_t st, SRC src, const uint32_t* d_slots, uint32_t* d_live
   const int bits = dp.bits, passes = dp.passes;
   const int64_t max_tiles = (w.cap + SL_TILE - 1) / SL_TILE;
   const int grid = (int)(max_tiles < 2048 ? (max_tiles < 1 ? 1 : max_tiles) : 2048);
+  // blocks of 16 waves where the previous run's tables say the tiles alone cannot fill the chip
+  static const int force_waves = vsv_dbg_env("VSV_SLIM_WAVES") ? atoi(vsv_dbg_env("VSV_SLIM_WAVES")) : 0;     // timing experiments
+  const bool wide = force_waves ? force_waves == 16 : w.rows_hint <= (int64_t)2048 * SL_TILE;
   Slim* dst = a;
   Slim* other = b;
   for (int p = 0; p < passes; ++p) {
@@ -991,12 +997,12 @@ Slim* sl_sort(hipStream_t st, SRC src, const uint32_t* d_slots, uint32_t* d_live
     ++*w.pass_cursor;
     const int shift = p * bits;
     if (p == 0) {
-      if (bits == 8) sl_pass<8, SRC, true>(st, src, d_slots, shift, kc, dst, w.hist, totals, d_live, grid);
-      else sl_pass<10, SRC, true>(st, src, d_slots, shift, kc, dst, w.hist, totals, d_live, grid);
+      if (bits == 8) sl_pass<8, SRC, true>(st, src, d_slots, shift, kc, dst, w.hist, totals, d_live, grid, wide);
+      else sl_pass<10, SRC, true>(st, src, d_slots, shift, kc, dst, w.hist, totals, d_live, grid, wide);
     } else {
       const SrcSlim in{other};
-      if (bits == 8) sl_pass<8, SrcSlim, false>(st, in, d_live, shift, kc, dst, w.hist, totals, nullptr, grid);
-      else sl_pass<10, SrcSlim, false>(st, in, d_live, shift, kc, dst, w.hist, totals, nullptr, grid);
+      if (bits == 8) sl_pass<8, SrcSlim, false>(st, in, d_live, shift, kc, dst, w.hist, totals, nullptr, grid, wide);
+      else sl_pass<10, SrcSlim, false>(st, in, d_live, shift, kc, dst, w.hist, totals, nullptr, grid, wide);
     }
     Slim* t = dst; dst = other; other = t;
   }
@@ -1061,12 +1067,14 @@ void vsv_slim_pair(hipStream_t st, const void* merged, const uint32_t* d_alive3,
 namespace {
 struct SrcPairs {
   const uint64_t* key; const uint32_t* val;
-  __device__ __forceinline__ Slim at(uint32_t i) const { Slim s; s.key = key[i]; s.svlen = 0; s.idx = val[i]; return s; }
+  __device__ __forceinline__ Slim at(uint32_t i) const { Slim s; s.key = key[i]; s.svlen = (int32_t)i; s.idx = val[i]; return s; }     // (svlen: the input ordinal)
 };
 // key of a split-pair slot, straight from the candidates sorted by (tid, hap, name) (as PairKey of radix_sort.hip): candidate j followed
 // by another one of the same name heads a pair slot keyed (tid, hap, record of the name's first candidate); every other slot is dead
+// With `cord` (the candidates' ordinals in record order) a slot carries its two candidates instead of its index: svlen = ordinal of
+// candidate j, idx = ordinal of candidate j + 1 (split_eval_info, sig_stages.hip).
 struct SrcPairSlots {
-  const uint64_t* ckey; const uint32_t* crec; int qid_bits, rec_bits; const uint32_t* d_n;
+  const uint64_t* ckey; const uint32_t* crec; int qid_bits, rec_bits; const uint32_t* d_n; const uint32_t* cord;
   __device__ __forceinline__ Slim at(uint32_t j) const {
     const uint32_t n = *d_n;
     const uint64_t k = ckey[j];
@@ -1075,31 +1083,32 @@ struct SrcPairSlots {
       uint32_t g = j;
       while (g > 0 && ckey[g - 1] == k) --g;
       s.key = ((k >> qid_bits) << rec_bits) | crec[g];
+      if (cord) { s.svlen = (int32_t)cord[j]; s.idx = cord[j + 1]; }
     }
     return s;
   }
 };
 // sorted elements -> (key, value) arrays of n slots: the live ones in order, dead keys behind them
 __global__ __launch_bounds__(256) void sl_unpack_pairs(const Slim* __restrict__ e, const uint32_t* __restrict__ d_live, const uint32_t* __restrict__ d_n,
-                                                       uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
+                                                       uint64_t* __restrict__ key, uint32_t* __restrict__ val, uint32_t* __restrict__ aux) {
   const uint32_t n = *d_n, live = *d_live;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    if (i < live) { const Slim x = ld_slim(e + i); key[i] = x.key; val[i] = x.idx; }
-    else { key[i] = VSV_KEY_DEAD; val[i] = 0; }
+    if (i < live) { const Slim x = ld_slim(e + i); key[i] = x.key; val[i] = x.idx; if (aux) aux[i] = (uint32_t)x.svlen; }
+    else { key[i] = VSV_KEY_DEAD; val[i] = 0; if (aux) aux[i] = 0; }
   }
 }
 }  // namespace
 
 SortResult vsv_slim_sort_pairs(hipStream_t st, const uint64_t* key, const uint32_t* val, const uint32_t* d_n, int nbits, uint64_t* out_key, uint32_t* out_val,
-                               uint32_t* d_live, const SlimWork& w) {
+                               uint32_t* d_live, const SlimWork& w, uint32_t* out_ord) {
   Slim* r = sl_sort(st, SrcPairs{key, val}, d_n, d_live, nbits, KeyCmp{0, 0}, (Slim*)w.buf[3], (Slim*)w.buf[4], w);
-  sl_unpack_pairs<<<w.grid, 256, 0, st>>>(r, d_live, d_n, out_key, out_val);
+  sl_unpack_pairs<<<w.grid, 256, 0, st>>>(r, d_live, d_n, out_key, out_val, out_ord);
   return SortResult{out_key, out_val};
 }
 SortResult vsv_slim_sort_pair_slots(hipStream_t st, const uint64_t* ckey, const uint32_t* crec, int qid_bits, int rec_bits, const uint32_t* d_n, int nbits,
-                                    uint64_t* out_key, uint32_t* out_val, uint32_t* d_live, const SlimWork& w) {
-  Slim* r = sl_sort(st, SrcPairSlots{ckey, crec, qid_bits, rec_bits, d_n}, d_n, d_live, nbits, KeyCmp{0, 0}, (Slim*)w.buf[3], (Slim*)w.buf[4], w);
-  sl_unpack_pairs<<<w.grid, 256, 0, st>>>(r, d_live, d_n, out_key, out_val);
+                                    uint64_t* out_key, uint32_t* out_val, uint32_t* d_live, const SlimWork& w, const uint32_t* cord, uint32_t* out_c1) {
+  Slim* r = sl_sort(st, SrcPairSlots{ckey, crec, qid_bits, rec_bits, d_n, cord}, d_n, d_live, nbits, KeyCmp{0, 0}, (Slim*)w.buf[3], (Slim*)w.buf[4], w);
+  sl_unpack_pairs<<<w.grid, 256, 0, st>>>(r, d_live, d_n, out_key, out_val, cord ? out_c1 : nullptr);
   return SortResult{out_key, out_val};
 }
 

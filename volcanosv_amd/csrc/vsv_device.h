@@ -179,11 +179,17 @@ struct SlimWork;
 void vsv_launch_clr_gate(hipStream_t st, const RecView& rv, uint8_t* gflag, Counters* ctr);   // CLR: gated flag bytes for the scan
 void vsv_launch_fold(hipStream_t st, const vsv_sig* raw, vsv_sig* s1in, const RecView& rv, const vsv_params& p, Counters* ctr, int grid,
                      const SlimOut& so = SlimOut{nullptr, 0, 0, 0, nullptr});
-struct SplitSorted { const uint64_t* ckey; const uint32_t* crec; const uint64_t* okey; const uint32_t* oval; };   // candidates by name / pairs by record
+struct SplitSorted {      // candidates by name / pairs by record
+  const uint64_t* ckey; const uint32_t* crec; const uint64_t* okey; const uint32_t* oval;
+  const uint32_t* oc1 = nullptr; const void* cinfo = nullptr;      // large read-shaped inputs: a slot's two candidates (oc1, oval) into cinfo
+  bool live_only = false;   // the slot sort dropped the dead slots: Counters::n_pairs live ones, in front (else n_cand slots, dead ones behind)
+};
+struct CandBufs { void* cinfo; uint32_t* cord; uint32_t* oc1; };     // 32 / 4 / 4 bytes per candidate (null: the record arrays are gathered per pair)
 SplitSorted vsv_launch_split_candidates(hipStream_t st, const RecView& rv, const vsv_params& p, int n_tids, uint32_t* tab, uint32_t tab_size,
                                         uint32_t* blk_cnt, uint32_t* blk_off, uint32_t* scan_tmp, uint64_t* ckey, uint32_t* crec,
                                         uint64_t* okey, uint32_t* oval, uint64_t* key2, uint32_t* idx2, const SortWork& sw,
-                                        uint32_t cap, Counters* ctr, uint8_t* cmask, int grid, const struct SlimWork* slim = nullptr);
+                                        uint32_t cap, Counters* ctr, uint8_t* cmask, int grid, const struct SlimWork* slim = nullptr,
+                                        const CandBufs& cb = CandBufs{nullptr, nullptr, nullptr});
 void vsv_launch_split_eval(hipStream_t st, const RecView& rv, const vsv_params& p, int n_tids, const SplitSorted& so, vsv_sig* s1in,
                            uint32_t cap, Counters* ctr, int grid, const SlimOut& sl = SlimOut{nullptr, 0, 0, 0, nullptr});
 // returns the sorted key array (kept for the cluster / pair kernel that follows)
@@ -201,6 +207,7 @@ struct SlimWork {
   void* buf[6];         // element buffers, cap x 16 bytes each: 0 / 1 scratch of the sorts, 2 stage-1 clusters (kept for VSV_T_CLUSTER1),
                         // 3 stage-2 clusters / pairing reservations, 4 / 5 merged elements (kept for VSV_T_MERGED and the calls)
   int64_t cap;          // elements per buffer (= row capacity of the handle)
+  int64_t rows_hint;    // largest table of the handle's previous run + 25 % (a first run: cap) - speed decisions only
   uint32_t* hist;       // [1024 * tiles of 4096]
   uint32_t* totals;     // zeroed per-pass digit totals, 2048 entries per slot (SortWork::totals)
   int* pass_cursor;
@@ -220,9 +227,10 @@ void vsv_slim_rows(hipStream_t st, const void* elems, uint32_t n, const vsv_sig*
 // (key, value) arrays through the element passes (element buffers 3 / 4 as scratch): the split stage's candidate sorts on large inputs.
 // Dead keys are dropped by the first pass and written back behind the live ones; *d_live = the live count.
 SortResult vsv_slim_sort_pairs(hipStream_t st, const uint64_t* key, const uint32_t* val, const uint32_t* d_n, int nbits, uint64_t* out_key, uint32_t* out_val,
-                               uint32_t* d_live, const SlimWork& w);
+                               uint32_t* d_live, const SlimWork& w, uint32_t* out_ord = nullptr);
 SortResult vsv_slim_sort_pair_slots(hipStream_t st, const uint64_t* ckey, const uint32_t* crec, int qid_bits, int rec_bits, const uint32_t* d_n, int nbits,
-                                    uint64_t* out_key, uint32_t* out_val, uint32_t* d_live, const SlimWork& w);
+                                    uint64_t* out_key, uint32_t* out_val, uint32_t* d_live, const SlimWork& w, const uint32_t* cord = nullptr,
+                                    uint32_t* out_c1 = nullptr);
 
 // bnd.hip
 void vsv_launch_bnd_segments(hipStream_t st, const vsv_segments& s, const vsv_bnd_params& p, vsv_bnd* cand, uint32_t cap, Counters* ctr);
