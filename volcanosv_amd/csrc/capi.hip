@@ -416,7 +416,7 @@ int slim_work(vsv_handle* h, SlimWork& w) {
   int st;
   if ((st = ensure(h, h->sl_hj, n * 4 + 64))) return st;
   if ((st = ensure(h, h->sl_done, n * 4 + 64))) return st;
-  { const Counters& c = h->host_ctr; const uint64_t r = c.n_s1 > c.n_cand ? c.n_s1 : c.n_cand; w.rows_hint = r ? (int64_t)(r + r / 4) : h->cap_sigs; }
+  { const Counters& c = h->host_ctr; w.rows_hint = c.n_s1 ? (int64_t)c.n_s1 + c.n_s1 / 4 : h->cap_sigs; w.cand_hint = c.n_cand ? (int64_t)c.n_cand + c.n_cand / 4 : h->cap_sigs; }
   w.cap = h->cap_sigs; w.hist = (uint32_t*)h->hist.p; w.totals = (uint32_t*)h->totals.p; w.pass_cursor = &h->pass_cursor;
   w.grid = ew_grid(h); w.cl = (int32_t*)h->cl.p; w.hj = (uint32_t*)h->sl_hj.p; w.done1 = (uint32_t*)h->sl_done.p;
   return 0;

@@ -982,14 +982,14 @@ DigitPlan sl_plan(int nbits) {
   return p10 < p8 ? DigitPlan{10, p10} : DigitPlan{8, p8};
 }
 template <typename SRC>
-Slim* sl_sort(hipStream_t st, SRC src, const uint32_t* d_slots, uint32_t* d_live, int nbits, KeyCmp kc, Slim* a, Slim* b, const SlimWork& w) {
+Slim* sl_sort(hipStream_t st, SRC src, const uint32_t* d_slots, uint32_t* d_live, int nbits, KeyCmp kc, Slim* a, Slim* b, const SlimWork& w, int64_t hint) {
   const DigitPlan dp = sl_plan(nbits - kc.zbits);
   const int bits = dp.bits, passes = dp.passes;
   const int64_t max_tiles = (w.cap + SL_TILE - 1) / SL_TILE;
   const int grid = (int)(max_tiles < 2048 ? (max_tiles < 1 ? 1 : max_tiles) : 2048);
   // blocks of 16 waves where the previous run's tables say the tiles alone cannot fill the chip
   static const int force_waves = vsv_dbg_env("VSV_SLIM_WAVES") ? atoi(vsv_dbg_env("VSV_SLIM_WAVES")) : 0;     // timing experiments
-  const bool wide = force_waves ? force_waves == 16 : w.rows_hint <= (int64_t)2048 * SL_TILE;
+  const bool wide = force_waves ? force_waves == 16 : hint <= (int64_t)2048 * SL_TILE;
   Slim* dst = a;
   Slim* other = b;
   for (int p = 0; p < passes; ++p) {
@@ -1020,7 +1020,7 @@ void* vsv_slim_stage1(hipStream_t st, const vsv_sig* s1in, const uint32_t* d_n_s
   Slim* b0 = (Slim*)w.buf[0]; Slim* b1 = (Slim*)w.buf[1]; Slim* e2 = (Slim*)w.buf[2];
   // (a fused run has the elements already: fold_kernel / split_eval wrote them next to the rows, vsv_slim_emit)
   if (!prebuilt) sl_from_rows<<<w.grid, 256, 0, st>>>(s1in, d_n_s1, pb, tid_lo, tid_bits, b0, &ctr->err);
-  Slim* sorted = sl_sort(st, SrcSlim{b0}, d_n_s1, d_alive1, pb + 3 + tid_bits, KeyCmp{0, 0}, b1, b0, w);
+  Slim* sorted = sl_sort(st, SrcSlim{b0}, d_n_s1, d_alive1, pb + 3 + tid_bits, KeyCmp{0, 0}, b1, b0, w, w.rows_hint);
   const int64_t tiles = (w.cap + CL_TILE - 1) / CL_TILE;
   sl_cluster<<<(int)(tiles < 4096 ? (tiles < 1 ? 1 : tiles) : 4096), 256, 0, st>>>(sorted, d_alive1, cluster_shift, KeyFmt{pb}, pb, e2, w.cl);
   return e2;
@@ -1030,11 +1030,11 @@ void* vsv_slim_stage1(hipStream_t st, const vsv_sig* s1in, const uint32_t* d_n_s
 void* vsv_slim_merge(hipStream_t st, const void* e2, const uint32_t* d_alive1, uint32_t* d_alive2, uint32_t* d_alive3, int pb, int tid_bits,
                      int cluster_shift, const SlimWork& w) {
   Slim* b0 = (Slim*)w.buf[0]; Slim* b1 = (Slim*)w.buf[1]; Slim* e3 = (Slim*)w.buf[3]; Slim* m0 = (Slim*)w.buf[4]; Slim* m1 = (Slim*)w.buf[5];
-  Slim* s2 = sl_sort(st, SrcSlim{(const Slim*)e2}, d_alive1, d_alive2, pb + 3 + tid_bits, KeyCmp{pb, 1}, b0, b1, w);
+  Slim* s2 = sl_sort(st, SrcSlim{(const Slim*)e2}, d_alive1, d_alive2, pb + 3 + tid_bits, KeyCmp{pb, 1}, b0, b1, w, w.rows_hint);
   const int64_t tiles = (w.cap + CL_TILE - 1) / CL_TILE;
   sl_cluster<<<(int)(tiles < 4096 ? (tiles < 1 ? 1 : tiles) : 4096), 256, 0, st>>>(s2, d_alive2, cluster_shift, KeyFmt{pb}, pb + 1, e3, w.cl);
   // the result must outlive the pairing stage and the readback: it lands in one of the two buffers reserved for it
-  return sl_sort(st, SrcSlim{e3}, d_alive2, d_alive3, pb + 3 + tid_bits, KeyCmp{pb, 2}, m0, m1, w);
+  return sl_sort(st, SrcSlim{e3}, d_alive2, d_alive3, pb + 3 + tid_bits, KeyCmp{pb, 2}, m0, m1, w, w.rows_hint);
 }
 
 // pair_sig + the final order: pairing state in w.cl, call elements sorted by (tid, pos), call rows gathered from s1in
@@ -1059,7 +1059,7 @@ void vsv_slim_pair(hipStream_t st, const void* merged, const uint32_t* d_alive3,
     const int64_t wins = (w.cap + QW - 1) / QW;
     sl_pair_lds<<<(int)(wins < 32768 ? (wins < 1 ? 1 : wins) : 32768), 64, 0, st>>>(m, d_alive3, kf, pair_shift, right, w.cl, w.hj, &ctr->max_stretch);
   }
-  Slim* cs = sl_sort(st, SrcCalls{m, w.cl, pb + 2}, d_alive3, d_ncalls, pb + 3 + tid_bits, KeyCmp{pb, 3}, b0, b1, w);
+  Slim* cs = sl_sort(st, SrcCalls{m, w.cl, pb + 2}, d_alive3, d_ncalls, pb + 3 + tid_bits, KeyCmp{pb, 3}, b0, b1, w, w.rows_hint);
   sl_calls_out<<<w.grid, 256, 0, st>>>(cs, d_ncalls, m, pb + 2, s1in, calls);
 }
 
@@ -1101,13 +1101,13 @@ __global__ __launch_bounds__(256) void sl_unpack_pairs(const Slim* __restrict__ 
 
 SortResult vsv_slim_sort_pairs(hipStream_t st, const uint64_t* key, const uint32_t* val, const uint32_t* d_n, int nbits, uint64_t* out_key, uint32_t* out_val,
                                uint32_t* d_live, const SlimWork& w, uint32_t* out_ord) {
-  Slim* r = sl_sort(st, SrcPairs{key, val}, d_n, d_live, nbits, KeyCmp{0, 0}, (Slim*)w.buf[3], (Slim*)w.buf[4], w);
+  Slim* r = sl_sort(st, SrcPairs{key, val}, d_n, d_live, nbits, KeyCmp{0, 0}, (Slim*)w.buf[3], (Slim*)w.buf[4], w, w.cand_hint);
   sl_unpack_pairs<<<w.grid, 256, 0, st>>>(r, d_live, d_n, out_key, out_val, out_ord);
   return SortResult{out_key, out_val};
 }
 SortResult vsv_slim_sort_pair_slots(hipStream_t st, const uint64_t* ckey, const uint32_t* crec, int qid_bits, int rec_bits, const uint32_t* d_n, int nbits,
                                     uint64_t* out_key, uint32_t* out_val, uint32_t* d_live, const SlimWork& w, const uint32_t* cord, uint32_t* out_c1) {
-  Slim* r = sl_sort(st, SrcPairSlots{ckey, crec, qid_bits, rec_bits, d_n, cord}, d_n, d_live, nbits, KeyCmp{0, 0}, (Slim*)w.buf[3], (Slim*)w.buf[4], w);
+  Slim* r = sl_sort(st, SrcPairSlots{ckey, crec, qid_bits, rec_bits, d_n, cord}, d_n, d_live, nbits, KeyCmp{0, 0}, (Slim*)w.buf[3], (Slim*)w.buf[4], w, w.cand_hint);
   sl_unpack_pairs<<<w.grid, 256, 0, st>>>(r, d_live, d_n, out_key, out_val, cord ? out_c1 : nullptr);
   return SortResult{out_key, out_val};
 }

@@ -207,7 +207,7 @@ struct SlimWork {
   void* buf[6];         // element buffers, cap x 16 bytes each: 0 / 1 scratch of the sorts, 2 stage-1 clusters (kept for VSV_T_CLUSTER1),
                         // 3 stage-2 clusters / pairing reservations, 4 / 5 merged elements (kept for VSV_T_MERGED and the calls)
   int64_t cap;          // elements per buffer (= row capacity of the handle)
-  int64_t rows_hint;    // largest table of the handle's previous run + 25 % (a first run: cap) - speed decisions only
+  int64_t rows_hint, cand_hint;   // signature rows / split candidates of the handle's previous run + 25 % (a first run: cap) - speed decisions only
   uint32_t* hist;       // [1024 * tiles of 4096]
   uint32_t* totals;     // zeroed per-pass digit totals, 2048 entries per slot (SortWork::totals)
   int* pass_cursor;
