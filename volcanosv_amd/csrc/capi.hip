@@ -78,6 +78,8 @@ struct vsv_handle {
   bool dense_pairing = false;      // the last run walked a pairing stretch of thousands of rows with one wave: pair in rounds
   bool in_rerun = false;
   int row_runs = 0;                // > 0: an input met the 32-bit limits of the element path recently: the next runs stay on rows
+  int lsd_slim_runs = 0;           // > 0: a rank-and-merge sort of the element path gave up recently (ERRB_MERGE_FALLBACK): the next runs sort with the LSD passes
+  const void* sl_sorted1 = nullptr; // element path: the sorted stage-1 table (anchors of the sort behind its clusters)
   int64_t reruns = 0;             // whole-run repetitions taken by finish() so far (vsv_rerun_count)
   // large tables (slim_path.hip): element buffers, pairing scratch, what the run in flight left where
   DevBuf sl[6], sl_hj, sl_done;
@@ -326,6 +328,7 @@ int enq_scan(vsv_handle* h) {
   { int rs = reset_run_state(h); if (rs) return rs; }
   if (h->lsd_runs > 0 && !h->in_rerun) --h->lsd_runs;
   if (h->row_runs > 0 && !h->in_rerun) --h->row_runs;
+  if (h->lsd_slim_runs > 0 && !h->in_rerun) --h->lsd_slim_runs;
   h->cutesv_rows = -1;   // the split-candidate table shares a buffer with the merge stage
   const int n_parts = vsv_cigar_parts(h->rv.n_ops, OPS_PER_PART);
   RecView srv = h->rv;
@@ -419,6 +422,9 @@ int slim_work(vsv_handle* h, SlimWork& w) {
   { const Counters& c = h->host_ctr; w.rows_hint = c.n_s1 ? (int64_t)c.n_s1 + c.n_s1 / 4 : h->cap_sigs; w.cand_hint = c.n_cand ? (int64_t)c.n_cand + c.n_cand / 4 : h->cap_sigs; }
   w.cap = h->cap_sigs; w.hist = (uint32_t*)h->hist.p; w.totals = (uint32_t*)h->totals.p; w.pass_cursor = &h->pass_cursor;
   w.grid = ew_grid(h); w.cl = (int32_t*)h->cl.p; w.hj = (uint32_t*)h->sl_hj.p; w.done1 = (uint32_t*)h->sl_done.p;
+  static const char* sort_mode = vsv_dbg_env("VSV_SLIM_SORT");      // tests / timing: "lsd" = the LSD passes for every sort of the element path
+  w.merge_sorts = h->lsd_slim_runs == 0 && !(sort_mode && sort_mode[0] == 'l');
+  w.err = &dctr(h)->err;
   return 0;
 }
 int sort_bits(vsv_handle* h) { return pos_bits(h) + 3 + tid_bits(h); }
@@ -433,7 +439,7 @@ int enq_stage1(vsv_handle* h) {
   if (h->big_run) {
     SlimWork w;
     { int ws = slim_work(h, w); if (ws) return ws; }
-    h->sl_e2 = vsv_slim_stage1(st, (const vsv_sig*)h->s1in.p, &c->n_s1, &c->n_alive1, pos_bits(h), h->rv.tid_lo, slim_tid_bits(h), h->prm.cluster_shift, w, c, h->sl_prebuilt);
+    h->sl_e2 = vsv_slim_stage1(st, (const vsv_sig*)h->s1in.p, &c->n_s1, &c->n_alive1, pos_bits(h), h->rv.tid_lo, slim_tid_bits(h), h->prm.cluster_shift, w, c, h->sl_prebuilt, &h->sl_sorted1);
     h->c1_stale = true;
     HIPCHK(h, hipGetLastError());
     h->stage_done = 3;
@@ -453,7 +459,7 @@ int enq_merge(vsv_handle* h) {
   if (h->big_run) {
     SlimWork w;
     { int ws = slim_work(h, w); if (ws) return ws; }
-    h->sl_m = vsv_slim_merge(st, h->sl_e2, &c->n_alive1, &c->n_alive2, &c->n_alive3, pos_bits(h), slim_tid_bits(h), h->prm.cluster_shift, w);
+    h->sl_m = vsv_slim_merge(st, h->sl_e2, h->sl_sorted1, &c->n_alive1, &c->n_alive2, &c->n_alive3, pos_bits(h), slim_tid_bits(h), h->prm.cluster_shift, w);
     h->merged_stale = true;
     HIPCHK(h, hipGetLastError());
     h->stage_done = 4;
@@ -516,7 +522,7 @@ int finish(vsv_handle* h) {
     fprintf(stderr, "[vsv] n_pool %u n_raw %u n_cand %u n_s1 %u alive %u %u %u calls %u max_stretch %u err %#x pad %u %u %u\n", c.n_pool, c.n_raw, c.n_cand, c.n_s1,
             c.n_alive1, c.n_alive2, c.n_alive3, c.n_calls, c.max_stretch, c.err, c.pad[0], c.pad[1], c.pad[2]);
   }
-  if (e & (ERRB_CLR_FALLBACK | ERRB_SORT_FALLBACK | ERRB_SLIM_FALLBACK)) {
+  if (e & (ERRB_CLR_FALLBACK | ERRB_SORT_FALLBACK | ERRB_SLIM_FALLBACK | ERRB_MERGE_FALLBACK)) {
     // ERRB_CLR_FALLBACK: a part of the read-shaped CLR scan held more chunks than its gate state — nothing that run decided can be
     // trusted; same input again with the gate as a separate pass (this handle keeps that form). ERRB_SORT_FALLBACK: a bucket of
     // the bucket sort did not fit in LDS (tables far from uniform, or much larger than the previous run's) — the stages behind it
@@ -532,6 +538,7 @@ int finish(vsv_handle* h) {
       const uint32_t ee = h->host_ctr.err;
       if (ee & ERRB_CLR_FALLBACK) h->clr_unfused = true;
       else if (ee & ERRB_SLIM_FALLBACK) h->row_runs = 16;       // a length outside [0, 2^30): the same input on rows (64-bit predicates)
+      else if (ee & ERRB_MERGE_FALLBACK) h->lsd_slim_runs = 16; // slots too dense for the windows of the rank-and-merge sorts: the same input through the LSD passes
       else {
         const uint64_t rows_now = h->host_ctr.n_s1 > h->host_ctr.n_cand ? h->host_ctr.n_s1 : h->host_ctr.n_cand;
         stale_hint = rows_now > h->sort_hint_rows + h->sort_hint_rows / 2;

@@ -25,6 +25,10 @@ struct __align__(16) Slim {
 };
 constexpr uint32_t SL_DEL = 0x80000000u;
 constexpr uint32_t SL_ROW = 0x7FFFFFFFu;
+// key bit that carries an element's CLASS from the stage that drops a list bit to the sort behind it (sl_merge_sort below): the value of
+// the dropped bit (source / type / haplotype). Set only when that sort runs as rank-inside-the-class + merge, which clears it again.
+constexpr uint64_t SL_CLASS = 1ull << 62;
+__device__ __forceinline__ uint64_t sl_stash(uint64_t key, uint64_t drop, uint64_t stash) { return (key & ~drop) | ((key & drop) ? stash : 0ull); }
 
 __device__ __forceinline__ Slim ld_slim(const Slim* p) {
   const uint4 v = *reinterpret_cast<const uint4*>(p);
@@ -93,7 +97,7 @@ struct SrcSlim {
 // its mate (1/1: the longer of the two signatures is kept, the hp1 one on ties, H:583-586); an hp2 row is a call iff nobody took
 // it. Key = (tid, pos) of the kept signature; svlen field = the mate's slot; idx = the slot itself.
 struct SrcCalls {
-  const Slim* m; const int32_t* st; int hap_bit;
+  const Slim* m; const int32_t* st; int hap_bit; uint64_t stash;
   __device__ __forceinline__ Slim at(uint32_t i) const {
     const Slim me = ld_slim(m + i);
     const uint64_t hb = 1ull << hap_bit;
@@ -102,7 +106,7 @@ struct SrcCalls {
     const int32_t s = st[i];
     if (me.key & hb) {
       c.svlen = -1;
-      c.key = s == -1 ? (me.key & ~hb) : VSV_KEY_DEAD;
+      c.key = s == -1 ? ((me.key & ~hb) | stash) : VSV_KEY_DEAD;
     } else {
       c.svlen = s;
       uint64_t k = me.key;
@@ -111,6 +115,18 @@ struct SrcCalls {
     }
     return c;
   }
+  // (sl_merge_sort) 0 = no call in this slot, 1 = class A (an hp1 row), 2 = class B (an hp2 row nobody took)
+  __device__ __forceinline__ uint32_t lc(uint32_t i) const {
+    return ((m[i].key >> hap_bit) & 1ull) ? (st[i] == -1 ? 2u : 0u) : 1u;
+  }
+  // ... the call element and the slot's ANCHOR: the slot's own key, which the slots ascend by inside a class (a call's key lies
+  // within pair_shift of it: its own or its mate's)
+  __device__ __forceinline__ Slim at2(uint32_t i, uint64_t& anchor) const {
+    const uint64_t hb = 1ull << hap_bit, k = m[i].key;
+    anchor = (k & ~hb) | ((k & hb) ? SL_CLASS : 0ull);
+    return at(i);
+  }
+  __device__ __forceinline__ uint64_t key2(uint32_t i, uint64_t& anchor) const { return at2(i, anchor).key; }
 };
 
 // The keys of the later stages carry list bits that are zero for every element (source after the first clustering, type after the
@@ -291,7 +307,7 @@ __device__ __forceinline__ void st_i32(int32_t* p, int32_t v) { __hip_atomic_sto
 
 // One wave on a long run [i, e): seeds stay sequential, the scan of a seed's window and the search for the next seed are 64-wide.
 // cl[] (one word per slot) is accessed with agent-scope relaxed atomics. Called by ALL 64 lanes with wave-uniform (i, e).
-__device__ __forceinline__ void sl_cluster_long(const Slim* __restrict__ s, int max_shift, KeyFmt kf, uint64_t drop, int32_t* __restrict__ cl,
+__device__ __forceinline__ void sl_cluster_long(const Slim* __restrict__ s, int max_shift, KeyFmt kf, uint64_t drop, uint64_t stash, int32_t* __restrict__ cl,
                                                 Slim* __restrict__ out, const uint32_t i, const uint32_t e, const int lane) {
   for (uint32_t k = i + lane; k < e; k += 64) st_i32(&cl[k], -1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -318,7 +334,7 @@ __device__ __forceinline__ void sl_cluster_long(const Slim* __restrict__ s, int 
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { const uint64_t o = __shfl_xor(best, d, 64); if (o > best) best = o; }
-    if (lane == 0) { Slim rep = ld_slim(s + (0xFFFFFFFFu - (uint32_t)best)); rep.key &= ~drop; st_slim(out + a, rep); }
+    if (lane == 0) { Slim rep = ld_slim(s + (0xFFFFFFFFu - (uint32_t)best)); rep.key = sl_stash(rep.key, drop, stash); st_slim(out + a, rep); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     uint32_t nxt = e;                            // next seed: first unassigned element after a
     for (uint32_t b0 = a + 1; b0 < e; b0 += 64) {
@@ -339,7 +355,7 @@ __device__ __forceinline__ void sl_cluster_long(const Slim* __restrict__ s, int 
 template <int N>
 __device__ __forceinline__ void sl_cluster_small(const int32_t* __restrict__ l_pos, const int32_t* __restrict__ l_len, const uint32_t* __restrict__ l_lid,
                                                  const uint32_t* __restrict__ l_idx, uint32_t rel0, uint32_t len, uint32_t i, int max_shift, KeyFmt kf, uint64_t drop,
-                                                 Slim* __restrict__ out) {
+                                                 uint64_t stash, Slim* __restrict__ out) {
   int32_t p[N], v[N];
 #pragma unroll
   for (int u = 0; u < N; ++u) { p[u] = l_pos[rel0 + u]; v[u] = l_len[rel0 + u]; }
@@ -360,7 +376,7 @@ __device__ __forceinline__ void sl_cluster_small(const int32_t* __restrict__ l_p
     if ((uint32_t)a < len) {
       Slim r = dead_slim();
       if (seed) {
-        r.key = ((((uint64_t)lid) << kf.pb) | vsv_kpos(l_pos[rel0 + best])) & ~drop;
+        r.key = sl_stash((((uint64_t)lid) << kf.pb) | vsv_kpos(l_pos[rel0 + best]), drop, stash);
         r.svlen = best_len;
         r.idx = l_idx[rel0 + best];
       }
@@ -370,7 +386,7 @@ __device__ __forceinline__ void sl_cluster_small(const int32_t* __restrict__ l_p
 }
 
 __global__ __launch_bounds__(256) void sl_cluster(const Slim* __restrict__ s, const uint32_t* __restrict__ d_n, int max_shift, KeyFmt kf, int drop_bit,
-                                                  Slim* __restrict__ out, int32_t* __restrict__ cl) {
+                                                  uint64_t stash, Slim* __restrict__ out, int32_t* __restrict__ cl) {
   constexpr int LDS_N = CL_TILE + CL_HALO + 1;
   __shared__ int32_t l_pos[LDS_N], l_len[LDS_N];
   __shared__ uint32_t l_lid[LDS_N], l_idx[LDS_N];
@@ -413,11 +429,11 @@ __global__ __launch_bounds__(256) void sl_cluster(const Slim* __restrict__ s, co
     // ---- runs of at most 4 and at most 8 elements: unrolled greedy on registers ----
     for (uint32_t h = threadIdx.x; h < n4; h += 256) {
       const uint32_t w = h4[h], r0 = w & 0xFFFu, len = (w >> 12) + 1u;
-      sl_cluster_small<4>(l_pos, l_len, l_lid, l_idx, r0 + 1u, len, t0 + r0, max_shift, kf, drop, out);
+      sl_cluster_small<4>(l_pos, l_len, l_lid, l_idx, r0 + 1u, len, t0 + r0, max_shift, kf, drop, stash, out);
     }
     for (uint32_t h = threadIdx.x; h < n8; h += 256) {
       const uint32_t w = h8[h], r0 = w & 0xFFFu, len = (w >> 12) + 5u;
-      sl_cluster_small<8>(l_pos, l_len, l_lid, l_idx, r0 + 1u, len, t0 + r0, max_shift, kf, drop, out);
+      sl_cluster_small<8>(l_pos, l_len, l_lid, l_idx, r0 + 1u, len, t0 + r0, max_shift, kf, drop, stash, out);
     }
     // ---- longer runs: the sequential greedy with loops; beyond SL_LONG_RUN elements the lane's whole wave ----
     auto get = [&](uint32_t k) -> Slim {            // element k: from LDS when the block staged it
@@ -475,7 +491,7 @@ __global__ __launch_bounds__(256) void sl_cluster(const Slim* __restrict__ s, co
               }
             }
             Slim rep = best == a ? s1 : get(i + best);
-            rep.key &= ~drop;
+            rep.key = sl_stash(rep.key, drop, stash);
             st_slim(out + i + a, rep);
           }
         }
@@ -484,7 +500,7 @@ __global__ __launch_bounds__(256) void sl_cluster(const Slim* __restrict__ s, co
       while (lm) {
         const int src = __builtin_ctzll(lm);
         lm &= lm - 1;
-        sl_cluster_long(s, max_shift, kf, drop, cl, out, (uint32_t)__shfl((int)i, src, 64), (uint32_t)__shfl((int)e, src, 64), lane);
+        sl_cluster_long(s, max_shift, kf, drop, stash, cl, out, (uint32_t)__shfl((int)i, src, 64), (uint32_t)__shfl((int)e, src, 64), lane);
       }
     }
   }
@@ -1009,6 +1025,250 @@ Slim* sl_sort(hipStream_t st, SRC src, const uint32_t* d_slots, uint32_t* d_live
   return other;        // the buffer the last pass wrote
 }
 
+
+// ---- the sorts behind a stage that drops a list bit: rank inside the class + ONE merge -------------------------------------------
+// Sorts 2 and 3 and the call sort do not meet unordered input. Their slots come in two CLASSES — the value of the key bit the stage
+// in front dropped: source for the merge of the cigar and split lists (H:478-490), type for the final list (H:492-499), haplotype for
+// the calls (H:571-594) — and inside a class the slots are in the order of the sorted table the stage worked on: slot j has an
+// ANCHOR a_j (the key of the stage's input element j, dropped bit cleared) that ascends with j, and the element a slot holds lies
+// within [a_j - dlo, a_j + dhi] (a cluster representative is a later element within cluster_shift of its seed, H:236-247; a call's kept
+// signature is the hp1 row's own or its mate's within pair_shift, H:583-586). So
+//   rank of element i inside its class = live class elements in front of slot i
+//                                        - those of them with a larger key      (only slots j < i with a_j + dhi > K_i can hold one)
+//                                        + those behind it with a smaller key   (only slots j > i with a_j - dlo < K_i),
+// both counted from an LDS window around the tile (anchors and keys of MS_T slots + MS_H on either side), and the two ranked
+// classes — each exactly sorted now, ties in slot order — are merged once (class A first on ties: its slots lie in front of class
+// B's inside every list). Three launches that move the table twice, where the LSD passes take nine and move it six times; the result
+// is the stable sort of the slots by key, bit for bit. Whatever the window cannot decide (a scan that reaches its edge: thousands of
+// slots within one shift) or an element outside its anchor's range raises ERRB_MERGE_FALLBACK: the run repeats on the LSD passes.
+// Keys of at most 31 bits after squeezing (KeyCmp): a single-chromosome shard has 30.
+constexpr int MS_T = 2048, MS_H = 128, MS_W = MS_T + 2 * MS_H, MS_R = MS_W / 256;      // 2304 window slots = 9 rounds of a 256-thread block
+constexpr int MS_MT = 4096;                                                            // outputs per merge tile
+constexpr int MS_GROUP = 64, MS_MAX_GROUPS = 1016;                                     // tile counts are also summed per group of 64 tiles
+struct MsCtl { uint32_t nA, nB, pad[14]; uint32_t grp[MS_MAX_GROUPS][2]; };            // lives in a zeroed per-pass totals slot (2048 words)
+static_assert(sizeof(MsCtl) == 2048 * 4, "one totals slot");
+static_assert(MS_H % 64 == 0 && MS_W % 256 == 0, "window rounds are whole waves");
+
+// a stage-2 / stage-3 sort: the cluster kernel's output slots with the sorted table it worked on as anchors
+struct SrcAnch {
+  const Slim* e; const Slim* anc; uint64_t drop;
+  __device__ __forceinline__ uint32_t lc(uint32_t i) const { const uint64_t k = e[i].key; return k == VSV_KEY_DEAD ? 0u : ((k & SL_CLASS) ? 2u : 1u); }
+  __device__ __forceinline__ Slim at2(uint32_t i, uint64_t& anchor) const { anchor = sl_stash(anc[i].key, drop, SL_CLASS); return ld_slim(e + i); }
+  __device__ __forceinline__ uint64_t key2(uint32_t i, uint64_t& anchor) const { anchor = sl_stash(anc[i].key, drop, SL_CLASS); return e[i].key; }
+  __device__ __forceinline__ Slim at(uint32_t i) const { return ld_slim(e + i); }
+};
+
+// tcnt[2 t + c] = live elements of class c in tile t; ctl->nA / nB += the same (a zeroed slot)
+template <typename SRC>
+__global__ __launch_bounds__(256) void sl_ms_count(SRC src, const uint32_t* __restrict__ d_n, uint32_t* __restrict__ tcnt, MsCtl* __restrict__ ctl) {
+  __shared__ uint32_t cA, cB;
+  const uint32_t n = *d_n, ntiles = (n + MS_T - 1) / MS_T;
+  const int lane = threadIdx.x & 63;
+  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    if (threadIdx.x == 0) { cA = 0; cB = 0; }
+    __syncthreads();
+    uint32_t a = 0, b = 0;
+#pragma unroll
+    for (int k = 0; k < MS_T / 256; ++k) {
+      const uint32_t i = tile * MS_T + k * 256 + threadIdx.x;
+      const uint32_t c = i < n ? src.lc(i) : 0u;
+      a += c == 1u ? 1u : 0u; b += c == 2u ? 1u : 0u;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { a += __shfl_xor(a, d, 64); b += __shfl_xor(b, d, 64); }
+    if (lane == 0) { atomicAdd(&cA, a); atomicAdd(&cB, b); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const uint32_t ta = cA, tb = cB;
+      tcnt[2 * tile] = ta; tcnt[2 * tile + 1] = tb;
+      if (ta) { atomicAdd(&ctl->nA, ta); atomicAdd(&ctl->grp[tile / MS_GROUP][0], ta); }
+      if (tb) { atomicAdd(&ctl->nB, tb); atomicAdd(&ctl->grp[tile / MS_GROUP][1], tb); }
+    }
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ uint32_t sl_wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(v, d, 64); if (lane >= d) v += o; }
+  return v;
+}
+
+// every live element to its rank inside its class: class A at out[0, nA), class B at out[nA, nA + nB)
+template <typename SRC>
+__global__ __launch_bounds__(256) void sl_ms_local(SRC src, const uint32_t* __restrict__ d_n, KeyCmp kc, uint32_t dlo, uint32_t dhi, const uint32_t* __restrict__ tcnt,
+                                                   const MsCtl* __restrict__ ctl, Slim* __restrict__ out, uint32_t* __restrict__ d_live, uint32_t* __restrict__ err) {
+  __shared__ uint32_t la[MS_W], lk[MS_W];          // per window slot: anchor | class << 31 (0xFFFFFFFF outside the table), key (0xFFFFFFFF: no element)
+  __shared__ uint32_t wc[2][64];                   // live elements per (round, wave) and class -> exclusive prefixes
+  __shared__ uint32_t below[2];                    // live elements of the tiles in front
+  const uint32_t n = *d_n, ntiles = (n + MS_T - 1) / MS_T;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t nA = ctl->nA;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *d_live = nA + ctl->nB;
+  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t w0 = (int64_t)tile * MS_T - MS_H;            // slot of window index 0
+    uint32_t myrank[MS_R];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < MS_R; ++r) {               // anchors and keys of the window (the elements themselves are fetched when their rank is known)
+      const uint32_t w = (uint32_t)r * 256u + threadIdx.x;
+      const int64_t slot = w0 + w;
+      uint32_t a = 0xFFFFFFFFu, k = 0xFFFFFFFFu, cls = 0;
+      if (slot >= 0 && slot < (int64_t)n) {
+        uint64_t anc;
+        const uint64_t key = src.key2((uint32_t)slot, anc);
+        cls = (uint32_t)(anc >> 62) & 1u;
+        a = ((uint32_t)kc(anc & ~SL_CLASS) & 0x7FFFFFFFu) | (cls << 31);
+        if (key != VSV_KEY_DEAD) k = (uint32_t)kc(key & ~SL_CLASS) & 0x7FFFFFFFu;
+      }
+      la[w] = a; lk[w] = k;
+      const bool live = k != 0xFFFFFFFFu;
+      const uint64_t mA = __ballot(live && cls == 0u), mB = __ballot(live && cls != 0u);
+      const uint64_t mine = cls ? mB : mA;
+      myrank[r] = __builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
+      if (lane == 0) { wc[0][r * 4 + wv] = (uint32_t)__popcll(mA); wc[1][r * 4 + wv] = (uint32_t)__popcll(mB); }
+    }
+    if (wv == 3) {  // live elements of either class in the tiles in front of this one: whole groups + the tiles of its own group
+      const uint32_t g = tile / MS_GROUP;
+      uint32_t ba = 0, bb = 0;
+      for (uint32_t q = lane; q < g; q += 64) { ba += ctl->grp[q][0]; bb += ctl->grp[q][1]; }
+      const uint32_t t = g * MS_GROUP + (uint32_t)lane;
+      if (t < tile) { const uint2 c = *reinterpret_cast<const uint2*>(tcnt + 2 * (size_t)t); ba += c.x; bb += c.y; }
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) { ba += __shfl_xor(ba, d, 64); bb += __shfl_xor(bb, d, 64); }
+      if (lane == 0) { below[0] = ba; below[1] = bb; }
+    }
+    __syncthreads();
+    if (wv < 2) {                                              // exclusive prefixes over the (round, wave) counts, one wave per class
+      const uint32_t v = lane < MS_R * 4 ? wc[wv][lane] : 0u;
+      const uint32_t incl = sl_wave_incl_scan(v, lane);
+      wc[wv][lane] = incl - v;
+    }
+    __syncthreads();
+    const bool open_left = w0 > 0, open_right = w0 + MS_W < (int64_t)n;      // the table goes on beyond the window
+    const uint32_t base[2] = {below[0] - wc[0][MS_H / 64], below[1] - wc[1][MS_H / 64] + nA};
+    bool trouble = false;
+#pragma unroll
+    for (int r = 0; r < MS_R; ++r) {
+      const uint32_t w = (uint32_t)r * 256u + threadIdx.x;
+      if (w < (uint32_t)MS_H || w >= (uint32_t)(MS_H + MS_T)) continue;      // halo
+      const uint32_t K = lk[w];
+      if (K == 0xFFFFFFFFu) continue;
+      const uint32_t aw = la[w], cls = aw >> 31, A = aw & 0x7FFFFFFFu;
+      if (K + dlo < A || K > A + dhi) trouble = true;                        // not what the caller promised
+      uint32_t back = 0, fwd = 0;
+      for (int j = (int)w - 1;; --j) {
+        if (j < 0) { trouble = trouble || open_left; break; }
+        const uint32_t aj = la[j];
+        if (aj == 0xFFFFFFFFu || (aj >> 31) != cls) break;                   // the table's start / the class's previous list lies in front
+        if ((aj & 0x7FFFFFFFu) + dhi <= K) break;                            // nothing at or in front of j exceeds K
+        const uint32_t kj = lk[j];
+        back += (kj != 0xFFFFFFFFu && kj > K) ? 1u : 0u;
+      }
+      for (int j = (int)w + 1;; ++j) {
+        if (j >= MS_W) { trouble = trouble || open_right; break; }
+        const uint32_t aj = la[j];
+        if (aj == 0xFFFFFFFFu || (aj >> 31) != cls) break;
+        if ((aj & 0x7FFFFFFFu) >= K + dlo) break;                            // nothing at or behind j lies below K
+        const uint32_t kj = lk[j];
+        fwd += (kj != 0xFFFFFFFFu && kj < K) ? 1u : 0u;
+      }
+      const uint32_t rank = (cls ? base[1] : base[0]) + wc[cls][r * 4 + wv] + myrank[r] - back + fwd;
+      st_slim(out + rank, src.at((uint32_t)(w0 + w)));
+    }
+    if (trouble) atomicOr(err, ERRB_MERGE_FALLBACK);
+  }
+}
+
+// the two ranked classes merged: a tile of MS_MT outputs finds its two diagonals by wave-wide 64-ary searches (four dependent rounds
+// over millions of elements), ranks its elements against the other class's keys in LDS and writes them with the class bit cleared
+__device__ __forceinline__ uint32_t sl_ms_key(const Slim* __restrict__ p, KeyCmp kc) { return (uint32_t)kc(p->key & ~SL_CLASS) & 0x7FFFFFFFu; }
+__device__ __forceinline__ uint32_t sl_ms_path(const Slim* __restrict__ A, uint32_t nA, const Slim* __restrict__ B, uint32_t nB, uint32_t d, KeyCmp kc, int lane) {
+  uint32_t lo = d > nB ? d - nB : 0u, hi = d < nA ? d : nA;
+  while (lo < hi) {                                  // a* = elements of A among the first d outputs: A[a] <= B[d - 1 - a] holds for a < a*
+    const uint32_t s = hi - lo, step = (s + 63u) / 64u;
+    const uint32_t p = lo + (uint32_t)lane * step;
+    bool q = false;
+    if (p < hi) q = sl_ms_key(A + p, kc) <= sl_ms_key(B + (d - 1u - p), kc);
+    const uint32_t t = (uint32_t)__popcll(__ballot(q));
+    if (t == 0u) { hi = lo; }
+    else {
+      const uint32_t nlo = lo + (t - 1u) * step + 1u;
+      const uint32_t cand = lo + t * step;
+      hi = (t < 64u && cand < hi) ? cand : hi;
+      lo = nlo;
+    }
+  }
+  return lo;
+}
+__global__ __launch_bounds__(512) void sl_ms_merge(const Slim* __restrict__ tmp, const MsCtl* __restrict__ ctl, KeyCmp kc, Slim* __restrict__ out) {
+  __shared__ uint32_t lkeys[MS_MT];
+  __shared__ uint32_t sh_a[2];
+  const uint32_t nA = ctl->nA, nB = ctl->nB, n = nA + nB;
+  const Slim* A = tmp; const Slim* B = tmp + nA;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t ntiles = (n + MS_MT - 1) / MS_MT;
+  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const uint32_t d0 = tile * MS_MT, d1 = min(n, d0 + MS_MT);
+    __syncthreads();
+    if (wv < 2) {
+      const uint32_t a = sl_ms_path(A, nA, B, nB, wv ? d1 : d0, kc, lane);
+      if (lane == 0) sh_a[wv] = a;
+    }
+    __syncthreads();
+    const uint32_t a0 = sh_a[0], a1 = sh_a[1], b0 = d0 - a0, cA = a1 - a0, cT = d1 - d0;
+    Slim e[MS_MT / 512];
+#pragma unroll
+    for (int k = 0; k < MS_MT / 512; ++k) {
+      const uint32_t c = (uint32_t)k * 512u + threadIdx.x;
+      if (c < cT) {
+        e[k] = ld_slim(c < cA ? A + a0 + c : B + b0 + (c - cA));
+        lkeys[c] = (uint32_t)kc(e[k].key & ~SL_CLASS) & 0x7FFFFFFFu;
+      }
+    }
+    __syncthreads();
+    const uint32_t cB = cT - cA;
+#pragma unroll
+    for (int k = 0; k < MS_MT / 512; ++k) {
+      const uint32_t c = (uint32_t)k * 512u + threadIdx.x;
+      if (c >= cT) continue;
+      const uint32_t K = lkeys[c];
+      uint32_t r;
+      if (c < cA) {                                   // + elements of B below K
+        uint32_t lo = 0, hi = cB;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (lkeys[cA + mid] < K) lo = mid + 1; else hi = mid; }
+        r = c + lo;
+      } else {                                        // + elements of A at or below K
+        uint32_t lo = 0, hi = cA;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (lkeys[mid] <= K) lo = mid + 1; else hi = mid; }
+        r = (c - cA) + lo;
+      }
+      e[k].key &= ~SL_CLASS;
+      st_slim(out + d0 + r, e[k]);
+    }
+  }
+}
+
+bool sl_merge_ok(const SlimWork& w, int nbits, KeyCmp kc) {
+  return w.merge_sorts && nbits - kc.zbits <= 31 && (w.cap + MS_T - 1) / MS_T <= (int64_t)MS_GROUP * MS_MAX_GROUPS;
+}
+
+template <typename SRC>
+Slim* sl_merge_sort(hipStream_t st, SRC src, const uint32_t* d_slots, uint32_t* d_live, KeyCmp kc, uint32_t dlo, uint32_t dhi, Slim* tmp, Slim* out, const SlimWork& w) {
+  MsCtl* ctl = (MsCtl*)(w.totals + (size_t)(*w.pass_cursor) * 2048);
+  ++*w.pass_cursor;
+  const int64_t tiles = (w.cap + MS_T - 1) / MS_T, mtiles = (w.cap + MS_MT - 1) / MS_MT;
+  const int64_t hint_tiles = (w.rows_hint + MS_T - 1) / MS_T;
+  const int64_t want = hint_tiles < tiles ? hint_tiles : tiles;
+  const int gc = (int)(want < 1 ? 1 : (want > 1024 ? 1024 : want));
+  const int gl = (int)(tiles < 1 ? 1 : (tiles > 8192 ? 8192 : tiles));
+  const int gm = (int)(mtiles < 1 ? 1 : (mtiles > 4096 ? 4096 : mtiles));
+  sl_ms_count<<<gc, 256, 0, st>>>(src, d_slots, w.hist, ctl);
+  sl_ms_local<<<gl, 256, 0, st>>>(src, d_slots, kc, dlo, dhi, w.hist, ctl, tmp, d_live, w.err);
+  sl_ms_merge<<<gm, 512, 0, st>>>(tmp, ctl, kc, out);
+  return out;
+}
+
 }  // namespace
 
 // ================================================== entry points (capi.hip) ==================================================
@@ -1016,25 +1276,36 @@ int vsv_slim_sort_passes(int nbits) { return (nbits + 7) / 8; }     // (upper bo
 
 // stage 1: rows -> elements, sort by (tid, hap, type, source, pos), cluster per list. Returns the cluster output (slots = *d_alive1).
 void* vsv_slim_stage1(hipStream_t st, const vsv_sig* s1in, const uint32_t* d_n_s1, uint32_t* d_alive1, int pb, int tid_lo, int tid_bits, int cluster_shift,
-                      const SlimWork& w, Counters* ctr, bool prebuilt) {
+                      const SlimWork& w, Counters* ctr, bool prebuilt, const void** sorted1) {
   Slim* b0 = (Slim*)w.buf[0]; Slim* b1 = (Slim*)w.buf[1]; Slim* e2 = (Slim*)w.buf[2];
   // (a fused run has the elements already: fold_kernel / split_eval wrote them next to the rows, vsv_slim_emit)
   if (!prebuilt) sl_from_rows<<<w.grid, 256, 0, st>>>(s1in, d_n_s1, pb, tid_lo, tid_bits, b0, &ctr->err);
   Slim* sorted = sl_sort(st, SrcSlim{b0}, d_n_s1, d_alive1, pb + 3 + tid_bits, KeyCmp{0, 0}, b1, b0, w, w.rows_hint);
   const int64_t tiles = (w.cap + CL_TILE - 1) / CL_TILE;
-  sl_cluster<<<(int)(tiles < 4096 ? (tiles < 1 ? 1 : tiles) : 4096), 256, 0, st>>>(sorted, d_alive1, cluster_shift, KeyFmt{pb}, pb, e2, w.cl);
+  const bool ms = sl_merge_ok(w, pb + 3 + tid_bits, KeyCmp{pb, 1});       // the sort behind these clusters: rank + merge (sl_merge_sort)
+  sl_cluster<<<(int)(tiles < 4096 ? (tiles < 1 ? 1 : tiles) : 4096), 256, 0, st>>>(sorted, d_alive1, cluster_shift, KeyFmt{pb}, pb, ms ? SL_CLASS : 0ull, e2, w.cl);
+  *sorted1 = sorted;         // (the anchors of that sort: stays in scratch buffer 0 / 1 until vsv_slim_merge has run)
   return e2;
 }
 
 // merge_all: sort the stage-1 representatives by (tid, hap, type, pos), cluster, sort by (tid, hap, pos). Returns the merged elements.
-void* vsv_slim_merge(hipStream_t st, const void* e2, const uint32_t* d_alive1, uint32_t* d_alive2, uint32_t* d_alive3, int pb, int tid_bits,
+void* vsv_slim_merge(hipStream_t st, const void* e2, const void* sorted1, const uint32_t* d_alive1, uint32_t* d_alive2, uint32_t* d_alive3, int pb, int tid_bits,
                      int cluster_shift, const SlimWork& w) {
   Slim* b0 = (Slim*)w.buf[0]; Slim* b1 = (Slim*)w.buf[1]; Slim* e3 = (Slim*)w.buf[3]; Slim* m0 = (Slim*)w.buf[4]; Slim* m1 = (Slim*)w.buf[5];
-  Slim* s2 = sl_sort(st, SrcSlim{(const Slim*)e2}, d_alive1, d_alive2, pb + 3 + tid_bits, KeyCmp{pb, 1}, b0, b1, w, w.rows_hint);
+  const int nbits = pb + 3 + tid_bits;
   const int64_t tiles = (w.cap + CL_TILE - 1) / CL_TILE;
-  sl_cluster<<<(int)(tiles < 4096 ? (tiles < 1 ? 1 : tiles) : 4096), 256, 0, st>>>(s2, d_alive2, cluster_shift, KeyFmt{pb}, pb + 1, e3, w.cl);
+  const int cgrid = (int)(tiles < 4096 ? (tiles < 1 ? 1 : tiles) : 4096);
+  if (sl_merge_ok(w, nbits, KeyCmp{pb, 1})) {
+    // classes by source / by type; anchors = the table the clusters were cut from; a representative lies at or behind its seed
+    Slim* free01 = (const Slim*)sorted1 == b0 ? b1 : b0;
+    Slim* s2 = sl_merge_sort(st, SrcAnch{(const Slim*)e2, (const Slim*)sorted1, 1ull << pb}, d_alive1, d_alive2, KeyCmp{pb, 1}, 0u, (uint32_t)cluster_shift, free01, m0, w);
+    sl_cluster<<<cgrid, 256, 0, st>>>(s2, d_alive2, cluster_shift, KeyFmt{pb}, pb + 1, SL_CLASS, e3, w.cl);
+    return sl_merge_sort(st, SrcAnch{e3, s2, 1ull << (pb + 1)}, d_alive2, d_alive3, KeyCmp{pb, 2}, 0u, (uint32_t)cluster_shift, b0, m1, w);
+  }
+  Slim* s2 = sl_sort(st, SrcSlim{(const Slim*)e2}, d_alive1, d_alive2, nbits, KeyCmp{pb, 1}, b0, b1, w, w.rows_hint);
+  sl_cluster<<<cgrid, 256, 0, st>>>(s2, d_alive2, cluster_shift, KeyFmt{pb}, pb + 1, 0ull, e3, w.cl);
   // the result must outlive the pairing stage and the readback: it lands in one of the two buffers reserved for it
-  return sl_sort(st, SrcSlim{e3}, d_alive2, d_alive3, pb + 3 + tid_bits, KeyCmp{pb, 2}, m0, m1, w, w.rows_hint);
+  return sl_sort(st, SrcSlim{e3}, d_alive2, d_alive3, nbits, KeyCmp{pb, 2}, m0, m1, w, w.rows_hint);
 }
 
 // pair_sig + the final order: pairing state in w.cl, call elements sorted by (tid, pos), call rows gathered from s1in
@@ -1059,7 +1330,10 @@ void vsv_slim_pair(hipStream_t st, const void* merged, const uint32_t* d_alive3,
     const int64_t wins = (w.cap + QW - 1) / QW;
     sl_pair_lds<<<(int)(wins < 32768 ? (wins < 1 ? 1 : wins) : 32768), 64, 0, st>>>(m, d_alive3, kf, pair_shift, right, w.cl, w.hj, &ctr->max_stretch);
   }
-  Slim* cs = sl_sort(st, SrcCalls{m, w.cl, pb + 2}, d_alive3, d_ncalls, pb + 3 + tid_bits, KeyCmp{pb, 3}, b0, b1, w, w.rows_hint);
+  // the call sort: classes by haplotype, anchors = the merged slots' own keys, a call's key within pair_shift of its slot's either way
+  Slim* cs = sl_merge_ok(w, pb + 3 + tid_bits, KeyCmp{pb, 3})
+      ? sl_merge_sort(st, SrcCalls{m, w.cl, pb + 2, SL_CLASS}, d_alive3, d_ncalls, KeyCmp{pb, 3}, (uint32_t)pair_shift, (uint32_t)pair_shift, b0, b1, w)
+      : sl_sort(st, SrcCalls{m, w.cl, pb + 2, 0ull}, d_alive3, d_ncalls, pb + 3 + tid_bits, KeyCmp{pb, 3}, b0, b1, w, w.rows_hint);
   sl_calls_out<<<w.grid, 256, 0, st>>>(cs, d_ncalls, m, pb + 2, s1in, calls);
 }
 

@@ -21,6 +21,7 @@ enum : uint32_t {
   ERRB_SEQLEN = 1u << 8,         // a walked record carries VSV_F_SEQ_MISMATCH (H:397-398)
   ERRB_CLR_FALLBACK = 1u << 9,   // a part too long for the gate state of the fused CLR scan: the run is repeated with the separate gate pass
   ERRB_SORT_FALLBACK = 1u << 7,  // a bucket of the bucket sort did not fit in LDS: the run is repeated with the LSD passes
+  ERRB_MERGE_FALLBACK = 1u << 11, // a rank-and-merge sort of the element path met a window it cannot decide (thousands of slots within one shift): the run is repeated with the LSD passes
   ERRB_SLIM_FALLBACK = 1u << 10, // an svlen outside [0, 2^30) or a position of 2^30 and more met the element path (32-bit predicates): the run is repeated on rows
 };
 
@@ -215,11 +216,13 @@ struct SlimWork {
   int32_t* cl;          // one word per slot: long-run cluster state, then the pairing state
   uint32_t* hj;         // pairing: first candidate of every hp1 row | stretch-start flag
   uint32_t* done1;      // pairing in rounds: decided flags
+  bool merge_sorts;     // sorts 2 / 3 / calls as rank-inside-the-class + merge (sl_merge_sort); false: the LSD passes
+  uint32_t* err;        // device error word (ERRB_MERGE_FALLBACK)
 };
 int vsv_slim_sort_passes(int nbits);
 void* vsv_slim_stage1(hipStream_t st, const vsv_sig* s1in, const uint32_t* d_n_s1, uint32_t* d_alive1, int pb, int tid_lo, int tid_bits, int cluster_shift,
-                      const SlimWork& w, Counters* ctr, bool prebuilt);
-void* vsv_slim_merge(hipStream_t st, const void* e2, const uint32_t* d_alive1, uint32_t* d_alive2, uint32_t* d_alive3, int pb, int tid_bits, int cluster_shift,
+                      const SlimWork& w, Counters* ctr, bool prebuilt, const void** sorted1);
+void* vsv_slim_merge(hipStream_t st, const void* e2, const void* sorted1, const uint32_t* d_alive1, uint32_t* d_alive2, uint32_t* d_alive3, int pb, int tid_bits, int cluster_shift,
                      const SlimWork& w);
 void vsv_slim_pair(hipStream_t st, const void* merged, const uint32_t* d_alive3, uint32_t* d_ncalls, int pb, int tid_bits, int pair_shift, int pair_window,
                    const vsv_sig* s1in, vsv_call* calls, bool dense, const SlimWork& w, Counters* ctr);
