@@ -1117,20 +1117,62 @@ def test_element_path_falls_back_to_rows_beyond_its_32_bit_limits():
     assert r.stdout.strip().splitlines()[-1].split()[1:] == ["1", "1"]
 
 
-def test_element_path_on_the_parity_cases():
+@pytest.mark.parametrize("slim_sort", ["merge", "lsd"])
+def test_element_path_on_the_parity_cases(slim_sort):
     """Tables of more than ~1.3 M rows run their sort / cluster / merge / pair stages on 16-byte elements (csrc/slim_path.hip); the
     handle picks the path from the row counts of its previous run, so the small parity cases above never reach it. VSV_BIG=1 forces it
     for every size: the golden fixtures, the synthetic shapes, multi-chromosome inputs, the key hints, the three fuzz families and the
     dense piles go through it in ONE child process (the same assertions against the oracle and the reference's outputs). On that path
-    the split stage of read-shaped input works per candidate (cand_info / split_eval_info, csrc/sig_stages.hip) instead of per pair."""
+    the split stage of read-shaped input works per candidate (cand_info / split_eval_info, csrc/sig_stages.hip) instead of per pair.
+    Twice: with the sorts behind the clusterings and the pairing as rank-inside-the-class + merge (sl_merge_sort, the default: keys of up
+    to 31 bits, anything its windows cannot decide repeats on the passes), and with the LSD passes for every sort (VSV_SLIM_SORT=lsd)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sel = ("golden_contig or golden_reads or synthetic_vs_oracle or multi_tid or tid_hint or random_small or dense_runs or config4_shape or clr_gate or "
            "split_overlap or edge_cases or unaligned_device_views")
+    env = dict(os.environ, VSV_DEBUG="1", VSV_BIG="1")
+    if slim_sort == "lsd":
+        env["VSV_SLIM_SORT"] = "lsd"
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu", "-k", sel,
-                        "-p", "no:cacheprovider"], capture_output=True, text=True, timeout=800, env=dict(os.environ, VSV_DEBUG="1", VSV_BIG="1"), cwd=root)
+                        "-p", "no:cacheprovider"], capture_output=True, text=True, timeout=800, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1500:]
     tail = r.stdout.strip().splitlines()[-1]
     assert " passed" in tail and "failed" not in tail and int(tail.split(" passed")[0].split()[-1]) >= 25, tail
+
+
+def test_rank_and_merge_sort_gives_up_on_a_pile_inside_one_shift():
+    """sl_merge_sort ranks an element against the slots whose anchors lie within one shift of its key, from an LDS window of 2048 + 2 x 128
+    slots. 8000 reads whose insertions all start within 90 bp — one cluster per haplotype whose representative (the first longest
+    member, H:236-247) lies 89 bp behind its seed, with thousands of slots in between — is more than a window can decide: the run
+    raises ERRB_MERGE_FALLBACK and repeats on the LSD passes (one repetition; the handle then stays on the passes for a while). Tables
+    equal the oracle's either way."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "from test_gpu_parity import oracle_run, assert_tables_equal\n"
+            "from volcanosv_amd.soa import RecordSoA\n"
+            "from volcanosv_amd.engine import Engine, default_params\n"
+            "from volcanosv_amd.abi import DTYPE_HIFI\n"
+            "recs = [(0, 1000, 'q%%d_hp%%d' %% (i, 1 + i %% 2), 60, False, [(0, 100 + (i // 2) %% 90), (1, 150 if (i // 2) %% 90 == 89 else 100), (0, 2000)]) for i in range(8000)]\n"
+            "recs += [(0, 50000 + 700 * i, 'r%%d_hp%%d' %% (i, 1 + i %% 2), 60, False, [(0, 300), (2, 60 + i %% 5), (0, 300)]) for i in range(300)]\n"
+            "soa = RecordSoA.from_tuples(recs)\n"
+            "soa.max_pos = 1 << 20\n"
+            "p = default_params(DTYPE_HIFI)\n"
+            "st, want = oracle_run(soa, DTYPE_HIFI, p)\n"
+            "assert st == 0 and len(want['calls']) > 100\n"
+            "with Engine(0) as e:\n"
+            "    e.run(soa, p)\n"
+            "    got = e.tables(DTYPE_HIFI)\n"
+            "    assert_tables_equal(got, want, list(got.keys()))\n"
+            "    n = e.rerun_count()\n"
+            "    e.run(soa, p)\n"
+            "    assert_tables_equal(e.tables(DTYPE_HIFI), want, list(got.keys()))\n"
+            "    print('MERGE_FALLBACK_OK', n, e.rerun_count())\n") % (root, os.path.join(root, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, VSV_DEBUG="1", VSV_BIG="1"), cwd=root)
+    assert r.returncode == 0 and "MERGE_FALLBACK_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+    assert r.stdout.strip().splitlines()[-1].split()[1:] == ["1", "1"]

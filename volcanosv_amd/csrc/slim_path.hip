@@ -1101,13 +1101,13 @@ __global__ __launch_bounds__(256) void sl_ms_local(SRC src, const uint32_t* __re
   __shared__ uint32_t la[MS_W], lk[MS_W];          // per window slot: anchor | class << 31 (0xFFFFFFFF outside the table), key (0xFFFFFFFF: no element)
   __shared__ uint32_t wc[2][64];                   // live elements per (round, wave) and class -> exclusive prefixes
   __shared__ uint32_t below[2];                    // live elements of the tiles in front
+  __shared__ uint8_t lr[MS_W];                     // live elements of the slot's class in front of it in its wave
   const uint32_t n = *d_n, ntiles = (n + MS_T - 1) / MS_T;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t nA = ctl->nA;
   if (blockIdx.x == 0 && threadIdx.x == 0) *d_live = nA + ctl->nB;
   for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t w0 = (int64_t)tile * MS_T - MS_H;            // slot of window index 0
-    uint32_t myrank[MS_R];
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < MS_R; ++r) {               // anchors and keys of the window (the elements themselves are fetched when their rank is known)
@@ -1125,7 +1125,7 @@ __global__ __launch_bounds__(256) void sl_ms_local(SRC src, const uint32_t* __re
       const bool live = k != 0xFFFFFFFFu;
       const uint64_t mA = __ballot(live && cls == 0u), mB = __ballot(live && cls != 0u);
       const uint64_t mine = cls ? mB : mA;
-      myrank[r] = __builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
+      lr[w] = (uint8_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
       if (lane == 0) { wc[0][r * 4 + wv] = (uint32_t)__popcll(mA); wc[1][r * 4 + wv] = (uint32_t)__popcll(mB); }
     }
     if (wv == 3) {  // live elements of either class in the tiles in front of this one: whole groups + the tiles of its own group
@@ -1148,13 +1148,13 @@ __global__ __launch_bounds__(256) void sl_ms_local(SRC src, const uint32_t* __re
     const bool open_left = w0 > 0, open_right = w0 + MS_W < (int64_t)n;      // the table goes on beyond the window
     const uint32_t base[2] = {below[0] - wc[0][MS_H / 64], below[1] - wc[1][MS_H / 64] + nA};
     bool trouble = false;
-#pragma unroll
-    for (int r = 0; r < MS_R; ++r) {
+#pragma unroll 1
+    for (int r = 0; r < MS_R; ++r) {               // (a rolled loop of per-lane work: nine copies of the two scans cost the kernel half of its wave slots)
       const uint32_t w = (uint32_t)r * 256u + threadIdx.x;
-      if (w < (uint32_t)MS_H || w >= (uint32_t)(MS_H + MS_T)) continue;      // halo
+      if (w < (uint32_t)MS_H || w >= (uint32_t)(MS_H + MS_T)) continue;                        // halo
       const uint32_t K = lk[w];
-      if (K == 0xFFFFFFFFu) continue;
-      const uint32_t aw = la[w], cls = aw >> 31, A = aw & 0x7FFFFFFFu;
+      if (K == 0xFFFFFFFFu) continue;                                                          // no element
+      const uint32_t aw = la[w], cls = aw >> 31, A = aw & 0x7FFFFFFFu, myrank = lr[w];
       if (K + dlo < A || K > A + dhi) trouble = true;                        // not what the caller promised
       uint32_t back = 0, fwd = 0;
       for (int j = (int)w - 1;; --j) {
@@ -1173,7 +1173,7 @@ __global__ __launch_bounds__(256) void sl_ms_local(SRC src, const uint32_t* __re
         const uint32_t kj = lk[j];
         fwd += (kj != 0xFFFFFFFFu && kj < K) ? 1u : 0u;
       }
-      const uint32_t rank = (cls ? base[1] : base[0]) + wc[cls][r * 4 + wv] + myrank[r] - back + fwd;
+      const uint32_t rank = (cls ? base[1] : base[0]) + wc[cls][r * 4 + wv] + myrank - back + fwd;
       st_slim(out + rank, src.at((uint32_t)(w0 + w)));
     }
     if (trouble) atomicOr(err, ERRB_MERGE_FALLBACK);
