@@ -29,6 +29,23 @@ constexpr uint32_t SL_ROW = 0x7FFFFFFFu;
 // the dropped bit (source / type / haplotype). Set only when that sort runs as rank-inside-the-class + merge, which clears it again.
 constexpr uint64_t SL_CLASS = 1ull << 62;
 __device__ __forceinline__ uint64_t sl_stash(uint64_t key, uint64_t drop, uint64_t stash) { return (key & ~drop) | ((key & drop) ? stash : 0ull); }
+// geometry of that sort (sl_merge_sort, further down; the cluster kernel counts its live outputs per tile for it)
+constexpr int MS_T = 2048, MS_H = 128, MS_W = MS_T + 2 * MS_H, MS_R = MS_W / 256;      // 2304 window slots = 9 rounds of a 256-thread block
+constexpr int MS_MT = 4096;                                                            // outputs per merge tile
+constexpr int MS_GROUP = 64, MS_MAX_GROUPS = 1016;                                     // tile counts are also summed per group of 64 tiles
+struct MsCtl { uint32_t nA, nB, pad[14]; uint32_t grp[MS_MAX_GROUPS][2]; };            // lives in a zeroed per-pass totals slot (2048 words)
+static_assert(sizeof(MsCtl) == 2048 * 4, "one totals slot");
+static_assert(MS_H % 64 == 0 && MS_W % 256 == 0, "window rounds are whole waves");
+
+// per-tile counts of a producer's live outputs: tcnt[2 tile + class], the group sums and class totals of ctl (all zeroed beforehand)
+struct MsCount {
+  uint32_t* tcnt; MsCtl* ctl;
+  __device__ __forceinline__ void add(uint32_t tile, uint32_t cls, uint32_t v) const {
+    atomicAdd(&tcnt[2 * tile + cls], v);
+    atomicAdd(&ctl->grp[tile / MS_GROUP][cls], v);
+    atomicAdd(cls ? &ctl->nB : &ctl->nA, v);
+  }
+};
 
 __device__ __forceinline__ Slim ld_slim(const Slim* p) {
   const uint4 v = *reinterpret_cast<const uint4*>(p);
@@ -308,7 +325,7 @@ __device__ __forceinline__ void st_i32(int32_t* p, int32_t v) { __hip_atomic_sto
 // One wave on a long run [i, e): seeds stay sequential, the scan of a seed's window and the search for the next seed are 64-wide.
 // cl[] (one word per slot) is accessed with agent-scope relaxed atomics. Called by ALL 64 lanes with wave-uniform (i, e).
 __device__ __forceinline__ void sl_cluster_long(const Slim* __restrict__ s, int max_shift, KeyFmt kf, uint64_t drop, uint64_t stash, int32_t* __restrict__ cl,
-                                                Slim* __restrict__ out, const uint32_t i, const uint32_t e, const int lane) {
+                                                Slim* __restrict__ out, const uint32_t i, const uint32_t e, const int lane, MsCount mc) {
   for (uint32_t k = i + lane; k < e; k += 64) st_i32(&cl[k], -1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   uint32_t a = i;
@@ -334,7 +351,10 @@ __device__ __forceinline__ void sl_cluster_long(const Slim* __restrict__ s, int 
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { const uint64_t o = __shfl_xor(best, d, 64); if (o > best) best = o; }
-    if (lane == 0) { Slim rep = ld_slim(s + (0xFFFFFFFFu - (uint32_t)best)); rep.key = sl_stash(rep.key, drop, stash); st_slim(out + a, rep); }
+    if (lane == 0) {
+      Slim rep = ld_slim(s + (0xFFFFFFFFu - (uint32_t)best)); rep.key = sl_stash(rep.key, drop, stash); st_slim(out + a, rep);
+      if (mc.tcnt) mc.add(a / (uint32_t)MS_T, (rep.key & SL_CLASS) ? 1u : 0u, 1u);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     uint32_t nxt = e;                            // next seed: first unassigned element after a
     for (uint32_t b0 = a + 1; b0 < e; b0 += 64) {
@@ -355,7 +375,7 @@ __device__ __forceinline__ void sl_cluster_long(const Slim* __restrict__ s, int 
 template <int N>
 __device__ __forceinline__ void sl_cluster_small(const int32_t* __restrict__ l_pos, const int32_t* __restrict__ l_len, const uint32_t* __restrict__ l_lid,
                                                  const uint32_t* __restrict__ l_idx, uint32_t rel0, uint32_t len, uint32_t i, int max_shift, KeyFmt kf, uint64_t drop,
-                                                 uint64_t stash, Slim* __restrict__ out) {
+                                                 uint64_t stash, Slim* __restrict__ out, uint32_t tb, uint32_t (&cn)[4]) {
   int32_t p[N], v[N];
 #pragma unroll
   for (int u = 0; u < N; ++u) { p[u] = l_pos[rel0 + u]; v[u] = l_len[rel0 + u]; }
@@ -379,6 +399,9 @@ __device__ __forceinline__ void sl_cluster_small(const int32_t* __restrict__ l_p
         r.key = sl_stash((((uint64_t)lid) << kf.pb) | vsv_kpos(l_pos[rel0 + best]), drop, stash);
         r.svlen = best_len;
         r.idx = l_idx[rel0 + best];
+        const uint32_t d = ((i + (uint32_t)a) / (uint32_t)MS_T) - tb, cb = (r.key & SL_CLASS) ? 1u : 0u;     // (a run of <= 8 slots ends in this tile or the next)
+        cn[0] += (d == 0u && cb == 0u) ? 1u : 0u; cn[1] += (d == 0u && cb != 0u) ? 1u : 0u;
+        cn[2] += (d != 0u && cb == 0u) ? 1u : 0u; cn[3] += (d != 0u && cb != 0u) ? 1u : 0u;
       }
       st_slim(out + i + a, r);
     }
@@ -386,8 +409,9 @@ __device__ __forceinline__ void sl_cluster_small(const int32_t* __restrict__ l_p
 }
 
 __global__ __launch_bounds__(256) void sl_cluster(const Slim* __restrict__ s, const uint32_t* __restrict__ d_n, int max_shift, KeyFmt kf, int drop_bit,
-                                                  uint64_t stash, Slim* __restrict__ out, int32_t* __restrict__ cl) {
+                                                  uint64_t stash, Slim* __restrict__ out, int32_t* __restrict__ cl, MsCount mc) {
   constexpr int LDS_N = CL_TILE + CL_HALO + 1;
+  __shared__ uint32_t lcnt[4];                                    // live outputs of this tile's runs: [this sort tile | the next][class]
   __shared__ int32_t l_pos[LDS_N], l_len[LDS_N];
   __shared__ uint32_t l_lid[LDS_N], l_idx[LDS_N];
   __shared__ uint16_t h4[CL_TILE], h8[CL_TILE], hx[CL_TILE];      // run heads (tile-relative slot) by class
@@ -400,6 +424,9 @@ __global__ __launch_bounds__(256) void sl_cluster(const Slim* __restrict__ s, co
     const uint32_t t0 = tile * CL_TILE;
     __syncthreads();
     if (threadIdx.x == 0) { n4 = 0; n8 = 0; nx = 0; }
+    if (threadIdx.x < 4) lcnt[threadIdx.x] = 0;
+    const uint32_t tb = t0 / (uint32_t)MS_T;
+    uint32_t cn[4] = {0, 0, 0, 0};
     for (int k = threadIdx.x; k < LDS_N; k += 256) {          // LDS index k = slot t0 - 1 + k
       const int64_t slot = (int64_t)t0 - 1 + k;
       if (slot >= 0 && slot < (int64_t)n) {
@@ -429,11 +456,11 @@ __global__ __launch_bounds__(256) void sl_cluster(const Slim* __restrict__ s, co
     // ---- runs of at most 4 and at most 8 elements: unrolled greedy on registers ----
     for (uint32_t h = threadIdx.x; h < n4; h += 256) {
       const uint32_t w = h4[h], r0 = w & 0xFFFu, len = (w >> 12) + 1u;
-      sl_cluster_small<4>(l_pos, l_len, l_lid, l_idx, r0 + 1u, len, t0 + r0, max_shift, kf, drop, stash, out);
+      sl_cluster_small<4>(l_pos, l_len, l_lid, l_idx, r0 + 1u, len, t0 + r0, max_shift, kf, drop, stash, out, tb, cn);
     }
     for (uint32_t h = threadIdx.x; h < n8; h += 256) {
       const uint32_t w = h8[h], r0 = w & 0xFFFu, len = (w >> 12) + 5u;
-      sl_cluster_small<8>(l_pos, l_len, l_lid, l_idx, r0 + 1u, len, t0 + r0, max_shift, kf, drop, stash, out);
+      sl_cluster_small<8>(l_pos, l_len, l_lid, l_idx, r0 + 1u, len, t0 + r0, max_shift, kf, drop, stash, out, tb, cn);
     }
     // ---- longer runs: the sequential greedy with loops; beyond SL_LONG_RUN elements the lane's whole wave ----
     auto get = [&](uint32_t k) -> Slim {            // element k: from LDS when the block staged it
@@ -493,6 +520,11 @@ __global__ __launch_bounds__(256) void sl_cluster(const Slim* __restrict__ s, co
             Slim rep = best == a ? s1 : get(i + best);
             rep.key = sl_stash(rep.key, drop, stash);
             st_slim(out + i + a, rep);
+            {
+              const uint32_t d = (i + a) / (uint32_t)MS_T - tb, cb = (rep.key & SL_CLASS) ? 1u : 0u;     // (at most SL_LONG_RUN slots behind the tile)
+              cn[0] += (d == 0u && cb == 0u) ? 1u : 0u; cn[1] += (d == 0u && cb != 0u) ? 1u : 0u;
+              cn[2] += (d != 0u && cb == 0u) ? 1u : 0u; cn[3] += (d != 0u && cb != 0u) ? 1u : 0u;
+            }
           }
         }
       }
@@ -500,8 +532,19 @@ __global__ __launch_bounds__(256) void sl_cluster(const Slim* __restrict__ s, co
       while (lm) {
         const int src = __builtin_ctzll(lm);
         lm &= lm - 1;
-        sl_cluster_long(s, max_shift, kf, drop, stash, cl, out, (uint32_t)__shfl((int)i, src, 64), (uint32_t)__shfl((int)e, src, 64), lane);
+        sl_cluster_long(s, max_shift, kf, drop, stash, cl, out, (uint32_t)__shfl((int)i, src, 64), (uint32_t)__shfl((int)e, src, 64), lane, mc);
       }
+    }
+    if (mc.tcnt) {                                                // (block-uniform)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        uint32_t v = cn[q];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+        if (lane == 0 && v) atomicAdd(&lcnt[q], v);
+      }
+      __syncthreads();
+      if (threadIdx.x < 4 && lcnt[threadIdx.x]) mc.add(tb + (threadIdx.x >> 1), threadIdx.x & 1u, lcnt[threadIdx.x]);
     }
   }
 }
@@ -1042,13 +1085,6 @@ Slim* sl_sort(hipStream_t st, SRC src, const uint32_t* d_slots, uint32_t* d_live
 // is the stable sort of the slots by key, bit for bit. Whatever the window cannot decide (a scan that reaches its edge: thousands of
 // slots within one shift) or an element outside its anchor's range raises ERRB_MERGE_FALLBACK: the run repeats on the LSD passes.
 // Keys of at most 31 bits after squeezing (KeyCmp): a single-chromosome shard has 30.
-constexpr int MS_T = 2048, MS_H = 128, MS_W = MS_T + 2 * MS_H, MS_R = MS_W / 256;      // 2304 window slots = 9 rounds of a 256-thread block
-constexpr int MS_MT = 4096;                                                            // outputs per merge tile
-constexpr int MS_GROUP = 64, MS_MAX_GROUPS = 1016;                                     // tile counts are also summed per group of 64 tiles
-struct MsCtl { uint32_t nA, nB, pad[14]; uint32_t grp[MS_MAX_GROUPS][2]; };            // lives in a zeroed per-pass totals slot (2048 words)
-static_assert(sizeof(MsCtl) == 2048 * 4, "one totals slot");
-static_assert(MS_H % 64 == 0 && MS_W % 256 == 0, "window rounds are whole waves");
-
 // a stage-2 / stage-3 sort: the cluster kernel's output slots with the sorted table it worked on as anchors
 struct SrcAnch {
   const Slim* e; const Slim* anc; uint64_t drop;
@@ -1253,17 +1289,24 @@ bool sl_merge_ok(const SlimWork& w, int nbits, KeyCmp kc) {
   return w.merge_sorts && nbits - kc.zbits <= 31 && (w.cap + MS_T - 1) / MS_T <= (int64_t)MS_GROUP * MS_MAX_GROUPS;
 }
 
-template <typename SRC>
-Slim* sl_merge_sort(hipStream_t st, SRC src, const uint32_t* d_slots, uint32_t* d_live, KeyCmp kc, uint32_t dlo, uint32_t dhi, Slim* tmp, Slim* out, const SlimWork& w) {
+// a zeroed control slot for one such sort; `counted`: the tile counts are zeroed too, for a producer that counts its own outputs (sl_cluster)
+MsCtl* sl_ms_begin(hipStream_t st, const SlimWork& w, bool counted) {
   MsCtl* ctl = (MsCtl*)(w.totals + (size_t)(*w.pass_cursor) * 2048);
   ++*w.pass_cursor;
+  if (counted) (void)hipMemsetAsync(w.hist, 0, (size_t)((w.cap + MS_T - 1) / MS_T) * 2 * sizeof(uint32_t), st);
+  return ctl;
+}
+template <typename SRC>
+Slim* sl_merge_sort(hipStream_t st, SRC src, const uint32_t* d_slots, uint32_t* d_live, KeyCmp kc, uint32_t dlo, uint32_t dhi, Slim* tmp, Slim* out, const SlimWork& w,
+                    MsCtl* counted) {
+  MsCtl* ctl = counted ? counted : sl_ms_begin(st, w, false);
   const int64_t tiles = (w.cap + MS_T - 1) / MS_T, mtiles = (w.cap + MS_MT - 1) / MS_MT;
   const int64_t hint_tiles = (w.rows_hint + MS_T - 1) / MS_T;
   const int64_t want = hint_tiles < tiles ? hint_tiles : tiles;
   const int gc = (int)(want < 1 ? 1 : (want > 1024 ? 1024 : want));
   const int gl = (int)(tiles < 1 ? 1 : (tiles > 8192 ? 8192 : tiles));
   const int gm = (int)(mtiles < 1 ? 1 : (mtiles > 4096 ? 4096 : mtiles));
-  sl_ms_count<<<gc, 256, 0, st>>>(src, d_slots, w.hist, ctl);
+  if (!counted) sl_ms_count<<<gc, 256, 0, st>>>(src, d_slots, w.hist, ctl);
   sl_ms_local<<<gl, 256, 0, st>>>(src, d_slots, kc, dlo, dhi, w.hist, ctl, tmp, d_live, w.err);
   sl_ms_merge<<<gm, 512, 0, st>>>(tmp, ctl, kc, out);
   return out;
@@ -1276,34 +1319,39 @@ int vsv_slim_sort_passes(int nbits) { return (nbits + 7) / 8; }     // (upper bo
 
 // stage 1: rows -> elements, sort by (tid, hap, type, source, pos), cluster per list. Returns the cluster output (slots = *d_alive1).
 void* vsv_slim_stage1(hipStream_t st, const vsv_sig* s1in, const uint32_t* d_n_s1, uint32_t* d_alive1, int pb, int tid_lo, int tid_bits, int cluster_shift,
-                      const SlimWork& w, Counters* ctr, bool prebuilt, const void** sorted1) {
+                      const SlimWork& w, Counters* ctr, bool prebuilt, const void** sorted1, void** ctl2) {
   Slim* b0 = (Slim*)w.buf[0]; Slim* b1 = (Slim*)w.buf[1]; Slim* e2 = (Slim*)w.buf[2];
   // (a fused run has the elements already: fold_kernel / split_eval wrote them next to the rows, vsv_slim_emit)
   if (!prebuilt) sl_from_rows<<<w.grid, 256, 0, st>>>(s1in, d_n_s1, pb, tid_lo, tid_bits, b0, &ctr->err);
   Slim* sorted = sl_sort(st, SrcSlim{b0}, d_n_s1, d_alive1, pb + 3 + tid_bits, KeyCmp{0, 0}, b1, b0, w, w.rows_hint);
   const int64_t tiles = (w.cap + CL_TILE - 1) / CL_TILE;
   const bool ms = sl_merge_ok(w, pb + 3 + tid_bits, KeyCmp{pb, 1});       // the sort behind these clusters: rank + merge (sl_merge_sort)
-  sl_cluster<<<(int)(tiles < 4096 ? (tiles < 1 ? 1 : tiles) : 4096), 256, 0, st>>>(sorted, d_alive1, cluster_shift, KeyFmt{pb}, pb, ms ? SL_CLASS : 0ull, e2, w.cl);
+  MsCtl* ctl = ms ? sl_ms_begin(st, w, true) : nullptr;                   // ... whose tile counts the cluster kernel leaves in w.hist
+  sl_cluster<<<(int)(tiles < 4096 ? (tiles < 1 ? 1 : tiles) : 4096), 256, 0, st>>>(sorted, d_alive1, cluster_shift, KeyFmt{pb}, pb, ms ? SL_CLASS : 0ull, e2, w.cl,
+                                                                                    MsCount{ms ? w.hist : nullptr, ctl});
   *sorted1 = sorted;         // (the anchors of that sort: stays in scratch buffer 0 / 1 until vsv_slim_merge has run)
+  *ctl2 = ctl;
   return e2;
 }
 
 // merge_all: sort the stage-1 representatives by (tid, hap, type, pos), cluster, sort by (tid, hap, pos). Returns the merged elements.
-void* vsv_slim_merge(hipStream_t st, const void* e2, const void* sorted1, const uint32_t* d_alive1, uint32_t* d_alive2, uint32_t* d_alive3, int pb, int tid_bits,
+void* vsv_slim_merge(hipStream_t st, const void* e2, const void* sorted1, void* ctl2, const uint32_t* d_alive1, uint32_t* d_alive2, uint32_t* d_alive3, int pb, int tid_bits,
                      int cluster_shift, const SlimWork& w) {
   Slim* b0 = (Slim*)w.buf[0]; Slim* b1 = (Slim*)w.buf[1]; Slim* e3 = (Slim*)w.buf[3]; Slim* m0 = (Slim*)w.buf[4]; Slim* m1 = (Slim*)w.buf[5];
   const int nbits = pb + 3 + tid_bits;
   const int64_t tiles = (w.cap + CL_TILE - 1) / CL_TILE;
   const int cgrid = (int)(tiles < 4096 ? (tiles < 1 ? 1 : tiles) : 4096);
-  if (sl_merge_ok(w, nbits, KeyCmp{pb, 1})) {
+  if (ctl2 && sl_merge_ok(w, nbits, KeyCmp{pb, 1})) {       // (ctl2: the stage-1 clusters carry their class bits and left their tile counts)
     // classes by source / by type; anchors = the table the clusters were cut from; a representative lies at or behind its seed
     Slim* free01 = (const Slim*)sorted1 == b0 ? b1 : b0;
-    Slim* s2 = sl_merge_sort(st, SrcAnch{(const Slim*)e2, (const Slim*)sorted1, 1ull << pb}, d_alive1, d_alive2, KeyCmp{pb, 1}, 0u, (uint32_t)cluster_shift, free01, m0, w);
-    sl_cluster<<<cgrid, 256, 0, st>>>(s2, d_alive2, cluster_shift, KeyFmt{pb}, pb + 1, SL_CLASS, e3, w.cl);
-    return sl_merge_sort(st, SrcAnch{e3, s2, 1ull << (pb + 1)}, d_alive2, d_alive3, KeyCmp{pb, 2}, 0u, (uint32_t)cluster_shift, b0, m1, w);
+    Slim* s2 = sl_merge_sort(st, SrcAnch{(const Slim*)e2, (const Slim*)sorted1, 1ull << pb}, d_alive1, d_alive2, KeyCmp{pb, 1}, 0u, (uint32_t)cluster_shift, free01, m0, w,
+                             (MsCtl*)ctl2);
+    MsCtl* ctl3 = sl_ms_begin(st, w, true);
+    sl_cluster<<<cgrid, 256, 0, st>>>(s2, d_alive2, cluster_shift, KeyFmt{pb}, pb + 1, SL_CLASS, e3, w.cl, MsCount{w.hist, ctl3});
+    return sl_merge_sort(st, SrcAnch{e3, s2, 1ull << (pb + 1)}, d_alive2, d_alive3, KeyCmp{pb, 2}, 0u, (uint32_t)cluster_shift, b0, m1, w, ctl3);
   }
   Slim* s2 = sl_sort(st, SrcSlim{(const Slim*)e2}, d_alive1, d_alive2, nbits, KeyCmp{pb, 1}, b0, b1, w, w.rows_hint);
-  sl_cluster<<<cgrid, 256, 0, st>>>(s2, d_alive2, cluster_shift, KeyFmt{pb}, pb + 1, 0ull, e3, w.cl);
+  sl_cluster<<<cgrid, 256, 0, st>>>(s2, d_alive2, cluster_shift, KeyFmt{pb}, pb + 1, 0ull, e3, w.cl, MsCount{nullptr, nullptr});
   // the result must outlive the pairing stage and the readback: it lands in one of the two buffers reserved for it
   return sl_sort(st, SrcSlim{e3}, d_alive2, d_alive3, nbits, KeyCmp{pb, 2}, m0, m1, w, w.rows_hint);
 }
@@ -1332,7 +1380,7 @@ void vsv_slim_pair(hipStream_t st, const void* merged, const uint32_t* d_alive3,
   }
   // the call sort: classes by haplotype, anchors = the merged slots' own keys, a call's key within pair_shift of its slot's either way
   Slim* cs = sl_merge_ok(w, pb + 3 + tid_bits, KeyCmp{pb, 3})
-      ? sl_merge_sort(st, SrcCalls{m, w.cl, pb + 2, SL_CLASS}, d_alive3, d_ncalls, KeyCmp{pb, 3}, (uint32_t)pair_shift, (uint32_t)pair_shift, b0, b1, w)
+      ? sl_merge_sort(st, SrcCalls{m, w.cl, pb + 2, SL_CLASS}, d_alive3, d_ncalls, KeyCmp{pb, 3}, (uint32_t)pair_shift, (uint32_t)pair_shift, b0, b1, w, nullptr)
       : sl_sort(st, SrcCalls{m, w.cl, pb + 2, 0ull}, d_alive3, d_ncalls, pb + 3 + tid_bits, KeyCmp{pb, 3}, b0, b1, w, w.rows_hint);
   sl_calls_out<<<w.grid, 256, 0, st>>>(cs, d_ncalls, m, pb + 2, s1in, calls);
 }
