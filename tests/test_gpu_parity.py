@@ -1131,7 +1131,7 @@ def test_element_path_on_the_parity_cases(slim_sort):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sel = ("golden_contig or golden_reads or synthetic_vs_oracle or multi_tid or tid_hint or random_small or dense_runs or config4_shape or clr_gate or "
-           "split_overlap or edge_cases or unaligned_device_views")
+           "split_overlap or edge_cases or unaligned_device_views or staged_api")
     env = dict(os.environ, VSV_DEBUG="1", VSV_BIG="1")
     if slim_sort == "lsd":
         env["VSV_SLIM_SORT"] = "lsd"

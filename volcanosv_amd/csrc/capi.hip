@@ -81,6 +81,7 @@ struct vsv_handle {
   int lsd_slim_runs = 0;           // > 0: a rank-and-merge sort of the element path gave up recently (ERRB_MERGE_FALLBACK): the next runs sort with the LSD passes
   const void* sl_sorted1 = nullptr; // element path: the sorted stage-1 table (anchors of the sort behind its clusters)
   void* sl_ctl2 = nullptr;          // ... and that sort's control slot (its tile counts come from the stage-1 cluster kernel)
+  int sl_shift1 = 0;                // ... and the cluster_shift those clusters were cut with (the staged entry points may change it in between)
   int64_t reruns = 0;             // whole-run repetitions taken by finish() so far (vsv_rerun_count)
   // large tables (slim_path.hip): element buffers, pairing scratch, what the run in flight left where
   DevBuf sl[6], sl_hj, sl_done;
@@ -441,6 +442,7 @@ int enq_stage1(vsv_handle* h) {
     SlimWork w;
     { int ws = slim_work(h, w); if (ws) return ws; }
     h->sl_e2 = vsv_slim_stage1(st, (const vsv_sig*)h->s1in.p, &c->n_s1, &c->n_alive1, pos_bits(h), h->rv.tid_lo, slim_tid_bits(h), h->prm.cluster_shift, w, c, h->sl_prebuilt, &h->sl_sorted1, &h->sl_ctl2);
+    h->sl_shift1 = h->prm.cluster_shift;
     h->c1_stale = true;
     HIPCHK(h, hipGetLastError());
     h->stage_done = 3;
@@ -460,7 +462,7 @@ int enq_merge(vsv_handle* h) {
   if (h->big_run) {
     SlimWork w;
     { int ws = slim_work(h, w); if (ws) return ws; }
-    h->sl_m = vsv_slim_merge(st, h->sl_e2, h->sl_sorted1, h->sl_ctl2, &c->n_alive1, &c->n_alive2, &c->n_alive3, pos_bits(h), slim_tid_bits(h), h->prm.cluster_shift, w);
+    h->sl_m = vsv_slim_merge(st, h->sl_e2, h->sl_sorted1, h->sl_ctl2, &c->n_alive1, &c->n_alive2, &c->n_alive3, pos_bits(h), slim_tid_bits(h), h->sl_shift1, h->prm.cluster_shift, w);
     h->merged_stale = true;
     HIPCHK(h, hipGetLastError());
     h->stage_done = 4;

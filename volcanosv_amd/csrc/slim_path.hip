@@ -1336,7 +1336,7 @@ void* vsv_slim_stage1(hipStream_t st, const vsv_sig* s1in, const uint32_t* d_n_s
 
 // merge_all: sort the stage-1 representatives by (tid, hap, type, pos), cluster, sort by (tid, hap, pos). Returns the merged elements.
 void* vsv_slim_merge(hipStream_t st, const void* e2, const void* sorted1, void* ctl2, const uint32_t* d_alive1, uint32_t* d_alive2, uint32_t* d_alive3, int pb, int tid_bits,
-                     int cluster_shift, const SlimWork& w) {
+                     int shift1, int cluster_shift, const SlimWork& w) {
   Slim* b0 = (Slim*)w.buf[0]; Slim* b1 = (Slim*)w.buf[1]; Slim* e3 = (Slim*)w.buf[3]; Slim* m0 = (Slim*)w.buf[4]; Slim* m1 = (Slim*)w.buf[5];
   const int nbits = pb + 3 + tid_bits;
   const int64_t tiles = (w.cap + CL_TILE - 1) / CL_TILE;
@@ -1344,8 +1344,8 @@ void* vsv_slim_merge(hipStream_t st, const void* e2, const void* sorted1, void* 
   if (ctl2 && sl_merge_ok(w, nbits, KeyCmp{pb, 1})) {       // (ctl2: the stage-1 clusters carry their class bits and left their tile counts)
     // classes by source / by type; anchors = the table the clusters were cut from; a representative lies at or behind its seed
     Slim* free01 = (const Slim*)sorted1 == b0 ? b1 : b0;
-    Slim* s2 = sl_merge_sort(st, SrcAnch{(const Slim*)e2, (const Slim*)sorted1, 1ull << pb}, d_alive1, d_alive2, KeyCmp{pb, 1}, 0u, (uint32_t)cluster_shift, free01, m0, w,
-                             (MsCtl*)ctl2);
+    Slim* s2 = sl_merge_sort(st, SrcAnch{(const Slim*)e2, (const Slim*)sorted1, 1ull << pb}, d_alive1, d_alive2, KeyCmp{pb, 1}, 0u, (uint32_t)shift1, free01, m0, w,
+                             (MsCtl*)ctl2);      // (shift1: what the stage-1 clusters were cut with)
     MsCtl* ctl3 = sl_ms_begin(st, w, true);
     sl_cluster<<<cgrid, 256, 0, st>>>(s2, d_alive2, cluster_shift, KeyFmt{pb}, pb + 1, SL_CLASS, e3, w.cl, MsCount{w.hist, ctl3});
     return sl_merge_sort(st, SrcAnch{e3, s2, 1ull << (pb + 1)}, d_alive2, d_alive3, KeyCmp{pb, 2}, 0u, (uint32_t)cluster_shift, b0, m1, w, ctl3);

@@ -222,7 +222,7 @@ struct SlimWork {
 int vsv_slim_sort_passes(int nbits);
 void* vsv_slim_stage1(hipStream_t st, const vsv_sig* s1in, const uint32_t* d_n_s1, uint32_t* d_alive1, int pb, int tid_lo, int tid_bits, int cluster_shift,
                       const SlimWork& w, Counters* ctr, bool prebuilt, const void** sorted1, void** ctl2);
-void* vsv_slim_merge(hipStream_t st, const void* e2, const void* sorted1, void* ctl2, const uint32_t* d_alive1, uint32_t* d_alive2, uint32_t* d_alive3, int pb, int tid_bits, int cluster_shift,
+void* vsv_slim_merge(hipStream_t st, const void* e2, const void* sorted1, void* ctl2, const uint32_t* d_alive1, uint32_t* d_alive2, uint32_t* d_alive3, int pb, int tid_bits, int shift1, int cluster_shift,
                      const SlimWork& w);
 void vsv_slim_pair(hipStream_t st, const void* merged, const uint32_t* d_alive3, uint32_t* d_ncalls, int pb, int tid_bits, int pair_shift, int pair_window,
                    const vsv_sig* s1in, vsv_call* calls, bool dense, const SlimWork& w, Counters* ctr);
