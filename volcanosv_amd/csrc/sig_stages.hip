@@ -1160,7 +1160,8 @@ SplitSorted vsv_launch_split_candidates(hipStream_t st, const RecView& rv, const
   qid_tile_max<<<qtiles, 256, 0, st>>>(rv.qid, rv.n_records, blk_cnt, vec, tab, (uint32_t)((nq + 31) / 32 + 1));
   // up to 8192 tiles / blocks (16 M records) the consumers reduce the per-tile values in front of them themselves: two 5-10 us
   // launches less; beyond that the reductions (quadratic in the tile count) cost more than the scan launches
-  const bool self_scan = qtiles <= 8192;
+  static const int self_max = vsv_dbg_env("VSV_SELF_SCAN") ? atoi(vsv_dbg_env("VSV_SELF_SCAN")) : 8192;     // timing experiments
+  const bool self_scan = qtiles <= self_max;
   if (!self_scan) qid_scan_max<<<1, 1024, 0, st>>>(blk_cnt, qtiles);
   qid_mark_dups<<<qtiles, 256, 0, st>>>(rv.qid, rv.n_records, blk_cnt, tab, vec, (uint32_t)nq, &ctr->err, self_scan);
   const int nblk = (int)(((uint64_t)rv.n_records + SC_TILE_REC - 1) / SC_TILE_REC);

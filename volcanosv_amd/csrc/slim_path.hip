@@ -1220,7 +1220,8 @@ __global__ __launch_bounds__(256) void sl_ms_local(SRC src, const uint32_t* __re
 // over millions of elements), ranks its elements against the other class's keys in LDS and writes them with the class bit cleared
 __device__ __forceinline__ uint32_t sl_ms_key(const Slim* __restrict__ p, KeyCmp kc) { return (uint32_t)kc(p->key & ~SL_CLASS) & 0x7FFFFFFFu; }
 __device__ __forceinline__ uint32_t sl_ms_path(const Slim* __restrict__ A, uint32_t nA, const Slim* __restrict__ B, uint32_t nB, uint32_t d, KeyCmp kc, int lane) {
-  uint32_t lo = d > nB ? d - nB : 0u, hi = d < nA ? d : nA;
+  // (lo, hi: wave-uniform by construction, and told so — the ballot sits in a loop the compiler can then branch on the scalar unit)
+  uint32_t lo = __builtin_amdgcn_readfirstlane(d > nB ? d - nB : 0u), hi = __builtin_amdgcn_readfirstlane(d < nA ? d : nA);
   while (lo < hi) {                                  // a* = elements of A among the first d outputs: A[a] <= B[d - 1 - a] holds for a < a*
     const uint32_t s = hi - lo, step = (s + 63u) / 64u;
     const uint32_t p = lo + (uint32_t)lane * step;
@@ -1231,8 +1232,8 @@ __device__ __forceinline__ uint32_t sl_ms_path(const Slim* __restrict__ A, uint3
     else {
       const uint32_t nlo = lo + (t - 1u) * step + 1u;
       const uint32_t cand = lo + t * step;
-      hi = (t < 64u && cand < hi) ? cand : hi;
-      lo = nlo;
+      hi = __builtin_amdgcn_readfirstlane((t < 64u && cand < hi) ? cand : hi);
+      lo = __builtin_amdgcn_readfirstlane(nlo);
     }
   }
   return lo;
@@ -1247,8 +1248,8 @@ __global__ __launch_bounds__(512) void sl_ms_merge(const Slim* __restrict__ tmp,
   for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const uint32_t d0 = tile * MS_MT, d1 = min(n, d0 + MS_MT);
     __syncthreads();
-    if (wv < 2) {
-      const uint32_t a = sl_ms_path(A, nA, B, nB, wv ? d1 : d0, kc, lane);
+    if (wv < 2) {                                                   // (wave-uniform: whole waves enter the search)
+      const uint32_t a = sl_ms_path(A, nA, B, nB, __builtin_amdgcn_readfirstlane(wv ? d1 : d0), kc, lane);
       if (lane == 0) sh_a[wv] = a;
     }
     __syncthreads();
