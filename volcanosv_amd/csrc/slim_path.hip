@@ -1192,6 +1192,7 @@ __global__ __launch_bounds__(256) void sl_ms_local(SRC src, const uint32_t* __re
       if (K == 0xFFFFFFFFu) continue;                                                          // no element
       const uint32_t aw = la[w], cls = aw >> 31, A = aw & 0x7FFFFFFFu, myrank = lr[w];
       if (K + dlo < A || K > A + dhi) trouble = true;                        // not what the caller promised
+      { const uint32_t ap = la[w - 1u]; if (ap != 0xFFFFFFFFu && (ap >> 31) == cls && (ap & 0x7FFFFFFFu) > A) trouble = true; }   // ... nor this: anchors ascend inside a class
       uint32_t back = 0, fwd = 0;
       for (int j = (int)w - 1;; --j) {
         if (j < 0) { trouble = trouble || open_left; break; }
