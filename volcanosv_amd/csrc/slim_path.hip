@@ -1193,8 +1193,35 @@ __global__ __launch_bounds__(256) void sl_ms_local(SRC src, const uint32_t* __re
       const uint32_t aw = la[w], cls = aw >> 31, A = aw & 0x7FFFFFFFu, myrank = lr[w];
       if (K + dlo < A || K > A + dhi) trouble = true;                        // not what the caller promised
       { const uint32_t ap = la[w - 1u]; if (ap != 0xFFFFFFFFu && (ap >> 31) == cls && (ap & 0x7FFFFFFFu) > A) trouble = true; }   // ... nor this: anchors ascend inside a class
+      // four slots either way in straight-line code (a pile with a signature per 45 bp looks two or three slots far; the loops behind
+      // take over where that does not reach a slot that ends the scan: every trip of a divergent loop costs scalar mask bookkeeping)
       uint32_t back = 0, fwd = 0;
-      for (int j = (int)w - 1;; --j) {
+      int jb, jf;
+      {
+        uint32_t stop = 0, inv = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                              // (w >= MS_H: the slots exist)
+          const uint32_t aj = la[w - 1u - u], kj = lk[w - 1u - u];
+          stop |= ((aj == 0xFFFFFFFFu || (aj >> 31) != cls || (aj & 0x7FFFFFFFu) + dhi <= K) ? 1u : 0u) << u;
+          inv |= ((kj != 0xFFFFFFFFu && kj > K) ? 1u : 0u) << u;
+        }
+        const uint32_t f = (uint32_t)__builtin_ctz(stop | 16u);
+        back = (uint32_t)__popc(inv & ((1u << f) - 1u));
+        jb = f < 4u ? -2 : (int)w - 5;                             // -2: decided
+      }
+      {
+        uint32_t stop = 0, inv = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                              // (w < MS_H + MS_T: the slots exist)
+          const uint32_t aj = la[w + 1u + u], kj = lk[w + 1u + u];
+          stop |= ((aj == 0xFFFFFFFFu || (aj >> 31) != cls || (aj & 0x7FFFFFFFu) >= K + dlo) ? 1u : 0u) << u;
+          inv |= ((kj != 0xFFFFFFFFu && kj < K) ? 1u : 0u) << u;
+        }
+        const uint32_t f = (uint32_t)__builtin_ctz(stop | 16u);
+        fwd = (uint32_t)__popc(inv & ((1u << f) - 1u));
+        jf = f < 4u ? -2 : (int)w + 5;
+      }
+      if (jb != -2) for (int j = jb;; --j) {
         if (j < 0) { trouble = trouble || open_left; break; }
         const uint32_t aj = la[j];
         if (aj == 0xFFFFFFFFu || (aj >> 31) != cls) break;                   // the table's start / the class's previous list lies in front
@@ -1202,7 +1229,7 @@ __global__ __launch_bounds__(256) void sl_ms_local(SRC src, const uint32_t* __re
         const uint32_t kj = lk[j];
         back += (kj != 0xFFFFFFFFu && kj > K) ? 1u : 0u;
       }
-      for (int j = (int)w + 1;; ++j) {
+      if (jf != -2) for (int j = jf;; ++j) {
         if (j >= MS_W) { trouble = trouble || open_right; break; }
         const uint32_t aj = la[j];
         if (aj == 0xFFFFFFFFu || (aj >> 31) != cls) break;
