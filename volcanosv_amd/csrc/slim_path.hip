@@ -412,6 +412,9 @@ __global__ __launch_bounds__(256) void sl_cluster(const Slim* __restrict__ s, co
                                                   uint64_t stash, Slim* __restrict__ out, int32_t* __restrict__ cl, MsCount mc) {
   constexpr int LDS_N = CL_TILE + CL_HALO + 1;
   __shared__ uint32_t lcnt[4];                                    // live outputs of this tile's runs: [this sort tile | the next][class]
+  __shared__ uint16_t mid_i[128];                                 // runs of 9 .. SL_LONG_RUN elements: tile-relative first slot, length
+  __shared__ uint8_t mid_len[128];
+  __shared__ uint32_t nmid;
   __shared__ int32_t l_pos[LDS_N], l_len[LDS_N];
   __shared__ uint32_t l_lid[LDS_N], l_idx[LDS_N];
   __shared__ uint16_t h4[CL_TILE], h8[CL_TILE], hx[CL_TILE];      // run heads (tile-relative slot) by class
@@ -423,7 +426,7 @@ __global__ __launch_bounds__(256) void sl_cluster(const Slim* __restrict__ s, co
   for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const uint32_t t0 = tile * CL_TILE;
     __syncthreads();
-    if (threadIdx.x == 0) { n4 = 0; n8 = 0; nx = 0; }
+    if (threadIdx.x == 0) { n4 = 0; n8 = 0; nx = 0; nmid = 0; }
     if (threadIdx.x < 4) lcnt[threadIdx.x] = 0;
     const uint32_t tb = t0 / (uint32_t)MS_T;
     uint32_t cn[4] = {0, 0, 0, 0};
@@ -497,35 +500,9 @@ __global__ __launch_bounds__(256) void sl_cluster(const Slim* __restrict__ s, co
             if ((x.key >> kf.pb) != lk || (int64_t)px - last > max_shift) break;
             last = px; ++e;
           }
-        } else {
-          const uint32_t len = e - i;
-          const bool del = (me.idx & SL_DEL) != 0;
-          uint64_t assigned = 0;
-          for (uint32_t a = 0; a < len; ++a) {
-            if ((assigned >> a) & 1ull) { st_slim(out + i + a, dead_slim()); continue; }
-            const Slim s1 = get(i + a);
-            const int32_t p1 = kf.pos(s1.key);
-            uint32_t best = a;
-            int32_t best_len = s1.svlen;
-            for (uint32_t b = a + 1; b < len; ++b) {
-              const Slim s2 = get(i + b);
-              const int32_t p2 = kf.pos(s2.key);
-              if ((int64_t)p2 - p1 > max_shift) break;
-              if ((assigned >> b) & 1ull) continue;
-              if (sl_match(p1, s1.svlen, p2, s2.svlen, del, max_shift)) {
-                assigned |= 1ull << b;
-                if (s2.svlen > best_len) { best = b; best_len = s2.svlen; }
-              }
-            }
-            Slim rep = best == a ? s1 : get(i + best);
-            rep.key = sl_stash(rep.key, drop, stash);
-            st_slim(out + i + a, rep);
-            {
-              const uint32_t d = (i + a) / (uint32_t)MS_T - tb, cb = (rep.key & SL_CLASS) ? 1u : 0u;     // (at most SL_LONG_RUN slots behind the tile)
-              cn[0] += (d == 0u && cb == 0u) ? 1u : 0u; cn[1] += (d == 0u && cb != 0u) ? 1u : 0u;
-              cn[2] += (d != 0u && cb == 0u) ? 1u : 0u; cn[3] += (d != 0u && cb != 0u) ? 1u : 0u;
-            }
-          }
+        } else {                                       // 9 .. SL_LONG_RUN elements, all of them staged: filed for the 16-lane groups below
+          const uint32_t q = atomicAdd(&nmid, 1u);
+          mid_i[q] = (uint16_t)(i - t0); mid_len[q] = (uint8_t)(e - i);
         }
       }
       uint64_t lm = __ballot(is_long);
@@ -533,6 +510,63 @@ __global__ __launch_bounds__(256) void sl_cluster(const Slim* __restrict__ s, co
         const int src = __builtin_ctzll(lm);
         lm &= lm - 1;
         sl_cluster_long(s, max_shift, kf, drop, stash, cl, out, (uint32_t)__shfl((int)i, src, 64), (uint32_t)__shfl((int)e, src, 64), lane, mc);
+      }
+    }
+    // ---- runs of 9 .. SL_LONG_RUN elements: a lane per run spent ~L^2 / 2 match evaluations one after the other while its wave
+    // waited (12 % of the pile's elements, 40 % of the kernel's time). Sixteen lanes per run instead, four runs per wave: the seeds stay
+    // sequential (H:236-247), a seed's members are tested sixteen at a time, the assigned set is a 64-bit mask every lane of the group
+    // keeps, the representative (first longest member) a packed maximum over the group. Loops and ballots are wave-uniform.
+    __syncthreads();
+    {
+      const uint32_t nm = nmid;
+      const int g = lane >> 4, gl = lane & 15, wv = threadIdx.x >> 6;
+      for (uint32_t base = (uint32_t)wv * 4u; base < nm; base += 16u) {
+        const uint32_t ridx = base + (uint32_t)g;
+        const bool has = ridx < nm;
+        const uint32_t r0 = has ? mid_i[ridx] : 0u, len = has ? mid_len[ridx] : 0u;
+        uint32_t maxlen = len;
+        maxlen = max(maxlen, (uint32_t)__shfl_xor((int)maxlen, 16, 64));
+        maxlen = max(maxlen, (uint32_t)__shfl_xor((int)maxlen, 32, 64));
+        const uint32_t rel0 = r0 + 1u;                             // (LDS index k = slot t0 - 1 + k)
+        const bool del = (l_idx[rel0] & SL_DEL) != 0;
+        const uint32_t lid = l_lid[rel0];
+        uint64_t assigned = 0;
+        for (uint32_t a = 0; a < maxlen; ++a) {
+          const bool act = a < len;
+          const bool seed = act && !((assigned >> a) & 1ull);
+          const uint32_t ra = rel0 + (act ? a : 0u);
+          const int32_t p1 = l_pos[ra], v1 = l_len[ra];
+          uint64_t best = ((uint64_t)(uint32_t)v1 << 32) | (uint64_t)(0xFFFFFFFFu - a);          // max length, then lowest index
+          const uint32_t rounds = __ballot(seed) ? (maxlen - a - 1u + 15u) / 16u : 0u;          // (wave-uniform: no group holds a seed here)
+          for (uint32_t q = 0; q < rounds; ++q) {
+            const uint32_t b = a + 1u + q * 16u + (uint32_t)gl;
+            bool m = false;
+            int32_t v2 = 0;
+            if (seed && b < len && !((assigned >> b) & 1ull)) {
+              v2 = l_len[rel0 + b];
+              m = sl_match(p1, v1, l_pos[rel0 + b], v2, del, max_shift);       // (a member beyond the shift fails the match)
+            }
+            const uint64_t bits = (__ballot(m) >> (g * 16)) & 0xFFFFull;
+            assigned |= bits << (a + 1u + q * 16u);                          // (< 64: a run holds at most SL_LONG_RUN elements)
+            if (m) { const uint64_t c = ((uint64_t)(uint32_t)v2 << 32) | (uint64_t)(0xFFFFFFFFu - b); if (c > best) best = c; }
+          }
+          if (rounds) {
+#pragma unroll
+            for (int d = 8; d > 0; d >>= 1) { const uint64_t o = __shfl_xor(best, d, 64); if (o > best) best = o; }
+          }
+          if (gl == 0 && act) {
+            Slim r = dead_slim();
+            if (seed) {
+              const uint32_t rb = rel0 + (0xFFFFFFFFu - (uint32_t)best);
+              r.key = sl_stash((((uint64_t)lid) << kf.pb) | vsv_kpos(l_pos[rb]), drop, stash);
+              r.svlen = l_len[rb]; r.idx = l_idx[rb];
+              const uint32_t d = (t0 + r0 + a) / (uint32_t)MS_T - tb, cb = (r.key & SL_CLASS) ? 1u : 0u;     // (at most SL_LONG_RUN slots behind the tile)
+              cn[0] += (d == 0u && cb == 0u) ? 1u : 0u; cn[1] += (d == 0u && cb != 0u) ? 1u : 0u;
+              cn[2] += (d != 0u && cb == 0u) ? 1u : 0u; cn[3] += (d != 0u && cb != 0u) ? 1u : 0u;
+            }
+            st_slim(out + t0 + r0 + a, r);
+          }
+        }
       }
     }
     if (mc.tcnt) {                                                // (block-uniform)
