@@ -40,6 +40,8 @@ struct vsv_handle {
   // workspace
   DevBuf part_rb, part_count, part_off, scan_tmp;
   DevBuf l_agg, l_carry_r, l_carry_q, l_tiles;   // long-record scan: per-part aggregates, carries, tile sums
+  DevBuf lbw; uint32_t lb_epoch = 0;             // look-back words of the placement's scan (valid by epoch: zeroed when allocated, never per run)
+  DevBuf l_prec;                                 // long-record scan: where every part's last descriptor batch lies
   DevBuf z_crctab, z_crc;  // CRC-32 tables (uploaded once) and per-member results of the device inflate
   const uint32_t* expect_crc = nullptr;   // vsv_bgzf_set_expected_crc: trailer CRCs of the members of the next inflate / parse
   int64_t expect_crc_n = 0;
@@ -161,16 +163,22 @@ int reserve(vsv_handle* h, int64_t max_records, int64_t max_ops, int64_t max_sig
   if (max_ops > h->cap_ops || max_records > h->cap_records) {
     const int64_t ops = max_ops > h->cap_ops ? max_ops : h->cap_ops;
     const int64_t recs = max_records > h->cap_records ? max_records : h->cap_records;
-    const size_t n_parts = (size_t)vsv_cigar_parts(ops, OPS_PER_PART) + 2;
+    const size_t n_parts = (size_t)vsv_cigar_parts(ops, OPS_PER_PART) + 16;
     const size_t nblk = (size_t)((recs * 2 + 2047) / 2048) + 2;
     int st;
     if ((st = ensure(h, h->part_rb, (n_parts + 1) * 4))) return st;
     if ((st = ensure(h, h->part_count, n_parts * 4))) return st;
     if ((st = ensure(h, h->part_off, n_parts * 4))) return st;
-    if ((st = ensure(h, h->l_agg, vsv_long_scan_bytes(ops, 0)))) return st;
-    if ((st = ensure(h, h->l_carry_r, vsv_long_scan_bytes(ops, 1)))) return st;
-    if ((st = ensure(h, h->l_carry_q, vsv_long_scan_bytes(ops, 1)))) return st;
-    if ((st = ensure(h, h->l_tiles, vsv_long_scan_bytes(ops, 2)))) return st;
+    if ((st = ensure(h, h->l_agg, vsv_long_scan_bytes(ops, 0, OPS_PER_PART)))) return st;
+    if ((st = ensure(h, h->l_carry_r, vsv_long_scan_bytes(ops, 1, OPS_PER_PART)))) return st;
+    if ((st = ensure(h, h->l_carry_q, vsv_long_scan_bytes(ops, 1, OPS_PER_PART)))) return st;
+    if ((st = ensure(h, h->l_tiles, vsv_long_scan_bytes(ops, 2, OPS_PER_PART)))) return st;
+    if ((st = ensure(h, h->l_prec, vsv_long_scan_bytes(ops, 3, OPS_PER_PART)))) return st;
+    {
+      const void* before = h->lbw.p;
+      if ((st = ensure(h, h->lbw, vsv_lookback_bytes(ops, OPS_PER_PART)))) return st;
+      if (h->lbw.p != before) { HIPCHK(h, hipMemsetAsync(h->lbw.p, 0, h->lbw.bytes, h->stream)); h->lb_epoch = 0; }
+    }
     if ((st = ensure(h, h->blk_cnt, nblk * 4))) return st;
     if ((st = ensure(h, h->blk_off, nblk * 4))) return st;
     if ((st = ensure(h, h->cmask, nblk * 512 + 1024))) return st;      // SC_ROUNDS (2) x 256 bytes per block of 2048 records
@@ -351,10 +359,15 @@ int enq_scan(vsv_handle* h) {
   const bool early_cands = h->fork_split && h->prm.enable_split && h->prm.dtype != VSV_DTYPE_SVIM && h->prm.dtype != VSV_DTYPE_CUTESV && h->rv.n_records > 0;
   const bool fork = early_cands && h->prm.split_overlap != VSV_OVERLAP_OFF && !(where && where[0] == 'm') && have_aux(h, false);
   if (fork) HIPCHK(h, hipEventRecord(h->ev_fork, st));
+  if (++h->lb_epoch >= (1u << 24)) {            // the epoch field of the look-back words is about to wrap: start over on zeroed words
+    HIPCHK(h, hipMemsetAsync(h->lbw.p, 0, h->lbw.bytes, st));
+    h->lb_epoch = 1;
+  }
   vsv_launch_cigar_scan(st, srv, h->prm, (uint32_t*)h->part_rb.p, n_parts, OPS_PER_PART, (vsv_sig*)h->pool.p,
                         (uint64_t*)h->pool_key.p, (uint32_t)h->cap_sigs, (uint32_t*)h->part_count.p, (uint32_t*)h->part_off.p,
                         (uint32_t*)h->scan_tmp.p, (vsv_sig*)h->raw0.p, dctr(h), (uint32_t*)h->shard_cnt.p, h->ev0, h->ev1,
-                        LongScanBufs{h->l_agg.p, (uint32_t*)h->l_carry_r.p, (uint32_t*)h->l_carry_q.p, h->l_tiles.p, h->tile_cnt, 4096, true, clr_fused});
+                        LongScanBufs{h->l_agg.p, (uint32_t*)h->l_carry_r.p, (uint32_t*)h->l_carry_q.p, h->l_tiles.p, h->tile_cnt, 4096, true, clr_fused,
+                                     (uint64_t*)h->lbw.p, h->lb_epoch, h->l_prec.p});
   h->have_scan_ev = n_parts > 0;
   // the path of the stages behind the split stage is decided here, so that the fold (and split_eval) can write the elements of a
   // large-table run next to their rows
@@ -563,6 +576,7 @@ int finish(vsv_handle* h) {
     h->last_count = need;
     return fail(h, VSV_E_CAPACITY, b);
   }
+  if (e & ERRB_LOOKBACK) return fail(h, VSV_E_HIP, "the scan's look-back over the part counts timed out (internal error)");
   if (e & ERRB_EMPTY_CIGAR) return fail(h, VSV_E_EMPTY_CIGAR, "record with no CIGAR ops / cigar_off not increasing");
   if (e & ERRB_RANGE) return fail(h, VSV_E_INVALID, "a part spans >= 2^30 CIGAR ops, a position exceeds the max_pos hint, a tid lies outside [tid_lo, n_tids), or a qid is >= n_qids");
   if (e & ERRB_REFEND) return fail(h, VSV_E_REFEND, "N/=/X op in an eligible record on the contig path (offset_ref != reference_end)");
@@ -691,7 +705,7 @@ void vsv_destroy(vsv_handle* h) {
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
   if (h->ev_join) hipEventDestroy(h->ev_join);
   DevBuf* bufs[] = {&h->scan_tmp2, &h->r_pos, &h->r_tid, &h->r_qid, &h->r_off, &h->r_mapq, &h->r_flag, &h->r_cigar, &h->part_rb, &h->part_count,
-                    &h->part_off, &h->scan_tmp, &h->l_agg, &h->l_carry_r, &h->l_carry_q, &h->l_tiles, &h->z_crctab, &h->z_crc, &h->pool, &h->pool_key, &h->raw0, &h->s1in, &h->s1s, &h->c1, &h->s2s, &h->c2,
+                    &h->part_off, &h->scan_tmp, &h->lbw, &h->l_prec, &h->l_agg, &h->l_carry_r, &h->l_carry_q, &h->l_tiles, &h->z_crctab, &h->z_crc, &h->pool, &h->pool_key, &h->raw0, &h->s1in, &h->s1s, &h->c1, &h->s2s, &h->c2,
                     &h->merged, &h->calls_tmp, &h->calls, &h->reads, &h->tab, &h->blk_cnt, &h->blk_off, &h->ckey, &h->crec,
                     &h->okey, &h->oval, &h->key, &h->idx, &h->cl, &h->key2, &h->idx2, &h->key_alt, &h->val_alt, &h->hist, &h->arena, &h->g_off, &h->g_qs, &h->g_qe, &h->g_rid, &h->g_rs,
                     &h->g_re, &h->g_rev, &h->g_hap, &h->g_len, &h->g_rank, &h->j_cpos, &h->j_clen, &h->j_spos, &h->j_slen, &h->j_send, &h->j_out, &h->j_err, &h->z_comp, &h->z_coff, &h->z_ooff, &h->z_out, &h->z_stat, &h->p_spec, &h->p_cnt, &h->p_land, &h->p_base, &h->p_recoff, &h->p_pos, &h->p_tid,

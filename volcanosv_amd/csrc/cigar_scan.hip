@@ -23,7 +23,10 @@
 //    signatures share the record) and appends to a pool sharded over 256 cursors. Each row carries (part,
 //    ordinal), and place_raw scatters rows to part_off[part]+ordinal, so T_RAW is in (record, op) order whatever
 //    the atomic order was.
+#include <stdio.h>
 #include <stdlib.h>
+
+#include <vector>
 
 #include "vsv_device.h"
 
@@ -632,7 +635,7 @@ constexpr uint32_t dup16(uint32_t t) { return t | (t << 16); }
 constexpr int K1L_STAGE = 64;             // rows a wave stages in LDS before it flushes them to the pool (one per lane)
 
 template <int CLS>
-__global__ __launch_bounds__(256) void cigar_scan_long(RecView rv, const uint32_t* __restrict__ rb, int n_parts,
+__global__ __launch_bounds__(256) void cigar_scan_long_pool(RecView rv, const uint32_t* __restrict__ rb, int n_parts,
                                                         int min_svlen, int min_mapq, EmitCtx ec,
                                                         uint32_t* __restrict__ part_count, PartAgg* __restrict__ agg, int ablate) {
   using T = OpTab<CLS>;
@@ -936,6 +939,386 @@ __global__ __launch_bounds__(256) void cigar_scan_long(RecView rv, const uint32_
   if (lane == 0) { part_count[part] = ord; PartAgg a; a.has_start = has_start; a.run_r = run_r; a.run_q = run_q; agg[part] = a; }
 }
 
+// ---- decoupled look-back: an exclusive scan inside one launch ------------------------------------------------------------------
+// A part's rows belong at raw[rows of the parts in front + ordinal], and the rows of the record that was open at its start still miss
+// that record's advance in the parts in front (the carry). Both are exclusive prefixes over the parts: x[p] = (has_start, run_r,
+// run_q, count) with (f1, v1) (+) (f2, v2) = (f1 | f2, f2 ? v2 : v1 + v2) for the runs and a plain sum for the counts. The placement
+// kernel (k1l_place) computes them for blocks of parts: every block publishes its aggregate, looks back over its predecessors' words
+// until it meets one that already holds an inclusive prefix, and publishes its own inclusive prefix.
+// Three 64-bit words per block, each valid by itself: [63:40] epoch of the run (the host counts runs; words of earlier runs are
+// simply "not yet"), [39:38] kind (aggregate / inclusive prefix), [32] has_start (word 0), [31:0] value. They are written and read
+// with relaxed agent-scope atomics and nothing else depends on their order, so no fence is needed (a fence writes back and
+// invalidates L2 for every engine on the chip); a reader that meets words of different kinds (the writer is between its stores) reads
+// again. Workgroups are dispatched in index order and a block waits for lower blocks only, so the lowest unfinished block is always
+// resident or next to be dispatched: the waits end. They are bounded all the same (ERRB_LOOKBACK instead of a hung GPU).
+constexpr uint64_t LB_AGG = 1ull, LB_PRE = 2ull;
+struct LbItem { uint32_t f, r, q, cnt; };
+__device__ __forceinline__ LbItem lb_combine(const LbItem& a, const LbItem& b) {          // a: the earlier parts, b: the later ones
+  LbItem c;
+  c.f = a.f | b.f; c.r = b.f ? b.r : a.r + b.r; c.q = b.f ? b.q : a.q + b.q; c.cnt = a.cnt + b.cnt;
+  return c;
+}
+__device__ __forceinline__ uint64_t lb_pack(uint32_t epoch, uint64_t kind, uint32_t f, uint32_t v) {
+  return ((uint64_t)epoch << 40) | (kind << 38) | ((uint64_t)(f & 1u) << 32) | (uint64_t)v;
+}
+__device__ __forceinline__ uint32_t lb_kind(uint64_t w, uint32_t epoch) { return (uint32_t)(w >> 40) == epoch ? (uint32_t)(w >> 38) & 3u : 0u; }
+__device__ __forceinline__ uint64_t lb_ld(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void lb_st(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) { return rdlane(wave_incl_scan(v), 63); }
+constexpr uint32_t LB_SPIN_LIMIT = 1u << 20;      // polls of ~1 us each
+
+// Called by all 64 lanes of one wave of the block that owns item `part` (wave-uniform arguments). lb_publish: the item's aggregate.
+// lb_resolve: the exclusive prefix over the items in front of it (waits until all of them have published), and the item's
+// inclusive prefix for its successors.
+__device__ __forceinline__ void lb_publish(uint64_t* __restrict__ lbw, uint32_t epoch, uint32_t part, const LbItem& own, uint64_t kind, int lane) {
+  uint64_t* w = lbw + 3 * (size_t)part;            // (three stores by three lanes: a select over the lane becomes an indexed read of a stack copy of `own`)
+  if (lane == 0) lb_st(w, lb_pack(epoch, kind, own.f, own.cnt));
+  if (lane == 1) lb_st(w + 1, lb_pack(epoch, kind, 0u, own.r));
+  if (lane == 2) lb_st(w + 2, lb_pack(epoch, kind, 0u, own.q));
+}
+__device__ __forceinline__ LbItem lb_resolve(uint64_t* __restrict__ lbw, uint32_t epoch, uint32_t part, const LbItem& own, int lane, uint32_t* err) {
+  LbItem acc{0, 0, 0, 0};
+  if (part != 0) {
+    int64_t j = (int64_t)part - 1;                 // the nearest part not yet accounted for
+    uint32_t spins = 0;
+    for (;;) {
+      const int64_t pj = j - lane;
+      uint64_t w0 = 0, w1 = 0, w2 = 0;
+      uint32_t state = 3u;                         // in front of part 0: an empty inclusive prefix
+      if (pj >= 0) {
+        const uint64_t* q = lbw + 3 * (size_t)pj;
+        w0 = lb_ld(q); w1 = lb_ld(q + 1); w2 = lb_ld(q + 2);
+        const uint32_t k0 = lb_kind(w0, epoch), k1 = lb_kind(w1, epoch), k2 = lb_kind(w2, epoch);
+        state = (k0 == k1 && k1 == k2) ? k0 : 0u;
+      }
+      const uint64_t m_inv = __ballot(state == 0u), m_pre = __ballot(state >= 2u);
+      const uint32_t lp = m_pre ? (uint32_t)__builtin_ctzll(m_pre) : 64u, li = m_inv ? (uint32_t)__builtin_ctzll(m_inv) : 64u;
+      if (li < lp) {                               // a part between this one and the nearest prefix has not published yet
+        if (++spins > LB_SPIN_LIMIT) { if (lane == 0) atomicOr(err, ERRB_LOOKBACK); break; }
+        __builtin_amdgcn_s_sleep(16);
+        continue;
+      }
+      const bool take = (uint32_t)lane <= lp;      // lanes 0 .. lp: aggregates, closed by the prefix of lane lp (if any)
+      const uint32_t f = take ? (uint32_t)(w0 >> 32) & 1u : 0u, cnt = take ? (uint32_t)w0 : 0u;
+      const uint64_t mf = __ballot(f != 0u);
+      const uint32_t lf = mf ? (uint32_t)__builtin_ctzll(mf) : 64u;          // the nearest part that holds a record start
+      const bool in_run = take && (uint32_t)lane <= lf;
+      LbItem t;
+      t.f = mf ? 1u : 0u; t.cnt = wave_sum(cnt);
+      t.r = wave_sum(in_run ? (uint32_t)w1 : 0u); t.q = wave_sum(in_run ? (uint32_t)w2 : 0u);
+      acc = lb_combine(t, acc);
+      if (lp < 64u) break;
+      j -= 64;
+    }
+  }
+  lb_publish(lbw, epoch, part, lb_combine(acc, own), LB_PRE, lane);
+  return acc;
+}
+// ---- K1L: the scan for LONG records, second form ---------------------------------------------------------------------------------
+// Same streaming blocks as cigar_scan_long_pool above; what changed is everything behind the candidate test:
+//  * a candidate leaves a 16-byte DESCRIPTOR in the wave's LDS stage — {pos, q_start (both still without the part's carry where the
+//    record was open at the part's start), len << 4 | flags, record} — instead of a finished 32-byte row and its 8-byte pool key;
+//  * the stage leaves as ONE batch per part (one slot allocation, coalesced 16-byte stores), and the part files where it lies;
+//  * k1l_place then scans the part counts and carries by a look-back among its own (short, uniform) blocks and builds the rows where
+//    they belong, coalesced: one launch for round 3's three scan launches + place_raw.
+// The scan itself never waits. (The rows straight from the scan, by a look-back over the parts INSIDE it, were built and measured
+// first: bit-exact, but a part waits a median 22-32 us for the slowest of the ~6000 lower parts in flight to end its stream —
+// per-part stream times spread p50 63 / p99 139 us at 16384 ops, evenly over XCDs and CUs — and this kernel needs every wave slot
+// streaming to saturate HBM (4 KiB in flight per wave, ~4 us of loaded latency): 4.66 ms at 8192-op parts, 2.59 ms at 65536;
+// resolving a part behind the stream of the wave's next one, parts handed out by a counter, 3.0 ms; the pool form 2.58.)
+constexpr int K1L_DSTAGE = 192;
+constexpr uint32_t KD_DEL = 1u, KD_CARRY = 2u, KD_HP2 = 4u;
+constexpr int K1L_RMAX = 64;               // record starts staged per wave (a part of a contig-shaped input holds a handful; more restage)
+__device__ __forceinline__ void k1l_row(const uint4& d, uint32_t cr, uint32_t cq, uint32_t tid, bool no_qend, uint4& lo4, uint4& hi4) {
+  const uint32_t fl = d.z & 15u, len = d.z >> 4;
+  const uint32_t pos = d.x + ((fl & KD_CARRY) ? cr : 0u), qs = d.y + ((fl & KD_CARRY) ? cq : 0u);
+  lo4 = make_uint4(pos, len, qs, no_qend ? 0u : qs + ((fl & KD_DEL) ? 1u : len));
+  hi4 = make_uint4(d.w, 0xFFFFFFFFu, ((fl & KD_DEL) ? (uint32_t)VSV_M_DEL : 0u) | ((fl & KD_HP2) ? (uint32_t)VSV_M_HP2 : 0u), tid);
+}
+struct K1LArgs {
+  RecView rv; const uint32_t* rb; Counters* ctr;
+  uint4* dpool; uint32_t* shard_cnt; uint32_t shard_cap;      // descriptor pool: K1_SHARDS shards of shard_cap descriptors, cursor s at shard_cnt[16 s]
+  uint4* batches; uint32_t batch_cap;                         // overflow list {part, first ordinal, location, descriptors}, cursor at shard_cnt[8]
+  uint2* prec; uint32_t* part_count; PartAgg* agg;            // per part: {location, descriptors} of its last batch, rows, (has_start, advance since its last start)
+  int n_parts, min_svlen, min_mapq; uint32_t part_ops; int ablate;
+};
+template <int CLS>
+__global__ __launch_bounds__(256) void cigar_scan_long(K1LArgs A) {
+  using T = OpTab<CLS>;
+  __shared__ uint32_t sh_off[K1_WAVES][K1L_RMAX + 1];
+  __shared__ uint4 sh_desc[K1_WAVES][K1L_DSTAGE];              // staged descriptors, wave-private
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const int part = blockIdx.x * K1_WAVES + wv;
+  const RecView& rv = A.rv;
+  const uint32_t* __restrict__ rb = A.rb;
+  Counters* ctr = A.ctr;
+  const int n_parts = A.n_parts, min_svlen = A.min_svlen, min_mapq = A.min_mapq, ablate = A.ablate;
+  const uint32_t part_ops = A.part_ops;
+  if (part >= n_parts) return;
+  const uint64_t n_rec = (uint64_t)rv.n_records;
+  uint64_t end_all = rv.cigar_off[n_rec];                       // ops behind the last record belong to nobody
+  if (end_all > (uint64_t)rv.n_ops) end_all = (uint64_t)rv.n_ops;
+  const uint64_t e0 = (uint64_t)part * part_ops;
+  uint32_t ord = 0;                                             // rows of this part so far (staged and spilled)
+  uint32_t r0 = __builtin_amdgcn_readfirstlane(rb[part]), r1 = __builtin_amdgcn_readfirstlane(rb[part + 1]);
+  if (r1 < r0) r1 = r0;                                          // offsets that do not ascend: reported below, never followed
+  const uint32_t part_len = __builtin_amdgcn_readfirstlane(e0 >= end_all ? 0u : (uint32_t)((end_all - e0) < (uint64_t)part_ops ? (end_all - e0) : (uint64_t)part_ops));
+
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const uint32_t* part_base = rv.cigar + e0;
+  const uint32_t base_lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)part_base);
+  const uint32_t base_hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)part_base >> 32));
+  // ring loads issued and awaited by hand, raw buffer descriptor clipped to the part: see cigar_scan_long_pool
+  u32x4 rsrc;
+  rsrc.x = base_lo; rsrc.y = base_hi & 0xFFFFu; rsrc.z = __builtin_amdgcn_readfirstlane(part_len * 4u); rsrc.w = 0x00020000u;
+  const uint32_t lane16 = 16u * (uint32_t)lane;
+  auto issue = [&](u32x4& dst, uint32_t cb) {
+    const uint32_t voff = cb * 4u + lane16;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(voff), "s"(rsrc) : "memory");
+  };
+  u32x4 wa, wb, wc, wd;
+  issue(wa, 0); issue(wb, 256); issue(wc, 512); issue(wd, 768);
+#define K1L_ARRIVE(reg) asm volatile("s_waitcnt vmcnt(3)" : "+v"(reg) : : "memory")
+
+  // ---- record starts of this part, relative to e0, staged K1_RMAX at a time; every record is checked by the part that holds
+  // its start (an empty CIGAR must raise: H:63 IndexError) -------------------------------------------------------------------
+  const uint32_t e0_lo = (uint32_t)e0;
+  uint32_t* my_off = sh_off[wv];
+  uint32_t tbase = r0, n_tab = 0, ti = 0;       // staged records [tbase, tbase + n_tab), next unconsumed entry ti
+  bool bad = false;
+  auto stage = [&](uint32_t first) {
+    tbase = first; ti = 0;
+    n_tab = min((uint32_t)K1L_RMAX, r1 - first);
+    bool ok = true;
+    for (uint32_t i = lane; i < n_tab; i += 64) {
+      const uint64_t o = rv.cigar_off[first + i], nx = rv.cigar_off[(uint64_t)first + i + 1];
+      my_off[i] = (uint32_t)o - e0_lo;
+      ok = ok && nx > o && o >= e0 && o - e0 < (uint64_t)part_len;      // ascending, inside this part
+      if (CLS == 0 || CLS == 1) {               // a walked record whose SEQ length differs from its CIGAR's: H:397-398, RS:123-124
+        const uint32_t fl = rv.flag[first + i];
+        if ((fl & VSV_F_SEQ_MISMATCH) && rv.mapq[first + i] >= (uint32_t)min_mapq && (CLS == 1 || (fl & (VSV_F_HP1 | VSV_F_HP2))))
+          atomicOr(&ctr->err, ERRB_SEQLEN);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (__ballot(!ok)) { if (lane == 0) atomicOr(&ctr->err, ERRB_EMPTY_CIGAR); bad = true; }
+  };
+  if (r1 > r0) stage(r0);
+  auto next_start = [&]() -> uint32_t {         // relative op index of the next record start of the part (wave-uniform)
+    if (ti >= n_tab) {
+      if (tbase + n_tab >= r1 || bad) return 0xFFFFFFFFu;
+      stage(tbase + n_tab);
+      if (bad || n_tab == 0) return 0xFFFFFFFFu;
+    }
+    return __builtin_amdgcn_readfirstlane(my_off[ti]);
+  };
+  uint32_t nxt = (r1 > r0 && !bad) ? next_start() : 0xFFFFFFFFu;
+  uint32_t cur_rec = (r0 > 0 && !(nxt == 0u)) ? r0 - 1u : 0xFFFFFFFFu;    // the record that is open at the part's start
+  bool in_head = true;                          // no record start seen yet: rows miss the carry of the part
+  uint32_t has_start = 0;
+  uint32_t run_r = 0, run_q = 0;                // advance since the current record's start (or since e0 while in_head)
+
+  // ---- descriptor stage: it leaves as ONE batch at the end of the part (a part of the pile holds ~16 candidates, the stage 192), in a
+  // pool sharded over 256 cursors; a part that fills its stage earlier files those batches in the overflow list ----------------------
+  const uint32_t shard = (uint32_t)part % K1_SHARDS;
+  uint4* my_desc = sh_desc[wv];
+  uint32_t n_staged = 0;
+  auto flush = [&](bool last) {
+    uint32_t loc = 0, n = 0;
+    if (n_staged != 0) {
+      uint32_t b = 0;
+      if (lane == 0) b = atomicAdd(&A.shard_cnt[shard * 16], n_staged);
+      const uint32_t slot = __builtin_amdgcn_readfirstlane(b);
+      if (slot + n_staged <= A.shard_cap) {                     // (else: the placement pass reports the shard's use, the rows of this batch stay unwritten)
+        loc = shard * A.shard_cap + slot; n = n_staged;
+        for (uint32_t i = lane; i < n_staged; i += 64) A.dpool[loc + i] = my_desc[i];
+      }
+      if (!last && n != 0 && lane == 0) {
+        const uint32_t e = atomicAdd(&A.shard_cnt[8], 1u);
+        if (e < A.batch_cap) A.batches[e] = make_uint4((uint32_t)part, ord - n_staged, loc, n);
+        else atomicOr(&ctr->err, ERRB_CAPACITY);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (last && lane == 0) A.prec[part] = make_uint2(loc, n);
+    n_staged = 0;
+  };
+
+  const uint32_t thr = (uint32_t)min_svlen;
+  const uint32_t thr16 = thr >= (1u << 28) ? 0xFFFFFFFFu : thr << 4;
+  constexpr uint32_t EMIT_R = rev32(EMIT_MASK | (EMIT_MASK << 16));
+  constexpr uint32_t BAD_R = rev32(T::BAD | (T::BAD << 16));
+  constexpr uint32_t REF2 = dup16(T::REF), QRY2 = dup16(T::QRY);   // bit (w & 31) of these = bit (op) of the table
+  uint32_t hd_rec = 0xFFFFFFFFu, hd_fl = 0, hd_mq = 0, hd_tid = 0, hd_first = 0, hd_pos = 0;   // cached record header (SGPRs)
+  uint32_t hd_hap = 0, hd_hc = 0;                                                               // ... and what the emissions derive from it
+
+  // ---- the chunk handed from the streaming blocks to the (single) emission block -----------------------------------------
+  uint32_t pw[4] = {0, 0, 0, 0}, p_pr0 = 0, p_pq0 = 0;          // its ops and each lane's exclusive in-chunk prefix
+  bool pe0 = false, pe1 = false, pe2 = false, pe3 = false;      // ... and which of them are candidates (lane masks: they stay in scalar registers)
+  bool p_badany = false;
+  uint32_t p_cb = 0, p_tot_r = 0, p_tot_q = 0;
+  bool pending = false;
+
+  auto stream = [&](const u32x4& wcur, const uint32_t cb) {
+    if (cb >= part_len || bad) return;
+    const uint32_t w[4] = {wcur.x, wcur.y, wcur.z, wcur.w};
+    const bool e0 = (int32_t)(EMIT_R << (w[0] & 31u)) < 0 && w[0] >= thr16, e1 = (int32_t)(EMIT_R << (w[1] & 31u)) < 0 && w[1] >= thr16;
+    const bool e2 = (int32_t)(EMIT_R << (w[2] & 31u)) < 0 && w[2] >= thr16, e3 = (int32_t)(EMIT_R << (w[3] & 31u)) < 0 && w[3] >= thr16;
+    bool bd = false;
+    if (T::BAD != 0) {
+      const uint32_t t = (BAD_R << (w[0] & 31u)) | (BAD_R << (w[1] & 31u)) | (BAD_R << (w[2] & 31u)) | (BAD_R << (w[3] & 31u));
+      bd = (int32_t)t < 0;
+    }
+    uint32_t sum_r = 0, sum_q = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t len = w[k] >> 4;
+      sum_r += len & (uint32_t)__builtin_amdgcn_sbfe(REF2, w[k], 1);
+      sum_q += len & (uint32_t)__builtin_amdgcn_sbfe(QRY2, w[k], 1);
+    }
+    const uint32_t incl_r = wave_incl_scan(sum_r), incl_q = wave_incl_scan(sum_q);
+    const uint32_t tot_r = rdlane(incl_r, 63), tot_q = rdlane(incl_q, 63);
+    const bool any_cand = __ballot(e0 | e1 | e2 | e3 | bd) != 0ull && !(ablate & 1);
+    if (!any_cand && !(nxt < cb + 256u)) { run_r += tot_r; run_q += tot_q; return; }
+    pw[0] = w[0]; pw[1] = w[1]; pw[2] = w[2]; pw[3] = w[3];
+    pe0 = e0 && !(ablate & 1); pe1 = e1 && !(ablate & 1); pe2 = e2 && !(ablate & 1); pe3 = e3 && !(ablate & 1);
+    p_pr0 = incl_r - sum_r; p_pq0 = incl_q - sum_q;
+    p_badany = any_cand && __ballot(bd) != 0ull;
+    p_cb = cb; p_tot_r = tot_r; p_tot_q = tot_q;
+    pending = true;
+  };
+
+  // emission block: the pending chunk is cut into segments at the record starts it holds (usually none: one segment); the
+  // candidate ops of a segment belong to one record and leave their descriptors together.
+  auto emit_pending = [&]() {
+    const uint32_t cb = p_cb;
+    const uint32_t x = cb + 4u * (uint32_t)lane;
+    uint32_t base_r = run_r, base_q = run_q, lo = cb, hi_cap = 0xFFFFFFFFu;
+    for (;;) {
+      uint32_t hi = nxt < cb + 256u ? nxt : cb + 256u;
+      if (hi_cap < hi) hi = hi_cap;
+      if (hi > lo && cur_rec != 0xFFFFFFFFu) {
+        bool e[4] = {pe0, pe1, pe2, pe3};                        // (the streaming block's tests: not evaluated again)
+        const bool whole = lo == cb && hi == cb + 256u;
+        if (!whole) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) e[k] = e[k] && x + k >= lo && x + k < hi;
+        }
+        const uint32_t c = (e[0] ? 1u : 0u) + (e[1] ? 1u : 0u) + (e[2] ? 1u : 0u) + (e[3] ? 1u : 0u);
+        const uint64_t many = __ballot(c != 0u);
+        bool any_b = false;
+        if (T::BAD != 0 && p_badany) {
+          bool b = false;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            uint32_t wk = pw[k];
+            asm volatile("" : "+v"(wk));       // keep the test behind its guard (the optimizer hoists loop-invariant arithmetic)
+            b = b || ((int32_t)(BAD_R << (wk & 31u)) < 0 && wk >= 16u && x + k >= lo && x + k < hi);
+          }
+          any_b = __ballot(b) != 0ull;
+        }
+        if (many != 0ull || any_b) {
+          const uint32_t rec = __builtin_amdgcn_readfirstlane(cur_rec);
+          if (rec != hd_rec) {                                   // header through the scalar cache, once per record and part
+            const uint64_t* po = rv.cigar_off + rec;
+            uint64_t fo;
+            asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(fo) : "s"(po) : "memory");
+            if (fo >= (uint64_t)rv.n_ops) fo = 0;                // garbage offsets are reported by the part that stages them
+            sload5(align4(rv.flag + rec), align4(rv.mapq + rec), rv.tid + rec, rv.cigar + fo, rv.pos + rec, hd_fl, hd_mq, hd_tid, hd_first, hd_pos);
+            hd_rec = rec;
+            const uint32_t fl = byte_of(hd_fl, rv.flag + rec), mq = byte_of(hd_mq, rv.mapq + rec);
+            if (CLS == 0) hd_hap = (mq >= (uint32_t)min_mapq) ? ((fl >> 2) & 3u) : 0u;               // H:392-394
+            else if (CLS == 1) hd_hap = (mq >= (uint32_t)min_mapq) ? 1u : 0u;                        // RS:120
+            else if (CLS == 3) hd_hap = (!(fl & VSV_F_SKIP) && mq >= (uint32_t)min_mapq) ? 1u : 0u; // SE:439, 446
+            else hd_hap = (!(fl & (VSV_F_UNMAPPED | VSV_F_SECONDARY)) && mq >= (uint32_t)min_mapq) ? 1u : 0u;
+            hd_hc = (T::HC && (hd_first & 15u) == 5u) ? (hd_first >> 4) : 0u;                       // H:63-65
+          }
+          const uint32_t hapbits = hd_hap;
+          if (hapbits && any_b && lane == 0) atomicOr(&ctr->err, ERRB_REFEND);   // N/=/X on the contig table: H:396 assert
+          if (hapbits && many != 0ull) {
+            const uint32_t sh = (hapbits == 3u) ? 1u : 0u;       // two rows per signature when the name carries both tags
+            uint32_t n, rank;
+            if (__ballot(c > 1u) == 0ull) {                      // (nearly always: at most one candidate per lane)
+              n = (uint32_t)__popcll(many);
+              rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(many >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)many, 0u));
+            } else {
+              const uint32_t incl = wave_incl_scan(c);
+              n = rdlane(incl, 63); rank = incl - c;
+            }
+            const uint32_t nrows = n << sh;
+            if (nrows > (uint32_t)K1L_DSTAGE) { hi_cap = lo + (uint32_t)K1L_DSTAGE / 2u; continue; }   // cut the segment: 96 ops hold at most 192 rows
+            if (n_staged + nrows > (uint32_t)K1L_DSTAGE) flush(false);
+            const uint32_t pos0 = hd_pos + base_r, q0 = base_q + hd_hc;
+            const uint32_t fbits = (in_head ? KD_CARRY : 0u) | ((CLS == 0 && hapbits == 2u) ? KD_HP2 : 0u);
+            if (c != 0u) {
+              uint32_t slot = n_staged + (rank << sh);
+              uint32_t pr = p_pr0, pq = p_pq0;                   // prefix in front of sub-slot k, advanced as k goes up
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                uint32_t wk = pw[k];
+                asm volatile("" : "+v"(wk));   // descriptors are built only by the lanes that hold a candidate: keep the arithmetic here
+                const uint32_t len = wk >> 4;
+                if (e[k]) {
+                  const uint4 d = make_uint4(pos0 + pr, q0 + pq, (wk & ~15u) | ((wk >> 1) & 1u) | fbits, rec);     // (op 1 = I, 2 = D: bit 1 of the op is "DEL")
+                  my_desc[slot] = d;
+                  if (sh) my_desc[slot + 1u] = make_uint4(d.x, d.y, d.z | KD_HP2, d.w);
+                  slot += 1u << sh;
+                }
+                if (k < 3) {
+                  pr += len & (uint32_t)__builtin_amdgcn_sbfe(REF2, wk, 1);
+                  pq += len & (uint32_t)__builtin_amdgcn_sbfe(QRY2, wk, 1);
+                }
+              }
+            }
+            __builtin_amdgcn_wave_barrier();
+            n_staged += nrows; ord += nrows;
+          }
+        }
+      }
+      lo = hi; hi_cap = 0xFFFFFFFFu;
+      if (lo >= cb + 256u) break;
+      if (lo != nxt) continue;                                   // a cut segment: same record, next slice
+      // ---- a record starts at nxt: ops from there on lie px - P(start) behind their record's start ----
+      {
+        const uint32_t ls = (nxt - cb) >> 2, ss = (nxt - cb) & 3u;
+        uint32_t pr = p_pr0, pq = p_pq0;
+        for (uint32_t k = 0; k < ss; ++k) {                      // prefix in front of sub-slot ss of lane ls (wave-uniform trip count)
+          uint32_t wk = k == 0 ? pw[0] : k == 1 ? pw[1] : pw[2];
+          asm volatile("" : "+v"(wk));
+          const uint32_t len = wk >> 4;
+          pr += len & (uint32_t)__builtin_amdgcn_sbfe(REF2, wk, 1);
+          pq += len & (uint32_t)__builtin_amdgcn_sbfe(QRY2, wk, 1);
+        }
+        base_r = 0u - rdlane(pr, ls); base_q = 0u - rdlane(pq, ls);
+      }
+      cur_rec = tbase + ti; in_head = false; has_start = 1;
+      ++ti;
+      nxt = next_start();
+      if (bad) return;
+    }
+    run_r = base_r + p_tot_r; run_q = base_q + p_tot_q;
+  };
+
+  uint32_t cb = 0, slot = 0;
+  while (cb < part_len && !bad) {
+    if (slot == 0 && !pending) { K1L_ARRIVE(wa); stream(wa, cb); issue(wa, cb + 1024); cb += 256; slot = 1; }
+    if (slot == 1 && !pending) { K1L_ARRIVE(wb); stream(wb, cb); issue(wb, cb + 1024); cb += 256; slot = 2; }
+    if (slot == 2 && !pending) { K1L_ARRIVE(wc); stream(wc, cb); issue(wc, cb + 1024); cb += 256; slot = 3; }
+    if (slot == 3 && !pending) { K1L_ARRIVE(wd); stream(wd, cb); issue(wd, cb + 1024); cb += 256; slot = 0; }
+    if (pending) { emit_pending(); pending = false; }
+  }
+  // the last prefetches are still in flight and will write their (clipped, zero) data into the ring registers: the registers stay
+  // reserved until everything has landed — the compiler does not know about loads issued by inline asm
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(wa), "+v"(wb), "+v"(wc), "+v"(wd) : : "memory");
+  if (pending && !bad) emit_pending();
+#undef K1L_ARRIVE
+  // records whose starts were never reached (offsets beyond the part, part cut short by end_all): still validate them
+  while (!bad && tbase + n_tab < r1) stage(tbase + n_tab);
+  flush(true);
+  if (lane == 0) { A.part_count[part] = ord; PartAgg a; a.has_start = has_start; a.run_r = run_r; a.run_q = run_q; A.agg[part] = a; }
+}
+
 // ---- carry of the long-record scan: segmented exclusive scan over the parts --------------------------------------------
 // x[p] = (has_start, run): S = x[0] (+) ... (+) x[p-1] with (f1,v1) (+) (f2,v2) = (f1|f2, f2 ? v2 : v1+v2); carry[p] = S.v.
 // Same three-kernel shape as the count scan below; the counts' exclusive sum (part_off) rides along.
@@ -1004,6 +1387,93 @@ __global__ __launch_bounds__(256) void k1l_scan_apply(const PartAgg* __restrict_
   for (int k = 0; k < 8; ++k) {
     if (base + k < n) { part_off[base + k] = run.cnt; carry_r[base + k] = run.r; carry_q[base + k] = run.q; }
     run = carry_op(run, it[k]);
+  }
+}
+
+// ---- placement of the long scan's descriptors: part scan by look-back + rows, one launch ------------------------------------------
+// A block owns 256 consecutive parts: their (has_start, advance, rows) are scanned in LDS, the block's aggregate goes through the
+// look-back over the BLOCKS in front (lb_publish / lb_resolve: every block reaches it a few microseconds after it starts and all
+// blocks are alike, so nobody waits long), and then the block's rows — consecutive in T_RAW — are built from the descriptors of its
+// parts' batches and stored coalesced. part_off / carries go to memory for the batches of the overflow list (k1l_place_batches).
+struct PlaceArgs {
+  const uint4* dpool; const uint32_t* shard_cnt; uint32_t shard_cap;
+  const uint2* prec; const uint32_t* part_count; const PartAgg* agg; int n_parts;
+  uint64_t* lbw; uint32_t epoch;
+  const int32_t* tid; vsv_sig* raw; uint32_t cap; Counters* ctr;
+  uint32_t* part_off; uint32_t* carry_r; uint32_t* carry_q; int no_qend;
+};
+constexpr int PL_PARTS = 256;
+__global__ __launch_bounds__(256) void k1l_place(PlaceArgs A) {
+  __shared__ CarryItem sh[256];
+  __shared__ uint32_t s_off[PL_PARTS + 1], s_cr[PL_PARTS], s_cq[PL_PARTS], s_loc[PL_PARTS], s_first[PL_PARTS];
+  __shared__ uint32_t s_ex[4];
+  const int t = threadIdx.x, lane = t & 63;
+  const int part = blockIdx.x * PL_PARTS + t;
+  CarryItem it{0, 0, 0, 0};
+  uint2 pr = make_uint2(0u, 0u);
+  if (part < A.n_parts) { const PartAgg a = A.agg[part]; it.f = a.has_start; it.r = a.run_r; it.q = a.run_q; it.cnt = A.part_count[part]; pr = A.prec[part]; }
+  k1l_block_scan(it, sh);                           // sh[t] = parts [block start, t] combined
+  if (t < 64) {                                     // (one whole wave: the look-back is wave-cooperative)
+    const CarryItem tot = sh[255];
+    LbItem own; own.f = tot.f; own.r = tot.r; own.q = tot.q; own.cnt = tot.cnt;
+    lb_publish(A.lbw, A.epoch, blockIdx.x, own, LB_AGG, lane);
+    const LbItem ex = lb_resolve(A.lbw, A.epoch, blockIdx.x, own, lane, &A.ctr->err);
+    if (lane == 0) { s_ex[0] = ex.f; s_ex[1] = ex.r; s_ex[2] = ex.q; s_ex[3] = ex.cnt; }
+  }
+  __syncthreads();
+  {
+    CarryItem ex{s_ex[0], s_ex[1], s_ex[2], s_ex[3]};
+    if (t > 0) ex = carry_op(ex, sh[t - 1]);
+    s_off[t] = ex.cnt; s_cr[t] = ex.r; s_cq[t] = ex.q; s_loc[t] = pr.x; s_first[t] = it.cnt - pr.y;
+    if (t == 255) s_off[PL_PARTS] = ex.cnt + it.cnt;
+    if (part < A.n_parts) { A.part_off[part] = ex.cnt; A.carry_r[part] = ex.r; A.carry_q[part] = ex.q; }
+    if (part == A.n_parts - 1) {                    // the table's size, and what a retry would have to reserve
+      const uint64_t total = (uint64_t)ex.cnt + it.cnt;
+      A.ctr->n_raw = total < (uint64_t)A.cap ? (uint32_t)total : A.cap;
+      atomicMax(&A.ctr->n_pool, total > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)total);
+      if (total > (uint64_t)A.cap) atomicOr(&A.ctr->err, ERRB_CAPACITY);
+    }
+  }
+  if (blockIdx.x == 0) {                            // a shard that overflowed: rows are missing, and a retry needs shards of that size
+    const uint32_t used = A.shard_cnt[t * 16];      // (K1_SHARDS == 256 threads)
+    if (used > A.shard_cap) {
+      atomicOr(&A.ctr->err, ERRB_CAPACITY);
+      const uint64_t need = ((uint64_t)used * K1_SHARDS + 1) / 2;           // rows of capacity = 2 descriptors each
+      atomicMax(&A.ctr->n_pool, need > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)need);
+    }
+  }
+  __syncthreads();
+  const uint32_t off0 = s_off[0], rows = s_off[PL_PARTS] - off0;
+  for (uint32_t i = t; i < rows; i += 256) {
+    const uint32_t row = off0 + i;
+    uint32_t lo = 0, hi = PL_PARTS;                 // the part p with s_off[p] <= row < s_off[p + 1]
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_off[mid] <= row) lo = mid; else hi = mid; }
+    const uint32_t o = row - s_off[lo];
+    if (o < s_first[lo] || row >= A.cap) continue;  // (a row of an earlier batch of the part: k1l_place_batches)
+    const uint4 d = A.dpool[s_loc[lo] + (o - s_first[lo])];
+    uint4 lo4, hi4;
+    k1l_row(d, s_cr[lo], s_cq[lo], (uint32_t)A.tid[d.w], A.no_qend != 0, lo4, hi4);
+    uint4* dst = reinterpret_cast<uint4*>(A.raw + row);
+    dst[0] = lo4; dst[1] = hi4;
+  }
+}
+// the batches a part filed before its last one (a part with more candidates than its stage holds): a wave per batch
+__global__ __launch_bounds__(256) void k1l_place_batches(const uint4* __restrict__ batches, const uint32_t* __restrict__ n_batches, uint32_t batch_cap,
+                                                         const uint4* __restrict__ dpool, const uint32_t* __restrict__ part_off, const uint32_t* __restrict__ carry_r,
+                                                         const uint32_t* __restrict__ carry_q, const int32_t* __restrict__ tid, vsv_sig* __restrict__ raw, uint32_t cap, int no_qend) {
+  const uint32_t nb = min(*n_batches, batch_cap);
+  const int lane = threadIdx.x & 63;
+  for (uint32_t e = blockIdx.x * 4 + (threadIdx.x >> 6); e < nb; e += gridDim.x * 4) {
+    const uint4 b = batches[e];                     // {part, first ordinal, location, descriptors}
+    const uint32_t row0 = part_off[b.x] + b.y, cr = carry_r[b.x], cq = carry_q[b.x];
+    for (uint32_t i = lane; i < b.w; i += 64) {
+      if (row0 + i >= cap) break;
+      const uint4 d = dpool[b.z + i];
+      uint4 lo4, hi4;
+      k1l_row(d, cr, cq, (uint32_t)tid[d.w], no_qend != 0, lo4, hi4);
+      uint4* dst = reinterpret_cast<uint4*>(raw + row0 + i);
+      dst[0] = lo4; dst[1] = hi4;
+    }
   }
 }
 
@@ -1176,7 +1646,17 @@ void vsv_launch_cigar_scan(hipStream_t st, const RecView& rv, const vsv_params& 
                            hipEvent_t ev0, hipEvent_t ev1, const LongScanBufs& lb) {
   if (n_parts <= 0) return;
   const bool long_mode = vsv_scan_is_long(rv, p);
-  if (long_mode) { n_parts = vsv_cigar_parts_long(rv.n_ops); ops_per_part = K1L_PART; }
+  static const char* k1l = vsv_dbg_env("VSV_K1L");                   // timing experiments / tests: "pool" = round 3's scan + placement pass
+  const bool long_pool = long_mode && ((k1l && k1l[0] == 'p') || !lb.lbw);
+  if (long_mode && long_pool) { n_parts = vsv_cigar_parts_long(rv.n_ops); ops_per_part = K1L_PART; }
+  if (long_mode && !long_pool) {
+    static const int forced = vsv_dbg_env("VSV_K1L_PART") ? atoi(vsv_dbg_env("VSV_K1L_PART")) : 0;      // timing experiments / tests
+    int64_t po = K1L_PART;
+    if (forced >= 256 && forced % 256 == 0) po = forced;
+    if (po < ops_per_part) po = ((ops_per_part + 255) / 256) * 256;        // (the part tables are sized for the read-shaped part length)
+    ops_per_part = (int)po;
+    n_parts = vsv_cigar_parts(rv.n_ops, ops_per_part);
+  }
   if (!lb.arena_zeroed) (void)hipMemsetAsync(shard_cnt, 0, K1_SHARDS * 16 * sizeof(uint32_t), st);
   if (n_parts < (1 << 20)) partition_search<<<(n_parts + 1 + 255) / 256, 256, 0, st>>>(rv.cigar_off, rv.n_records, part_rb, n_parts, ops_per_part, rv.n_ops, 1);
   else {
@@ -1192,9 +1672,12 @@ void vsv_launch_cigar_scan(hipStream_t st, const RecView& rv, const vsv_params& 
   static const int depth = vsv_dbg_env("VSV_K1_DEPTH") ? atoi(vsv_dbg_env("VSV_K1_DEPTH")) : 4;     // chunks in flight per wave (3 or 4)
   const int n_tiles = (n_parts + SCAN_TILE - 1) / SCAN_TILE;
   uint32_t* tsum = nullptr;
+  const uint32_t dshard_cap = (uint32_t)(((uint64_t)cap * 2) / K1_SHARDS);      // the row pool holds two 16-byte descriptors per row
 #define K1_LAUNCH(CLS)                                                                                                          \
   do {                                                                                                                          \
-    if (long_mode) cigar_scan_long<CLS><<<grid, 256, 0, st>>>(rv, part_rb, n_parts, p.min_svlen, p.min_cigar_mapq, ec, part_count, (PartAgg*)lb.agg, ablate); \
+    if (long_mode && !long_pool) cigar_scan_long<CLS><<<grid, 256, 0, st>>>(K1LArgs{rv, part_rb, ctr, (uint4*)pool, shard_cnt, dshard_cap, (uint4*)pool_key, cap / 2, \
+                                                                             (uint2*)lb.prec, part_count, (PartAgg*)lb.agg, n_parts, p.min_svlen, p.min_cigar_mapq, (uint32_t)ops_per_part, ablate}); \
+    else if (long_mode) cigar_scan_long_pool<CLS><<<grid, 256, 0, st>>>(rv, part_rb, n_parts, p.min_svlen, p.min_cigar_mapq, ec, part_count, (PartAgg*)lb.agg, ablate); \
     else if (CLS == 0 && lb.clr_fused) cigar_scan_emit<0, 4, true><<<grid, 256, 0, st>>>(rv, part_rb, n_parts, p.min_svlen, p.min_cigar_mapq, ec, part_count, ablate, tsum); \
     else if (depth == 4) cigar_scan_emit<CLS, 4><<<grid, 256, 0, st>>>(rv, part_rb, n_parts, p.min_svlen, p.min_cigar_mapq, ec, part_count, ablate, tsum); \
     else cigar_scan_emit<CLS, 3><<<grid, 256, 0, st>>>(rv, part_rb, n_parts, p.min_svlen, p.min_cigar_mapq, ec, part_count, ablate, tsum);            \
@@ -1206,6 +1689,13 @@ void vsv_launch_cigar_scan(hipStream_t st, const RecView& rv, const vsv_params& 
 #undef K1_LAUNCH
   if (ev1) (void)hipEventRecord(ev1, st);
   const bool add_qend = !(p.dtype == VSV_DTYPE_READS || p.dtype == VSV_DTYPE_CUTESV);
+  if (long_mode && !long_pool) {
+    const int no_qend = add_qend ? 0 : 1;
+    k1l_place<<<(n_parts + PL_PARTS - 1) / PL_PARTS, 256, 0, st>>>(PlaceArgs{(const uint4*)pool, shard_cnt, dshard_cap, (const uint2*)lb.prec, part_count, (const PartAgg*)lb.agg,
+                                                                   n_parts, lb.lbw, lb.epoch, rv.tid, raw, cap, ctr, part_off, lb.carry_r, lb.carry_q, no_qend});
+    k1l_place_batches<<<64, 256, 0, st>>>((const uint4*)pool_key, shard_cnt + 8, cap / 2, (const uint4*)pool, part_off, lb.carry_r, lb.carry_q, rv.tid, raw, cap, no_qend);
+    return;
+  }
   if (long_mode) {
     const int tiles = (n_parts + K1L_SCAN_TILE - 1) / K1L_SCAN_TILE;
     k1l_scan_tiles<<<tiles, 256, 0, st>>>((const PartAgg*)lb.agg, part_count, n_parts, (CarryItem*)lb.tile_sum);
@@ -1220,9 +1710,14 @@ void vsv_launch_cigar_scan(hipStream_t st, const RecView& rv, const vsv_params& 
   place_raw<<<K1_SHARDS * PLACE_CHUNKS, 256, 0, st>>>(pool, pool_key, shard_cnt, cap / K1_SHARDS, part_off, part_count, n_parts, raw, cap, ctr,
                                        lb.carry_r, lb.carry_q, add_qend);
 }
-size_t vsv_long_scan_bytes(int64_t n_ops, int which) {   // 0: PartAgg[], 1: carry (u32 per part), 2: tile sums
-  const size_t n_parts = (size_t)vsv_cigar_parts_long(n_ops) + 2;
-  return which == 0 ? n_parts * sizeof(PartAgg) : which == 1 ? n_parts * sizeof(uint32_t) : (n_parts / K1L_SCAN_TILE + 2) * sizeof(CarryItem);
+size_t vsv_lookback_bytes(int64_t n_ops, int ops_per_part) {
+  const size_t a = (size_t)vsv_cigar_parts_long(n_ops) + 16, b = (size_t)vsv_cigar_parts(n_ops, ops_per_part) + 16;
+  return (a > b ? a : b) * 3 * sizeof(uint64_t);
+}
+size_t vsv_long_scan_bytes(int64_t n_ops, int which, int ops_per_part) {   // 0: PartAgg[], 1: carry (u32 per part), 2: tile sums, 3: last-batch records
+  const size_t pa = (size_t)vsv_cigar_parts_long(n_ops), pb = (size_t)vsv_cigar_parts(n_ops, ops_per_part);      // (the long scan's parts are never shorter than the read-shaped ones)
+  const size_t n_parts = (pa > pb ? pa : pb) + 16;
+  return which == 0 ? n_parts * sizeof(PartAgg) : which == 1 ? n_parts * sizeof(uint32_t) : which == 3 ? n_parts * sizeof(uint2) : (n_parts / K1L_SCAN_TILE + 2) * sizeof(CarryItem);
 }
 
 // ---- streaming ceiling of this part, measured with the library's own kernels -----------------------------------

@@ -22,6 +22,7 @@ enum : uint32_t {
   ERRB_CLR_FALLBACK = 1u << 9,   // a part too long for the gate state of the fused CLR scan: the run is repeated with the separate gate pass
   ERRB_SORT_FALLBACK = 1u << 7,  // a bucket of the bucket sort did not fit in LDS: the run is repeated with the LSD passes
   ERRB_MERGE_FALLBACK = 1u << 11, // a rank-and-merge sort of the element path met a window it cannot decide (thousands of slots within one shift): the run is repeated with the LSD passes
+  ERRB_LOOKBACK = 1u << 12,      // a part of the scan waited for its predecessors' row counts beyond every plausible time (cigar_scan.hip, look-back): internal error
   ERRB_SLIM_FALLBACK = 1u << 10, // an svlen outside [0, 2^30) or a position of 2^30 and more met the element path (32-bit predicates): the run is repeated on rows
 };
 
@@ -167,9 +168,12 @@ struct LongScanBufs {   // scratch of the scan launcher beyond the part tables
   uint32_t* tile_cnt; int tile_cnt_cap;    // read-shaped scan: zeroed per run, the waves add their part counts per 2048-part tile
   bool arena_zeroed;                       // the caller zeroed shard_cnt together with the counters
   bool clr_fused;                          // CLR, read-shaped scan: the gate is computed inside the scan (flags arrive ungated)
+  uint64_t* lbw; uint32_t epoch;           // look-back words of the placement kernel's scan (3 per block of parts), and this run's epoch
+  void* prec;                              // long-record scan: {location, descriptors} of every part's last batch
 };
+size_t vsv_lookback_bytes(int64_t n_ops, int ops_per_part);
 bool vsv_scan_is_long(const RecView& rv, const vsv_params& p);
-size_t vsv_long_scan_bytes(int64_t n_ops, int which);
+size_t vsv_long_scan_bytes(int64_t n_ops, int which, int ops_per_part);
 void vsv_launch_cigar_scan(hipStream_t st, const RecView& rv, const vsv_params& p, uint32_t* part_rb, int n_parts,
                            int ops_per_part, vsv_sig* pool, uint64_t* pool_key, uint32_t cap, uint32_t* part_count,
                            uint32_t* part_off, uint32_t* scan_tmp, vsv_sig* raw, Counters* ctr, uint32_t* shard_cnt,
