@@ -1170,21 +1170,44 @@ __global__ __launch_bounds__(256) void cigar_scan_long(K1LArgs A) {
       const uint32_t t = (BAD_R << (w[0] & 31u)) | (BAD_R << (w[1] & 31u)) | (BAD_R << (w[2] & 31u)) | (BAD_R << (w[3] & 31u));
       bd = (int32_t)t < 0;
     }
-    uint32_t sum_r = 0, sum_q = 0;
+    uint32_t ar[4], aq[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const uint32_t len = w[k] >> 4;
-      sum_r += len & (uint32_t)__builtin_amdgcn_sbfe(REF2, w[k], 1);
-      sum_q += len & (uint32_t)__builtin_amdgcn_sbfe(QRY2, w[k], 1);
+      ar[k] = len & (uint32_t)__builtin_amdgcn_sbfe(REF2, w[k], 1);
+      aq[k] = len & (uint32_t)__builtin_amdgcn_sbfe(QRY2, w[k], 1);
     }
+    const uint32_t r1 = ar[0], r2 = r1 + ar[1], r3 = r2 + ar[2], sum_r = r3 + ar[3];      // (the partial sums: what a candidate in sub-slot k has in front of it in its lane)
+    const uint32_t q1 = aq[0], q2 = q1 + aq[1], q3 = q2 + aq[2], sum_q = q3 + aq[3];
     const uint32_t incl_r = wave_incl_scan(sum_r), incl_q = wave_incl_scan(sum_q);
     const uint32_t tot_r = rdlane(incl_r, 63), tot_q = rdlane(incl_q, 63);
-    const bool any_cand = __ballot(e0 | e1 | e2 | e3 | bd) != 0ull && !(ablate & 1);
+    const uint64_t m_bd = __ballot(bd);
+    const uint64_t m0 = __ballot(e0), m1 = __ballot(e1), m2 = __ballot(e2), m3 = __ballot(e3);
+    const uint64_t m01 = m0 | m1, m012 = m01 | m2, many = m012 | m3;
+    const bool any_cand = (many | m_bd) != 0ull && !(ablate & 1);
     if (!any_cand && !(nxt < cb + 256u)) { run_r += tot_r; run_q += tot_q; return; }
+    // The usual chunk of a contig pile — every second one holds a candidate, nearly always exactly one: no record starts inside, nothing the
+    // table forbids, the record's header is cached and carries one haplotype, at most one candidate per lane, room in the stage. Its
+    // descriptors are built without a branch (the sub-slot's values by selects) and without the segment loop of the general block
+    // below, which cost ~100 scalar + ~50 vector instructions per such chunk.
+    if (!(nxt < cb + 256u) && m_bd == 0ull && cur_rec == hd_rec && (hd_hap == 1u || hd_hap == 2u) && n_staged + 64u <= (uint32_t)K1L_DSTAGE &&
+        ((m0 & m1) | (m01 & m2) | (m012 & m3)) == 0ull && !(ablate & 2)) {
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(many >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)many, 0u));
+      uint32_t wk = e2 ? w[2] : w[3], fr = e2 ? r2 : r3, fq = e2 ? q2 : q3;
+      wk = e1 ? w[1] : wk; fr = e1 ? r1 : fr; fq = e1 ? q1 : fq;
+      wk = e0 ? w[0] : wk; fr = e0 ? 0u : fr; fq = e0 ? 0u : fq;
+      const uint32_t fbits = (in_head ? KD_CARRY : 0u) | ((CLS == 0 && hd_hap == 2u) ? KD_HP2 : 0u);
+      const uint4 d = make_uint4(hd_pos + run_r + (incl_r - sum_r) + fr, run_q + hd_hc + (incl_q - sum_q) + fq, (wk & ~15u) | ((wk >> 1) & 1u) | fbits, hd_rec);
+      if (e0 | e1 | e2 | e3) my_desc[n_staged + rank] = d;
+      const uint32_t n = (uint32_t)__popcll(many);
+      n_staged += n; ord += n;
+      run_r += tot_r; run_q += tot_q;
+      return;
+    }
     pw[0] = w[0]; pw[1] = w[1]; pw[2] = w[2]; pw[3] = w[3];
     pe0 = e0 && !(ablate & 1); pe1 = e1 && !(ablate & 1); pe2 = e2 && !(ablate & 1); pe3 = e3 && !(ablate & 1);
     p_pr0 = incl_r - sum_r; p_pq0 = incl_q - sum_q;
-    p_badany = any_cand && __ballot(bd) != 0ull;
+    p_badany = any_cand && m_bd != 0ull;
     p_cb = cb; p_tot_r = tot_r; p_tot_q = tot_q;
     pending = true;
   };
