@@ -211,6 +211,13 @@ int vsv_finish(vsv_handle* h);
  * scan (repeated with the separate gate pass). Results are identical either way; a bench line reports the count so that a hidden
  * repetition inside a timed region is visible. */
 int64_t vsv_rerun_count(vsv_handle* h);
+/* Measurement aid: which form of the stages behind the split stage the handle's runs took, and whether a cold handle had to wait.
+ * element_runs: runs (or staged vsv_sort_cluster calls) whose sort / cluster / merge / pair stages worked on 16-byte elements — the
+ * form for tables beyond ~1.3 M rows (10^6-10^7: contig alignments piled on one chromosome, ONT-scale read sets); the others took
+ * the row form. cold_syncs: fused runs of a handle without history (its first one — every invocation of the drop-in CLI, which runs
+ * one chromosome per process like Raw_variant_call.py:65-73) that waited for the scan once to take the row count from it, so that
+ * the first run of a handle takes the same path as a later one. Either pointer may be NULL. Results never depend on the path. */
+int vsv_path_counts(vsv_handle* h, int64_t* element_runs, int64_t* cold_syncs);
 
 /* two-phase readback: count, then fill a caller buffer (host or device) */
 int vsv_table_count(vsv_handle* h, int table, int64_t* n_rows);

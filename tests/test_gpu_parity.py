@@ -319,6 +319,49 @@ def test_staged_api_equals_fused(eng):
     assert_tables_equal(eng.tables(DTYPE_HIFI), fused2, list(fused2.keys()))
 
 
+def test_staged_api_stages_called_again(eng):
+    """A staged stage may be called again on the same run, e.g. with another threshold (include/volcanosv.h): whatever it and the
+    stages behind it produce equals a fused run with the thresholds that were in force when each stage last ran — on rows and (the
+    element path of large tables consumes its inputs: VSV_BIG=1 child suites) on elements. Long-record and read-shaped scans."""
+    from volcanosv_amd import synth
+    from volcanosv_amd.abi import SCAN_CONTIGS, SCAN_READS
+    from volcanosv_amd.engine import default_params
+    t, nq, _ = synth.generate(30000, "hifi", seed=9, chrom_len=600000, events_per_record=0.3, site_step=500)
+    soa = synth.to_soa(t, nq)
+    for layout in (SCAN_READS, SCAN_CONTIGS):
+        p = default_params(DTYPE_HIFI)
+        p.scan_layout = layout
+        q = default_params(DTYPE_HIFI)
+        q.scan_layout = layout
+        q.cluster_shift = 40
+        r = default_params(DTYPE_HIFI)
+        r.scan_layout = layout
+        r.cluster_shift = 40
+        r.pair_shift = 80
+        st, want_p = oracle_run(soa, DTYPE_HIFI, p)
+        st2, want_q = oracle_run(soa, DTYPE_HIFI, q)
+        st3, want_r = oracle_run(soa, DTYPE_HIFI, r)
+        assert st == 0 and st2 == 0 and st3 == 0
+        names = ["cigar", "split", "cluster1", "merged", "calls"]
+        eng.cigar_scan(soa, p)
+        eng.split_pairs(p)
+        eng.sort_cluster(p)
+        eng.sort_cluster(q)                       # again, another shift: cluster1 is the second call's
+        assert np.array_equal(eng.table("cluster1"), want_q["cluster1"])
+        eng.merge_sources(q)
+        eng.merge_sources(q)                      # again: same tables
+        assert np.array_equal(eng.table("merged"), want_q["merged"])
+        eng.pair_haplotypes(q)
+        eng.pair_haplotypes(r)                    # again, another pair_shift
+        got = {k: eng.table(k) for k in names + ["raw"]}
+        assert_tables_equal(got, want_r, names + ["raw"])
+        eng.sort_cluster(p)                       # and back to the defaults from the first stage on
+        eng.merge_sources(p)
+        eng.pair_haplotypes(p)
+        got = {k: eng.table(k) for k in names + ["raw"]}
+        assert_tables_equal(got, want_p, names + ["raw"])
+
+
 def test_split_overlap_modes_give_the_same_tables(eng):
     """vsv_params.split_overlap: the fused run builds the split candidates on the handle's auxiliary stream beside the scan (AUTO) or
     on the handle's stream (OFF); a timing choice only. Alternating runs on one handle, read-shaped and contig-shaped input, all
@@ -1078,6 +1121,43 @@ def test_full_size_row2c_contigs():
         assert st == 0 and len(want["calls"]) > 150_000
         assert_tables_equal(got, want, list(got.keys()))
     del t, sl
+    torch.cuda.empty_cache()
+
+
+def test_cold_engine_takes_the_element_path_on_a_contig_pile():
+    """The drop-in CLI runs one chromosome per process (Raw_variant_call.py:65-73): every run is the first of its handle. A fused run
+    of a handle without history waits for the scan once and takes the row count from it, so a pile of contigs (here 20 k contigs,
+    ~630 k raw signatures... above the row path's ~1.3 M-row limit only at full size: the limit is lowered for the test through the
+    row capacity hint) runs its stages on elements from the first run on: vsv_path_counts reports it, and the tables equal the
+    oracle's. A second engine that has seen the input before reports the same path without a wait."""
+    import torch
+    from volcanosv_amd import synth
+    from volcanosv_amd.engine import DeviceRecords, Engine, default_params
+    t, nq, nt = synth.generate(45_000, "contig", seed=20250328 + 6, tid=0, chrom_len=synth.CHR10_LEN, device="cuda")
+    p = default_params(DTYPE_HIFI)
+    dr = DeviceRecords(t, nq, 1, max_pos=synth.CHR10_LEN + 200000, tid_lo=0)
+    with Engine(0, max_sigs=1 << 23) as e:
+        assert e.path_counts() == (0, 0)
+        e.run(dr, p)
+        cold = {k: e.table(k) for k in ("raw", "cigar", "merged", "calls")}
+        assert len(cold["raw"]) > 1_350_000
+        assert e.path_counts() == (1, 1) and e.rerun_count() == 0           # elements on the first run, after one wait for the scan
+        e.run(dr, p)
+        warm = {k: e.table(k) for k in ("raw", "cigar", "merged", "calls")}
+        assert e.path_counts() == (2, 1)
+        assert_tables_equal(warm, cold, list(cold.keys()))
+    k = 6_000
+    n_ops = int(t["cigar_off"][k])
+    sl = {name: (v[: k + 1] if name == "cigar_off" else v[:n_ops] if name == "cigar" else v[:k]) for name, v in t.items()}
+    nq_k = int(sl["qid"].max()) + 1
+    with Engine(0, max_sigs=1 << 22) as e:                                  # a cold engine on the prefix the oracle finishes in seconds
+        e.run(DeviceRecords(sl, nq_k, 1, max_pos=synth.CHR10_LEN + 200000), p)
+        got = e.tables(DTYPE_HIFI)
+        assert e.path_counts()[1] == 1
+    st, want = oracle_run(synth.to_soa({n: v.cpu() for n, v in sl.items()}, nq_k), DTYPE_HIFI, p)
+    assert st == 0 and len(want["calls"]) > 40_000
+    assert_tables_equal(got, want, list(got.keys()))
+    del t, sl, dr
     torch.cuda.empty_cache()
 
 

@@ -92,6 +92,12 @@ struct vsv_handle {
   void* sl_e2 = nullptr;           // stage-1 cluster output (n_alive1 slots)
   void* sl_m = nullptr;            // merged elements (n_alive3)
   bool c1_stale = false, merged_stale = false;      // VSV_T_CLUSTER1 / VSV_T_MERGED rows not gathered yet
+  int raw_state = 0;               // VSV_T_RAW: 0 = in raw0; 1 = the scan placed its rows straight into the stage-1 table, raw0 is filled from the
+                                   // scan's descriptors when somebody asks; 2 = those are gone (buffers re-allocated since)
+  int raw_parts = 0;               // ... parts of that scan
+  bool have_history = false;       // a signature run of this handle has finished: host_ctr describes real tables (else: a COLD handle)
+  bool ctr_of_run = false;         // host_ctr holds the counters of the run in progress (a staged call's finish()), not of the previous one
+  int64_t element_runs = 0, cold_syncs = 0;          // vsv_path_counts
   vsv_bnd_params bnd_prm{};
   Counters host_ctr;
   Counters* pinned = nullptr;
@@ -142,10 +148,13 @@ int bits_for(uint64_t n) { int b = 1; while ((1ull << b) < n && b < 63) ++b; ret
 
 int reserve(vsv_handle* h, int64_t max_records, int64_t max_ops, int64_t max_sigs) {
   if (max_sigs < 1024) max_sigs = 1024;
+  if ((max_sigs > h->cap_sigs || max_ops > h->cap_ops || max_records > h->cap_records) && h->raw_state == 1) h->raw_state = 2;   // the descriptors move
   if (max_records < 1) max_records = 1;
   if (max_ops < 1) max_ops = 1;
   if (max_sigs > h->cap_sigs) {
     const size_t n = (size_t)max_sigs;
+    h->stage_done = 0; h->bnd_stage = 0; h->cutesv_rows = -1;      // the row buffers move: the tables of the last run are gone
+    h->c1_stale = h->merged_stale = false; h->sl_e2 = nullptr; h->sl_m = nullptr;
     DevBuf* sigbufs[] = {&h->pool, &h->raw0, &h->s1in, &h->s1s, &h->c1, &h->s2s, &h->c2, &h->merged, &h->reads};
     for (DevBuf* b : sigbufs) { int st = ensure(h, *b, n * sizeof(vsv_sig)); if (st) return st; }
     DevBuf* callbufs[] = {&h->calls_tmp, &h->calls};
@@ -286,10 +295,23 @@ int reset_run_state(vsv_handle* h) {
   h->group_cursor = 0;
   return 0;
 }
+// a staged stage called AGAIN on the same run (e.g. another cluster_shift): the sort scratch of the run starts over — per-pass digit
+// totals, tile counts, group sums; the counters and the scan's cursors (VSV_T_RAW may still be placed from them) stay
+int reenter_reset(vsv_handle* h) {
+  HIPCHK(h, hipMemsetAsync((char*)h->arena.p + ARENA_CTR + ARENA_SHARD, 0, ARENA_BYTES - ARENA_CTR - ARENA_SHARD, h->stream));
+  h->pass_cursor = 0;
+  h->group_cursor = 0;
+  return 0;
+}
 int tid_bits(vsv_handle* h);
+LongScanBufs long_bufs(vsv_handle* h, bool clr_fused, void* fused_rows, const SlimOut& so) {
+  return LongScanBufs{h->l_agg.p, (uint32_t*)h->l_carry_r.p, (uint32_t*)h->l_carry_q.p, h->l_tiles.p, h->tile_cnt, 4096, true, clr_fused,
+                      (uint64_t*)h->lbw.p, h->lb_epoch, h->l_prec.p, fused_rows, so};
+}
 bool want_big(vsv_handle* h);
 bool big_allowed(vsv_handle* h);
 int slim_work(vsv_handle* h, SlimWork& w);
+int slim_alloc(vsv_handle* h, bool all);
 int sort_bits(vsv_handle* h);
 // blocks of the row-parallel kernels: one row per thread for the largest table of the handle's previous run (+25 %), between 128
 // and 4096 blocks; a first run sizes for the row capacity. Every such kernel grid-strides, so this is speed only.
@@ -340,6 +362,11 @@ int enq_scan(vsv_handle* h) {
   if (h->row_runs > 0 && !h->in_rerun) --h->row_runs;
   if (h->lsd_slim_runs > 0 && !h->in_rerun) --h->lsd_slim_runs;
   h->cutesv_rows = -1;   // the split-candidate table shares a buffer with the merge stage
+  h->ctr_of_run = false;
+  if (is_contig(h->prm.dtype)) {   // the element buffers this run may need exist before its first launch (a large-table handle: all of them)
+    int as = slim_alloc(h, want_big(h) || !h->have_history);
+    if (as) return as;
+  }
   const int n_parts = vsv_cigar_parts(h->rv.n_ops, OPS_PER_PART);
   RecView srv = h->rv;
   // CLR: the read-shaped scan carries the gate itself (cigar_scan_emit<0, 4, true>); the long-record scan, and a handle whose fused
@@ -363,24 +390,42 @@ int enq_scan(vsv_handle* h) {
     HIPCHK(h, hipMemsetAsync(h->lbw.p, 0, h->lbw.bytes, st));
     h->lb_epoch = 1;
   }
+  // contig alignments through the long scan: the placement writes the rows straight into the stage-1 input table, next to their
+  // elements, and the fold runs there in place (VSV_T_RAW is re-placed from the scan's descriptors when somebody asks)
+  const int long_parts = vsv_long_scan_parts(srv, h->prm, OPS_PER_PART);
+  const bool fused = is_contig(h->prm.dtype) && long_parts > 0;
+  SlimOut so_f{nullptr, 0, 0, 0, nullptr};
+  if (fused) so_f = SlimOut{h->sl[0].p, pos_bits(h), h->rv.tid_lo, tid_bits(h), &dctr(h)->err};
   vsv_launch_cigar_scan(st, srv, h->prm, (uint32_t*)h->part_rb.p, n_parts, OPS_PER_PART, (vsv_sig*)h->pool.p,
                         (uint64_t*)h->pool_key.p, (uint32_t)h->cap_sigs, (uint32_t*)h->part_count.p, (uint32_t*)h->part_off.p,
                         (uint32_t*)h->scan_tmp.p, (vsv_sig*)h->raw0.p, dctr(h), (uint32_t*)h->shard_cnt.p, h->ev0, h->ev1,
-                        LongScanBufs{h->l_agg.p, (uint32_t*)h->l_carry_r.p, (uint32_t*)h->l_carry_q.p, h->l_tiles.p, h->tile_cnt, 4096, true, clr_fused,
-                                     (uint64_t*)h->lbw.p, h->lb_epoch, h->l_prec.p});
+                        long_bufs(h, clr_fused, fused ? h->s1in.p : nullptr, so_f));
   h->have_scan_ev = n_parts > 0;
+  h->raw_state = fused ? 1 : 0;
+  h->raw_parts = long_parts;
+  h->sl_prebuilt = false;
+  if (fused) { vsv_launch_fold_elems(st, (vsv_sig*)h->s1in.p, dctr(h), ew_grid(h), so_f); h->sl_prebuilt = true; }
+  // A COLD handle knows nothing about its tables — and every invocation of the drop-in CLI is one (one process per chromosome,
+  // Raw_variant_call.py:65-73): the fused run waits for the scan once and takes the row count from it, so that the path, the sort
+  // form and the grids of the stages behind it are those a warm handle would use.
+  if (h->fork_split && !h->have_history && !h->in_rerun && is_contig(h->prm.dtype) && h->rv.n_records > 0) {
+    HIPCHK(h, hipMemcpyAsync(h->pinned, h->ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    const Counters c = *h->pinned;
+    if (!(c.err & ERRB_CAPACITY)) { h->host_ctr.n_raw = c.n_raw; h->host_ctr.n_s1 = c.n_raw; h->small_sort_tiles = c.n_raw <= 128u * 4096u; }
+    ++h->cold_syncs;
+  }
   // the path of the stages behind the split stage is decided here, so that the fold (and split_eval) can write the elements of a
   // large-table run next to their rows
   h->big_run = want_big(h) && big_allowed(h) && 4 * vsv_slim_sort_passes(sort_bits(h)) + 16 <= MAX_SORT_PASSES;
-  h->sl_prebuilt = false;
-  SlimOut so{nullptr, 0, 0, 0, nullptr};
-  if (h->big_run) {
-    SlimWork w;
-    { int ws = slim_work(h, w); if (ws) return ws; }
-    so = SlimOut{w.buf[0], pos_bits(h), h->rv.tid_lo, tid_bits(h), &dctr(h)->err};
-    h->sl_prebuilt = true;
+  if (!fused) {
+    SlimOut so{nullptr, 0, 0, 0, nullptr};
+    if (h->big_run) {
+      so = SlimOut{h->sl[0].p, pos_bits(h), h->rv.tid_lo, tid_bits(h), &dctr(h)->err};
+      h->sl_prebuilt = true;
+    }
+    vsv_launch_fold(st, (const vsv_sig*)h->raw0.p, (vsv_sig*)h->s1in.p, h->rv, h->prm, dctr(h), ew_grid(h), so);
   }
-  vsv_launch_fold(st, (const vsv_sig*)h->raw0.p, (vsv_sig*)h->s1in.p, h->rv, h->prm, dctr(h), ew_grid(h), so);
   HIPCHK(h, hipGetLastError());
   if (early_cands) {
     if (fork) HIPCHK(h, hipStreamWaitEvent(h->aux, h->ev_fork, 0));
@@ -400,7 +445,7 @@ int enq_split(vsv_handle* h) {
   if (rv.n_records > 0 && !h->split_cands_done) { int cs = enq_split_candidates(h, st); if (cs) return cs; }
   { int js = join_aux(h); if (js) return js; }
   SlimOut so{nullptr, 0, 0, 0, nullptr};
-  if (h->big_run && h->sl_prebuilt) so = SlimOut{h->sl[0].p, pos_bits(h), h->rv.tid_lo, tid_bits(h), &dctr(h)->err};
+  if (h->sl_prebuilt) so = SlimOut{h->sl[0].p, pos_bits(h), h->rv.tid_lo, tid_bits(h), &dctr(h)->err};     // (the cigar rows have their elements: the split rows too)
   vsv_launch_split_eval(st, rv, p, h->n_tids, rv.n_records > 0 ? h->split_sorted : SplitSorted{nullptr, nullptr, nullptr, nullptr},
                         (vsv_sig*)h->s1in.p, (uint32_t)h->cap_sigs, dctr(h), ew_grid(h), so);
   if (p.dtype == VSV_DTYPE_READS) {
@@ -428,12 +473,23 @@ bool want_big(vsv_handle* h) {
 // (the element kernels compute positions and lengths in 32 bits: an input that does not fit raises ERRB_SLIM_FALLBACK and the handle stays
 // on rows for a while; element indices carry two flag bits)
 bool big_allowed(vsv_handle* h) { return h->row_runs == 0 && h->cap_sigs < (1ll << 30); }
-int slim_work(vsv_handle* h, SlimWork& w) {
+// the element buffers: allocated in front of a run's first launch (enq_scan), never in the middle of one
+int slim_alloc(vsv_handle* h, bool all) {
   const size_t n = (size_t)h->cap_sigs;
-  for (int k = 0; k < 6; ++k) { int st = ensure(h, h->sl[k], n * 16 + 64); if (st) return st; w.buf[k] = h->sl[k].p; }
+  for (int k = 0; k < (all ? 6 : 1); ++k) {
+    const void* before = h->sl[k].p;
+    int st = ensure(h, h->sl[k], n * 16 + 64); if (st) return st;
+    if (h->sl[k].p != before) { h->sl_e2 = nullptr; h->sl_m = nullptr; h->c1_stale = h->merged_stale = false; }     // (tables gathered from the old buffers are gone)
+  }
+  if (!all) return 0;
   int st;
   if ((st = ensure(h, h->sl_hj, n * 4 + 64))) return st;
   if ((st = ensure(h, h->sl_done, n * 4 + 64))) return st;
+  return 0;
+}
+int slim_work(vsv_handle* h, SlimWork& w) {
+  { int st = slim_alloc(h, true); if (st) return st; }
+  for (int k = 0; k < 6; ++k) w.buf[k] = h->sl[k].p;
   { const Counters& c = h->host_ctr; w.rows_hint = c.n_s1 ? (int64_t)c.n_s1 + c.n_s1 / 4 : h->cap_sigs; w.cand_hint = c.n_cand ? (int64_t)c.n_cand + c.n_cand / 4 : h->cap_sigs; }
   w.cap = h->cap_sigs; w.hist = (uint32_t*)h->hist.p; w.totals = (uint32_t*)h->totals.p; w.pass_cursor = &h->pass_cursor;
   w.grid = ew_grid(h); w.cl = (int32_t*)h->cl.p; w.hj = (uint32_t*)h->sl_hj.p; w.done1 = (uint32_t*)h->sl_done.p;
@@ -449,12 +505,17 @@ int slim_tid_bits(vsv_handle* h) { return h->n_tids > h->rv.tid_lo ? bits_for((u
 int enq_stage1(vsv_handle* h) {
   hipStream_t st = h->stream;
   Counters* c = dctr(h);
-  h->big_run = h->big_run && h->pass_cursor + 4 * vsv_slim_sort_passes(sort_bits(h)) <= MAX_SORT_PASSES;     // (decided in enq_scan)
+  if (h->stage_done >= 3) { int rs = reenter_reset(h); if (rs) return rs; }
+  // (decided in enq_scan; a staged call knows this run's own tables by now: vsv_finish() has read their counters)
+  if (h->ctr_of_run && !h->in_rerun) h->big_run = want_big(h) && big_allowed(h);
+  h->big_run = h->big_run && h->pass_cursor + 4 * vsv_slim_sort_passes(sort_bits(h)) <= MAX_SORT_PASSES;
+  if (h->big_run) ++h->element_runs;
   h->c1_stale = h->merged_stale = false;
   if (h->big_run) {
     SlimWork w;
     { int ws = slim_work(h, w); if (ws) return ws; }
     h->sl_e2 = vsv_slim_stage1(st, (const vsv_sig*)h->s1in.p, &c->n_s1, &c->n_alive1, pos_bits(h), h->rv.tid_lo, slim_tid_bits(h), h->prm.cluster_shift, w, c, h->sl_prebuilt, &h->sl_sorted1, &h->sl_ctl2);
+    h->sl_prebuilt = false;          // (the sort used the element buffer as scratch: a staged call that comes here again builds the elements from the rows)
     h->sl_shift1 = h->prm.cluster_shift;
     h->c1_stale = true;
     HIPCHK(h, hipGetLastError());
@@ -519,6 +580,7 @@ int finish(vsv_handle* h) {
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->host_ctr = *h->pinned;
   h->pending = false;
+  if (h->stage_done >= 1) { h->have_history = true; h->ctr_of_run = true; }
   if (h->stage_done >= 5) {   // pairing of the NEXT run: in rounds once a stretch of thousands of rows was met, back to the plain
                               // kernel when the merged table gets small again (the rounds cost ~20 launches)
     static const char* force = vsv_dbg_env("VSV_PAIR");          // tests: "rounds" / "walk"
@@ -729,6 +791,12 @@ void vsv_destroy(vsv_handle* h) {
 const char* vsv_last_error(vsv_handle* h) { return h ? h->err.c_str() : "null handle"; }
 int64_t vsv_last_count(vsv_handle* h) { return h ? h->last_count : 0; }
 int64_t vsv_rerun_count(vsv_handle* h) { return h ? h->reruns : 0; }
+int vsv_path_counts(vsv_handle* h, int64_t* element_runs, int64_t* cold_syncs) {
+  if (!h) return VSV_E_INVALID;
+  if (element_runs) *element_runs = h->element_runs;
+  if (cold_syncs) *cold_syncs = h->cold_syncs;
+  return 0;
+}
 
 int vsv_wait_for_stream(vsv_handle* h, void* producer_hip_stream) {
   if (!h) return VSV_E_INVALID;
@@ -783,8 +851,11 @@ int vsv_sort_cluster(vsv_handle* h, const vsv_params* p) {
 
 int vsv_merge_sources(vsv_handle* h, const vsv_params* p) {
   if (!h || h->stage_done < 3) return fail(h, VSV_E_INVALID, "vsv_sort_cluster must run first");
+  int st;
+  // (an element run consumed the stage-1 tables when it merged them: called again, the stage in front is enqueued again, with ITS shift)
+  if (h->big_run && h->stage_done >= 4) { const int keep = h->prm.cluster_shift; h->prm.cluster_shift = h->sl_shift1; st = enq_stage1(h); h->prm.cluster_shift = keep; if (st) return st; }
   if (p) h->prm.cluster_shift = p->cluster_shift;
-  int st = enq_merge(h);
+  st = enq_merge(h);
   if (st) return st;
   return finish(h);
 }
@@ -792,7 +863,18 @@ int vsv_merge_sources(vsv_handle* h, const vsv_params* p) {
 int vsv_pair_haplotypes(vsv_handle* h, const vsv_params* p) {
   if (!h || h->stage_done < 4) return fail(h, VSV_E_INVALID, "vsv_merge_sources must run first");
   if (p) { h->prm.pair_shift = p->pair_shift; h->prm.pair_window = p->pair_window; }
-  int st = enq_pair(h);
+  int st;
+  if (h->big_run && h->stage_done >= 5) {     // called again on an element run: its sorts take their scratch slots from the run's arena — start over from stage 1
+    const int keep = h->prm.cluster_shift;
+    h->prm.cluster_shift = h->sl_shift1;
+    st = enq_stage1(h);
+    h->prm.cluster_shift = keep;
+    if (st || (st = enq_merge(h))) return st;
+  } else if (h->stage_done >= 5) {            // ... on a row run: the pairing state (one word per merged row, -1 = free) was left by the sort in front
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemsetAsync(h->cl.p, 0xFF, (size_t)h->cap_sigs * sizeof(int32_t), h->stream));
+  }
+  st = enq_pair(h);
   if (st) return st;
   return finish(h);
 }
@@ -1671,6 +1753,18 @@ static int table_src(vsv_handle* h, int table, const void** src, int64_t* n_rows
     if (table == VSV_T_CLUSTER1) { vsv_slim_rows(h->stream, h->sl_e2, c.n_alive1, (const vsv_sig*)h->s1in.p, (vsv_sig*)h->c1.p); h->c1_stale = false; }
     else { vsv_slim_rows(h->stream, h->sl_m, c.n_alive3, (const vsv_sig*)h->s1in.p, (vsv_sig*)h->merged.p); h->merged_stale = false; }
     if (hipStreamSynchronize(h->stream) != hipSuccess) return VSV_E_HIP;
+  }
+  if (table == VSV_T_RAW && h->stage_done >= 1 && h->raw_state != 0) {
+    // the scan placed its rows straight into the stage-1 input table (where the fold has run since): the rows as the scan emitted
+    // them are built again from its descriptors, which nothing else writes
+    if (h->raw_state == 2) return VSV_E_INVALID;
+    if (hipSetDevice(h->device) != hipSuccess) return VSV_E_HIP;
+    if (++h->lb_epoch >= (1u << 24)) { if (hipMemsetAsync(h->lbw.p, 0, h->lbw.bytes, h->stream) != hipSuccess) return VSV_E_HIP; h->lb_epoch = 1; }
+    vsv_launch_long_place(h->stream, h->rv, h->prm, h->raw_parts, (vsv_sig*)h->pool.p, (uint64_t*)h->pool_key.p, (uint32_t)h->cap_sigs, (uint32_t*)h->part_count.p,
+                          (uint32_t*)h->part_off.p, (vsv_sig*)h->raw0.p, dctr(h), (uint32_t*)h->shard_cnt.p, long_bufs(h, false, nullptr, SlimOut{nullptr, 0, 0, 0, nullptr}),
+                          h->lb_epoch, SlimOut{nullptr, 0, 0, 0, nullptr});
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return VSV_E_HIP;
+    h->raw_state = 0;
   }
   *filter = true;
   *row = sizeof(vsv_sig);

@@ -1424,7 +1424,18 @@ struct PlaceArgs {
   uint64_t* lbw; uint32_t epoch;
   const int32_t* tid; vsv_sig* raw; uint32_t cap; Counters* ctr;
   uint32_t* part_off; uint32_t* carry_r; uint32_t* carry_q; int no_qend;
+  SlimOut so;                                       // the rows' 16-byte elements next to them (base == nullptr: rows only)
 };
+__device__ __forceinline__ void k1l_store(vsv_sig* __restrict__ raw, uint32_t row, const uint4& lo4, const uint4& hi4, const SlimOut& so) {
+  uint4* dst = reinterpret_cast<uint4*>(raw + row);
+  dst[0] = lo4; dst[1] = hi4;
+  if (so.base) {
+    vsv_sig v;
+    v.pos = (int32_t)lo4.x; v.svlen = (int32_t)lo4.y; v.q_start = (int32_t)lo4.z; v.q_end = (int32_t)lo4.w;
+    v.rec = hi4.x; v.rec2 = hi4.y; v.meta = hi4.z; v.tid = (int32_t)hi4.w;
+    vsv_slim_emit(so, row, v);
+  }
+}
 constexpr int PL_PARTS = 256;
 __global__ __launch_bounds__(256) void k1l_place(PlaceArgs A) {
   __shared__ CarryItem sh[256];
@@ -1476,14 +1487,14 @@ __global__ __launch_bounds__(256) void k1l_place(PlaceArgs A) {
     const uint4 d = A.dpool[s_loc[lo] + (o - s_first[lo])];
     uint4 lo4, hi4;
     k1l_row(d, s_cr[lo], s_cq[lo], (uint32_t)A.tid[d.w], A.no_qend != 0, lo4, hi4);
-    uint4* dst = reinterpret_cast<uint4*>(A.raw + row);
-    dst[0] = lo4; dst[1] = hi4;
+    k1l_store(A.raw, row, lo4, hi4, A.so);
   }
 }
 // the batches a part filed before its last one (a part with more candidates than its stage holds): a wave per batch
 __global__ __launch_bounds__(256) void k1l_place_batches(const uint4* __restrict__ batches, const uint32_t* __restrict__ n_batches, uint32_t batch_cap,
                                                          const uint4* __restrict__ dpool, const uint32_t* __restrict__ part_off, const uint32_t* __restrict__ carry_r,
-                                                         const uint32_t* __restrict__ carry_q, const int32_t* __restrict__ tid, vsv_sig* __restrict__ raw, uint32_t cap, int no_qend) {
+                                                         const uint32_t* __restrict__ carry_q, const int32_t* __restrict__ tid, vsv_sig* __restrict__ raw, uint32_t cap, int no_qend,
+                                                         SlimOut so) {
   const uint32_t nb = min(*n_batches, batch_cap);
   const int lane = threadIdx.x & 63;
   for (uint32_t e = blockIdx.x * 4 + (threadIdx.x >> 6); e < nb; e += gridDim.x * 4) {
@@ -1494,8 +1505,7 @@ __global__ __launch_bounds__(256) void k1l_place_batches(const uint4* __restrict
       const uint4 d = dpool[b.z + i];
       uint4 lo4, hi4;
       k1l_row(d, cr, cq, (uint32_t)tid[d.w], no_qend != 0, lo4, hi4);
-      uint4* dst = reinterpret_cast<uint4*>(raw + row0 + i);
-      dst[0] = lo4; dst[1] = hi4;
+      k1l_store(raw, row0 + i, lo4, hi4, so);
     }
   }
 }
@@ -1663,22 +1673,44 @@ bool vsv_scan_is_long(const RecView& rv, const vsv_params& p) {
 }
 int vsv_cigar_parts_long(int64_t n_ops) { return (int)((n_ops + K1L_PART - 1) / K1L_PART); }
 
+// the long scan's descriptors -> rows in T_RAW order (and their elements): behind the scan, and again into the raw table when a
+// caller asks for VSV_T_RAW of a run whose rows went straight into the stage-1 table (capi.hip). n_parts: the scan's.
+void vsv_launch_long_place(hipStream_t st, const RecView& rv, const vsv_params& p, int n_parts, vsv_sig* pool, uint64_t* pool_key, uint32_t cap, uint32_t* part_count,
+                           uint32_t* part_off, vsv_sig* rows, Counters* ctr, uint32_t* shard_cnt, const LongScanBufs& lb, uint32_t epoch, const SlimOut& so) {
+  const int no_qend = (p.dtype == VSV_DTYPE_READS || p.dtype == VSV_DTYPE_CUTESV) ? 1 : 0;
+  const uint32_t dshard_cap = (uint32_t)(((uint64_t)cap * 2) / K1_SHARDS);
+  k1l_place<<<(n_parts + PL_PARTS - 1) / PL_PARTS, 256, 0, st>>>(PlaceArgs{(const uint4*)pool, shard_cnt, dshard_cap, (const uint2*)lb.prec, part_count, (const PartAgg*)lb.agg,
+                                                                 n_parts, lb.lbw, epoch, rv.tid, rows, cap, ctr, part_off, lb.carry_r, lb.carry_q, no_qend, so});
+  k1l_place_batches<<<64, 256, 0, st>>>((const uint4*)pool_key, shard_cnt + 8, cap / 2, (const uint4*)pool, part_off, lb.carry_r, lb.carry_q, rv.tid, rows, cap, no_qend, so);
+}
+// parts of the long scan for this input (what vsv_launch_cigar_scan cuts it into): 0 = the call does not take that scan
+int vsv_long_scan_parts(const RecView& rv, const vsv_params& p, int ops_per_part) {
+  static const char* k1l = vsv_dbg_env("VSV_K1L");
+  if (!vsv_scan_is_long(rv, p) || (k1l && k1l[0] == 'p') || rv.n_ops <= 0) return 0;
+  static const int forced = vsv_dbg_env("VSV_K1L_PART") ? atoi(vsv_dbg_env("VSV_K1L_PART")) : 0;      // timing experiments / tests
+  int64_t po = K1L_PART;
+  if (forced >= 256 && forced % 256 == 0) po = forced;
+  if (po < ops_per_part) po = ((ops_per_part + 255) / 256) * 256;        // (the part tables are sized for the read-shaped part length)
+  return vsv_cigar_parts(rv.n_ops, (int)po);
+}
 void vsv_launch_cigar_scan(hipStream_t st, const RecView& rv, const vsv_params& p, uint32_t* part_rb, int n_parts,
                            int ops_per_part, vsv_sig* pool, uint64_t* pool_key, uint32_t cap, uint32_t* part_count,
                            uint32_t* part_off, uint32_t* scan_tmp, vsv_sig* raw, Counters* ctr, uint32_t* shard_cnt,
                            hipEvent_t ev0, hipEvent_t ev1, const LongScanBufs& lb) {
   if (n_parts <= 0) return;
+  const int ops_per_part0 = ops_per_part;
   const bool long_mode = vsv_scan_is_long(rv, p);
   static const char* k1l = vsv_dbg_env("VSV_K1L");                   // timing experiments / tests: "pool" = round 3's scan + placement pass
   const bool long_pool = long_mode && ((k1l && k1l[0] == 'p') || !lb.lbw);
   if (long_mode && long_pool) { n_parts = vsv_cigar_parts_long(rv.n_ops); ops_per_part = K1L_PART; }
   if (long_mode && !long_pool) {
-    static const int forced = vsv_dbg_env("VSV_K1L_PART") ? atoi(vsv_dbg_env("VSV_K1L_PART")) : 0;      // timing experiments / tests
+    n_parts = vsv_long_scan_parts(rv, p, ops_per_part);
+    ops_per_part = (int)((rv.n_ops + n_parts - 1) / n_parts);              // (only its multiple-of-256 value below matters)
+    static const int forced = vsv_dbg_env("VSV_K1L_PART") ? atoi(vsv_dbg_env("VSV_K1L_PART")) : 0;
     int64_t po = K1L_PART;
     if (forced >= 256 && forced % 256 == 0) po = forced;
-    if (po < ops_per_part) po = ((ops_per_part + 255) / 256) * 256;        // (the part tables are sized for the read-shaped part length)
+    if (po < ops_per_part0) po = ((ops_per_part0 + 255) / 256) * 256;
     ops_per_part = (int)po;
-    n_parts = vsv_cigar_parts(rv.n_ops, ops_per_part);
   }
   if (!lb.arena_zeroed) (void)hipMemsetAsync(shard_cnt, 0, K1_SHARDS * 16 * sizeof(uint32_t), st);
   if (n_parts < (1 << 20)) partition_search<<<(n_parts + 1 + 255) / 256, 256, 0, st>>>(rv.cigar_off, rv.n_records, part_rb, n_parts, ops_per_part, rv.n_ops, 1);
@@ -1713,10 +1745,8 @@ void vsv_launch_cigar_scan(hipStream_t st, const RecView& rv, const vsv_params& 
   if (ev1) (void)hipEventRecord(ev1, st);
   const bool add_qend = !(p.dtype == VSV_DTYPE_READS || p.dtype == VSV_DTYPE_CUTESV);
   if (long_mode && !long_pool) {
-    const int no_qend = add_qend ? 0 : 1;
-    k1l_place<<<(n_parts + PL_PARTS - 1) / PL_PARTS, 256, 0, st>>>(PlaceArgs{(const uint4*)pool, shard_cnt, dshard_cap, (const uint2*)lb.prec, part_count, (const PartAgg*)lb.agg,
-                                                                   n_parts, lb.lbw, lb.epoch, rv.tid, raw, cap, ctr, part_off, lb.carry_r, lb.carry_q, no_qend});
-    k1l_place_batches<<<64, 256, 0, st>>>((const uint4*)pool_key, shard_cnt + 8, cap / 2, (const uint4*)pool, part_off, lb.carry_r, lb.carry_q, rv.tid, raw, cap, no_qend);
+    vsv_launch_long_place(st, rv, p, n_parts, pool, pool_key, cap, part_count, part_off, lb.fused_rows ? (vsv_sig*)lb.fused_rows : raw, ctr, shard_cnt, lb, lb.epoch,
+                          lb.fused_rows ? lb.so : SlimOut{nullptr, 0, 0, 0, nullptr});
     return;
   }
   if (long_mode) {

@@ -85,6 +85,97 @@ __global__ __launch_bounds__(256) void fold_kernel(const vsv_sig* __restrict__ i
   }
 }
 
+// The same fold IN PLACE, for runs whose scan placed rows and elements straight into the stage-1 input table (cigar_scan.hip,
+// k1l_place): on a contig pile one row in ~700 has a neighbour it could fold with, and the out-of-place pass above moves 500 MB
+// (rows in, rows + elements out) to find that out. Here every thread reads its row's 16-byte ELEMENT and those around it: a row
+// without another element of its list (haplotype, type) within T on either side — scanned over whatever lies between, as the rule
+// does, and across record boundaries, which the elements do not show: a superset — is a chain of one and stays as it is. The few
+// others run the rule above on the rows. In place is safe because every decision reads fields no fold changes — record, position,
+// list — (the DEAD bit is ignored: the scan never emits a dead row, and a neighbour's owner may be setting it right now), a chain is
+// written by its head's thread only, and an element somebody already killed just counts as "something is near".
+__global__ __launch_bounds__(256) void fold_elems(vsv_sig* __restrict__ rows, uint4* __restrict__ elems, const Counters* ctr, SlimOut so) {
+  const uint32_t n = ctr->n_raw;
+  const int pb = so.pb;
+  const uint64_t pmask = pb >= 64 ? ~0ull : ((1ull << pb) - 1ull);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint4 e = elems[i];
+    const uint64_t key = (uint64_t)e.x | ((uint64_t)e.y << 32);
+    const int64_t pos = (int64_t)(key & pmask);
+    const uint32_t slot = (uint32_t)(key >> (pb + 1)) & 3u;          // hap << 1 | del
+    const uint64_t tidk = key >> (pb + 3);
+    const int64_t T = (slot & 1u) ? 150 : 380;
+    // (positions never decrease along a record: where they do between two neighbours, a record ends — the rule stops there, and so
+    // does the scan. Without that test the first and last element of every contig walked through its neighbours' whole records,
+    // whose positions lie megabases on the far side: 742 us on the pile)
+    bool near = false;
+    int64_t edge = pos;
+    for (uint32_t j = i; j-- > 0;) {
+      const uint4 x = elems[j];
+      const uint64_t kj = (uint64_t)x.x | ((uint64_t)x.y << 32);
+      if (kj == VSV_KEY_DEAD) { near = true; break; }
+      const int64_t pj = (int64_t)(kj & pmask);
+      if ((kj >> (pb + 3)) != tidk || pj > edge || pos - pj >= T) break;
+      if (((uint32_t)(kj >> (pb + 1)) & 3u) == slot) { near = true; break; }
+      edge = pj;
+    }
+    edge = pos;
+    for (uint32_t k = i + 1; !near && k < n; ++k) {
+      const uint4 x = elems[k];
+      const uint64_t kk = (uint64_t)x.x | ((uint64_t)x.y << 32);
+      if (kk == VSV_KEY_DEAD) { near = true; break; }
+      const int64_t pk = (int64_t)(kk & pmask);
+      if ((kk >> (pb + 3)) != tidk || pk < edge || pk - pos >= T) break;
+      if (((uint32_t)(kk >> (pb + 1)) & 3u) == slot) { near = true; break; }
+      edge = pk;
+    }
+    if (!near) continue;
+    // ---- the rule itself (fold_kernel), on the rows ----
+    const vsv_sig me = rows[i];
+    const int fslot = fold_slot(me.meta);
+    bool head = true;
+    for (uint32_t j = i; j-- > 0;) {
+      const vsv_sig p = rows[j];
+      if (p.rec != me.rec || (int64_t)me.pos - p.pos >= T) break;
+      if (fold_slot(p.meta) == fslot) { head = false; break; }
+    }
+    if (!head) continue;
+    vsv_sig s1 = me;
+    uint32_t last = i;
+    int32_t prev_pos = me.pos;
+    bool dirty = false;
+    auto put = [&]() {                                   // s1 changed: its row, and the length in its element
+      rows[last] = s1;
+      reinterpret_cast<uint32_t*>(elems + last)[2] = (uint32_t)s1.svlen;
+      if ((uint32_t)s1.svlen >= (1u << 30)) atomicOr(so.err, ERRB_SLIM_FALLBACK);
+    };
+    for (uint32_t k = i + 1; k < n; ++k) {
+      const vsv_sig s2 = rows[k];
+      if (s2.rec != me.rec || (int64_t)s2.pos - prev_pos >= T) break;
+      if (fold_slot(s2.meta) != fslot) continue;
+      prev_pos = s2.pos;
+      int64_t d = (int64_t)s2.pos - s1.pos; if (d < 0) d = -d;
+      // (the merged length and query end as values of their own, assigned to s1 in one place: with the assignments inside the two
+      // branches hipcc 7.2 dropped the copy of s2.q_end into s1.q_end on the INS side — q_end 0 in every folded insertion)
+      const bool is_del = (s2.meta & VSV_M_DEL) != 0;
+      const bool merged = is_del ? (s1.svlen > 150 && s2.svlen > 150 && d < 150)                                   // Hifi.py:148-150
+                                 : ((s1.svlen > 100 && s2.svlen > 100 && d < 250) ||                               // Hifi.py:115-117 (subset), 126-128
+                                    (s1.svlen > 320 && s2.svlen > 320 && d < 380));                                // Hifi.py:120-122
+      const int32_t new_qe = is_del ? s1.q_start + 1 : s2.q_end;                                                    // Hifi.py:94
+      const int32_t new_len = is_del ? s2.pos + s2.svlen - s1.pos : s2.q_end - s1.q_start;                          // Hifi.py:104 / 96
+      if (merged) { s1.q_end = new_qe; s1.svlen = new_len; }
+      if (merged) {
+        rows[k].meta = s2.meta | VSV_M_DEAD;
+        elems[k] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
+        dirty = true;
+      } else {
+        if (dirty) put();
+        last = k; s1 = s2; dirty = false;
+      }
+    }
+    if (dirty) put();
+  }
+}
+
 // ---- sig_extract.py generate_combine_sigs (SE:373-435): signals of one read merged by distance ---------------------------
 // One thread per record's group of raw rows, in op order, INS and DEL independently. INS: a signal at most
 // merge_ins_threshold after the LAST merged signal's position joins the current one (lengths add; the host concatenates the
@@ -1127,6 +1218,10 @@ void vsv_launch_fold(hipStream_t st, const vsv_sig* raw, vsv_sig* s1in, const Re
   if (dtype == VSV_DTYPE_HIFI || dtype == VSV_DTYPE_ONT || dtype == VSV_DTYPE_CLR) { fold_kernel<<<grid, 256, 0, st>>>(raw, s1in, ctr, so); return; }
   copy_rows<vsv_sig><<<grid, 256, 0, st>>>(raw, &ctr->n_raw, s1in);
   if (dtype == VSV_DTYPE_CUTESV) combine_kernel<<<EW_GRID, 256, 0, st>>>(s1in, ctr, p.merge_ins_threshold, p.merge_del_threshold);
+}
+
+void vsv_launch_fold_elems(hipStream_t st, vsv_sig* rows, Counters* ctr, int grid, const SlimOut& so) {
+  fold_elems<<<grid, 256, 0, st>>>(rows, (uint4*)so.base, ctr, so);
 }
 
 static int bits_for(uint64_t n) { int b = 1; while ((1ull << b) < n && b < 63) ++b; return b; }

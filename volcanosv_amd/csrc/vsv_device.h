@@ -170,7 +170,11 @@ struct LongScanBufs {   // scratch of the scan launcher beyond the part tables
   bool clr_fused;                          // CLR, read-shaped scan: the gate is computed inside the scan (flags arrive ungated)
   uint64_t* lbw; uint32_t epoch;           // look-back words of the placement kernel's scan (3 per block of parts), and this run's epoch
   void* prec;                              // long-record scan: {location, descriptors} of every part's last batch
+  void* fused_rows; SlimOut so;            // long-record scan: place the rows here (the stage-1 input table) with their elements, not in `raw`
 };
+void vsv_launch_long_place(hipStream_t st, const RecView& rv, const vsv_params& p, int n_parts, vsv_sig* pool, uint64_t* pool_key, uint32_t cap, uint32_t* part_count,
+                           uint32_t* part_off, vsv_sig* rows, Counters* ctr, uint32_t* shard_cnt, const LongScanBufs& lb, uint32_t epoch, const SlimOut& so);
+int vsv_long_scan_parts(const RecView& rv, const vsv_params& p, int ops_per_part);
 size_t vsv_lookback_bytes(int64_t n_ops, int ops_per_part);
 bool vsv_scan_is_long(const RecView& rv, const vsv_params& p);
 size_t vsv_long_scan_bytes(int64_t n_ops, int which, int ops_per_part);
@@ -184,6 +188,7 @@ struct SlimWork;
 void vsv_launch_clr_gate(hipStream_t st, const RecView& rv, uint8_t* gflag, Counters* ctr);   // CLR: gated flag bytes for the scan
 void vsv_launch_fold(hipStream_t st, const vsv_sig* raw, vsv_sig* s1in, const RecView& rv, const vsv_params& p, Counters* ctr, int grid,
                      const SlimOut& so = SlimOut{nullptr, 0, 0, 0, nullptr});
+void vsv_launch_fold_elems(hipStream_t st, vsv_sig* rows, Counters* ctr, int grid, const SlimOut& so);   // the fold in place, on rows placed with their elements
 struct SplitSorted {      // candidates by name / pairs by record
   const uint64_t* ckey; const uint32_t* crec; const uint64_t* okey; const uint32_t* oval;
   const uint32_t* oc1 = nullptr; const void* cinfo = nullptr;      // large read-shaped inputs: a slot's two candidates (oc1, oval) into cinfo

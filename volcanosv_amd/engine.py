@@ -103,6 +103,13 @@ class Engine:
         """Whole-run repetitions vsv_finish() took on this engine so far (bucket-sort overflow / fused-CLR-gate fallbacks)."""
         return int(self.lib.vsv_rerun_count(self.h))
 
+    def path_counts(self):
+        """(element_runs, cold_syncs) of this engine (vsv_path_counts): runs whose stages behind the split stage worked on 16-byte
+        elements, and first runs that waited for the scan once to pick that path from the run's own row count."""
+        a, b = C.c_int64(), C.c_int64()
+        self._check(self.lib.vsv_path_counts(self.h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     # ---- stage entry points --------------------------------------------------------------------------
     def _recs(self, soa):
         self._keep = soa  # keep host arrays / tensors alive while the GPU reads them
