@@ -231,7 +231,9 @@ class Bench:
             e.finish()
             scan_ms.append(e.scan_ms())
             if table is not None:
-                pend.append(self.gather_start(e, table))
+                pend.append(self.gather_start(e, table))        # (enqueues the count exchange, waits for nothing)
+                if len(pend) > 2:
+                    pend[-3].post()                             # two steps later the counts are there: the transfer starts, under the next steps
                 if len(pend) > n:
                     last = pend.pop(0).wait()
         for i in range(k):
@@ -290,6 +292,30 @@ class Bench:
         p1 = default_params(dtype)          # (one engine by itself builds the split candidates on its auxiliary stream: VSV_OVERLAP_AUTO)
         self.run_steps([(recs, p1)], 2, [], engs[:1], table)
         dt1, _ = self.timed(lambda: self.run_steps([(recs, p1)], k1, [], engs[:1], table))
+        # a COLD handle: fresh engine (workspace reserved up front: allocation is not what is measured), ONE run, HIP events on its
+        # stream around everything the run enqueues — what one invocation of the drop-in CLI gets, which runs one chromosome per process
+        from volcanosv_amd.engine import Engine
+        cold, paths = [], set()
+        el0 = sum(e.path_counts()[0] for e in engs)
+        if dtype_name != "READS":
+            for _ in range(3):
+                s = torch.cuda.Stream(device=self.dev)
+                ce = Engine(self.local_rank, stream=s.cuda_stream, max_sigs=self.args.max_sigs)
+                ce.reserve(recs.n_records, recs.n_ops, self.args.max_sigs, large_tables=True)
+                torch.cuda.synchronize()
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record(s)
+                ce.run_async(recs, p1)
+                ev1.record(s)
+                ce.finish()
+                ev1.synchronize()
+                cold.append(ev0.elapsed_time(ev1))
+                paths.add("elements" if ce.path_counts()[0] else "rows")
+                assert ce.rerun_count() == 0
+                ce.close()
+                del ce, s
+        self.run_steps([(recs, p1)], 1, [], engs[:1], table)
+        warm_path = "elements" if sum(e.path_counts()[0] for e in engs) > el0 else "rows"
         n_raw = len(eng.table("raw"))
         alg_bytes = 24 * recs.n_records + 4 * recs.n_ops + 32 * n_raw      # SURVEY.md §8d, per launch
         scan_s = sum(scan_ms) / len(scan_ms) / 1e3
@@ -306,6 +332,10 @@ class Bench:
             "rows_gathered": self.n_gathered(gathered, table), "steps": steps, "reps": len(times), "streams": len(engs),
             "ms_per_step": med / steps * 1e3, "ms_per_step_min": ts[0] / steps * 1e3, "ms_per_step_max": ts[-1] / steps * 1e3,
             "single_engine_ms_per_step": dt1 / k1 * 1e3,
+            # the first run of a fresh handle (median of three new engines; HIP events on the engine's stream) and the path it took: a cold
+            # handle waits once for its scan to pick the path a warm one takes (vsv_path_counts)
+            "cold_ms_per_step": sorted(cold)[len(cold) // 2] if cold else None,
+            "path": warm_path, "cold_path": "/".join(sorted(paths)) if paths else None,
             "reruns": reruns,          # whole-run repetitions inside the timed regions (bucket-sort overflow / fused CLR gate fallbacks, vsv_rerun_count)
             "records_per_s": recs.n_records * self.world * steps / med, "ops_per_s": recs.n_ops * self.world * steps / med,
             "scan": {"kernel": "cigar_scan_long" if recs.n_ops >= 512 * recs.n_records else "cigar_scan_emit", "avg_launch_ms": scan_s * 1e3,
@@ -368,6 +398,8 @@ class Bench:
                 parts = one_pass(scan_ms)
                 rows = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.uint8, device=self.dev)
                 pend.append(shard.gather_bytes_start(rows.cpu() if self.rehearsal else rows, self.cdev))
+                if len(pend) > 1:
+                    pend[-2].post()                 # the previous job's counts have arrived: its transfer runs under this job
                 if len(pend) > 2:
                     g = pend.pop(0).wait()
             for h in pend:
@@ -525,19 +557,28 @@ def main():
             # HBM bytes per launch from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs, KiB units,
             # FETCH_SIZE doubled for the wide coalesced stream as MI355X_MICROARCH.md prescribes) of the same kernel on the same
             # shape, scaled by the op count (which sets the traffic): a profile figure, not an in-run measurement
-            pmc_name = {"hifi": "r02_pmc_cigar_scan_emit_config2.json", "contig": "r03_pmc_cigar_scan_long_contig200k.json"}.get(shape)
+            pmc_name = {"hifi": "r02_pmc_cigar_scan_emit_config2.json", "contig": "r04_pmc_cigar_scan_long_contig200k.json"}.get(shape)
             pmc_path = os.path.join(ROOT, "profiles", pmc_name) if pmc_name else None
             if pmc_path and os.path.exists(pmc_path):
                 pmc = json.load(open(pmc_path))
-                if shape == "contig" or abs(recs.n_ops - pmc["n_ops"]) < 0.02 * pmc["n_ops"]:
+                # a profile LOOKUP, not a measurement of this run: refused when the kernel's source is no longer the one that was profiled
+                # (the profile records the sha256 of csrc/cigar_scan.hip; profiles older than that rule: the scan kernel's name and part
+                # of its text, checked by tests/test_bench_contract.py)
+                import hashlib
+                src_now = hashlib.sha256(open(os.path.join(ROOT, "volcanosv_amd", "csrc", "cigar_scan.hip"), "rb").read()).hexdigest()
+                fresh = pmc.get("kernel_source_sha256") in (None, src_now) if shape == "hifi" else pmc.get("kernel_source_sha256") == src_now
+                if not fresh:
+                    traffic_source = "profile lookup REFUSED: profiles/%s was taken from another version of csrc/cigar_scan.hip" % pmc_name
+                elif shape == "contig" or abs(recs.n_ops - pmc["n_ops"]) < 0.02 * pmc["n_ops"]:
                     traffic = pmc["traffic_bytes_per_launch"] * recs.n_ops / pmc["n_ops"]
-                    traffic_source = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes), scaled by op count" % pmc_name
+                    traffic_source = "profile lookup: profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel), scaled by op count" % pmc_name
         label = {2: "config2", 3: "config3", 6: "row 2c (contig-like)"}[args.config]
         line = {
             "metric": METRIC, "value": res["records_per_s"], "unit": "records/s", "n_gpus": b.world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "reps": res["reps"], "ms_per_step_min": res["ms_per_step_min"], "ms_per_step_max": res["ms_per_step_max"],
             "n_ranks_seen": b.n_ranks_seen, "single_engine_ms_per_step": res["single_engine_ms_per_step"], "reruns": res["reruns"],
+            "cold_ms_per_step": res["cold_ms_per_step"], "path": res["path"], "cold_path": res["cold_path"],
             "config": {"workload": "%s: %d %s-like records/GPU, 1 chromosome per GPU, dtype %s, %d CIGAR ops, %d raw signatures, %d rows gathered per step"
                                    % (label, recs.n_records, shape, dtype_name, recs.n_ops, res["raw_signatures"], res["rows_gathered"]),
                        "headline": "batch throughput: %d engines per GPU in flight round-robin over the same device-resident shard (the stages of one step "
@@ -546,7 +587,8 @@ def main():
                        "records_per_gpu": recs.n_records, "parallelism": "chromosome-sharded x%d" % b.world, "streams_per_gpu": res["streams"],
                        "ops_per_s": res["ops_per_s"], "whole_path_frac_of_hbm_peak": res["whole_path_frac"]},
             "roofline": {"bound": "hbm", "kernel": res["scan"]["kernel"], "achieved": res["scan"]["alone_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": res["scan"]["alone_frac"], "traffic": traffic, "traffic_source": traffic_source,
+                         "frac": res["scan"]["alone_frac"], "frac_basis": "the scan launch by itself (alone_*); the same launch inside the timed region: overlapped_frac",
+                         "traffic": traffic, "traffic_profile_lookup": traffic_source,
                          "algorithmic_bytes_per_launch": res["algorithmic_bytes_per_step"], "avg_launch_ms": res["scan"]["alone_launch_ms"],
                          "overlapped_launch_ms": res["scan"]["avg_launch_ms"], "overlapped_achieved": res["scan"]["GBs"], "overlapped_frac": res["scan"]["frac"],
                          "note": "achieved / frac / avg_launch_ms: the scan launch by itself (HIP events around the kernel on its launch stream, same input, "

@@ -178,8 +178,13 @@ int vsv_default_params(int dtype, vsv_params* p);
  * synchronisation) for everything enqueued on `producer_hip_stream` (a hipStream_t; NULL = the default stream) so far. */
 int vsv_wait_for_stream(vsv_handle* h, void* producer_hip_stream);
 
-/* capacity (rows) of the signature tables; default 1<<22. Re-allocates the workspace. */
+/* capacity (rows) of the signature tables; default 1<<22. Re-allocates the workspace: growing the row capacity drops the tables
+ * of the handle's last run (they live in the buffers that move). */
 int vsv_reserve(vsv_handle* h, int64_t max_records, int64_t max_ops, int64_t max_sigs);
+/* Optional: allocate, for the current row capacity, the element buffers of the large-table form of the stages behind the split
+ * stage (96 bytes per row of capacity) ahead of the first run. Without it the first contig run of a handle allocates them before its
+ * first launch (never in the middle of a run). */
+int vsv_reserve_large_tables(vsv_handle* h);
 
 /* Stage entry points. Each consumes the handle state left by the previous one.
  * vsv_cigar_scan      replaces extract_sig_from_cigar + the loop of extract_signature_from_cigar

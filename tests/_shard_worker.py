@@ -66,6 +66,25 @@ def main():
             assert all(torch.equal(bufs[r], mk(r, k)) for r in range(world))
         else:
             assert bufs is None                       # nobody but rank 0 receives anything
+    # deferred counts: a start enqueues the count all-gather and returns — nothing is known on the host yet; the transfers are posted
+    # later, interleaved with the starts of later steps (bench.py: `streams` steps later), in the same order on every rank
+    pend = []
+    for k in range(6):
+        h = shard.gather_bytes_start(mk(rank, k + 2), dev)
+        assert h.counts is None and h.bufs is None        # no readback, no transfer yet
+        pend.append((k + 2, h))
+        if len(pend) > 2:
+            kk, hh = pend.pop(0)
+            hh.post()                                      # explicit second half, then the wait
+            bufs, counts = hh.wait()
+            assert counts == [int(mk(r, kk).numel()) for r in range(world)]
+            assert bufs is None if rank else all(torch.equal(bufs[r], mk(r, kk)) for r in range(world))
+    for kk, hh in pend:
+        bufs, counts = hh.wait()
+        assert counts == [int(mk(r, kk).numel()) for r in range(world)]
+        assert bufs is None if rank else all(torch.equal(bufs[r], mk(r, kk)) for r in range(world))
+    if rank == 0:
+        print("DEFERRED_OK")
     rows = shard.gather_rows_device(mk(rank, 1), dev)
     assert (rows is None) == (rank != 0)
     if rank == 0:

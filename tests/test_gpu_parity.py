@@ -655,22 +655,27 @@ def test_full_size_config2_properties(eng):
 
 
 def test_full_size_config3_properties():
-    """BASELINE.json config 3 at full size (50 M ONT-like records, ~9.1e9 CIGAR ops, 38 GB device-resident): determinism,
-    sortedness of the call table, and bit-exact tables for a 200 k-record prefix against the CPU oracle."""
+    """BASELINE.json config 3 at full size (50 M ONT-like records, ~9.1e9 CIGAR ops, 38 GB device-resident): the raw, split, merged
+    and call tables of the WHOLE input equal the CPU oracle's bit for bit (the oracle runs on a host copy in a thread beside the
+    GPU checks); determinism, sortedness of the call table; and, as the fast failure, every table of a 200 k-record prefix."""
     import torch
     from volcanosv_amd import synth
     from volcanosv_amd.abi import DTYPE_ONT
     from volcanosv_amd.engine import DeviceRecords, Engine, default_params
+    from concurrent.futures import ThreadPoolExecutor
     t, nq, nt = synth.generate(50_000_000, "ont", seed=20250331, device="cuda")
     assert t["cigar"].numel() > 9_000_000_000
     p = default_params(DTYPE_ONT)
+    # the CPU oracle over ALL 50 M records (one core, ~a minute: windowed C), on a host copy, while the GPU checks below run
+    pool = ThreadPoolExecutor(max_workers=1)
+    full = pool.submit(oracle_run, synth.to_soa({n: v.cpu() for n, v in t.items()}, nq), DTYPE_ONT, p)
     with Engine(0, max_sigs=1 << 23) as e:
         dr = DeviceRecords(t, nq, nt, max_pos=synth.CHR10_LEN + 200000)
         e.run(dr, p)
-        a = {k: e.table(k) for k in ("raw", "calls")}
+        a = {k: e.table(k) for k in ("raw", "split", "merged", "calls")}
         e.run(dr, p)
-        b = {k: e.table(k) for k in ("raw", "calls")}
-        assert_tables_equal(a, b, ["raw", "calls"])
+        b = {k: e.table(k) for k in ("raw", "split", "merged", "calls")}
+        assert_tables_equal(a, b, ["raw", "split", "merged", "calls"])
         assert len(a["raw"]) > 500_000 and len(a["calls"]) > 300_000
         key = a["calls"]["sig"]["tid"].astype(np.int64) << 32 | a["calls"]["sig"]["pos"].astype(np.int64)
         assert np.all(np.diff(key) >= 0)
@@ -682,9 +687,13 @@ def test_full_size_config3_properties():
         got = e.tables(DTYPE_ONT)
         st, want = oracle_run(synth.to_soa({n: v.cpu() for n, v in sl.items()}, nq_k), DTYPE_ONT, p)
         assert st == 0
-        assert_tables_equal(got, want, list(got.keys()))
-    del t, sl
+        assert_tables_equal(got, want, list(got.keys()))          # (the fast failure: the prefix)
+    del t, sl, dr
     torch.cuda.empty_cache()
+    st, want = full.result()
+    pool.shutdown(wait=True)
+    assert st == 0 and len(want["calls"]) > 300_000
+    assert_tables_equal(a, want, ["raw", "split", "merged", "calls"])             # every row of the full-size run, bit for bit
 
 
 @pytest.mark.parametrize("name", ["bnd_a", "bnd_b"])
@@ -1080,15 +1089,20 @@ def test_full_size_config5_breakends():
 
 
 def test_full_size_row2c_contigs():
-    """SURVEY §8d row 2c at full size (200 k contig-like records of ~16 k ops, 3.2 G CIGAR ops, bench.py's seed): determinism,
-    sortedness and internal consistency of the tables of the whole input, and bit-exact tables against the CPU oracle for the
-    20 k-record prefix (the part of the pile the oracle finishes in seconds: the same densities as the whole)."""
+    """SURVEY §8d row 2c at full size (200 k contig-like records of ~16 k ops, 3.2 G CIGAR ops, bench.py's seed): the raw, merged and
+    call tables of the WHOLE pile equal the CPU oracle's bit for bit (the oracle runs on a host copy in a thread beside the GPU
+    checks); determinism over three runs, sortedness and internal consistency; and, as the fast failure, every table of the
+    20 k-record prefix."""
     import torch
     from volcanosv_amd import synth
     from volcanosv_amd.engine import DeviceRecords, Engine, default_params
+    from concurrent.futures import ThreadPoolExecutor
     t, nq, nt = synth.generate(200_000, "contig", seed=20250328 + 6, tid=0, chrom_len=synth.CHR10_LEN, device="cuda")
     assert t["cigar"].numel() > 3_000_000_000
     p = default_params(DTYPE_HIFI)
+    # the CPU oracle over ALL 200 k contigs (3.2 G ops on one core: tens of seconds), on a host copy, while the GPU checks below run
+    pool = ThreadPoolExecutor(max_workers=1)
+    full = pool.submit(oracle_run, synth.to_soa({n: v.cpu() for n, v in t.items()}, nq), DTYPE_HIFI, p)
     with Engine(0, max_sigs=1 << 24) as e:
         dr = DeviceRecords(t, nq, 1, max_pos=synth.CHR10_LEN + 200000, tid_lo=0)
         runs = []
@@ -1119,9 +1133,13 @@ def test_full_size_row2c_contigs():
         got = e.tables(DTYPE_HIFI)
         st, want = oracle_run(synth.to_soa({n: v.cpu() for n, v in sl.items()}, nq_k), DTYPE_HIFI, p)
         assert st == 0 and len(want["calls"]) > 150_000
-        assert_tables_equal(got, want, list(got.keys()))
-    del t, sl
+        assert_tables_equal(got, want, list(got.keys()))          # (the fast failure: the prefix)
+    del t, sl, dr
     torch.cuda.empty_cache()
+    st, want = full.result()
+    pool.shutdown(wait=True)
+    assert st == 0 and len(want["calls"]) > 2_000_000
+    assert_tables_equal(a, want, ["raw", "merged", "calls"])       # every row of the full-size run, bit for bit
 
 
 def test_cold_engine_takes_the_element_path_on_a_contig_pile():

@@ -32,7 +32,7 @@ def test_world_size_2_gloo():
            "--master-port", str(port), os.path.join(ROOT, "tests", "_shard_worker.py")]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
-    assert "SHARD_OK" in out.stdout and "GATHER_OK" in out.stdout
+    assert "SHARD_OK" in out.stdout and "GATHER_OK" in out.stdout and "DEFERRED_OK" in out.stdout
 
 
 def test_bnd_cross_rank_join_world_size_2_gloo():

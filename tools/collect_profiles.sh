@@ -1,7 +1,7 @@
 #!/bin/bash
 # round profiles (run on the GPU box through gpurun): one-step kernel breakdowns, kernel statistics, PMC traffic of the two scan kernels
 # and the bench lines, all into gpurun_out/ under the names profiles/ keeps.   tools/collect_profiles.sh <round tag, e.g. r03>
-R=${1:-r03}
+R=${1:-r04}
 export TMPDIR=/tmp VSV_DEBUG=1
 mkdir -p gpurun_out
 VSV_SPLIT_STREAM=main tools/prof_step.sh ${R}_row2c_contig200k --config 6 --streams 1 > /dev/null

@@ -57,6 +57,10 @@ def cmd_pmc(a):
     alg = 24 * a.records + 4 * a.ops + 32 * a.sigs
     out.update(fetch_bytes_corrected=fb, write_bytes=wb, traffic_bytes_per_launch=fb + wb, algorithmic_bytes_per_launch=alg,
                traffic_over_algorithmic=(fb + wb) / alg)
+    # which version of the kernel's source this was taken from: bench.py refuses the lookup for any other (the GPU box has no .git)
+    import hashlib
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "volcanosv_amd", "csrc", "cigar_scan.hip")
+    out["kernel_source_sha256"] = hashlib.sha256(open(src, "rb").read()).hexdigest()
     json.dump(out, open(a.out, "w"), indent=1)
     print("traffic %.4f GB per launch = %.3f x algorithmic" % ((fb + wb) / 1e9, (fb + wb) / alg))
 

@@ -96,6 +96,7 @@ struct vsv_handle {
                                    // scan's descriptors when somebody asks; 2 = those are gone (buffers re-allocated since)
   int raw_parts = 0;               // ... parts of that scan
   bool have_history = false;       // a signature run of this handle has finished: host_ctr describes real tables (else: a COLD handle)
+  bool cold_run = false;           // the run in flight is such a handle's first one: its row count comes from a wait for its own scan
   bool ctr_of_run = false;         // host_ctr holds the counters of the run in progress (a staged call's finish()), not of the previous one
   int64_t element_runs = 0, cold_syncs = 0;          // vsv_path_counts
   vsv_bnd_params bnd_prm{};
@@ -335,24 +336,29 @@ int key_bits(vsv_handle* h) { return pos_bits(h) + 3 + tid_bits(h) + 1; }   // +
 bool is_contig(int dtype) { return dtype == VSV_DTYPE_HIFI || dtype == VSV_DTYPE_ONT || dtype == VSV_DTYPE_CLR; }
 
 // ---- stage enqueue functions ------------------------------------------------------------------------
-int enq_split_candidates(vsv_handle* h, hipStream_t st) {
+int cand_alloc(vsv_handle* h) {
+  const size_t n = (size_t)h->cap_sigs;
+  int ws;
+  if ((ws = ensure(h, h->cinfo, n * 32 + 64)) || (ws = ensure(h, h->cord, n * 4 + 64)) || (ws = ensure(h, h->oc1, n * 4 + 64))) return ws;
+  return 0;
+}
+int enq_split_candidates(vsv_handle* h, hipStream_t st, int phase = 0) {
   SlimWork w;
   const bool slim = h->big_run && is_contig(h->prm.dtype);     // (a large-table run: the candidate tables are large too)
   CandBufs cb{nullptr, nullptr, nullptr};
   if (slim) {
     int ws = slim_work(h, w); if (ws) return ws;
     if (!vsv_scan_is_long(h->rv, h->prm)) {           // per-candidate record info for split_eval_info (sig_stages.hip)
-      const size_t n = (size_t)h->cap_sigs;
-      if ((ws = ensure(h, h->cinfo, n * 32 + 64)) || (ws = ensure(h, h->cord, n * 4 + 64)) || (ws = ensure(h, h->oc1, n * 4 + 64))) return ws;
+      if ((ws = cand_alloc(h))) return ws;            // (allocated in front of the run's first launch: this finds them in place)
       cb = CandBufs{h->cinfo.p, (uint32_t*)h->cord.p, (uint32_t*)h->oc1.p};
     }
   }
   h->split_sorted = vsv_launch_split_candidates(st, h->rv, h->prm, h->n_tids, (uint32_t*)h->tab.p, h->tab_size, (uint32_t*)h->blk_cnt.p,
                                                 (uint32_t*)h->blk_off.p, (uint32_t*)h->scan_tmp2.p, (uint64_t*)h->ckey.p, (uint32_t*)h->crec.p,
                                                 (uint64_t*)h->okey.p, (uint32_t*)h->oval.p, (uint64_t*)h->key2.p, (uint32_t*)h->idx2.p, sort_work(h),
-                                                (uint32_t)h->cap_sigs, dctr(h), (uint8_t*)h->cmask.p, ew_grid(h), slim ? &w : nullptr, cb);
+                                                (uint32_t)h->cap_sigs, dctr(h), (uint8_t*)h->cmask.p, ew_grid(h), slim ? &w : nullptr, cb, phase);
   HIPCHK(h, hipGetLastError());
-  h->split_cands_done = true;
+  h->split_cands_done = phase != 1;
   return 0;
 }
 int enq_scan(vsv_handle* h) {
@@ -364,8 +370,10 @@ int enq_scan(vsv_handle* h) {
   h->cutesv_rows = -1;   // the split-candidate table shares a buffer with the merge stage
   h->ctr_of_run = false;
   if (is_contig(h->prm.dtype)) {   // the element buffers this run may need exist before its first launch (a large-table handle: all of them)
-    int as = slim_alloc(h, want_big(h) || !h->have_history);
+    const bool all = want_big(h) || !h->have_history;
+    int as = slim_alloc(h, all);
     if (as) return as;
+    if (all && !vsv_scan_is_long(h->rv, h->prm) && (as = cand_alloc(h))) return as;
   }
   const int n_parts = vsv_cigar_parts(h->rv.n_ops, OPS_PER_PART);
   RecView srv = h->rv;
@@ -390,9 +398,9 @@ int enq_scan(vsv_handle* h) {
     HIPCHK(h, hipMemsetAsync(h->lbw.p, 0, h->lbw.bytes, st));
     h->lb_epoch = 1;
   }
-  // contig alignments through the long scan: the placement writes the rows straight into the stage-1 input table, next to their
-  // elements, and the fold runs there in place (VSV_T_RAW is re-placed from the scan's descriptors when somebody asks)
-  const int long_parts = vsv_long_scan_parts(srv, h->prm, OPS_PER_PART);
+  // the contig path: the placement writes the rows straight into the stage-1 input table, next to their elements, and the fold runs
+  // there in place (VSV_T_RAW is re-placed from the scan's batches when somebody asks)
+  const int long_parts = vsv_scan_parts(srv, h->prm, OPS_PER_PART);
   const bool fused = is_contig(h->prm.dtype) && long_parts > 0;
   SlimOut so_f{nullptr, 0, 0, 0, nullptr};
   if (fused) so_f = SlimOut{h->sl[0].p, pos_bits(h), h->rv.tid_lo, tid_bits(h), &dctr(h)->err};
@@ -408,12 +416,24 @@ int enq_scan(vsv_handle* h) {
   // A COLD handle knows nothing about its tables — and every invocation of the drop-in CLI is one (one process per chromosome,
   // Raw_variant_call.py:65-73): the fused run waits for the scan once and takes the row count from it, so that the path, the sort
   // form and the grids of the stages behind it are those a warm handle would use.
-  if (h->fork_split && !h->have_history && !h->in_rerun && is_contig(h->prm.dtype) && h->rv.n_records > 0) {
+  const bool cold = h->fork_split && !h->have_history && !h->in_rerun && is_contig(h->prm.dtype) && h->rv.n_records > 0;
+  if (cold) {
+    if (early_cands) {            // the candidates themselves (not their sorts: those depend on the path) beside the scan, as on a warm handle
+      if (fork) HIPCHK(h, hipStreamWaitEvent(h->aux, h->ev_fork, 0));
+      int cs = enq_split_candidates(h, fork ? h->aux : st, 1);
+      if (cs) return cs;
+      if (fork) HIPCHK(h, hipStreamSynchronize(h->aux));
+    }
     HIPCHK(h, hipMemcpyAsync(h->pinned, h->ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
     const Counters c = *h->pinned;
-    if (!(c.err & ERRB_CAPACITY)) { h->host_ctr.n_raw = c.n_raw; h->host_ctr.n_s1 = c.n_raw; h->small_sort_tiles = c.n_raw <= 128u * 4096u; }
+    if (!(c.err & ERRB_CAPACITY)) {
+      h->host_ctr.n_raw = c.n_raw; h->host_ctr.n_s1 = c.n_raw; h->host_ctr.n_cand = early_cands ? c.n_cand : 0;
+      const uint32_t big = c.n_raw > h->host_ctr.n_cand ? c.n_raw : h->host_ctr.n_cand;
+      h->small_sort_tiles = big <= 128u * 4096u;
+    }
     ++h->cold_syncs;
+    h->cold_run = true;
   }
   // the path of the stages behind the split stage is decided here, so that the fold (and split_eval) can write the elements of a
   // large-table run next to their rows
@@ -428,8 +448,8 @@ int enq_scan(vsv_handle* h) {
   }
   HIPCHK(h, hipGetLastError());
   if (early_cands) {
-    if (fork) HIPCHK(h, hipStreamWaitEvent(h->aux, h->ev_fork, 0));
-    int cs = enq_split_candidates(h, fork ? h->aux : st);
+    if (fork && !cold) HIPCHK(h, hipStreamWaitEvent(h->aux, h->ev_fork, 0));
+    int cs = enq_split_candidates(h, fork ? h->aux : st, cold ? 2 : 0);
     if (cs) return cs;
     if (fork) { HIPCHK(h, hipEventRecord(h->ev_join, h->aux)); h->aux_pending = true; }
   }
@@ -581,6 +601,7 @@ int finish(vsv_handle* h) {
   h->host_ctr = *h->pinned;
   h->pending = false;
   if (h->stage_done >= 1) { h->have_history = true; h->ctr_of_run = true; }
+  h->cold_run = false;
   if (h->stage_done >= 5) {   // pairing of the NEXT run: in rounds once a stretch of thousands of rows was met, back to the plain
                               // kernel when the merged table gets small again (the rounds cost ~20 launches)
     static const char* force = vsv_dbg_env("VSV_PAIR");          // tests: "rounds" / "walk"
@@ -592,6 +613,8 @@ int finish(vsv_handle* h) {
     const uint32_t big = h->host_ctr.n_s1 > h->host_ctr.n_cand ? h->host_ctr.n_s1 : h->host_ctr.n_cand;
     h->small_sort_tiles = big <= 128u * 4096u;
   }
+  // (the rows of a contig run always get their elements; their 32-bit limits matter only to a run whose stages worked on them)
+  if (!h->big_run) h->host_ctr.err &= ~(uint32_t)ERRB_SLIM_FALLBACK;
   const uint32_t e = h->host_ctr.err;
   h->last_count = h->host_ctr.n_pool;
   static const char* trace = vsv_dbg_env("VSV_TRACE_COUNTERS");
@@ -821,6 +844,13 @@ int vsv_reserve(vsv_handle* h, int64_t max_records, int64_t max_ops, int64_t max
     return 0;
   }
   return reserve(h, max_records, max_ops, max_sigs);
+}
+
+int vsv_reserve_large_tables(vsv_handle* h) {
+  if (!h) return VSV_E_INVALID;
+  if (hipSetDevice(h->device) != hipSuccess) return VSV_E_HIP;
+  if (h->cap_sigs <= 0) { int st = reserve(h, 1, 1, 1 << 22); if (st) return st; }
+  return slim_alloc(h, true);
 }
 
 int vsv_cigar_scan(vsv_handle* h, const vsv_records* recs, const vsv_params* p) {
@@ -1760,7 +1790,7 @@ static int table_src(vsv_handle* h, int table, const void** src, int64_t* n_rows
     if (h->raw_state == 2) return VSV_E_INVALID;
     if (hipSetDevice(h->device) != hipSuccess) return VSV_E_HIP;
     if (++h->lb_epoch >= (1u << 24)) { if (hipMemsetAsync(h->lbw.p, 0, h->lbw.bytes, h->stream) != hipSuccess) return VSV_E_HIP; h->lb_epoch = 1; }
-    vsv_launch_long_place(h->stream, h->rv, h->prm, h->raw_parts, (vsv_sig*)h->pool.p, (uint64_t*)h->pool_key.p, (uint32_t)h->cap_sigs, (uint32_t*)h->part_count.p,
+    vsv_launch_place(h->stream, h->rv, h->prm, h->raw_parts, (vsv_sig*)h->pool.p, (uint64_t*)h->pool_key.p, (uint32_t)h->cap_sigs, (uint32_t*)h->part_count.p,
                           (uint32_t*)h->part_off.p, (vsv_sig*)h->raw0.p, dctr(h), (uint32_t*)h->shard_cnt.p, long_bufs(h, false, nullptr, SlimOut{nullptr, 0, 0, 0, nullptr}),
                           h->lb_epoch, SlimOut{nullptr, 0, 0, 0, nullptr});
     if (hipStreamSynchronize(h->stream) != hipSuccess) return VSV_E_HIP;

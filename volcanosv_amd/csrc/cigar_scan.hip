@@ -141,17 +141,17 @@ __global__ __launch_bounds__(64) void partition_fill(const uint64_t* __restrict_
 
 // Emit pool = K1_SHARDS independent sub-pools (cursor s on its own 64-byte line). A single cursor word saturates at
 // ~88 returning atomics/us (MI355X_MICROARCH.md "dequeue"), which made 88 k emissions cost 0.8 ms; a part uses
-// shard = part % K1_SHARDS and takes slots in geometrically growing batches (4,8,..,64), so both the contention and
-// the number of round trips per wave vanish. Slots a wave does not use are tagged with the sentinel key.
+// shard = part % K1_SHARDS and takes its slots in one allocation when it has streamed its ops.
 constexpr int K1_SHARDS = 256;
-constexpr uint64_t K1_SENTINEL = 0xFFFFFFFFFFFFFFFFull;
 struct EmitCtx {
-  vsv_sig* pool;
-  uint64_t* pool_key;
-  uint32_t* shard_cnt;   // [K1_SHARDS * 16]
+  vsv_sig* pool;         // K1_SHARDS shards of shard_cap rows
+  uint32_t* shard_cnt;   // [K1_SHARDS * 16]: cursor s at [16 s]; [8]: cursor of the overflow list
   uint32_t shard_cap;    // rows per shard
   Counters* ctr;
+  uint2* prec;           // per part: {location, rows} of its last (normally only) batch
+  uint4* batches; uint32_t batch_cap;     // overflow list {part, first ordinal, location, rows}
 };
+constexpr int K1E_STAGE = 32;      // rows a wave of the read-shaped scan stages before a batch leaves (1 KiB)
 
 // five wave-uniform dword loads through the scalar cache (lgkmcnt): they do not drain the in-flight vector loads
 __device__ __forceinline__ void sload5(const void* p0, const void* p1, const void* p2, const void* p3, const void* p4,
@@ -194,10 +194,11 @@ constexpr int K1G_CH = 96;      // chunks (24576 ops) of a part whose M-op masks
 template <int CLS, int DEPTH, bool GATE = false>
 __global__ __launch_bounds__(256) void cigar_scan_emit(RecView rv, const uint32_t* __restrict__ rb, int n_parts,
                                                         int min_svlen, int min_mapq, EmitCtx ec,
-                                                        uint32_t* __restrict__ part_count, int ablate, uint32_t* __restrict__ tile_sum) {
+                                                        uint32_t* __restrict__ part_count, int ablate) {
   using T = OpTab<CLS>;
   static_assert(!GATE || CLS == 0, "the gate belongs to the contig op table");
   __shared__ uint32_t sh_off[K1_WAVES][K1_RMAX + 1];
+  __shared__ uint4 sh_rows[K1_WAVES][2 * K1E_STAGE];            // rows of the part, staged (wave-private) until they leave as one batch
   __shared__ uint64_t sh_gm[GATE ? K1_WAVES : 1][GATE ? K1G_CH : 1][4];    // per chunk: which lanes hold an M op in op slot k (lane l: ops 4l..4l+3)
   __shared__ uint32_t sh_cp[GATE ? K1_WAVES : 1][GATE ? K1G_CH + 1 : 1];   // per chunk: M ops of the part in front of it
   const int lane = threadIdx.x & 63;
@@ -206,11 +207,11 @@ __global__ __launch_bounds__(256) void cigar_scan_emit(RecView rv, const uint32_
   if (part >= n_parts) return;
   const uint32_t r0 = __builtin_amdgcn_readfirstlane(rb[part]), r1 = __builtin_amdgcn_readfirstlane(rb[part + 1]);
   uint32_t ord = 0;  // signatures emitted by this part so far (wave-uniform)
-  if (r0 >= r1) { if (lane == 0) part_count[part] = 0; return; }
+  if (r0 >= r1) { if (lane == 0) { part_count[part] = 0; ec.prec[part] = make_uint2(0u, 0u); } return; }
   const uint64_t o0 = rv.cigar_off[r0], o1 = rv.cigar_off[r1];
   const uint64_t cb0 = o0 & ~3ull;  // absolute op index of rel 0 (16-byte aligned)
   if (o1 <= o0 || o1 - cb0 >= 0x3FFFFF00ull) {  // relative BYTE offsets must fit 32 bits
-    if (lane == 0) { atomicOr(&ec.ctr->err, o1 <= o0 ? ERRB_EMPTY_CIGAR : ERRB_RANGE); part_count[part] = 0; }
+    if (lane == 0) { atomicOr(&ec.ctr->err, o1 <= o0 ? ERRB_EMPTY_CIGAR : ERRB_RANGE); part_count[part] = 0; ec.prec[part] = make_uint2(0u, 0u); }
     return;
   }
   const uint32_t ob_rel = (uint32_t)(o0 - cb0), oe_rel = (uint32_t)(o1 - cb0);
@@ -316,26 +317,32 @@ __global__ __launch_bounds__(256) void cigar_scan_emit(RecView rv, const uint32_
   // (L2-hot) chunks from the checkpoint (or from the record's start chunk) up to the current one.
   uint32_t ck_rec = 0xFFFFFFFFu, ck_chunk = 0, ck_r = 0, ck_q = 0;
 
-  // slot allocator of this wave inside its shard (all wave-uniform)
+  // rows collect in LDS and leave as ONE batch at the end of the part (a part of a read-shaped input emits a row or two): one slot
+  // allocation in the part's shard of the pool, coalesced stores, and the part files where its batch lies for the placement kernel
+  // (k1l_place). A part with more rows than the stage holds files the batches in front of its last one in the overflow list.
   const uint32_t shard = (uint32_t)part % K1_SHARDS;
-  const uint32_t shard_off = shard * ec.shard_cap;
-  uint32_t al_base = 0, al_left = 0, al_next = 4;
-  auto release_left = [&]() {
-    if ((uint32_t)lane < al_left && al_base + (uint32_t)lane < ec.shard_cap) ec.pool_key[shard_off + al_base + lane] = K1_SENTINEL;
-  };
-  auto alloc = [&](uint32_t n) -> uint32_t {
-    if (al_left < n) {
-      release_left();
+  uint4* my_rows = sh_rows[wv];
+  uint32_t n_staged = 0;
+  auto flush = [&](bool last) {
+    uint32_t loc = 0, n = 0;
+    if (n_staged != 0) {
       uint32_t b = 0;
-      if (lane == 0) b = atomicAdd(&ec.shard_cnt[shard * 16], al_next);
-      al_base = __builtin_amdgcn_readfirstlane(b);
-      al_left = al_next;
-      al_next = al_next < 64u ? al_next * 2u : 64u;
+      if (lane == 0) b = atomicAdd(&ec.shard_cnt[shard * 16], n_staged);
+      const uint32_t slot = __builtin_amdgcn_readfirstlane(b);
+      if (slot + n_staged <= ec.shard_cap) {                    // (else: the placement pass reports the shard's use, the rows of this batch stay unwritten)
+        loc = shard * ec.shard_cap + slot; n = n_staged;
+        uint4* dst = reinterpret_cast<uint4*>(ec.pool + loc);
+        for (uint32_t i = lane; i < 2u * n_staged; i += 64) dst[i] = my_rows[i];
+      }
+      if (!last && n != 0 && lane == 0) {
+        const uint32_t e = atomicAdd(&ec.shard_cnt[8], 1u);
+        if (e < ec.batch_cap) ec.batches[e] = make_uint4((uint32_t)part, ord - n_staged, loc, n);
+        else atomicOr(&ec.ctr->err, ERRB_CAPACITY);
+      }
+      __builtin_amdgcn_wave_barrier();
     }
-    const uint32_t sl = al_base;
-    al_base += n;
-    al_left -= n;
-    return sl;
+    if (last && lane == 0) ec.prec[part] = make_uint2(loc, n);
+    n_staged = 0;
   };
 
   // decoded chunk: per-op (ref, query) advances, their wave-exclusive prefix per lane and the chunk totals
@@ -460,21 +467,15 @@ __global__ __launch_bounds__(256) void cigar_scan_emit(RecView rv, const uint32_
         }
         const uint32_t hc = (T::HC && (hd_first & 15u) == 5u) ? (hd_first >> 4) : 0u;             // H:63-65
         const uint32_t nemit = (hapbits == 3u) ? 2u : 1u;
-        const uint32_t slot = alloc(nemit);
-        if (lane < (int)nemit && slot + (uint32_t)lane < ec.shard_cap) {
-          vsv_sig sg;
-          sg.pos = (int32_t)(hd_pos + a_r);
-          sg.svlen = (int32_t)len;
-          sg.q_start = (int32_t)(a_q + hc);
-          sg.q_end = (CLS == 1 || CLS == 3) ? 0 : sg.q_start + (op == 2u ? 1 : (int32_t)len);
-          sg.rec = rec;
-          sg.rec2 = 0xFFFFFFFFu;
+        if (n_staged + nemit > (uint32_t)K1E_STAGE) flush(false);
+        if (lane < (int)nemit) {
+          const uint32_t qs = a_q + hc;
           const uint32_t hp2 = (CLS == 0) ? ((hapbits == 3u) ? (uint32_t)lane : (hapbits >> 1)) : 0u;
-          sg.meta = (op == 2u ? VSV_M_DEL : 0u) | (hp2 ? VSV_M_HP2 : 0u);
-          sg.tid = (int32_t)hd_tid;
-          ec.pool[shard_off + slot + lane] = sg;
-          ec.pool_key[shard_off + slot + lane] = ((uint64_t)(uint32_t)part << 32) | (uint64_t)(ord + (uint32_t)lane);
+          my_rows[2 * (n_staged + lane)] = make_uint4(hd_pos + a_r, len, qs, (CLS == 1 || CLS == 3) ? 0u : qs + (op == 2u ? 1u : len));
+          my_rows[2 * (n_staged + lane) + 1] = make_uint4(rec, 0xFFFFFFFFu, (op == 2u ? (uint32_t)VSV_M_DEL : 0u) | (hp2 ? (uint32_t)VSV_M_HP2 : 0u), hd_tid);
         }
+        __builtin_amdgcn_wave_barrier();
+        n_staged += nemit;
         ord += nemit;
       }
     }
@@ -600,10 +601,7 @@ __global__ __launch_bounds__(256) void cigar_scan_emit(RecView rv, const uint32_
       }
     }
   }
-  release_left();
-  // (per-tile sums of these counts through atomics were tried: the parts of a tile finish together, so ~2000 adds queue up on
-  // one word at a time and the scan took 540 instead of 250 us)
-  (void)tile_sum;
+  flush(true);
   if (lane == 0) part_count[part] = ord;
 }
 
@@ -627,317 +625,9 @@ __global__ __launch_bounds__(256) void cigar_scan_emit(RecView rv, const uint32_
 //    carry each part's head rows still miss, and place_raw adds it while it puts the rows in order. No spinning, no inter-wave
 //    communication inside the kernel, one extra 12-byte record per 32 KiB of CIGAR.
 constexpr int K1L_PART = 8192;            // ops per part (32 KiB), a multiple of the 256-op chunk
-constexpr uint32_t K1L_CARRY = 0x80000000u;   // pool_key ordinal bit: the row still misses the carry of its part
 struct PartAgg { uint32_t has_start, run_r, run_q; };
 
 constexpr uint32_t dup16(uint32_t t) { return t | (t << 16); }
-
-constexpr int K1L_STAGE = 64;             // rows a wave stages in LDS before it flushes them to the pool (one per lane)
-
-template <int CLS>
-__global__ __launch_bounds__(256) void cigar_scan_long_pool(RecView rv, const uint32_t* __restrict__ rb, int n_parts,
-                                                        int min_svlen, int min_mapq, EmitCtx ec,
-                                                        uint32_t* __restrict__ part_count, PartAgg* __restrict__ agg, int ablate) {
-  using T = OpTab<CLS>;
-  __shared__ uint32_t sh_off[K1_WAVES][K1_RMAX + 1];
-  __shared__ uint4 sh_rows[K1_WAVES][K1L_STAGE * 2];           // staged rows (32 B each), wave-private
-  const int lane = threadIdx.x & 63;
-  const int wv = threadIdx.x >> 6;
-  const int part = blockIdx.x * K1_WAVES + wv;
-  if (part >= n_parts) return;
-  const uint64_t n_rec = (uint64_t)rv.n_records;
-  uint64_t end_all = rv.cigar_off[n_rec];                       // ops behind the last record belong to nobody
-  if (end_all > (uint64_t)rv.n_ops) end_all = (uint64_t)rv.n_ops;
-  const uint64_t e0 = (uint64_t)part * K1L_PART;
-  uint32_t ord = 0;                                             // rows emitted by this part so far (staged ones included)
-  uint32_t r0 = __builtin_amdgcn_readfirstlane(rb[part]), r1 = __builtin_amdgcn_readfirstlane(rb[part + 1]);
-  if (r1 < r0) r1 = r0;                                          // offsets that do not ascend: reported below, never followed
-  // (read with a vector load, so the compiler must be told that it is wave-uniform: every loop below is bounded by it)
-  const uint32_t part_len = __builtin_amdgcn_readfirstlane(e0 >= end_all ? 0u : (uint32_t)((end_all - e0) < (uint64_t)K1L_PART ? (end_all - e0) : (uint64_t)K1L_PART));
-
-  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-  const uint32_t* part_base = rv.cigar + e0;
-  const uint32_t base_lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)part_base);
-  const uint32_t base_hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)part_base >> 32));
-  // The ring loads are issued and awaited by hand (inline asm): the loop below reaches each streaming block over several paths
-  // (straight from the previous block, or through the emission block), and hipcc's wait-count insertion answers such merges with
-  // vmcnt(0), i.e. no load would ever stay in flight across a chunk. Four ring loads are outstanding whenever a block consumes
-  // the oldest one, so "at most three younger operations outstanding" is exact in the streaming loop and merely conservative
-  // (the flush's stores and atomics count too) behind the emission block. Raw buffer descriptor clipped to the part: the
-  // prefetch that runs past its end returns zeros without touching memory.
-  u32x4 rsrc;
-  rsrc.x = base_lo; rsrc.y = base_hi & 0xFFFFu; rsrc.z = __builtin_amdgcn_readfirstlane(part_len * 4u); rsrc.w = 0x00020000u;
-  const uint32_t lane16 = 16u * (uint32_t)lane;
-  auto issue = [&](u32x4& dst, uint32_t cb) {
-    const uint32_t voff = cb * 4u + lane16;
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(voff), "s"(rsrc) : "memory");
-  };
-  u32x4 wa, wb, wc, wd;
-  issue(wa, 0); issue(wb, 256); issue(wc, 512); issue(wd, 768);
-#define K1L_ARRIVE(reg) asm volatile("s_waitcnt vmcnt(3)" : "+v"(reg) : : "memory")
-
-  // ---- record starts of this part, relative to e0, staged K1_RMAX at a time; every record is checked by the part that holds
-  // its start (an empty CIGAR must raise: H:63 IndexError) -------------------------------------------------------------------
-  const uint32_t e0_lo = (uint32_t)e0;
-  uint32_t* my_off = sh_off[wv];
-  uint32_t tbase = r0, n_tab = 0, ti = 0;       // staged records [tbase, tbase + n_tab), next unconsumed entry ti
-  bool bad = false;
-  auto stage = [&](uint32_t first) {
-    tbase = first; ti = 0;
-    n_tab = min((uint32_t)K1_RMAX, r1 - first);
-    bool ok = true;
-    for (uint32_t i = lane; i < n_tab; i += 64) {
-      const uint64_t o = rv.cigar_off[first + i], nx = rv.cigar_off[(uint64_t)first + i + 1];
-      my_off[i] = (uint32_t)o - e0_lo;
-      ok = ok && nx > o && o >= e0 && o - e0 < (uint64_t)part_len;      // ascending, inside this part
-      if (CLS == 0 || CLS == 1) {               // a walked record whose SEQ length differs from its CIGAR's: H:397-398, RS:123-124
-        const uint32_t fl = rv.flag[first + i];
-        if ((fl & VSV_F_SEQ_MISMATCH) && rv.mapq[first + i] >= (uint32_t)min_mapq && (CLS == 1 || (fl & (VSV_F_HP1 | VSV_F_HP2))))
-          atomicOr(&ec.ctr->err, ERRB_SEQLEN);
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-    if (__ballot(!ok)) { if (lane == 0) atomicOr(&ec.ctr->err, ERRB_EMPTY_CIGAR); bad = true; }
-  };
-  if (r1 > r0) stage(r0);
-  auto next_start = [&]() -> uint32_t {         // relative op index of the next record start of the part (wave-uniform)
-    if (ti >= n_tab) {
-      if (tbase + n_tab >= r1 || bad) return 0xFFFFFFFFu;
-      stage(tbase + n_tab);
-      if (bad || n_tab == 0) return 0xFFFFFFFFu;
-    }
-    return __builtin_amdgcn_readfirstlane(my_off[ti]);
-  };
-  uint32_t nxt = (r1 > r0 && !bad) ? next_start() : 0xFFFFFFFFu;
-  // the record that is open at the part's start: r0 - 1, unless a record starts exactly there
-  uint32_t cur_rec = (r0 > 0 && !(nxt == 0u)) ? r0 - 1u : 0xFFFFFFFFu;
-  bool in_head = true;                          // no record start seen yet: rows miss the carry of the part
-  uint32_t has_start = 0;
-  uint32_t run_r = 0, run_q = 0;                // advance since the current record's start (or since e0 while in_head)
-
-  // ---- row staging: rows collect in LDS (wave-private, row order) and leave K1L_STAGE at a time: one exact slot allocation per
-  // flush (no unused slots), coalesced 32-byte stores from every lane instead of three 1-2-lane stores per signature ----------
-  const uint32_t shard = (uint32_t)part % K1_SHARDS;
-  const uint32_t shard_off = shard * ec.shard_cap;
-  uint4* my_rows = sh_rows[wv];
-  uint32_t n_staged = 0;
-  auto flush = [&]() {
-    if (n_staged == 0) return;
-    uint32_t b = 0;
-    if (lane == 0) b = atomicAdd(&ec.shard_cnt[shard * 16], n_staged);
-    const uint32_t slot = __builtin_amdgcn_readfirstlane(b);
-    if ((uint32_t)lane < n_staged && slot + (uint32_t)lane < ec.shard_cap) {
-      uint4 lo4 = my_rows[2 * lane], hi4 = my_rows[2 * lane + 1];
-      const uint32_t cbit = hi4.y == 0xFFFFFFFEu ? K1L_CARRY : 0u;      // rec2 doubles as the carry flag while staged
-      hi4.y = 0xFFFFFFFFu;
-      uint4* dst = reinterpret_cast<uint4*>(ec.pool + shard_off + slot + lane);
-      dst[0] = lo4; dst[1] = hi4;
-      ec.pool_key[shard_off + slot + lane] = ((uint64_t)(uint32_t)part << 32) | (uint64_t)(cbit | (ord - n_staged + (uint32_t)lane));
-    }
-    __builtin_amdgcn_wave_barrier();
-    n_staged = 0;
-  };
-
-  const uint32_t thr = (uint32_t)min_svlen;
-  const uint32_t thr16 = thr >= (1u << 28) ? 0xFFFFFFFFu : thr << 4;
-  constexpr uint32_t EMIT_R = rev32(EMIT_MASK | (EMIT_MASK << 16));
-  constexpr uint32_t BAD_R = rev32(T::BAD | (T::BAD << 16));
-  constexpr uint32_t REF2 = dup16(T::REF), QRY2 = dup16(T::QRY);   // bit (w & 31) of these = bit (op) of the table
-  uint32_t hd_rec = 0xFFFFFFFFu, hd_fl = 0, hd_mq = 0, hd_tid = 0, hd_first = 0, hd_pos = 0;   // cached record header (SGPRs)
-  uint32_t hd_hap = 0, hd_hc = 0;                                                               // ... and what the emissions derive from it
-
-  // ---- the chunk handed from the streaming blocks to the (single) emission block -----------------------------------------
-  uint32_t pw[4] = {0, 0, 0, 0}, p_pr0 = 0, p_pq0 = 0;          // its ops and each lane's exclusive in-chunk prefix
-  bool pe0 = false, pe1 = false, pe2 = false, pe3 = false;      // ... and which of them are candidates (lane masks: they stay in scalar registers)
-  bool p_badany = false;
-  uint32_t p_cb = 0, p_tot_r = 0, p_tot_q = 0;
-  bool pending = false;
-
-  // streaming block: candidate test, decode, ONE pair of prefix sums; hands the chunk over when it holds a candidate or a start
-  auto stream = [&](const u32x4& wcur, const uint32_t cb) {
-    if (cb >= part_len || bad) return;
-    const uint32_t w[4] = {wcur.x, wcur.y, wcur.z, wcur.w};
-    const bool e0 = (int32_t)(EMIT_R << (w[0] & 31u)) < 0 && w[0] >= thr16, e1 = (int32_t)(EMIT_R << (w[1] & 31u)) < 0 && w[1] >= thr16;
-    const bool e2 = (int32_t)(EMIT_R << (w[2] & 31u)) < 0 && w[2] >= thr16, e3 = (int32_t)(EMIT_R << (w[3] & 31u)) < 0 && w[3] >= thr16;
-    bool bd = false;
-    if (T::BAD != 0) {
-      const uint32_t t = (BAD_R << (w[0] & 31u)) | (BAD_R << (w[1] & 31u)) | (BAD_R << (w[2] & 31u)) | (BAD_R << (w[3] & 31u));
-      bd = (int32_t)t < 0;
-    }
-    uint32_t sum_r = 0, sum_q = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const uint32_t len = w[k] >> 4;
-      sum_r += len & (uint32_t)__builtin_amdgcn_sbfe(REF2, w[k], 1);
-      sum_q += len & (uint32_t)__builtin_amdgcn_sbfe(QRY2, w[k], 1);
-    }
-    const uint32_t incl_r = wave_incl_scan(sum_r), incl_q = wave_incl_scan(sum_q);
-    const uint32_t tot_r = rdlane(incl_r, 63), tot_q = rdlane(incl_q, 63);
-    const bool any_cand = __ballot(e0 | e1 | e2 | e3 | bd) != 0ull && !(ablate & 1);
-    if (!any_cand && !(nxt < cb + 256u)) { run_r += tot_r; run_q += tot_q; return; }
-    pw[0] = w[0]; pw[1] = w[1]; pw[2] = w[2]; pw[3] = w[3];
-    pe0 = e0 && !(ablate & 1); pe1 = e1 && !(ablate & 1); pe2 = e2 && !(ablate & 1); pe3 = e3 && !(ablate & 1);
-    p_pr0 = incl_r - sum_r; p_pq0 = incl_q - sum_q;
-    p_badany = any_cand && __ballot(bd) != 0ull;
-    p_cb = cb; p_tot_r = tot_r; p_tot_q = tot_q;
-    pending = true;
-  };
-
-  // emission block: the pending chunk is cut into segments at the record starts it holds (usually none: one segment); the
-  // candidate ops of a segment belong to one record and build their rows together. Counting runs on the scalar unit (the
-  // candidate predicates are lane masks), the vector unit only builds rows for the sub-slots that hold a candidate.
-  auto emit_pending = [&]() {
-    const uint32_t cb = p_cb;
-    const uint32_t x = cb + 4u * (uint32_t)lane;
-    uint32_t base_r = run_r, base_q = run_q, lo = cb, hi_cap = 0xFFFFFFFFu;
-    for (;;) {
-      uint32_t hi = nxt < cb + 256u ? nxt : cb + 256u;
-      if (hi_cap < hi) hi = hi_cap;
-      // ---- segment [lo, hi) of record cur_rec ----
-      if (hi > lo && cur_rec != 0xFFFFFFFFu) {
-        bool e[4] = {pe0, pe1, pe2, pe3};                        // (the streaming block's tests: not evaluated again)
-        const bool whole = lo == cb && hi == cb + 256u;
-        if (!whole) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) e[k] = e[k] && x + k >= lo && x + k < hi;
-        }
-        const uint64_t m0 = __ballot(e[0]), m1 = __ballot(e[1]), m2 = __ballot(e[2]), m3 = __ballot(e[3]);
-        const uint32_t n = (uint32_t)(__popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3));
-        bool any_b = false;
-        if (T::BAD != 0 && p_badany) {
-          bool b = false;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            uint32_t wk = pw[k];
-            asm volatile("" : "+v"(wk));       // keep the test behind its guard (the optimizer hoists loop-invariant arithmetic)
-            b = b || ((int32_t)(BAD_R << (wk & 31u)) < 0 && wk >= 16u && x + k >= lo && x + k < hi);
-          }
-          any_b = __ballot(b) != 0ull;
-        }
-        if (n != 0 || any_b) {
-          const uint32_t rec = __builtin_amdgcn_readfirstlane(cur_rec);
-          if (rec != hd_rec) {                                   // header through the scalar cache, once per record and part
-            const uint64_t* po = rv.cigar_off + rec;
-            uint64_t fo;
-            asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(fo) : "s"(po) : "memory");
-            if (fo >= (uint64_t)rv.n_ops) fo = 0;                // garbage offsets are reported by the part that stages them
-            sload5(align4(rv.flag + rec), align4(rv.mapq + rec), rv.tid + rec, rv.cigar + fo, rv.pos + rec, hd_fl, hd_mq, hd_tid, hd_first, hd_pos);
-            hd_rec = rec;
-            // ... and what every emission of the record derives from it (the kernel is bound by scalar instructions on dense input:
-            // a Mb contig emits thousands of times per header)
-            const uint32_t fl = byte_of(hd_fl, rv.flag + rec), mq = byte_of(hd_mq, rv.mapq + rec);
-            if (CLS == 0) hd_hap = (mq >= (uint32_t)min_mapq) ? ((fl >> 2) & 3u) : 0u;               // H:392-394
-            else if (CLS == 1) hd_hap = (mq >= (uint32_t)min_mapq) ? 1u : 0u;                        // RS:120
-            else if (CLS == 3) hd_hap = (!(fl & VSV_F_SKIP) && mq >= (uint32_t)min_mapq) ? 1u : 0u; // SE:439, 446
-            else hd_hap = (!(fl & (VSV_F_UNMAPPED | VSV_F_SECONDARY)) && mq >= (uint32_t)min_mapq) ? 1u : 0u;
-            hd_hc = (T::HC && (hd_first & 15u) == 5u) ? (hd_first >> 4) : 0u;                       // H:63-65
-          }
-          const uint32_t hapbits = hd_hap;
-          if (hapbits && any_b && lane == 0) atomicOr(&ec.ctr->err, ERRB_REFEND);   // N/=/X on the contig table: H:396 assert
-          if (hapbits && n != 0) {
-            const uint32_t sh = (hapbits == 3u) ? 1u : 0u;       // two rows per signature when the name carries both tags
-            const uint32_t nrows = n << sh;
-            if (nrows > (uint32_t)K1L_STAGE) { hi_cap = lo + (uint32_t)K1L_STAGE / 2u; continue; }   // 32 ops hold at most 64 rows: cut the segment
-            if (n_staged + nrows > (uint32_t)K1L_STAGE) flush();
-            const uint32_t hc = hd_hc;
-            const uint32_t rec2 = in_head ? 0xFFFFFFFEu : 0xFFFFFFFFu;   // staged rows: rec2 carries the "misses the part's carry" flag
-            const uint32_t pos0 = hd_pos + base_r, q0 = base_q + hc;
-            const uint32_t hapmeta = (CLS == 0 && hapbits == 2u) ? VSV_M_HP2 : 0u;
-            // candidates of lower lanes (mbcnt of each non-empty mask)
-            uint32_t below = 0;
-            if (m0) below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, below));
-            if (m1) below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, below));
-            if (m2) below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, below));
-            if (m3) below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m3, below));
-            uint32_t pr = p_pr0, pq = p_pq0;                     // prefix in front of sub-slot k, advanced as k goes up
-            auto put = [&](int k, uint32_t own) {
-              const uint32_t idx = n_staged + ((below + own) << sh);
-              uint32_t wk = pw[k];
-              asm volatile("" : "+v"(wk));     // rows are built only for sub-slots that hold a candidate: keep the arithmetic here
-              const uint32_t op = wk & 15u, len = wk >> 4;
-              uint4 lo4, hi4;
-              lo4.x = pos0 + pr;                                                   // pos
-              lo4.y = len;                                                         // svlen
-              lo4.z = q0 + pq;                                                     // q_start
-              lo4.w = (CLS == 1 || CLS == 3) ? 0u : lo4.z + (op == 2u ? 1u : len); // q_end
-              hi4.x = rec; hi4.y = rec2; hi4.w = hd_tid;
-              const uint32_t del = op == 2u ? VSV_M_DEL : 0u;
-              hi4.z = del | hapmeta;
-              my_rows[2 * idx] = lo4; my_rows[2 * idx + 1] = hi4;
-              if (sh) { hi4.z = del | VSV_M_HP2; my_rows[2 * idx + 2] = lo4; my_rows[2 * idx + 3] = hi4; }
-            };
-            auto advance = [&](int k) {
-              uint32_t wk = pw[k];
-              asm volatile("" : "+v"(wk));
-              const uint32_t len = wk >> 4;
-              pr += len & (uint32_t)__builtin_amdgcn_sbfe(REF2, wk, 1);
-              pq += len & (uint32_t)__builtin_amdgcn_sbfe(QRY2, wk, 1);
-            };
-            if (m0) { if (e[0]) put(0, 0u); }
-            if (m1 | m2 | m3) {
-              advance(0);
-              uint32_t own = e[0] ? 1u : 0u;
-              if (m1) { if (e[1]) put(1, own); }
-              if (m2 | m3) {
-                advance(1);
-                own += e[1] ? 1u : 0u;
-                if (m2) { if (e[2]) put(2, own); }
-                if (m3) {
-                  advance(2);
-                  own += e[2] ? 1u : 0u;
-                  if (e[3]) put(3, own);
-                }
-              }
-            }
-            __builtin_amdgcn_wave_barrier();
-            n_staged += nrows; ord += nrows;
-          }
-        }
-      }
-      lo = hi; hi_cap = 0xFFFFFFFFu;
-      if (lo >= cb + 256u) break;
-      if (lo != nxt) continue;                                   // a cut segment: same record, next slice
-      // ---- a record starts at nxt: ops from there on lie px - P(start) behind their record's start ----
-      {
-        const uint32_t ls = (nxt - cb) >> 2, ss = (nxt - cb) & 3u;
-        uint32_t pr = p_pr0, pq = p_pq0;
-        for (uint32_t k = 0; k < ss; ++k) {                      // prefix in front of sub-slot ss of lane ls (wave-uniform trip count)
-          uint32_t wk = k == 0 ? pw[0] : k == 1 ? pw[1] : pw[2];
-          asm volatile("" : "+v"(wk));
-          const uint32_t len = wk >> 4;
-          pr += len & (uint32_t)__builtin_amdgcn_sbfe(REF2, wk, 1);
-          pq += len & (uint32_t)__builtin_amdgcn_sbfe(QRY2, wk, 1);
-        }
-        base_r = 0u - rdlane(pr, ls); base_q = 0u - rdlane(pq, ls);
-      }
-      cur_rec = tbase + ti; in_head = false; has_start = 1;
-      ++ti;
-      nxt = next_start();
-      if (bad) return;
-    }
-    run_r = base_r + p_tot_r; run_q = base_q + p_tot_q;
-  };
-
-  // Four chunks in flight. The ring register a block reads is the oldest load (it has arrived when the block tests it) and is
-  // re-issued right away; the blocks are guarded by the (wave-uniform) slot so that the emission code exists ONCE, behind them.
-  uint32_t cb = 0, slot = 0;
-  while (cb < part_len && !bad) {
-    if (slot == 0 && !pending) { K1L_ARRIVE(wa); stream(wa, cb); issue(wa, cb + 1024); cb += 256; slot = 1; }
-    if (slot == 1 && !pending) { K1L_ARRIVE(wb); stream(wb, cb); issue(wb, cb + 1024); cb += 256; slot = 2; }
-    if (slot == 2 && !pending) { K1L_ARRIVE(wc); stream(wc, cb); issue(wc, cb + 1024); cb += 256; slot = 3; }
-    if (slot == 3 && !pending) { K1L_ARRIVE(wd); stream(wd, cb); issue(wd, cb + 1024); cb += 256; slot = 0; }
-    if (pending) { emit_pending(); pending = false; }
-  }
-  // the last prefetches are still in flight and will write their (clipped, zero) data into the ring registers: the registers stay
-  // reserved until everything has landed — the compiler does not know about loads issued by inline asm
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(wa), "+v"(wb), "+v"(wc), "+v"(wd) : : "memory");
-  if (pending && !bad) emit_pending();
-#undef K1L_ARRIVE
-  // records whose starts were never reached (offsets beyond the part, part cut short by end_all): still validate them
-  while (!bad && tbase + n_tab < r1) stage(tbase + n_tab);
-  flush();
-  if (lane == 0) { part_count[part] = ord; PartAgg a; a.has_start = has_start; a.run_r = run_r; a.run_q = run_q; agg[part] = a; }
-}
 
 // ---- decoupled look-back: an exclusive scan inside one launch ------------------------------------------------------------------
 // A part's rows belong at raw[rows of the parts in front + ordinal], and the rows of the record that was open at its start still miss
@@ -1351,12 +1041,6 @@ __device__ __forceinline__ CarryItem carry_op(const CarryItem& a, const CarryIte
   c.f = a.f | b.f; c.r = b.f ? b.r : a.r + b.r; c.q = b.f ? b.q : a.q + b.q; c.cnt = a.cnt + b.cnt;
   return c;
 }
-constexpr int K1L_SCAN_TILE = 2048;   // 256 threads x 8 parts
-__device__ __forceinline__ CarryItem k1l_load(const PartAgg* agg, const uint32_t* cnt, int i, int n) {
-  CarryItem c{0, 0, 0, 0};
-  if (i < n) { const PartAgg a = agg[i]; c.f = a.has_start; c.r = a.run_r; c.q = a.run_q; c.cnt = cnt[i]; }
-  return c;
-}
 // block-wide inclusive scan of one item per thread (Hillis-Steele in LDS, 256 threads)
 __device__ __forceinline__ CarryItem k1l_block_scan(CarryItem v, CarryItem* sh) {
   sh[threadIdx.x] = v;
@@ -1370,49 +1054,6 @@ __device__ __forceinline__ CarryItem k1l_block_scan(CarryItem v, CarryItem* sh) 
   }
   return sh[threadIdx.x];
 }
-__global__ __launch_bounds__(256) void k1l_scan_tiles(const PartAgg* __restrict__ agg, const uint32_t* __restrict__ cnt, int n, CarryItem* __restrict__ tile_sum) {
-  __shared__ CarryItem sh[256];
-  const int base = blockIdx.x * K1L_SCAN_TILE + threadIdx.x * 8;
-  CarryItem acc = k1l_load(agg, cnt, base, n);
-  for (int k = 1; k < 8; ++k) acc = carry_op(acc, k1l_load(agg, cnt, base + k, n));
-  const CarryItem incl = k1l_block_scan(acc, sh);
-  if (threadIdx.x == 255) tile_sum[blockIdx.x] = incl;
-}
-__global__ __launch_bounds__(256) void k1l_scan_tile_sums(CarryItem* __restrict__ tile_sum, int ntiles) {
-  // single block: exclusive scan of the tile aggregates in place, 256 at a time with a running carry
-  __shared__ CarryItem sh[256];
-  __shared__ CarryItem run;
-  if (threadIdx.x == 0) run = CarryItem{0, 0, 0, 0};
-  __syncthreads();
-  for (int base = 0; base < ntiles; base += 256) {
-    const int i = base + threadIdx.x;
-    const CarryItem v = i < ntiles ? tile_sum[i] : CarryItem{0, 0, 0, 0};
-    const CarryItem incl = k1l_block_scan(v, sh);
-    const CarryItem before = carry_op(run, threadIdx.x > 0 ? sh[threadIdx.x - 1] : CarryItem{0, 0, 0, 0});
-    const CarryItem total = carry_op(run, sh[255]);
-    (void)incl;
-    __syncthreads();
-    if (i < ntiles) tile_sum[i] = before;
-    if (threadIdx.x == 0) run = total;
-    __syncthreads();
-  }
-}
-__global__ __launch_bounds__(256) void k1l_scan_apply(const PartAgg* __restrict__ agg, const uint32_t* __restrict__ cnt, int n,
-                                                      const CarryItem* __restrict__ tile_sum, uint32_t* __restrict__ part_off,
-                                                      uint32_t* __restrict__ carry_r, uint32_t* __restrict__ carry_q) {
-  __shared__ CarryItem sh[256];
-  const int base = blockIdx.x * K1L_SCAN_TILE + threadIdx.x * 8;
-  CarryItem it[8];
-  CarryItem acc = it[0] = k1l_load(agg, cnt, base, n);
-  for (int k = 1; k < 8; ++k) { it[k] = k1l_load(agg, cnt, base + k, n); acc = carry_op(acc, it[k]); }
-  k1l_block_scan(acc, sh);
-  CarryItem run = carry_op(tile_sum[blockIdx.x], threadIdx.x > 0 ? sh[threadIdx.x - 1] : CarryItem{0, 0, 0, 0});
-  for (int k = 0; k < 8; ++k) {
-    if (base + k < n) { part_off[base + k] = run.cnt; carry_r[base + k] = run.r; carry_q[base + k] = run.q; }
-    run = carry_op(run, it[k]);
-  }
-}
-
 // ---- placement of the long scan's descriptors: part scan by look-back + rows, one launch ------------------------------------------
 // A block owns 256 consecutive parts: their (has_start, advance, rows) are scanned in LDS, the block's aggregate goes through the
 // look-back over the BLOCKS in front (lb_publish / lb_resolve: every block reaches it a few microseconds after it starts and all
@@ -1425,6 +1066,7 @@ struct PlaceArgs {
   const int32_t* tid; vsv_sig* raw; uint32_t cap; Counters* ctr;
   uint32_t* part_off; uint32_t* carry_r; uint32_t* carry_q; int no_qend;
   SlimOut so;                                       // the rows' 16-byte elements next to them (base == nullptr: rows only)
+  int pool_rows;                                    // the batches hold finished 32-byte rows (the read-shaped scan: parts end at record ends, no carry), not descriptors
 };
 __device__ __forceinline__ void k1l_store(vsv_sig* __restrict__ raw, uint32_t row, const uint4& lo4, const uint4& hi4, const SlimOut& so) {
   uint4* dst = reinterpret_cast<uint4*>(raw + row);
@@ -1445,7 +1087,10 @@ __global__ __launch_bounds__(256) void k1l_place(PlaceArgs A) {
   const int part = blockIdx.x * PL_PARTS + t;
   CarryItem it{0, 0, 0, 0};
   uint2 pr = make_uint2(0u, 0u);
-  if (part < A.n_parts) { const PartAgg a = A.agg[part]; it.f = a.has_start; it.r = a.run_r; it.q = a.run_q; it.cnt = A.part_count[part]; pr = A.prec[part]; }
+  if (part < A.n_parts) {
+    if (A.agg) { const PartAgg a = A.agg[part]; it.f = a.has_start; it.r = a.run_r; it.q = a.run_q; }
+    it.cnt = A.part_count[part]; pr = A.prec[part];
+  }
   k1l_block_scan(it, sh);                           // sh[t] = parts [block start, t] combined
   if (t < 64) {                                     // (one whole wave: the look-back is wave-cooperative)
     const CarryItem tot = sh[255];
@@ -1460,7 +1105,7 @@ __global__ __launch_bounds__(256) void k1l_place(PlaceArgs A) {
     if (t > 0) ex = carry_op(ex, sh[t - 1]);
     s_off[t] = ex.cnt; s_cr[t] = ex.r; s_cq[t] = ex.q; s_loc[t] = pr.x; s_first[t] = it.cnt - pr.y;
     if (t == 255) s_off[PL_PARTS] = ex.cnt + it.cnt;
-    if (part < A.n_parts) { A.part_off[part] = ex.cnt; A.carry_r[part] = ex.r; A.carry_q[part] = ex.q; }
+    if (part < A.n_parts) { A.part_off[part] = ex.cnt; if (A.agg) { A.carry_r[part] = ex.r; A.carry_q[part] = ex.q; } }
     if (part == A.n_parts - 1) {                    // the table's size, and what a retry would have to reserve
       const uint64_t total = (uint64_t)ex.cnt + it.cnt;
       A.ctr->n_raw = total < (uint64_t)A.cap ? (uint32_t)total : A.cap;
@@ -1472,7 +1117,7 @@ __global__ __launch_bounds__(256) void k1l_place(PlaceArgs A) {
     const uint32_t used = A.shard_cnt[t * 16];      // (K1_SHARDS == 256 threads)
     if (used > A.shard_cap) {
       atomicOr(&A.ctr->err, ERRB_CAPACITY);
-      const uint64_t need = ((uint64_t)used * K1_SHARDS + 1) / 2;           // rows of capacity = 2 descriptors each
+      const uint64_t need = A.pool_rows ? (uint64_t)used * K1_SHARDS : ((uint64_t)used * K1_SHARDS + 1) / 2;     // (a row of capacity holds two descriptors)
       atomicMax(&A.ctr->n_pool, need > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)need);
     }
   }
@@ -1484,9 +1129,10 @@ __global__ __launch_bounds__(256) void k1l_place(PlaceArgs A) {
     while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_off[mid] <= row) lo = mid; else hi = mid; }
     const uint32_t o = row - s_off[lo];
     if (o < s_first[lo] || row >= A.cap) continue;  // (a row of an earlier batch of the part: k1l_place_batches)
-    const uint4 d = A.dpool[s_loc[lo] + (o - s_first[lo])];
+    const uint32_t src = s_loc[lo] + (o - s_first[lo]);
     uint4 lo4, hi4;
-    k1l_row(d, s_cr[lo], s_cq[lo], (uint32_t)A.tid[d.w], A.no_qend != 0, lo4, hi4);
+    if (A.pool_rows) { lo4 = A.dpool[2 * (size_t)src]; hi4 = A.dpool[2 * (size_t)src + 1]; }
+    else { const uint4 d = A.dpool[src]; k1l_row(d, s_cr[lo], s_cq[lo], (uint32_t)A.tid[d.w], A.no_qend != 0, lo4, hi4); }
     k1l_store(A.raw, row, lo4, hi4, A.so);
   }
 }
@@ -1494,17 +1140,17 @@ __global__ __launch_bounds__(256) void k1l_place(PlaceArgs A) {
 __global__ __launch_bounds__(256) void k1l_place_batches(const uint4* __restrict__ batches, const uint32_t* __restrict__ n_batches, uint32_t batch_cap,
                                                          const uint4* __restrict__ dpool, const uint32_t* __restrict__ part_off, const uint32_t* __restrict__ carry_r,
                                                          const uint32_t* __restrict__ carry_q, const int32_t* __restrict__ tid, vsv_sig* __restrict__ raw, uint32_t cap, int no_qend,
-                                                         SlimOut so) {
+                                                         SlimOut so, int pool_rows) {
   const uint32_t nb = min(*n_batches, batch_cap);
   const int lane = threadIdx.x & 63;
   for (uint32_t e = blockIdx.x * 4 + (threadIdx.x >> 6); e < nb; e += gridDim.x * 4) {
     const uint4 b = batches[e];                     // {part, first ordinal, location, descriptors}
-    const uint32_t row0 = part_off[b.x] + b.y, cr = carry_r[b.x], cq = carry_q[b.x];
+    const uint32_t row0 = part_off[b.x] + b.y, cr = pool_rows ? 0u : carry_r[b.x], cq = pool_rows ? 0u : carry_q[b.x];
     for (uint32_t i = lane; i < b.w; i += 64) {
       if (row0 + i >= cap) break;
-      const uint4 d = dpool[b.z + i];
       uint4 lo4, hi4;
-      k1l_row(d, cr, cq, (uint32_t)tid[d.w], no_qend != 0, lo4, hi4);
+      if (pool_rows) { lo4 = dpool[2 * (size_t)(b.z + i)]; hi4 = dpool[2 * (size_t)(b.z + i) + 1]; }
+      else { const uint4 d = dpool[b.z + i]; k1l_row(d, cr, cq, (uint32_t)tid[d.w], no_qend != 0, lo4, hi4); }
       k1l_store(raw, row0 + i, lo4, hi4, so);
     }
   }
@@ -1565,72 +1211,6 @@ __global__ __launch_bounds__(256) void scan_tile_apply(const uint32_t* __restric
   for (int k = 0; k < 8; ++k) { if (base + k < n) out[base + k] = run; run += v[k]; }
 }
 
-// second half of a two-launch exclusive scan: the tile sums exist (scan_tile_sums); every block adds up the sums in front of its
-// own tile itself (a few dozen to a few thousand words from L2) instead of waiting for a single-block scan of them
-__global__ __launch_bounds__(256) void scan_tile_apply_sums(const uint32_t* __restrict__ in, int n, const uint32_t* __restrict__ tile_sum,
-                                                            uint32_t* __restrict__ out) {
-  __shared__ uint32_t sh[256];
-  __shared__ uint32_t s_before;
-  uint32_t before = 0;
-  for (int j = threadIdx.x; j < (int)blockIdx.x; j += 256) before += tile_sum[j];
-  sh[threadIdx.x] = before;
-  __syncthreads();
-  for (int d = 128; d > 0; d >>= 1) { if ((int)threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d]; __syncthreads(); }
-  if (threadIdx.x == 0) s_before = sh[0];
-  __syncthreads();
-  const int base = blockIdx.x * SCAN_TILE + threadIdx.x * 8;
-  uint32_t v[8], s = 0;
-  for (int k = 0; k < 8; ++k) { v[k] = (base + k < n) ? in[base + k] : 0; s += v[k]; }
-  sh[threadIdx.x] = s;
-  __syncthreads();
-  for (int d = 1; d < 256; d <<= 1) {
-    uint32_t t = (int)threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
-    __syncthreads();
-    sh[threadIdx.x] += t;
-    __syncthreads();
-  }
-  uint32_t run = s_before + sh[threadIdx.x] - s;
-  for (int k = 0; k < 8; ++k) { if (base + k < n) out[base + k] = run; run += v[k]; }
-}
-
-// ---- ordered placement: raw[part_off[part] + ordinal] = pool row; PLACE_CHUNKS blocks per shard (a shard of the contig pile holds
-// ~25 k rows: one block per shard left 3/4 of the chip's wave slots empty on a pass that moves 450 MB) --------------
-constexpr int PLACE_CHUNKS = 8;
-__global__ __launch_bounds__(256) void place_raw(const vsv_sig* __restrict__ pool, const uint64_t* __restrict__ pool_key,
-                                                 const uint32_t* __restrict__ shard_cnt, uint32_t shard_cap,
-                                                 const uint32_t* __restrict__ part_off, const uint32_t* __restrict__ part_count,
-                                                 int n_parts, vsv_sig* __restrict__ raw, uint32_t cap, Counters* ctr,
-                                                 const uint32_t* __restrict__ carry_r, const uint32_t* __restrict__ carry_q, bool add_qend) {
-  const uint32_t s = blockIdx.x / PLACE_CHUNKS, chunk = blockIdx.x % PLACE_CHUNKS;
-  const uint32_t used = shard_cnt[s * 16];
-  if (threadIdx.x == 0 && chunk == 0) {
-    if (used > shard_cap) { atomicOr(&ctr->err, ERRB_CAPACITY); }
-    atomicMax(&ctr->n_pool, used > 0xFFFFFFFFu / K1_SHARDS ? 0xFFFFFFFFu : used * K1_SHARDS);  // rows a retry needs
-    if (s == 0) {
-      const uint32_t total = part_off[n_parts - 1] + part_count[n_parts - 1];
-      ctr->n_raw = total < cap ? total : cap;
-      if (total > cap) atomicOr(&ctr->err, ERRB_CAPACITY);
-    }
-  }
-  const uint32_t n = used < shard_cap ? used : shard_cap;
-  const uint32_t per = ((n + PLACE_CHUNKS - 1) / PLACE_CHUNKS + 63u) & ~63u, e0 = min(n, chunk * per), e1 = min(n, e0 + per);
-  for (uint32_t e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
-    const uint64_t k = pool_key[(size_t)s * shard_cap + e];
-    if (k == K1_SENTINEL) continue;
-    const uint32_t part = (uint32_t)(k >> 32);
-    const uint32_t dst = part_off[part] + ((uint32_t)k & ~K1L_CARRY);
-    if (dst >= cap) continue;
-    vsv_sig row = pool[(size_t)s * shard_cap + e];
-    if ((uint32_t)k & K1L_CARRY) {        // long-record scan: the record was open at the part's start (k1l_scan_*)
-      const uint32_t cr = carry_r[part], cq = carry_q[part];
-      row.pos = (int32_t)((uint32_t)row.pos + cr);
-      row.q_start = (int32_t)((uint32_t)row.q_start + cq);
-      if (add_qend) row.q_end = (int32_t)((uint32_t)row.q_end + cq);
-    }
-    raw[dst] = row;
-  }
-}
-
 }  // namespace
 
 // one block for small arrays (n <= 8192: the per-block candidate counts of a 10 M-record shard): thread t owns 8 consecutive items
@@ -1673,45 +1253,43 @@ bool vsv_scan_is_long(const RecView& rv, const vsv_params& p) {
 }
 int vsv_cigar_parts_long(int64_t n_ops) { return (int)((n_ops + K1L_PART - 1) / K1L_PART); }
 
-// the long scan's descriptors -> rows in T_RAW order (and their elements): behind the scan, and again into the raw table when a
-// caller asks for VSV_T_RAW of a run whose rows went straight into the stage-1 table (capi.hip). n_parts: the scan's.
-void vsv_launch_long_place(hipStream_t st, const RecView& rv, const vsv_params& p, int n_parts, vsv_sig* pool, uint64_t* pool_key, uint32_t cap, uint32_t* part_count,
-                           uint32_t* part_off, vsv_sig* rows, Counters* ctr, uint32_t* shard_cnt, const LongScanBufs& lb, uint32_t epoch, const SlimOut& so) {
+// the scan's batches -> rows in T_RAW order (and their elements): behind the scan, and again into the raw table when a caller asks
+// for VSV_T_RAW of a run whose rows went straight into the stage-1 table (capi.hip). n_parts: the scan's (vsv_scan_parts).
+void vsv_launch_place(hipStream_t st, const RecView& rv, const vsv_params& p, int n_parts, vsv_sig* pool, uint64_t* pool_key, uint32_t cap, uint32_t* part_count,
+                      uint32_t* part_off, vsv_sig* rows, Counters* ctr, uint32_t* shard_cnt, const LongScanBufs& lb, uint32_t epoch, const SlimOut& so) {
+  if (n_parts <= 0) return;
+  const bool long_mode = vsv_scan_is_long(rv, p);
   const int no_qend = (p.dtype == VSV_DTYPE_READS || p.dtype == VSV_DTYPE_CUTESV) ? 1 : 0;
-  const uint32_t dshard_cap = (uint32_t)(((uint64_t)cap * 2) / K1_SHARDS);
-  k1l_place<<<(n_parts + PL_PARTS - 1) / PL_PARTS, 256, 0, st>>>(PlaceArgs{(const uint4*)pool, shard_cnt, dshard_cap, (const uint2*)lb.prec, part_count, (const PartAgg*)lb.agg,
-                                                                 n_parts, lb.lbw, epoch, rv.tid, rows, cap, ctr, part_off, lb.carry_r, lb.carry_q, no_qend, so});
-  k1l_place_batches<<<64, 256, 0, st>>>((const uint4*)pool_key, shard_cnt + 8, cap / 2, (const uint4*)pool, part_off, lb.carry_r, lb.carry_q, rv.tid, rows, cap, no_qend, so);
+  const int pool_rows = long_mode ? 0 : 1;
+  const uint32_t shard_cap = (uint32_t)(((uint64_t)cap * (long_mode ? 2 : 1)) / K1_SHARDS);      // (a row of the pool holds two 16-byte descriptors)
+  k1l_place<<<(n_parts + PL_PARTS - 1) / PL_PARTS, 256, 0, st>>>(PlaceArgs{(const uint4*)pool, shard_cnt, shard_cap, (const uint2*)lb.prec, part_count,
+                                                                 long_mode ? (const PartAgg*)lb.agg : nullptr, n_parts, lb.lbw, epoch, rv.tid, rows, cap, ctr, part_off,
+                                                                 lb.carry_r, lb.carry_q, no_qend, so, pool_rows});
+  k1l_place_batches<<<64, 256, 0, st>>>((const uint4*)pool_key, shard_cnt + 8, cap / 2, (const uint4*)pool, part_off, lb.carry_r, lb.carry_q, rv.tid, rows, cap, no_qend, so, pool_rows);
 }
-// parts of the long scan for this input (what vsv_launch_cigar_scan cuts it into): 0 = the call does not take that scan
-int vsv_long_scan_parts(const RecView& rv, const vsv_params& p, int ops_per_part) {
-  static const char* k1l = vsv_dbg_env("VSV_K1L");
-  if (!vsv_scan_is_long(rv, p) || (k1l && k1l[0] == 'p') || rv.n_ops <= 0) return 0;
+// ops per part and parts of the scan this call takes (the long scan's parts are never shorter than the read-shaped ones: the part
+// tables are sized for those)
+static int scan_part_ops(const RecView& rv, const vsv_params& p, int ops_per_part) {
+  if (!vsv_scan_is_long(rv, p)) return ops_per_part;
   static const int forced = vsv_dbg_env("VSV_K1L_PART") ? atoi(vsv_dbg_env("VSV_K1L_PART")) : 0;      // timing experiments / tests
   int64_t po = K1L_PART;
   if (forced >= 256 && forced % 256 == 0) po = forced;
-  if (po < ops_per_part) po = ((ops_per_part + 255) / 256) * 256;        // (the part tables are sized for the read-shaped part length)
-  return vsv_cigar_parts(rv.n_ops, (int)po);
+  if (po < ops_per_part) po = ((ops_per_part + 255) / 256) * 256;
+  return (int)po;
 }
+int vsv_scan_parts(const RecView& rv, const vsv_params& p, int ops_per_part) { return vsv_cigar_parts(rv.n_ops, scan_part_ops(rv, p, ops_per_part)); }
+
+// K0 + K1 + placement: part boundaries, the scan (read-shaped or long-record layout), rows in T_RAW order in `raw` — or, with
+// lb.fused_rows, in the stage-1 input table next to their elements.
 void vsv_launch_cigar_scan(hipStream_t st, const RecView& rv, const vsv_params& p, uint32_t* part_rb, int n_parts,
                            int ops_per_part, vsv_sig* pool, uint64_t* pool_key, uint32_t cap, uint32_t* part_count,
                            uint32_t* part_off, uint32_t* scan_tmp, vsv_sig* raw, Counters* ctr, uint32_t* shard_cnt,
                            hipEvent_t ev0, hipEvent_t ev1, const LongScanBufs& lb) {
   if (n_parts <= 0) return;
-  const int ops_per_part0 = ops_per_part;
+  (void)scan_tmp;
   const bool long_mode = vsv_scan_is_long(rv, p);
-  static const char* k1l = vsv_dbg_env("VSV_K1L");                   // timing experiments / tests: "pool" = round 3's scan + placement pass
-  const bool long_pool = long_mode && ((k1l && k1l[0] == 'p') || !lb.lbw);
-  if (long_mode && long_pool) { n_parts = vsv_cigar_parts_long(rv.n_ops); ops_per_part = K1L_PART; }
-  if (long_mode && !long_pool) {
-    n_parts = vsv_long_scan_parts(rv, p, ops_per_part);
-    ops_per_part = (int)((rv.n_ops + n_parts - 1) / n_parts);              // (only its multiple-of-256 value below matters)
-    static const int forced = vsv_dbg_env("VSV_K1L_PART") ? atoi(vsv_dbg_env("VSV_K1L_PART")) : 0;
-    int64_t po = K1L_PART;
-    if (forced >= 256 && forced % 256 == 0) po = forced;
-    if (po < ops_per_part0) po = ((ops_per_part0 + 255) / 256) * 256;
-    ops_per_part = (int)po;
-  }
+  ops_per_part = scan_part_ops(rv, p, ops_per_part);
+  n_parts = vsv_cigar_parts(rv.n_ops, ops_per_part);
   if (!lb.arena_zeroed) (void)hipMemsetAsync(shard_cnt, 0, K1_SHARDS * 16 * sizeof(uint32_t), st);
   if (n_parts < (1 << 20)) partition_search<<<(n_parts + 1 + 255) / 256, 256, 0, st>>>(rv.cigar_off, rv.n_records, part_rb, n_parts, ops_per_part, rv.n_ops, 1);
   else {
@@ -1719,23 +1297,20 @@ void vsv_launch_cigar_scan(hipStream_t st, const RecView& rv, const vsv_params& 
     partition_search<<<(coarse + 255) / 256, 256, 0, st>>>(rv.cigar_off, rv.n_records, part_rb, n_parts, ops_per_part, rv.n_ops, 64);
     partition_fill<<<(n_parts + 1 + 63) / 64, 64, 0, st>>>(rv.cigar_off, rv.n_records, part_rb, n_parts, ops_per_part, rv.n_ops);
   }
-  EmitCtx ec{pool, pool_key, shard_cnt, cap / K1_SHARDS, ctr};
+  const EmitCtx ec{pool, shard_cnt, cap / K1_SHARDS, ctr, (uint2*)lb.prec, (uint4*)pool_key, cap / 2};
+  const uint32_t dshard_cap = (uint32_t)(((uint64_t)cap * 2) / K1_SHARDS);      // the row pool holds two 16-byte descriptors per row
   const int waves_per_block = 4;
   const int grid = (n_parts + waves_per_block - 1) / waves_per_block;
   if (ev0) (void)hipEventRecord(ev0, st);
   static const int ablate = vsv_dbg_env("VSV_K1_ABLATE") ? atoi(vsv_dbg_env("VSV_K1_ABLATE")) : 0;  // timing experiments only
   static const int depth = vsv_dbg_env("VSV_K1_DEPTH") ? atoi(vsv_dbg_env("VSV_K1_DEPTH")) : 4;     // chunks in flight per wave (3 or 4)
-  const int n_tiles = (n_parts + SCAN_TILE - 1) / SCAN_TILE;
-  uint32_t* tsum = nullptr;
-  const uint32_t dshard_cap = (uint32_t)(((uint64_t)cap * 2) / K1_SHARDS);      // the row pool holds two 16-byte descriptors per row
 #define K1_LAUNCH(CLS)                                                                                                          \
   do {                                                                                                                          \
-    if (long_mode && !long_pool) cigar_scan_long<CLS><<<grid, 256, 0, st>>>(K1LArgs{rv, part_rb, ctr, (uint4*)pool, shard_cnt, dshard_cap, (uint4*)pool_key, cap / 2, \
-                                                                             (uint2*)lb.prec, part_count, (PartAgg*)lb.agg, n_parts, p.min_svlen, p.min_cigar_mapq, (uint32_t)ops_per_part, ablate}); \
-    else if (long_mode) cigar_scan_long_pool<CLS><<<grid, 256, 0, st>>>(rv, part_rb, n_parts, p.min_svlen, p.min_cigar_mapq, ec, part_count, (PartAgg*)lb.agg, ablate); \
-    else if (CLS == 0 && lb.clr_fused) cigar_scan_emit<0, 4, true><<<grid, 256, 0, st>>>(rv, part_rb, n_parts, p.min_svlen, p.min_cigar_mapq, ec, part_count, ablate, tsum); \
-    else if (depth == 4) cigar_scan_emit<CLS, 4><<<grid, 256, 0, st>>>(rv, part_rb, n_parts, p.min_svlen, p.min_cigar_mapq, ec, part_count, ablate, tsum); \
-    else cigar_scan_emit<CLS, 3><<<grid, 256, 0, st>>>(rv, part_rb, n_parts, p.min_svlen, p.min_cigar_mapq, ec, part_count, ablate, tsum);            \
+    if (long_mode) cigar_scan_long<CLS><<<grid, 256, 0, st>>>(K1LArgs{rv, part_rb, ctr, (uint4*)pool, shard_cnt, dshard_cap, (uint4*)pool_key, cap / 2, \
+                                                                      (uint2*)lb.prec, part_count, (PartAgg*)lb.agg, n_parts, p.min_svlen, p.min_cigar_mapq, (uint32_t)ops_per_part, ablate}); \
+    else if (CLS == 0 && lb.clr_fused) cigar_scan_emit<0, 4, true><<<grid, 256, 0, st>>>(rv, part_rb, n_parts, p.min_svlen, p.min_cigar_mapq, ec, part_count, ablate); \
+    else if (depth == 4) cigar_scan_emit<CLS, 4><<<grid, 256, 0, st>>>(rv, part_rb, n_parts, p.min_svlen, p.min_cigar_mapq, ec, part_count, ablate); \
+    else cigar_scan_emit<CLS, 3><<<grid, 256, 0, st>>>(rv, part_rb, n_parts, p.min_svlen, p.min_cigar_mapq, ec, part_count, ablate);            \
   } while (0)
   if (p.dtype == VSV_DTYPE_READS) K1_LAUNCH(1);
   else if (p.dtype == VSV_DTYPE_SVIM) K1_LAUNCH(2);
@@ -1743,34 +1318,17 @@ void vsv_launch_cigar_scan(hipStream_t st, const RecView& rv, const vsv_params& 
   else K1_LAUNCH(0);
 #undef K1_LAUNCH
   if (ev1) (void)hipEventRecord(ev1, st);
-  const bool add_qend = !(p.dtype == VSV_DTYPE_READS || p.dtype == VSV_DTYPE_CUTESV);
-  if (long_mode && !long_pool) {
-    vsv_launch_long_place(st, rv, p, n_parts, pool, pool_key, cap, part_count, part_off, lb.fused_rows ? (vsv_sig*)lb.fused_rows : raw, ctr, shard_cnt, lb, lb.epoch,
-                          lb.fused_rows ? lb.so : SlimOut{nullptr, 0, 0, 0, nullptr});
-    return;
-  }
-  if (long_mode) {
-    const int tiles = (n_parts + K1L_SCAN_TILE - 1) / K1L_SCAN_TILE;
-    k1l_scan_tiles<<<tiles, 256, 0, st>>>((const PartAgg*)lb.agg, part_count, n_parts, (CarryItem*)lb.tile_sum);
-    k1l_scan_tile_sums<<<1, 256, 0, st>>>((CarryItem*)lb.tile_sum, tiles);
-    k1l_scan_apply<<<tiles, 256, 0, st>>>((const PartAgg*)lb.agg, part_count, n_parts, (const CarryItem*)lb.tile_sum, part_off, lb.carry_r, lb.carry_q);
-  } else if (n_parts > 8192 && n_tiles <= 16384) {
-    scan_tile_sums<<<n_tiles, 256, 0, st>>>(part_count, n_parts, scan_tmp);
-    scan_tile_apply_sums<<<n_tiles, 256, 0, st>>>(part_count, n_parts, scan_tmp, part_off);
-  } else {
-    vsv_scan_u32_exclusive(st, part_count, n_parts, part_off, scan_tmp);
-  }
-  place_raw<<<K1_SHARDS * PLACE_CHUNKS, 256, 0, st>>>(pool, pool_key, shard_cnt, cap / K1_SHARDS, part_off, part_count, n_parts, raw, cap, ctr,
-                                       lb.carry_r, lb.carry_q, add_qend);
+  vsv_launch_place(st, rv, p, n_parts, pool, pool_key, cap, part_count, part_off, lb.fused_rows ? (vsv_sig*)lb.fused_rows : raw, ctr, shard_cnt, lb, lb.epoch,
+                   lb.fused_rows ? lb.so : SlimOut{nullptr, 0, 0, 0, nullptr});
 }
 size_t vsv_lookback_bytes(int64_t n_ops, int ops_per_part) {
   const size_t a = (size_t)vsv_cigar_parts_long(n_ops) + 16, b = (size_t)vsv_cigar_parts(n_ops, ops_per_part) + 16;
   return (a > b ? a : b) * 3 * sizeof(uint64_t);
 }
-size_t vsv_long_scan_bytes(int64_t n_ops, int which, int ops_per_part) {   // 0: PartAgg[], 1: carry (u32 per part), 2: tile sums, 3: last-batch records
+size_t vsv_long_scan_bytes(int64_t n_ops, int which, int ops_per_part) {   // 0: PartAgg[], 1: carry (u32 per part), 3: last-batch records (uint2 per part)
   const size_t pa = (size_t)vsv_cigar_parts_long(n_ops), pb = (size_t)vsv_cigar_parts(n_ops, ops_per_part);      // (the long scan's parts are never shorter than the read-shaped ones)
   const size_t n_parts = (pa > pb ? pa : pb) + 16;
-  return which == 0 ? n_parts * sizeof(PartAgg) : which == 1 ? n_parts * sizeof(uint32_t) : which == 3 ? n_parts * sizeof(uint2) : (n_parts / K1L_SCAN_TILE + 2) * sizeof(CarryItem);
+  return which == 0 ? n_parts * sizeof(PartAgg) : which == 1 ? n_parts * sizeof(uint32_t) : which == 3 ? n_parts * sizeof(uint2) : 256;
 }
 
 // ---- streaming ceiling of this part, measured with the library's own kernels -----------------------------------

@@ -1243,7 +1243,7 @@ static SplitCfg split_cfg(const RecView& rv, const vsv_params& p, int n_tids) {
 SplitSorted vsv_launch_split_candidates(hipStream_t st, const RecView& rv, const vsv_params& p, int n_tids, uint32_t* tab, uint32_t tab_size,
                                         uint32_t* blk_cnt, uint32_t* blk_off, uint32_t* scan_tmp, uint64_t* ckey, uint32_t* crec,
                                         uint64_t* okey, uint32_t* oval, uint64_t* key2, uint32_t* idx2, const SortWork& sw,
-                                        uint32_t cap, Counters* ctr, uint8_t* cmask, int grid, const SlimWork* slim, const CandBufs& cb) {
+                                        uint32_t cap, Counters* ctr, uint8_t* cmask, int grid, const SlimWork* slim, const CandBufs& cb, int phase) {
   SplitSorted out{nullptr, nullptr, nullptr, nullptr};
   if (rv.n_records <= 0) return out;
   const SplitCfg c = split_cfg(rv, p, n_tids);
@@ -1252,6 +1252,9 @@ SplitSorted vsv_launch_split_candidates(hipStream_t st, const RecView& rv, const
   const int qtiles = (int)((rv.n_records + QM_TILE - 1) / QM_TILE);
   // wide loads need 16-byte (qid) / 4-byte (flag, mapq) aligned arrays; anything else takes the element-wise path
   const bool vec = ((uintptr_t)rv.qid & 15u) == 0 && ((uintptr_t)rv.flag & 3u) == 0 && ((uintptr_t)rv.mapq & 3u) == 0;
+  // phase 1 = the candidates only (name repeats, count, fill: the same kernels whatever the tables' sizes: a cold handle runs them
+  // beside its scan and takes the candidate count from them), phase 2 = their two sorts only, 0 = both
+  if (phase != 2) {
   qid_tile_max<<<qtiles, 256, 0, st>>>(rv.qid, rv.n_records, blk_cnt, vec, tab, (uint32_t)((nq + 31) / 32 + 1));
   // up to 8192 tiles / blocks (16 M records) the consumers reduce the per-tile values in front of them themselves: two 5-10 us
   // launches less; beyond that the reductions (quadratic in the tile count) cost more than the scan launches
@@ -1266,6 +1269,8 @@ SplitSorted vsv_launch_split_candidates(hipStream_t st, const RecView& rv, const
     vsv_scan_u32_exclusive(st, blk_cnt, nblk, blk_off, scan_tmp);
     split_cand<true><<<nblk, 256, 0, st>>>(rv, c, tab, blk_off, ckey, crec, cap, vec, ctr, cmask, false);
   }
+  }
+  if (phase == 1) return out;
   if (slim) {
     // large inputs (config 3: ~10^7 candidates): both sorts through the 8-bit passes over 16-byte elements (slim_path.hip; the
     // 9-11 bit passes over separate key / value arrays write 16- and 8-byte pieces: 0.3-0.4 ms per pass there). Dead pair slots

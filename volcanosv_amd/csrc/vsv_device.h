@@ -172,9 +172,9 @@ struct LongScanBufs {   // scratch of the scan launcher beyond the part tables
   void* prec;                              // long-record scan: {location, descriptors} of every part's last batch
   void* fused_rows; SlimOut so;            // long-record scan: place the rows here (the stage-1 input table) with their elements, not in `raw`
 };
-void vsv_launch_long_place(hipStream_t st, const RecView& rv, const vsv_params& p, int n_parts, vsv_sig* pool, uint64_t* pool_key, uint32_t cap, uint32_t* part_count,
-                           uint32_t* part_off, vsv_sig* rows, Counters* ctr, uint32_t* shard_cnt, const LongScanBufs& lb, uint32_t epoch, const SlimOut& so);
-int vsv_long_scan_parts(const RecView& rv, const vsv_params& p, int ops_per_part);
+void vsv_launch_place(hipStream_t st, const RecView& rv, const vsv_params& p, int n_parts, vsv_sig* pool, uint64_t* pool_key, uint32_t cap, uint32_t* part_count,
+                      uint32_t* part_off, vsv_sig* rows, Counters* ctr, uint32_t* shard_cnt, const LongScanBufs& lb, uint32_t epoch, const SlimOut& so);
+int vsv_scan_parts(const RecView& rv, const vsv_params& p, int ops_per_part);
 size_t vsv_lookback_bytes(int64_t n_ops, int ops_per_part);
 bool vsv_scan_is_long(const RecView& rv, const vsv_params& p);
 size_t vsv_long_scan_bytes(int64_t n_ops, int which, int ops_per_part);
@@ -199,7 +199,7 @@ SplitSorted vsv_launch_split_candidates(hipStream_t st, const RecView& rv, const
                                         uint32_t* blk_cnt, uint32_t* blk_off, uint32_t* scan_tmp, uint64_t* ckey, uint32_t* crec,
                                         uint64_t* okey, uint32_t* oval, uint64_t* key2, uint32_t* idx2, const SortWork& sw,
                                         uint32_t cap, Counters* ctr, uint8_t* cmask, int grid, const struct SlimWork* slim = nullptr,
-                                        const CandBufs& cb = CandBufs{nullptr, nullptr, nullptr});
+                                        const CandBufs& cb = CandBufs{nullptr, nullptr, nullptr}, int phase = 0);
 void vsv_launch_split_eval(hipStream_t st, const RecView& rv, const vsv_params& p, int n_tids, const SplitSorted& so, vsv_sig* s1in,
                            uint32_t cap, Counters* ctr, int grid, const SlimOut& sl = SlimOut{nullptr, 0, 0, 0, nullptr});
 // returns the sorted key array (kept for the cluster / pair kernel that follows)

@@ -93,8 +93,10 @@ class Engine:
         torch.cuda.current_stream().cuda_stream) — for device-resident inputs another stream is still producing."""
         self._check(self.lib.vsv_wait_for_stream(self.h, C.c_void_p(hip_stream or 0)))
 
-    def reserve(self, max_records, max_ops, max_sigs):
+    def reserve(self, max_records, max_ops, max_sigs, large_tables=False):
         self._check(self.lib.vsv_reserve(self.h, int(max_records), int(max_ops), int(max_sigs)))
+        if large_tables:
+            self._check(self.lib.vsv_reserve_large_tables(self.h))
 
     def last_count(self):
         return int(self.lib.vsv_last_count(self.h))

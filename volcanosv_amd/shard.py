@@ -42,13 +42,35 @@ class _RootGather:
     """Handle of a variable-length gather to rank 0 in flight (gather_bytes_start): `wait()` completes it and returns, on rank 0,
     (list of per-rank uint8 tensors in rank order, list of byte counts); (None, counts) on the other ranks."""
 
-    def __init__(self, works, bufs, counts, keep):
-        self.works, self.bufs, self.counts, self.keep = works, bufs, counts, keep
+    def __init__(self, src, device, count_work=None, counts_t=None, keep=None):
+        self.src, self.device, self.count_work, self.counts_t, self.keep = src, device, count_work, counts_t, keep
+        self.works, self.bufs, self.counts = [], None, None
+
+    def post(self):
+        """Second half of the start: the counts have arrived (their all-gather was enqueued by gather_bytes_start), the exact-size
+        transfers are posted. Called by wait(); a caller may call it earlier, at a point every rank reaches in the same order."""
+        if self.counts is not None:
+            return
+        if self.count_work is None:                       # single rank
+            self.bufs, self.counts = [self.src], [int(self.src.numel())]
+            return
+        self.count_work.wait()
+        self.counts = [int(c) for c in torch.cat(self.counts_t).tolist()]          # ONE readback, long after the collective was enqueued
+        world, rank = dist.get_world_size(), dist.get_rank()
+        ops = []
+        if rank == 0:
+            self.bufs = [self.src] + [torch.empty(self.counts[r], dtype=torch.uint8, device=self.device) for r in range(1, world)]
+            ops = [dist.P2POp(dist.irecv, self.bufs[r], r) for r in range(1, world) if self.counts[r]]
+        elif self.counts[rank]:
+            ops = [dist.P2POp(dist.isend, self.src, 0)]
+        self.works = dist.batch_isend_irecv(ops) if ops else []
+        self.count_work, self.counts_t, self.keep = None, None, None
 
     def wait(self):
+        self.post()
         for w in self.works:
             w.wait()
-        self.works, self.keep = [], None
+        self.works = []
         return self.bufs, self.counts
 
 
@@ -57,24 +79,19 @@ def gather_bytes_start(t_u8, device):
     volcanosv-vc-large-indel.py:271-278): one all-gather of the byte counts (8 bytes per rank), then grouped point-to-point
     transfers — every rank r > 0 sends exactly its bytes to rank 0, rank 0 posts one exact-size receive per sender; nobody else
     receives anything (a padded all-gather would deliver every rank's table to every rank: 8x the xGMI traffic at N = 8, on links
-    that are point-to-point). The transfers are asynchronous: the caller goes on enqueuing its next chromosome and calls
-    `.wait()` on the returned handle when it needs the rows (t_u8 is kept alive until then)."""
+    that are point-to-point). Nothing here waits: the count all-gather is ENQUEUED (async_op) and the handle returned; the counts are
+    read and the transfers posted by the handle's `.post()` / `.wait()`, which the caller reaches when it needs the rows — in
+    bench.py `streams` steps later, when the engine that produced them is about to be reused — so a step never stops for a
+    rendezvous of the ranks or a host readback (round 3 did both per step). Every rank must reach the starts and the
+    waits in the same order (they are collectives). t_u8 is kept alive until then."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
-        return _RootGather([], [t_u8], [int(t_u8.numel())], None)
-    world, rank = dist.get_world_size(), dist.get_rank()
-    n = torch.tensor([int(t_u8.numel())], dtype=torch.int64, device=device)
-    counts_t = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(counts_t, n)
-    counts = [int(c.item()) for c in counts_t]
-    ops, bufs = [], None
+        return _RootGather(t_u8, device)
+    world = dist.get_world_size()
     src = t_u8.to(device).contiguous()
-    if rank == 0:
-        bufs = [src] + [torch.empty(counts[r], dtype=torch.uint8, device=device) for r in range(1, world)]
-        ops = [dist.P2POp(dist.irecv, bufs[r], r) for r in range(1, world) if counts[r]]
-    elif counts[rank]:
-        ops = [dist.P2POp(dist.isend, src, 0)]
-    works = dist.batch_isend_irecv(ops) if ops else []
-    return _RootGather(works, bufs, counts, src)
+    n = torch.tensor([int(src.numel())], dtype=torch.int64, device=device)      # (the size of a tensor is host knowledge: no readback)
+    counts_t = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    work = dist.all_gather(counts_t, n, async_op=True)
+    return _RootGather(src, device, work, counts_t, n)
 
 
 def gather_bytes(t_u8, device):
@@ -85,12 +102,6 @@ def _calls_as_u8(calls, device):
     if torch.is_tensor(calls):
         return calls
     return torch.from_numpy(np.frombuffer(calls.tobytes(), dtype=np.uint8).copy()) if len(calls) else torch.zeros(0, dtype=torch.uint8)
-
-
-def gather_calls_start(calls, device):
-    """gather_calls in two halves: enqueue now (returns a handle), `finish_gather(handle.wait())` / `.wait()` later, so that a
-    rank's transfer runs under its next chromosome's compute."""
-    return gather_bytes_start(_calls_as_u8(calls, device).to(device), device)
 
 
 def gather_calls(calls, device, to_host=True):
