@@ -40,6 +40,7 @@ struct vsv_handle {
   // workspace
   DevBuf part_rb, part_count, part_off, scan_tmp;
   DevBuf l_agg, l_carry_r, l_carry_q, l_tiles;   // long-record scan: per-part aggregates, carries, tile sums
+  uint32_t cand_epoch = 0;                       // ... of the candidate kernels' scans
   DevBuf lbw; uint32_t lb_epoch = 0;             // look-back words of the placement's scan (valid by epoch: zeroed when allocated, never per run)
   DevBuf l_prec;                                 // long-record scan: where every part's last descriptor batch lies
   DevBuf z_crctab, z_crc;  // CRC-32 tables (uploaded once) and per-member results of the device inflate
@@ -48,7 +49,9 @@ struct vsv_handle {
   DevBuf cmask;           // split stage: item masks of the candidate count pass (1 byte per 4 records)
   DevBuf gflag;           // CLR: flag bytes with the haplotype bits cleared where the gate fails (input of the scan)
   DevBuf pool, pool_key, raw0, s1in, s1s, c1, s2s, c2, merged, calls_tmp, calls, reads;
-  DevBuf tab, blk_cnt, blk_off, ckey, crec, okey, oval;
+  DevBuf tab, tab2, blk_cnt, blk_off, ckey, crec, okey, oval;   // tab / tab2: the name table ("occurs more than once") of this run and of the next
+  DevBuf qlbw, clbw;               // look-back words of the two scans inside the candidate kernels (one per 2048 records each)
+  uint32_t tab_dirty[2] = {0, 0};  // words a run may have left set in each (cleared by the run in front of the one that uses it)
   DevBuf cinfo, cord, oc1;             // large read-shaped inputs: per-candidate record info, candidate ordinals by name, a slot's first candidate
   DevBuf key, idx, cl, key2, idx2, key_alt, val_alt, hist;
   DevBuf ctr, shard_cnt, totals;   // views into `arena`
@@ -96,6 +99,9 @@ struct vsv_handle {
                                    // scan's descriptors when somebody asks; 2 = those are gone (buffers re-allocated since)
   int raw_parts = 0;               // ... parts of that scan
   bool have_history = false;       // a signature run of this handle has finished: host_ctr describes real tables (else: a COLD handle)
+  bool skip_batches = false;       // the handle's last run filed no overflow batch (parts with more rows than their stage): the next one has no launch for them
+  bool batches_skipped = false;    // ... and the run in flight went without
+  int batch_runs = 0;              // > 0: such a run met one and was repeated: the next runs keep the launch
   bool cold_run = false;           // the run in flight is such a handle's first one: its row count comes from a wait for its own scan
   bool ctr_of_run = false;         // host_ctr holds the counters of the run in progress (a staged call's finish()), not of the previous one
   int64_t element_runs = 0, cold_syncs = 0;          // vsv_path_counts
@@ -242,8 +248,23 @@ int bind_records(vsv_handle* h, const vsv_records* r) {
   // 1 bit per query name ("name occurs more than once"); n_qids = max qid + 1 is part of the contract
   if (r->n_qids <= 0 && r->n_records > 0) return fail(h, VSV_E_INVALID, "n_qids (max qid + 1) is required");
   const uint32_t words = (uint32_t)(((uint64_t)r->n_qids + 31) / 32 + 2);
-  if ((st = ensure(h, h->tab, (size_t)words * 4))) return st;
+  for (DevBuf* t : {&h->tab, &h->tab2}) {
+    const void* before = t->p;
+    if ((st = ensure(h, *t, (size_t)words * 4))) return st;
+    if (t->p != before) {            // a new table: clean, once (afterwards every run clears the table of the run behind it)
+      HIPCHK(h, hipMemsetAsync(t->p, 0, t->bytes, h->stream));
+      h->tab_dirty[t == &h->tab ? 0 : 1] = 0;
+    }
+  }
   h->tab_size = words;
+  {
+    const size_t nw = (size_t)(r->n_records / 2048 + 4) * sizeof(uint64_t);
+    for (DevBuf* t : {&h->qlbw, &h->clbw}) {
+      const void* before = t->p;
+      if ((st = ensure(h, *t, nw))) return st;
+      if (t->p != before) HIPCHK(h, hipMemsetAsync(t->p, 0, t->bytes, h->stream));
+    }
+  }
   return 0;
 }
 
@@ -305,9 +326,9 @@ int reenter_reset(vsv_handle* h) {
   return 0;
 }
 int tid_bits(vsv_handle* h);
-LongScanBufs long_bufs(vsv_handle* h, bool clr_fused, void* fused_rows, const SlimOut& so) {
+LongScanBufs long_bufs(vsv_handle* h, bool clr_fused, void* fused_rows, const SlimOut& so, bool skip_batches = false) {
   return LongScanBufs{h->l_agg.p, (uint32_t*)h->l_carry_r.p, (uint32_t*)h->l_carry_q.p, h->l_tiles.p, h->tile_cnt, 4096, true, clr_fused,
-                      (uint64_t*)h->lbw.p, h->lb_epoch, h->l_prec.p, fused_rows, so};
+                      (uint64_t*)h->lbw.p, h->lb_epoch, h->l_prec.p, fused_rows, so, skip_batches};
 }
 bool want_big(vsv_handle* h);
 bool big_allowed(vsv_handle* h);
@@ -353,10 +374,30 @@ int enq_split_candidates(vsv_handle* h, hipStream_t st, int phase = 0) {
       cb = CandBufs{h->cinfo.p, (uint32_t*)h->cord.p, (uint32_t*)h->oc1.p};
     }
   }
-  h->split_sorted = vsv_launch_split_candidates(st, h->rv, h->prm, h->n_tids, (uint32_t*)h->tab.p, h->tab_size, (uint32_t*)h->blk_cnt.p,
+  // Shards of more than 8192 tiles of 2048 records take the one-launch candidate kernels (scans by look-back, words valid by epoch): they
+  // mark in one name table, which must be clean, and clear the other for the run behind them. Smaller shards take the two-launch
+  // kernels, which clear table 0 themselves and leave their marks there.
+  const bool cand_lb = h->rv.n_records > (int64_t)8192 * 2048;
+  int cur = 0;
+  CandLb clb{nullptr, nullptr, 0, nullptr, 0};
+  if (cand_lb) {
+    cur = h->tab_dirty[0] == 0 ? 0 : 1;
+    if (phase != 2) {
+      if (h->tab_dirty[cur] != 0) { HIPCHK(h, hipMemsetAsync(h->tab2.p, 0, h->tab2.bytes, st)); h->tab_dirty[1] = 0; }     // (both hold marks: a switch of forms)
+      if (++h->cand_epoch >= (1u << 24)) {
+        HIPCHK(h, hipMemsetAsync(h->qlbw.p, 0, h->qlbw.bytes, st));
+        HIPCHK(h, hipMemsetAsync(h->clbw.p, 0, h->clbw.bytes, st));
+        h->cand_epoch = 1;
+      }
+    }
+    clb = CandLb{(uint64_t*)h->qlbw.p, (uint64_t*)h->clbw.p, h->cand_epoch, (uint32_t*)(cur ? h->tab.p : h->tab2.p), h->tab_dirty[1 - cur]};
+    if (phase != 2) { h->tab_dirty[1 - cur] = 0; h->tab_dirty[cur] = h->tab_size; }
+  } else if (phase != 2) h->tab_dirty[0] = h->tab_size;
+  DevBuf& tcur = cur ? h->tab2 : h->tab;
+  h->split_sorted = vsv_launch_split_candidates(st, h->rv, h->prm, h->n_tids, (uint32_t*)tcur.p, h->tab_size, (uint32_t*)h->blk_cnt.p,
                                                 (uint32_t*)h->blk_off.p, (uint32_t*)h->scan_tmp2.p, (uint64_t*)h->ckey.p, (uint32_t*)h->crec.p,
                                                 (uint64_t*)h->okey.p, (uint32_t*)h->oval.p, (uint64_t*)h->key2.p, (uint32_t*)h->idx2.p, sort_work(h),
-                                                (uint32_t)h->cap_sigs, dctr(h), (uint8_t*)h->cmask.p, ew_grid(h), slim ? &w : nullptr, cb, phase);
+                                                (uint32_t)h->cap_sigs, dctr(h), (uint8_t*)h->cmask.p, ew_grid(h), slim ? &w : nullptr, cb, phase, clb);
   HIPCHK(h, hipGetLastError());
   h->split_cands_done = phase != 1;
   return 0;
@@ -367,6 +408,7 @@ int enq_scan(vsv_handle* h) {
   if (h->lsd_runs > 0 && !h->in_rerun) --h->lsd_runs;
   if (h->row_runs > 0 && !h->in_rerun) --h->row_runs;
   if (h->lsd_slim_runs > 0 && !h->in_rerun) --h->lsd_slim_runs;
+  if (h->batch_runs > 0 && !h->in_rerun) --h->batch_runs;
   h->cutesv_rows = -1;   // the split-candidate table shares a buffer with the merge stage
   h->ctr_of_run = false;
   if (is_contig(h->prm.dtype)) {   // the element buffers this run may need exist before its first launch (a large-table handle: all of them)
@@ -407,7 +449,8 @@ int enq_scan(vsv_handle* h) {
   vsv_launch_cigar_scan(st, srv, h->prm, (uint32_t*)h->part_rb.p, n_parts, OPS_PER_PART, (vsv_sig*)h->pool.p,
                         (uint64_t*)h->pool_key.p, (uint32_t)h->cap_sigs, (uint32_t*)h->part_count.p, (uint32_t*)h->part_off.p,
                         (uint32_t*)h->scan_tmp.p, (vsv_sig*)h->raw0.p, dctr(h), (uint32_t*)h->shard_cnt.p, h->ev0, h->ev1,
-                        long_bufs(h, clr_fused, fused ? h->s1in.p : nullptr, so_f));
+                        long_bufs(h, clr_fused, fused ? h->s1in.p : nullptr, so_f, h->skip_batches));
+  h->batches_skipped = h->skip_batches;
   h->have_scan_ev = n_parts > 0;
   h->raw_state = fused ? 1 : 0;
   h->raw_parts = long_parts;
@@ -600,7 +643,11 @@ int finish(vsv_handle* h) {
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->host_ctr = *h->pinned;
   h->pending = false;
-  if (h->stage_done >= 1) { h->have_history = true; h->ctr_of_run = true; }
+  if (h->stage_done >= 1) {
+    h->have_history = true; h->ctr_of_run = true;
+    if (h->batches_skipped && h->host_ctr.pad[0] != 0) h->host_ctr.err |= ERRB_BATCH_FALLBACK;    // rows of those batches were never placed: again, with the launch
+    h->skip_batches = h->host_ctr.pad[0] == 0 && h->batch_runs == 0;
+  }
   h->cold_run = false;
   if (h->stage_done >= 5) {   // pairing of the NEXT run: in rounds once a stretch of thousands of rows was met, back to the plain
                               // kernel when the merged table gets small again (the rounds cost ~20 launches)
@@ -623,7 +670,7 @@ int finish(vsv_handle* h) {
     fprintf(stderr, "[vsv] n_pool %u n_raw %u n_cand %u n_s1 %u alive %u %u %u calls %u max_stretch %u err %#x pad %u %u %u\n", c.n_pool, c.n_raw, c.n_cand, c.n_s1,
             c.n_alive1, c.n_alive2, c.n_alive3, c.n_calls, c.max_stretch, c.err, c.pad[0], c.pad[1], c.pad[2]);
   }
-  if (e & (ERRB_CLR_FALLBACK | ERRB_SORT_FALLBACK | ERRB_SLIM_FALLBACK | ERRB_MERGE_FALLBACK)) {
+  if (e & (ERRB_CLR_FALLBACK | ERRB_SORT_FALLBACK | ERRB_SLIM_FALLBACK | ERRB_MERGE_FALLBACK | ERRB_BATCH_FALLBACK)) {
     // ERRB_CLR_FALLBACK: a part of the read-shaped CLR scan held more chunks than its gate state — nothing that run decided can be
     // trusted; same input again with the gate as a separate pass (this handle keeps that form). ERRB_SORT_FALLBACK: a bucket of
     // the bucket sort did not fit in LDS (tables far from uniform, or much larger than the previous run's) — the stages behind it
@@ -637,7 +684,8 @@ int finish(vsv_handle* h) {
     bool stale_hint = false;
     for (int attempt = 0; attempt < 4 && st == 1; ++attempt) {
       const uint32_t ee = h->host_ctr.err;
-      if (ee & ERRB_CLR_FALLBACK) h->clr_unfused = true;
+      if (ee & ERRB_BATCH_FALLBACK) { h->batch_runs = 16; h->skip_batches = false; }
+      else if (ee & ERRB_CLR_FALLBACK) h->clr_unfused = true;
       else if (ee & ERRB_SLIM_FALLBACK) h->row_runs = 16;       // a length outside [0, 2^30): the same input on rows (64-bit predicates)
       else if (ee & ERRB_MERGE_FALLBACK) h->lsd_slim_runs = 16; // slots too dense for the windows of the rank-and-merge sorts: the same input through the LSD passes
       else {
@@ -791,7 +839,7 @@ void vsv_destroy(vsv_handle* h) {
   if (h->ev_join) hipEventDestroy(h->ev_join);
   DevBuf* bufs[] = {&h->scan_tmp2, &h->r_pos, &h->r_tid, &h->r_qid, &h->r_off, &h->r_mapq, &h->r_flag, &h->r_cigar, &h->part_rb, &h->part_count,
                     &h->part_off, &h->scan_tmp, &h->lbw, &h->l_prec, &h->l_agg, &h->l_carry_r, &h->l_carry_q, &h->l_tiles, &h->z_crctab, &h->z_crc, &h->pool, &h->pool_key, &h->raw0, &h->s1in, &h->s1s, &h->c1, &h->s2s, &h->c2,
-                    &h->merged, &h->calls_tmp, &h->calls, &h->reads, &h->tab, &h->blk_cnt, &h->blk_off, &h->ckey, &h->crec,
+                    &h->merged, &h->calls_tmp, &h->calls, &h->reads, &h->tab, &h->tab2, &h->qlbw, &h->clbw, &h->blk_cnt, &h->blk_off, &h->ckey, &h->crec,
                     &h->okey, &h->oval, &h->key, &h->idx, &h->cl, &h->key2, &h->idx2, &h->key_alt, &h->val_alt, &h->hist, &h->arena, &h->g_off, &h->g_qs, &h->g_qe, &h->g_rid, &h->g_rs,
                     &h->g_re, &h->g_rev, &h->g_hap, &h->g_len, &h->g_rank, &h->j_cpos, &h->j_clen, &h->j_spos, &h->j_slen, &h->j_send, &h->j_out, &h->j_err, &h->z_comp, &h->z_coff, &h->z_ooff, &h->z_out, &h->z_stat, &h->p_spec, &h->p_cnt, &h->p_land, &h->p_base, &h->p_recoff, &h->p_pos, &h->p_tid,
                     &h->p_mapq, &h->p_flag, &h->p_lseq, &h->p_sflag, &h->p_ncig, &h->p_cgsrc, &h->p_hash, &h->p_keep, &h->p_kidx, &h->p_cigoff, &h->p_sums,

@@ -1113,6 +1113,7 @@ __global__ __launch_bounds__(256) void k1l_place(PlaceArgs A) {
       if (total > (uint64_t)A.cap) atomicOr(&A.ctr->err, ERRB_CAPACITY);
     }
   }
+  if (blockIdx.x == 0 && t == 0) A.ctr->pad[0] = A.shard_cnt[8];      // overflow batches of this run: the host skips their launch while there are none
   if (blockIdx.x == 0) {                            // a shard that overflowed: rows are missing, and a retry needs shards of that size
     const uint32_t used = A.shard_cnt[t * 16];      // (K1_SHARDS == 256 threads)
     if (used > A.shard_cap) {
@@ -1256,7 +1257,8 @@ int vsv_cigar_parts_long(int64_t n_ops) { return (int)((n_ops + K1L_PART - 1) / 
 // the scan's batches -> rows in T_RAW order (and their elements): behind the scan, and again into the raw table when a caller asks
 // for VSV_T_RAW of a run whose rows went straight into the stage-1 table (capi.hip). n_parts: the scan's (vsv_scan_parts).
 void vsv_launch_place(hipStream_t st, const RecView& rv, const vsv_params& p, int n_parts, vsv_sig* pool, uint64_t* pool_key, uint32_t cap, uint32_t* part_count,
-                      uint32_t* part_off, vsv_sig* rows, Counters* ctr, uint32_t* shard_cnt, const LongScanBufs& lb, uint32_t epoch, const SlimOut& so) {
+                      uint32_t* part_off, vsv_sig* rows, Counters* ctr, uint32_t* shard_cnt, const LongScanBufs& lb, uint32_t epoch, const SlimOut& so,
+                      bool with_batches) {
   if (n_parts <= 0) return;
   const bool long_mode = vsv_scan_is_long(rv, p);
   const int no_qend = (p.dtype == VSV_DTYPE_READS || p.dtype == VSV_DTYPE_CUTESV) ? 1 : 0;
@@ -1265,7 +1267,7 @@ void vsv_launch_place(hipStream_t st, const RecView& rv, const vsv_params& p, in
   k1l_place<<<(n_parts + PL_PARTS - 1) / PL_PARTS, 256, 0, st>>>(PlaceArgs{(const uint4*)pool, shard_cnt, shard_cap, (const uint2*)lb.prec, part_count,
                                                                  long_mode ? (const PartAgg*)lb.agg : nullptr, n_parts, lb.lbw, epoch, rv.tid, rows, cap, ctr, part_off,
                                                                  lb.carry_r, lb.carry_q, no_qend, so, pool_rows});
-  k1l_place_batches<<<64, 256, 0, st>>>((const uint4*)pool_key, shard_cnt + 8, cap / 2, (const uint4*)pool, part_off, lb.carry_r, lb.carry_q, rv.tid, rows, cap, no_qend, so, pool_rows);
+  if (with_batches) k1l_place_batches<<<64, 256, 0, st>>>((const uint4*)pool_key, shard_cnt + 8, cap / 2, (const uint4*)pool, part_off, lb.carry_r, lb.carry_q, rv.tid, rows, cap, no_qend, so, pool_rows);
 }
 // ops per part and parts of the scan this call takes (the long scan's parts are never shorter than the read-shaped ones: the part
 // tables are sized for those)
@@ -1319,7 +1321,7 @@ void vsv_launch_cigar_scan(hipStream_t st, const RecView& rv, const vsv_params& 
 #undef K1_LAUNCH
   if (ev1) (void)hipEventRecord(ev1, st);
   vsv_launch_place(st, rv, p, n_parts, pool, pool_key, cap, part_count, part_off, lb.fused_rows ? (vsv_sig*)lb.fused_rows : raw, ctr, shard_cnt, lb, lb.epoch,
-                   lb.fused_rows ? lb.so : SlimOut{nullptr, 0, 0, 0, nullptr});
+                   lb.fused_rows ? lb.so : SlimOut{nullptr, 0, 0, 0, nullptr}, !lb.skip_batches);
 }
 size_t vsv_lookback_bytes(int64_t n_ops, int ops_per_part) {
   const size_t a = (size_t)vsv_cigar_parts_long(n_ops) + 16, b = (size_t)vsv_cigar_parts(n_ops, ops_per_part) + 16;

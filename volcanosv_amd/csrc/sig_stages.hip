@@ -279,6 +279,7 @@ __device__ __forceinline__ void load_qid8(const uint32_t* __restrict__ qid, int6
     for (int k = 0; k < 8; ++k) q[k] = (base + k < n) ? qid[base + k] + 1u : 0u;
   }
 }
+// Shards of up to 8192 tiles: two launches, every marking block reduces the raw maxima of the tiles in front of it itself.
 // (+ every block clears its slice of the name table's bits for qid_mark_dups: no fill launch)
 __global__ __launch_bounds__(256) void qid_tile_max(const uint32_t* __restrict__ qid, int64_t n, uint32_t* __restrict__ tile_max, bool vec,
                                                     uint32_t* __restrict__ tab, uint32_t tab_words) {
@@ -299,33 +300,7 @@ __global__ __launch_bounds__(256) void qid_tile_max(const uint32_t* __restrict__
   __syncthreads();
   if (threadIdx.x == 0) tile_max[blockIdx.x] = max(max(sh[0], sh[1]), max(sh[2], sh[3]));
 }
-// single block: exclusive prefix maximum over the tiles, in place
-__global__ __launch_bounds__(1024) void qid_scan_max(uint32_t* __restrict__ tile_max, int ntiles) {
-  __shared__ uint32_t sh[1024];
-  __shared__ uint32_t carry;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (int base = 0; base < ntiles; base += 1024) {
-    const int i = base + threadIdx.x;
-    const uint32_t v = i < ntiles ? tile_max[i] : 0;
-    sh[threadIdx.x] = v;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-      const uint32_t t = (int)threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
-      __syncthreads();
-      sh[threadIdx.x] = max(sh[threadIdx.x], t);
-      __syncthreads();
-    }
-    const uint32_t c = carry;
-    const uint32_t excl = max(c, threadIdx.x > 0 ? sh[threadIdx.x - 1] : 0u);
-    const uint32_t last = max(c, sh[1023]);
-    __syncthreads();
-    if (i < ntiles) tile_max[i] = excl;
-    if (threadIdx.x == 0) carry = last;
-    __syncthreads();
-  }
-}
-// raw_tiles: tile_excl still holds the tiles' own maxima (no qid_scan_max launch ran)
+// raw_tiles: tile_excl holds the tiles' own maxima
 __global__ __launch_bounds__(256) void qid_mark_dups(const uint32_t* __restrict__ qid, int64_t n, const uint32_t* __restrict__ tile_excl,
                                                      uint32_t* __restrict__ dupbits, bool vec, uint32_t n_qids, uint32_t* __restrict__ err,
                                                      bool raw_tiles) {
@@ -363,19 +338,73 @@ __global__ __launch_bounds__(256) void qid_mark_dups(const uint32_t* __restrict_
   }
 }
 
+// One launch: the tile's largest id, its exclusive prefix maximum over the tiles in front by look-back (vsv_lb1_exclusive), the marks.
+// For shards of MORE than 8192 tiles (config 3: 24 k), where the two-launch form above needed a single-block scan launch in between
+// (45 us) — on smaller shards the look-back loses: the blocks wait for the blocks in front while another engine's scan holds the
+// chip's slots (config 2, four engines, same box: 0.433 against 0.417 ms per step). The table this run marks in was cleared by the run in front (or when it was
+// allocated); every block clears its slice of the OTHER table, which the next run marks in: a launch cannot clear the table it marks.
+constexpr int QD_SUB = 4;                    // sub-tiles of QM_TILE records per block: one look-back per 8192 records (a block of 2048 spent
+                                             // more time waiting for the blocks in front than working: 33 us against 24 for the two launches)
+__global__ __launch_bounds__(256) void qid_dups(const uint32_t* __restrict__ qid, int64_t n, uint32_t* __restrict__ dupbits, bool vec, uint32_t n_qids,
+                                                uint32_t* __restrict__ err, uint64_t* __restrict__ lbw, uint32_t epoch, uint32_t* __restrict__ tab_next, uint32_t clear_words) {
+  __shared__ uint32_t sh[QD_SUB][4];
+  __shared__ uint32_t sh_before;
+  {
+    const uint32_t per = (clear_words + gridDim.x - 1) / gridDim.x;
+    const uint32_t a = min(clear_words, blockIdx.x * per), e = min(clear_words, a + per);
+    for (uint32_t i = a + threadIdx.x; i < e; i += 256) tab_next[i] = 0;
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t q[QD_SUB][8], excl[QD_SUB];
+#pragma unroll
+  for (int s = 0; s < QD_SUB; ++s) {
+    load_qid8(qid, ((int64_t)blockIdx.x * QD_SUB + s) * QM_TILE + threadIdx.x * 8, n, vec, q[s]);
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m = max(m, q[s][k]);
+    uint32_t incl = m;                     // inclusive prefix maximum over the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl = max(incl, o); }
+    if (lane == 63) sh[s][wv] = incl;
+    excl[s] = (uint32_t)__shfl_up((int)incl, 1, 64);
+    if (lane == 0) excl[s] = 0;
+  }
+  __syncthreads();
+  if (wv == 0) {                           // the largest id of the blocks in front of this one
+    uint32_t tile = 0;
+#pragma unroll
+    for (int s = 0; s < QD_SUB; ++s) tile = max(tile, max(max(sh[s][0], sh[s][1]), max(sh[s][2], sh[s][3])));
+    const uint32_t before = vsv_lb1_exclusive<true>(lbw, epoch, blockIdx.x, tile, lane, err);
+    if (lane == 0) sh_before = before;
+  }
+  __syncthreads();
+  uint32_t front = sh_before;              // everything in front of the sub-tile
+#pragma unroll
+  for (int s = 0; s < QD_SUB; ++s) {
+    uint32_t run = max(front, excl[s]);
+    for (int w = 0; w < wv; ++w) run = max(run, sh[s][w]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (q[s][k] != 0 && q[s][k] - 1u >= n_qids) atomicOr(err, ERRB_RANGE);                 // qid outside [0, n_qids): the table has no bit for it
+      else if (q[s][k] != 0 && q[s][k] <= run) atomicOr(&dupbits[(q[s][k] - 1u) >> 5], 1u << ((q[s][k] - 1u) & 31u));
+      run = max(run, q[s][k]);
+    }
+    front = max(front, max(max(sh[s][0], sh[s][1]), max(sh[s][2], sh[s][3])));
+  }
+}
+
 // ordered compaction of candidate (record, hap) items. A thread owns 4 consecutive records per round (flag / mapq as one
 // dword each, qid as one 16-byte load when the arrays are aligned), i.e. 8 items in (record, hap) order as an 8-bit mask.
-constexpr int SC_ROUNDS = 2;
+constexpr int SC_ROUNDS = 8;     // (one look-back per 8192 records: see qid_dups)
 constexpr int SC_TILE_REC = 256 * 4 * SC_ROUNDS;    // records per block
-// WRITE with raw_counts: blk still holds the blocks' own counts (no scan launch ran)
-template <bool WRITE>
-__global__ __launch_bounds__(256) void split_cand(RecView rv, SplitCfg c, const uint32_t* __restrict__ tab,
-                                                  uint32_t* __restrict__ blk, uint64_t* __restrict__ ckey,
+// One launch: the block's item masks and count, its offset by look-back over the blocks in front (vsv_lb1_exclusive), the writes.
+// (Round 3: a count launch that left the masks in memory and a fill launch that read them back, with a scan between them beyond
+// 8192 blocks.)
+__global__ __launch_bounds__(256) void split_cand(RecView rv, SplitCfg c, const uint32_t* __restrict__ tab, uint64_t* __restrict__ ckey,
                                                   uint32_t* __restrict__ crec, uint32_t cap, bool vec, Counters* __restrict__ ctr,
-                                                  uint8_t* __restrict__ masks, bool raw_counts = false) {
-  // masks[block][round][thread]: the 8-bit item mask of a thread's 4 records. The count pass writes it, the write pass reads it
-  // back instead of streaming qid / flag / mapq and probing the name table a second time.
+                                                  uint64_t* __restrict__ lbw, uint32_t epoch) {
   __shared__ uint32_t cnt[SC_ROUNDS][4];
+  __shared__ uint32_t sh_off;
   const uint64_t n = (uint64_t)rv.n_records;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   uint32_t m[SC_ROUNDS], below[SC_ROUNDS], q[SC_ROUNDS][4];
@@ -384,7 +413,98 @@ __global__ __launch_bounds__(256) void split_cand(RecView rv, SplitCfg c, const 
     const uint64_t r0 = (uint64_t)blockIdx.x * SC_TILE_REC + (uint64_t)k * 1024 + (uint64_t)threadIdx.x * 4;
     m[k] = 0;
     uint32_t fl4 = 0, mq4 = 0;
-    const size_t mi = ((size_t)blockIdx.x * SC_ROUNDS + k) * 256 + threadIdx.x;
+    if (vec && r0 + 4 <= n) {
+      const uint4 qq = *reinterpret_cast<const uint4*>(rv.qid + r0);
+      q[k][0] = qq.x; q[k][1] = qq.y; q[k][2] = qq.z; q[k][3] = qq.w;
+      if (c.contig) { fl4 = *reinterpret_cast<const uint32_t*>(rv.flag + r0); mq4 = *reinterpret_cast<const uint32_t*>(rv.mapq + r0); }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        q[k][j] = 0;
+        if (r0 + j < n) {
+          q[k][j] = rv.qid[r0 + j];
+          if (c.contig) { fl4 |= (uint32_t)rv.flag[r0 + j] << (8 * j); mq4 |= (uint32_t)rv.mapq[r0 + j] << (8 * j); }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (r0 + j >= n) continue;
+      uint32_t e;                                                     // bit 0: hap 0 item, bit 1: hap 1 item
+      if (!c.contig) e = 1u;
+      else {
+        const uint32_t fl = (fl4 >> (8 * j)) & 0xFFu, mq = (mq4 >> (8 * j)) & 0xFFu;
+        e = (mq >= (uint32_t)c.min_mapq) ? (((fl & VSV_F_HP1) ? 1u : 0u) | ((fl & VSV_F_HP2) ? 2u : 0u)) : 0u;   // Hifi.py:425-427
+      }
+      if (e && q[k][j] < (uint32_t)rv.n_qids && ((tab[q[k][j] >> 5] >> (q[k][j] & 31u)) & 1u)) m[k] |= e << (2 * j);
+    }
+    const uint32_t cc = (uint32_t)__popc(m[k]);
+    uint32_t incl = cc;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += o; }
+    below[k] = incl - cc;
+    if (lane == 63) cnt[k][wv] = incl;
+  }
+  __syncthreads();
+  if (wv == 0) {
+    uint32_t t = 0;
+    for (int k = 0; k < SC_ROUNDS; ++k) for (int w = 0; w < 4; ++w) t += cnt[k][w];
+    const uint32_t before = vsv_lb1_exclusive<false>(lbw, epoch, blockIdx.x, t, lane, &ctr->err);
+    if (lane == 0) {
+      sh_off = before;
+      if (blockIdx.x == gridDim.x - 1) {                    // the last block knows the total: publish the candidate count
+        const uint64_t tot = (uint64_t)before + t;          // (n_s1 = n_raw + n_cand is split_eval's: this kernel may run next to the scan)
+        ctr->n_cand = tot < cap ? (uint32_t)tot : cap;
+        if (tot > cap) atomicOr(&ctr->err, ERRB_CAPACITY);
+      }
+    }
+  }
+  __syncthreads();
+  uint32_t off = sh_off;
+#pragma unroll
+  for (int k = 0; k < SC_ROUNDS; ++k) {
+    uint32_t dst = off + below[k];
+    for (int w = 0; w < wv; ++w) dst += cnt[k][w];
+    const uint64_t r0 = (uint64_t)blockIdx.x * SC_TILE_REC + (uint64_t)k * 1024 + (uint64_t)threadIdx.x * 4;
+    uint32_t mm = m[k];
+    while (mm) {
+      const int it = __builtin_ctz(mm);
+      mm &= mm - 1;
+      const uint32_t j = (uint32_t)it >> 1, hap = (uint32_t)it & 1u;
+      if (dst < cap) {
+        const uint32_t qj = rv.qid[r0 + j];
+        const uint32_t trel = (uint32_t)(rv.tid[r0 + j] - c.tid_lo);
+        if (trel >> c.tid_bits) atomicOr(&ctr->err, ERRB_RANGE);     // tid outside [tid_lo, n_tids)
+        ckey[dst] = ((uint64_t)trel << c.tid_shift) | ((uint64_t)hap << c.qid_bits) | qj;
+        crec[dst] = (uint32_t)(r0 + j);
+      }
+      ++dst;
+    }
+    off += cnt[k][0] + cnt[k][1] + cnt[k][2] + cnt[k][3];
+  }
+}
+
+constexpr int SC2_ROUNDS = 2;
+constexpr int SC2_TILE_REC = 256 * 4 * SC2_ROUNDS;    // records per block
+// The two-launch form (count, then fill from the masks the count pass left): shards of up to 8192 blocks of 2048 records, where every
+// fill block adds up the raw counts of the blocks in front of it itself. WRITE with raw_counts: blk still holds the blocks' own counts
+template <bool WRITE>
+__global__ __launch_bounds__(256) void split_cand_2pass(RecView rv, SplitCfg c, const uint32_t* __restrict__ tab,
+                                                  uint32_t* __restrict__ blk, uint64_t* __restrict__ ckey,
+                                                  uint32_t* __restrict__ crec, uint32_t cap, bool vec, Counters* __restrict__ ctr,
+                                                  uint8_t* __restrict__ masks, bool raw_counts = false) {
+  // masks[block][round][thread]: the 8-bit item mask of a thread's 4 records. The count pass writes it, the write pass reads it
+  // back instead of streaming qid / flag / mapq and probing the name table a second time.
+  __shared__ uint32_t cnt[SC2_ROUNDS][4];
+  const uint64_t n = (uint64_t)rv.n_records;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t m[SC2_ROUNDS], below[SC2_ROUNDS], q[SC2_ROUNDS][4];
+#pragma unroll
+  for (int k = 0; k < SC2_ROUNDS; ++k) {
+    const uint64_t r0 = (uint64_t)blockIdx.x * SC2_TILE_REC + (uint64_t)k * 1024 + (uint64_t)threadIdx.x * 4;
+    m[k] = 0;
+    uint32_t fl4 = 0, mq4 = 0;
+    const size_t mi = ((size_t)blockIdx.x * SC2_ROUNDS + k) * 256 + threadIdx.x;
     if (WRITE) {
       m[k] = masks[mi];
     } else if (vec && r0 + 4 <= n) {
@@ -424,7 +544,7 @@ __global__ __launch_bounds__(256) void split_cand(RecView rv, SplitCfg c, const 
   if (!WRITE) {
     if (threadIdx.x == 0) {
       uint32_t t = 0;
-      for (int k = 0; k < SC_ROUNDS; ++k) for (int w = 0; w < 4; ++w) t += cnt[k][w];
+      for (int k = 0; k < SC2_ROUNDS; ++k) for (int w = 0; w < 4; ++w) t += cnt[k][w];
       blk[blockIdx.x] = t;
     }
     return;
@@ -442,15 +562,15 @@ __global__ __launch_bounds__(256) void split_cand(RecView rv, SplitCfg c, const 
   off = sh_off[0] + sh_off[1] + sh_off[2] + sh_off[3];
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {   // the last block knows the total: publish the candidate count
     uint32_t t = off;                                       // (n_s1 = n_raw + n_cand is split_eval's: this kernel may run next to the scan)
-    for (int k = 0; k < SC_ROUNDS; ++k) for (int w = 0; w < 4; ++w) t += cnt[k][w];
+    for (int k = 0; k < SC2_ROUNDS; ++k) for (int w = 0; w < 4; ++w) t += cnt[k][w];
     ctr->n_cand = t < cap ? t : cap;
     if (t > cap) atomicOr(&ctr->err, ERRB_CAPACITY);
   }
 #pragma unroll
-  for (int k = 0; k < SC_ROUNDS; ++k) {
+  for (int k = 0; k < SC2_ROUNDS; ++k) {
     uint32_t dst = off + below[k];
     for (int w = 0; w < wv; ++w) dst += cnt[k][w];
-    const uint64_t r0 = (uint64_t)blockIdx.x * SC_TILE_REC + (uint64_t)k * 1024 + (uint64_t)threadIdx.x * 4;
+    const uint64_t r0 = (uint64_t)blockIdx.x * SC2_TILE_REC + (uint64_t)k * 1024 + (uint64_t)threadIdx.x * 4;
     uint32_t mm = m[k];
     while (mm) {
       const int it = __builtin_ctz(mm);
@@ -1243,7 +1363,9 @@ static SplitCfg split_cfg(const RecView& rv, const vsv_params& p, int n_tids) {
 SplitSorted vsv_launch_split_candidates(hipStream_t st, const RecView& rv, const vsv_params& p, int n_tids, uint32_t* tab, uint32_t tab_size,
                                         uint32_t* blk_cnt, uint32_t* blk_off, uint32_t* scan_tmp, uint64_t* ckey, uint32_t* crec,
                                         uint64_t* okey, uint32_t* oval, uint64_t* key2, uint32_t* idx2, const SortWork& sw,
-                                        uint32_t cap, Counters* ctr, uint8_t* cmask, int grid, const SlimWork* slim, const CandBufs& cb, int phase) {
+                                        uint32_t cap, Counters* ctr, uint8_t* cmask, int grid, const SlimWork* slim, const CandBufs& cb, int phase,
+                                        const CandLb& lb) {
+  (void)blk_off; (void)scan_tmp;
   SplitSorted out{nullptr, nullptr, nullptr, nullptr};
   if (rv.n_records <= 0) return out;
   const SplitCfg c = split_cfg(rv, p, n_tids);
@@ -1255,20 +1377,17 @@ SplitSorted vsv_launch_split_candidates(hipStream_t st, const RecView& rv, const
   // phase 1 = the candidates only (name repeats, count, fill: the same kernels whatever the tables' sizes: a cold handle runs them
   // beside its scan and takes the candidate count from them), phase 2 = their two sorts only, 0 = both
   if (phase != 2) {
-  qid_tile_max<<<qtiles, 256, 0, st>>>(rv.qid, rv.n_records, blk_cnt, vec, tab, (uint32_t)((nq + 31) / 32 + 1));
-  // up to 8192 tiles / blocks (16 M records) the consumers reduce the per-tile values in front of them themselves: two 5-10 us
-  // launches less; beyond that the reductions (quadratic in the tile count) cost more than the scan launches
-  static const int self_max = vsv_dbg_env("VSV_SELF_SCAN") ? atoi(vsv_dbg_env("VSV_SELF_SCAN")) : 8192;     // timing experiments
-  const bool self_scan = qtiles <= self_max;
-  if (!self_scan) qid_scan_max<<<1, 1024, 0, st>>>(blk_cnt, qtiles);
-  qid_mark_dups<<<qtiles, 256, 0, st>>>(rv.qid, rv.n_records, blk_cnt, tab, vec, (uint32_t)nq, &ctr->err, self_scan);
-  const int nblk = (int)(((uint64_t)rv.n_records + SC_TILE_REC - 1) / SC_TILE_REC);
-  split_cand<false><<<nblk, 256, 0, st>>>(rv, c, tab, blk_cnt, ckey, crec, cap, vec, ctr, cmask);
-  if (self_scan) split_cand<true><<<nblk, 256, 0, st>>>(rv, c, tab, blk_cnt, ckey, crec, cap, vec, ctr, cmask, true);
-  else {
-    vsv_scan_u32_exclusive(st, blk_cnt, nblk, blk_off, scan_tmp);
-    split_cand<true><<<nblk, 256, 0, st>>>(rv, c, tab, blk_off, ckey, crec, cap, vec, ctr, cmask, false);
-  }
+    if (lb.qwords) {              // large shards: one launch each, scans by look-back
+      qid_dups<<<(qtiles + QD_SUB - 1) / QD_SUB, 256, 0, st>>>(rv.qid, rv.n_records, tab, vec, (uint32_t)nq, &ctr->err, lb.qwords, lb.epoch, lb.tab_next, lb.clear_words);
+      const int nblk = (int)(((uint64_t)rv.n_records + SC_TILE_REC - 1) / SC_TILE_REC);
+      split_cand<<<nblk, 256, 0, st>>>(rv, c, tab, ckey, crec, cap, vec, ctr, lb.cwords, lb.epoch);
+    } else {                      // up to 8192 tiles: the consumers reduce the per-tile values in front of them themselves
+      qid_tile_max<<<qtiles, 256, 0, st>>>(rv.qid, rv.n_records, blk_cnt, vec, tab, (uint32_t)((nq + 31) / 32 + 1));
+      qid_mark_dups<<<qtiles, 256, 0, st>>>(rv.qid, rv.n_records, blk_cnt, tab, vec, (uint32_t)nq, &ctr->err, true);
+      const int nblk = (int)(((uint64_t)rv.n_records + SC2_TILE_REC - 1) / SC2_TILE_REC);
+      split_cand_2pass<false><<<nblk, 256, 0, st>>>(rv, c, tab, blk_cnt, ckey, crec, cap, vec, ctr, cmask);
+      split_cand_2pass<true><<<nblk, 256, 0, st>>>(rv, c, tab, blk_cnt, ckey, crec, cap, vec, ctr, cmask, true);
+    }
   }
   if (phase == 1) return out;
   if (slim) {

@@ -22,6 +22,7 @@ enum : uint32_t {
   ERRB_CLR_FALLBACK = 1u << 9,   // a part too long for the gate state of the fused CLR scan: the run is repeated with the separate gate pass
   ERRB_SORT_FALLBACK = 1u << 7,  // a bucket of the bucket sort did not fit in LDS: the run is repeated with the LSD passes
   ERRB_MERGE_FALLBACK = 1u << 11, // a rank-and-merge sort of the element path met a window it cannot decide (thousands of slots within one shift): the run is repeated with the LSD passes
+  ERRB_BATCH_FALLBACK = 1u << 13, // (host side) a part of the scan filed an overflow batch in a run that skipped their placement launch: the run is repeated with it
   ERRB_LOOKBACK = 1u << 12,      // a part of the scan waited for its predecessors' row counts beyond every plausible time (cigar_scan.hip, look-back): internal error
   ERRB_SLIM_FALLBACK = 1u << 10, // an svlen outside [0, 2^30) or a position of 2^30 and more met the element path (32-bit predicates): the run is repeated on rows
 };
@@ -111,6 +112,47 @@ __device__ __forceinline__ void vsv_slim_emit(const SlimOut& so, uint32_t i, con
   reinterpret_cast<uint4*>(so.base)[i] = make_uint4((uint32_t)k, (uint32_t)(k >> 32), (uint32_t)v.svlen, i | ((v.meta & VSV_M_DEL) ? VSV_SL_DEL : 0u));
 }
 
+// ---- decoupled look-back on ONE 32-bit value per block: an exclusive scan (sum or maximum) inside one launch -----------------
+// Every block publishes its own value, looks back over its predecessors' words until it meets one that holds an inclusive prefix, and
+// publishes its own inclusive prefix. A word is valid by itself: [63:40] epoch of the run (words of earlier runs are "not yet": the
+// buffer is zeroed when allocated, never per run), [39:38] kind (1 own value / 2 inclusive prefix), [31:0] value; relaxed agent-scope
+// atomics, no fence. Workgroups are dispatched in index order and a block waits for lower blocks only, so the waits end; they are
+// bounded all the same (ERRB_LOOKBACK). Called by all 64 lanes of ONE wave of the block, wave-uniform arguments.
+__device__ __forceinline__ uint64_t vsv_lb1_ld(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void vsv_lb1_st(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <bool MAX>
+__device__ __forceinline__ uint32_t vsv_lb1_exclusive(uint64_t* __restrict__ words, uint32_t epoch, uint32_t idx, uint32_t own, int lane, uint32_t* err) {
+  const uint64_t tag = (uint64_t)epoch << 40;
+  if (lane == 0) vsv_lb1_st(words + idx, tag | (1ull << 38) | own);
+  uint32_t acc = 0;
+  if (idx != 0) {
+    int64_t j = (int64_t)idx - 1;
+    uint32_t spins = 0;
+    for (;;) {
+      const int64_t pj = j - lane;
+      uint64_t w = tag | (2ull << 38);             // in front of block 0: an empty inclusive prefix
+      if (pj >= 0) w = vsv_lb1_ld(words + pj);
+      const uint32_t kind = (uint32_t)(w >> 40) == epoch ? (uint32_t)(w >> 38) & 3u : 0u;
+      const uint64_t m_inv = __ballot(kind == 0u), m_pre = __ballot(kind == 2u);
+      const uint32_t lp = m_pre ? (uint32_t)__builtin_ctzll(m_pre) : 64u, li = m_inv ? (uint32_t)__builtin_ctzll(m_inv) : 64u;
+      if (li < lp) {                               // a block between this one and the nearest prefix has not published yet
+        if (++spins > (1u << 20)) { if (lane == 0) atomicOr(err, ERRB_LOOKBACK); break; }
+        __builtin_amdgcn_s_sleep(8);
+        continue;
+      }
+      uint32_t v = (uint32_t)lane <= lp ? (uint32_t)w : 0u;
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64); v = MAX ? (v > o ? v : o) : v + o; }
+      acc = MAX ? (acc > v ? acc : v) : acc + v;
+      if (lp < 64u) break;
+      j -= 64;
+    }
+  }
+  const uint32_t incl = MAX ? (acc > own ? acc : own) : acc + own;
+  if (lane == 0) vsv_lb1_st(words + idx, tag | (2ull << 38) | incl);
+  return acc;
+}
+
 // ---- launch wrappers implemented in the .hip files ------------------------------------------------
 struct SortWork {       // scratch for vsv_radix_sort_pairs
   uint64_t* key_alt;
@@ -170,10 +212,12 @@ struct LongScanBufs {   // scratch of the scan launcher beyond the part tables
   bool clr_fused;                          // CLR, read-shaped scan: the gate is computed inside the scan (flags arrive ungated)
   uint64_t* lbw; uint32_t epoch;           // look-back words of the placement kernel's scan (3 per block of parts), and this run's epoch
   void* prec;                              // long-record scan: {location, descriptors} of every part's last batch
-  void* fused_rows; SlimOut so;            // long-record scan: place the rows here (the stage-1 input table) with their elements, not in `raw`
+  void* fused_rows; SlimOut so;            // place the rows here (the stage-1 input table) with their elements, not in `raw`
+  bool skip_batches;                       // no launch for the overflow batches: the handle's last runs filed none (Counters::pad[0] tells whether this one did)
 };
 void vsv_launch_place(hipStream_t st, const RecView& rv, const vsv_params& p, int n_parts, vsv_sig* pool, uint64_t* pool_key, uint32_t cap, uint32_t* part_count,
-                      uint32_t* part_off, vsv_sig* rows, Counters* ctr, uint32_t* shard_cnt, const LongScanBufs& lb, uint32_t epoch, const SlimOut& so);
+                      uint32_t* part_off, vsv_sig* rows, Counters* ctr, uint32_t* shard_cnt, const LongScanBufs& lb, uint32_t epoch, const SlimOut& so,
+                      bool with_batches = true);
 int vsv_scan_parts(const RecView& rv, const vsv_params& p, int ops_per_part);
 size_t vsv_lookback_bytes(int64_t n_ops, int ops_per_part);
 bool vsv_scan_is_long(const RecView& rv, const vsv_params& p);
@@ -195,11 +239,16 @@ struct SplitSorted {      // candidates by name / pairs by record
   bool live_only = false;   // the slot sort dropped the dead slots: Counters::n_pairs live ones, in front (else n_cand slots, dead ones behind)
 };
 struct CandBufs { void* cinfo; uint32_t* cord; uint32_t* oc1; };     // 32 / 4 / 4 bytes per candidate (null: the record arrays are gathered per pair)
+struct CandLb {              // the two scans inside the candidate kernels: look-back words (one per 2048 records each), this run's epoch, and
+  uint64_t* qwords; uint64_t* cwords; uint32_t epoch;      // the name table of the NEXT run, which this run's kernel clears (its first
+  uint32_t* tab_next; uint32_t clear_words;                 // clear_words words: what the run before the last left in it)
+};
 SplitSorted vsv_launch_split_candidates(hipStream_t st, const RecView& rv, const vsv_params& p, int n_tids, uint32_t* tab, uint32_t tab_size,
                                         uint32_t* blk_cnt, uint32_t* blk_off, uint32_t* scan_tmp, uint64_t* ckey, uint32_t* crec,
                                         uint64_t* okey, uint32_t* oval, uint64_t* key2, uint32_t* idx2, const SortWork& sw,
                                         uint32_t cap, Counters* ctr, uint8_t* cmask, int grid, const struct SlimWork* slim = nullptr,
-                                        const CandBufs& cb = CandBufs{nullptr, nullptr, nullptr}, int phase = 0);
+                                        const CandBufs& cb = CandBufs{nullptr, nullptr, nullptr}, int phase = 0,
+                                        const CandLb& lb = CandLb{nullptr, nullptr, 0, nullptr, 0});
 void vsv_launch_split_eval(hipStream_t st, const RecView& rv, const vsv_params& p, int n_tids, const SplitSorted& so, vsv_sig* s1in,
                            uint32_t cap, Counters* ctr, int grid, const SlimOut& sl = SlimOut{nullptr, 0, 0, 0, nullptr});
 // returns the sorted key array (kept for the cluster / pair kernel that follows)
