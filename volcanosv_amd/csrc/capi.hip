@@ -270,7 +270,9 @@ int bind_records(vsv_handle* h, const vsv_records* r) {
 
 constexpr int MAX_SORT_PASSES = 64;
 constexpr int MAX_GROUP_SLOTS = 8;      // bucket sorts of one run that may skip their scan launch (a contig run has 6-7)
-SortWork sort_work(vsv_handle* h) {
+// table_rows >= 0: a sort of a table of about that many rows, whatever the handle's largest table is (the few thousand split candidates
+// of a contig pile whose signature tables hold millions)
+SortWork sort_work(vsv_handle* h, int64_t table_rows = -1) {
   SortWork w;
   w.key_alt = (uint64_t*)h->key_alt.p; w.val_alt = (uint32_t*)h->val_alt.p; w.hist = (uint32_t*)h->hist.p; w.max_items = h->cap_sigs;
   w.totals = (uint32_t*)h->totals.p; w.pass_cursor = &h->pass_cursor; w.max_passes = MAX_SORT_PASSES; w.small_tiles = h->small_sort_tiles;
@@ -281,13 +283,14 @@ SortWork sort_work(vsv_handle* h) {
   // handle whose last bucket sort overflowed, and VSV_SORT=lsd take the LSD passes
   static const char* mode = vsv_dbg_env("VSV_SORT");
   const Counters& c = h->host_ctr;
-  const uint64_t rows = c.n_s1 > c.n_cand ? c.n_s1 : c.n_cand;
+  const uint64_t rows = table_rows >= 0 ? (uint64_t)table_rows : (c.n_s1 > c.n_cand ? c.n_s1 : c.n_cand);
+  if (table_rows >= 0 && !force) w.small_tiles = rows <= 128u * 4096u;
   static const int per_bucket = vsv_dbg_env("VSV_BK_ROWS") ? atoi(vsv_dbg_env("VSV_BK_ROWS")) : 640;     // timing experiments
   int bb = 8;
   while (bb < 11 && (rows >> bb) > (uint64_t)per_bucket) ++bb;
   // (a handle's first run knows no row count: LSD passes rather than a guess that overflows and repeats the run)
   w.bucket_bits = (h->lsd_runs > 0 || rows == 0 || (mode && mode[0] == 'l') || (rows >> 11) > 640) ? 0 : bb;
-  h->sort_hint_rows = rows;
+  if (table_rows < 0) h->sort_hint_rows = rows;
   w.hint_rows = rows;
   w.shared_gpu = h->prm.split_overlap == VSV_OVERLAP_OFF;
   w.groups = h->groups; w.group_cursor = &h->group_cursor; w.max_group_slots = MAX_GROUP_SLOTS;
@@ -365,7 +368,11 @@ int cand_alloc(vsv_handle* h) {
 }
 int enq_split_candidates(vsv_handle* h, hipStream_t st, int phase = 0) {
   SlimWork w;
-  const bool slim = h->big_run && is_contig(h->prm.dtype);     // (a large-table run: the candidate tables are large too)
+  // a large-table run: the candidate tables are usually large too (config 3: 10^7) — unless the handle knows better: the contig pile
+  // has a few thousand split candidates, which the bucket sort of small tables orders in 6 launches where the element passes take 20
+  const uint64_t ncand = h->host_ctr.n_cand;
+  const bool few = h->big_run && ncand != 0 && ((ncand + ncand / 4) >> 11) <= 640;
+  const bool slim = h->big_run && is_contig(h->prm.dtype) && !few;
   CandBufs cb{nullptr, nullptr, nullptr};
   if (slim) {
     int ws = slim_work(h, w); if (ws) return ws;
@@ -396,7 +403,8 @@ int enq_split_candidates(vsv_handle* h, hipStream_t st, int phase = 0) {
   DevBuf& tcur = cur ? h->tab2 : h->tab;
   h->split_sorted = vsv_launch_split_candidates(st, h->rv, h->prm, h->n_tids, (uint32_t*)tcur.p, h->tab_size, (uint32_t*)h->blk_cnt.p,
                                                 (uint32_t*)h->blk_off.p, (uint32_t*)h->scan_tmp2.p, (uint64_t*)h->ckey.p, (uint32_t*)h->crec.p,
-                                                (uint64_t*)h->okey.p, (uint32_t*)h->oval.p, (uint64_t*)h->key2.p, (uint32_t*)h->idx2.p, sort_work(h),
+                                                (uint64_t*)h->okey.p, (uint32_t*)h->oval.p, (uint64_t*)h->key2.p, (uint32_t*)h->idx2.p,
+                                                few ? sort_work(h, (int64_t)(ncand + ncand / 4)) : sort_work(h),
                                                 (uint32_t)h->cap_sigs, dctr(h), (uint8_t*)h->cmask.p, ew_grid(h), slim ? &w : nullptr, cb, phase, clb);
   HIPCHK(h, hipGetLastError());
   h->split_cands_done = phase != 1;
