@@ -774,6 +774,49 @@ def test_dense_runs_use_the_wave_cooperative_kernels(eng):
         e.close()
 
 
+def test_overflow_batches_after_runs_without_any():
+    """A part of the scan sends its rows as one batch when it has streamed its ops; a part with more rows than its stage holds (32
+    rows read-shaped, 192 descriptors long-record) files the batches in front of the last one in an overflow list, placed by a
+    launch of its own — which a handle skips while its runs file none. A handle that has only seen sparse input and then meets
+    insertions packed into every read (hundreds of rows per 4096-op part) repeats that ONE run with the launch (vsv_rerun_count),
+    keeps it for the next runs, and its tables equal the oracle's throughout. Both scan layouts."""
+    from volcanosv_amd import synth
+    from volcanosv_amd.abi import SCAN_CONTIGS, SCAN_READS
+    from volcanosv_amd.engine import Engine, default_params
+    from volcanosv_amd.soa import RecordSoA
+    t, nq, _ = synth.generate(20000, "hifi", seed=31, chrom_len=2_000_000, events_per_record=0.05, site_step=1000)
+    sparse = synth.to_soa(t, nq)
+    recs = []
+    for i in range(600):                                    # 40 insertions of 60-99 bp per read of 81 ops, 150 bp apart
+        cig = [(0, 200)]
+        for k in range(40):
+            cig += [(1, 60 + (i + k) % 40), (0, 150)]
+        recs.append((0, 1000 + 37 * i, "d%d_hp%d" % (i, 1 + i % 2), 60, False, cig))
+    dense = RecordSoA.from_tuples(recs)
+    dense.max_pos = 1 << 20
+    for layout in (SCAN_READS, SCAN_CONTIGS):
+        p = default_params(DTYPE_HIFI)
+        p.scan_layout = layout
+        st, want_s = oracle_run(sparse, DTYPE_HIFI, p)
+        st2, want_d = oracle_run(dense, DTYPE_HIFI, p)
+        assert st == 0 and st2 == 0 and len(want_d["raw"]) == 600 * 40
+        with Engine(0) as e:
+            for _ in range(2):
+                e.run(sparse, p)
+                assert_tables_equal(e.tables(DTYPE_HIFI), want_s, list(want_s.keys())[:6])
+            assert e.rerun_count() == 0
+            e.run(dense, p)
+            got = e.tables(DTYPE_HIFI)
+            assert_tables_equal(got, want_d, list(got.keys()))
+            n = e.rerun_count()
+            assert n in (1, 2), n       # the batches (a 4096-op part holds ~2000 of these rows, an 8192-op one ~4000) — and the sort buckets, sized for the sparse tables
+            e.run(dense, p)
+            assert_tables_equal(e.tables(DTYPE_HIFI), want_d, list(got.keys()))
+            assert e.rerun_count() == n                              # the handle keeps the launch now
+            e.run(sparse, p)
+            assert_tables_equal(e.tables(DTYPE_HIFI), want_s, list(want_s.keys())[:6])
+
+
 def test_config4_shape_22_chromosomes(eng):
     """BASELINE config 4 in miniature: 22 tids with records on every one of them (hg19-ordered lengths scaled down) through the
     HIP path — (a) the whole multi-chromosome SoA in one call against the oracle, (b) sharded like bench.py --config 4 / the WGS
