@@ -216,6 +216,11 @@ int vsv_finish(vsv_handle* h);
  * scan (repeated with the separate gate pass). Results are identical either way; a bench line reports the count so that a hidden
  * repetition inside a timed region is visible. */
 int64_t vsv_rerun_count(vsv_handle* h);
+/* Measurement aid: runs of this handle whose first sort on 16-byte elements (one counting pass into position buckets + an LDS sort per
+ * bucket) met a bucket too large for LDS — a pile far from uniform over the chromosome, or a size hint that was stale. Such a bucket
+ * is sorted in global memory by the same launch (slower, same result: no repetition) and the handle's next runs take the LSD radix
+ * passes for that sort. */
+int64_t vsv_sort1_slow_count(vsv_handle* h);
 /* Measurement aid: which form of the stages behind the split stage the handle's runs took, and whether a cold handle had to wait.
  * element_runs: runs (or staged vsv_sort_cluster calls) whose sort / cluster / merge / pair stages worked on 16-byte elements — the
  * form for tables beyond ~1.3 M rows (10^6-10^7: contig alignments piled on one chromosome, ONT-scale read sets); the others took

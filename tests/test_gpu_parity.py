@@ -1286,6 +1286,61 @@ def test_element_path_on_the_parity_cases(slim_sort):
     assert " passed" in tail and "failed" not in tail and int(tail.split(" passed")[0].split()[-1]) >= need, tail
 
 
+@pytest.mark.parametrize("form", ["lds", "global"])
+def test_first_element_sort_in_position_buckets(form):
+    """The first sort of the element path: one counting pass into ~2000 position buckets (a monotone map of the stage-1 key: list pair,
+    then cigar / split list, then position up to the max_pos hint) + a complete sort of every bucket, in LDS where it fits
+    (sl_bucket_lds) and by the same passes in global memory where it does not (sl_bucket_global: same result, slower; the handle then
+    takes the LSD passes for a while and vsv_sort1_slow_count reports it). `global` lowers the LDS limit to 4 elements
+    (VSV_SORT1_CAP), so nearly every bucket takes that form. Shapes: HiFi-like reads on a 2 Mb chromosome (cigar and split lists), two
+    chromosomes with key hints, and 12000 reads whose insertions start within 60 bp — one bucket holds them all, beyond the real LDS
+    limit in both forms. Tables equal the oracle's; a second run (on the passes after a slow bucket) too."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "from test_gpu_parity import oracle_run, assert_tables_equal\n"
+            "from volcanosv_amd import synth\n"
+            "from volcanosv_amd.soa import RecordSoA\n"
+            "from volcanosv_amd.engine import Engine, default_params\n"
+            "from volcanosv_amd.abi import DTYPE_HIFI\n"
+            "p = default_params(DTYPE_HIFI)\n"
+            "slow = []\n"
+            "def check(soa, name):\n"
+            "    st, want = oracle_run(soa, DTYPE_HIFI, p)\n"
+            "    assert st == 0 and len(want['calls']) > 50, name\n"
+            "    with Engine(0) as e:\n"
+            "        for rep in range(2):\n"
+            "            e.run(soa, p)\n"
+            "            got = e.tables(DTYPE_HIFI)\n"
+            "            assert_tables_equal(got, want, list(got.keys()))\n"
+            "            if rep == 0: slow.append(e.sort1_slow_count())\n"
+            "        assert e.path_counts()[0] >= 2, name\n"
+            "t, nq, _ = synth.generate(60000, 'hifi', seed=77, chrom_len=2000000, events_per_record=0.5, site_step=700)\n"
+            "a = synth.to_soa(t, nq); a.max_pos = 2200000\n"
+            "check(a, 'reads')\n"
+            "parts = [synth.generate(20000, 'hifi', seed=78 + c, tid=c, chrom_len=1500000, events_per_record=0.5, site_step=900) for c in range(2)]\n"
+            "t2, nq2 = synth.concat([(x[0], x[1]) for x in parts])\n"
+            "b = synth.to_soa(t2, nq2); b.max_pos = 1700000; b.n_tids = 2\n"
+            "check(b, 'two chromosomes')\n"
+            "recs = [(0, 100000 + (i %% 50), 'q%%d_hp%%d' %% (i, 1 + i %% 2), 60, False, [(0, 500), (1, 60 + i %% 9), (0, 700)]) for i in range(12000)]\n"
+            "recs += [(0, 300000 + 997 * i, 'r%%d_hp%%d' %% (i, 1 + i %% 2), 60, False, [(0, 400), (2, 80 + i %% 5), (0, 300)]) for i in range(300)]\n"
+            "recs.sort(key=lambda r: r[1])\n"
+            "c = RecordSoA.from_tuples(recs); c.max_pos = 1 << 20\n"
+            "check(c, 'pile')\n"
+            "print('BUCKETS_OK', *slow)\n") % (root, os.path.join(root, "tests"))
+    env = dict(os.environ, VSV_DEBUG="1", VSV_BIG="1")
+    if form == "global":
+        env["VSV_SORT1_CAP"] = "4"
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0 and "BUCKETS_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+    slow = [int(x) for x in r.stdout.strip().splitlines()[-1].split()[1:]]
+    assert slow[2] == 1                                   # the pile: one bucket beyond LDS whatever the limit
+    assert slow[:2] == ([1, 1] if form == "global" else [0, 0])
+
+
 def test_rank_and_merge_sort_gives_up_on_a_pile_inside_one_shift():
     """sl_merge_sort ranks an element against the slots whose anchors lie within one shift of its key, from an LDS window of 2048 + 2 x 128
     slots. 8000 reads whose insertions all start within 90 bp — one cluster per haplotype whose representative (the first longest

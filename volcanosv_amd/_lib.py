@@ -17,7 +17,7 @@ _lib = None
 
 # every symbol include/volcanosv.h declares
 SYMBOLS = [
-    "vsv_abi_version", "vsv_status_string", "vsv_create", "vsv_destroy", "vsv_bam_device_want_sa", "vsv_bam_device_sa_tags", "vsv_bam_device_want_seq", "vsv_bam_device_seq_slices", "vsv_stream_ceiling", "vsv_bgzf_set_expected_crc", "vsv_last_error", "vsv_last_count", "vsv_rerun_count", "vsv_path_counts", "vsv_reserve_large_tables",
+    "vsv_abi_version", "vsv_status_string", "vsv_create", "vsv_destroy", "vsv_bam_device_want_sa", "vsv_bam_device_sa_tags", "vsv_bam_device_want_seq", "vsv_bam_device_seq_slices", "vsv_stream_ceiling", "vsv_bgzf_set_expected_crc", "vsv_last_error", "vsv_last_count", "vsv_rerun_count", "vsv_sort1_slow_count", "vsv_path_counts", "vsv_reserve_large_tables",
     "vsv_default_params", "vsv_reserve", "vsv_wait_for_stream", "vsv_cutesv_split_tra", "vsv_cigar_scan", "vsv_split_pairs", "vsv_sort_cluster", "vsv_merge_sources",
     "vsv_pair_haplotypes", "vsv_run_chromosome", "vsv_run_chromosome_async", "vsv_finish", "vsv_table_count",
     "vsv_table_fill", "vsv_last_scan_ms", "vsv_default_bnd_params", "vsv_bnd_segments", "vsv_bnd_pair", "vsv_bnd_set_candidates",
@@ -58,6 +58,8 @@ def load():
     lib.vsv_last_count.restype = C.c_int64
     lib.vsv_rerun_count.argtypes = [H]
     lib.vsv_rerun_count.restype = C.c_int64
+    lib.vsv_sort1_slow_count.argtypes = [H]
+    lib.vsv_sort1_slow_count.restype = C.c_int64
     lib.vsv_path_counts.argtypes = [H, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.vsv_reserve_large_tables.argtypes = [H]
     lib.vsv_default_params.argtypes = [C.c_int, C.POINTER(Params)]
@@ -100,7 +102,7 @@ def load():
     lib.vsv_support_join.argtypes = [H, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(SupportParams),
                                      C.c_int, C.c_void_p]
     for name in SYMBOLS:
-        if name not in ("vsv_destroy", "vsv_last_error", "vsv_last_count", "vsv_rerun_count", "vsv_status_string") and not name.startswith("vsv_bam"):
+        if name not in ("vsv_destroy", "vsv_last_error", "vsv_last_count", "vsv_rerun_count", "vsv_sort1_slow_count", "vsv_status_string") and not name.startswith("vsv_bam"):
             getattr(lib, name).restype = C.c_int
     B = C.c_void_p
     lib.vsv_bam_open.argtypes = [C.c_char_p, C.POINTER(B)]

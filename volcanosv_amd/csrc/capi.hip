@@ -83,6 +83,8 @@ struct vsv_handle {
   bool dense_pairing = false;      // the last run walked a pairing stretch of thousands of rows with one wave: pair in rounds
   bool in_rerun = false;
   int row_runs = 0;                // > 0: an input met the 32-bit limits of the element path recently: the next runs stay on rows
+  int lsd_sort1_runs = 0;          // > 0: a bucket of the element path's first sort did not fit in LDS recently (ERRB_BUCKET1_SLOW): the next runs sort 1 with the LSD passes
+  int64_t sort1_slow_runs = 0;     // runs whose first sort met a bucket too large for LDS (vsv_path_counts)
   int lsd_slim_runs = 0;           // > 0: a rank-and-merge sort of the element path gave up recently (ERRB_MERGE_FALLBACK): the next runs sort with the LSD passes
   const void* sl_sorted1 = nullptr; // element path: the sorted stage-1 table (anchors of the sort behind its clusters)
   void* sl_ctl2 = nullptr;          // ... and that sort's control slot (its tile counts come from the stage-1 cluster kernel)
@@ -416,6 +418,7 @@ int enq_scan(vsv_handle* h) {
   if (h->lsd_runs > 0 && !h->in_rerun) --h->lsd_runs;
   if (h->row_runs > 0 && !h->in_rerun) --h->row_runs;
   if (h->lsd_slim_runs > 0 && !h->in_rerun) --h->lsd_slim_runs;
+  if (h->lsd_sort1_runs > 0 && !h->in_rerun) --h->lsd_sort1_runs;
   if (h->batch_runs > 0 && !h->in_rerun) --h->batch_runs;
   h->cutesv_rows = -1;   // the split-candidate table shares a buffer with the merge stage
   h->ctr_of_run = false;
@@ -566,6 +569,12 @@ int slim_work(vsv_handle* h, SlimWork& w) {
   w.grid = ew_grid(h); w.cl = (int32_t*)h->cl.p; w.hj = (uint32_t*)h->sl_hj.p; w.done1 = (uint32_t*)h->sl_done.p;
   static const char* sort_mode = vsv_dbg_env("VSV_SLIM_SORT");      // tests / timing: "lsd" = the LSD passes for every sort of the element path
   w.merge_sorts = h->lsd_slim_runs == 0 && !(sort_mode && sort_mode[0] == 'l');
+  w.bucket_sort1 = h->lsd_sort1_runs == 0 && !(sort_mode && sort_mode[0] == 'l');
+  {  // share of split-list elements: pair slots of the previous run, or — a cold handle knows its candidates only — half of those (a slot takes two)
+    const Counters& c = h->host_ctr;
+    const double pairs = c.n_pairs ? (double)c.n_pairs : 0.5 * (double)c.n_cand, rows = (double)c.n_raw + pairs;
+    w.split_share = rows > 0 ? pairs / rows : 0.05;
+  }
   w.err = &dctr(h)->err;
   return 0;
 }
@@ -670,6 +679,8 @@ int finish(vsv_handle* h) {
   }
   // (the rows of a contig run always get their elements; their 32-bit limits matter only to a run whose stages worked on them)
   if (!h->big_run) h->host_ctr.err &= ~(uint32_t)ERRB_SLIM_FALLBACK;
+  // a bucket of sort 1 went through global memory (correct, slow: a pile far from uniform, or a stale size hint): the passes for a while
+  if (h->host_ctr.err & ERRB_BUCKET1_SLOW) { h->lsd_sort1_runs = 16; ++h->sort1_slow_runs; h->host_ctr.err &= ~(uint32_t)ERRB_BUCKET1_SLOW; }
   const uint32_t e = h->host_ctr.err;
   h->last_count = h->host_ctr.n_pool;
   static const char* trace = vsv_dbg_env("VSV_TRACE_COUNTERS");
@@ -876,6 +887,7 @@ int vsv_path_counts(vsv_handle* h, int64_t* element_runs, int64_t* cold_syncs) {
   if (cold_syncs) *cold_syncs = h->cold_syncs;
   return 0;
 }
+int64_t vsv_sort1_slow_count(vsv_handle* h) { return h ? h->sort1_slow_runs : 0; }
 
 int vsv_wait_for_stream(vsv_handle* h, void* producer_hip_stream) {
   if (!h) return VSV_E_INVALID;

@@ -156,6 +156,56 @@ struct KeyCmp {
   }
 };
 
+// the digit a pass sorts on: a bit field of the (squeezed) key for the LSD passes, or — the first sort's one counting pass in front
+// of its LDS sort per bucket — a monotone map of the whole stage-1 key onto contiguous buckets (sl_bucket_sort1 below)
+struct LsdDigit {
+  int shift; KeyCmp kc; uint32_t mask;
+  __device__ __forceinline__ LsdDigit prep() const { return *this; }
+  __device__ __forceinline__ uint32_t operator()(uint64_t key) const { return (uint32_t)(kc(key) >> shift) & mask; }
+};
+// list pair p = key >> (pb + 1) owns buckets [p << bp_log, (p + 1) << bp_log): b0 for its cigar list, nb1 for its split list, each cut
+// into equal position ranges between the smallest and the largest position the table holds (mm[0] = max kpos, mm[1] = max ~kpos:
+// sl_minmax) — a shard that covers a part of its chromosome, or contigs that reach beyond the max_pos hint, fill all buckets alike
+struct MsdPrepared {
+  int pb, bp_log; uint32_t b0, nb1, mul0, mul1, kmin;
+  __device__ __forceinline__ uint32_t operator()(uint64_t key) const {
+    const uint32_t list = (uint32_t)(key >> pb), src = list & 1u;
+    const uint32_t kp = ((uint32_t)key & ((1u << pb) - 1u)) - kmin;
+    uint32_t b = (uint32_t)(((uint64_t)kp * (src ? mul1 : mul0)) >> 32);
+    const uint32_t nb = src ? nb1 : b0;
+    b = b < nb ? b : nb - 1u;
+    return ((list >> 1) << bp_log) + (src ? b0 : 0u) + b;
+  }
+};
+struct MsdDigit {
+  int pb, bp_log; uint32_t b0, nb1; const uint32_t* mm;
+  __device__ __forceinline__ MsdPrepared prep() const {
+    const uint32_t kmax = mm[0], kmin = ~mm[1];
+    const uint64_t range = kmax >= kmin ? (uint64_t)(kmax - kmin) + 1u : 1u;        // (no live element: nothing is mapped)
+    // floor(b << 32 / range) as a 32-bit multiplier; a range smaller than the bucket count maps one position per bucket
+    const uint64_t m0 = ((uint64_t)b0 << 32) / range, m1 = ((uint64_t)nb1 << 32) / range;
+    return MsdPrepared{pb, bp_log, b0, nb1, m0 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)m0, m1 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)m1, kmin};
+  }
+};
+
+// mm[0] = max kpos, mm[1] = max ~kpos over the live elements (both words zeroed with the run's sort scratch)
+__global__ __launch_bounds__(256) void sl_minmax(const Slim* __restrict__ e, const uint32_t* __restrict__ d_n, int pb, uint32_t* __restrict__ mm) {
+  __shared__ uint32_t s_hi, s_lo;
+  const uint32_t n = *d_n, pmask = (1u << pb) - 1u;
+  if (threadIdx.x == 0) { s_hi = 0; s_lo = 0; }
+  __syncthreads();
+  uint32_t hi = 0, lo = 0;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+    const uint64_t k = e[i].key;
+    if (k != VSV_KEY_DEAD) { const uint32_t kp = (uint32_t)k & pmask; hi = max(hi, kp); lo = max(lo, ~kp); }
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) { hi = max(hi, (uint32_t)__shfl_xor((int)hi, d, 64)); lo = max(lo, (uint32_t)__shfl_xor((int)lo, d, 64)); }
+  if ((threadIdx.x & 63) == 0) { atomicMax(&s_hi, hi); atomicMax(&s_lo, lo); }
+  __syncthreads();
+  if (threadIdx.x == 0) { if (s_hi) atomicMax(&mm[0], s_hi); if (s_lo) atomicMax(&mm[1], s_lo); }
+}
+
 template <int BITS>
 __device__ __forceinline__ uint64_t sl_match_digit(uint32_t d, bool valid) {
   uint64_t m = __ballot(valid);
@@ -169,11 +219,12 @@ __device__ __forceinline__ uint64_t sl_match_digit(uint32_t d, bool valid) {
 __device__ __forceinline__ uint32_t sl_tiles(uint32_t n) { return (n + SL_TILE - 1) / SL_TILE; }
 
 // hist[tile][d] = elements of the tile with digit d (dead elements of a first pass do not count); totals[d] += the same
-template <int BITS, typename SRC, bool SKIP_DEAD, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void sl_hist(SRC src, const uint32_t* __restrict__ d_n, int shift, KeyCmp kc, uint32_t* __restrict__ hist, uint32_t* __restrict__ totals) {
+template <int BITS, typename SRC, bool SKIP_DEAD, int WAVES, typename DIG>
+__global__ __launch_bounds__(WAVES * 64) void sl_hist(SRC src, const uint32_t* __restrict__ d_n, DIG dig_, uint32_t* __restrict__ hist, uint32_t* __restrict__ totals) {
   constexpr int BINS = 1 << BITS, T = WAVES * 64;
   __shared__ uint32_t cnt[BINS];
   const uint32_t n = *d_n, ntiles = sl_tiles(n);
+  const auto dig = dig_.prep();
   for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     for (int d = threadIdx.x; d < BINS; d += T) cnt[d] = 0;
     __syncthreads();
@@ -183,7 +234,7 @@ __global__ __launch_bounds__(WAVES * 64) void sl_hist(SRC src, const uint32_t* _
       const uint32_t i = base + k * T + threadIdx.x;
       if (i < n) {
         const uint64_t key = src.at(i).key;
-        if (!SKIP_DEAD || key != VSV_KEY_DEAD) atomicAdd(&cnt[(uint32_t)(kc(key) >> shift) & (BINS - 1)], 1u);
+        if (!SKIP_DEAD || key != VSV_KEY_DEAD) atomicAdd(&cnt[dig(key)], 1u);
       }
     }
     __syncthreads();
@@ -261,11 +312,12 @@ __global__ __launch_bounds__(1024) void sl_scan(uint32_t* __restrict__ hist, con
 }
 
 // stable scatter of one pass: ranks inside a wave from ballot matches, per-wave running counters in LDS (as rs_scatter)
-template <int BITS, typename SRC, bool SKIP_DEAD, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void sl_scatter(SRC src, const uint32_t* __restrict__ d_n, int shift, KeyCmp kc, const uint32_t* __restrict__ hist, Slim* __restrict__ out) {
+template <int BITS, typename SRC, bool SKIP_DEAD, int WAVES, typename DIG>
+__global__ __launch_bounds__(WAVES * 64) void sl_scatter(SRC src, const uint32_t* __restrict__ d_n, DIG dig_, const uint32_t* __restrict__ hist, Slim* __restrict__ out) {
   constexpr int BINS = 1 << BITS, T = WAVES * 64, ROUNDS = (int)SL_TILE / T;
   __shared__ uint32_t wcnt[WAVES][BINS];
   const uint32_t n = *d_n, ntiles = sl_tiles(n);
+  const auto dig = dig_.prep();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint64_t lt = (1ull << lane) - 1ull;
   for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -282,7 +334,7 @@ __global__ __launch_bounds__(WAVES * 64) void sl_scatter(SRC src, const uint32_t
       bool ok = i < n;
       if (ok) e_[r] = src.at(i); else e_[r] = dead_slim();
       if (SKIP_DEAD) ok = ok && e_[r].key != VSV_KEY_DEAD;
-      const uint32_t d = (uint32_t)(kc(e_[r].key) >> shift) & (BINS - 1);
+      const uint32_t d = ok ? dig(e_[r].key) : 0u;
       const uint64_t m = sl_match_digit<BITS>(d, ok);
       const uint32_t old = ok ? wcnt[wv][d] : 0;
       __builtin_amdgcn_wave_barrier();
@@ -300,7 +352,7 @@ __global__ __launch_bounds__(WAVES * 64) void sl_scatter(SRC src, const uint32_t
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
       if (rk[r] != 0xFFFFFFFFu) {
-        const uint32_t d = (uint32_t)(kc(e_[r].key) >> shift) & (BINS - 1);
+        const uint32_t d = dig(e_[r].key);
         st_slim(out + wcnt[wv][d] + rk[r], e_[r]);
       }
     }
@@ -1053,11 +1105,12 @@ __global__ __launch_bounds__(256) void sl_rows_out(const Slim* __restrict__ e, u
 // ---- host side ---------------------------------------------------------------------------------------------------------------------
 template <int BITS, typename SRC, bool SKIP>
 void sl_pass(hipStream_t st, SRC src, const uint32_t* d_n, int shift, KeyCmp kc, Slim* out, uint32_t* hist, uint32_t* totals, uint32_t* d_total, int grid, bool wide) {
-  if (wide) sl_hist<BITS, SRC, SKIP, 16><<<grid, 1024, 0, st>>>(src, d_n, shift, kc, hist, totals);
-  else sl_hist<BITS, SRC, SKIP, 4><<<grid, 256, 0, st>>>(src, d_n, shift, kc, hist, totals);
+  const LsdDigit dig{shift, kc, (1u << BITS) - 1u};
+  if (wide) sl_hist<BITS, SRC, SKIP, 16><<<grid, 1024, 0, st>>>(src, d_n, dig, hist, totals);
+  else sl_hist<BITS, SRC, SKIP, 4><<<grid, 256, 0, st>>>(src, d_n, dig, hist, totals);
   sl_scan<BITS><<<(1 << BITS) / 16, 1024, 0, st>>>(hist, totals, d_n, d_total);
-  if (wide) sl_scatter<BITS, SRC, SKIP, 16><<<grid, 1024, 0, st>>>(src, d_n, shift, kc, hist, out);
-  else sl_scatter<BITS, SRC, SKIP, 4><<<grid, 256, 0, st>>>(src, d_n, shift, kc, hist, out);
+  if (wide) sl_scatter<BITS, SRC, SKIP, 16><<<grid, 1024, 0, st>>>(src, d_n, dig, hist, out);
+  else sl_scatter<BITS, SRC, SKIP, 4><<<grid, 256, 0, st>>>(src, d_n, dig, hist, out);
 }
 
 // Stable sort of the live elements of `src` (n slots, *d_slots) by key bits [0, nbits): the first pass skips dead elements and
@@ -1102,6 +1155,164 @@ Slim* sl_sort(hipStream_t st, SRC src, const uint32_t* d_slots, uint32_t* d_live
   return other;        // the buffer the last pass wrote
 }
 
+
+// ---- the FIRST sort: one counting pass into position buckets + an LDS sort per bucket ----------------------------------------------
+// The stage-1 elements arrive in (record, op) order, and a coordinate-sorted BAM's records ascend by position: a tile of 4096 of them
+// lies within a few megabases, i.e. in a handful of the ~2000-4000 buckets a monotone map cuts the populated key range into — a list
+// pair (tid, hap, type) owns 2^bp_log consecutive buckets, most of them for its cigar list, the others for its split list (by the
+// share of split elements the handle expects), equally wide in position between the smallest and the largest position the table
+// holds (sl_minmax: one read of the keys). So ONE stable counting pass (the kernels of the LSD passes with that map as the digit)
+// writes long contiguous pieces, and every bucket — one list, a position range — is then sorted completely in LDS by position (keys
+// relative to the bucket's minimum, stable passes of <= 9 bits) and written in order: five launches that move the table twice, where
+// the four 8-bit passes take twelve and move it eight times. A bucket of more than SB_CAP elements (a
+// pile far from uniform, a stale size hint) is sorted by the same block with the same passes on the elements themselves, ping-pong
+// between the bucket's own ranges of the two buffers (sl_bucket_global: correct whatever the bucket holds, slow), and raises
+// ERRB_BUCKET1_SLOW: no table is ever left unsorted, the handle just takes the LSD passes for its next runs.
+constexpr int SB_CAP = 4096, SB_DBITS = 9;
+
+// digit totals of the waves' chunks (wcnt[w][d], counted) -> first destination of every (wave, digit): digits ascending, waves
+// ascending inside a digit (wave-major chunks: the input order inside equal digits is kept). Called by the whole block.
+template <int SB_THREADS>
+__device__ __forceinline__ void sb_bases(uint32_t (*wcnt)[1 << SB_DBITS], uint32_t* tot, uint32_t nbins) {
+  constexpr int SB_WAVES = SB_THREADS / 64;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  uint32_t mine = 0, incl = 0;
+  if ((uint32_t)t < nbins) {
+#pragma unroll
+    for (int w = 0; w < SB_WAVES; ++w) mine += wcnt[w][t];
+  }
+  incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += o; }
+  if (lane == 63) tot[wv] = incl;
+  __syncthreads();
+  if ((uint32_t)t < nbins) {
+    uint32_t run = incl - mine;
+    for (int w = 0; w < wv; ++w) run += tot[w];
+#pragma unroll
+    for (int w = 0; w < SB_WAVES; ++w) { const uint32_t c = wcnt[w][t]; wcnt[w][t] = run; run += c; }
+  }
+  __syncthreads();
+}
+
+// a bucket too large for LDS: the passes on global memory, a = the bucket's range of the counting pass's output (consumed),
+// b = its range of the sorted table. Block-uniform arguments; any m.
+template <int SB_THREADS>
+__device__ void sl_bucket_global(Slim* __restrict__ a, Slim* __restrict__ b, uint32_t m, uint32_t pmask, uint32_t kmin, uint32_t kmax,
+                                 uint32_t (*wcnt)[1 << SB_DBITS], uint32_t* tot) {
+  constexpr int SB_WAVES = SB_THREADS / 64;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const uint32_t width = kmax - kmin;
+  Slim* src = a; Slim* dst = b;
+  if (width != 0) {
+    const int wbits = 32 - __builtin_clz(width);
+    const int passes = (wbits + SB_DBITS - 1) / SB_DBITS;
+    const int db = (wbits + passes - 1) / passes;
+    const uint32_t dmask = (1u << db) - 1u, nbins = 1u << db;
+    const uint32_t per = ((m + SB_WAVES - 1) / SB_WAVES + 63u) & ~63u;
+    const uint32_t c0 = min(m, (uint32_t)wv * per), c1 = min(m, c0 + per);
+    const uint64_t lt = (1ull << lane) - 1ull;
+    for (int pass = 0, shift = 0; pass < passes; ++pass, shift += db) {
+      for (uint32_t d = t; d < SB_WAVES * nbins; d += SB_THREADS) wcnt[d / nbins][d % nbins] = 0;
+      __syncthreads();
+      for (uint32_t i = c0 + lane; i < c1; i += 64) atomicAdd(&wcnt[wv][((((uint32_t)src[i].key & pmask) - kmin) >> shift) & dmask], 1u);
+      __syncthreads();
+      sb_bases<SB_THREADS>(wcnt, tot, nbins);
+      for (uint32_t i0 = c0; i0 < c1; i0 += 64) {            // whole waves iterate together (c0, c1 are wave-uniform)
+        const uint32_t i = i0 + lane;
+        const bool ok = i < c1;
+        Slim e = dead_slim();
+        if (ok) e = ld_slim(src + i);
+        const uint32_t d = ok ? ((((uint32_t)e.key & pmask) - kmin) >> shift) & dmask : 0u;
+        uint64_t mm = __ballot(ok);
+        for (int bit = 0; bit < db; ++bit) { const uint64_t bal = __ballot((d >> bit) & 1u); mm &= ((d >> bit) & 1u) ? bal : ~bal; }
+        const uint32_t old = ok ? wcnt[wv][d] : 0u;
+        __builtin_amdgcn_wave_barrier();
+        if (ok && (mm & lt) == 0) wcnt[wv][d] = old + (uint32_t)__popcll(mm);
+        __builtin_amdgcn_wave_barrier();
+        if (ok) st_slim(dst + old + (uint32_t)__popcll(mm & lt), e);
+      }
+      __threadfence();                                       // the next pass reads what other waves of the block wrote
+      __syncthreads();
+      Slim* x = src; src = dst; dst = x;
+    }
+  }
+  if (src != b) for (uint32_t i = t; i < m; i += SB_THREADS) st_slim(b + i, ld_slim(src + i));
+}
+
+template <int SB_THREADS>
+__global__ __launch_bounds__(SB_THREADS) void sl_bucket_lds(Slim* __restrict__ in, const uint32_t* __restrict__ offs, int nbuckets, const uint32_t* __restrict__ d_live,
+                                                            int pb, uint32_t cap, Slim* __restrict__ out, uint32_t* __restrict__ err) {
+  constexpr int SB_WAVES = SB_THREADS / 64;
+  __shared__ uint32_t sk[2][SB_CAP];
+  __shared__ uint16_t sv[2][SB_CAP];
+  __shared__ uint32_t wcnt[SB_WAVES][1 << SB_DBITS];
+  __shared__ uint32_t tot[SB_WAVES];
+  __shared__ uint32_t s_min, s_max;
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const uint32_t n = *d_live;
+  uint32_t lo = offs[b], hi = b + 1 < nbuckets ? offs[b + 1] : n;      // (tile 0's row of the scanned histogram: the buckets' first elements)
+  if (lo > n) lo = n;
+  if (hi > n) hi = n;
+  if (hi <= lo) return;
+  const uint32_t m = hi - lo;
+  const bool slow = m > cap;                                           // (block-uniform)
+  const uint32_t pmask = pb >= 32 ? 0xFFFFFFFFu : (1u << pb) - 1u;
+  if (t == 0) { s_min = 0xFFFFFFFFu; s_max = 0u; }
+  __syncthreads();
+  uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+  for (uint32_t i = t; i < m; i += SB_THREADS) {
+    const uint32_t k = (uint32_t)in[lo + i].key & pmask;               // a bucket lies in one list: the position orders it
+    if (!slow) { sk[0][i] = k; sv[0][i] = (uint16_t)i; }
+    kmin = min(kmin, k); kmax = max(kmax, k);
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) { kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, d, 64)); kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, d, 64)); }
+  if (lane == 0) { atomicMin(&s_min, kmin); atomicMax(&s_max, kmax); }
+  __syncthreads();
+  kmin = s_min; kmax = s_max;
+  if (slow) {
+    if (t == 0) atomicOr(err, ERRB_BUCKET1_SLOW);
+    sl_bucket_global<SB_THREADS>(in + lo, out + lo, m, pmask, kmin, kmax, wcnt, tot);
+    return;
+  }
+  const uint32_t width = kmax - kmin;
+  int src = 0;
+  if (width != 0) {
+    const int wbits = 32 - __builtin_clz(width);
+    const int passes = (wbits + SB_DBITS - 1) / SB_DBITS;
+    const int db = (wbits + passes - 1) / passes;
+    const uint32_t dmask = (1u << db) - 1u, nbins = 1u << db;
+    // elements of wave w: [w * per, (w + 1) * per) — wave-major chunks keep the input order inside equal digits
+    const uint32_t per = ((m + SB_WAVES - 1) / SB_WAVES + 63u) & ~63u;
+    const uint32_t c0 = min(m, (uint32_t)wv * per), c1 = min(m, c0 + per);
+    const uint64_t lt = (1ull << lane) - 1ull;
+    for (int pass = 0, shift = 0; pass < passes; ++pass, shift += db) {
+      for (uint32_t d = t; d < SB_WAVES * nbins; d += SB_THREADS) wcnt[d / nbins][d % nbins] = 0;
+      __syncthreads();
+      for (uint32_t i = c0 + lane; i < c1; i += 64) atomicAdd(&wcnt[wv][((sk[src][i] - kmin) >> shift) & dmask], 1u);
+      __syncthreads();
+      sb_bases<SB_THREADS>(wcnt, tot, nbins);
+      for (uint32_t i0 = c0; i0 < c1; i0 += 64) {            // whole waves iterate together (c0, c1 are wave-uniform)
+        const uint32_t i = i0 + lane;
+        const bool ok = i < c1;
+        const uint32_t k = ok ? sk[src][i] : 0u;
+        const uint16_t v = ok ? sv[src][i] : (uint16_t)0;
+        const uint32_t d = ((k - kmin) >> shift) & dmask;
+        uint64_t mm = __ballot(ok);
+        for (int bit = 0; bit < db; ++bit) { const uint64_t bal = __ballot((d >> bit) & 1u); mm &= ((d >> bit) & 1u) ? bal : ~bal; }
+        const uint32_t old = ok ? wcnt[wv][d] : 0u;
+        __builtin_amdgcn_wave_barrier();
+        if (ok && (mm & lt) == 0) wcnt[wv][d] = old + (uint32_t)__popcll(mm);
+        __builtin_amdgcn_wave_barrier();
+        if (ok) { const uint32_t dst = old + (uint32_t)__popcll(mm & lt); sk[src ^ 1][dst] = k; sv[src ^ 1][dst] = v; }
+      }
+      __syncthreads();
+      src ^= 1;
+    }
+  }
+  for (uint32_t i = t; i < m; i += SB_THREADS) st_slim(out + lo + i, ld_slim(in + lo + sv[src][i]));       // (the bucket's 64 KB were just read: L2)
+}
 
 // ---- the sorts behind a stage that drops a list bit: rank inside the class + ONE merge -------------------------------------------
 // Sorts 2 and 3 and the call sort do not meet unordered input. Their slots come in two CLASSES — the value of the key bit the stage
@@ -1377,6 +1588,43 @@ Slim* sl_merge_sort(hipStream_t st, SRC src, const uint32_t* d_slots, uint32_t* 
 
 }  // namespace
 
+// sort 1 as counting pass + LDS sort per bucket; nullptr when the shape does not take it (the caller runs the LSD passes)
+template <int BITS>
+Slim* sl_bucket_sort1_bits(hipStream_t st, const Slim* in, const uint32_t* d_slots, uint32_t* d_live, int pb, int tid_bits, Slim* tmp, Slim* out, const SlimWork& w) {
+  const int pairs_log = 2 + tid_bits, bp_log = BITS - pairs_log;                 // list pairs (tid, hap, type); buckets per pair
+  if (bp_log < 3 || pb > 31) return nullptr;
+  // a pair's buckets go to its cigar and its split list by the share of split elements the handle expects (+25 %; at least one each)
+  const uint32_t bp = 1u << bp_log;
+  double want1 = w.split_share * 1.25 * (double)bp;
+  uint32_t nb1 = want1 < 1.0 ? 1u : (uint32_t)(want1 + 0.5);
+  if (nb1 > bp / 2) nb1 = bp / 2;
+  const uint32_t b0 = bp - nb1;
+  constexpr int SLOTS = (1 << BITS) > 2048 ? (1 << BITS) / 2048 : 1;              // totals slots of 2048 words (+ one for the position range)
+  uint32_t* totals = w.totals + (size_t)(*w.pass_cursor) * 2048;
+  uint32_t* mm = totals + (size_t)SLOTS * 2048;
+  *w.pass_cursor += SLOTS + 1;
+  const MsdDigit dig{pb, bp_log, b0, nb1, mm};
+  const int64_t max_tiles = (w.cap + SL_TILE - 1) / SL_TILE;
+  const int grid = (int)(max_tiles < 2048 ? (max_tiles < 1 ? 1 : max_tiles) : 2048);
+  static const int cap_env = vsv_dbg_env("VSV_SORT1_CAP") ? atoi(vsv_dbg_env("VSV_SORT1_CAP")) : 0;      // tests: buckets above this many elements take the global-memory form
+  const uint32_t cap = cap_env > 0 && cap_env < SB_CAP ? (uint32_t)cap_env : (uint32_t)SB_CAP;
+  sl_minmax<<<grid < 1024 ? grid : 1024, 256, 0, st>>>(in, d_slots, pb, mm);
+  sl_hist<BITS, SrcSlim, true, 4><<<grid, 256, 0, st>>>(SrcSlim{in}, d_slots, dig, w.hist, totals);
+  sl_scan<BITS><<<(1 << BITS) / 16, 1024, 0, st>>>(w.hist, totals, d_slots, d_live);
+  sl_scatter<BITS, SrcSlim, true, 4><<<grid, 256, 0, st>>>(SrcSlim{in}, d_slots, dig, w.hist, tmp);
+  sl_bucket_lds<512><<<1 << BITS, 512, 0, st>>>(tmp, w.hist, 1 << BITS, d_live, pb, cap, out, w.err);
+  return out;
+}
+Slim* sl_bucket_sort1(hipStream_t st, const Slim* in, const uint32_t* d_slots, uint32_t* d_live, int pb, int tid_bits, Slim* tmp, Slim* out, const SlimWork& w) {
+  static const int forced = vsv_dbg_env("VSV_SORT1_BITS") ? atoi(vsv_dbg_env("VSV_SORT1_BITS")) : 0;       // timing experiments / tests: 11 | 12 (0: by the size hint), -1: the passes
+  if (!w.bucket_sort1 || forced < 0) return nullptr;
+  // ~2000 or ~4000 buckets: the fewest that keep the previous run's table (+25 %) at <= ~1600 elements per bucket on average; beyond
+  // ~2000 per bucket (LDS holds 4096: a list pair or a region twice as dense as the average still fits) the passes
+  const bool big = forced ? forced == 12 : w.rows_hint > (int64_t)1600 * 2048;
+  if (!forced && w.rows_hint > (int64_t)2048 * 4096) return nullptr;
+  return big ? sl_bucket_sort1_bits<12>(st, in, d_slots, d_live, pb, tid_bits, tmp, out, w) : sl_bucket_sort1_bits<11>(st, in, d_slots, d_live, pb, tid_bits, tmp, out, w);
+}
+
 // ================================================== entry points (capi.hip) ==================================================
 int vsv_slim_sort_passes(int nbits) { return (nbits + 7) / 8; }     // (upper bound: a 10-bit plan never takes more passes)
 
@@ -1386,7 +1634,8 @@ void* vsv_slim_stage1(hipStream_t st, const vsv_sig* s1in, const uint32_t* d_n_s
   Slim* b0 = (Slim*)w.buf[0]; Slim* b1 = (Slim*)w.buf[1]; Slim* e2 = (Slim*)w.buf[2];
   // (a fused run has the elements already: fold_kernel / split_eval wrote them next to the rows, vsv_slim_emit)
   if (!prebuilt) sl_from_rows<<<w.grid, 256, 0, st>>>(s1in, d_n_s1, pb, tid_lo, tid_bits, b0, &ctr->err);
-  Slim* sorted = sl_sort(st, SrcSlim{b0}, d_n_s1, d_alive1, pb + 3 + tid_bits, KeyCmp{0, 0}, b1, b0, w, w.rows_hint);
+  Slim* sorted = sl_bucket_sort1(st, b0, d_n_s1, d_alive1, pb, tid_bits, b1, b0, w);       // (in: b0, bucket order: b1, sorted: b0 again)
+  if (!sorted) sorted = sl_sort(st, SrcSlim{b0}, d_n_s1, d_alive1, pb + 3 + tid_bits, KeyCmp{0, 0}, b1, b0, w, w.rows_hint);
   const int64_t tiles = (w.cap + CL_TILE - 1) / CL_TILE;
   const bool ms = sl_merge_ok(w, pb + 3 + tid_bits, KeyCmp{pb, 1});       // the sort behind these clusters: rank + merge (sl_merge_sort)
   MsCtl* ctl = ms ? sl_ms_begin(st, w, true) : nullptr;                   // ... whose tile counts the cluster kernel leaves in w.hist

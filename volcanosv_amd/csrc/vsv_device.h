@@ -23,6 +23,7 @@ enum : uint32_t {
   ERRB_SORT_FALLBACK = 1u << 7,  // a bucket of the bucket sort did not fit in LDS: the run is repeated with the LSD passes
   ERRB_MERGE_FALLBACK = 1u << 11, // a rank-and-merge sort of the element path met a window it cannot decide (thousands of slots within one shift): the run is repeated with the LSD passes
   ERRB_BATCH_FALLBACK = 1u << 13, // (host side) a part of the scan filed an overflow batch in a run that skipped their placement launch: the run is repeated with it
+  ERRB_BUCKET1_SLOW = 1u << 14,  // (not an error) a bucket of the element path's first sort (one counting pass + an LDS sort per bucket) held more than fits in LDS and was sorted in global memory: the handle's next runs take the LSD passes
   ERRB_LOOKBACK = 1u << 12,      // a part of the scan waited for its predecessors' row counts beyond every plausible time (cigar_scan.hip, look-back): internal error
   ERRB_SLIM_FALLBACK = 1u << 10, // an svlen outside [0, 2^30) or a position of 2^30 and more met the element path (32-bit predicates): the run is repeated on rows
 };
@@ -275,6 +276,8 @@ struct SlimWork {
   uint32_t* hj;         // pairing: first candidate of every hp1 row | stretch-start flag
   uint32_t* done1;      // pairing in rounds: decided flags
   bool merge_sorts;     // sorts 2 / 3 / calls as rank-inside-the-class + merge (sl_merge_sort); false: the LSD passes
+  bool bucket_sort1;    // sort 1 as one counting pass into position buckets + an LDS sort per bucket (sl_bucket_sort1); false: the LSD passes
+  double split_share;   // expected share of split-list elements among the stage-1 elements (previous run / cold wait): their part of the buckets
   uint32_t* err;        // device error word (ERRB_MERGE_FALLBACK)
 };
 int vsv_slim_sort_passes(int nbits);

@@ -105,6 +105,10 @@ class Engine:
         """Whole-run repetitions vsv_finish() took on this engine so far (bucket-sort overflow / fused-CLR-gate fallbacks)."""
         return int(self.lib.vsv_rerun_count(self.h))
 
+    def sort1_slow_count(self):
+        """Runs whose first element sort met a bucket too large for LDS and sorted it in global memory (vsv_sort1_slow_count)."""
+        return int(self.lib.vsv_sort1_slow_count(self.h))
+
     def path_counts(self):
         """(element_runs, cold_syncs) of this engine (vsv_path_counts): runs whose stages behind the split stage worked on 16-byte
         elements, and first runs that waited for the scan once to pick that path from the run's own row count."""
