@@ -93,6 +93,7 @@ struct vsv_handle {
   // large tables (slim_path.hip): element buffers, pairing scratch, what the run in flight left where
   DevBuf sl[6], sl_hj, sl_done;
   bool big_run = false;            // the stages of this run work on 16-byte elements; rows are gathered on request
+  bool sl_mm_ready = false;        // ... and the in-place fold has left their position range behind the counters (fold_mm)
   bool sl_prebuilt = false;        // ... and fold / split_eval have written the stage-1 elements next to their rows
   void* sl_e2 = nullptr;           // stage-1 cluster output (n_alive1 slots)
   void* sl_m = nullptr;            // merged elements (n_alive3)
@@ -297,8 +298,11 @@ SortWork sort_work(vsv_handle* h, int64_t table_rows = -1) {
   w.shared_gpu = h->prm.split_overlap == VSV_OVERLAP_OFF;
   w.groups = h->groups; w.group_cursor = &h->group_cursor; w.max_group_slots = MAX_GROUP_SLOTS;
   w.err = h->ctr.p ? &((Counters*)h->ctr.p)->err : nullptr;
+  w.slots_ok = true;      // (the signature stages read nothing but the key of a dead row)
   return w;
 }
+// ... for callers that gather by the values of dead rows too (breakend candidates, name hashes): the three-launch forms
+SortWork sort_work_plain(vsv_handle* h) { SortWork w = sort_work(h); w.slots_ok = false; return w; }
 // zero the device counters and the per-pass sort totals: start of every run
 constexpr size_t ARENA_CTR = 256, ARENA_SHARD = 256 * 16 * sizeof(uint32_t), ARENA_TILES = 4096 * sizeof(uint32_t),
                  ARENA_TOTALS = (size_t)MAX_SORT_PASSES * 2048 * sizeof(uint32_t),
@@ -355,6 +359,8 @@ StageBufs stage_bufs(vsv_handle* h) {
   return StageBufs{(uint64_t*)h->key.p, (uint32_t*)h->idx.p, (int32_t*)h->cl.p, h->rv.tid_lo, tid_bits(h), kmax, ew_grid(h)};
 }
 Counters* dctr(vsv_handle* h) { return (Counters*)h->ctr.p; }
+// two words behind the counters (zeroed with them): the position range of the stage-1 cigar elements, left by the in-place fold
+uint32_t* fold_mm(vsv_handle* h) { static_assert(sizeof(Counters) <= 128, "counters"); return (uint32_t*)h->ctr.p + 32; }
 int pos_bits(vsv_handle* h) { return h->max_pos > 0 ? bits_for((uint64_t)h->max_pos + VSV_POS_BIAS + 2) : 32; }
 int tid_bits(vsv_handle* h) { return bits_for((uint64_t)(h->n_tids > 0 ? h->n_tids - h->rv.tid_lo : 65536) + 1); }
 int key_bits(vsv_handle* h) { return pos_bits(h) + 3 + tid_bits(h) + 1; }   // +1: dead keys (all ones) sort last
@@ -456,7 +462,10 @@ int enq_scan(vsv_handle* h) {
   const int long_parts = vsv_scan_parts(srv, h->prm, OPS_PER_PART);
   const bool fused = is_contig(h->prm.dtype) && long_parts > 0;
   SlimOut so_f{nullptr, 0, 0, 0, nullptr};
-  if (fused) so_f = SlimOut{h->sl[0].p, pos_bits(h), h->rv.tid_lo, tid_bits(h), &dctr(h)->err};
+  // (the position range of the elements, for the first sort of a run on elements: a handle that knows its tables are small skips it)
+  const bool want_mm = fused && pos_bits(h) < 32 && (!h->have_history || (want_big(h) && big_allowed(h)));
+  if (fused) so_f = SlimOut{h->sl[0].p, pos_bits(h), h->rv.tid_lo, tid_bits(h), &dctr(h)->err, want_mm ? fold_mm(h) : nullptr};
+  h->sl_mm_ready = want_mm;
   vsv_launch_cigar_scan(st, srv, h->prm, (uint32_t*)h->part_rb.p, n_parts, OPS_PER_PART, (vsv_sig*)h->pool.p,
                         (uint64_t*)h->pool_key.p, (uint32_t)h->cap_sigs, (uint32_t*)h->part_count.p, (uint32_t*)h->part_off.p,
                         (uint32_t*)h->scan_tmp.p, (vsv_sig*)h->raw0.p, dctr(h), (uint32_t*)h->shard_cnt.p, h->ev0, h->ev1,
@@ -575,6 +584,7 @@ int slim_work(vsv_handle* h, SlimWork& w) {
     const double pairs = c.n_pairs ? (double)c.n_pairs : 0.5 * (double)c.n_cand, rows = (double)c.n_raw + pairs;
     w.split_share = rows > 0 ? pairs / rows : 0.05;
   }
+  w.mm = h->sl_mm_ready && h->sl_prebuilt ? fold_mm(h) : nullptr;
   w.err = &dctr(h)->err;
   return 0;
 }
@@ -748,7 +758,7 @@ int rerun(vsv_handle* h) {
     h->pass_cursor = 0;
     h->group_cursor = MAX_GROUP_SLOTS;      // (the group sums are not zeroed here: these sorts keep their scan launch)
     vsv_launch_bnd_pair(h->stream, (const vsv_bnd*)h->s1in.p, h->segs.contig_rank, bits_for((uint64_t)h->segs.n_tids + 1), h->bnd_prm,
-                        (vsv_bnd*)h->s1s.p, (vsv_bnd*)h->c1.p, dctr(h), stage_bufs(h), sort_work(h), h->cap_sigs);
+                        (vsv_bnd*)h->s1s.p, (vsv_bnd*)h->c1.p, dctr(h), stage_bufs(h), sort_work_plain(h), h->cap_sigs);
     HIPCHK(h, hipGetLastError());
     return finish(h);
   }
@@ -1174,7 +1184,7 @@ int vsv_bnd_pair(vsv_handle* h, const vsv_bnd_params* p) {
   HIPCHK(h, hipSetDevice(h->device));
   h->bnd_prm = *p;
   vsv_launch_bnd_pair(h->stream, (const vsv_bnd*)h->s1in.p, h->segs.contig_rank, bits_for((uint64_t)h->segs.n_tids + 1), *p,
-                      (vsv_bnd*)h->s1s.p, (vsv_bnd*)h->c1.p, dctr(h), stage_bufs(h), sort_work(h), h->cap_sigs);
+                      (vsv_bnd*)h->s1s.p, (vsv_bnd*)h->c1.p, dctr(h), stage_bufs(h), sort_work_plain(h), h->cap_sigs);
   HIPCHK(h, hipGetLastError());
   h->bnd_stage = 2;
   return finish(h);
@@ -1649,7 +1659,7 @@ int vsv_bam_parse_device(vsv_handle* h, const uint8_t* comp, const uint64_t* com
   HIPCHK(h, hipMemcpyAsync(h->o_n.p, &nk32, 4, hipMemcpyHostToDevice, st));
   HIPCHK(h, hipMemcpyAsync(h->key.p, h->o_hash.p, K * 8, hipMemcpyDeviceToDevice, st));
   vsv_bamdev_iota(st, (uint32_t*)h->idx.p, nk);
-  SortWork sw = sort_work(h);
+  SortWork sw = sort_work_plain(h);
   sw.small_tiles = nk <= 128 * 4096;
   const SortResult sr = vsv_radix_sort_pairs(st, (uint64_t*)h->key.p, (uint32_t*)h->idx.p, sw.key_alt, sw.val_alt, (const uint32_t*)h->o_n.p, nk, 64, sw);
   HIPCHK(h, hipMemsetAsync(h->o_first.p, 0, K * 4, st));

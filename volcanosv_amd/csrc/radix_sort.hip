@@ -62,6 +62,7 @@ struct KeyArr {
   const uint64_t* key; const uint32_t* val;
   __device__ __forceinline__ uint64_t key_at(uint32_t i, bool) const { return key[i]; }
   __device__ __forceinline__ uint32_t val_at(uint32_t i) const { return val[i]; }
+  const uint32_t* val_lut() const { return val; }
 };
 struct SigKey {      // stage key of a signature row (vsv_key_stage; stage 5 = the READS final order, reads.py:281-286)
   const vsv_sig* rows; int stage, pb, tid_lo, tid_bits; uint32_t* err;
@@ -77,6 +78,7 @@ struct SigKey {      // stage key of a signature row (vsv_key_stage; stage 5 = t
     return k;
   }
   __device__ __forceinline__ uint32_t val_at(uint32_t i) const { return i; }
+  const uint32_t* val_lut() const { return nullptr; }
 };
 // (tid, pos) key of a call row: the final order of pair_sig's output (H:594). The hp1 rows' calls were written by the pairing
 // kernels; an hp2 row's call is derived here from the merged table and the pairing state — unpaired -> a 0/1 call of its own
@@ -91,6 +93,7 @@ struct CallKey {
     return vsv_key_stage(rows[i].sig, 4, pb, tid_lo);
   }
   __device__ __forceinline__ uint32_t val_at(uint32_t i) const { return i; }
+  const uint32_t* val_lut() const { return nullptr; }
 };
 
 // key of a split-pair slot, straight from the candidates sorted by (tid, hap, name): candidate j followed by another one of the same
@@ -109,6 +112,7 @@ struct PairKey {
     return VSV_KEY_DEAD;
   }
   __device__ __forceinline__ uint32_t val_at(uint32_t j) const { return j; }
+  const uint32_t* val_lut() const { return nullptr; }
 };
 
 template <int BITS, int ROUNDS, typename DIGIT, typename SRC>
@@ -580,6 +584,235 @@ __global__ __launch_bounds__(BK_THREADS) void bk_lds_sort(const uint64_t* __rest
   }
 }
 
+// ---- the same bucket sort in TWO launches: no histogram launch in front of the counting pass ------------------------------------------
+// Every bucket owns a fixed region of `caps` (key, input index) slots in the scratch pair. A tile ranks its rows per bucket as
+// rs_scatter does, reserves room for each bucket it touches with ONE atomicAdd on the bucket's counter (the per-pass digit totals,
+// zeroed with the run) and writes its rows there: a bucket's region is a sequence of per-tile chunks, each in input order, the chunks
+// in the order the tiles happened to arrive. The LDS sort puts the chunks back into tile order first (stable passes on the tile number
+// of the input index; skipped when the indices already ascend: position-clustered input feeds a bucket from one or two tiles), then
+// sorts by key as before: the result is the stable sort, bit for bit. Dead rows (the last bucket) are only counted. A bucket with more
+// rows than its region raises ERRB_SORT_FALLBACK like a bucket beyond LDS does.
+template <int BITS, int RS_ROUNDS, typename DIGIT, typename SRC>
+__global__ __launch_bounds__(256) void rs_slot_scatter(SRC src, const uint32_t* __restrict__ d_n, DIGIT dg, uint32_t* __restrict__ totals, uint32_t caps,
+                                                       uint64_t* __restrict__ slot_key, uint32_t* __restrict__ slot_idx, uint32_t* __restrict__ slot_val,
+                                                       uint32_t* __restrict__ err) {
+  constexpr int BINS = 1 << BITS;
+  __shared__ uint32_t wcnt[RS_WAVES][BINS];   // per-wave running digit counters, then (wave, digit) bases inside the bucket's region
+  constexpr uint32_t RS_TILE = rs_tile<RS_ROUNDS>();
+  const uint32_t n = *d_n, ntiles = n_tiles_of<RS_ROUNDS>(n);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint64_t lt = (1ull << lane) - 1ull;
+  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int d = threadIdx.x; d < BINS; d += 256)
+#pragma unroll
+      for (int w = 0; w < RS_WAVES; ++w) wcnt[w][d] = 0;
+    __syncthreads();
+    const uint32_t wbase = tile * RS_TILE + wv * (RS_ROUNDS * 64);
+    uint64_t k_[RS_ROUNDS];
+    uint32_t rk[RS_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; ++r) {
+      const uint32_t i = wbase + r * 64 + lane;
+      const bool ok = i < n;
+      k_[r] = ok ? src.key_at(i, true) : 0;
+      const uint32_t d = dg.template get<BITS>(k_[r]);
+      const uint64_t m = match_digit<BITS>(d, ok);
+      const uint32_t old = ok ? wcnt[wv][d] : 0;
+      __builtin_amdgcn_wave_barrier();
+      if (ok && (m & lt) == 0) wcnt[wv][d] = old + (uint32_t)__popcll(m);
+      __builtin_amdgcn_wave_barrier();
+      rk[r] = ok ? old + (uint32_t)__popcll(m & lt) : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < BINS; d += 256) {      // room in the bucket's region for this tile's rows, then the waves' shares of it
+      uint32_t c[RS_WAVES], tot = 0;
+#pragma unroll
+      for (int w = 0; w < RS_WAVES; ++w) { c[w] = wcnt[w][d]; tot += c[w]; }
+      uint32_t run = tot ? atomicAdd(&totals[d], tot) : 0u;
+      if (tot && d != BINS - 1 && run + tot > caps) atomicOr(err, ERRB_SORT_FALLBACK);
+#pragma unroll
+      for (int w = 0; w < RS_WAVES; ++w) { wcnt[w][d] = run; run += c[w]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; ++r) {
+      if (rk[r] != 0xFFFFFFFFu) {
+        const uint32_t d = dg.template get<BITS>(k_[r]);
+        const uint32_t dst = wcnt[wv][d] + rk[r];
+        if (d != BINS - 1 && dst < caps) {
+          const uint32_t i = wbase + r * 64 + lane;
+          const size_t at = (size_t)d * caps + dst;
+          slot_key[at] = k_[r]; slot_idx[at] = i;
+          if (slot_val) slot_val[at] = src.val_at(i);      // (values that are not the input index travel beside it: the sort may run in place)
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// slot_val: the values of the rows where they are not the input indices themselves (KeyArr), or nullptr
+template <typename ROW, int BK_THREADS>
+__global__ __launch_bounds__(BK_THREADS) void bk_slot_sort(const uint64_t* __restrict__ slot_key, const uint32_t* __restrict__ slot_idx, const uint32_t* __restrict__ slot_val, uint32_t caps,
+                                                            const uint32_t* __restrict__ totals, int nbuckets, const uint32_t* __restrict__ d_n,
+                                                            uint64_t* __restrict__ key_out, uint32_t* __restrict__ val_out, uint32_t* __restrict__ err, uint32_t cap,
+                                                            uint32_t tile_rows, RowIO<ROW> io) {
+  constexpr bool ROWS = !std::is_same<ROW, void>::value;
+  constexpr int BK_WAVES = BK_THREADS / 64, BK_DBITS = BK_THREADS >= 512 ? 9 : 8;
+  __shared__ uint32_t sk[2][BK_CAP];
+  __shared__ uint16_t sv[2][BK_CAP];          // the row's place in the bucket's region
+  __shared__ uint32_t wcnt[BK_WAVES][1 << BK_DBITS];
+  __shared__ uint32_t tot[BK_WAVES];
+  __shared__ unsigned long long s_min, s_max;
+  __shared__ uint32_t s_lo, s_unordered;
+  const uint32_t n = *d_n;
+  const int b = blockIdx.x;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  {                      // the bucket's first output row = the totals of the buckets in front of it
+    uint32_t part = 0;
+    for (int d = t; d < b; d += BK_THREADS) part += totals[d];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) part += (uint32_t)__shfl_xor((int)part, d, 64);
+    if (t == 0) { s_lo = 0; s_unordered = 0; s_min = ~0ull; s_max = 0ull; }
+    __syncthreads();
+    if (lane == 0 && part) atomicAdd(&s_lo, part);
+    __syncthreads();
+  }
+  {  // the last bucket counts the dead rows: every workgroup writes a slice of the dead tail
+    uint32_t dlo = n - min(n, totals[nbuckets - 1]);
+    const uint32_t dm = n - dlo, per = (dm + gridDim.x - 1) / gridDim.x;
+    const uint32_t a = dlo + min(dm, (uint32_t)b * per), e = dlo + min(dm, (uint32_t)(b + 1) * per);
+    for (uint32_t i = a + t; i < e; i += BK_THREADS) { key_out[i] = VSV_KEY_DEAD; if (!ROWS) val_out[i] = 0; }
+    if constexpr (ROWS) {
+      if (b == 0 && t == 0) { *io.d_alive = dlo; *io.n_long = 0; }
+      if (io.fill) {
+        const uint32_t fper = (n + gridDim.x - 1) / gridDim.x;
+        const uint32_t fa = min(n, (uint32_t)b * fper), fe = min(n, fa + fper);
+        for (uint32_t i = fa + t; i < fe; i += BK_THREADS) io.fill[i] = -1;
+      }
+    }
+  }
+  if (b == nbuckets - 1) return;
+  const uint32_t lo = min(n, s_lo), m_all = totals[b];
+  if (m_all == 0) return;
+  if (m_all > cap || m_all > caps || lo + m_all > n) { if (t == 0) atomicOr(err, ERRB_SORT_FALLBACK); return; }
+  const uint32_t m = m_all;
+  const uint64_t* kin = slot_key + (size_t)b * caps;
+  const uint32_t* iin = slot_idx + (size_t)b * caps;
+  uint64_t kmin = ~0ull, kmax = 0;
+  for (uint32_t i = (uint32_t)t; i < m; i += BK_THREADS) { const uint64_t k = kin[i]; kmin = k < kmin ? k : kmin; kmax = k > kmax ? k : kmax; }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    const uint64_t a = __shfl_xor(kmin, d, 64), c = __shfl_xor(kmax, d, 64);
+    kmin = a < kmin ? a : kmin; kmax = c > kmax ? c : kmax;
+  }
+  if (lane == 0) { atomicMin(&s_min, (unsigned long long)kmin); atomicMax(&s_max, (unsigned long long)kmax); }
+  __syncthreads();
+  kmin = s_min; kmax = s_max;
+  const uint64_t width = kmax - kmin;
+  if (width > 0xFFFFFFFFull) { if (t == 0) atomicOr(err, ERRB_SORT_FALLBACK); return; }
+  bool bad = false;                                      // input indices that do not ascend: chunks of several tiles, out of order
+  for (uint32_t i = (uint32_t)t; i + 1 < m; i += BK_THREADS) if (iin[i + 1] < iin[i]) bad = true;
+  if (bad) s_unordered = 1;
+  for (uint32_t i = (uint32_t)t; i < m; i += BK_THREADS) { sk[0][i] = (uint32_t)(kin[i] - kmin); sv[0][i] = (uint16_t)i; }
+  __syncthreads();
+  const bool unordered = s_unordered != 0;               // (block-uniform)
+  int src = 0;
+  const uint32_t per = ((m + BK_WAVES - 1) / BK_WAVES + 63u) & ~63u;
+  const uint32_t c0 = min(m, (uint32_t)wv * per), c1 = min(m, c0 + per);
+  const uint64_t lt = (1ull << lane) - 1ull;
+  // stable LSD passes over bits [0, nb) of sk (digits as equal as possible, at most BK_DBITS wide), (sk, sv) moving together; called
+  // by the whole block
+  auto lsd = [&](int nb) {
+    const int passes = (nb + BK_DBITS - 1) / BK_DBITS;
+    const int db = passes ? (nb + passes - 1) / passes : 0;
+    const uint32_t dmask = (1u << db) - 1u, nbins = 1u << db;
+    for (int pass = 0, shift = 0; pass < passes; ++pass, shift += db) {
+      for (uint32_t d = t; d < BK_WAVES * nbins; d += BK_THREADS) wcnt[d / nbins][d % nbins] = 0;
+      __syncthreads();
+      for (uint32_t i = c0 + lane; i < c1; i += 64) atomicAdd(&wcnt[wv][(sk[src][i] >> shift) & dmask], 1u);
+      __syncthreads();
+      uint32_t mine = 0, incl = 0;
+      if ((uint32_t)t < nbins) {
+#pragma unroll
+        for (int w = 0; w < BK_WAVES; ++w) mine += wcnt[w][t];
+      }
+      incl = mine;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += o; }
+      if (lane == 63) tot[wv] = incl;
+      __syncthreads();
+      if ((uint32_t)t < nbins) {
+        uint32_t run = incl - mine;
+        for (int w = 0; w < wv; ++w) run += tot[w];
+#pragma unroll
+        for (int w = 0; w < BK_WAVES; ++w) { const uint32_t c = wcnt[w][t]; wcnt[w][t] = run; run += c; }
+      }
+      __syncthreads();
+      for (uint32_t i0 = c0; i0 < c1; i0 += 64) {            // whole waves iterate together (c0, c1 are wave-uniform)
+        const uint32_t i = i0 + lane;
+        const bool ok = i < c1;
+        const uint32_t k = ok ? sk[src][i] : 0u;
+        const uint16_t v = ok ? sv[src][i] : (uint16_t)0;
+        const uint32_t d = (k >> shift) & dmask;
+        const uint64_t mm = match_digit_rt(d, ok, db);
+        const uint32_t old = ok ? wcnt[wv][d] : 0u;
+        __builtin_amdgcn_wave_barrier();
+        if (ok && (mm & lt) == 0) wcnt[wv][d] = old + (uint32_t)__popcll(mm);
+        __builtin_amdgcn_wave_barrier();
+        if (ok) { const uint32_t dst = old + (uint32_t)__popcll(mm & lt); sk[src ^ 1][dst] = k; sv[src ^ 1][dst] = v; }
+      }
+      __syncthreads();
+      src ^= 1;
+    }
+  };
+  const int wbits = width ? 64 - __builtin_clzll(width) : 0;
+  lsd(wbits);
+  if (unordered) {
+    // The passes kept the order the rows had in the region: rows of equal key whose chunks arrived out of order are out of order still.
+    // Every such run (<= 64 rows: beyond that the whole bucket is sorted again, tile order first) is put into input order by rank.
+    constexpr uint32_t TIE_MAX = 64;
+    __syncthreads();
+    if (t == 0) s_unordered = 0;                           // (now: "a run too long for the ranks")
+    __syncthreads();
+    for (uint32_t i = (uint32_t)t; i < m; i += BK_THREADS) {
+      const uint32_t k = sk[src][i];
+      uint32_t dst = i;
+      if ((i > 0 && sk[src][i - 1] == k) || (i + 1 < m && sk[src][i + 1] == k)) {
+        uint32_t a = i, e = i + 1;
+        while (a > 0 && sk[src][a - 1] == k && i - a < TIE_MAX) --a;
+        while (e < m && sk[src][e] == k && e - i < TIE_MAX) ++e;
+        if (e - a > TIE_MAX || (a > 0 && sk[src][a - 1] == k) || (e < m && sk[src][e] == k)) s_unordered = 1;
+        else {
+          const uint32_t me = iin[sv[src][i]];
+          uint32_t r = 0;
+          for (uint32_t x = a; x < e; ++x) r += iin[sv[src][x]] < me ? 1u : 0u;
+          dst = a + r;
+        }
+      }
+      sk[src ^ 1][i] = k;                                  // (keys inside a run are equal: a row's key stays where it is)
+      sv[src ^ 1][dst] = sv[src][i];
+    }
+    __syncthreads();
+    src ^= 1;
+    if (s_unordered) {                                     // (block-uniform) a pile of equal keys: tile order first, then the keys again
+      const uint32_t ntiles = (n + tile_rows - 1) / tile_rows;
+      for (uint32_t i = (uint32_t)t; i < m; i += BK_THREADS) { sk[src][i] = iin[i] / tile_rows; sv[src][i] = (uint16_t)i; }
+      __syncthreads();
+      lsd(ntiles > 1 ? 32 - __builtin_clz(ntiles - 1) : 0);
+      for (uint32_t i = (uint32_t)t; i < m; i += BK_THREADS) sk[src][i] = (uint32_t)(kin[sv[src][i]] - kmin);
+      __syncthreads();
+      lsd(wbits);
+    }
+  }
+  const uint32_t* vin = slot_val ? slot_val + (size_t)b * caps : iin;
+  for (uint32_t i = t; i < m; i += BK_THREADS) {
+    key_out[lo + i] = kmin + sk[src][i];
+    const uint32_t j = sv[src][i];
+    if constexpr (ROWS) io.out[lo + i] = io.fetch(iin[j]); else val_out[lo + i] = vin[j];
+  }
+}
+
 template <int BITS, int ROUNDS, typename SRC, typename ROW>
 SortResult bucket_sort(hipStream_t st, SRC src, uint64_t* key, uint32_t* val, uint64_t* key_scratch, uint32_t* val_scratch, const uint32_t* d_n,
                        int64_t max_n, uint64_t kmax, const SortWork& w, RowIO<ROW> io) {
@@ -592,8 +825,22 @@ SortResult bucket_sort(hipStream_t st, SRC src, uint64_t* key, uint32_t* val, ui
   ++*w.pass_cursor;
   const int64_t max_tiles = (max_n + rs_tile<ROUNDS>() - 1) / rs_tile<ROUNDS>();
   const int grid = (int)(max_tiles < 1024 ? (max_tiles < 1 ? 1 : max_tiles) : 1024);
-  // the self-scanning form needs a zeroed slot of group sums and a table of at most VSV_RS_MAX_GROUPS groups of tiles (the row
-  // count of the handle's previous run; a table that grew past it is caught below: the sort falls back like an overflowing bucket)
+  static const int cap_env = vsv_dbg_env("VSV_BK_CAP") ? atoi(vsv_dbg_env("VSV_BK_CAP")) : BK_CAP;      // tests force the fallback with a tiny capacity
+  const uint32_t cap = (uint32_t)(cap_env < 2 ? 2 : cap_env > BK_CAP ? BK_CAP : cap_env);
+  // two launches: a fixed region of slots per bucket in the scratch pair (when it holds 2^BITS regions of a useful size)
+  static const char* slots_env = vsv_dbg_env("VSV_BK_SLOTS");      // timing experiments / tests: "0" = the three-launch forms
+  const int64_t caps64 = max_n >> BITS;
+  const uint32_t caps = (uint32_t)(caps64 > BK_CAP ? BK_CAP : caps64);
+  if (w.slots_ok && caps >= 2048 && (int64_t)caps << BITS <= w.max_items && !(slots_env && slots_env[0] == '0')) {
+    uint32_t* slot_val = src.val_lut() ? w.hist : nullptr;        // (the histogram buffer is free in this form: 2 words per row of capacity)
+    rs_slot_scatter<BITS, ROUNDS, BucketDigit, SRC><<<grid, 256, 0, st>>>(src, d_n, dg, totals, caps, key_scratch, val_scratch, slot_val, w.err);
+    if (w.shared_gpu) bk_slot_sort<ROW, 256><<<1 << BITS, 256, 0, st>>>(key_scratch, val_scratch, slot_val, caps, totals, 1 << BITS, d_n, key, val, w.err, cap, rs_tile<ROUNDS>(), io);
+    else bk_slot_sort<ROW, 512><<<1 << BITS, 512, 0, st>>>(key_scratch, val_scratch, slot_val, caps, totals, 1 << BITS, d_n, key, val, w.err, cap, rs_tile<ROUNDS>(), io);
+    return SortResult{key, val};
+  }
+  // three launches. The self-scanning form needs a zeroed slot of group sums and a table of at most VSV_RS_MAX_GROUPS groups of tiles
+  // (the row count of the handle's previous run; a table that grew past it is caught below: the sort falls back like an overflowing
+  // bucket); bucket bases = the scanned histogram row of tile 0 (offset of the first tile's rows of every bucket), or the totals in front
   static const char* scan_env = vsv_dbg_env("VSV_BK_SCAN");      // timing experiments / tests: "self" | "launch"
   uint32_t* groups = nullptr;
   if (w.groups && *w.group_cursor < w.max_group_slots && w.hint_rows > 0 &&
@@ -608,9 +855,6 @@ SortResult bucket_sort(hipStream_t st, SRC src, uint64_t* key, uint32_t* val, ui
     rs_scan_mb<BITS, ROUNDS, 32, 32><<<(1 << BITS) / 32, 1024, 0, st>>>(w.hist, totals, d_n);
     rs_scatter<BITS, ROUNDS, BucketDigit, SRC, false><<<grid, 256, 0, st>>>(src, d_n, dg, w.hist, key_scratch, val_scratch, totals);
   }
-  // bucket bases = the scanned histogram row of tile 0 (offset of the first tile's rows of every bucket), or the totals in front
-  static const int cap_env = vsv_dbg_env("VSV_BK_CAP") ? atoi(vsv_dbg_env("VSV_BK_CAP")) : BK_CAP;      // tests force the fallback with a tiny capacity
-  const uint32_t cap = (uint32_t)(cap_env < 2 ? 2 : cap_env > BK_CAP ? BK_CAP : cap_env);
   if (w.shared_gpu) bk_lds_sort<ROW, 256><<<1 << BITS, 256, 0, st>>>(key_scratch, val_scratch, w.hist, self ? totals : nullptr, 1 << BITS, d_n, key, val, w.err, cap, rs_tile<ROUNDS>(), io);
   else bk_lds_sort<ROW, 512><<<1 << BITS, 512, 0, st>>>(key_scratch, val_scratch, w.hist, self ? totals : nullptr, 1 << BITS, d_n, key, val, w.err, cap, rs_tile<ROUNDS>(), io);
   return SortResult{key, val};

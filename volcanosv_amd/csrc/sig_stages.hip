@@ -97,10 +97,16 @@ __global__ __launch_bounds__(256) void fold_elems(vsv_sig* __restrict__ rows, ui
   const uint32_t n = ctr->n_raw;
   const int pb = so.pb;
   const uint64_t pmask = pb >= 64 ? ~0ull : ((1ull << pb) - 1ull);
+  // the position range of the table (sort 1 of the element path cuts it into buckets): every element passes through here anyway
+  __shared__ uint32_t s_hi, s_lo;
+  if (threadIdx.x == 0) { s_hi = 0; s_lo = 0; }
+  __syncthreads();
+  uint32_t p_hi = 0, p_lo = 0;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const uint4 e = elems[i];
     const uint64_t key = (uint64_t)e.x | ((uint64_t)e.y << 32);
     const int64_t pos = (int64_t)(key & pmask);
+    p_hi = max(p_hi, (uint32_t)pos); p_lo = max(p_lo, ~(uint32_t)pos);
     const uint32_t slot = (uint32_t)(key >> (pb + 1)) & 3u;          // hap << 1 | del
     const uint64_t tidk = key >> (pb + 3);
     const int64_t T = (slot & 1u) ? 150 : 380;
@@ -173,6 +179,13 @@ __global__ __launch_bounds__(256) void fold_elems(vsv_sig* __restrict__ rows, ui
       }
     }
     if (dirty) put();
+  }
+  if (so.mm && pb < 32) {            // (block-uniform; every thread gets here)
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { p_hi = max(p_hi, (uint32_t)__shfl_xor((int)p_hi, d, 64)); p_lo = max(p_lo, (uint32_t)__shfl_xor((int)p_lo, d, 64)); }
+    if ((threadIdx.x & 63) == 0) { atomicMax(&s_hi, p_hi); atomicMax(&s_lo, p_lo); }
+    __syncthreads();
+    if (threadIdx.x == 0) { if (s_hi) atomicMax(&so.mm[0], s_hi); if (s_lo) atomicMax(&so.mm[1], s_lo); }
   }
 }
 

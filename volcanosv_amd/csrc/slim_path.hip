@@ -170,7 +170,7 @@ struct MsdPrepared {
   int pb, bp_log; uint32_t b0, nb1, mul0, mul1, kmin;
   __device__ __forceinline__ uint32_t operator()(uint64_t key) const {
     const uint32_t list = (uint32_t)(key >> pb), src = list & 1u;
-    const uint32_t kp = ((uint32_t)key & ((1u << pb) - 1u)) - kmin;
+    const uint32_t kq = (uint32_t)key & ((1u << pb) - 1u), kp = kq > kmin ? kq - kmin : 0u;
     uint32_t b = (uint32_t)(((uint64_t)kp * (src ? mul1 : mul0)) >> 32);
     const uint32_t nb = src ? nb1 : b0;
     b = b < nb ? b : nb - 1u;
@@ -1601,14 +1601,14 @@ Slim* sl_bucket_sort1_bits(hipStream_t st, const Slim* in, const uint32_t* d_slo
   const uint32_t b0 = bp - nb1;
   constexpr int SLOTS = (1 << BITS) > 2048 ? (1 << BITS) / 2048 : 1;              // totals slots of 2048 words (+ one for the position range)
   uint32_t* totals = w.totals + (size_t)(*w.pass_cursor) * 2048;
-  uint32_t* mm = totals + (size_t)SLOTS * 2048;
+  uint32_t* mm_own = totals + (size_t)SLOTS * 2048;
   *w.pass_cursor += SLOTS + 1;
-  const MsdDigit dig{pb, bp_log, b0, nb1, mm};
+  const MsdDigit dig{pb, bp_log, b0, nb1, w.mm ? w.mm : mm_own};     // (w.mm: the fold measured the cigar elements; a split element outside lands in an end bucket)
   const int64_t max_tiles = (w.cap + SL_TILE - 1) / SL_TILE;
   const int grid = (int)(max_tiles < 2048 ? (max_tiles < 1 ? 1 : max_tiles) : 2048);
   static const int cap_env = vsv_dbg_env("VSV_SORT1_CAP") ? atoi(vsv_dbg_env("VSV_SORT1_CAP")) : 0;      // tests: buckets above this many elements take the global-memory form
   const uint32_t cap = cap_env > 0 && cap_env < SB_CAP ? (uint32_t)cap_env : (uint32_t)SB_CAP;
-  sl_minmax<<<grid < 1024 ? grid : 1024, 256, 0, st>>>(in, d_slots, pb, mm);
+  if (!w.mm) sl_minmax<<<grid < 1024 ? grid : 1024, 256, 0, st>>>(in, d_slots, pb, mm_own);
   sl_hist<BITS, SrcSlim, true, 4><<<grid, 256, 0, st>>>(SrcSlim{in}, d_slots, dig, w.hist, totals);
   sl_scan<BITS><<<(1 << BITS) / 16, 1024, 0, st>>>(w.hist, totals, d_slots, d_live);
   sl_scatter<BITS, SrcSlim, true, 4><<<grid, 256, 0, st>>>(SrcSlim{in}, d_slots, dig, w.hist, tmp);

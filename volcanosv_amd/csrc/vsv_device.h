@@ -102,7 +102,7 @@ __host__ __device__ inline bool vsv_match(const vsv_sig& a, const vsv_sig& b, in
 
 // 16-byte element of the large-table path (slim_path.hip): {stage-1 key, svlen, row | type}. The kernels that write the stage-1
 // input rows (fold, split_eval) emit it next to the row when the run works on elements, so no pass re-reads the rows for it.
-struct SlimOut { void* base; int pb, tid_lo, tid_bits; uint32_t* err; };     // base == nullptr: the run does not use elements
+struct SlimOut { void* base; int pb, tid_lo, tid_bits; uint32_t* err; uint32_t* mm = nullptr; };     // base == nullptr: the run does not use elements; mm: where fold_elems leaves the position range (max kpos, max ~kpos)
 #define VSV_SL_DEL 0x80000000u
 __device__ __forceinline__ void vsv_slim_emit(const SlimOut& so, uint32_t i, const vsv_sig& v) {
   if (!so.base) return;
@@ -173,6 +173,7 @@ struct SortWork {       // scratch for vsv_radix_sort_pairs
   uint32_t* groups;
   int* group_cursor;
   int max_group_slots;
+  bool slots_ok = false; // the caller's consumers read nothing but the key of a dead row: the two-launch bucket sort may be used (rs_slot_scatter)
 };
 constexpr int VSV_RS_MAX_GROUPS = 64;
 struct StageBufs {
@@ -277,6 +278,7 @@ struct SlimWork {
   uint32_t* done1;      // pairing in rounds: decided flags
   bool merge_sorts;     // sorts 2 / 3 / calls as rank-inside-the-class + merge (sl_merge_sort); false: the LSD passes
   bool bucket_sort1;    // sort 1 as one counting pass into position buckets + an LDS sort per bucket (sl_bucket_sort1); false: the LSD passes
+  const uint32_t* mm;   // position range of the stage-1 cigar elements where the in-place fold measured it (max kpos, max ~kpos), or nullptr
   double split_share;   // expected share of split-list elements among the stage-1 elements (previous run / cold wait): their part of the buckets
   uint32_t* err;        // device error word (ERRB_MERGE_FALLBACK)
 };
