@@ -304,7 +304,7 @@ SortWork sort_work(vsv_handle* h, int64_t table_rows = -1) {
 // ... for callers that gather by the values of dead rows too (breakend candidates, name hashes): the three-launch forms
 SortWork sort_work_plain(vsv_handle* h) { SortWork w = sort_work(h); w.slots_ok = false; return w; }
 // zero the device counters and the per-pass sort totals: start of every run
-constexpr size_t ARENA_CTR = 256, ARENA_SHARD = 256 * 16 * sizeof(uint32_t), ARENA_TILES = 4096 * sizeof(uint32_t),
+constexpr size_t ARENA_CTR = 1024, ARENA_SHARD = 256 * 16 * sizeof(uint32_t), ARENA_TILES = 4096 * sizeof(uint32_t),
                  ARENA_TOTALS = (size_t)MAX_SORT_PASSES * 2048 * sizeof(uint32_t),
                  ARENA_GROUPS = (size_t)MAX_GROUP_SLOTS * VSV_RS_MAX_GROUPS * 2048 * sizeof(uint32_t),     // 4 MB: ~1 us more of the fill
                  ARENA_BYTES = ARENA_CTR + ARENA_SHARD + ARENA_TILES + ARENA_TOTALS + ARENA_GROUPS;
@@ -359,8 +359,8 @@ StageBufs stage_bufs(vsv_handle* h) {
   return StageBufs{(uint64_t*)h->key.p, (uint32_t*)h->idx.p, (int32_t*)h->cl.p, h->rv.tid_lo, tid_bits(h), kmax, ew_grid(h)};
 }
 Counters* dctr(vsv_handle* h) { return (Counters*)h->ctr.p; }
-// two words behind the counters (zeroed with them): the position range of the stage-1 cigar elements, left by the in-place fold
-uint32_t* fold_mm(vsv_handle* h) { static_assert(sizeof(Counters) <= 128, "counters"); return (uint32_t*)h->ctr.p + 32; }
+// 2 x 64 words behind the counters (zeroed with them): the position range of the stage-1 cigar elements, left by the in-place fold
+uint32_t* fold_mm(vsv_handle* h) { static_assert(sizeof(Counters) <= 256, "counters"); return (uint32_t*)h->ctr.p + 64; }
 int pos_bits(vsv_handle* h) { return h->max_pos > 0 ? bits_for((uint64_t)h->max_pos + VSV_POS_BIAS + 2) : 32; }
 int tid_bits(vsv_handle* h) { return bits_for((uint64_t)(h->n_tids > 0 ? h->n_tids - h->rv.tid_lo : 65536) + 1); }
 int key_bits(vsv_handle* h) { return pos_bits(h) + 3 + tid_bits(h) + 1; }   // +1: dead keys (all ones) sort last

@@ -185,7 +185,9 @@ __global__ __launch_bounds__(256) void fold_elems(vsv_sig* __restrict__ rows, ui
     for (int d = 32; d > 0; d >>= 1) { p_hi = max(p_hi, (uint32_t)__shfl_xor((int)p_hi, d, 64)); p_lo = max(p_lo, (uint32_t)__shfl_xor((int)p_lo, d, 64)); }
     if ((threadIdx.x & 63) == 0) { atomicMax(&s_hi, p_hi); atomicMax(&s_lo, p_lo); }
     __syncthreads();
-    if (threadIdx.x == 0) { if (s_hi) atomicMax(&so.mm[0], s_hi); if (s_lo) atomicMax(&so.mm[1], s_lo); }
+    // (one slot per residue of the block index: thousands of atomics on ONE address take their turns at the L2, ~10 ns each, and in a
+    // position-sorted table every block brings a new maximum; MsdDigit::prep reduces the slots)
+    if (threadIdx.x == 0) { if (s_hi) atomicMax(&so.mm[blockIdx.x & 63], s_hi); if (s_lo) atomicMax(&so.mm[64 + (blockIdx.x & 63)], s_lo); }
   }
 }
 

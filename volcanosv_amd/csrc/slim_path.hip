@@ -164,8 +164,7 @@ struct LsdDigit {
   __device__ __forceinline__ uint32_t operator()(uint64_t key) const { return (uint32_t)(kc(key) >> shift) & mask; }
 };
 // list pair p = key >> (pb + 1) owns buckets [p << bp_log, (p + 1) << bp_log): b0 for its cigar list, nb1 for its split list, each cut
-// into equal position ranges between the smallest and the largest position the table holds (mm[0] = max kpos, mm[1] = max ~kpos:
-// sl_minmax) — a shard that covers a part of its chromosome, or contigs that reach beyond the max_pos hint, fill all buckets alike
+// into equal position ranges between the smallest and the largest position the table holds (mm: sl_minmax or the in-place fold) — a shard that covers a part of its chromosome, or contigs that reach beyond the max_pos hint, fill all buckets alike
 struct MsdPrepared {
   int pb, bp_log; uint32_t b0, nb1, mul0, mul1, kmin;
   __device__ __forceinline__ uint32_t operator()(uint64_t key) const {
@@ -177,10 +176,16 @@ struct MsdPrepared {
     return ((list >> 1) << bp_log) + (src ? b0 : 0u) + b;
   }
 };
+// mm[0..63] = max kpos, mm[64..127] = max ~kpos over the live elements, one slot per residue of the writing block's index (thousands of
+// atomics on ONE address take their turns at the L2, ~10 ns each, and in a position-sorted table every block brings a new maximum)
 struct MsdDigit {
   int pb, bp_log; uint32_t b0, nb1; const uint32_t* mm;
-  __device__ __forceinline__ MsdPrepared prep() const {
-    const uint32_t kmax = mm[0], kmin = ~mm[1];
+  __device__ __forceinline__ MsdPrepared prep() const {          // called by whole waves
+    const int lane = threadIdx.x & 63;
+    uint32_t kmax = mm[lane], lo = mm[64 + lane];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, d, 64)); lo = max(lo, (uint32_t)__shfl_xor((int)lo, d, 64)); }
+    const uint32_t kmin = ~lo;
     const uint64_t range = kmax >= kmin ? (uint64_t)(kmax - kmin) + 1u : 1u;        // (no live element: nothing is mapped)
     // floor(b << 32 / range) as a 32-bit multiplier; a range smaller than the bucket count maps one position per bucket
     const uint64_t m0 = ((uint64_t)b0 << 32) / range, m1 = ((uint64_t)nb1 << 32) / range;
@@ -188,7 +193,7 @@ struct MsdDigit {
   }
 };
 
-// mm[0] = max kpos, mm[1] = max ~kpos over the live elements (both words zeroed with the run's sort scratch)
+// the position range of the live elements (both halves of mm zeroed with the run's sort scratch)
 __global__ __launch_bounds__(256) void sl_minmax(const Slim* __restrict__ e, const uint32_t* __restrict__ d_n, int pb, uint32_t* __restrict__ mm) {
   __shared__ uint32_t s_hi, s_lo;
   const uint32_t n = *d_n, pmask = (1u << pb) - 1u;
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(256) void sl_minmax(const Slim* __restrict__ e, con
   for (int d = 32; d > 0; d >>= 1) { hi = max(hi, (uint32_t)__shfl_xor((int)hi, d, 64)); lo = max(lo, (uint32_t)__shfl_xor((int)lo, d, 64)); }
   if ((threadIdx.x & 63) == 0) { atomicMax(&s_hi, hi); atomicMax(&s_lo, lo); }
   __syncthreads();
-  if (threadIdx.x == 0) { if (s_hi) atomicMax(&mm[0], s_hi); if (s_lo) atomicMax(&mm[1], s_lo); }
+  if (threadIdx.x == 0) { if (s_hi) atomicMax(&mm[blockIdx.x & 63], s_hi); if (s_lo) atomicMax(&mm[64 + (blockIdx.x & 63)], s_lo); }
 }
 
 template <int BITS>
