@@ -58,6 +58,19 @@ __device__ __forceinline__ void st_slim(Slim* p, const Slim& s) {
 }
 __device__ __forceinline__ Slim dead_slim() { Slim s; s.key = VSV_KEY_DEAD; s.svlen = 0; s.idx = 0; return s; }
 
+// 8-byte element of the split stage's candidate sorts on large inputs (config 3: 10^7 candidates): a key of at most 31 bits and the
+// row's ordinal; what the consumers need beyond that (record, candidate ordinals) is gathered by ordinal when the sorted list is unpacked.
+// The passes below take either element type (SRC::at decides).
+struct Slim8 { uint32_t key, val; };
+constexpr uint32_t SL8_DEAD = 0xFFFFFFFFu;
+__device__ __forceinline__ Slim8 ld_slim(const Slim8* p) { const uint2 v = *reinterpret_cast<const uint2*>(p); return Slim8{v.x, v.y}; }
+__device__ __forceinline__ void st_slim(Slim8* p, const Slim8& s) { *reinterpret_cast<uint2*>(p) = make_uint2(s.key, s.val); }
+__device__ __forceinline__ bool sl_dead(const Slim& e) { return e.key == VSV_KEY_DEAD; }
+__device__ __forceinline__ bool sl_dead(const Slim8& e) { return e.key == SL8_DEAD; }
+template <typename E> __device__ __forceinline__ E sl_dead_elem();
+template <> __device__ __forceinline__ Slim sl_dead_elem<Slim>() { return dead_slim(); }
+template <> __device__ __forceinline__ Slim8 sl_dead_elem<Slim8>() { return Slim8{SL8_DEAD, 0u}; }
+
 struct KeyFmt {      // bit layout of the run's keys
   int pb;            // position bits; hap at pb + 2, type at pb + 1, source at pb, tid above pb + 3
   __device__ __forceinline__ int32_t pos(uint64_t k) const {
@@ -107,13 +120,24 @@ constexpr uint32_t SL_TILE = 4096;
 
 // where the elements of a sort's first pass come from: an array, or the pairing state (the call elements are never materialised)
 struct SrcSlim {
+  using elem = Slim;
   const Slim* p;
   __device__ __forceinline__ Slim at(uint32_t i) const { return ld_slim(p + i); }
 };
+struct SrcSlim8 {
+  using elem = Slim8;
+  const Slim8* p;
+  __device__ __forceinline__ Slim8 at(uint32_t i) const { return ld_slim(p + i); }
+};
+template <typename E> struct SrcOf;
+template <> struct SrcOf<Slim> { using type = SrcSlim; };
+template <> struct SrcOf<Slim8> { using type = SrcSlim8; };
+template <typename SRC> using SlElem = typename SRC::elem;       // the element type a source yields
 // Call element of merged slot i (pair_sig's output rows, H:571-592): an hp1 row is a call whatever happened — alone (0/1) or with
 // its mate (1/1: the longer of the two signatures is kept, the hp1 one on ties, H:583-586); an hp2 row is a call iff nobody took
 // it. Key = (tid, pos) of the kept signature; svlen field = the mate's slot; idx = the slot itself.
 struct SrcCalls {
+  using elem = Slim;
   const Slim* m; const int32_t* st; int hap_bit; uint64_t stash;
   __device__ __forceinline__ Slim at(uint32_t i) const {
     const Slim me = ld_slim(m + i);
@@ -238,8 +262,8 @@ __global__ __launch_bounds__(WAVES * 64) void sl_hist(SRC src, const uint32_t* _
     for (int k = 0; k < (int)SL_TILE / T; ++k) {
       const uint32_t i = base + k * T + threadIdx.x;
       if (i < n) {
-        const uint64_t key = src.at(i).key;
-        if (!SKIP_DEAD || key != VSV_KEY_DEAD) atomicAdd(&cnt[dig(key)], 1u);
+        const auto e = src.at(i);
+        if (!SKIP_DEAD || !sl_dead(e)) atomicAdd(&cnt[dig(e.key)], 1u);
       }
     }
     __syncthreads();
@@ -318,7 +342,8 @@ __global__ __launch_bounds__(1024) void sl_scan(uint32_t* __restrict__ hist, con
 
 // stable scatter of one pass: ranks inside a wave from ballot matches, per-wave running counters in LDS (as rs_scatter)
 template <int BITS, typename SRC, bool SKIP_DEAD, int WAVES, typename DIG>
-__global__ __launch_bounds__(WAVES * 64) void sl_scatter(SRC src, const uint32_t* __restrict__ d_n, DIG dig_, const uint32_t* __restrict__ hist, Slim* __restrict__ out) {
+__global__ __launch_bounds__(WAVES * 64) void sl_scatter(SRC src, const uint32_t* __restrict__ d_n, DIG dig_, const uint32_t* __restrict__ hist, SlElem<SRC>* __restrict__ out) {
+  using E = SlElem<SRC>;
   constexpr int BINS = 1 << BITS, T = WAVES * 64, ROUNDS = (int)SL_TILE / T;
   __shared__ uint32_t wcnt[WAVES][BINS];
   const uint32_t n = *d_n, ntiles = sl_tiles(n);
@@ -331,14 +356,14 @@ __global__ __launch_bounds__(WAVES * 64) void sl_scatter(SRC src, const uint32_t
       for (int w = 0; w < WAVES; ++w) wcnt[w][d] = 0;
     __syncthreads();
     const uint32_t wbase = tile * SL_TILE + wv * (ROUNDS * 64);
-    Slim e_[ROUNDS];
+    E e_[ROUNDS];
     uint32_t rk[ROUNDS];
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
       const uint32_t i = wbase + r * 64 + lane;
       bool ok = i < n;
-      if (ok) e_[r] = src.at(i); else e_[r] = dead_slim();
-      if (SKIP_DEAD) ok = ok && e_[r].key != VSV_KEY_DEAD;
+      if (ok) e_[r] = src.at(i); else e_[r] = sl_dead_elem<E>();
+      if (SKIP_DEAD) ok = ok && !sl_dead(e_[r]);
       const uint32_t d = ok ? dig(e_[r].key) : 0u;
       const uint64_t m = sl_match_digit<BITS>(d, ok);
       const uint32_t old = ok ? wcnt[wv][d] : 0;
@@ -1109,7 +1134,7 @@ __global__ __launch_bounds__(256) void sl_rows_out(const Slim* __restrict__ e, u
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------------
 template <int BITS, typename SRC, bool SKIP>
-void sl_pass(hipStream_t st, SRC src, const uint32_t* d_n, int shift, KeyCmp kc, Slim* out, uint32_t* hist, uint32_t* totals, uint32_t* d_total, int grid, bool wide) {
+void sl_pass(hipStream_t st, SRC src, const uint32_t* d_n, int shift, KeyCmp kc, SlElem<SRC>* out, uint32_t* hist, uint32_t* totals, uint32_t* d_total, int grid, bool wide) {
   const LsdDigit dig{shift, kc, (1u << BITS) - 1u};
   if (wide) sl_hist<BITS, SRC, SKIP, 16><<<grid, 1024, 0, st>>>(src, d_n, dig, hist, totals);
   else sl_hist<BITS, SRC, SKIP, 4><<<grid, 256, 0, st>>>(src, d_n, dig, hist, totals);
@@ -1133,7 +1158,9 @@ DigitPlan sl_plan(int nbits) {
   return p10 < p8 ? DigitPlan{10, p10} : DigitPlan{8, p8};
 }
 template <typename SRC>
-Slim* sl_sort(hipStream_t st, SRC src, const uint32_t* d_slots, uint32_t* d_live, int nbits, KeyCmp kc, Slim* a, Slim* b, const SlimWork& w, int64_t hint) {
+SlElem<SRC>* sl_sort(hipStream_t st, SRC src, const uint32_t* d_slots, uint32_t* d_live, int nbits, KeyCmp kc, SlElem<SRC>* a, SlElem<SRC>* b, const SlimWork& w, int64_t hint) {
+  using E = SlElem<SRC>;
+  using SrcE = typename SrcOf<E>::type;
   const DigitPlan dp = sl_plan(nbits - kc.zbits);
   const int bits = dp.bits, passes = dp.passes;
   const int64_t max_tiles = (w.cap + SL_TILE - 1) / SL_TILE;
@@ -1141,8 +1168,8 @@ Slim* sl_sort(hipStream_t st, SRC src, const uint32_t* d_slots, uint32_t* d_live
   // blocks of 16 waves where the previous run's tables say the tiles alone cannot fill the chip
   static const int force_waves = vsv_dbg_env("VSV_SLIM_WAVES") ? atoi(vsv_dbg_env("VSV_SLIM_WAVES")) : 0;     // timing experiments
   const bool wide = force_waves ? force_waves == 16 : hint <= (int64_t)2048 * SL_TILE;
-  Slim* dst = a;
-  Slim* other = b;
+  E* dst = a;
+  E* other = b;
   for (int p = 0; p < passes; ++p) {
     uint32_t* totals = w.totals + (size_t)(*w.pass_cursor) * 2048;
     ++*w.pass_cursor;
@@ -1151,11 +1178,11 @@ Slim* sl_sort(hipStream_t st, SRC src, const uint32_t* d_slots, uint32_t* d_live
       if (bits == 8) sl_pass<8, SRC, true>(st, src, d_slots, shift, kc, dst, w.hist, totals, d_live, grid, wide);
       else sl_pass<10, SRC, true>(st, src, d_slots, shift, kc, dst, w.hist, totals, d_live, grid, wide);
     } else {
-      const SrcSlim in{other};
-      if (bits == 8) sl_pass<8, SrcSlim, false>(st, in, d_live, shift, kc, dst, w.hist, totals, nullptr, grid, wide);
-      else sl_pass<10, SrcSlim, false>(st, in, d_live, shift, kc, dst, w.hist, totals, nullptr, grid, wide);
+      const SrcE in{other};
+      if (bits == 8) sl_pass<8, SrcE, false>(st, in, d_live, shift, kc, dst, w.hist, totals, nullptr, grid, wide);
+      else sl_pass<10, SrcE, false>(st, in, d_live, shift, kc, dst, w.hist, totals, nullptr, grid, wide);
     }
-    Slim* t = dst; dst = other; other = t;
+    E* t = dst; dst = other; other = t;
   }
   return other;        // the buffer the last pass wrote
 }
@@ -1705,6 +1732,7 @@ void vsv_slim_pair(hipStream_t st, const void* merged, const uint32_t* d_alive3,
 // ---- (key, value) pair arrays through the same passes: the split stage's candidate sorts on large inputs ---------------------------
 namespace {
 struct SrcPairs {
+  using elem = Slim;
   const uint64_t* key; const uint32_t* val;
   __device__ __forceinline__ Slim at(uint32_t i) const { Slim s; s.key = key[i]; s.svlen = (int32_t)i; s.idx = val[i]; return s; }     // (svlen: the input ordinal)
 };
@@ -1713,6 +1741,7 @@ struct SrcPairs {
 // With `cord` (the candidates' ordinals in record order) a slot carries its two candidates instead of its index: svlen = ordinal of
 // candidate j, idx = ordinal of candidate j + 1 (split_eval_info, sig_stages.hip).
 struct SrcPairSlots {
+  using elem = Slim;
   const uint64_t* ckey; const uint32_t* crec; int qid_bits, rec_bits; const uint32_t* d_n; const uint32_t* cord;
   __device__ __forceinline__ Slim at(uint32_t j) const {
     const uint32_t n = *d_n;
@@ -1736,16 +1765,71 @@ __global__ __launch_bounds__(256) void sl_unpack_pairs(const Slim* __restrict__ 
     else { key[i] = VSV_KEY_DEAD; val[i] = 0; if (aux) aux[i] = 0; }
   }
 }
+// the same two sorts on 8-byte elements (keys of at most 31 bits): (key, ordinal) travels through the passes — half the bytes — and the
+// unpack kernels gather what the 16-byte elements carried (the record; the two candidates' ordinals) by ordinal
+struct SrcPairs8 {
+  using elem = Slim8;
+  const uint64_t* key;
+  __device__ __forceinline__ Slim8 at(uint32_t i) const { return Slim8{(uint32_t)key[i], i}; }
+};
+struct SrcPairSlots8 {
+  using elem = Slim8;
+  const uint64_t* ckey; const uint32_t* crec; int qid_bits, rec_bits; const uint32_t* d_n;
+  __device__ __forceinline__ Slim8 at(uint32_t j) const {
+    const uint32_t n = *d_n;
+    const uint64_t k = ckey[j];
+    Slim8 s{SL8_DEAD, j};
+    if (j + 1 < n && ckey[j + 1] == k) {
+      uint32_t g = j;
+      while (g > 0 && ckey[g - 1] == k) --g;
+      s.key = (uint32_t)(((k >> qid_bits) << rec_bits) | crec[g]);
+    }
+    return s;
+  }
+};
+__global__ __launch_bounds__(256) void sl_unpack_pairs8(const Slim8* __restrict__ e, const uint32_t* __restrict__ d_live, const uint32_t* __restrict__ d_n,
+                                                        const uint32_t* __restrict__ val_in, uint64_t* __restrict__ key, uint32_t* __restrict__ val, uint32_t* __restrict__ ord) {
+  const uint32_t n = *d_n, live = *d_live;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    if (i < live) { const Slim8 x = ld_slim(e + i); key[i] = x.key; val[i] = val_in[x.val]; if (ord) ord[i] = x.val; }
+    else { key[i] = VSV_KEY_DEAD; val[i] = 0; if (ord) ord[i] = 0; }
+  }
+}
+__global__ __launch_bounds__(256) void sl_unpack_slots8(const Slim8* __restrict__ e, const uint32_t* __restrict__ d_live, const uint32_t* __restrict__ d_n,
+                                                        const uint32_t* __restrict__ cord, uint64_t* __restrict__ key, uint32_t* __restrict__ val, uint32_t* __restrict__ c1) {
+  const uint32_t n = *d_n, live = *d_live;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    if (i < live) {
+      const Slim8 x = ld_slim(e + i);
+      key[i] = x.key;
+      if (cord) { c1[i] = cord[x.val]; val[i] = cord[x.val + 1]; } else val[i] = x.val;
+    } else { key[i] = VSV_KEY_DEAD; val[i] = 0; if (cord) c1[i] = 0; }
+  }
+}
+bool sl_use8(int nbits) {
+  static const char* e8 = vsv_dbg_env("VSV_SLIM8");       // timing experiments / tests: "0" = 16-byte elements for the candidate sorts too
+  return nbits <= 31 && !(e8 && e8[0] == '0');
+}
 }  // namespace
 
 SortResult vsv_slim_sort_pairs(hipStream_t st, const uint64_t* key, const uint32_t* val, const uint32_t* d_n, int nbits, uint64_t* out_key, uint32_t* out_val,
                                uint32_t* d_live, const SlimWork& w, uint32_t* out_ord) {
+  if (sl_use8(nbits)) {
+    Slim8* r = sl_sort(st, SrcPairs8{key}, d_n, d_live, nbits, KeyCmp{0, 0}, (Slim8*)w.buf[3], (Slim8*)w.buf[4], w, w.cand_hint);
+    sl_unpack_pairs8<<<w.grid, 256, 0, st>>>(r, d_live, d_n, val, out_key, out_val, out_ord);
+    return SortResult{out_key, out_val};
+  }
   Slim* r = sl_sort(st, SrcPairs{key, val}, d_n, d_live, nbits, KeyCmp{0, 0}, (Slim*)w.buf[3], (Slim*)w.buf[4], w, w.cand_hint);
   sl_unpack_pairs<<<w.grid, 256, 0, st>>>(r, d_live, d_n, out_key, out_val, out_ord);
   return SortResult{out_key, out_val};
 }
 SortResult vsv_slim_sort_pair_slots(hipStream_t st, const uint64_t* ckey, const uint32_t* crec, int qid_bits, int rec_bits, const uint32_t* d_n, int nbits,
                                     uint64_t* out_key, uint32_t* out_val, uint32_t* d_live, const SlimWork& w, const uint32_t* cord, uint32_t* out_c1) {
+  if (sl_use8(nbits)) {
+    Slim8* r = sl_sort(st, SrcPairSlots8{ckey, crec, qid_bits, rec_bits, d_n}, d_n, d_live, nbits, KeyCmp{0, 0}, (Slim8*)w.buf[3], (Slim8*)w.buf[4], w, w.cand_hint);
+    sl_unpack_slots8<<<w.grid, 256, 0, st>>>(r, d_live, d_n, cord, out_key, out_val, out_c1);
+    return SortResult{out_key, out_val};
+  }
   Slim* r = sl_sort(st, SrcPairSlots{ckey, crec, qid_bits, rec_bits, d_n, cord}, d_n, d_live, nbits, KeyCmp{0, 0}, (Slim*)w.buf[3], (Slim*)w.buf[4], w, w.cand_hint);
   sl_unpack_pairs<<<w.grid, 256, 0, st>>>(r, d_live, d_n, out_key, out_val, cord ? out_c1 : nullptr);
   return SortResult{out_key, out_val};
