@@ -296,6 +296,8 @@ SortWork sort_work(vsv_handle* h, int64_t table_rows = -1) {
   if (table_rows < 0) h->sort_hint_rows = rows;
   w.hint_rows = rows;
   w.shared_gpu = h->prm.split_overlap == VSV_OVERLAP_OFF;
+  static const int bk_threads = vsv_dbg_env("VSV_BK_THREADS") ? atoi(vsv_dbg_env("VSV_BK_THREADS")) : 0;     // timing experiments: 256 | 512
+  if (bk_threads) w.shared_gpu = bk_threads == 256;
   w.groups = h->groups; w.group_cursor = &h->group_cursor; w.max_group_slots = MAX_GROUP_SLOTS;
   w.err = h->ctr.p ? &((Counters*)h->ctr.p)->err : nullptr;
   w.slots_ok = true;      // (the signature stages read nothing but the key of a dead row)
