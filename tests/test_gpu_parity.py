@@ -897,7 +897,9 @@ def test_bucket_sort_overflow_falls_back_to_the_lsd_passes():
             "    run_both(e, soa, DTYPE_READS)\n"
             "print('SORT_OK', len(g['calls']))\n") % (root, os.path.join(root, "tests"))
     outs = []
-    for env_extra in ({"VSV_BK_CAP": "48"}, {"VSV_SORT": "lsd"}, {}, {"VSV_BK_SLOTS": "0"}, {"VSV_BK_SLOTS": "0", "VSV_BK_CAP": "48"}):
+    # (VSV_BK_TIEMAX=0: rows of equal key whose chunks arrived out of tile order are put back by tile-number passes — the form for runs of
+    # more than 64 equal keys — instead of by rank inside the run)
+    for env_extra in ({"VSV_BK_CAP": "48"}, {"VSV_SORT": "lsd"}, {}, {"VSV_BK_TIEMAX": "0"}, {"VSV_BK_SLOTS": "0"}, {"VSV_BK_SLOTS": "0", "VSV_BK_CAP": "48"}):
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env_extra), cwd=root)
         assert r.returncode == 0 and "SORT_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
         outs.append(r.stdout.strip().splitlines()[-1])

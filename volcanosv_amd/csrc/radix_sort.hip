@@ -656,7 +656,7 @@ template <typename ROW, int BK_THREADS>
 __global__ __launch_bounds__(BK_THREADS) void bk_slot_sort(const uint64_t* __restrict__ slot_key, const uint32_t* __restrict__ slot_idx, const uint32_t* __restrict__ slot_val, uint32_t caps,
                                                             const uint32_t* __restrict__ totals, int nbuckets, const uint32_t* __restrict__ d_n,
                                                             uint64_t* __restrict__ key_out, uint32_t* __restrict__ val_out, uint32_t* __restrict__ err, uint32_t cap,
-                                                            uint32_t tile_rows, RowIO<ROW> io) {
+                                                            uint32_t tile_rows, uint32_t tie_max, RowIO<ROW> io) {
   constexpr bool ROWS = !std::is_same<ROW, void>::value;
   constexpr int BK_WAVES = BK_THREADS / 64, BK_DBITS = BK_THREADS >= 512 ? 9 : 8;
   __shared__ uint32_t sk[2][BK_CAP];
@@ -770,8 +770,8 @@ __global__ __launch_bounds__(BK_THREADS) void bk_slot_sort(const uint64_t* __res
   lsd(wbits);
   if (unordered) {
     // The passes kept the order the rows had in the region: rows of equal key whose chunks arrived out of order are out of order still.
-    // Every such run (<= 64 rows: beyond that the whole bucket is sorted again, tile order first) is put into input order by rank.
-    constexpr uint32_t TIE_MAX = 64;
+    // Every such run (<= tie_max = 64 rows: beyond that the whole bucket is sorted again, tile order first) is put into input order by rank.
+    const uint32_t TIE_MAX = tie_max;
     __syncthreads();
     if (t == 0) s_unordered = 0;                           // (now: "a run too long for the ranks")
     __syncthreads();
@@ -833,9 +833,11 @@ SortResult bucket_sort(hipStream_t st, SRC src, uint64_t* key, uint32_t* val, ui
   const uint32_t caps = (uint32_t)(caps64 > BK_CAP ? BK_CAP : caps64);
   if (w.slots_ok && caps >= 2048 && (int64_t)caps << BITS <= w.max_items && !(slots_env && slots_env[0] == '0')) {
     uint32_t* slot_val = src.val_lut() ? w.hist : nullptr;        // (the histogram buffer is free in this form: 2 words per row of capacity)
+    static const int tie_env = vsv_dbg_env("VSV_BK_TIEMAX") ? atoi(vsv_dbg_env("VSV_BK_TIEMAX")) : 64;      // tests: 0 = every bucket whose chunks arrived out of order takes the tile-number passes
+    const uint32_t tie_max = (uint32_t)(tie_env < 0 ? 0 : tie_env > 64 ? 64 : tie_env);
     rs_slot_scatter<BITS, ROUNDS, BucketDigit, SRC><<<grid, 256, 0, st>>>(src, d_n, dg, totals, caps, key_scratch, val_scratch, slot_val, w.err);
-    if (w.shared_gpu) bk_slot_sort<ROW, 256><<<1 << BITS, 256, 0, st>>>(key_scratch, val_scratch, slot_val, caps, totals, 1 << BITS, d_n, key, val, w.err, cap, rs_tile<ROUNDS>(), io);
-    else bk_slot_sort<ROW, 512><<<1 << BITS, 512, 0, st>>>(key_scratch, val_scratch, slot_val, caps, totals, 1 << BITS, d_n, key, val, w.err, cap, rs_tile<ROUNDS>(), io);
+    if (w.shared_gpu) bk_slot_sort<ROW, 256><<<1 << BITS, 256, 0, st>>>(key_scratch, val_scratch, slot_val, caps, totals, 1 << BITS, d_n, key, val, w.err, cap, rs_tile<ROUNDS>(), tie_max, io);
+    else bk_slot_sort<ROW, 512><<<1 << BITS, 512, 0, st>>>(key_scratch, val_scratch, slot_val, caps, totals, 1 << BITS, d_n, key, val, w.err, cap, rs_tile<ROUNDS>(), tie_max, io);
     return SortResult{key, val};
   }
   // three launches. The self-scanning form needs a zeroed slot of group sums and a table of at most VSV_RS_MAX_GROUPS groups of tiles
