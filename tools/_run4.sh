@@ -1,5 +1,10 @@
 export VSV_DEBUG=1 PYTHONUNBUFFERED=1
-timeout -k 10 600 python -u -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "bucket_sort_overflow" --timeout=300 --timeout-method=thread > gpurun_out/r4i_tests.log 2>&1 || { grep -v "^  File\|^    " gpurun_out/r4i_tests.log | tail -40; exit 1; }
-tail -3 gpurun_out/r4i_tests.log
-VSV_BK_TIEMAX=0 timeout -k 10 900 python -u -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "golden or synthetic_vs_oracle or multi_tid or random_small or dense_runs or pairing_in_rounds or full_size_config2 or config4_shape" --timeout=300 --timeout-method=thread > gpurun_out/r4i_tests2.log 2>&1 || { grep -v "^  File\|^    " gpurun_out/r4i_tests2.log | tail -40; exit 1; }
-tail -3 gpurun_out/r4i_tests2.log
+for v in A B A B; do
+if [ $v = A ]; then export VSV_LIB=$PWD/volcanosv_amd/libvolcanosv_hip_A.so; else unset VSV_LIB; fi
+python3 bench.py --extras none --cpu-sample 0 > gpurun_out/r4k_bench2_$v.json 2> gpurun_out/r4k_bench2.err
+python3 - <<PY
+import json
+d=json.loads(open("gpurun_out/r4k_bench2_$v.json").read().strip().splitlines()[-1])
+print("$v", d["ms_per_step"], d["single_engine_ms_per_step"])
+PY
+done

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """What S engines in flight cost per step when the chain behind the scan shrinks (diagnostic): the same 10 M-record shard through
-SVIM (the scan + its placement only), READS (scan, split stage, one sort) and Hifi (everything).  tools/overlap_floor.py [records]"""
+SVIM (the scan + its placement only), READS (scan, split stage, one sort), Hifi (everything) and Hifi without its split stage.  tools/overlap_floor.py [records]"""
 import os
 import sys
 import time
@@ -16,8 +16,10 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 K = 60
 t, nq, nt = synth.generate(n, "hifi", seed=20250330, tid=0, chrom_len=synth.CHR10_LEN, device="cuda")
 dr = DeviceRecords(t, nq, 1, max_pos=synth.CHR10_LEN + 200000, tid_lo=0)
-for name in ("SVIM", "READS", "Hifi"):
-    p = default_params(DTYPE_BY_NAME[name])
+for name in ("SVIM", "READS", "Hifi", "Hifi-nosplit"):
+    p = default_params(DTYPE_BY_NAME[name.split("-")[0]])
+    if name.endswith("nosplit"):
+        p.enable_split = 0          # everything but the split stage (name repeats, candidates, their two sorts, the pair rules)
     for S in (1, 2, 4):
         p.split_overlap = 1 if S >= 3 else 0
         streams = [torch.cuda.Stream() for _ in range(S)]
