@@ -82,7 +82,9 @@ typedef struct vsv_records {
                                   library reads them on the handle's stream and does not know the stream that produced them */
   int32_t n_qids;              /* max qid + 1 (required when n_records > 0)                            */
   int32_t n_tids;              /* max tid + 1; 0 = unknown (16 key bits are reserved for it)       */
-  int32_t max_pos;             /* upper bound of pos (e.g. contig length); 0 = unknown. Only trims sort passes. */
+  int32_t max_pos;             /* upper bound of pos (e.g. contig length); 0 = unknown. Speed only: it trims sort passes and balances the
+                                * sorters' buckets - without it a handle's bucket sorts overflow on a real chromosome and vsv_finish repeats
+                                * the run on the radix passes now and then (vsv_rerun_count). */
   int32_t tid_lo;              /* lowest tid of this run (0 = unknown): sort keys carry tid - tid_lo, so a single-
                                   chromosome shard (tid_lo = tid, n_tids = tid + 1) sorts on one tid bit        */
   int32_t reserved0;
