@@ -282,11 +282,13 @@ class Bench:
         p.split_overlap = 1 if len(engs) >= 3 else 0      # VSV_OVERLAP_OFF: three engines in flight fill the GPU by themselves
         self.run_steps([(recs, p)], max(warmup, len(engs)), [], engs, table)     # (warm-up of the gather path too: the first transfer between two ranks sets up its channels)
         reruns0 = sum(e.rerun_count() for e in engs)
+        slow0 = sum(e.sort1_slow_count() for e in engs)
         times, scan_ms, gathered = [], [], None
         for _ in range(max(1, reps)):
             dt, (eng, gathered) = self.timed(lambda: self.run_steps([(recs, p)], steps, scan_ms, engs, table))
             times.append(dt)
         reruns = sum(e.rerun_count() for e in engs) - reruns0
+        slow = sum(e.sort1_slow_count() for e in engs) - slow0
         # the same steps on ONE engine, one after the other (the latency of a chromosome, no overlap between steps)
         k1 = max(3, min(steps, 10))
         p1 = default_params(dtype)          # (one engine by itself builds the split candidates on its auxiliary stream: VSV_OVERLAP_AUTO)
@@ -337,6 +339,7 @@ class Bench:
             "cold_ms_per_step": sorted(cold)[len(cold) // 2] if cold else None,
             "path": warm_path, "cold_path": "/".join(sorted(paths)) if paths else None,
             "reruns": reruns,          # whole-run repetitions inside the timed regions (bucket-sort overflow / fused CLR gate fallbacks, vsv_rerun_count)
+            "sort1_slow_runs": slow,   # ... and runs whose first element sort met a bucket beyond LDS and sorted it in global memory (vsv_sort1_slow_count)
             "records_per_s": recs.n_records * self.world * steps / med, "ops_per_s": recs.n_ops * self.world * steps / med,
             "scan": {"kernel": "cigar_scan_long" if recs.n_ops >= 512 * recs.n_records else "cigar_scan_emit", "avg_launch_ms": scan_s * 1e3,
                      "GBs": alg_bytes / scan_s / 1e9, "frac": alg_bytes / scan_s / 1e9 / HBM_PEAK_GBS,
@@ -577,7 +580,7 @@ def main():
             "metric": METRIC, "value": res["records_per_s"], "unit": "records/s", "n_gpus": b.world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "reps": res["reps"], "ms_per_step_min": res["ms_per_step_min"], "ms_per_step_max": res["ms_per_step_max"],
-            "n_ranks_seen": b.n_ranks_seen, "single_engine_ms_per_step": res["single_engine_ms_per_step"], "reruns": res["reruns"],
+            "n_ranks_seen": b.n_ranks_seen, "single_engine_ms_per_step": res["single_engine_ms_per_step"], "reruns": res["reruns"], "sort1_slow_runs": res["sort1_slow_runs"],
             "cold_ms_per_step": res["cold_ms_per_step"], "path": res["path"], "cold_path": res["cold_path"],
             "config": {"workload": "%s: %d %s-like records/GPU, 1 chromosome per GPU, dtype %s, %d CIGAR ops, %d raw signatures, %d rows gathered per step"
                                    % (label, recs.n_records, shape, dtype_name, recs.n_ops, res["raw_signatures"], res["rows_gathered"]),
