@@ -390,6 +390,60 @@ __global__ __launch_bounds__(WAVES * 64) void sl_scatter(SRC src, const uint32_t
   }
 }
 
+// The counting pass of the first sort (11 / 12-bit digits: sl_bucket_sort1) in blocks of 8 waves: the 4-wave form above keeps 16 elements
+// per lane in registers (196 VGPRs: two waves per SIMD) next to 64 KB of per-wave counters (two blocks per CU). Here a lane holds 8
+// elements, the per-wave counters are 16 bits wide (a wave counts at most 512 of a digit, a tile 4096) and the tile's digit bases sit in
+// an array of their own: 80 KB per block, two blocks = 16 waves per CU.
+template <int BITS, typename SRC, typename DIG>
+__global__ __launch_bounds__(512) void sl_scatter_msd(SRC src, const uint32_t* __restrict__ d_n, DIG dig_, const uint32_t* __restrict__ hist, SlElem<SRC>* __restrict__ out) {
+  using E = SlElem<SRC>;
+  constexpr int BINS = 1 << BITS, WAVES = 8, T = WAVES * 64, ROUNDS = (int)SL_TILE / T;
+  __shared__ uint16_t wcnt[WAVES][BINS];
+  __shared__ uint32_t base[BINS];
+  const uint32_t n = *d_n, ntiles = sl_tiles(n);
+  const auto dig = dig_.prep();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint64_t lt = (1ull << lane) - 1ull;
+  uint32_t* wz = reinterpret_cast<uint32_t*>(&wcnt[0][0]);
+  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int d = threadIdx.x; d < WAVES * BINS / 2; d += T) wz[d] = 0;
+    __syncthreads();
+    const uint32_t wbase = tile * SL_TILE + wv * (ROUNDS * 64);
+    E e_[ROUNDS];
+    uint32_t rk[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      const uint32_t i = wbase + r * 64 + lane;
+      bool ok = i < n;
+      if (ok) e_[r] = src.at(i); else e_[r] = sl_dead_elem<E>();
+      ok = ok && !sl_dead(e_[r]);
+      const uint32_t d = ok ? dig(e_[r].key) : 0u;
+      const uint64_t m = sl_match_digit<BITS>(d, ok);
+      const uint32_t old = ok ? wcnt[wv][d] : 0;
+      __builtin_amdgcn_wave_barrier();
+      if (ok && (m & lt) == 0) wcnt[wv][d] = (uint16_t)(old + (uint32_t)__popcll(m));
+      __builtin_amdgcn_wave_barrier();
+      rk[r] = ok ? old + (uint32_t)__popcll(m & lt) : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < BINS; d += T) {    // the waves' shares of the digit's piece, and where the piece starts
+      uint32_t run = 0;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) { const uint32_t c = wcnt[w][d]; wcnt[w][d] = (uint16_t)run; run += c; }
+      base[d] = hist[(size_t)tile * BINS + d];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      if (rk[r] != 0xFFFFFFFFu) {
+        const uint32_t d = dig(e_[r].key);
+        st_slim(out + base[d] + wcnt[wv][d] + rk[r], e_[r]);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ---- seeded greedy clustering on the sorted elements (H:196-288) ------------------------------------------------------------
 // A run = maximal stretch of one list whose consecutive positions differ by <= max_shift; no match crosses a run boundary, so
 // runs are independent and the reference's full scans reduce to a scan inside the run. The lane that holds a run's first element
@@ -1643,7 +1697,9 @@ Slim* sl_bucket_sort1_bits(hipStream_t st, const Slim* in, const uint32_t* d_slo
   if (!w.mm) sl_minmax<<<grid < 1024 ? grid : 1024, 256, 0, st>>>(in, d_slots, pb, mm_own);
   sl_hist<BITS, SrcSlim, true, 4><<<grid, 256, 0, st>>>(SrcSlim{in}, d_slots, dig, w.hist, totals);
   sl_scan<BITS><<<(1 << BITS) / 16, 1024, 0, st>>>(w.hist, totals, d_slots, d_live);
-  sl_scatter<BITS, SrcSlim, true, 4><<<grid, 256, 0, st>>>(SrcSlim{in}, d_slots, dig, w.hist, tmp);
+  static const char* sc_form = vsv_dbg_env("VSV_SORT1_SCATTER");      // timing experiments: "4" = the 4-wave scatter of the LSD passes
+  if (sc_form && sc_form[0] == '4') sl_scatter<BITS, SrcSlim, true, 4><<<grid, 256, 0, st>>>(SrcSlim{in}, d_slots, dig, w.hist, tmp);
+  else sl_scatter_msd<BITS, SrcSlim><<<grid, 512, 0, st>>>(SrcSlim{in}, d_slots, dig, w.hist, tmp);
   sl_bucket_lds<512><<<1 << BITS, 512, 0, st>>>(tmp, w.hist, 1 << BITS, d_live, pb, cap, out, w.err);
   return out;
 }
